@@ -1,0 +1,163 @@
+/*
+ * soswsod_hip.h — C ABI of the MI355X-native (gfx950) kernels behind SoS-WSOD's Stage-1 OICR+ hot path.
+ *
+ * The reference has no C FFI on this path: its operator boundary is a pybind11 module called from
+ * torch.autograd.Function (uwsod/projects/WSL/wsl/layers/roi_loop_pool.py:9-35 <->
+ * uwsod/projects/WSL/wsl/layers/csrc/vision.cpp:21-23 <-> .../ROILoopPool/ROILoopPool.h:48-107), plus the
+ * third-party ops it calls (torchvision RoIPool / nms, cuDNN conv, cuBLAS GEMM).  This header is the plain-C
+ * replacement of that operator tier; each entry cites the reference code it stands in for.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", return 0 on success, a positive hipError_t from the launch, or a negative argument error
+ *     (-1 bad dtype, -2 split-K without atomic accumulate, -3 unsupported operand layout, -4 pointer not
+ *     16-byte aligned, -5 leading dimension / extent not a multiple of the 16-byte chunk, -6 size limit).
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated, freed or synchronised
+ *     inside; work is enqueued on `stream`; no global state => thread-compatible.
+ *   - dtype: SW_F32 (0) or SW_BF16 (1; raw 16-bit words).  Activations are NHWC.
+ */
+#ifndef SOSWSOD_HIP_H
+#define SOSWSOD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef SW_F32
+#define SW_F32 0
+#define SW_BF16 1
+#endif
+
+typedef struct ihipStream_t* sw_stream_t; /* == hipStream_t */
+
+/* Fused GEMM / implicit-GEMM epilogue:  v = acc (+bias[n]); relu; dropout; relu-backward mask; store. */
+typedef struct sw_epilogue {
+  const float* bias;          /* [N] or NULL */
+  int relu;                   /* v = max(v, 0) */
+  const uint8_t* drop_mask;   /* [M][ld_drop] keep mask or NULL: v = keep ? v*drop_scale : 0   (F.dropout, box_head.py:90) */
+  long ld_drop;
+  float drop_scale;
+  const void* relu_ref;       /* [M][ld_ref] or NULL: v = ref>0 ? v*ref_scale : 0   (ReLU(+dropout) backward) */
+  long ld_ref;
+  float ref_scale;
+  int ref_dtype;
+  int out_dtype;              /* dtype of C */
+  int accumulate_atomic;      /* C is f32 and is atomically accumulated (required when splitk > 1) */
+} sw_epilogue;
+
+/* ---- dense contractions (reference: cuBLAS via torch Linear — box_head.py:88-90,
+ *      fast_rcnn_wsddn.py:558-559, fast_rcnn_oicr.py:517-519, and their autograd backward) ----------------
+ * C[m][n] = sum_k A(m,k) B(k,n).  a_kstrided=0: A[m*lda+k], 1: A[k*lda+m];  b_kstrided=0: B[n*ldb+k], 1: B[k*ldb+n].
+ * Supported (a,b): (0,0) forward, (0,1) data gradient, (1,1) weight gradient. */
+int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, int K, const void* A, long lda, const void* B,
+            long ldb, void* C, long ldc, const sw_epilogue* ep, int splitk, sw_stream_t stream);
+
+/* ---- 3x3 convolution, stride 1, padding = dilation (reference: torch Conv2d/cuDNN, wsl/modeling/backbone/vgg.py:44-97,104-122)
+ * in  [nimg][H][W][Cin], wk [Cout][3*3][Cin] (see sw_conv_weight_prep), out [nimg][H][W][Cout].
+ * Used for forward (ep: bias+relu) and for the data gradient (wk = flipped/transposed weights, ep: relu_ref). */
+int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in,
+                     const void* wk, void* out, const sw_epilogue* ep, sw_stream_t stream);
+/* dW (OIHW f32, caller zero-fills; atomically accumulated) from x [nimg][H][W][Cin] and dy [nimg][H][W][Cout]. */
+int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
+                     const void* dy, float* dw_oihw, int splitk, sw_stream_t stream);
+/* OIHW f32 master weights -> kernel layout.  mode 0: wk[co][tap][ci_pad] (forward, ci zero padded to cin_pad);
+ * mode 1: wk[ci][8-tap][co] (data gradient: taps flipped, in/out swapped). */
+int sw_conv_weight_prep(int dtype, int mode, int Cout, int Cin, int cin_pad, const float* w_oihw, void* wk,
+                        sw_stream_t stream);
+
+/* ---- 2x2 max pooling, stride 1 or 2, no padding (reference: nn.MaxPool2d, vgg.py:99-100,119-120) --------- */
+int sw_maxpool2x2_fwd(int dtype, int nimg, int H, int W, int C, int stride, const void* in, void* out,
+                      sw_stream_t stream);
+/* din = route(dout) to the first max of each window (scan order, strict >), times (in > 0) when relu_mask. */
+int sw_maxpool2x2_bwd(int dtype, int nimg, int H, int W, int C, int stride, const void* in, const void* dout,
+                      void* din, int relu_mask, sw_stream_t stream);
+
+/* ---- image normalisation (reference: MultiInputRCNN.preprocess_image, rcnn_multi.py:256-269) -------------
+ * img u8 [3][H][W] -> out [H][W][cpad] = (img - mean) / std, channels >= 3 zero.
+ * mean3/std3 are HOST float[3] (configuration constants, passed by value into the launch). */
+int sw_preprocess(int dtype, int H, int W, int cpad, const uint8_t* img_chw, const float* mean3,
+                  const float* std3, void* out_nhwc, sw_stream_t stream);
+
+/* ---- max ROI pooling (reference: torchvision.ops.RoIPool called at wsl/modeling/poolers.py:183-186,267-270;
+ *      arithmetic as stated in wsl/layers/csrc/ROILoopPool/ROILoopPool_cpu.cpp:26-79 fwd, :98-123 bwd) -------
+ * feat [nimg][H][W][C]; rois [R][5] f32 (batch, x1,y1,x2,y2); out [R][C][PH][PW] (reference flatten order),
+ * argmax [R][C][PH][PW] int32 (h*W+w or -1).  row_scale (may be NULL): out *= (row_scale[r] + row_scale_add)
+ * = the objectness prior of roi_heads_oicrplus.py:200-221. */
+int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale, const void* feat,
+                    const float* rois, int R, const float* row_scale, float row_scale_add, void* out,
+                    int32_t* argmax, sw_stream_t stream);
+/* dfeat [nimg][H][W][C] (dtype, fully overwritten) = scatter-add of dout by argmax, times the same row scale,
+ * times (relu_ref > 0) when relu_ref != NULL (relu_ref has feat's layout/dtype). */
+int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
+                    const int32_t* argmax, const float* rois, int R, const float* row_scale, float row_scale_add,
+                    const void* relu_ref, void* dfeat, sw_stream_t stream);
+
+/* ---- WSDDN MIL head: scores, image-level BCE, gradient (reference: fast_rcnn_wsddn.py:556-567 forward,
+ *      :340-375 loss; autograd backward) -------------------------------------------------------------------
+ * logits f32 [V*R][ld]: cls logits at columns [cls_col, cls_col+K), det logits at [det_col, det_col+K);
+ * per view v: scores[v][r][k] = softmax_k(cls) * softmax_r(det); loss_view[v] = BCE(clamp(sum_r scores), onehot)/K.
+ * If dlogits != NULL (f32): dlogits[(v*R+r)*ld_d + col] = grad_scale[0]/V * d loss_view[v] / d logit, where
+ * grad_scale is a DEVICE scalar (the cotangent of the mean-over-views loss) so that no host sync is needed. */
+int sw_wsddn_mil(int V, int R, int K, const float* logits, long ld, int cls_col, int det_col, const float* gt_onehot,
+                 float* scores, float* loss_view, float* dlogits, long ld_d, const float* grad_scale,
+                 sw_stream_t stream);
+
+/* ---- mean over V score matrices (reference: roi_heads_oicrplus.py:290-294,390-395) ----------------------- */
+int sw_mean_views(int V, long n, const float* in, float* out, sw_stream_t stream);
+
+/* ---- pseudo-GT mining + proposal labelling, all device side (reference: get_pgt_top_k
+ *      roi_heads_oicrplus.py:607-757, get_pgt_mist :560-605 incl. torchvision batched_nms, pairwise_iou
+ *      structures/boxes.py:329-361, Matcher matcher.py:63-111, label_and_sample_proposals roi_heads.py:266-375)
+ * scores [R][ncol] f32; gt_classes [G] int32 sorted unique; boxes [R][4] f32.
+ * Outputs: per proposal lab_class (class | K background | -1 ignore), lab_weight, lab_index; the kept pseudo-GT
+ * list (score-descending): pgt_count[1], pgt_index/pgt_class/pgt_score [>= top_k*G].
+ * top_k = max(int(R * MIST_P), 1) is computed by the host exactly as the reference does (:659-660).
+ * workspace: >= sw_mine_workspace_bytes(top_k, G) bytes. Limits: R <= 16384, top_k*G <= 16384. */
+long sw_mine_workspace_bytes(int top_k, int G);
+int sw_oicr_mine_label(int R, int ncol, int K, const float* scores, const int32_t* gt_classes, int G,
+                       const float* boxes, int top_k, float score_thresh, float nms_thresh, float iou_bg,
+                       float iou_fg, int32_t* lab_class, float* lab_weight, int32_t* lab_index, int32_t* pgt_count,
+                       int32_t* pgt_index, int32_t* pgt_class, float* pgt_score, void* workspace,
+                       sw_stream_t stream);
+
+/* ---- OICR refinement losses + gradient + next-round scores (reference: OICROutputs.__init__/
+ *      softmax_cross_entropy_loss/box_reg_loss fast_rcnn_oicr.py:157-226,258-273,276-352; get_deltas
+ *      box_regression.py:38-71; predict_probs fast_rcnn_oicr.py:702-716; cross-view targets and the
+ *      predictions_k2 quirk roi_heads_oicrplus.py:327-381) ---------------------------------------------------
+ * logits f32 [V*R][ld]: class logits at [cls_col, cls_col+K+1), box deltas at [box_col, box_col+4K).
+ * boxes [V][R][4].  pred_view[v] = which view's predictions are paired with view v's targets ({0,1,2,2}).
+ * loss_view [2][V] (cls then box, already divided by R).  probs [V][R][K+1] = softmax of each view's OWN logits.
+ * dlogits (f32, may be NULL): the columns of this round are overwritten with
+ * (grad_scale[0]*dcls + grad_scale[1]*dbox)/V; grad_scale is a DEVICE float[2]; reg_weights4 is a HOST float[4]
+ * (BBOX_REG_WEIGHTS, a configuration constant passed by value into the launch). */
+int sw_oicr_refine_loss(int V, int R, int K, const float* logits, long ld, int cls_col, int box_col,
+                        const float* boxes, const int32_t* lab_class, const float* lab_weight,
+                        const int32_t* lab_index, const int32_t* pred_view, const float* reg_weights4,
+                        float* loss_view, float* probs, float* dlogits, long ld_d,
+                        const float* grad_scale, sw_stream_t stream);
+
+/* ---- small utilities ------------------------------------------------------------------------------------ */
+/* out[n] = sum_m X[m][ld..] (column sums; bias gradients).  out f32, overwritten. */
+int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, sw_stream_t stream);
+/* rows x cols copy/convert f32 -> dtype with independent leading dimensions (weight staging). */
+int sw_convert_2d(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
+                  sw_stream_t stream);
+/* dst(f32) = src(dtype) */
+int sw_to_f32(int dtype, long n, const void* src, float* dst, sw_stream_t stream);
+int sw_fill_zero(void* p, long bytes, sw_stream_t stream);
+/* keep[i] = hash(seed, offset+i) >= p   (Bernoulli keep mask for F.dropout, box_head.py:90) */
+int sw_dropout_mask(uint8_t* keep, long n, uint64_t seed, uint64_t offset, float p, sw_stream_t stream);
+/* SGD with momentum + weight decay, torch.optim.SGD semantics (reference: solver/build.py:191-215,
+ * train_net_multi.py:157-164):  g += wd*p;  buf = first ? g : mom*buf + g;  p -= lr*buf. */
+int sw_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, long n, float lr, float momentum,
+                         float weight_decay, int first_step, float grad_scale, sw_stream_t stream);
+/* out[i] = sum_v loss_view[i][v] / V   (loss assembly, roi_heads_oicrplus.py:283-288,384-388) */
+int sw_loss_finalize(int n_losses, int V, const float* loss_view, float* out, sw_stream_t stream);
+
+const char* sw_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOSWSOD_HIP_H */

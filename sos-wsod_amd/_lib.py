@@ -1,0 +1,91 @@
+"""ctypes binding of the C-ABI HIP library (include/soswsod_hip.h).
+
+The product path has NO fallback: if libsoswsod_hip.so is missing or a symbol cannot be
+resolved, importing this module raises.  (Build it with sos-wsod_amd/csrc/build.sh or
+__graft_entry__.build().)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsoswsod_hip.so")
+
+SW_F32, SW_BF16 = 0, 1
+
+c_int, c_long, c_float, c_void_p, c_u64 = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64
+
+
+class Epilogue(ctypes.Structure):
+    """struct sw_epilogue"""
+    _fields_ = [
+        ("bias", c_void_p), ("relu", c_int), ("drop_mask", c_void_p), ("ld_drop", c_long), ("drop_scale", c_float),
+        ("relu_ref", c_void_p), ("ld_ref", c_long), ("ref_scale", c_float), ("ref_dtype", c_int),
+        ("out_dtype", c_int), ("accumulate_atomic", c_int),
+    ]
+
+
+_EP = ctypes.POINTER(Epilogue)
+_F4 = ctypes.POINTER(c_float)
+
+# name -> (restype, argtypes); must list every symbol the header declares
+SIGNATURES = {
+    "sw_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long,
+                        _EP, c_int, c_void_p]),
+    "sw_conv3x3_igemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, _EP,
+                                 c_void_p]),
+    "sw_conv3x3_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_void_p]),
+    "sw_conv_weight_prep": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_maxpool2x2_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_maxpool2x2_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_void_p]),
+    "sw_preprocess": (c_int, [c_int, c_int, c_int, c_int, c_void_p, _F4, _F4, c_void_p, c_void_p]),
+    "sw_roi_pool_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
+                                c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "sw_roi_pool_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "sw_wsddn_mil": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_long, c_void_p, c_void_p]),
+    "sw_mean_views": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    "sw_mine_workspace_bytes": (c_long, [c_int, c_int]),
+    "sw_oicr_mine_label": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float,
+                                   c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
+    "sw_oicr_refine_loss": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, _F4, c_void_p, c_void_p, c_void_p, c_long, c_void_p,
+                                    c_void_p]),
+    "sw_colsum": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p]),
+    "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "sw_to_f32": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    "sw_fill_zero": (c_int, [c_void_p, c_long, c_void_p]),
+    "sw_dropout_mask": (c_int, [c_void_p, c_long, c_u64, c_u64, c_float, c_void_p]),
+    "sw_sgd_momentum_step": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_int, c_float,
+                                     c_void_p]),
+    "sw_loss_finalize": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_version": (ctypes.c_char_p, []),
+}
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU / eager fallback exists). "
+            "Build it with `bash sos-wsod_amd/csrc/build.sh` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud failure
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def check(rc, name):
+    if rc != 0:
+        raise HipKernelError(f"{name} failed with code {rc}")

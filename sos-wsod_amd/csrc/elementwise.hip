@@ -1,0 +1,305 @@
+// HBM-bound helpers of the OICR+ path on gfx950: image normalisation, 2x2 max pooling (fwd/bwd),
+// weight staging (OIHW f32 -> kernel layouts), column sums (bias gradients), dropout keep-masks,
+// SGD-momentum update, loss assembly.  Grid-stride loops capped at 256 CUs x 8 workgroups.
+#include "common.h"
+#include "soswsod_hip.h"
+
+namespace {
+
+inline int grid_for(long n, int block = 256) {
+  long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+// ---------------------------------------------------------------- preprocess (rcnn_multi.py:256-269)
+template <typename T>
+__global__ void preprocess_kernel(int H, int W, int cpad, const uint8_t* __restrict__ img, float m0, float m1, float m2,
+                                  float s0, float s1, float s2, T* __restrict__ out) {
+  const long npix = (long)H * W;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    const float v0 = __fdiv_rn((float)img[p] - m0, s0);
+    const float v1 = __fdiv_rn((float)img[npix + p] - m1, s1);
+    const float v2 = __fdiv_rn((float)img[2 * npix + p] - m2, s2);
+    T* o = out + p * cpad;
+    Elem<T>::store(o + 0, v0); Elem<T>::store(o + 1, v1); Elem<T>::store(o + 2, v2);
+    for (int c = 3; c < cpad; ++c) Elem<T>::store(o + c, 0.f);
+  }
+}
+
+// ---------------------------------------------------------------- maxpool 2x2 (vgg.py:99-100)
+template <typename T>
+__global__ void maxpool_fwd_kernel(int nimg, int H, int W, int C, int stride, int OH, int OW, const T* __restrict__ in,
+                                   T* __restrict__ out) {
+  const long total = (long)nimg * OH * OW * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long t = i / C;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH); const int n = (int)(t / OH);
+    const T* b = in + (((long)n * H + oy * stride) * W + ox * stride) * C + c;
+    float m = Elem<T>::load(b);
+    m = fmaxf(m, Elem<T>::load(b + C));
+    m = fmaxf(m, Elem<T>::load(b + (long)W * C));
+    m = fmaxf(m, Elem<T>::load(b + (long)W * C + C));
+    Elem<T>::store(out + i, m);
+  }
+}
+
+// gather form: every input element collects from the (<= 4) windows that contain it and whose first
+// maximum (scan order (0,0),(0,1),(1,0),(1,1), strict >) is this element — torch MaxPool2d backward.
+template <typename T>
+__global__ void maxpool_bwd_kernel(int nimg, int H, int W, int C, int stride, int OH, int OW, const T* __restrict__ in,
+                                   const T* __restrict__ dout, T* __restrict__ din, int relu_mask) {
+  const long total = (long)nimg * H * W * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long t = i / C;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H); const int n = (int)(t / H);
+    const float self = Elem<T>::load(in + i);
+    float g = 0.f;
+    if (!(relu_mask && !(self > 0.f))) {
+      const int oy_lo = stride == 2 ? (y >> 1) : max(y - 1, 0);
+      const int oy_hi = stride == 2 ? (y >> 1) : y;
+      const int ox_lo = stride == 2 ? (x >> 1) : max(x - 1, 0);
+      const int ox_hi = stride == 2 ? (x >> 1) : x;
+      for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        if (oy >= OH) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+          if (ox >= OW) continue;
+          const int y0 = oy * stride, x0 = ox * stride;
+          const T* b = in + (((long)n * H + y0) * W + x0) * C + c;
+          float m = Elem<T>::load(b); int am = 0;
+          float v = Elem<T>::load(b + C); if (v > m) { m = v; am = 1; }
+          v = Elem<T>::load(b + (long)W * C); if (v > m) { m = v; am = 2; }
+          v = Elem<T>::load(b + (long)W * C + C); if (v > m) { m = v; am = 3; }
+          if (am == (y - y0) * 2 + (x - x0)) g += Elem<T>::load(dout + (((long)n * OH + oy) * OW + ox) * C + c);
+        }
+      }
+    }
+    Elem<T>::store(din + i, g);
+  }
+}
+
+// ---------------------------------------------------------------- conv weight staging
+// mode 0: wk[co][tap][ci_pad] = w[co][ci][tap]            (forward)
+// mode 1: wk[ci][8-tap][co]   = w[co][ci][tap]            (data gradient: flipped taps, swapped in/out)
+template <typename T>
+__global__ void conv_weight_prep_kernel(int mode, int Cout, int Cin, int cin_pad, const float* __restrict__ w,
+                                        T* __restrict__ wk) {
+  const long total = mode == 0 ? (long)Cout * 9 * cin_pad : (long)Cin * 9 * Cout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (mode == 0) {
+      const int ci = (int)(i % cin_pad); long t = i / cin_pad;
+      const int tap = (int)(t % 9); const int co = (int)(t / 9);
+      if (ci < Cin) v = w[((long)co * Cin + ci) * 9 + tap];
+    } else {
+      const int co = (int)(i % Cout); long t = i / Cout;
+      const int tapf = (int)(t % 9); const int ci = (int)(t / 9);
+      v = w[((long)co * Cin + ci) * 9 + (8 - tapf)];
+    }
+    Elem<T>::store(wk + i, v);
+  }
+}
+
+template <typename T>
+__global__ void convert_2d_kernel(int rows, int cols, const float* __restrict__ src, long ld_src, T* __restrict__ dst,
+                                  long ld_dst) {
+  const long total = (long)rows * cols;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols; const int c = (int)(i - r * cols);
+    Elem<T>::store(dst + r * ld_dst + c, src[r * ld_src + c]);
+  }
+}
+
+template <typename T>
+__global__ void to_f32_kernel(long n, const T* __restrict__ src, float* __restrict__ dst) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = Elem<T>::load(src + i);
+}
+
+// ---------------------------------------------------------------- column sums: out[n] = sum_m X[m][n]
+// workgroup = 64 columns x 4 row-lanes; deterministic (fixed order), no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const T* __restrict__ X, long ld,
+                                                     float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < N)
+    for (int m = rl; m < M; m += 4) s += Elem<T>::load(X + (long)m * ld + col);
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < N) out[col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------- dropout keep mask
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, uint64_t seed, uint64_t offset, float p) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const uint64_t z = splitmix64(splitmix64(seed) + offset + (uint64_t)i);
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+    keep[i] = u >= p ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------- SGD momentum (torch.optim.SGD semantics)
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n, float lr,
+                           float mom, float wd, int first, float gscale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    float d = g[i] * gscale + wd * w;
+    const float b = first ? d : mom * buf[i] + d;
+    buf[i] = b;
+    p[i] = w - lr * b;
+  }
+}
+
+__global__ void mean_views_kernel(int V, long n, const float* __restrict__ in, float* __restrict__ out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = in[i];
+    for (int v = 1; v < V; ++v) s += in[(long)v * n + i];      // ((s0+s1)+s2)+s3, as the reference adds them
+    out[i] = __fdiv_rn(s, (float)V);
+  }
+}
+
+__global__ void loss_finalize_kernel(int nl, int V, const float* __restrict__ lv, float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i < nl) {
+    float s = lv[i * V];
+    for (int v = 1; v < V; ++v) s += lv[i * V + v];
+    out[i] = __fdiv_rn(s, (float)V);
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
+  if ((dtype) == SW_BF16) { CALL_BF16; } else if ((dtype) == SW_F32) { CALL_F32; } else return -1;
+
+extern "C" int sw_preprocess(int dtype, int H, int W, int cpad, const uint8_t* img, const float* mean3,
+                             const float* std3, void* out, hipStream_t stream) {
+  // mean/std are HOST floats here? No: device pointers are the convention, but these 6 scalars are
+  // configuration constants; they are passed by value through the launch instead of dereferenced on device.
+  // => mean3/std3 are HOST pointers (documented exception).
+  const long n = (long)H * W;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(preprocess_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, H, W, cpad, img,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (unsigned short*)out),
+    hipLaunchKernelGGL(preprocess_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, H, W, cpad, img,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (float*)out));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_maxpool2x2_fwd(int dtype, int nimg, int H, int W, int C, int stride, const void* in, void* out,
+                                 hipStream_t stream) {
+  const int OH = (H - 2) / stride + 1, OW = (W - 2) / stride + 1;
+  const long n = (long)nimg * OH * OW * C;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(maxpool_fwd_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, nimg, H, W, C, stride,
+                       OH, OW, (const unsigned short*)in, (unsigned short*)out),
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, nimg, H, W, C, stride, OH, OW,
+                       (const float*)in, (float*)out));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_maxpool2x2_bwd(int dtype, int nimg, int H, int W, int C, int stride, const void* in,
+                                 const void* dout, void* din, int relu_mask, hipStream_t stream) {
+  const int OH = (H - 2) / stride + 1, OW = (W - 2) / stride + 1;
+  const long n = (long)nimg * H * W * C;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(maxpool_bwd_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, nimg, H, W, C, stride,
+                       OH, OW, (const unsigned short*)in, (const unsigned short*)dout, (unsigned short*)din, relu_mask),
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, nimg, H, W, C, stride, OH, OW,
+                       (const float*)in, (const float*)dout, (float*)din, relu_mask));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_conv_weight_prep(int dtype, int mode, int Cout, int Cin, int cin_pad, const float* w, void* wk,
+                                   hipStream_t stream) {
+  if (mode != 0 && mode != 1) return -3;
+  if (mode == 1 && cin_pad != Cin) return -3;
+  const long n = mode == 0 ? (long)Cout * 9 * cin_pad : (long)Cin * 9 * Cout;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(conv_weight_prep_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, mode, Cout, Cin,
+                       cin_pad, w, (unsigned short*)wk),
+    hipLaunchKernelGGL(conv_weight_prep_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, mode, Cout, Cin, cin_pad,
+                       w, (float*)wk));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_convert_2d(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
+                             hipStream_t stream) {
+  const long n = (long)rows * cols;
+  if (n <= 0) return 0;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(convert_2d_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, rows, cols, src, ld_src,
+                       (unsigned short*)dst, ld_dst),
+    hipLaunchKernelGGL(convert_2d_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, rows, cols, src, ld_src,
+                       (float*)dst, ld_dst));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_to_f32(int dtype, long n, const void* src, float* dst, hipStream_t stream) {
+  if (n <= 0) return 0;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(to_f32_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const unsigned short*)src, dst),
+    hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const float*)src, dst));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, hipStream_t stream) {
+  if (N <= 0) return 0;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(colsum_kernel<unsigned short>, dim3((N + 63) / 64), dim3(256), 0, stream, M, N, (const unsigned short*)X, ld, out),
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64), dim3(256), 0, stream, M, N, (const float*)X, ld, out));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_fill_zero(void* p, long bytes, hipStream_t stream) {
+  if (bytes <= 0) return 0;
+  return (int)hipMemsetAsync(p, 0, (size_t)bytes, stream);
+}
+
+extern "C" int sw_dropout_mask(uint8_t* keep, long n, uint64_t seed, uint64_t offset, float p, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, stream, keep, n, seed, offset, p);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_sgd_momentum_step(float* param, const float* grad, float* buf, long n, float lr, float momentum,
+                                    float weight_decay, int first_step, float grad_scale, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, param, grad, buf, n, lr, momentum, weight_decay,
+                     first_step, grad_scale);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_mean_views(int V, long n, const float* in, float* out, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(mean_views_kernel, dim3(grid_for(n)), dim3(256), 0, stream, V, n, in, out);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_loss_finalize(int n_losses, int V, const float* loss_view, float* out, hipStream_t stream) {
+  if (n_losses > 64) return -6;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, n_losses, V, loss_view, out);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" const char* sw_version(void) { return "soswsod-hip 0.1 (gfx950)"; }

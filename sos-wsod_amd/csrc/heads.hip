@@ -1,0 +1,385 @@
+// Fused per-proposal kernels of the WSDDN / OICR heads on gfx950 (all f32 arithmetic):
+//   sw_wsddn_mil        dual softmax (classes x proposals), image-level BCE and its gradient
+//   sw_oicr_refine_loss weighted CE + L1 box loss, gradients, next-round softmax scores
+//   sw_oicr_mine_label  top-p% mining, score threshold, class-agnostic NMS, IoU matching -> labels
+// They are latency-bound glue in the reference (dozens of tiny kernels + host syncs);
+// here each is ONE launch with wave64 shuffle reductions and no host round trip.
+#include <float.h>
+#include "common.h"
+#include "soswsod_hip.h"
+
+namespace {
+
+constexpr int KMAX = 128;      // max classes (+1) held in LDS column accumulators
+constexpr int NWAVE = 16;      // 1024-thread workgroups
+
+// ------------------------------------------------------------------------------------------- WSDDN
+// column reduction helper: every wave reduces its 64 rows with shuffles and folds the result into its own
+// LDS row; rows are then combined in fixed wave order => deterministic.
+template <bool IS_MAX, typename F>
+__device__ __forceinline__ void column_reduce(int R, int K, float (*part)[KMAX], float* result, F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = lane; k < K; k += 64) part[wave][k] = IS_MAX ? -FLT_MAX : 0.f;
+  __syncthreads();
+  for (int r0 = wave * 64; r0 < R; r0 += NWAVE * 64) {
+    const int r = r0 + lane;
+    for (int k = 0; k < K; ++k) {
+      float v = (r < R) ? f(r, k) : (IS_MAX ? -FLT_MAX : 0.f);
+      v = IS_MAX ? wave_reduce_max(v) : wave_reduce_sum(v);
+      if (lane == 0) part[wave][k] = IS_MAX ? fmaxf(part[wave][k], v) : part[wave][k] + v;
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float a = part[0][k];
+    for (int w = 1; w < NWAVE; ++w) a = IS_MAX ? fmaxf(a, part[w][k]) : a + part[w][k];
+    result[k] = a;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void wsddn_kernel(int R, int K, const float* __restrict__ logits, long ld, int cls_col,
+                                                     int det_col, const float* __restrict__ onehot,
+                                                     float* __restrict__ scores, float* __restrict__ loss_view,
+                                                     float* __restrict__ dlogits, long ld_d,
+                                                     const float* __restrict__ grad_scale, int V) {
+  __shared__ float part[NWAVE][KMAX];
+  __shared__ float s_max[KMAX], s_sum[KMAX], s_S[KMAX], s_g[KMAX];
+  __shared__ float red[32];
+  const int v = blockIdx.x;
+  const float* L = logits + (long)v * R * ld;
+  float* S = scores + (long)v * R * K;
+
+  // softmax over proposals (dim 0) of the detection stream: column max, column sum of exp
+  column_reduce<true>(R, K, part, s_max, [&](int r, int k) { return L[(long)r * ld + det_col + k]; });
+  column_reduce<false>(R, K, part, s_sum, [&](int r, int k) { return expf(L[(long)r * ld + det_col + k] - s_max[k]); });
+
+  // scores = softmax_k(cls) * softmax_r(det); written once, column sums folded in the same sweep
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const float* c = L + (long)r * ld + cls_col;
+    const float* d = L + (long)r * ld + det_col;
+    float m = -FLT_MAX;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, c[k]);
+    float z = 0.f;
+    for (int k = 0; k < K; ++k) z += expf(c[k] - m);
+    for (int k = 0; k < K; ++k) {
+      const float p = expf(c[k] - m) / z;
+      const float q = expf(d[k] - s_max[k]) / s_sum[k];
+      S[(long)r * K + k] = p * q;
+    }
+  }
+  __syncthreads();
+  column_reduce<false>(R, K, part, s_S, [&](int r, int k) { return S[(long)r * K + k]; });
+
+  // BCE on the clamped image-level score (fast_rcnn_wsddn.py:340-375); gradient is zero where clamped
+  float lpart = 0.f;
+  const float gs = (dlogits && grad_scale) ? grad_scale[0] / (float)V : 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float raw = s_S[k];
+    const float y = fminf(fmaxf(raw, 1e-6f), 1.0f - 1e-6f);
+    const float t = onehot[k];
+    lpart += -(t * fmaxf(logf(y), -100.f) + (1.f - t) * fmaxf(logf(1.f - y), -100.f));
+    const bool inside = (raw >= 1e-6f) && (raw <= 1.0f - 1e-6f);
+    s_g[k] = inside ? gs * (-(t / y - (1.f - t) / (1.f - y)) / (float)K) : 0.f;
+  }
+  const float ltot = block_reduce_sum(lpart, red);
+  if (threadIdx.x == 0) loss_view[v] = ltot / (float)K;
+  __syncthreads();
+  if (!dlogits) return;
+
+  // backward of the two softmaxes
+  float* DL = dlogits + (long)v * R * ld_d;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const float* c = L + (long)r * ld + cls_col;
+    const float* d = L + (long)r * ld + det_col;
+    float m = -FLT_MAX;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, c[k]);
+    float z = 0.f;
+    for (int k = 0; k < K; ++k) z += expf(c[k] - m);
+    float dot = 0.f;                              // sum_j g_j s_rj
+    for (int k = 0; k < K; ++k) dot += s_g[k] * S[(long)r * K + k];
+    for (int k = 0; k < K; ++k) {
+      const float p = expf(c[k] - m) / z;
+      const float q = expf(d[k] - s_max[k]) / s_sum[k];
+      DL[(long)r * ld_d + cls_col + k] = p * (s_g[k] * q - dot);
+      DL[(long)r * ld_d + det_col + k] = s_g[k] * q * (p - s_S[k]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- OICR refine loss
+// One workgroup per PREDICTION view pv; it serves every target view v with pred_view[v] == pv in order,
+// so the (reference-quirk) double use of view 2's logits needs no atomics and stays deterministic.
+__global__ __launch_bounds__(1024) void refine_loss_kernel(int V, int R, int K, const float* __restrict__ logits, long ld,
+                                                           int cls_col, int box_col, const float* __restrict__ boxes,
+                                                           const int* __restrict__ lab_class,
+                                                           const float* __restrict__ lab_weight,
+                                                           const int* __restrict__ lab_index,
+                                                           const int* __restrict__ pred_view,
+                                                           float wx, float wy, float ww, float wh,
+                                                           float* __restrict__ loss_view, float* __restrict__ probs,
+                                                           float* __restrict__ dlogits, long ld_d,
+                                                           const float* __restrict__ grad_scale) {
+  __shared__ float red[32];
+  const int pv = blockIdx.x;
+  const int K1 = K + 1;
+  const float* L = logits + (long)pv * R * ld;
+  float* DL = dlogits ? dlogits + (long)pv * R * ld_d : nullptr;
+  const float gs_cls = (dlogits && grad_scale) ? grad_scale[0] / (float)V / (float)R : 0.f;
+  const float gs_box = (dlogits && grad_scale) ? grad_scale[1] / (float)V / (float)R : 0.f;
+
+  // own softmax (predict_probs, fast_rcnn_oicr.py:702-716) + zero this view's gradient columns
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const float* x = L + (long)r * ld + cls_col;
+    float m = -FLT_MAX;
+    for (int j = 0; j < K1; ++j) m = fmaxf(m, x[j]);
+    float z = 0.f;
+    for (int j = 0; j < K1; ++j) z += expf(x[j] - m);
+    float* P = probs + ((long)pv * R + r) * K1;
+    for (int j = 0; j < K1; ++j) P[j] = expf(x[j] - m) / z;
+    if (DL) {
+      for (int j = 0; j < K1; ++j) DL[(long)r * ld_d + cls_col + j] = 0.f;
+      for (int j = 0; j < 4 * K; ++j) DL[(long)r * ld_d + box_col + j] = 0.f;
+    }
+  }
+  for (int v = 0; v < V; ++v) {
+    if (pred_view[v] != pv) continue;             // block-uniform
+    const float* B = boxes + (long)v * R * 4;
+    float lc = 0.f, lb = 0.f;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+      const int gt = lab_class[r];
+      const float w = gt == -1 ? 0.f : lab_weight[r];                 // fast_rcnn_oicr.py:217-218
+      const float* x = L + (long)r * ld + cls_col;
+      float m = -FLT_MAX;
+      for (int j = 0; j < K1; ++j) m = fmaxf(m, x[j]);
+      float z = 0.f;
+      for (int j = 0; j < K1; ++j) z += expf(x[j] - m);
+      const float logz = logf(z);
+      if (gt >= 0) lc += -((x[gt] - m) - logz) * w;                   // CE(ignore_index=-1) * weight
+      if (DL && gt >= 0 && w != 0.f) {
+        for (int j = 0; j < K1; ++j) {
+          const float p = expf(x[j] - m) / z;
+          DL[(long)r * ld_d + cls_col + j] += gs_cls * w * (p - (j == gt ? 1.f : 0.f));
+        }
+      }
+      if (gt >= 0 && gt < K) {                                         // foreground: L1 on the gt-class deltas
+        const float* s = B + (long)r * 4;
+        const float* t = B + (long)lab_index[r] * 4;                   // target = this view's proposal[gt_index]
+        const float sw_ = s[2] - s[0], sh_ = s[3] - s[1];
+        const float sx = s[0] + 0.5f * sw_, sy = s[1] + 0.5f * sh_;
+        const float tw_ = t[2] - t[0], th_ = t[3] - t[1];
+        const float tx = t[0] + 0.5f * tw_, ty = t[1] + 0.5f * th_;
+        float tgt[4];
+        tgt[0] = __fdiv_rn(wx * (tx - sx), sw_);                       // box_regression.py:59-62
+        tgt[1] = __fdiv_rn(wy * (ty - sy), sh_);
+        tgt[2] = ww * logf(__fdiv_rn(tw_, sw_));
+        tgt[3] = wh * logf(__fdiv_rn(th_, sh_));
+        const float* pd = L + (long)r * ld + box_col + 4 * gt;
+        for (int j = 0; j < 4; ++j) {
+          const float d = pd[j] - tgt[j];
+          lb += fabsf(d);
+          if (DL) DL[(long)r * ld_d + box_col + 4 * gt + j] += gs_box * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+      }
+    }
+    const float lc_t = block_reduce_sum(lc, red);
+    const float lb_t = block_reduce_sum(lb, red);
+    if (threadIdx.x == 0) {
+      loss_view[v] = lc_t / (float)R;                                  // mean over ALL R (fast_rcnn_oicr.py:269-273)
+      loss_view[V + v] = lb_t / (float)R;                              // sum / R (:351)
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------- mining + labelling
+__device__ __forceinline__ unsigned int orderable(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// ascending sort of this key == descending score, ascending index (the oracle's tie rule)
+__device__ __forceinline__ unsigned long long make_key(float score, unsigned int idx) {
+  return ((unsigned long long)(~orderable(score)) << 32) | idx;
+}
+
+__device__ void bitonic_sort(unsigned long long* keys, int N) {
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], b = keys[ixj];
+          const bool asc = (i & k) == 0;
+          if ((a > b) == asc) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ int next_pow2(int n) { int p = 64; while (p < n) p <<= 1; return p; }
+
+__device__ __forceinline__ float box_area(const float* b) { return __fmul_rn(b[2] - b[0], b[3] - b[1]); }
+
+// torchvision nms IoU: inter / (a_i + a_j - inter), inter = max(0,dx)*max(0,dy)
+__device__ __forceinline__ float iou_nms(const float* a, const float* b) {
+  const float w = fmaxf(0.f, fminf(a[2], b[2]) - fmaxf(a[0], b[0]));
+  const float h = fmaxf(0.f, fminf(a[3], b[3]) - fmaxf(a[1], b[1]));
+  const float inter = __fmul_rn(w, h);
+  return __fdiv_rn(inter, __fadd_rn(box_area(a), box_area(b)) - inter);
+}
+// detectron2 pairwise_iou (structures/boxes.py:329-361): 0 where inter <= 0
+__device__ __forceinline__ float iou_pair(const float* gtb, const float* pb) {
+  const float w = fmaxf(fminf(gtb[2], pb[2]) - fmaxf(gtb[0], pb[0]), 0.f);
+  const float h = fmaxf(fminf(gtb[3], pb[3]) - fmaxf(gtb[1], pb[1]), 0.f);
+  const float inter = __fmul_rn(w, h);
+  return inter > 0.f ? __fdiv_rn(inter, __fadd_rn(box_area(gtb), box_area(pb)) - inter) : 0.f;
+}
+
+__global__ __launch_bounds__(1024) void mine_label_kernel(int R, int ncol, int K, const float* __restrict__ scores,
+                                                          const int* __restrict__ gt_classes, int G,
+                                                          const float* __restrict__ boxes, int top_k, float score_thresh,
+                                                          float nms_thresh, float iou_bg, float iou_fg,
+                                                          int* __restrict__ lab_class, float* __restrict__ lab_weight,
+                                                          int* __restrict__ lab_index, int* __restrict__ pgt_count,
+                                                          int* __restrict__ pgt_index, int* __restrict__ pgt_class,
+                                                          float* __restrict__ pgt_score, char* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n_slots = top_k * G;
+  const int NP = next_pow2(R > n_slots ? R : n_slots);
+  unsigned long long* keys = (unsigned long long*)smem;                 // [NP]
+  unsigned char* sup = (unsigned char*)(smem + (size_t)NP * 8);          // [n_slots]
+  __shared__ int s_scan[1024];
+  __shared__ int s_nk;
+  float* slot_score = (float*)ws;                                        // [n_slots]  rank-major, class-minor
+  int* slot_idx = (int*)(slot_score + n_slots);
+  float* c_score = (float*)(slot_idx + n_slots);                         // compacted candidates
+  int* c_idx = (int*)(c_score + n_slots);
+  int* c_cls = c_idx + n_slots;
+  const int tid = threadIdx.x;
+
+  // ---- 1. per gt class: full sort of the score column, take the first top_k (get_pgt_top_k :646-666)
+  const int NPR = next_pow2(R);
+  for (int g = 0; g < G; ++g) {
+    const int col = gt_classes[g];
+    for (int i = tid; i < NPR; i += blockDim.x)
+      keys[i] = i < R ? make_key(scores[(long)i * ncol + col], (unsigned)i) : ~0ull;
+    __syncthreads();
+    bitonic_sort(keys, NPR);
+    for (int rank = tid; rank < top_k; rank += blockDim.x) {
+      const unsigned int idx = (unsigned int)(keys[rank] & 0xFFFFFFFFu);
+      slot_idx[rank * G + g] = (int)idx;
+      slot_score[rank * G + g] = scores[(long)idx * ncol + col];
+    }
+    __syncthreads();
+  }
+  __threadfence_block();
+  // ---- 2. threshold mask with rank 0 always kept (:698-704), masked_select order = slot order
+  const int per = (n_slots + 1023) / 1024;
+  int cnt = 0;
+  for (int s = tid * per; s < min(n_slots, (tid + 1) * per); ++s)
+    cnt += (s < G || slot_score[s] >= score_thresh) ? 1 : 0;
+  s_scan[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int add = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += add;
+    __syncthreads();
+  }
+  const int n = s_scan[1023];
+  int pos = s_scan[tid] - cnt;
+  for (int s = tid * per; s < min(n_slots, (tid + 1) * per); ++s) {
+    if (s < G || slot_score[s] >= score_thresh) {
+      c_score[pos] = slot_score[s]; c_idx[pos] = slot_idx[s]; c_cls[pos] = gt_classes[s % G];
+      ++pos;
+    }
+  }
+  __syncthreads();
+  // ---- 3. class-agnostic greedy NMS (get_pgt_mist :576-581; torchvision nms): sort by score desc, position asc
+  const int NPN = next_pow2(n);
+  for (int i = tid; i < NPN; i += blockDim.x) keys[i] = i < n ? make_key(c_score[i], (unsigned)i) : ~0ull;
+  for (int i = tid; i < n; i += blockDim.x) sup[i] = 0;
+  if (tid == 0) s_nk = 0;
+  __syncthreads();
+  bitonic_sort(keys, NPN);
+  int nk = 0;
+  for (int t = 0; t < n; ++t) {
+    const int p = (int)(keys[t] & 0xFFFFFFFFu);
+    if (sup[p]) continue;                                               // uniform across the workgroup
+    if (tid == 0) { pgt_index[nk] = c_idx[p]; pgt_class[nk] = c_cls[p]; pgt_score[nk] = c_score[p]; }
+    ++nk;
+    const float* bp = boxes + (long)c_idx[p] * 4;
+    for (int u = t + 1 + tid; u < n; u += blockDim.x) {
+      const int q = (int)(keys[u] & 0xFFFFFFFFu);
+      if (!sup[q] && iou_nms(bp, boxes + (long)c_idx[q] * 4) > nms_thresh) sup[q] = 1;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { pgt_count[0] = nk; __threadfence(); }
+  __syncthreads();
+  // ---- 4. IoU matching + labels (pairwise_iou, Matcher [iou_bg, iou_fg] -> {0,-1,1}, roi_heads.py:225-257,266-375)
+  for (int r = tid; r < R; r += blockDim.x) {
+    const float* pb = boxes + (long)r * 4;
+    float best = -1.f; int bj = 0;
+    for (int j = 0; j < nk; ++j) {
+      const float v = iou_pair(boxes + (long)pgt_index[j] * 4, pb);
+      if (v > best) { best = v; bj = j; }                               // first max = lowest pgt index
+    }
+    int cls; float w = 0.f; int gi = 0;
+    if (nk == 0) { cls = K; }
+    else {
+      const int lab = best >= iou_fg ? 1 : (best >= iou_bg ? -1 : 0);
+      cls = lab == 1 ? pgt_class[bj] : (lab == 0 ? K : -1);
+      w = pgt_score[bj]; gi = pgt_index[bj];
+    }
+    lab_class[r] = cls; lab_weight[r] = w; lab_index[r] = gi;
+  }
+}
+
+}  // namespace
+
+extern "C" int sw_wsddn_mil(int V, int R, int K, const float* logits, long ld, int cls_col, int det_col,
+                            const float* gt_onehot, float* scores, float* loss_view, float* dlogits, long ld_d,
+                            const float* grad_scale, hipStream_t stream) {
+  if (K > KMAX) return -6;
+  hipLaunchKernelGGL(wsddn_kernel, dim3(V), dim3(1024), 0, stream, R, K, logits, ld, cls_col, det_col, gt_onehot, scores,
+                     loss_view, dlogits, ld_d, grad_scale, V);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_oicr_refine_loss(int V, int R, int K, const float* logits, long ld, int cls_col, int box_col,
+                                   const float* boxes, const int32_t* lab_class, const float* lab_weight,
+                                   const int32_t* lab_index, const int32_t* pred_view, const float* reg_weights4,
+                                   float* loss_view, float* probs, float* dlogits, long ld_d,
+                                   const float* grad_scale, hipStream_t stream) {
+  // reg_weights4: HOST pointer (configuration constants BBOX_REG_WEIGHTS)
+  hipLaunchKernelGGL(refine_loss_kernel, dim3(V), dim3(1024), 0, stream, V, R, K, logits, ld, cls_col, box_col, boxes,
+                     lab_class, lab_weight, lab_index, pred_view, reg_weights4[0], reg_weights4[1], reg_weights4[2],
+                     reg_weights4[3], loss_view, probs, dlogits, ld_d, grad_scale);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" long sw_mine_workspace_bytes(int top_k, int G) { return (long)top_k * G * 20 + 64; }
+
+extern "C" int sw_oicr_mine_label(int R, int ncol, int K, const float* scores, const int32_t* gt_classes, int G,
+                                  const float* boxes, int top_k, float score_thresh, float nms_thresh, float iou_bg,
+                                  float iou_fg, int32_t* lab_class, float* lab_weight, int32_t* lab_index,
+                                  int32_t* pgt_count, int32_t* pgt_index, int32_t* pgt_class, float* pgt_score,
+                                  void* workspace, hipStream_t stream) {
+  if (R > 16384 || (long)top_k * G > 16384 || top_k > R || G < 1) return -6;
+  int np = 64;
+  const int need = R > top_k * G ? R : top_k * G;
+  while (np < need) np <<= 1;
+  const size_t lds = (size_t)np * 8 + (size_t)top_k * G;
+  hipError_t e = hipFuncSetAttribute((const void*)mine_label_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(mine_label_kernel, dim3(1), dim3(1024), lds, stream, R, ncol, K, scores, gt_classes, G, boxes, top_k,
+                     score_thresh, nms_thresh, iou_bg, iou_fg, lab_class, lab_weight, lab_index, pgt_count, pgt_index,
+                     pgt_class, pgt_score, (char*)workspace);
+  SW_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,178 @@
+// Max ROI pooling over an NHWC feature map, gfx950.
+// Arithmetic follows the reference statement in
+//   uwsod/projects/WSL/wsl/layers/csrc/ROILoopPool/ROILoopPool_cpu.cpp:26-79 (fwd), :98-123 (bwd)
+// (= torchvision 0.7 RoIPool): round(x*scale), +1 extent, float bin = extent/P, floor/ceil bin edges,
+// clip to the map, strict '>' from -FLT_MAX (first max in row-major order), empty bin -> 0 / -1.
+//
+// Forward: one workgroup per (roi, 64-channel slab).  Lanes run over channels so that every pixel read
+// is one coalesced 128/256-byte row segment of the NHWC map (the whole map is L2 / Infinity-Cache
+// resident); the 4 waves split the PHxPW bins; results are transposed through LDS so that the
+// (R, C, PH, PW) output — the layout the reference's fc6 weight expects — is written as one contiguous
+// run of 64*PH*PW elements per workgroup.  HBM-bound on the output + argmax stream.
+//
+// Backward: one workgroup per (image, CB-channel slab) owns dfeat[:, :, slab] in LDS (H*W*CB f32),
+// sweeps every ROI of that image once, accumulates with LDS atomics and writes its slab exactly once:
+// no global atomics, no cross-workgroup traffic (a per-channel argmax scatters 64 lanes to 64 different
+// rows, which global float atomics serve ~17x below their peak rate).
+#include <float.h>
+#include "common.h"
+#include "soswsod_hip.h"
+
+namespace {
+
+constexpr int FWD_CH = 64;
+
+struct RoiGeom {
+  int batch, start_w, start_h;
+  float bin_h, bin_w;
+};
+
+__device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int PH, int PW) {
+  RoiGeom g;
+  g.batch = (int)roi[0];
+  g.start_w = (int)roundf(__fmul_rn(roi[1], scale));
+  g.start_h = (int)roundf(__fmul_rn(roi[2], scale));
+  const int end_w = (int)roundf(__fmul_rn(roi[3], scale));
+  const int end_h = (int)roundf(__fmul_rn(roi[4], scale));
+  const int rw = max(end_w - g.start_w + 1, 1);
+  const int rh = max(end_h - g.start_h + 1, 1);
+  g.bin_h = __fdiv_rn((float)rh, (float)PH);
+  g.bin_w = __fdiv_rn((float)rw, (float)PW);
+  return g;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, int PH, int PW, float scale,
+                                                           const T* __restrict__ feat, const float* __restrict__ rois,
+                                                           const float* __restrict__ row_scale, float row_scale_add,
+                                                           T* __restrict__ out, int* __restrict__ argmax) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nb = PH * PW;
+  float* s_val = (float*)smem;                 // [FWD_CH][nb]  (row stride nb: odd for 7x7 -> conflict free)
+  int* s_arg = (int*)(smem + (size_t)FWD_CH * nb * 4);
+  const int r = blockIdx.x, c0 = blockIdx.y * FWD_CH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const RoiGeom g = roi_geom(rois + (long)r * 5, scale, PH, PW);
+  const float mul = row_scale ? (row_scale[r] + row_scale_add) : 1.0f;
+  const int c = c0 + lane;
+  const T* fimg = feat + (long)g.batch * H * W * C;
+  for (int b = wave; b < nb; b += 4) {
+    const int ph = b / PW, pw = b - ph * PW;
+    int hs = (int)floorf(__fmul_rn((float)ph, g.bin_h));
+    int ws = (int)floorf(__fmul_rn((float)pw, g.bin_w));
+    int he = (int)ceilf(__fmul_rn((float)(ph + 1), g.bin_h));
+    int we = (int)ceilf(__fmul_rn((float)(pw + 1), g.bin_w));
+    hs = min(max(hs + g.start_h, 0), H); he = min(max(he + g.start_h, 0), H);
+    ws = min(max(ws + g.start_w, 0), W); we = min(max(we + g.start_w, 0), W);
+    const bool empty = (he <= hs) || (we <= ws);
+    float mv = empty ? 0.f : -FLT_MAX;
+    int mi = -1;
+    if (c < C) {
+      for (int h = hs; h < he; ++h) {
+        const T* row = fimg + ((long)h * W) * C + c;
+        for (int w = ws; w < we; ++w) {
+          const float v = Elem<T>::load(row + (long)w * C);
+          if (v > mv) { mv = v; mi = h * W + w; }
+        }
+      }
+    }
+    s_val[lane * nb + b] = __fmul_rn(mv, mul);
+    s_arg[lane * nb + b] = mi;
+  }
+  __syncthreads();
+  const int nch = min(FWD_CH, C - c0);
+  const int total = nch * nb;
+  const long obase = ((long)r * C + c0) * nb;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    Elem<T>::store(out + obase + i, s_val[i]);
+    argmax[obase + i] = s_arg[i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C, int nb, int CB,
+                                                            const T* __restrict__ dout, const int* __restrict__ argmax,
+                                                            const float* __restrict__ rois, int R,
+                                                            const float* __restrict__ row_scale, float row_scale_add,
+                                                            const T* __restrict__ relu_ref, T* __restrict__ dfeat) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* acc = (float*)smem;                   // [H*W][CB]
+  const int img = blockIdx.y, c0 = blockIdx.x * CB;
+  const int npix = H * W;
+  for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const int per_roi = CB * nb;                 // contiguous (c, bin) run of this slab inside one ROI
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  for (int r = wave; r < R; r += nwave) {
+    if ((int)rois[(long)r * 5] != img) continue;           // wave-uniform
+    const float mul = row_scale ? (row_scale[r] + row_scale_add) : 1.0f;
+    const long base = ((long)r * C + c0) * nb;
+    for (int i = lane; i < per_roi; i += 64) {
+      const int a = argmax[base + i];
+      if (a >= 0) {
+        const int cc = i / nb;
+        atomicAdd(&acc[a * CB + cc], __fmul_rn(Elem<T>::load(dout + base + i), mul));
+      }
+    }
+  }
+  __syncthreads();
+  T* dimg = dfeat + (long)img * npix * C;
+  const T* rimg = relu_ref ? relu_ref + (long)img * npix * C : nullptr;
+  for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) {
+    const int p = i / CB, cc = i - p * CB;
+    float v = acc[i];
+    if (rimg && !(Elem<T>::load(rimg + (long)p * C + c0 + cc) > 0.f)) v = 0.f;
+    Elem<T>::store(dimg + (long)p * C + c0 + cc, v);
+  }
+}
+
+}  // namespace
+
+extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale,
+                               const void* feat, const float* rois, int R, const float* row_scale,
+                               float row_scale_add, void* out, int32_t* argmax, hipStream_t stream) {
+  (void)nimg;
+  if (R <= 0) return 0;
+  const size_t lds = (size_t)FWD_CH * PH * PW * 8;
+  if (lds > 64 * 1024) return -6;
+  dim3 grid(R, (C + FWD_CH - 1) / FWD_CH), block(256);
+  if (dtype == SW_BF16)
+    hipLaunchKernelGGL(roi_pool_fwd_kernel<unsigned short>, grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
+                       (const unsigned short*)feat, rois, row_scale, row_scale_add, (unsigned short*)out, argmax);
+  else if (dtype == SW_F32)
+    hipLaunchKernelGGL(roi_pool_fwd_kernel<float>, grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
+                       (const float*)feat, rois, row_scale, row_scale_add, (float*)out, argmax);
+  else
+    return -1;
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
+                               const int32_t* argmax, const float* rois, int R, const float* row_scale,
+                               float row_scale_add, const void* relu_ref, void* dfeat, hipStream_t stream) {
+  // channel slab per workgroup: largest power of two with H*W*CB*4 <= 128 KiB
+  int CB = 64;
+  while (CB > 1 && ((size_t)H * W * CB * 4 > 128 * 1024 || (C % CB))) CB >>= 1;
+  const size_t lds = (size_t)H * W * CB * 4;
+  if (lds > 160 * 1024) return -6;
+  dim3 grid(C / CB, nimg), block(1024);
+  hipError_t e;
+  if (dtype == SW_BF16) {
+    auto k = roi_pool_bwd_kernel<unsigned short>;
+    e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, block, lds, stream, H, W, C, PH * PW, CB, (const unsigned short*)dout, argmax, rois, R,
+                       row_scale, row_scale_add, (const unsigned short*)relu_ref, (unsigned short*)dfeat);
+  } else if (dtype == SW_F32) {
+    auto k = roi_pool_bwd_kernel<float>;
+    e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, block, lds, stream, H, W, C, PH * PW, CB, (const float*)dout, argmax, rois, R, row_scale,
+                       row_scale_add, (const float*)relu_ref, (float*)dfeat);
+  } else {
+    return -1;
+  }
+  SW_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,206 @@
+"""Thin torch-tensor wrappers over the C-ABI kernels (include/soswsod_hip.h).
+
+torch is used here only for device memory and the current HIP stream; every computation is a
+hand-written gfx950 kernel.  All tensors must live on the GPU and be contiguous where stated.
+"""
+import ctypes
+
+import torch
+
+from ._lib import SW_BF16, SW_F32, Epilogue, check, lib
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dt(t_or_dtype):
+    d = t_or_dtype if isinstance(t_or_dtype, torch.dtype) else t_or_dtype.dtype
+    if d == torch.float32:
+        return SW_F32
+    if d == torch.bfloat16:
+        return SW_BF16
+    raise TypeError(f"unsupported dtype {d}")
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("sos-wsod_amd kernels need GPU tensors (there is no CPU fallback)")
+
+
+def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_ref=None, ref_scale=1.0,
+                  out_dtype=torch.float32, atomic=False):
+    ep = Epilogue()
+    ep.bias = None if bias is None else bias.data_ptr()
+    ep.relu = int(relu)
+    ep.drop_mask = None if drop_mask is None else drop_mask.data_ptr()
+    ep.ld_drop = 0 if drop_mask is None else drop_mask.stride(0)
+    ep.drop_scale = float(drop_scale)
+    ep.relu_ref = None if relu_ref is None else relu_ref.data_ptr()
+    ep.ld_ref = 0 if relu_ref is None else relu_ref.stride(0)
+    ep.ref_scale = float(ref_scale)
+    ep.ref_dtype = SW_F32 if relu_ref is None else dt(relu_ref)
+    ep.out_dtype = dt(out_dtype)
+    ep.accumulate_atomic = int(atomic)
+    return ep
+
+
+def gemm(A, B, C, M, N, K, a_kstrided=False, b_kstrided=False, lda=None, ldb=None, ldc=None, ep=None, splitk=1):
+    """C[m][n] = sum_k A(m,k) B(k,n); see sw_gemm.  A and B share one dtype (f32 / bf16)."""
+    _need_gpu(A, B, C)
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    ldc = C.stride(0) if ldc is None else ldc
+    if ep is None:
+        ep = make_epilogue(out_dtype=C.dtype)
+    check(lib.sw_gemm(dt(A), int(a_kstrided), int(b_kstrided), M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc,
+                      ctypes.byref(ep), splitk, _stream()), "sw_gemm")
+    return C
+
+
+def conv3x3(x, wk, out, dilation, ep):
+    """x [n][H][W][Cin], wk [Cout][9][Cin], out [n][H][W][Cout]"""
+    _need_gpu(x, wk, out)
+    n, H, W, Cin = x.shape
+    Cout = out.shape[3]
+    check(lib.sw_conv3x3_igemm(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(wk), _p(out), ctypes.byref(ep), _stream()),
+          "sw_conv3x3_igemm")
+    return out
+
+
+def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1):
+    _need_gpu(x, dy, dw_oihw)
+    n, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    check(lib.sw_conv3x3_wgrad(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(dy), _p(dw_oihw), splitk, _stream()),
+          "sw_conv3x3_wgrad")
+    return dw_oihw
+
+
+def conv_weight_prep(w_oihw, wk, mode, cin_pad=None):
+    Cout, Cin = w_oihw.shape[:2]
+    cin_pad = Cin if cin_pad is None else cin_pad
+    check(lib.sw_conv_weight_prep(dt(wk), mode, Cout, Cin, cin_pad, _p(w_oihw), _p(wk), _stream()), "sw_conv_weight_prep")
+    return wk
+
+
+def maxpool_fwd(x, out, stride):
+    n, H, W, C = x.shape
+    check(lib.sw_maxpool2x2_fwd(dt(x), n, H, W, C, stride, _p(x), _p(out), _stream()), "sw_maxpool2x2_fwd")
+    return out
+
+
+def maxpool_bwd(x, dout, din, stride, relu_mask):
+    n, H, W, C = x.shape
+    check(lib.sw_maxpool2x2_bwd(dt(x), n, H, W, C, stride, _p(x), _p(dout), _p(din), int(relu_mask), _stream()),
+          "sw_maxpool2x2_bwd")
+    return din
+
+
+def preprocess(img_u8_chw, out_hwc, mean, std):
+    _need_gpu(img_u8_chw, out_hwc)
+    H, W, cpad = out_hwc.shape
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(lib.sw_preprocess(dt(out_hwc), H, W, cpad, _p(img_u8_chw), m, s, _p(out_hwc), _stream()), "sw_preprocess")
+    return out_hwc
+
+
+def roi_pool_fwd(feat, rois, out, argmax, spatial_scale, PH, PW, row_scale=None, row_scale_add=0.0):
+    """feat [n][H][W][C], rois [R][5] f32, out [R][C*PH*PW], argmax int32 same shape"""
+    _need_gpu(feat, rois, out, argmax)
+    n, H, W, C = feat.shape
+    R = rois.shape[0]
+    check(lib.sw_roi_pool_fwd(dt(feat), n, H, W, C, PH, PW, float(spatial_scale), _p(feat), _p(rois), R, _p(row_scale),
+                              float(row_scale_add), _p(out), _p(argmax), _stream()), "sw_roi_pool_fwd")
+    return out, argmax
+
+
+def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_add=0.0, relu_ref=None):
+    _need_gpu(dout, argmax, rois, dfeat)
+    n, H, W, C = dfeat.shape
+    R = rois.shape[0]
+    check(lib.sw_roi_pool_bwd(dt(dfeat), n, H, W, C, PH, PW, _p(dout), _p(argmax), _p(rois), R, _p(row_scale),
+                              float(row_scale_add), _p(relu_ref), _p(dfeat), _stream()), "sw_roi_pool_bwd")
+    return dfeat
+
+
+def wsddn_mil(logits, V, R, K, cls_col, det_col, gt_onehot, scores, loss_view, dlogits=None, grad_scale=None):
+    _need_gpu(logits, gt_onehot, scores, loss_view)
+    check(lib.sw_wsddn_mil(V, R, K, _p(logits), logits.stride(0), cls_col, det_col, _p(gt_onehot), _p(scores),
+                           _p(loss_view), _p(dlogits), 0 if dlogits is None else dlogits.stride(0), _p(grad_scale),
+                           _stream()), "sw_wsddn_mil")
+
+
+def mean_views(x, out):
+    V = x.shape[0]
+    check(lib.sw_mean_views(V, out.numel(), _p(x), _p(out), _stream()), "sw_mean_views")
+    return out
+
+
+def mine_workspace_bytes(top_k, G):
+    return int(lib.sw_mine_workspace_bytes(top_k, G))
+
+
+def oicr_mine_label(scores, gt_classes_i32, boxes, K, top_k, thresh, nms_thresh, iou_bg, iou_fg, lab_class, lab_weight,
+                    lab_index, pgt_count, pgt_index, pgt_class, pgt_score, workspace):
+    _need_gpu(scores, gt_classes_i32, boxes)
+    R, ncol = scores.shape
+    G = gt_classes_i32.numel()
+    check(lib.sw_oicr_mine_label(R, ncol, K, _p(scores), _p(gt_classes_i32), G, _p(boxes), int(top_k), float(thresh),
+                                 float(nms_thresh), float(iou_bg), float(iou_fg), _p(lab_class), _p(lab_weight),
+                                 _p(lab_index), _p(pgt_count), _p(pgt_index), _p(pgt_class), _p(pgt_score),
+                                 _p(workspace), _stream()), "sw_oicr_mine_label")
+
+
+def oicr_refine_loss(logits, V, R, K, cls_col, box_col, boxes, lab_class, lab_weight, lab_index, pred_view, reg_weights,
+                     loss_view, probs, dlogits=None, grad_scale=None):
+    rw = (ctypes.c_float * 4)(*[float(v) for v in reg_weights])
+    check(lib.sw_oicr_refine_loss(V, R, K, _p(logits), logits.stride(0), cls_col, box_col, _p(boxes), _p(lab_class),
+                                  _p(lab_weight), _p(lab_index), _p(pred_view), rw, _p(loss_view), _p(probs),
+                                  _p(dlogits), 0 if dlogits is None else dlogits.stride(0), _p(grad_scale), _stream()),
+          "sw_oicr_refine_loss")
+
+
+def colsum(X, M, N, out, ld=None):
+    check(lib.sw_colsum(dt(X), M, N, _p(X), X.stride(0) if ld is None else ld, _p(out), _stream()), "sw_colsum")
+    return out
+
+
+def convert_2d(src_f32, dst, rows, cols, ld_src=None, ld_dst=None):
+    check(lib.sw_convert_2d(dt(dst), rows, cols, _p(src_f32), src_f32.stride(0) if ld_src is None else ld_src, _p(dst),
+                            dst.stride(0) if ld_dst is None else ld_dst, _stream()), "sw_convert_2d")
+    return dst
+
+
+def to_f32(src, dst):
+    check(lib.sw_to_f32(dt(src), src.numel(), _p(src), _p(dst), _stream()), "sw_to_f32")
+    return dst
+
+
+def fill_zero(t):
+    check(lib.sw_fill_zero(_p(t), t.numel() * t.element_size(), _stream()), "sw_fill_zero")
+    return t
+
+
+def dropout_mask(keep_u8, seed, offset, p=0.5):
+    check(lib.sw_dropout_mask(_p(keep_u8), keep_u8.numel(), int(seed) & (2 ** 64 - 1), int(offset), float(p), _stream()),
+          "sw_dropout_mask")
+    return keep_u8
+
+
+def sgd_momentum_step(param, grad, buf, lr, momentum, weight_decay, first_step, grad_scale=1.0):
+    check(lib.sw_sgd_momentum_step(_p(param), _p(grad), _p(buf), param.numel(), float(lr), float(momentum),
+                                   float(weight_decay), int(first_step), float(grad_scale), _stream()),
+          "sw_sgd_momentum_step")
+
+
+def loss_finalize(loss_view, out):
+    n, V = loss_view.shape
+    check(lib.sw_loss_finalize(n, V, _p(loss_view), _p(out), _stream()), "sw_loss_finalize")
+    return out

@@ -1,0 +1,293 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle / an fp64 torch reference.
+Integer outputs (ROI argmax, mined indices, labels) must be bit exact; floating point within the
+tolerance written next to each check."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oicr_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import sos_wsod_amd  # noqa: F401
+    import sos_wsod_amd.ops as ops
+    assert torch.cuda.is_available()
+    return ops
+
+
+def _rand(shape, seed, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-5}     # inputs are pre-rounded; accumulation is f32 in both
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+def test_gemm_modes(ops, dtype, mode):
+    M, N, K = 300, 448, 520 if mode == "tn" else 512
+    if mode == "tn":
+        M = 296                                            # K-strided operands need M, N multiples of 8
+    a = _rand((M, K), 1, dtype); b = _rand((K, N), 2, dtype)
+    ref = (a.double() @ b.double())
+    A = (a.t().contiguous() if mode == "tn" else a).cuda()             # tn: A stored [K][M]
+    B = (b.contiguous() if mode in ("nn", "tn") else b.t().contiguous()).cuda()   # nt: B stored [N][K]
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm(A, B, C, M, N, K, a_kstrided=(mode == "tn"), b_kstrided=(mode != "nt"))
+    err = (C.cpu().double() - ref).abs().max() / ref.abs().max()
+    assert err < TOL[dtype], err
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_epilogue_bias_relu_dropout_and_splitk_atomic(ops, dtype):
+    M, N, K = 200, 256, 1024
+    a = _rand((M, K), 3, dtype); w = _rand((N, K), 4, dtype); bias = _rand((N,), 5)
+    keep = (torch.rand(M, N, generator=torch.Generator().manual_seed(6)) > 0.5).to(torch.uint8)
+    ref = F.relu(a.double() @ w.double().t() + bias.double()) * keep.double() * 2.0
+    C = torch.empty((M, N), device="cuda", dtype=dtype)
+    ep = ops.make_epilogue(bias=bias.cuda(), relu=True, drop_mask=keep.cuda(), drop_scale=2.0, out_dtype=dtype)
+    ops.gemm(a.cuda(), w.cuda(), C, M, N, K, ep=ep)
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-5      # bf16 output rounding
+    assert ((C.cpu().double() - ref).abs().max() / ref.abs().max()) < tol
+    # relu-backward mask epilogue + split-K atomic accumulation
+    refm = _rand((M, N), 7, dtype)
+    C2 = torch.zeros((M, N), device="cuda")
+    ep2 = ops.make_epilogue(relu_ref=refm.cuda(), ref_scale=2.0, out_dtype=torch.float32, atomic=True)
+    ops.gemm(a.cuda(), w.cuda(), C2, M, N, K, ep=ep2, splitk=4)
+    ref2 = (a.double() @ w.double().t()) * (refm.double() > 0) * 2.0
+    assert ((C2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ conv
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cin,cout,dil", [(3, 64, 1), (64, 128, 1), (128, 64, 2)])
+def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cin, cout, dil):
+    n, H, W = 2, 19, 23
+    epc = 8 if dtype == torch.bfloat16 else 4
+    cpad = (cin + epc - 1) // epc * epc
+    x = _rand((n, cin, H, W), 10, dtype); w = _rand((cout, cin, 3, 3), 11, dtype, 0.1); b = _rand((cout,), 12)
+    xd = x.double().requires_grad_(True); wd = w.double().requires_grad_(True)
+    y = F.relu(F.conv2d(xd, wd, b.double(), padding=dil, dilation=dil))
+    gy = _rand((n, cout, H, W), 13, dtype)
+    (y * gy.double()).sum().backward()
+    # forward
+    xp = torch.zeros(n, H, W, cpad, dtype=dtype); xp[..., :cin] = _nhwc(x)
+    wk = torch.empty(cout, 9, cpad, device="cuda", dtype=dtype)
+    ops.conv_weight_prep(w.float().cuda(), wk, 0, cpad)
+    out = torch.empty(n, H, W, cout, device="cuda", dtype=dtype)
+    ops.conv3x3(xp.cuda(), wk, out, dil, ops.make_epilogue(bias=b.cuda(), relu=True, out_dtype=dtype))
+    tol = 1e-2 if dtype == torch.bfloat16 else 3e-5
+    ref = _nhwc(y.detach())
+    assert ((out.cpu().double() - ref).abs().max() / ref.abs().max()) < tol
+    if cin % epc:
+        return
+    # dz = gy * relu'(y)  (pre-activation gradient), as the product path forms it
+    dz = (_nhwc(gy).double() * (ref > 0)).to(dtype)
+    # weight gradient (f32, OIHW, atomic)
+    dw = torch.zeros(cout, cin, 3, 3, device="cuda")
+    ops.conv3x3_wgrad(xp.cuda(), dz.cuda(), dw, dil, splitk=3)
+    dz_ref = dz.double().permute(0, 3, 1, 2)
+    gw_ref = torch.autograd.grad(F.conv2d(xd, wd, None, padding=dil, dilation=dil), wd, dz_ref)[0]
+    assert ((dw.cpu().double() - gw_ref).abs().max() / gw_ref.abs().max()) < 3e-5
+    # data gradient = conv with flipped / transposed weights, masked by (x > 0)
+    wkd = torch.empty(cin, 9, cout, device="cuda", dtype=dtype)
+    ops.conv_weight_prep(w.float().cuda(), wkd, 1)
+    dx = torch.empty(n, H, W, cin, device="cuda", dtype=torch.float32)
+    ops.conv3x3(dz.cuda(), wkd, dx, dil, ops.make_epilogue(relu_ref=xp.cuda().view(n * H * W, cin), out_dtype=torch.float32))
+    gx_ref = torch.autograd.grad(F.conv2d(xd, wd, None, padding=dil, dilation=dil), xd, dz_ref)[0]
+    gx_ref = _nhwc(gx_ref) * (_nhwc(x).double() > 0)
+    assert ((dx.cpu().double() - gx_ref).abs().max() / gx_ref.abs().max()) < 3e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("stride", [1, 2])
+def test_maxpool_fwd_bwd(ops, dtype, stride):
+    n, C, H, W = 2, 24, 11, 14
+    x = F.relu(_rand((n, C, H, W), 20, dtype)).float()          # post-ReLU like the backbone (ties at 0)
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 2, stride)
+    gy = _rand(tuple(y.shape), 21, dtype).float()
+    y.backward(gy)
+    xin = _nhwc(x).to(dtype).cuda()
+    out = torch.empty(n, y.shape[2], y.shape[3], C, device="cuda", dtype=dtype)
+    ops.maxpool_fwd(xin, out, stride)
+    assert torch.equal(out.cpu().float(), _nhwc(y.detach()))
+    din = torch.empty_like(xin)
+    ops.maxpool_bwd(xin, _nhwc(gy).to(dtype).cuda(), din, stride, relu_mask=True)
+    ref = _nhwc(xr.grad) * (_nhwc(x) > 0)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-6
+    assert (din.cpu().float() - ref).abs().max() <= tol * ref.abs().max()
+
+
+# ------------------------------------------------------------------------------------------ ROIPool
+@pytest.mark.parametrize("dtype", DT)
+def test_roi_pool_bit_exact_and_backward(ops, dtype):
+    n, C, H, W, R = 2, 96, 31, 40, 300
+    feat = _rand((n, C, H, W), 30, dtype).float()
+    views, _ = O.make_views(H * 8, W * 8, R, tag="rp")
+    boxes = views[0]["boxes"].copy()
+    boxes[:5] = [[0, 0, 1e4, 1e4], [-50, -50, -10, -10], [100, 100, 90, 90], [8 * W - 1, 8 * H - 1, 8 * W + 40, 8 * H + 40],
+                 [3.9, 3.9, 4.1, 4.1]]                           # clipped / outside / malformed / edge / tiny
+    rois = np.concatenate([(np.arange(R) % n)[:, None].astype(np.float32), boxes], 1).astype(np.float32)
+    obj = views[0]["obj"]
+    ref_out, ref_arg = O.roi_pool_fwd(feat.numpy(), rois, 1.0 / 8)
+    ref_scaled = torch.from_numpy(ref_out) * (torch.from_numpy(obj) + 1).view(-1, 1, 1, 1)
+    f = _nhwc(feat).to(dtype).cuda()
+    out = torch.empty(R, C * 49, device="cuda", dtype=dtype)
+    arg = torch.empty(R, C * 49, device="cuda", dtype=torch.int32)
+    ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7, row_scale=torch.from_numpy(obj).cuda(),
+                     row_scale_add=1.0)
+    assert np.array_equal(arg.cpu().numpy().reshape(ref_arg.shape), ref_arg)              # bit exact bins/argmax
+    assert torch.equal(out.cpu().float().view(ref_scaled.shape), ref_scaled.to(dtype).float())   # values copied
+    g = _rand((R, C, 7, 7), 31, dtype).float()
+    ref_g = O.roi_pool_bwd((g * (torch.from_numpy(obj) + 1).view(-1, 1, 1, 1)).numpy(), ref_arg, rois, feat.shape)
+    ref_g = _nhwc(torch.from_numpy(ref_g)) * (_nhwc(feat) > 0)
+    dfeat = torch.empty(n, H, W, C, device="cuda", dtype=dtype)
+    ops.roi_pool_bwd(g.to(dtype).view(R, -1).cuda(), arg, torch.from_numpy(rois).cuda(), dfeat, 7, 7,
+                     row_scale=torch.from_numpy(obj).cuda(), row_scale_add=1.0, relu_ref=f)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert (dfeat.cpu().float() - ref_g).abs().max() <= tol * ref_g.abs().max()
+
+
+# ------------------------------------------------------------------------------------------ heads
+@pytest.mark.parametrize("R,K", [(37, 20), (2000, 20), (700, 80)])
+def test_wsddn_mil_loss_and_grad(ops, R, K):
+    V, LD = 4, 448
+    lg = _rand((V * R, LD), 40, scale=3.0)
+    gt = torch.zeros(1, K); gt[0, [1, K // 2]] = 1
+    gs = torch.tensor([0.7])
+    x = lg.clone().requires_grad_(True)
+    losses, sc = [], []
+    for v in range(V):
+        blk = x[v * R:(v + 1) * R]
+        s = F.softmax(blk[:, 3:3 + K], 1) * F.softmax(blk[:, 200:200 + K], 0)
+        sc.append(s); losses.append(O.wsddn_loss(s, gt))
+    (sum(losses) / V * gs[0]).backward()
+    scores = torch.empty(V, R, K, device="cuda"); lv = torch.empty(V, device="cuda")
+    dl = torch.zeros(V * R, LD, device="cuda")
+    ops.wsddn_mil(lg.cuda(), V, R, K, 3, 200, gt.cuda().view(-1), scores, lv, dl, gs.cuda())
+    np.testing.assert_allclose(lv.cpu().numpy(), torch.stack(losses).detach().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(scores.cpu().numpy(), torch.stack(sc).detach().numpy(), rtol=2e-5, atol=1e-10)
+    ref = x.grad
+    assert (dl.cpu() - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_mining_and_labels_bit_exact_vs_golden(ops, case, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"mining_{case}.npz"))
+    R, K = int(g["R"]), int(g["K"])
+    views, _ = O.make_views(256, 320, R, n_gt=len(g["gt"]), K=K, tag=str(g["boxes_tag"]))
+    boxes = torch.from_numpy(views[0]["boxes"]).cuda()
+    gt = torch.from_numpy(g["gt"].astype(np.int32)).cuda()
+    G = gt.numel(); top_k = max(int(R * 0.10), 1)
+    for variant in ("wsddn", "refine"):
+        sc = torch.from_numpy(g[f"{variant}/scores"]).cuda()
+        lab_c = torch.empty(R, dtype=torch.int32, device="cuda"); lab_w = torch.empty(R, device="cuda")
+        lab_i = torch.empty(R, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        pi = torch.empty(top_k * G, dtype=torch.int32, device="cuda"); pc = torch.empty_like(pi)
+        ps = torch.empty(top_k * G, device="cuda")
+        ws = torch.empty(ops.mine_workspace_bytes(top_k, G), dtype=torch.uint8, device="cuda")
+        ops.oicr_mine_label(sc, gt, boxes, K, top_k, 0.05, 0.01, 0.5, 0.6, lab_c, lab_w, lab_i, cnt, pi, pc, ps, ws)
+        n = int(cnt.item())
+        assert np.array_equal(pi[:n].cpu().numpy(), g[f"{variant}/pgt_index"])
+        assert np.array_equal(pc[:n].cpu().numpy(), g[f"{variant}/pgt_classes"])
+        assert np.array_equal(ps[:n].cpu().numpy(), g[f"{variant}/pgt_scores"])
+        assert np.array_equal(lab_c.cpu().numpy(), g[f"{variant}/gt_classes"])
+        assert np.array_equal(lab_i.cpu().numpy(), g[f"{variant}/gt_index"])
+        assert np.array_equal(lab_w.cpu().numpy(), g[f"{variant}/gt_weights"])
+
+
+def test_mining_ties_and_single_proposal(ops):
+    """ties -> ascending index (the oracle's documented rule); R=1 edge case"""
+    for R in (1, 70):
+        K = 20
+        sc = np.full((R, K), 0.25, np.float32)
+        views, _ = O.make_views(200, 200, R, tag=f"tie{R}")
+        gt = np.array([2, 5], np.int64)
+        o = O.get_pgt_mist(sc, views[0]["boxes"], gt); l = O.label_proposals(o, views[0]["boxes"], K)
+        top_k = max(int(R * 0.1), 1); G = 2
+        lab_c = torch.empty(R, dtype=torch.int32, device="cuda"); lab_w = torch.empty(R, device="cuda")
+        lab_i = torch.empty(R, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        pi = torch.empty(top_k * G, dtype=torch.int32, device="cuda"); pc = torch.empty_like(pi); ps = torch.empty(top_k * G, device="cuda")
+        ws = torch.empty(ops.mine_workspace_bytes(top_k, G), dtype=torch.uint8, device="cuda")
+        ops.oicr_mine_label(torch.from_numpy(sc).cuda(), torch.from_numpy(gt.astype(np.int32)).cuda(),
+                            torch.from_numpy(views[0]["boxes"]).cuda(), K, top_k, 0.05, 0.01, 0.5, 0.6, lab_c, lab_w, lab_i,
+                            cnt, pi, pc, ps, ws)
+        n = int(cnt.item())
+        assert np.array_equal(pi[:n].cpu().numpy(), o["index"]) and np.array_equal(lab_c.cpu().numpy(), l["gt_classes"])
+        assert np.array_equal(lab_i.cpu().numpy(), l["gt_index"])
+
+
+@pytest.mark.parametrize("R,K", [(500, 20), (300, 80)])
+def test_refine_loss_and_grad(ops, R, K):
+    V, LD = 4, 4 + (K + 1) + 4 * K + 7
+    LD = (LD + 7) // 8 * 8
+    cls_col, box_col = 4, 4 + K + 1
+    lg = _rand((V * R, LD), 50, scale=2.0)
+    views, _ = O.make_views(256, 320, R, tag="rl")
+    gen = torch.Generator().manual_seed(51)
+    lab_class = torch.randint(-1, K + 1, (R,), generator=gen)
+    lab_index = torch.randint(0, R, (R,), generator=gen)
+    lab_weight = torch.rand(R, generator=gen)
+    boxes = np.stack([v["boxes"] for v in views])
+    gs = torch.tensor([0.9, 1.3])
+    x = lg.clone().requires_grad_(True)
+    lc, lb, probs = [], [], []
+    for v in range(V):
+        pv = 2 if v == 3 else v
+        blk = x[pv * R:(pv + 1) * R]
+        a, b = O.oicr_losses(blk[:, cls_col:cls_col + K + 1], blk[:, box_col:box_col + 4 * K], boxes[v],
+                             boxes[v][lab_index.numpy()], lab_class.numpy(), lab_weight.numpy(), K)
+        lc.append(a); lb.append(b)
+        probs.append(F.softmax(x[v * R:(v + 1) * R, cls_col:cls_col + K + 1].detach(), -1))
+    (sum(lc) / V * gs[0] + sum(lb) / V * gs[1]).backward()
+    lv = torch.empty(2, V, device="cuda"); pr = torch.empty(V, R, K + 1, device="cuda")
+    dl = torch.full((V * R, LD), 7.0, device="cuda")
+    ops.oicr_refine_loss(lg.cuda(), V, R, K, cls_col, box_col, torch.from_numpy(boxes).cuda(),
+                         lab_class.to(torch.int32).cuda(), lab_weight.cuda(), lab_index.to(torch.int32).cuda(),
+                         torch.tensor([0, 1, 2, 2], dtype=torch.int32).cuda(), (10.0, 10.0, 5.0, 5.0), lv, pr, dl, gs.cuda())
+    np.testing.assert_allclose(lv[0].cpu().numpy(), torch.stack(lc).detach().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(lv[1].cpu().numpy(), torch.stack(lb).detach().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(pr.cpu().numpy(), torch.stack(probs).numpy(), rtol=2e-5, atol=1e-9)
+    ref = x.grad[:, cls_col:box_col + 4 * K]
+    got = dl.cpu()[:, cls_col:box_col + 4 * K]
+    assert (got - ref).abs().max() <= 2e-5 * ref.abs().max()
+    assert torch.all(dl.cpu()[:, :cls_col] == 7.0)             # other columns untouched
+
+
+# ------------------------------------------------------------------------------------------ utilities
+def test_preprocess_colsum_sgd_dropout(ops):
+    img = torch.randint(0, 256, (3, 37, 53), dtype=torch.uint8)
+    out = torch.empty(37, 53, 4, device="cuda")
+    ops.preprocess(img.cuda(), out, O.PIXEL_MEAN, O.PIXEL_STD)
+    ref = O.preprocess(img).permute(1, 2, 0)
+    assert torch.equal(out.cpu()[..., :3], ref) and torch.all(out.cpu()[..., 3] == 0)
+    X = _rand((1001, 130), 60)
+    cs = torch.empty(130, device="cuda")
+    ops.colsum(X.cuda(), 1001, 130, cs)
+    np.testing.assert_allclose(cs.cpu().numpy(), X.double().sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    p = _rand((5000,), 61); g = _rand((5000,), 62); buf = torch.zeros(5000)
+    opt_p = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([opt_p], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    pc, bc = p.cuda(), buf.cuda()
+    for step in range(3):
+        opt_p.grad = g.clone(); opt.step()
+        ops.sgd_momentum_step(pc, g.cuda(), bc, 0.01, 0.9, 5e-4, first_step=(step == 0))
+    np.testing.assert_allclose(pc.cpu().numpy(), opt_p.detach().numpy(), rtol=1e-5, atol=1e-7)
+    keep = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    ops.dropout_mask(keep, seed=1234, offset=0, p=0.5)
+    frac = keep.float().mean().item()
+    assert abs(frac - 0.5) < 5e-3
