@@ -47,6 +47,7 @@ def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_re
     ep.ref_dtype = SW_F32 if relu_ref is None else dt(relu_ref)
     ep.out_dtype = dt(out_dtype)
     ep.accumulate_atomic = int(atomic)
+    ep._keepalive = (bias, drop_mask, relu_ref)     # the struct holds raw pointers only
     return ep
 
 
