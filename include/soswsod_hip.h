@@ -143,6 +143,14 @@ int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, sw_st
 /* rows x cols copy/convert f32 -> dtype with independent leading dimensions (weight staging). */
 int sw_convert_2d(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
                   sw_stream_t stream);
+/* f32 NCHW -> dtype NHWC, channels zero padded to cpad (generic backbone entry, vgg.py:216-223 takes NCHW). */
+int sw_nchw_to_nhwc(int dtype, int N, int C, int H, int W, int cpad, const float* in_nchw, void* out_nhwc,
+                    sw_stream_t stream);
+/* ReLU backward in place: grad = ref > 0 ? grad : 0  (F.relu_ backward, vgg.py:105-116). */
+int sw_relu_bwd(int dtype, long n, const void* ref, void* grad, sw_stream_t stream);
+/* out[m][n] = in[m][n] * colscale[n] (f32 -> dtype): applies each loss term's cotangent to its logit columns. */
+int sw_scale_cols(int dtype, int M, int N, const float* in, long ld_in, const float* colscale, void* out,
+                  long ld_out, sw_stream_t stream);
 /* dst(f32) = src(dtype) */
 int sw_to_f32(int dtype, long n, const void* src, float* dst, sw_stream_t stream);
 int sw_fill_zero(void* p, long bytes, sw_stream_t stream);

@@ -56,6 +56,9 @@ SIGNATURES = {
                                     c_void_p]),
     "sw_colsum": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "sw_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_relu_bwd": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    "sw_scale_cols": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
     "sw_to_f32": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "sw_fill_zero": (c_int, [c_void_p, c_long, c_void_p]),
     "sw_dropout_mask": (c_int, [c_void_p, c_long, c_u64, c_u64, c_float, c_void_p]),

@@ -1,0 +1,226 @@
+"""VGG16 conv backbone on gfx950 behind the reference's interface
+(uwsod/projects/WSL/wsl/modeling/backbone/vgg.py: PlainBlock :20-122, VGG16 :125-231, build_vgg_backbone :234-245).
+
+Same module tree / state-dict names (`plain{1..5}.0.conv{1..3}.{weight,bias}`, OIHW f32 master weights), same
+freeze_at semantics, `forward(x) -> {"plain5": (N,512,h,w)}`.  Every conv is the implicit-GEMM MFMA kernel
+(sw_conv3x3_igemm) on NHWC bf16/f32 activations with bias+ReLU fused; backward is explicit
+(sw_conv3x3_wgrad, sw_conv3x3_igemm with flipped weights + fused ReLU mask, sw_maxpool2x2_bwd) inside ONE
+torch.autograd.Function, so autograd sees a single node.  The returned feature is an NCHW *view* of NHWC storage."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import BACKBONE_REGISTRY
+from .structures import ShapeSpec
+
+# (name, cin, cout, n_conv, pool_stride, dilation) for conv5_dilation == 2 is patched in VGG16.__init__
+_STAGES = [("plain1", 3, 64, 2), ("plain2", 64, 128, 2), ("plain3", 128, 256, 3), ("plain4", 256, 512, 3),
+           ("plain5", 512, 512, 3)]
+
+
+def _epc(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+class _Conv(nn.Module):
+    """parameter holder with nn.Conv2d's names/shapes (weight OIHW, bias)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # c2_msra_fill (vgg.py:56)
+
+
+class PlainBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, num_conv=3, dilation=1, stride=1, has_pool=False):
+        super().__init__()
+        assert num_conv < 5
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_conv, self.dilation, self.has_pool, self.pool_stride = num_conv, dilation, has_pool, stride
+        for i in range(num_conv):
+            self.add_module(f"conv{i + 1}", _Conv(in_channels if i == 0 else out_channels, out_channels))
+
+    def convs(self):
+        return [getattr(self, f"conv{i + 1}") for i in range(self.num_conv)]
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        return self
+
+
+class _VGGFunction(torch.autograd.Function):
+    """x: NHWC (N,H,W,cpad) compute-dtype tensor (no grad).  Returns plain5 NHWC."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        dtype = x.dtype
+        acts = []          # per conv: (input activation, output activation)
+        pools = []         # per stage: (pre-pool act, stride) or None
+        cur = x
+        pi = 0
+        stage_info = []
+        for blk in module.blocks:
+            conv_io = []
+            for ci in range(blk.num_conv):
+                w, b = params[pi], params[pi + 1]
+                pi += 2
+                cin = cur.shape[3]
+                wk = torch.empty(blk.out_channels, 9, cin, device=x.device, dtype=dtype)
+                ops.conv_weight_prep(w, wk, 0, cin)
+                out = torch.empty(cur.shape[0], cur.shape[1], cur.shape[2], blk.out_channels, device=x.device, dtype=dtype)
+                ops.conv3x3(cur, wk, out, blk.dilation, ops.make_epilogue(bias=b, relu=True, out_dtype=dtype))
+                conv_io.append((cur, out))
+                cur = out
+            pre_pool = None
+            if blk.has_pool:
+                pre_pool = cur
+                s = blk.pool_stride
+                oh, ow = (cur.shape[1] - 2) // s + 1, (cur.shape[2] - 2) // s + 1
+                pooled = torch.empty(cur.shape[0], oh, ow, cur.shape[3], device=x.device, dtype=dtype)
+                ops.maxpool_fwd(cur, pooled, s)
+                cur = pooled
+            stage_info.append((conv_io, pre_pool))
+        ctx.module = module
+        ctx.stage_info = stage_info
+        ctx.params = params
+        return cur
+
+    @staticmethod
+    def backward(ctx, g):
+        module, stage_info, params = ctx.module, ctx.stage_info, ctx.params
+        dtype = stage_info[0][0][0][0].dtype
+        grads = [None] * len(params)
+        g = g.contiguous()
+        if g.dtype != dtype:
+            g = g.to(dtype)
+        first_trainable = module.first_trainable_conv()      # (stage idx, conv idx) or None
+        if first_trainable is None:
+            return (None, None) + tuple(grads)
+        # dz of the last conv: ReLU backward of the output feature (idempotent if the producer already masked)
+        last_out = stage_info[-1][0][-1][1]
+        assert stage_info[-1][1] is None, "backward expects the last stage to have no pool (vgg.py:197)"
+        dz = ops.relu_bwd(last_out, g.clone())
+        pidx = len(params)
+        done = False
+        for si in range(len(stage_info) - 1, -1, -1):
+            blk = module.blocks[si]
+            conv_io, _ = stage_info[si]
+            for ci in range(blk.num_conv - 1, -1, -1):
+                pidx -= 2
+                x_in, _ = conv_io[ci]
+                w = params[pidx]
+                n, H, W, cin = x_in.shape
+                if w.requires_grad:
+                    dw = torch.zeros(blk.out_channels, cin, 3, 3, device=g.device, dtype=torch.float32)
+                    npix = n * H * W
+                    tiles = ((blk.out_channels + 127) // 128) * ((9 * cin + 127) // 128)
+                    splitk = max(1, min(32, (512 + tiles - 1) // tiles, npix // 2048 if npix >= 4096 else 1))
+                    ops.conv3x3_wgrad(x_in, dz, dw, blk.dilation, splitk=splitk)
+                    grads[pidx] = dw[:, : w.shape[1]].contiguous() if cin != w.shape[1] else dw
+                    db = torch.empty(blk.out_channels, device=g.device, dtype=torch.float32)
+                    ops.colsum(dz.view(npix, blk.out_channels), npix, blk.out_channels, db)
+                    grads[pidx + 1] = db
+                if (si, ci) == first_trainable:
+                    done = True
+                    break
+                # data gradient: conv with flipped/transposed weights; ReLU mask of the producer fused when the
+                # input is a direct conv output (ci > 0); stage inputs go through the pool backward instead
+                wkd = torch.empty(cin, 9, blk.out_channels, device=g.device, dtype=dtype)
+                ops.conv_weight_prep(w, wkd, 1)
+                dx = torch.empty(n, H, W, cin, device=g.device, dtype=dtype)
+                ref = x_in.view(n * H * W, cin) if ci > 0 else None
+                ops.conv3x3(dz, wkd, dx, blk.dilation, ops.make_epilogue(relu_ref=ref, out_dtype=dtype))
+                dz = dx
+            if done:
+                break
+            # dz is now the gradient wrt this stage's input = previous stage's pooled output
+            prev_pre_pool = stage_info[si - 1][1]
+            pblk = module.blocks[si - 1]
+            din = torch.empty_like(prev_pre_pool)
+            ops.maxpool_bwd(prev_pre_pool, dz, din, pblk.pool_stride, relu_mask=True)
+            dz = din
+        return (None, None) + tuple(grads)
+
+
+class VGG16(nn.Module):
+    """vgg.py:125-231.  `compute_dtype`: torch.bfloat16 (MFMA bf16) or torch.float32 (exact f32 MFMA)."""
+
+    def __init__(self, conv5_dilation, freeze_at, num_classes=None, out_features=None, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.num_classes = num_classes
+        self.compute_dtype = compute_dtype
+        self._out_feature_strides, self._out_feature_channels = {}, {}
+        self.stages_and_names = []
+        strides = {"plain1": 2, "plain2": 4, "plain3": 8, "plain4": 8 if conv5_dilation == 2 else 16,
+                   "plain5": 8 if conv5_dilation == 2 else 16}
+        self.blocks = []
+        for i, (name, cin, cout, nconv) in enumerate(_STAGES):
+            if name == "plain4":
+                blk = PlainBlock(cin, cout, num_conv=nconv, stride=1 if conv5_dilation == 2 else 2, has_pool=True)
+            elif name == "plain5":
+                blk = PlainBlock(cin, cout, num_conv=nconv, stride=1, dilation=conv5_dilation, has_pool=False)
+            else:
+                blk = PlainBlock(cin, cout, num_conv=nconv, stride=2, has_pool=True)
+            stage = nn.Sequential(blk)               # keeps the reference's "plainK.0.convJ" names
+            self.add_module(name, stage)
+            self.stages_and_names.append((stage, name))
+            self.blocks.append(blk)
+            self._out_feature_strides[name] = strides[name]
+            self._out_feature_channels[name] = cout
+            if freeze_at >= i + 1:
+                blk.freeze()
+        if out_features is None:
+            out_features = ["plain5"]
+        self._out_features = out_features
+        assert self._out_features == ["plain5"], "this build exposes the hot path's feature only (IN_FEATURES ['plain5'])"
+
+    @property
+    def size_divisibility(self):
+        return 0
+
+    def first_trainable_conv(self):
+        for si, blk in enumerate(self.blocks):
+            for ci, c in enumerate(blk.convs()):
+                if c.weight.requires_grad:
+                    return (si, ci)
+        return None
+
+    def _flat_params(self):
+        out = []
+        for blk in self.blocks:
+            for c in blk.convs():
+                out += [c.weight, c.bias]
+        return out
+
+    def forward_nhwc(self, x_nhwc):
+        """x_nhwc: (N,H,W,cpad) compute-dtype, channels >= 3 zero.  Returns NHWC plain5."""
+        return _VGGFunction.apply(self, x_nhwc, *self._flat_params())
+
+    def forward(self, x):
+        """x: (N,3,H,W) float32 normalised image batch (reference call shape) -> {"plain5": (N,512,h,w) view}"""
+        assert x.dim() == 4 and x.shape[1] == 3
+        n, _, H, W = x.shape
+        xin = torch.empty(n, H, W, _epc(self.compute_dtype), device=x.device, dtype=self.compute_dtype)
+        ops.nchw_to_nhwc(x.contiguous().float(), xin)
+        f = self.forward_nhwc(xin)
+        return {"plain5": f.permute(0, 3, 1, 2)}
+
+    def output_shape(self):
+        return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
+                for name in self._out_features}
+
+
+def _dtype_from_cfg(cfg):
+    s = str(cfg.MODEL.get("AMD", {}).get("COMPUTE_DTYPE", "bf16")).lower()
+    return torch.float32 if s in ("fp32", "f32", "float32") else torch.bfloat16
+
+
+@BACKBONE_REGISTRY.register()
+def build_vgg_backbone(cfg, input_shape=None):
+    depth = cfg.MODEL.VGG.DEPTH
+    if depth != 16:
+        raise NotImplementedError("only VGG16 is on the OICR+ hot path (voc07_oicr_plus.yaml:7-12)")
+    return VGG16(cfg.MODEL.VGG.CONV5_DILATION, cfg.MODEL.BACKBONE.FREEZE_AT, out_features=cfg.MODEL.VGG.OUT_FEATURES,
+                 compute_dtype=_dtype_from_cfg(cfg))

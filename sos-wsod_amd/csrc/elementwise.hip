@@ -159,6 +159,36 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
   }
 }
 
+// f32 NCHW -> dtype NHWC with channel padding (generic backbone entry; the fused path is sw_preprocess)
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(int N, int C, int H, int W, int cpad, const float* __restrict__ in, T* __restrict__ out) {
+  const long total = (long)N * H * W * cpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad); long t = i / cpad;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H); const int n = (int)(t / H);
+    Elem<T>::store(out + i, c < C ? in[(((long)n * C + c) * H + y) * W + x] : 0.f);
+  }
+}
+
+// ReLU backward: g = ref > 0 ? g : 0 (in place)
+template <typename T>
+__global__ void relu_bwd_kernel(long n, const T* __restrict__ ref, T* __restrict__ g) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    if (!(Elem<T>::load(ref + i) > 0.f)) Elem<T>::store(g + i, 0.f);
+}
+
+// out[m][n] = in[m][n] * colscale[n]  (f32 -> dtype): applies the per-loss cotangents to the unit logit gradients
+template <typename T>
+__global__ void scale_cols_kernel(int M, int N, const float* __restrict__ in, long ld_in, const float* __restrict__ cs,
+                                  T* __restrict__ out, long ld_out) {
+  const long total = (long)M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / N; const int n = (int)(i - m * N);
+    Elem<T>::store(out + m * ld_out + n, in[m * ld_in + n] * cs[n]);
+  }
+}
+
 __global__ void mean_views_kernel(int V, long n, const float* __restrict__ in, float* __restrict__ out) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = in[i];
@@ -254,6 +284,37 @@ extern "C" int sw_to_f32(int dtype, long n, const void* src, float* dst, hipStre
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(to_f32_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const unsigned short*)src, dst),
     hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const float*)src, dst));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_nchw_to_nhwc(int dtype, int N, int C, int H, int W, int cpad, const float* in, void* out,
+                               hipStream_t stream) {
+  const long n = (long)N * H * W * cpad;
+  if (n <= 0) return 0;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, N, C, H, W, cpad, in, (unsigned short*)out),
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, N, C, H, W, cpad, in, (float*)out));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_relu_bwd(int dtype, long n, const void* ref, void* grad, hipStream_t stream) {
+  if (n <= 0) return 0;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(relu_bwd_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const unsigned short*)ref, (unsigned short*)grad),
+    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const float*)ref, (float*)grad));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_scale_cols(int dtype, int M, int N, const float* in, long ld_in, const float* colscale, void* out,
+                             long ld_out, hipStream_t stream) {
+  const long n = (long)M * N;
+  if (n <= 0) return 0;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(scale_cols_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, M, N, in, ld_in, colscale, (unsigned short*)out, ld_out),
+    hipLaunchKernelGGL(scale_cols_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, M, N, in, ld_in, colscale, (float*)out, ld_out));
   SW_CHECK_LAUNCH();
   return 0;
 }

@@ -205,3 +205,21 @@ def loss_finalize(loss_view, out):
     n, V = loss_view.shape
     check(lib.sw_loss_finalize(n, V, _p(loss_view), _p(out), _stream()), "sw_loss_finalize")
     return out
+
+
+def nchw_to_nhwc(x_nchw_f32, out_nhwc):
+    N, C, H, W = x_nchw_f32.shape
+    check(lib.sw_nchw_to_nhwc(dt(out_nhwc), N, C, H, W, out_nhwc.shape[3], _p(x_nchw_f32), _p(out_nhwc), _stream()),
+          "sw_nchw_to_nhwc")
+    return out_nhwc
+
+
+def relu_bwd(ref, grad):
+    check(lib.sw_relu_bwd(dt(grad), grad.numel(), _p(ref), _p(grad), _stream()), "sw_relu_bwd")
+    return grad
+
+
+def scale_cols(src_f32, colscale, dst, M, N):
+    check(lib.sw_scale_cols(dt(dst), M, N, _p(src_f32), src_f32.stride(0), _p(colscale), _p(dst), dst.stride(0), _stream()),
+          "sw_scale_cols")
+    return dst

@@ -1,0 +1,368 @@
+"""OICR+ ROI heads on gfx950 behind the reference's interface
+(uwsod/projects/WSL/wsl/modeling/roi_heads/roi_heads_oicrplus.py:37-757 `OICRPlusHeads`,
+helpers from roi_heads.py:144-164,225-375).
+
+Same constructor keys / child-module names (`box_pooler`, `box_head`, `box_predictor`, `box_refinery_{k}`), same
+call: `roi_heads(images_list, features_list, proposals_list, targets_list) -> (None, losses)` in training.
+
+What differs is the execution plan (MI355X-first, not a translation):
+  * the 4 views are stacked to one (4R)-row problem, so fc6/fc7 and the 10 predictor matrices run as 3 MFMA
+    GEMMs (the predictor matrices are packed into one (22K+4) x 4096 operand);
+  * ROIPool writes the fc6 input directly ((R,C,7,7) order, objectness prior fused);
+  * MIL scoring, pseudo-GT mining (top-p%, threshold, NMS), IoU labelling and the refinement losses are one
+    kernel each, entirely device side: no .item()/nonzero host syncs inside the iteration;
+  * forward and backward are ONE autograd node with an explicit backward (no autograd tape over ~200 ops);
+    the loss kernels emit unit logit-gradients in the forward sweep, the backward only scales them by the
+    incoming cotangents.
+Reference quirks kept on purpose: losses_k2_flip pairs predictions_k2 with the flipped targets
+(#1), pseudo-GT weights = scores (#2), class-agnostic NMS at 0.01 (#3), int() truncation of R*0.1 and rank-0
+always kept (#4), CE mean over all R / box loss / R, L1 (#5), targets are proposals[gt_index] (#6)."""
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .box_head import DiscriminativeAdaptionNeck
+from .events import get_event_storage, has_event_storage
+from .fast_rcnn_oicr import OICROutputLayers
+from .fast_rcnn_wsddn import WSDDNOutputLayers
+from .poolers import ROIPooler
+from .registry import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
+from .structures import Boxes, Instances, ShapeSpec
+
+LOSS_NAMES_FMT = ["loss_cls"]
+
+
+def get_image_level_gt(targets, num_classes):
+    """roi_heads.py:144-164 — host side (a handful of ints; done before anything is queued on the GPU)."""
+    if targets is None:
+        return None, None, None
+    cls, ints, ohs = [], [], []
+    for t in targets:
+        g = t.gt_classes
+        u = np.unique(g.detach().cpu().numpy().astype(np.int64))
+        oh = np.zeros((1, num_classes), np.float32)
+        oh[0, u] = 1.0
+        cls.append(torch.from_numpy(u)); ints.append(torch.from_numpy(u)); ohs.append(torch.from_numpy(oh))
+    return cls, ints, torch.cat(ohs, dim=0)
+
+
+def loss_names(refine_K):
+    names = ["loss_cls"]
+    for k in range(refine_K):
+        names += [f"loss_cls_r{k}", f"loss_box_reg_r{k}"]
+    return names
+
+
+class _HeadsTrainFunction(torch.autograd.Function):
+    """(feat1, feat2, *head params) -> vector of 1 + 2*refine_K losses."""
+
+    @staticmethod
+    def forward(ctx, heads, inp, feat1, feat2, *params):
+        st = heads._train_forward(inp, feat1, feat2, params)
+        ctx.heads, ctx.st, ctx.params = heads, st, params
+        ctx.feat_req = (ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        return st["losses"]
+
+    @staticmethod
+    def backward(ctx, g_losses):
+        dfeats, dparams = ctx.heads._train_backward(ctx.st, ctx.params, g_losses.contiguous().float(), ctx.feat_req)
+        ctx.st = None
+        return (None, None, dfeats[0], dfeats[1]) + tuple(dparams)
+
+
+@ROI_HEADS_REGISTRY.register()
+class OICRPlusHeads(nn.Module):
+    def __init__(self, *, box_in_features: List[str], box_pooler: ROIPooler, box_head: nn.Module,
+                 box_predictor: nn.Module, refine_K: int = 4, refine_mist: bool = True, mist_p: float = 0.10,
+                 mist_thre: float = 0.05, mist_type: str = "nms", refine_reg=None, box_refinery=None,
+                 cls_agnostic_bbox_reg: bool = False, pooler_type: str = "ROIPool", cfg=None, num_classes: int = 20,
+                 iou_thresholds=(0.5, 0.6), iou_labels=(0, -1, 1), bbox_reg_weights=(10.0, 10.0, 5.0, 5.0),
+                 test_score_thresh=1e-6, test_nms_thresh=0.3, test_topk_per_image=100,
+                 compute_dtype=torch.bfloat16, **unused):
+        super().__init__()
+        assert refine_mist and mist_type == "nms", "WSL.REFINE_MIST True / MIST_TYPE nms is the configured path"
+        assert list(iou_labels) == [0, -1, 1] and len(iou_thresholds) == 2
+        assert pooler_type == "ROIPool" and not cls_agnostic_bbox_reg
+        self.box_in_features = box_in_features
+        self.in_features = box_in_features
+        self.box_pooler = box_pooler
+        self.box_head = box_head
+        self.box_predictor = box_predictor
+        self.refine_K = refine_K
+        self.mist_p, self.mist_thre = mist_p, mist_thre
+        self.refine_reg = refine_reg if refine_reg is not None else [True] * refine_K
+        self.box_refinery = []
+        for k in range(refine_K):
+            self.add_module("box_refinery_{}".format(k), box_refinery[k])     # roi_heads_oicrplus.py:76-79
+            self.box_refinery.append(box_refinery[k])
+        self.num_classes = num_classes
+        self.iou_thresholds = tuple(float(t) for t in iou_thresholds)
+        self.bbox_reg_weights = tuple(float(w) for w in bbox_reg_weights)
+        self.test_score_thresh, self.test_nms_thresh, self.test_topk_per_image = test_score_thresh, test_nms_thresh, test_topk_per_image
+        self.compute_dtype = compute_dtype
+        self.cfg = cfg
+        self.iter = 0
+        self.dropout_seed = 0x5051
+        self._drop_counter = 0
+        self.debug_drop_masks = None      # tests: [[m1, m2] per view] uint8 keep masks (A.2 #9)
+        self.last_aux = None              # tests / metrics: device tensors of the last iteration
+        K = num_classes
+        self.n_head_cols = 2 * K + refine_K * (5 * K + 1)
+        self.ld_head = (self.n_head_cols + 7) // 8 * 8
+
+    # ------------------------------------------------------------------ construction from cfg
+    @classmethod
+    def from_config(cls, cfg, input_shape: Dict[str, ShapeSpec]):
+        from .backbone_vgg import _dtype_from_cfg
+        dtype = _dtype_from_cfg(cfg)
+        in_features = cfg.MODEL.ROI_HEADS.IN_FEATURES
+        res = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        scales = tuple(1.0 / input_shape[k].stride for k in in_features)
+        ch = input_shape[in_features[0]].channels
+        pooler = ROIPooler(output_size=res, scales=scales, sampling_ratio=cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO,
+                           pooler_type=cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE)
+        head_cls = ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)
+        box_head = head_cls(**head_cls.from_config(cfg, ShapeSpec(channels=ch, height=res, width=res)))
+        predictor = WSDDNOutputLayers(**WSDDNOutputLayers.from_config(cfg, box_head.output_shape))
+        refinery = [OICROutputLayers(**OICROutputLayers.from_config(cfg, box_head.output_shape, k))
+                    for k in range(cfg.WSL.REFINE_NUM)]
+        return dict(box_in_features=in_features, box_pooler=pooler, box_head=box_head, box_predictor=predictor,
+                    refine_K=cfg.WSL.REFINE_NUM, refine_mist=cfg.WSL.REFINE_MIST, mist_p=cfg.WSL.MIST_P,
+                    mist_thre=cfg.WSL.MIST_THRE, mist_type=cfg.WSL.MIST_TYPE, refine_reg=cfg.WSL.REFINE_REG,
+                    box_refinery=refinery, cls_agnostic_bbox_reg=cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG,
+                    pooler_type=cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE, cfg=cfg, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES,
+                    iou_thresholds=cfg.MODEL.ROI_HEADS.IOU_THRESHOLDS, iou_labels=cfg.MODEL.ROI_HEADS.IOU_LABELS,
+                    bbox_reg_weights=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS,
+                    test_score_thresh=cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+                    test_nms_thresh=cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST,
+                    test_topk_per_image=cfg.TEST.DETECTIONS_PER_IMAGE, compute_dtype=dtype)
+
+    # ------------------------------------------------------------------ parameter packing
+    def _flat_params(self):
+        ps = [self.box_head.fc1.weight, self.box_head.fc1.bias, self.box_head.fc2.weight, self.box_head.fc2.bias,
+              self.box_predictor.cls.weight, self.box_predictor.cls.bias, self.box_predictor.det.weight,
+              self.box_predictor.det.bias]
+        for r in self.box_refinery:
+            ps += [r.cls_score.weight, r.cls_score.bias, r.bbox_pred.weight, r.bbox_pred.bias]
+        return ps
+
+    def _col_layout(self):
+        """column ranges of the packed predictor matrix: [cls K | det K | k x (cls_score K+1 | bbox_pred 4K)]"""
+        K = self.num_classes
+        cols = {"cls": 0, "det": K}
+        for k in range(self.refine_K):
+            base = 2 * K + k * (5 * K + 1)
+            cols[f"cls_score{k}"] = base
+            cols[f"bbox_pred{k}"] = base + K + 1
+        return cols
+
+    def _pack_head_weights(self, params, device):
+        """10 (out, 4096) f32 masters -> one (ld_head, 4096) compute-dtype operand + f32 bias vector."""
+        D = params[4].shape[1]
+        Wh = torch.zeros(self.ld_head, D, device=device, dtype=self.compute_dtype)
+        bh = torch.zeros(self.ld_head, device=device, dtype=torch.float32)
+        row = 0
+        for i in range(4, len(params), 2):
+            w, b = params[i], params[i + 1]
+            n = w.shape[0]
+            ops.convert_2d(w, Wh[row:row + n], n, D)
+            bh[row:row + n].copy_(b.detach())
+            row += n
+        assert row == self.n_head_cols
+        return Wh, bh
+
+    # ------------------------------------------------------------------ training forward (explicit)
+    def _train_forward(self, inp, feat1, feat2, params):
+        dt_, dev = self.compute_dtype, feat1.device
+        K, V, RK = self.num_classes, 4, self.refine_K
+        R = inp["R"]
+        boxes = inp["boxes"]                      # (4, R, 4) f32
+        obj = inp["obj"]                          # (4, R) f32
+        feats = [feat1.permute(0, 2, 3, 1).contiguous(), feat2.permute(0, 2, 3, 1).contiguous()]  # NHWC (no copy if already)
+        feats = [f if f.dtype == dt_ else f.to(dt_) for f in feats]
+        C = feats[0].shape[3]
+        P = self.box_pooler.output_size
+        D0 = C * P * P
+        # --- ROIPool (+ objectness prior fused) straight into the stacked fc6 operand
+        pooled = torch.empty(V * R, D0, device=dev, dtype=dt_)
+        argmax = torch.empty(V * R, D0, device=dev, dtype=torch.int32)
+        rois = inp["rois"]                        # [2] x (2R, 5): batch index 0 = view, 1 = flipped view
+        for s in range(2):
+            ops.roi_pool_fwd(feats[s], rois[s], pooled[2 * s * R:(2 * s + 2) * R], argmax[2 * s * R:(2 * s + 2) * R],
+                             self.box_pooler.scale, P, P, row_scale=obj[2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0)
+        # --- fc6 / fc7 with bias + ReLU + dropout fused (box_head.py:82-91)
+        fc1w, fc1b, fc2w, fc2b = params[0], params[1], params[2], params[3]
+        D1, D2 = fc1w.shape[0], fc2w.shape[0]
+        training_dropout = self.training
+        masks = [None, None]
+        if training_dropout:
+            if self.debug_drop_masks is not None:
+                masks = [torch.cat([self.debug_drop_masks[v][l].to(dev) for v in range(V)], 0).contiguous() for l in range(2)]
+            else:
+                for l, d in enumerate((D1, D2)):
+                    m = torch.empty(V * R, d, device=dev, dtype=torch.uint8)
+                    ops.dropout_mask(m, self.dropout_seed, self._drop_counter, 0.5)
+                    self._drop_counter += m.numel()
+                    masks[l] = m
+        W1 = torch.empty(D1, D0, device=dev, dtype=dt_); ops.convert_2d(fc1w, W1, D1, D0)
+        W2 = torch.empty(D2, D1, device=dev, dtype=dt_); ops.convert_2d(fc2w, W2, D2, D1)
+        h1 = torch.empty(V * R, D1, device=dev, dtype=dt_)
+        ops.gemm(pooled, W1, h1, V * R, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], out_dtype=dt_))
+        h2 = torch.empty(V * R, D2, device=dev, dtype=dt_)
+        ops.gemm(h1, W2, h2, V * R, D2, D1, ep=ops.make_epilogue(bias=fc2b, relu=True, drop_mask=masks[1], out_dtype=dt_))
+        # --- all 10 predictor matrices as one GEMM, f32 logits
+        Wh, bh = self._pack_head_weights(params, dev)
+        LD = self.ld_head
+        logits = torch.empty(V * R, LD, device=dev, dtype=torch.float32)
+        ops.gemm(h2, Wh, logits, V * R, LD, D2, ep=ops.make_epilogue(bias=bh, out_dtype=torch.float32))
+        cols = self._col_layout()
+        # --- WSDDN MIL scores + loss (+ unit gradient), view average
+        n_loss = 1 + 2 * RK
+        loss_view = torch.zeros(n_loss, V, device=dev, dtype=torch.float32)
+        dlogits = torch.zeros(V * R, LD, device=dev, dtype=torch.float32) if inp["need_grad"] else None
+        ones = inp["ones"]
+        scores = torch.empty(V, R, K, device=dev, dtype=torch.float32)
+        ops.wsddn_mil(logits, V, R, K, cols["cls"], cols["det"], inp["gt_onehot"], scores, loss_view[0], dlogits, ones)
+        prev = torch.empty(R, K, device=dev, dtype=torch.float32)
+        ops.mean_views(scores, prev)
+        # --- K refinement rounds: mine pseudo-GT on the averaged scores, label, losses, next scores
+        top_k = max(int(R * self.mist_p), 1)                      # roi_heads_oicrplus.py:659-660
+        G = inp["G"]
+        ws = torch.empty(ops.mine_workspace_bytes(top_k, G), device=dev, dtype=torch.uint8)
+        aux = {"scores": scores, "rounds": []}
+        probs = torch.empty(V, R, K + 1, device=dev, dtype=torch.float32)
+        for k in range(RK):
+            lab_c = torch.empty(R, device=dev, dtype=torch.int32); lab_w = torch.empty(R, device=dev, dtype=torch.float32)
+            lab_i = torch.empty(R, device=dev, dtype=torch.int32); cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+            pi = torch.empty(top_k * G, device=dev, dtype=torch.int32); pc = torch.empty_like(pi)
+            ps = torch.empty(top_k * G, device=dev, dtype=torch.float32)
+            ops.oicr_mine_label(prev, inp["gt_int32"], boxes[0], K, top_k, self.mist_thre, 0.01,
+                                self.iou_thresholds[0], self.iou_thresholds[1], lab_c, lab_w, lab_i, cnt, pi, pc, ps, ws)
+            lv = loss_view[1 + 2 * k:3 + 2 * k]
+            ops.oicr_refine_loss(logits, V, R, K, cols[f"cls_score{k}"], cols[f"bbox_pred{k}"], boxes, lab_c, lab_w, lab_i,
+                                 inp["pred_view"], self.bbox_reg_weights, lv, probs, dlogits, ones)
+            prev = torch.empty(R, K + 1, device=dev, dtype=torch.float32)
+            ops.mean_views(probs, prev)
+            aux["rounds"].append(dict(lab_class=lab_c, lab_weight=lab_w, lab_index=lab_i, pgt_count=cnt, pgt_index=pi,
+                                      pgt_class=pc, pgt_score=ps))
+        losses = torch.empty(n_loss, device=dev, dtype=torch.float32)
+        ops.loss_finalize(loss_view, losses)
+        self.last_aux = aux
+        aux["fc7"] = h2
+        aux["logits"] = logits
+        return dict(losses=losses, feats=feats, rois=rois, obj=obj, pooled=pooled, argmax=argmax, h1=h1, h2=h2, W1=W1, W2=W2,
+                    Wh=Wh, dlogits=dlogits, R=R, train_dropout=training_dropout)
+
+    def _col_to_loss(self, device):
+        """loss index of every packed logit column (each column belongs to exactly one loss term)."""
+        K = self.num_classes
+        idx = torch.zeros(self.ld_head, dtype=torch.int64)
+        idx[: 2 * K] = 0
+        for k in range(self.refine_K):
+            base = 2 * K + k * (5 * K + 1)
+            idx[base: base + K + 1] = 1 + 2 * k
+            idx[base + K + 1: base + 5 * K + 1] = 2 + 2 * k
+        return idx.to(device)
+
+    # ------------------------------------------------------------------ training backward (explicit)
+    def _train_backward(self, st, params, g_losses, feat_req):
+        dt_ = self.compute_dtype
+        dev = g_losses.device
+        V, R = 4, st["R"]
+        M = V * R
+        LD = self.ld_head
+        pooled, h1, h2, W1, W2, Wh = st["pooled"], st["h1"], st["h2"], st["W1"], st["W2"], st["Wh"]
+        D0, D1, D2 = pooled.shape[1], h1.shape[1], h2.shape[1]
+        # cotangent of each loss -> its logit columns; unit gradients -> compute dtype
+        if not hasattr(self, "_c2l") or self._c2l.device != dev:
+            self._c2l = self._col_to_loss(dev)
+        colscale = g_losses[self._c2l].contiguous()
+        dl = torch.empty(M, LD, device=dev, dtype=dt_)
+        ops.scale_cols(st["dlogits"], colscale, dl, M, LD)
+        rs = 2.0 if st["train_dropout"] else 1.0
+        # predictor matrices
+        dbh = torch.empty(LD, device=dev, dtype=torch.float32); ops.colsum(dl, M, LD, dbh)
+        dWh = torch.zeros(LD, D2, device=dev, dtype=torch.float32)
+        ops.gemm(dl, h2, dWh, LD, D2, M, a_kstrided=True, b_kstrided=True, ep=ops.make_epilogue(atomic=True), splitk=4)
+        dz2 = torch.empty(M, D2, device=dev, dtype=dt_)
+        ops.gemm(dl, Wh, dz2, M, D2, LD, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h2, ref_scale=rs, out_dtype=dt_))
+        # fc7
+        db2 = torch.empty(D2, device=dev, dtype=torch.float32); ops.colsum(dz2, M, D2, db2)
+        dW2 = torch.empty(D2, D1, device=dev, dtype=torch.float32)
+        ops.gemm(dz2, h1, dW2, D2, D1, M, a_kstrided=True, b_kstrided=True)
+        dz1 = torch.empty(M, D1, device=dev, dtype=dt_)
+        ops.gemm(dz2, W2, dz1, M, D1, D2, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h1, ref_scale=rs, out_dtype=dt_))
+        # fc6
+        db1 = torch.empty(D1, device=dev, dtype=torch.float32); ops.colsum(dz1, M, D1, db1)
+        dW1 = torch.empty(D1, D0, device=dev, dtype=torch.float32)
+        ops.gemm(dz1, pooled, dW1, D1, D0, M, a_kstrided=True, b_kstrided=True)
+        dfeats = [None, None]
+        if feat_req[0] or feat_req[1]:
+            dpooled = torch.empty(M, D0, device=dev, dtype=dt_)
+            ops.gemm(dz1, W1, dpooled, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt_))
+            P = self.box_pooler.output_size
+            for s in range(2):
+                if not feat_req[s]:
+                    continue
+                f = st["feats"][s]
+                df = torch.empty_like(f)
+                ops.roi_pool_bwd(dpooled[2 * s * R:(2 * s + 2) * R], st["argmax"][2 * s * R:(2 * s + 2) * R], st["rois"][s], df,
+                                 P, P, row_scale=st["obj"][2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0, relu_ref=f)
+                dfeats[s] = df.permute(0, 3, 1, 2)          # NCHW view, like the forward feature
+        # split the packed gradients back onto the 10 predictor tensors (row slices are contiguous views)
+        dparams = [dW1, db1, dW2, db2]
+        row = 0
+        for i in range(4, len(params), 2):
+            n = params[i].shape[0]
+            dparams += [dWh[row:row + n], dbh[row:row + n]]
+            row += n
+        dparams = [g if p.requires_grad else None for g, p in zip(dparams, params)]
+        return dfeats, dparams
+
+    # ------------------------------------------------------------------ public forward
+    def _prepare_inputs(self, proposals_list, targets1, device, need_grad):
+        K = self.num_classes
+        assert all(len(p) == 1 for p in proposals_list), "the batchsize should be 1"     # roi_heads_oicrplus.py:193
+        props = [p[0] for p in proposals_list]
+        R = len(props[0])
+        assert all(len(p) == R for p in props), "the 4 proposal sets are index aligned (dataset_mapper.py:353-361)"
+        _, gt_ints, gt_oh = get_image_level_gt(targets1, K)
+        gt_int = gt_ints[0]
+        boxes = torch.stack([p.proposal_boxes.tensor.to(device=device, dtype=torch.float32) for p in props], 0).contiguous()
+        obj = torch.stack([p.objectness_logits.to(device=device, dtype=torch.float32) for p in props], 0).contiguous()
+        idx = torch.cat([torch.zeros(R, 1, device=device), torch.ones(R, 1, device=device)], 0)
+        rois = [torch.cat([idx, boxes[2 * s:2 * s + 2].reshape(2 * R, 4)], 1).contiguous() for s in range(2)]
+        if not hasattr(self, "_consts") or self._consts[0].device != device:
+            self._consts = (torch.ones(2, device=device), torch.tensor([0, 1, 2, 2], dtype=torch.int32, device=device))
+        return dict(R=R, G=int(gt_int.numel()), boxes=boxes, obj=obj, rois=rois,
+                    gt_int32=gt_int.to(torch.int32).to(device), gt_onehot=gt_oh.view(-1).to(device),
+                    ones=self._consts[0], pred_view=self._consts[1], need_grad=need_grad)
+
+    def forward(self, images_list, features_list, proposals_list, targets_list=(None, None, None, None)):
+        if not self.training:
+            pred_instances, all_scores, all_boxes = self._forward_box_test(features_list, proposals_list, targets_list)
+            return pred_instances, {}, all_scores, all_boxes
+        features1, features2 = features_list
+        f1 = features1[self.box_in_features[0]]
+        f2 = features2[self.box_in_features[0]]
+        targets1 = targets_list[0]
+        inp = self._prepare_inputs(proposals_list, targets1, f1.device, need_grad=torch.is_grad_enabled())
+        self.gt_classes_img_int = [inp["gt_int32"].to(torch.int64)]
+        vec = _HeadsTrainFunction.apply(self, inp, f1, f2, *self._flat_params())
+        names = loss_names(self.refine_K)
+        losses = {n: vec[i] for i, n in enumerate(names)}
+        self.iter = self.iter + 1
+        if has_event_storage():
+            st = get_event_storage()
+            for k, r in enumerate(self.last_aux["rounds"]):
+                st.put_scalar(f"roi_head/num_pgt_r{k}", r["pgt_count"])      # device scalars: no host sync here
+        return None, losses
+
+    # ------------------------------------------------------------------ inference (roi_heads_oicrplus.py:432-475)
+    @torch.no_grad()
+    def _forward_box_test(self, features, proposals, targets_list=None):
+        from .inference import oicr_inference
+        return oicr_inference(self, features, proposals)

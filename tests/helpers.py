@@ -1,0 +1,55 @@
+"""Shared test plumbing: build the product model with explicit kwargs (as the golden script builds the
+reference one), load closed-form parameters, wrap oracle-style views into the reference's input dict."""
+import numpy as np
+import torch
+
+from oracle import oicr_oracle as O
+
+
+def build_model(K=20, dan_dim=(4096, 4096), dtype=torch.float32, device="cuda", freeze_at=2):
+    import sos_wsod_amd  # noqa: F401
+    from sos_wsod_amd.backbone_vgg import VGG16
+    from sos_wsod_amd.box_head import DiscriminativeAdaptionNeck
+    from sos_wsod_amd.fast_rcnn_oicr import OICROutputLayers
+    from sos_wsod_amd.fast_rcnn_wsddn import WSDDNOutputLayers
+    from sos_wsod_amd.poolers import ROIPooler
+    from sos_wsod_amd.rcnn_multi import MultiInputRCNN
+    from sos_wsod_amd.roi_heads_oicrplus import OICRPlusHeads
+    from sos_wsod_amd.structures import ShapeSpec
+    backbone = VGG16(conv5_dilation=2, freeze_at=freeze_at, out_features=["plain5"], compute_dtype=dtype)
+    shape = backbone.output_shape()
+    pooler = ROIPooler(output_size=7, scales=(1.0 / shape["plain5"].stride,), sampling_ratio=0, pooler_type="ROIPool")
+    head = DiscriminativeAdaptionNeck(ShapeSpec(channels=512, height=7, width=7), conv_dims=[], fc_dims=list(dan_dim),
+                                      compute_dtype=dtype)
+    pred = WSDDNOutputLayers(head.output_shape, num_classes=K)
+    refs = [OICROutputLayers(head.output_shape, num_classes=K, refine_k=k, refine_reg=[True] * 4) for k in range(4)]
+    heads = OICRPlusHeads(box_in_features=["plain5"], box_pooler=pooler, box_head=head, box_predictor=pred, refine_K=4,
+                          refine_mist=True, mist_p=0.10, mist_thre=0.05, mist_type="nms", refine_reg=[True] * 4,
+                          box_refinery=refs, num_classes=K, compute_dtype=dtype)
+    model = MultiInputRCNN(backbone=backbone, roi_heads=heads, pixel_mean=list(O.PIXEL_MEAN), pixel_std=list(O.PIXEL_STD))
+    return model.to(device)
+
+
+def load_params(model, P):
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in P.items():
+            assert tuple(sd[k].shape) == tuple(v.shape), (k, tuple(sd[k].shape), v.shape)
+            sd[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
+
+
+def to_batched_inputs(views, gt):
+    from sos_wsod_amd.structures import Boxes, Instances
+    d = {}
+    for name, v in zip(["1", "1_flip", "2", "2_flip"], views):
+        h, w = v["image"].shape[1:]
+        p = Instances((h, w))
+        p.proposal_boxes = Boxes(torch.from_numpy(v["boxes"]))
+        p.objectness_logits = torch.from_numpy(v["obj"])
+        t = Instances((h, w))
+        t.gt_boxes = Boxes(torch.zeros(len(gt), 4))
+        t.gt_classes = torch.from_numpy(np.asarray(gt, np.int64))
+        d["image" + name] = torch.from_numpy(np.ascontiguousarray(v["image"]))
+        d["proposals" + name] = p
+        d["instances" + name] = t
+    return [d]
