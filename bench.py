@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Throughput of the Stage-1 OICR+ training step on MI355X (BASELINE.json metric: images/s, VGG16+OICR, 2000 proposals).
+
+One "step" = one OICR+ iteration per GPU = 4 views (2 scales x {orig, h-flip}) of one image:
+u8 image -> VGG16 -> ROIPool(2000 proposals) -> fc6/fc7 -> WSDDN + 4 OICR refinement heads with device-side
+pseudo-label mining -> 9 losses -> full backward (backbone from plain3 up, FREEZE_AT 2) -> (RCCL gradient
+all-reduce when N > 1) -> SGD-momentum update of all 135.8 M trainable parameters.
+"image" = one view, so value = 4 * N * steps / time.
+
+    python bench.py [--gpus N --steps K --warmup W]        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 with the driver's contract plus `roofline` (dominant kernel, timed live with HIP
+events on the launch stream) and `cpu_baseline` (the oracle, timed on this host's cores, rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+H = W = 512
+R = 2000
+K = 20
+DAN = (4096, 4096)
+
+
+def make_inputs(device, seed):
+    """Synthetic VOC-shaped 4-view input: u8 images, proposals sorted by objectness, flipped views mirror x."""
+    from sos_wsod_amd.structures import Boxes, Instances
+    g = torch.Generator().manual_seed(seed)
+    d = {}
+    x1 = torch.rand(R, generator=g) * (W - 32); y1 = torch.rand(R, generator=g) * (H - 32)
+    bw = 24 + torch.rand(R, generator=g) * (W - x1 - 24); bh = 24 + torch.rand(R, generator=g) * (H - y1 - 24)
+    boxes = torch.stack([x1, y1, torch.minimum(x1 + bw, torch.tensor(float(W))), torch.minimum(y1 + bh, torch.tensor(float(H)))], 1)
+    obj = torch.sort(torch.rand(R, generator=g), descending=True).values
+    gt = torch.unique(torch.randint(0, K, (2,), generator=g))
+    for scale in ("1", "2"):
+        img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+        for flip in ("", "_flip"):
+            b = boxes.clone()
+            im = img
+            if flip:
+                b[:, 0], b[:, 2] = W - boxes[:, 2], W - boxes[:, 0]
+                im = img.flip(-1).contiguous()
+            p = Instances((H, W)); p.proposal_boxes = Boxes(b.to(device)); p.objectness_logits = obj.to(device)
+            t = Instances((H, W)); t.gt_boxes = Boxes(torch.zeros(len(gt), 4)); t.gt_classes = gt      # stays on host
+            d["image" + scale + flip] = im.to(device)
+            d["proposals" + scale + flip] = p
+            d["instances" + scale + flip] = t
+    return [d]
+
+
+def build(device, dtype):
+    from sos_wsod_amd.backbone_vgg import VGG16
+    from sos_wsod_amd.box_head import DiscriminativeAdaptionNeck
+    from sos_wsod_amd.fast_rcnn_oicr import OICROutputLayers
+    from sos_wsod_amd.fast_rcnn_wsddn import WSDDNOutputLayers
+    from sos_wsod_amd.poolers import ROIPooler
+    from sos_wsod_amd.rcnn_multi import MultiInputRCNN
+    from sos_wsod_amd.roi_heads_oicrplus import OICRPlusHeads
+    from sos_wsod_amd.structures import ShapeSpec
+    torch.manual_seed(1234)
+    with torch.device(device):
+        backbone = VGG16(conv5_dilation=2, freeze_at=2, out_features=["plain5"], compute_dtype=dtype)
+        pooler = ROIPooler(output_size=7, scales=(1.0 / 8,), sampling_ratio=0, pooler_type="ROIPool")
+        head = DiscriminativeAdaptionNeck(ShapeSpec(channels=512, height=7, width=7), conv_dims=[], fc_dims=list(DAN),
+                                          compute_dtype=dtype)
+        pred = WSDDNOutputLayers(head.output_shape, num_classes=K)
+        refs = [OICROutputLayers(head.output_shape, num_classes=K, refine_k=k, refine_reg=[True] * 4) for k in range(4)]
+        heads = OICRPlusHeads(box_in_features=["plain5"], box_pooler=pooler, box_head=head, box_predictor=pred, refine_K=4,
+                              refine_mist=True, mist_p=0.10, mist_thre=0.05, mist_type="nms", refine_reg=[True] * 4,
+                              box_refinery=refs, num_classes=K, compute_dtype=dtype)
+        model = MultiInputRCNN(backbone=backbone, roi_heads=heads, pixel_mean=[103.939, 116.779, 123.68],
+                               pixel_std=[1.0, 1.0, 1.0])
+    return model.to(device)
+
+
+def cpu_baseline():
+    """The oracle's restatement of the same step (fp32, torch-CPU contractions + C ROIPool), one full-size iteration."""
+    from oracle import oicr_oracle as O
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+    P = {}
+    for stage, cin, cout, nconv, _, _ in O.VGG_CFG:
+        for i in range(nconv):
+            ci = cin if i == 0 else cout
+            P[f"backbone.{stage}.0.conv{i + 1}.weight"] = (torch.randn(cout, ci, 3, 3, generator=g) * (2.0 / (cout * 9)) ** 0.5).numpy()
+            P[f"backbone.{stage}.0.conv{i + 1}.bias"] = np.zeros(cout, np.float32)
+    d_in = 25088
+    for i, d in enumerate(DAN):
+        P[f"roi_heads.box_head.fc{i + 1}.weight"] = (torch.randn(d, d_in, generator=g) * 0.005).numpy()
+        P[f"roi_heads.box_head.fc{i + 1}.bias"] = np.full(d, 0.1, np.float32)
+        d_in = d
+    for n in ("cls", "det"):
+        P[f"roi_heads.box_predictor.{n}.weight"] = (torch.randn(K, d_in, generator=g) * 0.02).numpy()
+        P[f"roi_heads.box_predictor.{n}.bias"] = np.zeros(K, np.float32)
+    for k in range(4):
+        P[f"roi_heads.box_refinery_{k}.cls_score.weight"] = (torch.randn(K + 1, d_in, generator=g) * 0.01).numpy()
+        P[f"roi_heads.box_refinery_{k}.cls_score.bias"] = np.zeros(K + 1, np.float32)
+        P[f"roi_heads.box_refinery_{k}.bbox_pred.weight"] = (torch.randn(4 * K, d_in, generator=g) * 0.001).numpy()
+        P[f"roi_heads.box_refinery_{k}.bbox_pred.bias"] = np.zeros(4 * K, np.float32)
+    views, gt = O.make_views(H, W, R, n_gt=2, K=K, scale2=1.0, tag="cpubase")
+    masks = [[(torch.rand(R, d, generator=g) >= 0.5).numpy().astype(np.uint8) for d in DAN] for _ in range(4)]
+    t0 = time.perf_counter()
+    O.oicr_plus_iteration(P, views, gt, masks, K=K, want_grads=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(4.0 / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 full OICR+ iteration (4 views {H}x{W}, R={R}, K={K}, fp32) forward+backward through the oracle "
+                      f"(torch-CPU contractions with {threads} threads + single-thread C ROIPool), no optimizer step; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import sos_wsod_amd  # noqa: F401  (fails loudly if the HIP extension is missing)
+    import sos_wsod_amd.ops as ops
+    from sos_wsod_amd.solver import HipSGD
+    from sos_wsod_amd.trainer import Trainer, init_distributed
+    import torch.distributed as dist
+
+    rank, local_rank, world = init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)"
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; there is no CPU fallback"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    model = build(device, dtype)
+    model.train()
+    groups = []
+    for name, p in model.named_parameters():
+        if p.requires_grad:                      # voc07_oicr_plus.yaml:36-45 solver values
+            groups.append({"params": [p], "lr": 2e-3 if name.endswith(".bias") else 1e-3,
+                           "weight_decay": 0.0 if name.endswith(".bias") else 5e-4})
+    opt = HipSGD(groups, 1e-3, momentum=0.9)
+    trainer = Trainer(model, opt)
+    batches = [make_inputs(device, 100 + rank * 17 + i) for i in range(2)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.run_step(batches[i % 2])
+    tags = ["fc6_fwd", "fc6_dgrad", "fc6_wgrad", "plain5.conv3_fwd"]
+    ops.TIMER = ops.KernelTimer(tags)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.run_step(batches[i % 2])
+    sync()
+    dt = time.perf_counter() - t0
+    times = ops.TIMER.summary_ms()
+    ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        M = 4 * R
+        flops = {"fc6_fwd": 2.0 * M * 25088 * DAN[0], "fc6_dgrad": 2.0 * M * 25088 * DAN[0], "fc6_wgrad": 2.0 * M * 25088 * DAN[0],
+                 "plain5.conv3_fwd": 2.0 * (2 * 63 * 63) * 512 * 4608}
+        avg_ms = {t: (sum(v) / len(v) if v else None) for t, v in times.items()}
+        tot_ms = {t: sum(v) / args.steps for t, v in times.items()}
+        dom = max((t for t in ("fc6_fwd", "fc6_dgrad", "fc6_wgrad")), key=lambda t: tot_ms[t])
+        peak = MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else 157.3
+
+        def roof(tag):
+            a = flops[tag] / (avg_ms[tag] * 1e-3) / 1e12
+            return {"kernel": tag, "bound": "mfma", "achieved": round(a, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(a / peak, 4), "traffic": None, "avg_ms": round(avg_ms[tag], 4),
+                    "flop_per_launch": flops[tag]}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # filled from the committed rocprofv3 --pmc passes
+        roofline = roof(dom)
+        if os.path.exists(pmc):
+            roofline["traffic"] = json.load(open(pmc)).get(dom)
+        out = {
+            "metric": "images/s (1/2/4/8 MI355X) VGG16+OICR 2000-prop; conv5_3 MFMA-util %",
+            "value": round(4.0 * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"OICR+ training iteration: 4 views/step/GPU (2 scales x h-flip, every view {H}x{W}), "
+                                   f"R={R} proposals/view, K={K}, VGG16 dilated-C5 + ROIPool 7x7 + fc6/fc7 4096 + WSDDN + 4 OICR heads, "
+                                   "fwd+bwd+SGD(momentum, wd)", "views_per_step_per_gpu": 4, "image": "one view",
+                       "oicr_iterations_per_s": round(world * args.steps / dt, 3), "parallelism": f"dp{world}"},
+            "roofline": roofline,
+            "roofline_conv5_3": roof("plain5.conv3_fwd"),
+            "kernel_ms_per_step": {t: round(v, 3) for t, v in tot_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,7 +70,8 @@ class _VGGFunction(torch.autograd.Function):
                 wk = torch.empty(blk.out_channels, 9, cin, device=x.device, dtype=dtype)
                 ops.conv_weight_prep(w, wk, 0, cin)
                 out = torch.empty(cur.shape[0], cur.shape[1], cur.shape[2], blk.out_channels, device=x.device, dtype=dtype)
-                ops.conv3x3(cur, wk, out, blk.dilation, ops.make_epilogue(bias=b, relu=True, out_dtype=dtype))
+                ops.conv3x3(cur, wk, out, blk.dilation, ops.make_epilogue(bias=b, relu=True, out_dtype=dtype),
+                            tag=f"{blk.tag}.conv{ci + 1}_fwd")
                 conv_io.append((cur, out))
                 cur = out
             pre_pool = None
@@ -166,6 +167,7 @@ class VGG16(nn.Module):
             stage = nn.Sequential(blk)               # keeps the reference's "plainK.0.convJ" names
             self.add_module(name, stage)
             self.stages_and_names.append((stage, name))
+            blk.tag = name
             self.blocks.append(blk)
             self._out_feature_strides[name] = strides[name]
             self._out_feature_channels[name] = cout

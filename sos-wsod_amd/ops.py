@@ -27,6 +27,38 @@ def dt(t_or_dtype):
     raise TypeError(f"unsupported dtype {d}")
 
 
+class KernelTimer:
+    """Optional in-process timing of tagged launches with HIP events recorded on the launch stream (used by
+    bench.py to price the dominant kernels live; off by default => zero overhead)."""
+
+    def __init__(self, tags):
+        self.tags = set(tags)
+        self.pairs = {t: [] for t in tags}
+
+    def wrap(self, tag, fn):
+        if tag not in self.tags:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.pairs[tag].append((a, b))
+        return r
+
+    def summary_ms(self):
+        torch.cuda.synchronize()
+        return {t: [a.elapsed_time(b) for a, b in ps] for t, ps in self.pairs.items()}
+
+
+TIMER = None
+
+
+def _launch(tag, fn):
+    if TIMER is None or tag is None:
+        return fn()
+    return TIMER.wrap(tag, fn)
+
+
 def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -51,7 +83,7 @@ def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_re
     return ep
 
 
-def gemm(A, B, C, M, N, K, a_kstrided=False, b_kstrided=False, lda=None, ldb=None, ldc=None, ep=None, splitk=1):
+def gemm(A, B, C, M, N, K, a_kstrided=False, b_kstrided=False, lda=None, ldb=None, ldc=None, ep=None, splitk=1, tag=None):
     """C[m][n] = sum_k A(m,k) B(k,n); see sw_gemm.  A and B share one dtype (f32 / bf16)."""
     _need_gpu(A, B, C)
     lda = A.stride(0) if lda is None else lda
@@ -59,18 +91,18 @@ def gemm(A, B, C, M, N, K, a_kstrided=False, b_kstrided=False, lda=None, ldb=Non
     ldc = C.stride(0) if ldc is None else ldc
     if ep is None:
         ep = make_epilogue(out_dtype=C.dtype)
-    check(lib.sw_gemm(dt(A), int(a_kstrided), int(b_kstrided), M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc,
-                      ctypes.byref(ep), splitk, _stream()), "sw_gemm")
+    check(_launch(tag, lambda: lib.sw_gemm(dt(A), int(a_kstrided), int(b_kstrided), M, N, K, _p(A), lda, _p(B), ldb, _p(C),
+                                           ldc, ctypes.byref(ep), splitk, _stream())), "sw_gemm")
     return C
 
 
-def conv3x3(x, wk, out, dilation, ep):
+def conv3x3(x, wk, out, dilation, ep, tag=None):
     """x [n][H][W][Cin], wk [Cout][9][Cin], out [n][H][W][Cout]"""
     _need_gpu(x, wk, out)
     n, H, W, Cin = x.shape
     Cout = out.shape[3]
-    check(lib.sw_conv3x3_igemm(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(wk), _p(out), ctypes.byref(ep), _stream()),
-          "sw_conv3x3_igemm")
+    check(_launch(tag, lambda: lib.sw_conv3x3_igemm(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(wk), _p(out),
+                                                    ctypes.byref(ep), _stream())), "sw_conv3x3_igemm")
     return out
 
 

@@ -210,7 +210,8 @@ class OICRPlusHeads(nn.Module):
         W1 = torch.empty(D1, D0, device=dev, dtype=dt_); ops.convert_2d(fc1w, W1, D1, D0)
         W2 = torch.empty(D2, D1, device=dev, dtype=dt_); ops.convert_2d(fc2w, W2, D2, D1)
         h1 = torch.empty(V * R, D1, device=dev, dtype=dt_)
-        ops.gemm(pooled, W1, h1, V * R, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], out_dtype=dt_))
+        ops.gemm(pooled, W1, h1, V * R, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], out_dtype=dt_),
+                 tag="fc6_fwd")
         h2 = torch.empty(V * R, D2, device=dev, dtype=dt_)
         ops.gemm(h1, W2, h2, V * R, D2, D1, ep=ops.make_epilogue(bias=fc2b, relu=True, drop_mask=masks[1], out_dtype=dt_))
         # --- all 10 predictor matrices as one GEMM, f32 logits
@@ -298,11 +299,11 @@ class OICRPlusHeads(nn.Module):
         # fc6
         db1 = torch.empty(D1, device=dev, dtype=torch.float32); ops.colsum(dz1, M, D1, db1)
         dW1 = torch.empty(D1, D0, device=dev, dtype=torch.float32)
-        ops.gemm(dz1, pooled, dW1, D1, D0, M, a_kstrided=True, b_kstrided=True)
+        ops.gemm(dz1, pooled, dW1, D1, D0, M, a_kstrided=True, b_kstrided=True, tag="fc6_wgrad")
         dfeats = [None, None]
         if feat_req[0] or feat_req[1]:
             dpooled = torch.empty(M, D0, device=dev, dtype=dt_)
-            ops.gemm(dz1, W1, dpooled, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt_))
+            ops.gemm(dz1, W1, dpooled, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt_), tag="fc6_dgrad")
             P = self.box_pooler.output_size
             for s in range(2):
                 if not feat_req[s]:

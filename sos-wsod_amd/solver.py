@@ -1,0 +1,75 @@
+"""Solver of the OICR+ step loop (needed inside the measured step):
+per-parameter SGD groups exactly as the reference builds them (uwsod/detectron2/solver/build.py:143-218:
+bias lr x BIAS_LR_FACTOR, WEIGHT_DECAY_BIAS for biases), torch.optim.SGD update semantics executed by the
+HIP kernel sw_sgd_momentum_step, and WarmupMultiStepLR (solver/lr_scheduler.py:13-58)."""
+from bisect import bisect_right
+from typing import List
+
+import torch
+
+from . import ops
+
+
+class HipSGD(torch.optim.Optimizer):
+    """SGD + momentum + weight decay; state and hyper-parameters follow torch.optim.SGD so that schedulers and
+    checkpoints interoperate.  One fused elementwise launch per parameter tensor (no host sync)."""
+
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                first = "momentum_buffer" not in st
+                if first:
+                    st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                ops.sgd_momentum_step(p, g, st["momentum_buffer"], group["lr"], group["momentum"], group["weight_decay"],
+                                      first, grad_scale)
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=set_to_none)
+
+
+def build_optimizer(cfg, model) -> torch.optim.Optimizer:
+    """solver/build.py:191-215: one group per parameter; biases get BASE_LR*BIAS_LR_FACTOR and WEIGHT_DECAY_BIAS."""
+    groups = []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        lr, wd = cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY
+        if name.endswith(".bias"):
+            lr = cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR
+            wd = cfg.SOLVER.WEIGHT_DECAY_BIAS
+        groups.append({"params": [p], "lr": lr, "weight_decay": wd})
+    return HipSGD(groups, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
+
+
+class WarmupMultiStepLR(torch.optim.lr_scheduler.LRScheduler):
+    def __init__(self, optimizer, milestones: List[int], gamma=0.1, warmup_factor=0.001, warmup_iters=1000,
+                 warmup_method="linear", last_epoch=-1):
+        assert list(milestones) == sorted(milestones)
+        self.milestones, self.gamma = list(milestones), gamma
+        self.warmup_factor, self.warmup_iters, self.warmup_method = warmup_factor, warmup_iters, warmup_method
+        super().__init__(optimizer, last_epoch)
+
+    def _warmup(self, it):
+        if it >= self.warmup_iters:
+            return 1.0
+        if self.warmup_method == "constant":
+            return self.warmup_factor
+        alpha = it / self.warmup_iters
+        return self.warmup_factor * (1 - alpha) + alpha
+
+    def get_lr(self):
+        w = self._warmup(self.last_epoch)
+        return [b * w * self.gamma ** bisect_right(self.milestones, self.last_epoch) for b in self.base_lrs]
+
+
+def build_lr_scheduler(cfg, optimizer):
+    return WarmupMultiStepLR(optimizer, cfg.SOLVER.STEPS, cfg.SOLVER.GAMMA, warmup_factor=cfg.SOLVER.WARMUP_FACTOR,
+                             warmup_iters=cfg.SOLVER.WARMUP_ITERS, warmup_method=cfg.SOLVER.WARMUP_METHOD)
