@@ -118,18 +118,21 @@ __global__ void to_f32_kernel(long n, const T* __restrict__ src, float* __restri
 }
 
 // ---------------------------------------------------------------- column sums: out[n] = sum_m X[m][n]
-// workgroup = 64 columns x 4 row-lanes; deterministic (fixed order), no atomics.
+// grid = (column slabs of 64, row chunks); each workgroup folds its rows (4 row-lanes x 64 columns, coalesced
+// 128/256-byte row segments) and adds ONE f32 atomic per column into the zero-filled output.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const T* __restrict__ X, long ld,
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, int rows_per_chunk, const T* __restrict__ X, long ld,
                                                      float* __restrict__ out) {
   __shared__ float part[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
   float s = 0.f;
   if (col < N)
-    for (int m = rl; m < M; m += 4) s += Elem<T>::load(X + (long)m * ld + col);
+    for (int m = m0 + rl; m < m1; m += 4) s += Elem<T>::load(X + (long)m * ld + col);
   part[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && col < N) out[col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (rl == 0 && col < N)
+    atomicAdd(out + col, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
 // ---------------------------------------------------------------- dropout keep mask
@@ -321,9 +324,18 @@ extern "C" int sw_scale_cols(int dtype, int M, int N, const float* in, long ld_i
 
 extern "C" int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, hipStream_t stream) {
   if (N <= 0) return 0;
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  if (M <= 0) return 0;
+  const int slabs = (N + 63) / 64;
+  int chunks = (2048 + slabs - 1) / slabs;                 // aim at ~2048 workgroups (256 CUs x 8)
+  int rpc = (M + chunks - 1) / chunks;
+  if (rpc < 32) rpc = 32;
+  chunks = (M + rpc - 1) / rpc;
+  dim3 grid(slabs, chunks);
   DISPATCH_T(dtype,
-    hipLaunchKernelGGL(colsum_kernel<unsigned short>, dim3((N + 63) / 64), dim3(256), 0, stream, M, N, (const unsigned short*)X, ld, out),
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64), dim3(256), 0, stream, M, N, (const float*)X, ld, out));
+    hipLaunchKernelGGL(colsum_kernel<unsigned short>, grid, dim3(256), 0, stream, M, N, rpc, (const unsigned short*)X, ld, out),
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, M, N, rpc, (const float*)X, ld, out));
   SW_CHECK_LAUNCH();
   return 0;
 }
