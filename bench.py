@@ -188,7 +188,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # filled from the committed rocprofv3 --pmc passes
         roofline = roof(dom)
         if os.path.exists(pmc):
-            roofline["traffic"] = json.load(open(pmc)).get(dom)
+            entry = json.load(open(pmc)).get(dom)                     # HBM bytes per launch: (2*FETCH_SIZE + WRITE_SIZE)*1024
+            roofline["traffic"] = entry["hbm_bytes_per_launch"] if entry else None
+            roofline["algorithmic_bytes"] = 2.0 * (M * 25088 + DAN[0] * 25088 + M * DAN[0])
         out = {
             "metric": "images/s (1/2/4/8 MI355X) VGG16+OICR 2000-prop; conv5_3 MFMA-util %",
             "value": round(4.0 * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
