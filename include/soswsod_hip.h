@@ -130,12 +130,13 @@ int sw_oicr_mine_label(int R, int ncol, int K, const float* scores, const int32_
  * loss_view [2][V] (cls then box, already divided by R).  probs [V][R][K+1] = softmax of each view's OWN logits.
  * dlogits (f32, may be NULL): the columns of this round are overwritten with
  * (grad_scale[0]*dcls + grad_scale[1]*dbox)/V; grad_scale is a DEVICE float[2]; reg_weights4 is a HOST float[4]
- * (BBOX_REG_WEIGHTS, a configuration constant passed by value into the launch). */
+ * (BBOX_REG_WEIGHTS, a configuration constant passed by value into the launch); workspace: 2*V*R floats
+ * (per-row loss terms, summed in fixed order => deterministic losses). */
 int sw_oicr_refine_loss(int V, int R, int K, const float* logits, long ld, int cls_col, int box_col,
                         const float* boxes, const int32_t* lab_class, const float* lab_weight,
                         const int32_t* lab_index, const int32_t* pred_view, const float* reg_weights4,
                         float* loss_view, float* probs, float* dlogits, long ld_d,
-                        const float* grad_scale, sw_stream_t stream);
+                        const float* grad_scale, float* workspace, sw_stream_t stream);
 
 /* ---- small utilities ------------------------------------------------------------------------------------ */
 /* out[n] = sum_m X[m][ld..] (column sums; bias gradients).  out f32, overwritten. */

@@ -53,7 +53,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p]),
     "sw_oicr_refine_loss": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, _F4, c_void_p, c_void_p, c_void_p, c_long, c_void_p,
-                                    c_void_p]),
+                                    c_void_p, c_void_p]),
     "sw_colsum": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

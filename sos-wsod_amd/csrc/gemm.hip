@@ -188,14 +188,63 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
   }
 
+  // ---- gather index math kept out of the K loop (integer divisions would otherwise out-weigh the MFMAs):
+  //  OP_CONV_A: the pixel of each staged row is fixed; when Cin % BK == 0 the tap is uniform per K-tile.
+  //  OP_CONV_B: the (tap, ci) of each staged column is fixed; the pixel of each staged row advances by BK per K-tile.
+  constexpr int EPC = GT<T>::EPC;
+  const bool a_fast = (AMODE == OP_CONV_A) && (g.cC % BK == 0);
+  long a_pixoff[4];
+  int bq_pb[4], bq_py[4], bq_px[4], b_dy[4], b_dx[4], b_c0[4];
+  bool b_colok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_pixoff[i] = (((long)a_pb[i] * g.cH + a_py[i]) * g.cW + a_px[i]) * g.cC;
+    bq_pb[i] = bq_py[i] = bq_px[i] = b_dy[i] = b_dx[i] = b_c0[i] = 0; b_colok[i] = false;
+    if (BMODE == OP_CONV_B) {
+      const int n0 = bn * TILE + b_chk[i] * EPC;
+      b_colok[i] = n0 < g.N;
+      const int tap = n0 / g.cC; b_c0[i] = n0 - tap * g.cC;
+      const int ty = tap / 3, tx = tap - ty * 3;
+      b_dy[i] = (ty - 1) * g.cDil; b_dx[i] = (tx - 1) * g.cDil;
+      const int k = kbeg + b_row[i];
+      const int hw = g.cH * g.cW;
+      bq_pb[i] = k / hw; const int rem = k - bq_pb[i] * hw;
+      bq_py[i] = rem / g.cW; bq_px[i] = rem - bq_py[i] * g.cW;
+    }
+  }
+
   u32x4 ra[4], rb[4];
-  auto stage_load = [&](int kt) {
+  auto stage_load = [&](int kt) {       // called with kt = 0, 1, 2, ... in order (OP_CONV_B state is incremental)
     const int kb = kbeg + kt * BK;
+    int f_dy = 0, f_dx = 0, f_c = 0;
+    if (a_fast) {
+      const int tap = kb / g.cC; f_c = kb - tap * g.cC;
+      const int ty = tap / 3, tx = tap - ty * 3;
+      f_dy = (ty - 1) * g.cDil; f_dx = (tx - 1) * g.cDil;
+    }
+    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const u32x4* pa = a_chunk_ptr<T, AMODE>(g, bm, a_row[i], a_chk[i], kb, kend, a_pb[i], a_py[i], a_px[i]);
-      const u32x4* pb = b_chunk_ptr<T, BMODE>(g, bn, b_row[i], b_chk[i], kb, kend);
-      const u32x4 z = {0u, 0u, 0u, 0u};
+      const u32x4* pa;
+      if (a_fast) {
+        const int m = bm * TILE + a_row[i], k0 = kb + a_chk[i] * EPC;
+        const int yy = a_py[i] + f_dy, xx = a_px[i] + f_dx;
+        const bool ok = m < g.M && k0 < kend && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
+        pa = ok ? (const u32x4*)((const T*)g.A + a_pixoff[i] + ((long)f_dy * g.cW + f_dx) * g.cC + f_c + a_chk[i] * EPC) : nullptr;
+      } else {
+        pa = a_chunk_ptr<T, AMODE>(g, bm, a_row[i], a_chk[i], kb, kend, a_pb[i], a_py[i], a_px[i]);
+      }
+      const u32x4* pb;
+      if (BMODE == OP_CONV_B) {
+        const int yy = bq_py[i] + b_dy[i], xx = bq_px[i] + b_dx[i];
+        const bool ok = b_colok[i] && (kb + b_row[i] < kend) && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
+        pb = ok ? (const u32x4*)((const T*)g.B + (((long)bq_pb[i] * g.cH + yy) * g.cW + xx) * g.cC + b_c0[i]) : nullptr;
+        bq_px[i] += BK;                                    // advance this row's pixel to the next K-tile
+        while (bq_px[i] >= g.cW) { bq_px[i] -= g.cW; ++bq_py[i]; }
+        while (bq_py[i] >= g.cH) { bq_py[i] -= g.cH; ++bq_pb[i]; }
+      } else {
+        pb = b_chunk_ptr<T, BMODE>(g, bn, b_row[i], b_chk[i], kb, kend);
+      }
       ra[i] = pa ? *pa : z;
       rb[i] = pb ? *pb : z;
     }

@@ -108,88 +108,87 @@ __global__ __launch_bounds__(1024) void wsddn_kernel(int R, int K, const float* 
 }
 
 // ------------------------------------------------------------------------------------------- OICR refine loss
-// One workgroup per PREDICTION view pv; it serves every target view v with pred_view[v] == pv in order,
-// so the (reference-quirk) double use of view 2's logits needs no atomics and stays deterministic.
-__global__ __launch_bounds__(1024) void refine_loss_kernel(int V, int R, int K, const float* __restrict__ logits, long ld,
-                                                           int cls_col, int box_col, const float* __restrict__ boxes,
-                                                           const int* __restrict__ lab_class,
-                                                           const float* __restrict__ lab_weight,
-                                                           const int* __restrict__ lab_index,
-                                                           const int* __restrict__ pred_view,
-                                                           float wx, float wy, float ww, float wh,
-                                                           float* __restrict__ loss_view, float* __restrict__ probs,
-                                                           float* __restrict__ dlogits, long ld_d,
-                                                           const float* __restrict__ grad_scale) {
-  __shared__ float red[32];
-  const int pv = blockIdx.x;
+// grid = (row chunks, prediction views).  A thread owns one proposal row of prediction view pv and serves every
+// target view v with pred_view[v] == pv in order, so the (reference-quirk) double use of view 2's logits needs no
+// atomics.  Per-row loss terms go to a scratch array and are summed in fixed order by refine_reduce_kernel
+// (deterministic, no float atomics).
+__global__ __launch_bounds__(256) void refine_loss_kernel(int V, int R, int K, const float* __restrict__ logits, long ld,
+                                                          int cls_col, int box_col, const float* __restrict__ boxes,
+                                                          const int* __restrict__ lab_class,
+                                                          const float* __restrict__ lab_weight,
+                                                          const int* __restrict__ lab_index,
+                                                          const int* __restrict__ pred_view,
+                                                          float wx, float wy, float ww, float wh,
+                                                          float* __restrict__ row_loss, float* __restrict__ probs,
+                                                          float* __restrict__ dlogits, long ld_d,
+                                                          const float* __restrict__ grad_scale) {
+  const int pv = blockIdx.y;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
   const int K1 = K + 1;
-  const float* L = logits + (long)pv * R * ld;
-  float* DL = dlogits ? dlogits + (long)pv * R * ld_d : nullptr;
+  const float* x = logits + ((long)pv * R + r) * ld + cls_col;
+  float* DL = dlogits ? dlogits + ((long)pv * R + r) * ld_d : nullptr;
   const float gs_cls = (dlogits && grad_scale) ? grad_scale[0] / (float)V / (float)R : 0.f;
   const float gs_box = (dlogits && grad_scale) ? grad_scale[1] / (float)V / (float)R : 0.f;
-
-  // own softmax (predict_probs, fast_rcnn_oicr.py:702-716) + zero this view's gradient columns
-  for (int r = threadIdx.x; r < R; r += blockDim.x) {
-    const float* x = L + (long)r * ld + cls_col;
-    float m = -FLT_MAX;
-    for (int j = 0; j < K1; ++j) m = fmaxf(m, x[j]);
-    float z = 0.f;
-    for (int j = 0; j < K1; ++j) z += expf(x[j] - m);
-    float* P = probs + ((long)pv * R + r) * K1;
-    for (int j = 0; j < K1; ++j) P[j] = expf(x[j] - m) / z;
-    if (DL) {
-      for (int j = 0; j < K1; ++j) DL[(long)r * ld_d + cls_col + j] = 0.f;
-      for (int j = 0; j < 4 * K; ++j) DL[(long)r * ld_d + box_col + j] = 0.f;
+  // own softmax (predict_probs, fast_rcnn_oicr.py:702-716)
+  float m = -FLT_MAX;
+  for (int j = 0; j < K1; ++j) m = fmaxf(m, x[j]);
+  float z = 0.f;
+  for (int j = 0; j < K1; ++j) z += expf(x[j] - m);
+  float* P = probs + ((long)pv * R + r) * K1;
+  for (int j = 0; j < K1; ++j) P[j] = expf(x[j] - m) / z;
+  const float logz = logf(z);
+  const int gt = lab_class[r];
+  const float w = gt == -1 ? 0.f : lab_weight[r];                       // fast_rcnn_oicr.py:217-218
+  int ntgt = 0;
+  for (int v = 0; v < V; ++v) ntgt += (pred_view[v] == pv) ? 1 : 0;
+  if (DL) {
+    // CE gradient is identical for every target view served by this prediction view
+    const float s = gs_cls * w * (float)ntgt;
+    for (int j = 0; j < K1; ++j) {
+      const float p = expf(x[j] - m) / z;
+      DL[cls_col + j] = (gt >= 0 && s != 0.f) ? s * (p - (j == gt ? 1.f : 0.f)) : 0.f;
     }
+    for (int j = 0; j < 4 * K; ++j) DL[box_col + j] = 0.f;
   }
+  const float ce = gt >= 0 ? -((x[gt] - m) - logz) * w : 0.f;            // CE(ignore_index=-1) * weight
   for (int v = 0; v < V; ++v) {
-    if (pred_view[v] != pv) continue;             // block-uniform
-    const float* B = boxes + (long)v * R * 4;
-    float lc = 0.f, lb = 0.f;
-    for (int r = threadIdx.x; r < R; r += blockDim.x) {
-      const int gt = lab_class[r];
-      const float w = gt == -1 ? 0.f : lab_weight[r];                 // fast_rcnn_oicr.py:217-218
-      const float* x = L + (long)r * ld + cls_col;
-      float m = -FLT_MAX;
-      for (int j = 0; j < K1; ++j) m = fmaxf(m, x[j]);
-      float z = 0.f;
-      for (int j = 0; j < K1; ++j) z += expf(x[j] - m);
-      const float logz = logf(z);
-      if (gt >= 0) lc += -((x[gt] - m) - logz) * w;                   // CE(ignore_index=-1) * weight
-      if (DL && gt >= 0 && w != 0.f) {
-        for (int j = 0; j < K1; ++j) {
-          const float p = expf(x[j] - m) / z;
-          DL[(long)r * ld_d + cls_col + j] += gs_cls * w * (p - (j == gt ? 1.f : 0.f));
-        }
-      }
-      if (gt >= 0 && gt < K) {                                         // foreground: L1 on the gt-class deltas
-        const float* s = B + (long)r * 4;
-        const float* t = B + (long)lab_index[r] * 4;                   // target = this view's proposal[gt_index]
-        const float sw_ = s[2] - s[0], sh_ = s[3] - s[1];
-        const float sx = s[0] + 0.5f * sw_, sy = s[1] + 0.5f * sh_;
-        const float tw_ = t[2] - t[0], th_ = t[3] - t[1];
-        const float tx = t[0] + 0.5f * tw_, ty = t[1] + 0.5f * th_;
-        float tgt[4];
-        tgt[0] = __fdiv_rn(wx * (tx - sx), sw_);                       // box_regression.py:59-62
-        tgt[1] = __fdiv_rn(wy * (ty - sy), sh_);
-        tgt[2] = ww * logf(__fdiv_rn(tw_, sw_));
-        tgt[3] = wh * logf(__fdiv_rn(th_, sh_));
-        const float* pd = L + (long)r * ld + box_col + 4 * gt;
-        for (int j = 0; j < 4; ++j) {
-          const float d = pd[j] - tgt[j];
-          lb += fabsf(d);
-          if (DL) DL[(long)r * ld_d + box_col + 4 * gt + j] += gs_box * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-        }
+    if (pred_view[v] != pv) continue;
+    float lb = 0.f;
+    if (gt >= 0 && gt < K) {                                             // foreground: L1 on the gt-class deltas
+      const float* B = boxes + (long)v * R * 4;
+      const float* s = B + (long)r * 4;
+      const float* t = B + (long)lab_index[r] * 4;                       // target = this view's proposal[gt_index]
+      const float sw_ = s[2] - s[0], sh_ = s[3] - s[1];
+      const float sx = s[0] + 0.5f * sw_, sy = s[1] + 0.5f * sh_;
+      const float tw_ = t[2] - t[0], th_ = t[3] - t[1];
+      const float tx = t[0] + 0.5f * tw_, ty = t[1] + 0.5f * th_;
+      float tgt[4];
+      tgt[0] = __fdiv_rn(wx * (tx - sx), sw_);                           // box_regression.py:59-62
+      tgt[1] = __fdiv_rn(wy * (ty - sy), sh_);
+      tgt[2] = ww * logf(__fdiv_rn(tw_, sw_));
+      tgt[3] = wh * logf(__fdiv_rn(th_, sh_));
+      const float* pd = logits + ((long)pv * R + r) * ld + box_col + 4 * gt;
+      for (int j = 0; j < 4; ++j) {
+        const float d = pd[j] - tgt[j];
+        lb += fabsf(d);
+        if (DL) DL[box_col + 4 * gt + j] += gs_box * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
       }
     }
-    const float lc_t = block_reduce_sum(lc, red);
-    const float lb_t = block_reduce_sum(lb, red);
-    if (threadIdx.x == 0) {
-      loss_view[v] = lc_t / (float)R;                                  // mean over ALL R (fast_rcnn_oicr.py:269-273)
-      loss_view[V + v] = lb_t / (float)R;                              // sum / R (:351)
-    }
-    __syncthreads();
+    row_loss[(long)v * R + r] = ce;
+    row_loss[((long)V + v) * R + r] = lb;
   }
+}
+
+// loss_view[i] = sum_r row_loss[i][r] / R, fixed summation order (i = term * V + view)
+__global__ __launch_bounds__(256) void refine_reduce_kernel(int R, const float* __restrict__ row_loss,
+                                                            float* __restrict__ loss_view) {
+  __shared__ float red[32];
+  const float* src = row_loss + (long)blockIdx.x * R;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) s += src[r];
+  s = block_reduce_sum(s, red);
+  if (threadIdx.x == 0) loss_view[blockIdx.x] = s / (float)R;           // mean over ALL R (:269-273) / sum over R (:351)
 }
 
 // ------------------------------------------------------------------------------------------- mining + labelling
@@ -354,11 +353,14 @@ extern "C" int sw_oicr_refine_loss(int V, int R, int K, const float* logits, lon
                                    const float* boxes, const int32_t* lab_class, const float* lab_weight,
                                    const int32_t* lab_index, const int32_t* pred_view, const float* reg_weights4,
                                    float* loss_view, float* probs, float* dlogits, long ld_d,
-                                   const float* grad_scale, hipStream_t stream) {
-  // reg_weights4: HOST pointer (configuration constants BBOX_REG_WEIGHTS)
-  hipLaunchKernelGGL(refine_loss_kernel, dim3(V), dim3(1024), 0, stream, V, R, K, logits, ld, cls_col, box_col, boxes,
-                     lab_class, lab_weight, lab_index, pred_view, reg_weights4[0], reg_weights4[1], reg_weights4[2],
-                     reg_weights4[3], loss_view, probs, dlogits, ld_d, grad_scale);
+                                   const float* grad_scale, float* workspace, hipStream_t stream) {
+  // reg_weights4: HOST pointer (configuration constants BBOX_REG_WEIGHTS); workspace: 2*V*R floats
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(refine_loss_kernel, dim3((R + 255) / 256, V), dim3(256), 0, stream, V, R, K, logits, ld, cls_col,
+                     box_col, boxes, lab_class, lab_weight, lab_index, pred_view, reg_weights4[0], reg_weights4[1],
+                     reg_weights4[2], reg_weights4[3], workspace, probs, dlogits, ld_d, grad_scale);
+  SW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(refine_reduce_kernel, dim3(2 * V), dim3(256), 0, stream, R, workspace, loss_view);
   SW_CHECK_LAUNCH();
   return 0;
 }

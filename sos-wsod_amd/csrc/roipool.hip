@@ -68,11 +68,18 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, 
     float mv = empty ? 0.f : -FLT_MAX;
     int mi = -1;
     if (c < C) {
+      // 8 loads in flight per lane: the scan is latency bound (every pixel row segment comes from L2 / MALL).
+      // Out-of-range slots re-read the last valid pixel; with the strict '>' a duplicate can never win, so the
+      // first maximum in row-major order is kept exactly as the serial scan keeps it.
       for (int h = hs; h < he; ++h) {
         const T* row = fimg + ((long)h * W) * C + c;
-        for (int w = ws; w < we; ++w) {
-          const float v = Elem<T>::load(row + (long)w * C);
-          if (v > mv) { mv = v; mi = h * W + w; }
+        for (int w = ws; w < we; w += 8) {
+          float v[8]; int wi[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { wi[u] = min(w + u, we - 1); v[u] = Elem<T>::load(row + (long)wi[u] * C); }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (v[u] > mv) { mv = v[u]; mi = h * W + wi[u]; }
         }
       }
     }
@@ -103,15 +110,29 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
   __syncthreads();
   const int per_roi = CB * nb;                 // contiguous (c, bin) run of this slab inside one ROI
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-  for (int r = wave; r < R; r += nwave) {
-    if ((int)rois[(long)r * 5] != img) continue;           // wave-uniform
-    const float mul = row_scale ? (row_scale[r] + row_scale_add) : 1.0f;
-    const long base = ((long)r * C + c0) * nb;
-    for (int i = lane; i < per_roi; i += 64) {
-      const int a = argmax[base + i];
-      if (a >= 0) {
-        const int cc = i / nb;
-        atomicAdd(&acc[a * CB + cc], __fmul_rn(Elem<T>::load(dout + base + i), mul));
+  const int iters = (per_roi + 63) / 64;
+  for (int r0 = wave * 4; r0 < R; r0 += nwave * 4) {
+    // stage 4 ROIs x (argmax, grad) in registers first (memory-level parallelism), then scatter into LDS
+    for (int j = 0; j < iters; ++j) {
+      const int i = lane + 64 * j;
+      int a[4]; float d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u;
+        a[u] = -1; d[u] = 0.f;
+        if (r < R && i < per_roi && (int)rois[(long)r * 5] == img) {
+          const long base = ((long)r * C + c0) * nb;
+          a[u] = argmax[base + i];
+          d[u] = Elem<T>::load(dout + base + i);
+        }
+      }
+      const int cc = i / nb;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (a[u] >= 0) {
+          const float mul = row_scale ? (row_scale[r0 + u] + row_scale_add) : 1.0f;
+          atomicAdd(&acc[a[u] * CB + cc], __fmul_rn(d[u], mul));
+        }
       }
     }
   }
@@ -151,9 +172,10 @@ extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH,
 extern "C" int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
                                const int32_t* argmax, const float* rois, int R, const float* row_scale,
                                float row_scale_add, const void* relu_ref, void* dfeat, hipStream_t stream) {
-  // channel slab per workgroup: largest power of two with H*W*CB*4 <= 128 KiB
+  // channel slab per workgroup: power of two, H*W*CB*4 <= 64 KiB (two 1024-thread workgroups per CU) and enough
+  // slabs to give every CU work (C/CB * nimg >= 512 where the map allows)
   int CB = 64;
-  while (CB > 1 && ((size_t)H * W * CB * 4 > 128 * 1024 || (C % CB))) CB >>= 1;
+  while (CB > 1 && ((size_t)H * W * CB * 4 > 64 * 1024 || (C % CB) || (C / CB) * nimg < 512)) CB >>= 1;
   const size_t lds = (size_t)H * W * CB * 4;
   if (lds > 160 * 1024) return -6;
   dim3 grid(C / CB, nimg), block(1024);

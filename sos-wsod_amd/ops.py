@@ -192,12 +192,14 @@ def oicr_mine_label(scores, gt_classes_i32, boxes, K, top_k, thresh, nms_thresh,
 
 
 def oicr_refine_loss(logits, V, R, K, cls_col, box_col, boxes, lab_class, lab_weight, lab_index, pred_view, reg_weights,
-                     loss_view, probs, dlogits=None, grad_scale=None):
+                     loss_view, probs, dlogits=None, grad_scale=None, workspace=None):
     rw = (ctypes.c_float * 4)(*[float(v) for v in reg_weights])
+    if workspace is None:
+        workspace = torch.empty(2 * V * R, device=logits.device, dtype=torch.float32)
     check(lib.sw_oicr_refine_loss(V, R, K, _p(logits), logits.stride(0), cls_col, box_col, _p(boxes), _p(lab_class),
                                   _p(lab_weight), _p(lab_index), _p(pred_view), rw, _p(loss_view), _p(probs),
-                                  _p(dlogits), 0 if dlogits is None else dlogits.stride(0), _p(grad_scale), _stream()),
-          "sw_oicr_refine_loss")
+                                  _p(dlogits), 0 if dlogits is None else dlogits.stride(0), _p(grad_scale), _p(workspace),
+                                  _stream()), "sw_oicr_refine_loss")
 
 
 def colsum(X, M, N, out, ld=None):
