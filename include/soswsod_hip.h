@@ -58,9 +58,10 @@ int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, int K, cons
  * Used for forward (ep: bias+relu) and for the data gradient (wk = flipped/transposed weights, ep: relu_ref). */
 int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in,
                      const void* wk, void* out, const sw_epilogue* ep, sw_stream_t stream);
-/* dW (OIHW f32, caller zero-fills; atomically accumulated) from x [nimg][H][W][Cin] and dy [nimg][H][W][Cout]. */
+/* dW (OIHW f32, overwritten) from x [nimg][H][W][Cin] and dy [nimg][H][W][Cout]; workspace: Cout*9*Cin floats
+ * (split-K partials are accumulated there with f32 atomics in [co][tap][ci] order, then permuted to OIHW). */
 int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
-                     const void* dy, float* dw_oihw, int splitk, sw_stream_t stream);
+                     const void* dy, float* dw_oihw, float* workspace, int splitk, sw_stream_t stream);
 /* OIHW f32 master weights -> kernel layout.  mode 0: wk[co][tap][ci_pad] (forward, ci zero padded to cin_pad);
  * mode 1: wk[ci][8-tap][co] (data gradient: taps flipped, in/out swapped). */
 int sw_conv_weight_prep(int dtype, int mode, int Cout, int Cin, int cin_pad, const float* w_oihw, void* wk,

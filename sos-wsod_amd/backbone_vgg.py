@@ -114,7 +114,7 @@ class _VGGFunction(torch.autograd.Function):
                 w = params[pidx]
                 n, H, W, cin = x_in.shape
                 if w.requires_grad:
-                    dw = torch.zeros(blk.out_channels, cin, 3, 3, device=g.device, dtype=torch.float32)
+                    dw = torch.empty(blk.out_channels, cin, 3, 3, device=g.device, dtype=torch.float32)
                     npix = n * H * W
                     tiles = ((blk.out_channels + 127) // 128) * ((9 * cin + 127) // 128)
                     splitk = max(1, min(32, (512 + tiles - 1) // tiles, npix // 2048 if npix >= 4096 else 1))

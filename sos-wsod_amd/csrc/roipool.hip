@@ -20,7 +20,6 @@
 
 namespace {
 
-constexpr int FWD_CH = 64;
 
 struct RoiGeom {
   int batch, start_w, start_h;
@@ -41,21 +40,40 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int P
   return g;
 }
 
-template <typename T>
+// Forward.  Workgroup = (roi, slab of 64*VEC channels), 4 waves split the PHxPW bins, lane = VEC adjacent channels
+// (bf16: one 4-byte load carries 2 channels => 256-byte wave loads).  The scan of a bin is latency bound (every NHWC
+// row segment is an L2 / Infinity-Cache hit), so a wave keeps 8 pixel loads in flight: the bin window is walked as a
+// flat list (h ascending, w ascending — a wave-uniform scalar cursor), 8 elements per batch; slots past the end
+// re-read the last pixel, which can never win the strict '>' => the first maximum in row-major order is kept
+// exactly as in the serial reference.
+template <typename T, int VEC> struct VecLoad;
+template <> struct VecLoad<float, 1> {
+  __device__ static __forceinline__ void load(const float* p, float* v) { v[0] = *p; }
+};
+template <> struct VecLoad<unsigned short, 2> {
+  __device__ static __forceinline__ void load(const unsigned short* p, float* v) {
+    const unsigned int u = *(const unsigned int*)p;
+    v[0] = __uint_as_float(u << 16); v[1] = __uint_as_float(u & 0xFFFF0000u);
+  }
+};
+
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, int PH, int PW, float scale,
                                                            const T* __restrict__ feat, const float* __restrict__ rois,
                                                            const float* __restrict__ row_scale, float row_scale_add,
                                                            T* __restrict__ out, int* __restrict__ argmax) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CH = 64 * VEC;
   const int nb = PH * PW;
-  float* s_val = (float*)smem;                 // [FWD_CH][nb]  (row stride nb: odd for 7x7 -> conflict free)
-  int* s_arg = (int*)(smem + (size_t)FWD_CH * nb * 4);
-  const int r = blockIdx.x, c0 = blockIdx.y * FWD_CH;
+  float* s_val = (float*)smem;                 // [CH][nb]  (row stride nb: odd for 7x7 -> conflict free)
+  int* s_arg = (int*)(smem + (size_t)CH * nb * 4);
+  const int r = blockIdx.x, c0 = blockIdx.y * CH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const RoiGeom g = roi_geom(rois + (long)r * 5, scale, PH, PW);
   const float mul = row_scale ? (row_scale[r] + row_scale_add) : 1.0f;
-  const int c = c0 + lane;
-  const T* fimg = feat + (long)g.batch * H * W * C;
+  const int c = c0 + lane * VEC;
+  const bool cok = c < C;                       // C % VEC == 0 is checked by the host
+  const T* fimg = feat + (long)g.batch * H * W * C + (cok ? c : 0);
   for (int b = wave; b < nb; b += 4) {
     const int ph = b / PW, pw = b - ph * PW;
     int hs = (int)floorf(__fmul_rn((float)ph, g.bin_h));
@@ -65,32 +83,36 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, 
     hs = min(max(hs + g.start_h, 0), H); he = min(max(he + g.start_h, 0), H);
     ws = min(max(ws + g.start_w, 0), W); we = min(max(we + g.start_w, 0), W);
     const bool empty = (he <= hs) || (we <= ws);
-    float mv = empty ? 0.f : -FLT_MAX;
-    int mi = -1;
-    if (c < C) {
-      // 8 loads in flight per lane: the scan is latency bound (every pixel row segment comes from L2 / MALL).
-      // Out-of-range slots re-read the last valid pixel; with the strict '>' a duplicate can never win, so the
-      // first maximum in row-major order is kept exactly as the serial scan keeps it.
-      for (int h = hs; h < he; ++h) {
-        const T* row = fimg + ((long)h * W) * C + c;
-        for (int w = ws; w < we; w += 8) {
-          float v[8]; int wi[8];
+    float mv[VEC]; int mi[VEC];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { wi[u] = min(w + u, we - 1); v[u] = Elem<T>::load(row + (long)wi[u] * C); }
+    for (int q = 0; q < VEC; ++q) { mv[q] = empty ? 0.f : -FLT_MAX; mi[q] = -1; }
+    const int n = empty ? 0 : (he - hs) * (we - ws);
+    int hh = hs, ww = ws;                        // wave-uniform cursor over the window, row-major
+    for (int e0 = 0; e0 < n; e0 += 8) {
+      float v[8][VEC]; int idx[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (v[u] > mv) { mv = v[u]; mi = h * W + wi[u]; }
-        }
+      for (int u = 0; u < 8; ++u) {
+        idx[u] = hh * W + ww;
+        VecLoad<T, VEC>::load(fimg + (long)idx[u] * C, v[u]);
+        if (e0 + u + 1 < n) { ++ww; if (ww == we) { ww = ws; ++hh; } }
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q)
+          if (v[u][q] > mv[q]) { mv[q] = v[u][q]; mi[q] = idx[u]; }
     }
-    s_val[lane * nb + b] = __fmul_rn(mv, mul);
-    s_arg[lane * nb + b] = mi;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      s_val[(lane * VEC + q) * nb + b] = __fmul_rn(mv[q], mul);
+      s_arg[(lane * VEC + q) * nb + b] = mi[q];
+    }
   }
   __syncthreads();
-  const int nch = min(FWD_CH, C - c0);
+  const int nch = min(CH, C - c0);
   const int total = nch * nb;
   const long obase = ((long)r * C + c0) * nb;
-  for (int i = threadIdx.x; i < total; i += 256) {
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
     Elem<T>::store(out + obase + i, s_val[i]);
     argmax[obase + i] = s_arg[i];
   }
@@ -154,17 +176,19 @@ extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH,
                                float row_scale_add, void* out, int32_t* argmax, hipStream_t stream) {
   (void)nimg;
   if (R <= 0) return 0;
-  const size_t lds = (size_t)FWD_CH * PH * PW * 8;
+  if (dtype != SW_BF16 && dtype != SW_F32) return -1;
+  const int vec = dtype == SW_BF16 ? 2 : 1;
+  if (C % vec) return -5;
+  const int ch = 64 * vec;
+  const size_t lds = (size_t)ch * PH * PW * 8;
   if (lds > 64 * 1024) return -6;
-  dim3 grid(R, (C + FWD_CH - 1) / FWD_CH), block(256);
+  dim3 grid(R, (C + ch - 1) / ch), block(256);
   if (dtype == SW_BF16)
-    hipLaunchKernelGGL(roi_pool_fwd_kernel<unsigned short>, grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
+    hipLaunchKernelGGL((roi_pool_fwd_kernel<unsigned short, 2>), grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
                        (const unsigned short*)feat, rois, row_scale, row_scale_add, (unsigned short*)out, argmax);
-  else if (dtype == SW_F32)
-    hipLaunchKernelGGL(roi_pool_fwd_kernel<float>, grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
-                       (const float*)feat, rois, row_scale, row_scale_add, (float*)out, argmax);
   else
-    return -1;
+    hipLaunchKernelGGL((roi_pool_fwd_kernel<float, 1>), grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
+                       (const float*)feat, rois, row_scale, row_scale_add, (float*)out, argmax);
   SW_CHECK_LAUNCH();
   return 0;
 }

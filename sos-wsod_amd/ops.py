@@ -106,12 +106,15 @@ def conv3x3(x, wk, out, dilation, ep, tag=None):
     return out
 
 
-def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1):
+def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1, workspace=None, tag=None):
+    """dw_oihw (Cout, Cin, 3, 3) f32 is overwritten; workspace: Cout*9*Cin floats (allocated here if None)"""
     _need_gpu(x, dy, dw_oihw)
     n, H, W, Cin = x.shape
     Cout = dy.shape[3]
-    check(lib.sw_conv3x3_wgrad(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(dy), _p(dw_oihw), splitk, _stream()),
-          "sw_conv3x3_wgrad")
+    if workspace is None:
+        workspace = torch.empty(Cout * 9 * Cin, device=x.device, dtype=torch.float32)
+    check(_launch(tag, lambda: lib.sw_conv3x3_wgrad(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(dy), _p(dw_oihw),
+                                                    _p(workspace), splitk, _stream())), "sw_conv3x3_wgrad")
     return dw_oihw
 
 
