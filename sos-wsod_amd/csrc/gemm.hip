@@ -39,6 +39,8 @@ template <typename T> struct GT;
 template <> struct GT<unsigned short> { static constexpr int EPC = 8, BK = 64; };   // bf16
 template <> struct GT<float> { static constexpr int EPC = 4, BK = 32; };
 
+__device__ const u32x4 g_zero_chunk = {0u, 0u, 0u, 0u};   // source of zero fill for out-of-range 16-byte chunks
+
 constexpr int TILE = 128;
 constexpr int LDS_TILE_BYTES = 16384;
 
@@ -213,8 +215,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
   }
 
-  u32x4 ra[4], rb[4];
-  auto stage_load = [&](int kt) {       // called with kt = 0, 1, 2, ... in order (OP_CONV_B state is incremental)
+  // two register sets: the global loads of K-tile t+2 are issued before the MFMAs of tile t and are only waited for
+  // at the end of tile t+1 (counted vmcnt), i.e. a load has a full K-tile + one MFMA block to land.
+  u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+  auto stage_load = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[4]) {   // called with kt = 0, 1, 2, ... in order
     const int kb = kbeg + kt * BK;
     int f_dy = 0, f_dx = 0, f_c = 0;
     if (a_fast) {
@@ -222,7 +226,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       const int ty = tap / 3, tx = tap - ty * 3;
       f_dy = (ty - 1) * g.cDil; f_dx = (tx - 1) * g.cDil;
     }
-    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const u32x4* pa;
@@ -245,11 +248,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       } else {
         pb = b_chunk_ptr<T, BMODE>(g, bn, b_row[i], b_chk[i], kb, kend);
       }
-      ra[i] = pa ? *pa : z;
-      rb[i] = pb ? *pb : z;
+      // Out-of-range chunks read a 16-byte zero constant instead: the select is on the ADDRESS, never on the data.
+      // (A conditional load makes hipcc branch around every load and wait for it; a select on the loaded value
+      // makes it wait for the whole K-tile right after issue — either way the HBM/L2 latency is exposed per K-tile.)
+      typedef const __attribute__((address_space(1))) u32x4* gptr;          // keep these global_load (not flat_load:
+      ra[i] = *(gptr)(pa ? pa : &g_zero_chunk);                             //  flat ops also count on lgkmcnt and would
+      rb[i] = *(gptr)(pb ? pb : &g_zero_chunk);                             //  be waited for before every ds_read use)
     }
   };
-  auto stage_write = [&](int buf) {
+  auto stage_write = [&](int buf, const u32x4 (&ra)[4], const u32x4 (&rb)[4]) {
     char* sa = smem + buf * (2 * LDS_TILE_BYTES);
     char* sb = sa + LDS_TILE_BYTES;
 #pragma unroll
@@ -267,14 +274,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  stage_load(0);
-  stage_write(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nt) stage_load(kt + 1);
-    const char* sa = smem + cur * (2 * LDS_TILE_BYTES);
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * (2 * LDS_TILE_BYTES);
     const char* sb = sa + LDS_TILE_BYTES;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -288,7 +289,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) mma<T>(acc[i][j], fa[i], fb[j]);
     }
-    if (kt + 1 < nt) stage_write(cur ^ 1);
+  };
+
+  stage_load(0, ra0, rb0);
+  stage_write(0, ra0, rb0);
+  if (nt > 1) stage_load(1, ra1, rb1);
+  __syncthreads();
+
+  for (int kt = 0; kt < nt; kt += 2) {
+    // even tile kt lives in LDS buffer 0; set 1 holds tile kt+1 (in flight or landed)
+    if (kt + 2 < nt) stage_load(kt + 2, ra0, rb0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nt) stage_write(1, ra1, rb1);
+    __syncthreads();
+    if (kt + 1 >= nt) break;
+    // odd tile kt+1 lives in LDS buffer 1; set 0 holds tile kt+2
+    if (kt + 3 < nt) stage_load(kt + 3, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nt) stage_write(0, ra0, rb0);
     __syncthreads();
   }
 
