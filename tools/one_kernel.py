@@ -1,0 +1,23 @@
+#!/usr/bin/env python
+"""Run ONE hot-path GEMM/conv shape a few times (for rocprofv3 --pmc passes).  usage: one_kernel.py conv5_3|fc6_fwd|fc6_dgrad|fc6_wgrad"""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import sos_wsod_amd.ops as ops
+which = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dt, dev = torch.bfloat16, "cuda"
+rnd = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(dt)
+if which == "conv5_3":
+    x = rnd(2, 63, 63, 512); wk = rnd(512, 9, 512); b = torch.zeros(512, device=dev); out = torch.empty(2, 63, 63, 512, device=dev, dtype=dt)
+    ep = ops.make_epilogue(bias=b, relu=True, out_dtype=dt)
+    f = lambda: ops.conv3x3(x, wk, out, 2, ep)
+else:
+    M, D0, D1 = 8000, 25088, 4096
+    X = rnd(M, D0); W1 = rnd(D1, D0); dZ = rnd(M, D1)
+    if which == "fc6_fwd":
+        Y = torch.empty(M, D1, device=dev, dtype=dt); f = lambda: ops.gemm(X, W1, Y, M, D1, D0)
+    elif which == "fc6_dgrad":
+        dX = torch.empty(M, D0, device=dev, dtype=dt); f = lambda: ops.gemm(dZ, W1, dX, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt))
+    else:
+        dW = torch.empty(D1, D0, device=dev); f = lambda: ops.gemm(dZ, X, dW, D1, D0, M, a_kstrided=True, b_kstrided=True)
+for _ in range(n): f()
+torch.cuda.synchronize()
