@@ -67,8 +67,7 @@ class _VGGFunction(torch.autograd.Function):
                 w, b = params[pi], params[pi + 1]
                 pi += 2
                 cin = cur.shape[3]
-                wk = torch.empty(blk.out_channels, 9, cin, device=x.device, dtype=dtype)
-                ops.conv_weight_prep(w, wk, 0, cin)
+                wk = module.staged_weight(w, 0, cin, dtype)
                 out = torch.empty(cur.shape[0], cur.shape[1], cur.shape[2], blk.out_channels, device=x.device, dtype=dtype)
                 ops.conv3x3(cur, wk, out, blk.dilation, ops.make_epilogue(bias=b, relu=True, out_dtype=dtype),
                             tag=f"{blk.tag}.conv{ci + 1}_fwd")
@@ -128,8 +127,7 @@ class _VGGFunction(torch.autograd.Function):
                     break
                 # data gradient: conv with flipped/transposed weights; ReLU mask of the producer fused when the
                 # input is a direct conv output (ci > 0); stage inputs go through the pool backward instead
-                wkd = torch.empty(cin, 9, blk.out_channels, device=g.device, dtype=dtype)
-                ops.conv_weight_prep(w, wkd, 1)
+                wkd = module.staged_weight(w, 1, cin, dtype)
                 dx = torch.empty(n, H, W, cin, device=g.device, dtype=dtype)
                 ref = x_in.view(n * H * W, cin) if ci > 0 else None
                 ops.conv3x3(dz, wkd, dx, blk.dilation, ops.make_epilogue(relu_ref=ref, out_dtype=dtype))
@@ -152,6 +150,7 @@ class VGG16(nn.Module):
         super().__init__()
         self.num_classes = num_classes
         self.compute_dtype = compute_dtype
+        self._wk_cache = {}
         self._out_feature_strides, self._out_feature_channels = {}, {}
         self.stages_and_names = []
         strides = {"plain1": 2, "plain2": 4, "plain3": 8, "plain4": 8 if conv5_dilation == 2 else 16,
@@ -181,6 +180,34 @@ class VGG16(nn.Module):
     @property
     def size_divisibility(self):
         return 0
+
+    def staged_weight(self, w, mode, cin_pad, dtype):
+        """compute-dtype kernel-layout copy of an OIHW master weight (mode 0: forward [co][tap][ci], mode 1: data
+        gradient [ci][8-tap][co]); rebuilt only when the parameter changed (the two backbone calls of an iteration and
+        the backward share one copy)."""
+        key = (ops.param_key(w), mode, cin_pad, dtype)
+        slot = (id(w), mode)
+        hit = self._wk_cache.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        cout, cin = w.shape[:2]
+        shape = (cout, 9, cin_pad) if mode == 0 else (cin, 9, cout)
+        wk = torch.empty(shape, device=w.device, dtype=dtype)
+        ops.conv_weight_prep(w.detach(), wk, mode, cin_pad if mode == 0 else None)
+        self._wk_cache[slot] = (key, wk)
+        return wk
+
+    def stage_all_weights(self, with_dgrad):
+        """build every compute-dtype weight copy on the CURRENT stream (call before forking side streams)"""
+        dtype = self.compute_dtype
+        epc = _epc(dtype)
+        ft = self.first_trainable_conv()
+        for si, blk in enumerate(self.blocks):
+            for ci, c in enumerate(blk.convs()):
+                cin = c.weight.shape[1]
+                self.staged_weight(c.weight, 0, (cin + epc - 1) // epc * epc, dtype)
+                if with_dgrad and ft is not None and (si, ci) > ft:
+                    self.staged_weight(c.weight, 1, cin, dtype)
 
     def first_trainable_conv(self):
         for si, blk in enumerate(self.blocks):

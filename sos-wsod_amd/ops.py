@@ -51,6 +51,12 @@ class KernelTimer:
 
 
 TIMER = None
+PARAM_EPOCH = 0        # bumped by HipSGD.step (the kernel updates parameters behind torch's version counter)
+
+
+def param_key(p):
+    """cache key of a parameter's current value (compute-dtype weight copies are rebuilt only when it changes)"""
+    return (p.data_ptr(), p._version, PARAM_EPOCH)
 
 
 def _launch(tag, fn):

@@ -47,6 +47,8 @@ class MultiInputRCNN(nn.Module):
         self.input_format, self.vis_period = input_format, vis_period
         self.register_buffer("pixel_mean", torch.Tensor(pixel_mean).view(-1, 1, 1))
         self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1))
+        self.dual_stream = True
+        self._side = None
         self._mean_host = [float(v) for v in pixel_mean]
         self._std_host = [float(v) for v in pixel_std]
 
@@ -81,8 +83,25 @@ class MultiInputRCNN(nn.Module):
         x = batched_inputs[0]
         for k in ("proposals1", "proposals1_flip", "proposals2", "proposals2_flip"):
             assert k in x
-        f1 = self.backbone.forward_nhwc(self._views_to_nhwc([x["image1"], x["image1_flip"]]))
-        f2 = self.backbone.forward_nhwc(self._views_to_nhwc([x["image2"], x["image2_flip"]]))
+        # the two scales are independent until the ROI heads: run them on two HIP streams so that their ~250-workgroup
+        # conv4/conv5 launches (one workgroup per CU each) share the CUs (64 KiB LDS per workgroup -> two per CU)
+        x1 = self._views_to_nhwc([x["image1"], x["image1_flip"]])
+        x2 = self._views_to_nhwc([x["image2"], x["image2_flip"]])
+        if self.dual_stream:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self.backbone.stage_all_weights(with_dgrad=torch.is_grad_enabled())
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                f2 = self.backbone.forward_nhwc(x2)
+            f1 = self.backbone.forward_nhwc(x1)
+            main.wait_stream(self._side)
+            x2.record_stream(self._side)
+            f2.record_stream(main)
+        else:
+            f1 = self.backbone.forward_nhwc(x1)
+            f2 = self.backbone.forward_nhwc(x2)
         features1 = {"plain5": f1.permute(0, 3, 1, 2)}
         features2 = {"plain5": f2.permute(0, 3, 1, 2)}
         proposals_list = [[x["proposals1"]], [x["proposals1_flip"]], [x["proposals2"]], [x["proposals2_flip"]]]

@@ -19,6 +19,7 @@ class HipSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
+        ops.PARAM_EPOCH += 1
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
