@@ -44,6 +44,7 @@ typedef struct sw_epilogue {
   int ref_dtype;
   int out_dtype;              /* dtype of C */
   int accumulate_atomic;      /* C is f32 and is atomically accumulated (required when splitk > 1) */
+  float* absmax_out;          /* optional device scalar (caller zero-fills): atomicMax of |stored value| (sw_gemm only) */
 } sw_epilogue;
 
 /* ---- dense contractions (reference: cuBLAS via torch Linear — box_head.py:88-90,
@@ -89,10 +90,14 @@ int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, fl
                     const float* rois, int R, const float* row_scale, float row_scale_add, void* out,
                     int32_t* argmax, sw_stream_t stream);
 /* dfeat [nimg][H][W][C] (dtype, fully overwritten) = scatter-add of dout by argmax, times the same row scale,
- * times (relu_ref > 0) when relu_ref != NULL (relu_ref has feat's layout/dtype). */
+ * times (relu_ref > 0) when relu_ref != NULL (relu_ref has feat's layout/dtype).
+ * dout_absmax (device scalar >= max|dout|, e.g. from sw_absmax or a GEMM epilogue; may be NULL): selects the
+ * 64-bit fixed-point LDS accumulation (bitwise reproducible, ~3x faster than LDS float atomics); NULL => f32 atomics. */
 int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
                     const int32_t* argmax, const float* rois, int R, const float* row_scale, float row_scale_add,
-                    const void* relu_ref, void* dfeat, sw_stream_t stream);
+                    const void* relu_ref, const float* dout_absmax, void* dfeat, sw_stream_t stream);
+/* out[0] = max |x[i]| (f32 device scalar, overwritten). */
+int sw_absmax(int dtype, long n, const void* x, float* out, sw_stream_t stream);
 
 /* ---- WSDDN MIL head: scores, image-level BCE, gradient (reference: fast_rcnn_wsddn.py:556-567 forward,
  *      :340-375 loss; autograd backward) -------------------------------------------------------------------

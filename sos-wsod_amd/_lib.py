@@ -20,7 +20,7 @@ class Epilogue(ctypes.Structure):
     _fields_ = [
         ("bias", c_void_p), ("relu", c_int), ("drop_mask", c_void_p), ("ld_drop", c_long), ("drop_scale", c_float),
         ("relu_ref", c_void_p), ("ld_ref", c_long), ("ref_scale", c_float), ("ref_dtype", c_int),
-        ("out_dtype", c_int), ("accumulate_atomic", c_int),
+        ("out_dtype", c_int), ("accumulate_atomic", c_int), ("absmax_out", c_void_p),
     ]
 
 
@@ -43,7 +43,8 @@ SIGNATURES = {
     "sw_roi_pool_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
                                 c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "sw_roi_pool_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
-                                c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+                                c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sw_absmax": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "sw_wsddn_mil": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_long, c_void_p, c_void_p]),
     "sw_mean_views": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),

@@ -34,6 +34,7 @@ struct GemmArgs {
   const uint8_t* drop; long ldd; float drop_scale;
   const void* ref; long ldr; float ref_scale; int ref_bf16;
   int relu, out_bf16, atomic, oihw_cin;
+  float* absmax;                   // optional: atomicMax of |stored value| (IEEE bits of a non-negative float are monotone)
 };
 
 template <typename T> struct GT;
@@ -239,53 +240,68 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
     }
   }
 
-  auto stage_issue = [&](int kt) {          // kt = 0, 1, 2, ... in order (the slot state is incremental)
-    const int kb = kbeg + kt * BK;
-    char* sbase = smem + (kt % STAGES) * STAGE_BYTES;
-    const bool tail = kb + BK > kend;         // only the last K-tile of a split can be partial (wave-uniform)
-#pragma unroll
-    for (int i = 0; i < A_SLOTS; ++i) {
-      bool ok;
-      const char* p = a_ptr[i];
-      if (AMODE == OP_CONV_A_GEN) {               // generic path (first layer, Cin padded to 8/4): per chunk tap math
-        const int k0 = kb + a_k[i];
-        ok = a_ok[i] && k0 < kend;
-        const int kc = ok ? k0 : 0;
-        const int tap = kc / g.cC, c0 = kc - tap * g.cC;
-        const int ty = tap / 3, tx = tap - ty * 3;
-        const int dy = (ty - 1) * g.cDil, dx = (tx - 1) * g.cDil;
-        const int yy = a_py[i] + dy, xx = a_px[i] + dx;
-        ok = ok && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
-        p = a_pix[i] + (((long)dy * g.cW + dx) * g.cC + c0 - a_k[i]) * (long)sizeof(T);
-      } else if (AMODE == OP_CONV_A) {
-        ok = a_tapok[i];                          // K = 9*Cin is a multiple of BK here: no partial K-tile
-      } else {
-        ok = a_ok[i];
-        if (tail) ok = ok && (kb + a_k[i] < kend);
-      }
-      const void* src = ok ? (const void*)p : (const void*)&g_zero_chunk;
-      __builtin_amdgcn_global_load_lds((gvoid)src, (lvoid)(sbase + (i * NW + wave) * 1024), 16, 0, 0);
-      a_ptr[i] += a_step;
+  // DMA issue of one K-tile, split into per-slot pieces so that the main loop can spread them between the MFMA
+  // sub-steps (right after the barrier every wave would otherwise issue its whole group while the matrix pipe idles).
+  int is_kb = 0; char* is_base = nullptr; bool is_tail = false;
+  auto issue_begin = [&](int kt) {          // kt = 0, 1, 2, ... in order (the slot state is incremental)
+    is_kb = kbeg + kt * BK;
+    is_base = smem + (kt % STAGES) * STAGE_BYTES;
+    is_tail = is_kb + BK > kend;            // only the last K-tile of a split can be partial (wave-uniform)
+  };
+  auto issue_a = [&](int i) {
+    const int kb = is_kb;
+    bool ok;
+    const char* p = a_ptr[i];
+    if (AMODE == OP_CONV_A_GEN) {               // generic path (first layer, Cin padded to 8/4): per chunk tap math
+      const int k0 = kb + a_k[i];
+      ok = a_ok[i] && k0 < kend;
+      const int kc = ok ? k0 : 0;
+      const int tap = kc / g.cC, c0 = kc - tap * g.cC;
+      const int ty = tap / 3, tx = tap - ty * 3;
+      const int dy = (ty - 1) * g.cDil, dx = (tx - 1) * g.cDil;
+      const int yy = a_py[i] + dy, xx = a_px[i] + dx;
+      ok = ok && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
+      p = a_pix[i] + (((long)dy * g.cW + dx) * g.cC + c0 - a_k[i]) * (long)sizeof(T);
+    } else if (AMODE == OP_CONV_A) {
+      ok = a_tapok[i];                          // K = 9*Cin is a multiple of BK here: no partial K-tile
+    } else {
+      ok = a_ok[i];
+      if (is_tail) ok = ok && (kb + a_k[i] < kend);
     }
+    const void* src = ok ? (const void*)p : (const void*)&g_zero_chunk;
+    __builtin_amdgcn_global_load_lds((gvoid)src, (lvoid)(is_base + (i * NW + wave) * 1024), 16, 0, 0);
+    a_ptr[i] += a_step;
+  };
+  auto issue_b = [&](int i) {
+    const int kb = is_kb;
+    bool ok = b_ok[i];
+    if (is_tail) ok = ok && (kb + b_k[i] < kend);
+    if (BMODE == OP_CONV_B) {
+      const int yy = bq_py[i] + b_dy[i], xx = bq_px[i] + b_dx[i];
+      ok = ok && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
+      bq_px[i] += BK;
+      while (bq_px[i] >= g.cW) { bq_px[i] -= g.cW; ++bq_py[i]; }
+      while (bq_py[i] >= g.cH) bq_py[i] -= g.cH;
+    }
+    const void* src = ok ? (const void*)b_ptr[i] : (const void*)&g_zero_chunk;
+    __builtin_amdgcn_global_load_lds((gvoid)src, (lvoid)(is_base + GA::BYTES + (i * NW + wave) * 1024), 16, 0, 0);
+    b_ptr[i] += b_step;
+  };
+  auto issue_end = [&]() {
     if (a_fast) {
       if (++a_tt == tiles_per_tap) { a_tt = 0; ++a_tap; if (a_tap < 9) conv_a_set_tap(a_tap, 0); }
     }
-#pragma unroll
-    for (int i = 0; i < B_SLOTS; ++i) {
-      bool ok = b_ok[i];
-      if (tail) ok = ok && (kb + b_k[i] < kend);
-      if (BMODE == OP_CONV_B) {
-        const int yy = bq_py[i] + b_dy[i], xx = bq_px[i] + b_dx[i];
-        ok = ok && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
-        bq_px[i] += BK;
-        while (bq_px[i] >= g.cW) { bq_px[i] -= g.cW; ++bq_py[i]; }
-        while (bq_py[i] >= g.cH) bq_py[i] -= g.cH;
-      }
-      const void* src = ok ? (const void*)b_ptr[i] : (const void*)&g_zero_chunk;
-      __builtin_amdgcn_global_load_lds((gvoid)src, (lvoid)(sbase + GA::BYTES + (i * NW + wave) * 1024), 16, 0, 0);
-      b_ptr[i] += b_step;
-    }
   };
+  // slots [lo, hi) of the combined A|B slot list
+  auto issue_range = [&](int lo, int hi) {
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i)
+      if (i >= lo && i < hi) issue_a(i);
+#pragma unroll
+    for (int i = 0; i < B_SLOTS; ++i)
+      if (A_SLOTS + i >= lo && A_SLOTS + i < hi) issue_b(i);
+  };
+  auto stage_issue = [&](int kt) { issue_begin(kt); issue_range(0, GROUP); issue_end(); };
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -295,7 +311,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  auto compute = [&](int kt) {
+  auto compute = [&](int kt, bool refill) {
     const char* sa = smem + (kt % STAGES) * STAGE_BYTES;
     const char* sb = sa + GA::BYTES;
     u32x4 fa[MI], fb[NI], na[MI], nb[NI];
@@ -315,6 +331,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) mma<T>(acc[i][j], fa[i], fb[j]);
+      if (refill) issue_range(s * GROUP / 4, (s + 1) * GROUP / 4);     // this sub-step's share of the next DMA group
       if (s < 3) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) fa[i] = na[i];
@@ -334,12 +351,20 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
     if (kt + STAGES - 2 < nt) wait_vmcnt<GROUP * (STAGES - 2)>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();           // everybody's DMA for tile kt landed; everybody finished computing tile kt-1
-    if (kt + STAGES - 1 < nt) stage_issue(kt + STAGES - 1);      // refill the stage tile kt-1 lived in
-    compute(kt);
+    const bool refill = kt + STAGES - 1 < nt;                    // refill the stage tile kt-1 lived in
+    if (STAGES >= 3) {                                           // deep ring: spread the DMA issue over the MFMA sub-steps
+      if (refill) issue_begin(kt + STAGES - 1);
+      compute(kt, refill);
+      if (refill) issue_end();
+    } else {                                                     // 2 stages: the DMA needs the whole tile time to land
+      if (refill) stage_issue(kt + STAGES - 1);                  // (measured: interleaving costs 10-25 % here)
+      compute(kt, false);
+    }
   }
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const int r = lane & 31, h = lane >> 5;
+  float vmax = 0.f;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -366,11 +391,16 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
         } else {
           o = (long)m * g.ldc + n;
         }
+        vmax = fmaxf(vmax, fabsf(v));
         if (g.atomic) atomicAdd((float*)g.C + o, v);
         else if (g.out_bf16) ((unsigned short*)g.C)[o] = f32_to_bf16_bits(v);
         else ((float*)g.C)[o] = v;
       }
     }
+  if (g.absmax) {
+    vmax = wave_reduce_max(vmax);
+    if (lane == 0) atomicMax((unsigned int*)g.absmax, __float_as_uint(vmax));
+  }
 }
 
 template <typename T, int AMODE, int BMODE, int BM, int BN, int STAGES, int WTM = 64, int WTN = 64>
@@ -448,7 +478,7 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
   if (ep) {
     g.bias = ep->bias; g.drop = ep->drop_mask; g.ldd = ep->ld_drop; g.drop_scale = ep->drop_scale;
     g.ref = ep->relu_ref; g.ldr = ep->ld_ref; g.ref_scale = ep->ref_scale; g.ref_bf16 = ep->ref_dtype == SW_BF16;
-    g.relu = ep->relu; g.out_bf16 = ep->out_dtype == SW_BF16; g.atomic = ep->accumulate_atomic;
+    g.relu = ep->relu; g.out_bf16 = ep->out_dtype == SW_BF16; g.atomic = ep->accumulate_atomic; g.absmax = ep->absmax_out;
   }
   const int am = a_kstrided ? OP_KSTRIDED : OP_KCONTIG, bmo = b_kstrided ? OP_KSTRIDED : OP_KCONTIG;
   return dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, am, bmo, splitk, stream)

@@ -15,6 +15,7 @@
 // no global atomics, no cross-workgroup traffic (a per-channel argmax scatters 64 lanes to 64 different
 // rows, which global float atomics serve ~17x below their peak rate).
 #include <float.h>
+#include <stdlib.h>
 #include "common.h"
 #include "soswsod_hip.h"
 
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CH = 64 * VEC;
   const int nb = PH * PW;
-  float* s_val = (float*)smem;                 // [CH][nb]  (row stride nb: odd for 7x7 -> conflict free)
-  int* s_arg = (int*)(smem + (size_t)CH * nb * 4);
+  int* s_arg = (int*)smem;                     // [CH][nb]  (row stride nb: odd for 7x7 -> conflict free)
+  T* s_val = (T*)(smem + (size_t)CH * nb * 4); // [CH][nb]  stored in the output dtype: 6 B/entry -> 4 workgroups per CU
   const int r = blockIdx.x, c0 = blockIdx.y * CH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const RoiGeom g = roi_geom(rois + (long)r * 5, scale, PH, PW);
@@ -88,23 +89,23 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, 
     for (int q = 0; q < VEC; ++q) { mv[q] = empty ? 0.f : -FLT_MAX; mi[q] = -1; }
     const int n = empty ? 0 : (he - hs) * (we - ws);
     int hh = hs, ww = ws;                        // wave-uniform cursor over the window, row-major
-    for (int e0 = 0; e0 < n; e0 += 8) {
-      float v[8][VEC]; int idx[8];
+    for (int e0 = 0; e0 < n; e0 += 6) {         // 6 loads in flight (typical bins hold 6..16 pixels)
+      float v[6][VEC]; int idx[6];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 6; ++u) {
         idx[u] = hh * W + ww;
         VecLoad<T, VEC>::load(fimg + (long)idx[u] * C, v[u]);
         if (e0 + u + 1 < n) { ++ww; if (ww == we) { ww = ws; ++hh; } }
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 6; ++u)
 #pragma unroll
         for (int q = 0; q < VEC; ++q)
           if (v[u][q] > mv[q]) { mv[q] = v[u][q]; mi[q] = idx[u]; }
     }
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
-      s_val[(lane * VEC + q) * nb + b] = __fmul_rn(mv[q], mul);
+      Elem<T>::store(&s_val[(lane * VEC + q) * nb + b], __fmul_rn(mv[q], mul));
       s_arg[(lane * VEC + q) * nb + b] = mi[q];
     }
   }
@@ -112,9 +113,21 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, 
   const int nch = min(CH, C - c0);
   const int total = nch * nb;
   const long obase = ((long)r * C + c0) * nb;
-  for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    Elem<T>::store(out + obase + i, s_val[i]);
-    argmax[obase + i] = s_arg[i];
+#ifdef ROI_FWD_NOSTORE
+  if (total < 0)
+#endif
+  if ((total & 7) == 0 && ((obase * (long)sizeof(T)) & 15) == 0) {
+    // 16-byte stores: 8 (bf16) / 4 (f32) values and 4 argmax words per lane
+    constexpr int VPV = 16 / (int)sizeof(T);
+    for (int i = threadIdx.x; i < total / VPV; i += blockDim.x)
+      *(u32x4*)(out + obase + (long)i * VPV) = *(const u32x4*)(s_val + i * VPV);
+    for (int i = threadIdx.x; i < total / 4; i += blockDim.x)
+      *(u32x4*)(argmax + obase + (long)i * 4) = *(const u32x4*)(s_arg + i * 4);
+  } else {
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      out[obase + i] = s_val[i];
+      argmax[obase + i] = s_arg[i];
+    }
   }
 }
 
@@ -169,6 +182,94 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
   }
 }
 
+// Backward, fixed-point path.  Measured on MI355X (tools/roi_bench.py): LDS float atomics (ds_add_f32) run ~3.4x
+// slower than LDS integer atomics (ds_add_u32 / ds_add_u64 ~ plain ds_write rate) and set the kernel's time.  So the slab
+// accumulates in 64-bit fixed point: every product grad*scale (rounded to f32 exactly as the float path does) is
+// converted with 2^FRAC, FRAC chosen from max|grad|*max|scale| so that 2^40 bounds one term and 4*R terms (a pixel is
+// the argmax of at most 4 bins per ROI) cannot overflow 63 bits.  Integer adds are associative => the result is
+// BITWISE REPRODUCIBLE and at least as accurate as f32 accumulation.
+// Workgroup = (image, slab of CB channels, CB % 4 == 0) owning H*W*CB int64 in LDS; a lane loads 4 gradients and 4
+// argmax words of 4 ROIs (16-byte aligned, 8 loads in flight) before scattering.
+template <typename T>
+__global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int C, int nb, int CB,
+                                                               const T* __restrict__ dout, const int* __restrict__ argmax,
+                                                               const float* __restrict__ rois, int R,
+                                                               const float* __restrict__ row_scale, float row_scale_add,
+                                                               const float* __restrict__ dout_absmax,
+                                                               const T* __restrict__ relu_ref, T* __restrict__ dfeat) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[32];
+  unsigned long long* acc = (unsigned long long*)smem;          // [H*W][CB] two's-complement fixed point
+  const int img = blockIdx.y, c0 = blockIdx.x * CB;
+  const int npix = H * W;
+  for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) acc[i] = 0ull;
+  float smax = 0.f;                                             // max |row_scale + add| (wave/block reduce, tiny)
+  if (row_scale) { for (int r = threadIdx.x; r < R; r += blockDim.x) smax = fmaxf(smax, fabsf(row_scale[r] + row_scale_add)); }
+  else smax = 1.f;
+  smax = block_reduce_max(smax, red);
+  smax = __shfl(smax, 0, 64);
+  const float bound = dout_absmax[0] * smax;
+  int frac = 0;
+  if (bound > 0.f && bound < 3.0e38f) frac = 40 - (ilogbf(bound) + 1);
+  __syncthreads();
+  const int nvec = (CB * nb) / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  for (int r0 = wave * 4; r0 < R; r0 += nwave * 4) {
+    for (int j = lane; j < nvec; j += 64) {
+      u32x4 a4[4]; float d[4][4]; bool on[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u;
+        on[u] = r < R && (int)rois[(long)r * 5] == img;
+        const long base = ((long)(on[u] ? r : 0) * C + c0) * nb + (long)j * 4;
+        a4[u] = *(const u32x4*)(argmax + base);
+        if (sizeof(T) == 2) {
+          const u32x2 v = *(const u32x2*)(dout + base);
+          d[u][0] = __uint_as_float(v[0] << 16); d[u][1] = __uint_as_float(v[0] & 0xFFFF0000u);
+          d[u][2] = __uint_as_float(v[1] << 16); d[u][3] = __uint_as_float(v[1] & 0xFFFF0000u);
+        } else {
+          const u32x4 v = *(const u32x4*)(dout + base);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[u][e] = __uint_as_float(v[e]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!on[u]) continue;
+        const float mul = row_scale ? (row_scale[r0 + u] + row_scale_add) : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int a = (int)a4[u][e];
+          const int cc = (j * 4 + e) / nb;
+          if (a >= 0) {
+            const long long q = __float2ll_rn(scalbnf(__fmul_rn(d[u][e], mul), frac));
+            atomicAdd(&acc[a * CB + cc], (unsigned long long)q);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  T* dimg = dfeat + (long)img * npix * C;
+  const T* rimg = relu_ref ? relu_ref + (long)img * npix * C : nullptr;
+  for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) {
+    const int p = i / CB, cc = i - p * CB;
+    float v = scalbnf((float)(long long)acc[i], -frac);
+    if (rimg && !(Elem<T>::load(rimg + (long)p * C + c0 + cc) > 0.f)) v = 0.f;
+    Elem<T>::store(dimg + (long)p * C + c0 + cc, v);
+  }
+}
+
+// max |x| over n elements -> out[0] (f32; caller zero-fills).  |x| as IEEE bits is monotone => integer atomicMax.
+template <typename T>
+__global__ void absmax_kernel(long n, const T* __restrict__ x, float* __restrict__ out) {
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(Elem<T>::load(x + i)));
+  m = wave_reduce_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(m));
+}
+
 }  // namespace
 
 extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale,
@@ -180,7 +281,7 @@ extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH,
   const int vec = dtype == SW_BF16 ? 2 : 1;
   if (C % vec) return -5;
   const int ch = 64 * vec;
-  const size_t lds = (size_t)ch * PH * PW * 8;
+  const size_t lds = (size_t)ch * PH * PW * (4 + (dtype == SW_BF16 ? 2 : 4));
   if (lds > 64 * 1024) return -6;
   dim3 grid(R, (C + ch - 1) / ch), block(256);
   if (dtype == SW_BF16)
@@ -195,9 +296,36 @@ extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH,
 
 extern "C" int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
                                const int32_t* argmax, const float* rois, int R, const float* row_scale,
-                               float row_scale_add, const void* relu_ref, void* dfeat, hipStream_t stream) {
+                               float row_scale_add, const void* relu_ref, const float* dout_absmax, void* dfeat,
+                               hipStream_t stream) {
   // channel slab per workgroup: power of two, H*W*CB*4 <= 64 KiB (two 1024-thread workgroups per CU) and enough
   // slabs to give every CU work (C/CB * nimg >= 512 where the map allows)
+  // fixed-point path: CB in {8, 4} with H*W*CB*8 bytes of LDS; needs max|dout| (device scalar)
+  int cbx = 8;
+  while (cbx >= 4 && ((size_t)H * W * cbx * 8 > 128 * 1024 || (C % cbx))) cbx >>= 1;
+  if (cbx >= 4 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) &&
+      getenv("SW_ROI_FLOAT_ATOMICS") == nullptr) {
+    const size_t ldsx = (size_t)H * W * cbx * 8;
+    dim3 gridx(C / cbx, nimg), blockx(1024);
+    hipError_t ex;
+    if (dtype == SW_BF16) {
+      auto k = roi_pool_bwd_fx_kernel<unsigned short>;
+      ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+      if (ex != hipSuccess) return (int)ex;
+      hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, PH * PW, cbx, (const unsigned short*)dout, argmax, rois, R,
+                         row_scale, row_scale_add, dout_absmax, (const unsigned short*)relu_ref, (unsigned short*)dfeat);
+    } else if (dtype == SW_F32) {
+      auto k = roi_pool_bwd_fx_kernel<float>;
+      ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+      if (ex != hipSuccess) return (int)ex;
+      hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, PH * PW, cbx, (const float*)dout, argmax, rois, R, row_scale,
+                         row_scale_add, dout_absmax, (const float*)relu_ref, (float*)dfeat);
+    } else {
+      return -1;
+    }
+    SW_CHECK_LAUNCH();
+    return 0;
+  }
   int CB = 64;
   while (CB > 1 && ((size_t)H * W * CB * 4 > 64 * 1024 || (C % CB) || (C / CB) * nimg < 512)) CB >>= 1;
   const size_t lds = (size_t)H * W * CB * 4;
@@ -219,6 +347,22 @@ extern "C" int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH,
   } else {
     return -1;
   }
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_absmax(int dtype, long n, const void* x, float* out, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  if (n <= 0) return 0;
+  long blocks = (n + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == SW_BF16)
+    hipLaunchKernelGGL(absmax_kernel<unsigned short>, dim3((unsigned)blocks), dim3(256), 0, stream, n, (const unsigned short*)x, out);
+  else if (dtype == SW_F32)
+    hipLaunchKernelGGL(absmax_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, n, (const float*)x, out);
+  else
+    return -1;
   SW_CHECK_LAUNCH();
   return 0;
 }

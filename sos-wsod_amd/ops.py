@@ -72,7 +72,7 @@ def _need_gpu(*ts):
 
 
 def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_ref=None, ref_scale=1.0,
-                  out_dtype=torch.float32, atomic=False):
+                  out_dtype=torch.float32, atomic=False, absmax_out=None):
     ep = Epilogue()
     ep.bias = None if bias is None else bias.data_ptr()
     ep.relu = int(relu)
@@ -85,7 +85,8 @@ def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_re
     ep.ref_dtype = SW_F32 if relu_ref is None else dt(relu_ref)
     ep.out_dtype = dt(out_dtype)
     ep.accumulate_atomic = int(atomic)
-    ep._keepalive = (bias, drop_mask, relu_ref)     # the struct holds raw pointers only
+    ep.absmax_out = None if absmax_out is None else absmax_out.data_ptr()
+    ep._keepalive = (bias, drop_mask, relu_ref, absmax_out)     # the struct holds raw pointers only
     return ep
 
 
@@ -163,12 +164,23 @@ def roi_pool_fwd(feat, rois, out, argmax, spatial_scale, PH, PW, row_scale=None,
     return out, argmax
 
 
-def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_add=0.0, relu_ref=None):
+def absmax(x, out=None):
+    if out is None:
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+    check(lib.sw_absmax(dt(x), x.numel(), _p(x), _p(out), _stream()), "sw_absmax")
+    return out
+
+
+def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_add=0.0, relu_ref=None, dout_absmax="auto"):
+    """dout_absmax: device scalar >= max|dout| (selects the fixed-point accumulation), "auto" = compute it here,
+    None = LDS float atomics."""
     _need_gpu(dout, argmax, rois, dfeat)
     n, H, W, C = dfeat.shape
     R = rois.shape[0]
+    if isinstance(dout_absmax, str):
+        dout_absmax = absmax(dout)
     check(lib.sw_roi_pool_bwd(dt(dfeat), n, H, W, C, PH, PW, _p(dout), _p(argmax), _p(rois), R, _p(row_scale),
-                              float(row_scale_add), _p(relu_ref), _p(dfeat), _stream()), "sw_roi_pool_bwd")
+                              float(row_scale_add), _p(relu_ref), _p(dout_absmax), _p(dfeat), _stream()), "sw_roi_pool_bwd")
     return dfeat
 
 

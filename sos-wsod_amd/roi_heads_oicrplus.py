@@ -303,7 +303,9 @@ class OICRPlusHeads(nn.Module):
         dfeats = [None, None]
         if feat_req[0] or feat_req[1]:
             dpooled = torch.empty(M, D0, device=dev, dtype=dt_)
-            ops.gemm(dz1, W1, dpooled, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt_), tag="fc6_dgrad")
+            amax = torch.zeros(1, device=dev, dtype=torch.float32)      # max|dpooled| -> fixed-point scale of the ROI scatter
+            ops.gemm(dz1, W1, dpooled, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt_, absmax_out=amax),
+                     tag="fc6_dgrad")
             P = self.box_pooler.output_size
             for s in range(2):
                 if not feat_req[s]:
@@ -311,7 +313,8 @@ class OICRPlusHeads(nn.Module):
                 f = st["feats"][s]
                 df = torch.empty_like(f)
                 ops.roi_pool_bwd(dpooled[2 * s * R:(2 * s + 2) * R], st["argmax"][2 * s * R:(2 * s + 2) * R], st["rois"][s], df,
-                                 P, P, row_scale=st["obj"][2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0, relu_ref=f)
+                                 P, P, row_scale=st["obj"][2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0, relu_ref=f,
+                                 dout_absmax=amax)
                 dfeats[s] = df.permute(0, 3, 1, 2)          # NCHW view, like the forward feature
         # split the packed gradients back onto the 10 predictor tensors (row slices are contiguous views)
         dparams = [dW1, db1, dW2, db2]
