@@ -131,10 +131,10 @@ def main():
     from sos_wsod_amd.trainer import Trainer, init_distributed
     import torch.distributed as dist
 
-    rank, local_rank, world = init_distributed()
+    rank, local_rank, world = init_distributed(backend=os.environ.get("SW_DIST_BACKEND"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)"
     assert torch.cuda.is_available(), "bench.py measures the HIP path; there is no CPU fallback"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", int(os.environ.get("SW_BENCH_DEVICE", local_rank)))   # override: DDP smoke test on 1 GPU
     torch.cuda.set_device(device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 

@@ -144,6 +144,25 @@ int sw_oicr_refine_loss(int V, int R, int K, const float* logits, long ld, int c
                         float* loss_view, float* probs, float* dlogits, long ld_d,
                         const float* grad_scale, float* workspace, sw_stream_t stream);
 
+/* ---- inference (reference: OICRPlusHeads._forward_box_test roi_heads_oicrplus.py:432-475, predict_probs_K /
+ *      predict_boxes_K fast_rcnn_oicr.py:674-735, Box2BoxTransform.apply_deltas box_regression.py:73-110,
+ *      fast_rcnn_inference_single_image fast_rcnn_oicr.py:86-148 incl. torchvision batched_nms) ----------------
+ * sw_oicr_predict: logits f32 [R][ld] with refine_k blocks (cls_score K+1 | bbox_pred 4K) starting at base_col, one
+ * every round_stride columns; boxes [R][4].  all_scores [R][K+1] = mean softmax, all_boxes [R][4K] = decoded mean
+ * deltas (dw, dh clamped to scale_clamp), NOT clipped.  reg_weights4: HOST float[4]. */
+int sw_oicr_predict(int R, int K, int refine_k, const float* logits, long ld, int base_col, int round_stride,
+                    const float* boxes, const float* reg_weights4, float scale_clamp, float* all_scores,
+                    float* all_boxes, sw_stream_t stream);
+/* sw_detect_postprocess: clip boxes to the image, keep score > score_thresh (background column excluded), per-class
+ * greedy NMS (IoU > nms_thresh on boxes offset by class*(max_coord+1), as batched_nms forms them), first topk by
+ * score.  Outputs det_count[1], det_boxes [topk][4], det_scores, det_classes, det_rows (proposal index).
+ * workspace >= sw_detect_workspace_bytes(K, topk).  Limits: R <= 16384, K*topk <= 16384. */
+long sw_detect_workspace_bytes(int K, int topk);
+int sw_detect_postprocess(int R, int K, const float* all_scores, const float* all_boxes, int img_h, int img_w,
+                          float score_thresh, float nms_thresh, int topk, int32_t* det_count, float* det_boxes,
+                          float* det_scores, int32_t* det_classes, int32_t* det_rows, void* workspace,
+                          sw_stream_t stream);
+
 /* ---- small utilities ------------------------------------------------------------------------------------ */
 /* out[n] = sum_m X[m][ld..] (column sums; bias gradients).  out f32, overwritten. */
 int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, sw_stream_t stream);

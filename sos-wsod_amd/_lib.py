@@ -55,6 +55,11 @@ SIGNATURES = {
     "sw_oicr_refine_loss": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, _F4, c_void_p, c_void_p, c_void_p, c_long, c_void_p,
                                     c_void_p, c_void_p]),
+    "sw_oicr_predict": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, _F4, c_float, c_void_p,
+                                c_void_p, c_void_p]),
+    "sw_detect_workspace_bytes": (c_long, [c_int, c_int]),
+    "sw_detect_postprocess": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_colsum": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -337,6 +337,149 @@ __global__ __launch_bounds__(1024) void mine_label_kernel(int R, int ncol, int K
   }
 }
 
+// ------------------------------------------------------------------------------------------- inference (a23)
+// all_scores[r][j] = mean_k softmax(cls_score_k logits)[j]; all_boxes[r][4c..] = apply_deltas(mean_k deltas_k, proposal)
+// (predict_probs_K / predict_boxes_K fast_rcnn_oicr.py:674-735, Box2BoxTransform.apply_deltas box_regression.py:73-110)
+__global__ __launch_bounds__(256) void predict_kernel(int R, int K, int RK, const float* __restrict__ logits, long ld,
+                                                      int base_col, int round_stride, const float* __restrict__ boxes,
+                                                      float wx, float wy, float ww, float wh, float scale_clamp,
+                                                      float* __restrict__ all_scores, float* __restrict__ all_boxes) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int K1 = K + 1;
+  const float* L = logits + (long)r * ld;
+  float* S = all_scores + (long)r * K1;
+  for (int j = 0; j < K1; ++j) S[j] = 0.f;
+  for (int k = 0; k < RK; ++k) {                       // probs += softmax(scores_k)  (:727-729)
+    const float* x = L + base_col + k * round_stride;
+    float m = -FLT_MAX;
+    for (int j = 0; j < K1; ++j) m = fmaxf(m, x[j]);
+    float z = 0.f;
+    for (int j = 0; j < K1; ++j) z += expf(x[j] - m);
+    for (int j = 0; j < K1; ++j) S[j] += expf(x[j] - m) / z;
+  }
+  for (int j = 0; j < K1; ++j) S[j] = __fdiv_rn(S[j], (float)RK);
+  const float* b = boxes + (long)r * 4;
+  const float w = b[2] - b[0], h = b[3] - b[1];
+  const float cx = b[0] + 0.5f * w, cy = b[1] + 0.5f * h;
+  float* O = all_boxes + (long)r * 4 * K;
+  for (int c = 0; c < K; ++c) {
+    float d[4];
+    for (int q = 0; q < 4; ++q) {
+      float acc = 0.f;
+      for (int k = 0; k < RK; ++k) acc += L[base_col + k * round_stride + K1 + 4 * c + q];   // sum in branch order (:691-693)
+      d[q] = __fdiv_rn(acc, (float)RK);
+    }
+    const float dx = __fdiv_rn(d[0], wx), dy = __fdiv_rn(d[1], wy);
+    const float dw = fminf(__fdiv_rn(d[2], ww), scale_clamp), dh = fminf(__fdiv_rn(d[3], wh), scale_clamp);
+    const float px = __fadd_rn(__fmul_rn(dx, w), cx), py = __fadd_rn(__fmul_rn(dy, h), cy);
+    const float pw = __fmul_rn(expf(dw), w), ph = __fmul_rn(expf(dh), h);
+    O[4 * c + 0] = px - __fmul_rn(0.5f, pw); O[4 * c + 1] = py - __fmul_rn(0.5f, ph);
+    O[4 * c + 2] = px + __fmul_rn(0.5f, pw); O[4 * c + 3] = py + __fmul_rn(0.5f, ph);
+  }
+}
+
+__device__ __forceinline__ float clipf(float v, float hi) { return fminf(fmaxf(v, 0.f), hi); }
+
+// max coordinate over the clipped boxes that pass the score filter (boxes.max() inside batched_nms)
+__global__ void det_maxcoord_kernel(int R, int K, float thresh, float imw, float imh, const float* __restrict__ scores,
+                                    const float* __restrict__ boxes, float* __restrict__ out) {
+  float m = 0.f;
+  const long total = (long)R * K;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / K; const int c = (int)(i - r * K);
+    if (scores[r * (K + 1) + c] > thresh) {
+      const float* b = boxes + r * 4 * K + 4 * c;
+      m = fmaxf(m, fmaxf(fmaxf(clipf(b[0], imw), clipf(b[2], imw)), fmaxf(clipf(b[1], imh), clipf(b[3], imh))));
+    }
+  }
+  m = wave_reduce_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(m));
+}
+
+// one workgroup per class: score filter, sort (score desc, proposal asc), greedy NMS on the class-offset boxes exactly as
+// torchvision batched_nms forms them (box + class * (max_coord + 1)), keep the first `topk` (fast_rcnn_oicr.py:124-140)
+__global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float thresh, float nms_thresh, int topk,
+                                                             float imw, float imh, const float* __restrict__ scores,
+                                                             const float* __restrict__ boxes,
+                                                             const float* __restrict__ maxcoord,
+                                                             int* __restrict__ cls_count, int* __restrict__ cls_rows,
+                                                             float* __restrict__ cls_scores) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int NP = next_pow2(R);
+  unsigned long long* keys = (unsigned long long*)smem;           // [NP]
+  unsigned char* sup = (unsigned char*)(smem + (size_t)NP * 8);     // [R]
+  const float off = __fmul_rn((float)c, __fadd_rn(maxcoord[0], 1.0f));
+  for (int i = tid; i < NP; i += blockDim.x) {
+    const bool ok = i < R && scores[(long)i * (K + 1) + c] > thresh;
+    keys[i] = ok ? make_key(scores[(long)i * (K + 1) + c], (unsigned)i) : ~0ull;
+    if (i < R) sup[i] = 0;
+  }
+  __syncthreads();
+  bitonic_sort(keys, NP);
+  int nk = 0;
+  for (int t = 0; t < R && nk < topk; ++t) {
+    const unsigned long long key = keys[t];
+    if (key == ~0ull) break;                                        // uniform
+    const int p = (int)(key & 0xFFFFFFFFu);
+    if (sup[p]) continue;
+    if (tid == 0) { cls_rows[c * topk + nk] = p; cls_scores[c * topk + nk] = scores[(long)p * (K + 1) + c]; }
+    ++nk;
+    const float* bp = boxes + (long)p * 4 * K + 4 * c;
+    float a[4] = {__fadd_rn(clipf(bp[0], imw), off), __fadd_rn(clipf(bp[1], imh), off), __fadd_rn(clipf(bp[2], imw), off),
+                  __fadd_rn(clipf(bp[3], imh), off)};
+    for (int u = t + 1 + tid; u < R; u += blockDim.x) {
+      const unsigned long long ku = keys[u];
+      if (ku == ~0ull) continue;
+      const int q = (int)(ku & 0xFFFFFFFFu);
+      if (sup[q]) continue;
+      const float* bq = boxes + (long)q * 4 * K + 4 * c;
+      float b[4] = {__fadd_rn(clipf(bq[0], imw), off), __fadd_rn(clipf(bq[1], imh), off), __fadd_rn(clipf(bq[2], imw), off),
+                    __fadd_rn(clipf(bq[3], imh), off)};
+      if (iou_nms(a, b) > nms_thresh) sup[q] = 1;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) cls_count[c] = nk;
+}
+
+// merge the per-class lists: global order = score desc, ties by filtered position (r*K + c) asc; first topk
+__global__ __launch_bounds__(1024) void det_merge_kernel(int K, int topk, float imw, float imh, const float* __restrict__ boxes,
+                                                         const int* __restrict__ cls_count, const int* __restrict__ cls_rows,
+                                                         const float* __restrict__ cls_scores, int* __restrict__ det_count,
+                                                         float* __restrict__ det_boxes, float* __restrict__ det_scores,
+                                                         int* __restrict__ det_classes, int* __restrict__ det_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n_slots = K * topk, NP = next_pow2(n_slots), tid = threadIdx.x;
+  unsigned long long* keys = (unsigned long long*)smem;
+  __shared__ int s_n;
+  if (tid == 0) { int n = 0; for (int c = 0; c < K; ++c) n += cls_count[c]; s_n = n; }
+  for (int i = tid; i < NP; i += blockDim.x) {
+    unsigned long long key = ~0ull;
+    if (i < n_slots) {
+      const int c = i / topk, j = i - c * topk;
+      if (j < cls_count[c]) key = make_key(cls_scores[i], (unsigned)(cls_rows[i] * K + c));
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  bitonic_sort(keys, NP);
+  const int n = min(s_n, topk);
+  for (int t = tid; t < n; t += blockDim.x) {
+    const unsigned int pos = (unsigned int)(keys[t] & 0xFFFFFFFFu);
+    const int r = pos / K, c = pos - r * K;
+    const float* b = boxes + (long)r * 4 * K + 4 * c;
+    det_boxes[4 * t + 0] = clipf(b[0], imw); det_boxes[4 * t + 1] = clipf(b[1], imh);
+    det_boxes[4 * t + 2] = clipf(b[2], imw); det_boxes[4 * t + 3] = clipf(b[3], imh);
+    // score: recover from the sorted key (exact bits)
+    const unsigned int ob = ~(unsigned int)(keys[t] >> 32);
+    det_scores[t] = __uint_as_float((ob & 0x80000000u) ? (ob & 0x7FFFFFFFu) : ~ob);
+    det_classes[t] = c; det_rows[t] = r;
+  }
+  if (tid == 0) det_count[0] = n;
+}
+
 }  // namespace
 
 extern "C" int sw_wsddn_mil(int V, int R, int K, const float* logits, long ld, int cls_col, int det_col,
@@ -382,6 +525,54 @@ extern "C" int sw_oicr_mine_label(int R, int ncol, int K, const float* scores, c
   hipLaunchKernelGGL(mine_label_kernel, dim3(1), dim3(1024), lds, stream, R, ncol, K, scores, gt_classes, G, boxes, top_k,
                      score_thresh, nms_thresh, iou_bg, iou_fg, lab_class, lab_weight, lab_index, pgt_count, pgt_index,
                      pgt_class, pgt_score, (char*)workspace);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_oicr_predict(int R, int K, int refine_k, const float* logits, long ld, int base_col, int round_stride,
+                               const float* boxes, const float* reg_weights4, float scale_clamp, float* all_scores,
+                               float* all_boxes, hipStream_t stream) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(predict_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, K, refine_k, logits, ld, base_col,
+                     round_stride, boxes, reg_weights4[0], reg_weights4[1], reg_weights4[2], reg_weights4[3], scale_clamp,
+                     all_scores, all_boxes);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" long sw_detect_workspace_bytes(int K, int topk) { return (long)K * topk * 8 + (long)K * 4 + 64; }
+
+extern "C" int sw_detect_postprocess(int R, int K, const float* all_scores, const float* all_boxes, int img_h, int img_w,
+                                     float score_thresh, float nms_thresh, int topk, int32_t* det_count, float* det_boxes,
+                                     float* det_scores, int32_t* det_classes, int32_t* det_rows, void* workspace,
+                                     hipStream_t stream) {
+  if (R > 16384 || (long)K * topk > 16384 || topk < 1) return -6;
+  char* ws = (char*)workspace;
+  float* maxcoord = (float*)ws;                                    // [1] (+pad)
+  int* cls_count = (int*)(ws + 64);                                // [K]
+  int* cls_rows = cls_count + K;                                   // [K][topk]
+  float* cls_scores = (float*)(cls_rows + (long)K * topk);         // [K][topk]
+  hipError_t e = hipMemsetAsync(maxcoord, 0, 64, stream);
+  if (e != hipSuccess) return (int)e;
+  if (R <= 0) return (int)hipMemsetAsync(det_count, 0, 4, stream);
+  const long total = (long)R * K;
+  long blocks = (total + 255) / 256; if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(det_maxcoord_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, R, K, score_thresh, (float)img_w,
+                     (float)img_h, all_scores, all_boxes, maxcoord);
+  SW_CHECK_LAUNCH();
+  int np = 64; while (np < R) np <<= 1;
+  const size_t lds1 = (size_t)np * 8 + (size_t)R;
+  e = hipFuncSetAttribute((const void*)det_class_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(det_class_nms_kernel, dim3(K), dim3(1024), lds1, stream, R, K, score_thresh, nms_thresh, topk,
+                     (float)img_w, (float)img_h, all_scores, all_boxes, maxcoord, cls_count, cls_rows, cls_scores);
+  SW_CHECK_LAUNCH();
+  int np2 = 64; while (np2 < K * topk) np2 <<= 1;
+  const size_t lds2 = (size_t)np2 * 8;
+  e = hipFuncSetAttribute((const void*)det_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(det_merge_kernel, dim3(1), dim3(1024), lds2, stream, K, topk, (float)img_w, (float)img_h, all_boxes,
+                     cls_count, cls_rows, cls_scores, det_count, det_boxes, det_scores, det_classes, det_rows);
   SW_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,54 @@
+"""Inference of the OICR+ heads: the reference's `OICRPlusHeads._forward_box_test`
+(roi_heads_oicrplus.py:432-475) -> `OICROutputLayers.inference` with the K refinement branches averaged
+(fast_rcnn_oicr.py:584-614, 674-735) -> `fast_rcnn_inference_single_image` (:86-148).
+ROIPool -> x(objectness+1) -> fc6/fc7 (no dropout) -> the packed predictor GEMM -> sw_oicr_predict -> sw_detect_postprocess;
+the only host synchronisation is reading the detection count to size the returned Instances."""
+import math
+
+import torch
+
+from . import ops
+from .structures import Boxes, Instances
+
+SCALE_CLAMP = math.log(1000.0 / 16)      # box_regression.py:12
+
+
+@torch.no_grad()
+def oicr_inference(heads, features, proposals):
+    dt_ = heads.compute_dtype
+    f = features[heads.box_in_features[-1]]
+    dev = f.device
+    feat = f.permute(0, 2, 3, 1).contiguous()
+    if feat.dtype != dt_:
+        feat = feat.to(dt_)
+    assert len(proposals) == feat.shape[0] == 1, "one image per call (rcnn_multi.py:148)"
+    prop = proposals[0]
+    K = heads.num_classes
+    boxes = prop.proposal_boxes.tensor.to(device=dev, dtype=torch.float32).contiguous()
+    obj = prop.objectness_logits.to(device=dev, dtype=torch.float32).contiguous()
+    R = boxes.shape[0]
+    P = heads.box_pooler.output_size
+    C = feat.shape[3]
+    rois = torch.cat([torch.zeros(R, 1, device=dev), boxes], 1).contiguous()
+    pooled = torch.empty(R, C * P * P, device=dev, dtype=dt_)
+    argmax = torch.empty(R, C * P * P, device=dev, dtype=torch.int32)
+    ops.roi_pool_fwd(feat, rois, pooled, argmax, heads.box_pooler.scale, P, P, row_scale=obj, row_scale_add=1.0)
+    h = heads.box_head(pooled)                                        # eval: no dropout
+    params = [p.detach() for p in heads._flat_params()]
+    Wh, bh = heads._pack_head_weights(params, dev)
+    LD = heads.ld_head
+    logits = torch.empty(R, LD, device=dev, dtype=torch.float32)
+    ops.gemm(h, Wh, logits, R, LD, h.shape[1], ep=ops.make_epilogue(bias=bh, out_dtype=torch.float32))
+    all_scores = torch.empty(R, K + 1, device=dev, dtype=torch.float32)
+    all_boxes = torch.empty(R, 4 * K, device=dev, dtype=torch.float32)
+    ops.oicr_predict(logits, R, K, heads.refine_K, 2 * K, 5 * K + 1, boxes, heads.bbox_reg_weights, SCALE_CLAMP, all_scores,
+                     all_boxes)
+    H, W = prop.image_size
+    cnt, dboxes, dscores, dclasses, drows = ops.detect_postprocess(all_scores, all_boxes, H, W, heads.test_score_thresh,
+                                                                   heads.test_nms_thresh, heads.test_topk_per_image)
+    n = int(cnt.item())
+    result = Instances((H, W))
+    result.pred_boxes = Boxes(dboxes[:n])
+    result.scores = dscores[:n]
+    result.pred_classes = dclasses[:n].to(torch.int64)
+    return [result], all_scores.unsqueeze(0), all_boxes.unsqueeze(0)

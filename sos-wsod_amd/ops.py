@@ -278,3 +278,24 @@ def scale_cols(src_f32, colscale, dst, M, N):
     check(lib.sw_scale_cols(dt(dst), M, N, _p(src_f32), src_f32.stride(0), _p(colscale), _p(dst), dst.stride(0), _stream()),
           "sw_scale_cols")
     return dst
+
+
+def oicr_predict(logits, R, K, refine_k, base_col, round_stride, boxes, reg_weights, scale_clamp, all_scores, all_boxes):
+    rw = (ctypes.c_float * 4)(*[float(v) for v in reg_weights])
+    check(lib.sw_oicr_predict(R, K, refine_k, _p(logits), logits.stride(0), base_col, round_stride, _p(boxes), rw,
+                              float(scale_clamp), _p(all_scores), _p(all_boxes), _stream()), "sw_oicr_predict")
+
+
+def detect_postprocess(all_scores, all_boxes, img_h, img_w, score_thresh, nms_thresh, topk):
+    """-> (count[1] i32, boxes [topk,4], scores [topk], classes [topk] i32, rows [topk] i32) device tensors"""
+    R, K1 = all_scores.shape
+    K = K1 - 1
+    dev = all_scores.device
+    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    boxes = torch.zeros(topk, 4, device=dev); scores = torch.zeros(topk, device=dev)
+    classes = torch.zeros(topk, device=dev, dtype=torch.int32); rows = torch.zeros(topk, device=dev, dtype=torch.int32)
+    ws = torch.empty(int(lib.sw_detect_workspace_bytes(K, topk)), device=dev, dtype=torch.uint8)
+    check(lib.sw_detect_postprocess(R, K, _p(all_scores), _p(all_boxes), int(img_h), int(img_w), float(score_thresh),
+                                    float(nms_thresh), int(topk), _p(cnt), _p(boxes), _p(scores), _p(classes), _p(rows), _p(ws),
+                                    _stream()), "sw_detect_postprocess")
+    return cnt, boxes, scores, classes, rows

@@ -21,7 +21,7 @@ def init_distributed(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if backend == "nccl" and "SW_BENCH_DEVICE" not in os.environ:
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world

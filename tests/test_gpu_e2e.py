@@ -146,3 +146,23 @@ def test_backbone_backward_matches_autograd(dtype):
         worst[k] = err
     print({k: f"{v:.1e}" for k, v in worst.items()})
     assert max(worst.values()) < 1e-4, worst
+
+
+def test_inference_matches_reference_golden(golden_dir):
+    """a23: _forward_box_test + fast_rcnn_inference_single_image (mean of 4 softmaxes / delta sets, decode, clip,
+    score > 1e-6, per-class NMS 0.3, top-100) vs the reference's own output on the same inputs (fp32 mode)."""
+    from sos_wsod_amd.structures import Boxes, Instances
+    g, P, views, gt, masks, model = _setup("s0", golden_dir, torch.float32)
+    ref = np.load(os.path.join(golden_dir, "infer_s0.npz"))
+    model.eval()
+    v = views[0]
+    H, W = v["image"].shape[1:]
+    p = Instances((H, W)); p.proposal_boxes = Boxes(torch.from_numpy(v["boxes"])); p.objectness_logits = torch.from_numpy(v["obj"])
+    out = model([{"image": torch.from_numpy(v["image"]), "proposals": p}])
+    inst = out[0]["instances"]
+    assert len(inst) == len(ref["scores"])
+    assert np.array_equal(inst.pred_classes.cpu().numpy(), ref["pred_classes"])        # detection order and classes: exact
+    np.testing.assert_allclose(inst.scores.cpu().numpy(), ref["scores"], rtol=1e-4)
+    np.testing.assert_allclose(inst.pred_boxes.tensor.cpu().numpy(), ref["pred_boxes"], rtol=1e-4, atol=1e-2)
+    res, all_scores, all_boxes = model.inference([{"image": torch.from_numpy(v["image"]), "proposals": p}], do_postprocess=False)
+    np.testing.assert_allclose(all_scores[0].cpu().numpy(), ref["all_scores"].reshape(all_scores[0].shape), rtol=1e-4, atol=1e-9)

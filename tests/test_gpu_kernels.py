@@ -291,3 +291,25 @@ def test_preprocess_colsum_sgd_dropout(ops):
     ops.dropout_mask(keep, seed=1234, offset=0, p=0.5)
     frac = keep.float().mean().item()
     assert abs(frac - 0.5) < 5e-3
+
+
+@pytest.mark.parametrize("R,K", [(600, 20), (300, 80)])
+def test_detect_postprocess_vs_oracle(ops, R, K):
+    """per-class NMS on class-offset clipped boxes + global top-100 (fast_rcnn_oicr.py:86-148) — order bit exact"""
+    g = torch.Generator().manual_seed(70)
+    sc = torch.softmax(torch.randn(R, K + 1, generator=g) * 3, 1)
+    ctr = torch.rand(R, K, 2, generator=g) * torch.tensor([320.0, 240.0]); wh = torch.rand(R, K, 2, generator=g) * 120 + 4
+    bx = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).reshape(R, 4 * K)          # partly outside the image -> clipping
+    H, W, thr, nms_thr, topk = 240, 320, 0.02, 0.3, 100
+    # oracle: same steps as oracle.oicr_plus_inference's tail
+    s = sc[:, :-1].numpy(); pb = bx.numpy().reshape(R, K, 4).copy()
+    pb[..., 0::2] = pb[..., 0::2].clip(0, W); pb[..., 1::2] = pb[..., 1::2].clip(0, H)
+    r_idx, c_idx = np.nonzero(s > np.float32(thr))
+    bsel, ssel = pb[r_idx, c_idx], s[r_idx, c_idx]
+    off = c_idx.astype(np.float32) * np.float32(bsel.max() + 1)
+    keep = O.nms_keep((bsel + off[:, None]).astype(np.float32), ssel, nms_thr)[:topk]
+    cnt, dboxes, dscores, dclasses, drows = ops.detect_postprocess(sc.cuda(), bx.cuda(), H, W, thr, nms_thr, topk)
+    n = int(cnt.item())
+    assert n == len(keep)
+    assert np.array_equal(dclasses[:n].cpu().numpy(), c_idx[keep]) and np.array_equal(drows[:n].cpu().numpy(), r_idx[keep])
+    assert np.array_equal(dscores[:n].cpu().numpy(), ssel[keep]) and np.array_equal(dboxes[:n].cpu().numpy(), bsel[keep])
