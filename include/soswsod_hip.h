@@ -59,8 +59,10 @@ int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, int K, cons
  * Used for forward (ep: bias+relu) and for the data gradient (wk = flipped/transposed weights, ep: relu_ref). */
 int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in,
                      const void* wk, void* out, const sw_epilogue* ep, sw_stream_t stream);
-/* dW (OIHW f32, overwritten) from x [nimg][H][W][Cin] and dy [nimg][H][W][Cout]; workspace: Cout*9*Cin floats
- * (split-K partials are accumulated there with f32 atomics in [co][tap][ci] order, then permuted to OIHW). */
+/* dW (OIHW f32, overwritten) from x [nimg][H][W][Cin] and dy [nimg][H][W][Cout].  workspace: at least
+ * sw_conv3x3_wgrad_workspace_floats(...) floats: every K-split stores its partial [co][tap][ci] tile into its own
+ * slab (plain stores), a second kernel adds the slabs in fixed order and permutes to OIHW (deterministic). */
+long sw_conv3x3_wgrad_workspace_floats(int dtype, int nimg, int H, int W, int Cin, int Cout, int splitk);
 int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                      const void* dy, float* dw_oihw, float* workspace, int splitk, sw_stream_t stream);
 /* OIHW f32 master weights -> kernel layout.  mode 0: wk[co][tap][ci_pad] (forward, ci zero padded to cin_pad);

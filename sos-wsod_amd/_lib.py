@@ -35,6 +35,7 @@ SIGNATURES = {
                                  c_void_p]),
     "sw_conv3x3_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_void_p]),
+    "sw_conv3x3_wgrad_workspace_floats": (c_long, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sw_conv_weight_prep": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_maxpool2x2_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_maxpool2x2_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,

@@ -34,6 +34,8 @@ struct GemmArgs {
   const uint8_t* drop; long ldd; float drop_scale;
   const void* ref; long ldr; float ref_scale; int ref_bf16;
   int relu, out_bf16, atomic, oihw_cin;
+  unsigned a_bytes, b_bytes;       // extents of the A / B operands (buffer descriptors' num_records)
+  long slab_stride;                // > 0: split z stores its partial tile to C + z*slab_stride (plain stores, no atomics)
   float* absmax;                   // optional: atomicMax of |stored value| (IEEE bits of a non-negative float are monotone)
 };
 
@@ -143,71 +145,74 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
   const int wm = wave / NWN, wn = wave % NWN;
 
   // ---- per-thread DMA slots: slot i owns physical chunk L = i*NT + tid of the operand's LDS image.
-  // All address arithmetic is incremental: per K-tile a slot costs one pointer add, one bound compare and the DMA
-  // itself (the first version recomputed pointers, taps and bounds per K-tile: ~160 VALU + ~200 SALU instructions per
-  // wave per K-tile against 16 MFMAs — the kernel was instruction-issue bound, SQ counters in profiles/).
-  typedef const __attribute__((address_space(1))) void* gvoid;
+  // The DMA is a raw BUFFER load to LDS (buffer_load_dwordx4 ... offen lds): per slot a 32-bit byte offset in a VGPR
+  // (fixed for the plain GEMM modes), the K-tile advance in the wave-uniform SGPR soffset, and zero fill for rows /
+  // taps / K-tails outside the operand by handing the hardware an offset beyond num_records (out-of-range buffer loads
+  // return 0) — no pointer selects, no 64-bit adds.  (Recomputing pointers, taps and bounds per K-tile cost ~160 VALU +
+  // ~200 SALU instructions per wave per K-tile against 8-16 MFMAs: the kernel was instruction-issue bound; profiles/.)
   typedef __attribute__((address_space(3))) void* lvoid;
+  constexpr unsigned INVALID = 0xFFFFFF00u;                // >= num_records of every operand (checked by the host)
+  constexpr unsigned ES = (unsigned)sizeof(T);
   constexpr bool a_fast = (AMODE == OP_CONV_A);            // Cin % BK == 0: the tap is uniform per K-tile
-  constexpr bool a_conv = (AMODE == OP_CONV_A || AMODE == OP_CONV_A_GEN);
   const int tiles_per_tap = a_fast ? g.cC / BK : 1;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)g.b_bytes, 0x00020000);
 
-  const char* a_ptr[A_SLOTS];      // source of this slot for the NEXT K-tile to be issued
-  bool a_ok[A_SLOTS];              // row/column (and, conv: tap) validity
-  int a_k[A_SLOTS];                // k index this slot starts at inside a K-tile (bound check against kend)
-  int a_py[A_SLOTS], a_px[A_SLOTS], a_pb[A_SLOTS];
-  const char* a_pix[A_SLOTS];
-  long a_step = 0;
+  unsigned a_v[A_SLOTS];           // byte offset of this slot (valid rows) or INVALID
+  bool a_ok[A_SLOTS];
+  int a_k[A_SLOTS];                // k index this slot starts at inside a K-tile (tail check against kend)
+  int a_py[A_SLOTS], a_px[A_SLOTS];
+  unsigned a_pix[A_SLOTS];         // conv: byte offset of (pixel, logical chunk) before the tap shift
+  unsigned a_sstep = 0;            // soffset advance per K-tile
 #pragma unroll
   for (int i = 0; i < A_SLOTS; ++i) {
     const int L = i * NT + tid;
     const int row = L / GA::CPR, chk = (L % GA::CPR) ^ GA::swz(row);      // logical chunk fetched into physical slot L
-    a_py[i] = a_px[i] = a_pb[i] = 0; a_pix[i] = nullptr;
+    a_py[i] = a_px[i] = 0; a_pix[i] = 0;
     if (AMODE == OP_KCONTIG) {
       const int m = m0 + row;
       a_ok[i] = m < g.M; a_k[i] = chk * EPC;
-      a_ptr[i] = (const char*)((const T*)g.A + (long)(a_ok[i] ? m : 0) * g.lda + kbeg + chk * EPC);
-      a_step = (long)BK * sizeof(T);
+      a_v[i] = a_ok[i] ? (unsigned)(((long)m * g.lda + kbeg + chk * EPC) * ES) : INVALID;
+      a_sstep = BK * ES;
     } else if (AMODE == OP_KSTRIDED) {
       const int mm = m0 + chk * EPC;
       a_ok[i] = mm < g.M; a_k[i] = row;
-      a_ptr[i] = (const char*)((const T*)g.A + (long)(kbeg + row) * g.lda + (a_ok[i] ? mm : 0));
-      a_step = (long)BK * g.lda * sizeof(T);
+      a_v[i] = a_ok[i] ? (unsigned)(((long)(kbeg + row) * g.lda + mm) * ES) : INVALID;
+      a_sstep = (unsigned)((long)BK * g.lda * ES);
     } else {   // conv gather: row = output pixel
       const int m = m0 + row;
       const int hw = g.cH * g.cW;
       const int mc = m < g.M ? m : 0;
-      a_pb[i] = mc / hw; const int rem = mc - a_pb[i] * hw;
+      const int pb = mc / hw, rem = mc - pb * hw;
       a_py[i] = rem / g.cW; a_px[i] = rem - a_py[i] * g.cW;
       a_ok[i] = m < g.M; a_k[i] = chk * EPC;
-      a_pix[i] = (const char*)((const T*)g.A + (((long)a_pb[i] * g.cH + a_py[i]) * g.cW + a_px[i]) * g.cC + chk * EPC);
-      a_ptr[i] = a_pix[i];
-      a_step = (long)BK * sizeof(T);
+      a_pix[i] = (unsigned)(((((long)pb * g.cH + a_py[i]) * g.cW + a_px[i]) * g.cC + chk * EPC) * ES);
+      a_v[i] = INVALID;
+      a_sstep = BK * ES;
     }
   }
-  bool a_tapok[A_SLOTS];
   int a_tap = 0, a_tt = 0;          // conv fast path: current tap and K-tiles consumed inside it
-  auto conv_a_set_tap = [&](int tap, int cofs) {
+  auto conv_a_set_tap = [&](int tap) {
     const int ty = tap / 3, tx = tap - ty * 3;
     const int dy = (ty - 1) * g.cDil, dx = (tx - 1) * g.cDil;
+    const int shift = (dy * g.cW + dx) * g.cC * (int)ES;                 // wave-uniform byte shift of this tap
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) {
       const int yy = a_py[i] + dy, xx = a_px[i] + dx;
-      a_tapok[i] = a_ok[i] && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
-      a_ptr[i] = a_pix[i] + (((long)dy * g.cW + dx) * g.cC + cofs) * (long)sizeof(T);
+      const bool ok = a_ok[i] && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
+      a_v[i] = ok ? a_pix[i] + (unsigned)shift : INVALID;
     }
   };
   if (a_fast) {
     a_tap = kbeg / g.cC;
-    const int cofs = kbeg - a_tap * g.cC;
-    a_tt = cofs / BK;
-    conv_a_set_tap(a_tap, cofs);
+    a_tt = (kbeg - a_tap * g.cC) / BK;
+    conv_a_set_tap(a_tap);
   }
 
-  const char* b_ptr[B_SLOTS];
+  unsigned b_v[B_SLOTS];
   bool b_ok[B_SLOTS];
   int b_k[B_SLOTS], bq_py[B_SLOTS], bq_px[B_SLOTS], b_dy[B_SLOTS], b_dx[B_SLOTS];
-  long b_step = 0;
+  unsigned b_sstep = 0, b_vstep = 0;
 #pragma unroll
   for (int i = 0; i < B_SLOTS; ++i) {
     const int L = i * NT + tid;
@@ -216,13 +221,13 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
     if (BMODE == OP_KCONTIG) {
       const int n = n0t + row;
       b_ok[i] = n < g.N; b_k[i] = chk * EPC;
-      b_ptr[i] = (const char*)((const T*)g.B + (long)(b_ok[i] ? n : 0) * g.ldb + kbeg + chk * EPC);
-      b_step = (long)BK * sizeof(T);
+      b_v[i] = b_ok[i] ? (unsigned)(((long)n * g.ldb + kbeg + chk * EPC) * ES) : INVALID;
+      b_sstep = BK * ES;
     } else if (BMODE == OP_KSTRIDED) {
       const int nn = n0t + chk * EPC;
       b_ok[i] = nn < g.N; b_k[i] = row;
-      b_ptr[i] = (const char*)((const T*)g.B + (long)(kbeg + row) * g.ldb + (b_ok[i] ? nn : 0));
-      b_step = (long)BK * g.ldb * sizeof(T);
+      b_v[i] = b_ok[i] ? (unsigned)(((long)(kbeg + row) * g.ldb + nn) * ES) : INVALID;
+      b_sstep = (unsigned)((long)BK * g.ldb * ES);
     } else {   // OP_CONV_B: column = (tap, ci) fixed; row = pixel kbeg+row, advancing BK pixels per K-tile
       const int nn = n0t + chk * EPC;
       b_ok[i] = nn < g.N; b_k[i] = row;
@@ -234,62 +239,67 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
       const int hw = g.cH * g.cW;
       const int pb = k / hw, rem = k - pb * hw;
       bq_py[i] = rem / g.cW; bq_px[i] = rem - bq_py[i] * g.cW;
-      // shifted pixel = linear pixel + dy*W + dx whenever it is inside the image (checked per K-tile)
-      b_ptr[i] = (const char*)((const T*)g.B + ((long)k + (long)b_dy[i] * g.cW + b_dx[i]) * g.cC + c0);
-      b_step = (long)BK * g.cC * sizeof(T);
+      // shifted pixel = linear pixel + dy*W + dx whenever it is inside the image (checked per K-tile); 32-bit
+      // wrap-around arithmetic: an out-of-image (possibly "negative") offset is never used
+      b_v[i] = (unsigned)((((long)k + (long)b_dy[i] * g.cW + b_dx[i]) * g.cC + c0) * ES);
+      b_vstep = (unsigned)((long)BK * g.cC * ES);
     }
   }
 
-  // DMA issue of one K-tile, split into per-slot pieces so that the main loop can spread them between the MFMA
-  // sub-steps (right after the barrier every wave would otherwise issue its whole group while the matrix pipe idles).
-  int is_kb = 0; char* is_base = nullptr; bool is_tail = false;
+  const int adv_q = (BMODE == OP_CONV_B) ? BK / g.cW : 0, adv_r = (BMODE == OP_CONV_B) ? BK - adv_q * g.cW : 0;
+  // DMA issue of one K-tile, split into per-slot pieces so that a deep ring can spread them between the MFMA sub-steps
+  int is_kb = 0, is_kt = 0; char* is_base = nullptr; bool is_tail = false;
   auto issue_begin = [&](int kt) {          // kt = 0, 1, 2, ... in order (the slot state is incremental)
+    is_kt = kt;
     is_kb = kbeg + kt * BK;
     is_base = smem + (kt % STAGES) * STAGE_BYTES;
     is_tail = is_kb + BK > kend;            // only the last K-tile of a split can be partial (wave-uniform)
   };
   auto issue_a = [&](int i) {
-    const int kb = is_kb;
-    bool ok;
-    const char* p = a_ptr[i];
+    unsigned voff = a_v[i], soff;
     if (AMODE == OP_CONV_A_GEN) {               // generic path (first layer, Cin padded to 8/4): per chunk tap math
-      const int k0 = kb + a_k[i];
-      ok = a_ok[i] && k0 < kend;
+      const int k0 = is_kb + a_k[i];
+      bool ok = a_ok[i] && k0 < kend;
       const int kc = ok ? k0 : 0;
       const int tap = kc / g.cC, c0 = kc - tap * g.cC;
       const int ty = tap / 3, tx = tap - ty * 3;
       const int dy = (ty - 1) * g.cDil, dx = (tx - 1) * g.cDil;
       const int yy = a_py[i] + dy, xx = a_px[i] + dx;
       ok = ok && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
-      p = a_pix[i] + (((long)dy * g.cW + dx) * g.cC + c0 - a_k[i]) * (long)sizeof(T);
+      voff = ok ? a_pix[i] + (unsigned)(((dy * g.cW + dx) * g.cC + c0 - a_k[i]) * (int)ES) : INVALID;
+      soff = 0;
     } else if (AMODE == OP_CONV_A) {
-      ok = a_tapok[i];                          // K = 9*Cin is a multiple of BK here: no partial K-tile
+      soff = (unsigned)a_tt * BK * ES;          // K = 9*Cin is a multiple of BK here: no partial K-tile
     } else {
-      ok = a_ok[i];
-      if (is_tail) ok = ok && (kb + a_k[i] < kend);
+      soff = (unsigned)is_kt * a_sstep;
+      if (is_tail && !(is_kb + a_k[i] < kend)) voff = INVALID;
     }
-    const void* src = ok ? (const void*)p : (const void*)&g_zero_chunk;
-    __builtin_amdgcn_global_load_lds((gvoid)src, (lvoid)(is_base + (i * NW + wave) * 1024), 16, 0, 0);
-    a_ptr[i] += a_step;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lvoid)(is_base + (i * NW + wave) * 1024), 16, (int)voff, (int)soff, 0, 0);
   };
   auto issue_b = [&](int i) {
-    const int kb = is_kb;
-    bool ok = b_ok[i];
-    if (is_tail) ok = ok && (kb + b_k[i] < kend);
+    unsigned voff = b_v[i], soff = 0;
     if (BMODE == OP_CONV_B) {
       const int yy = bq_py[i] + b_dy[i], xx = bq_px[i] + b_dx[i];
-      ok = ok && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
-      bq_px[i] += BK;
-      while (bq_px[i] >= g.cW) { bq_px[i] -= g.cW; ++bq_py[i]; }
-      while (bq_py[i] >= g.cH) bq_py[i] -= g.cH;
+      bool ok = b_ok[i] && yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW;
+      if (is_tail) ok = ok && (is_kb + b_k[i] < kend);
+      if (!ok) voff = INVALID;
+      // advance this row's pixel by BK, branch-free: BK = adv_q * W + adv_r (wave-uniform), one carry each
+      int px = bq_px[i] + adv_r, py = bq_py[i] + adv_q;
+      const bool cx = px >= g.cW;
+      px = cx ? px - g.cW : px; py = cx ? py + 1 : py;
+      py = py >= g.cH ? py - g.cH : py;
+      py = py >= g.cH ? py - g.cH : py;           // adv_q + 1 <= 2*H is checked by the host wrapper
+      bq_px[i] = px; bq_py[i] = py;
+      b_v[i] += b_vstep;
+    } else {
+      soff = (unsigned)is_kt * b_sstep;
+      if (is_tail && !(is_kb + b_k[i] < kend)) voff = INVALID;
     }
-    const void* src = ok ? (const void*)b_ptr[i] : (const void*)&g_zero_chunk;
-    __builtin_amdgcn_global_load_lds((gvoid)src, (lvoid)(is_base + GA::BYTES + (i * NW + wave) * 1024), 16, 0, 0);
-    b_ptr[i] += b_step;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lvoid)(is_base + GA::BYTES + (i * NW + wave) * 1024), 16, (int)voff, (int)soff, 0, 0);
   };
   auto issue_end = [&]() {
     if (a_fast) {
-      if (++a_tt == tiles_per_tap) { a_tt = 0; ++a_tap; if (a_tap < 9) conv_a_set_tap(a_tap, 0); }
+      if (++a_tt == tiles_per_tap) { a_tt = 0; ++a_tap; if (a_tap < 9) conv_a_set_tap(a_tap); }
     }
   };
   // slots [lo, hi) of the combined A|B slot list
@@ -392,7 +402,8 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
           o = (long)m * g.ldc + n;
         }
         vmax = fmaxf(vmax, fabsf(v));
-        if (g.atomic) atomicAdd((float*)g.C + o, v);
+        if (g.slab_stride > 0) ((float*)g.C)[o + (long)blockIdx.z * g.slab_stride] = v;
+        else if (g.atomic) atomicAdd((float*)g.C + o, v);
         else if (g.out_bf16) ((unsigned short*)g.C)[o] = f32_to_bf16_bits(v);
         else ((float*)g.C)[o] = v;
       }
@@ -419,7 +430,7 @@ int launch2(GemmArgs& g, int splitk, hipStream_t stream) {
   kps = ((kps + BK - 1) / BK) * BK;
   g.k_per_split = kps;
   splitk = (g.K + kps - 1) / kps;
-  if (splitk > 1 && !g.atomic) return -2;
+  if (splitk > 1 && !g.atomic && g.slab_stride <= 0) return -2;
   dim3 grid(g.patches_m * patches_n * 64, 1, splitk), block(NT);
   auto kern = gemm2_kernel<T, AMODE, BMODE, BM, BN, STAGES, WTM, WTN>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -480,6 +491,12 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
     g.ref = ep->relu_ref; g.ldr = ep->ld_ref; g.ref_scale = ep->ref_scale; g.ref_bf16 = ep->ref_dtype == SW_BF16;
     g.relu = ep->relu; g.out_bf16 = ep->out_dtype == SW_BF16; g.atomic = ep->accumulate_atomic; g.absmax = ep->absmax_out;
   }
+  {
+    const long es = dtype == SW_BF16 ? 2 : 4;
+    const long ab = (long)(a_kstrided ? K : M) * lda * es, bb = (long)(b_kstrided ? K : N) * ldb * es;
+    if (ab >= 0xFFFFFF00L || bb >= 0xFFFFFF00L) return -6;           // 32-bit buffer offsets
+    g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+  }
   const int am = a_kstrided ? OP_KSTRIDED : OP_KCONTIG, bmo = b_kstrided ? OP_KSTRIDED : OP_KCONTIG;
   return dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, am, bmo, splitk, stream)
                           : dispatch_modes<float>(g, am, bmo, splitk, stream);
@@ -501,6 +518,12 @@ extern "C" int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int 
     g.ref = ep->relu_ref; g.ldr = ep->ld_ref; g.ref_scale = ep->ref_scale; g.ref_bf16 = ep->ref_dtype == SW_BF16;
     g.relu = ep->relu; g.out_bf16 = ep->out_dtype == SW_BF16; g.atomic = ep->accumulate_atomic;
   }
+  {
+    const long es = dtype == SW_BF16 ? 2 : 4;
+    const long ab = (long)nimg * H * W * Cin * es, bb = (long)Cout * 9 * Cin * es;
+    if (ab >= 0xFFFFFF00L || bb >= 0xFFFFFF00L) return -6;
+    g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+  }
   const int bk = dtype == SW_BF16 ? 64 : 32;
   const int amode = (Cin % bk == 0) ? OP_CONV_A : OP_CONV_A_GEN;
   return dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, amode, OP_KCONTIG, 1, stream)
@@ -508,40 +531,60 @@ extern "C" int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int 
 }
 
 namespace {
-// workspace [co][tap][ci] -> OIHW [co][ci][tap]  (reads coalesced along ci; 14.7 M elements for the whole VGG16)
-__global__ void wk_to_oihw_kernel(int Cout, int Cin, const float* __restrict__ wk, float* __restrict__ out) {
+// sum the split-K slabs [z][co][tap][ci] in fixed order and permute to OIHW [co][ci][tap] (deterministic, no atomics;
+// reads coalesced along ci)
+__global__ void wgrad_reduce_kernel(int Cout, int Cin, int nslab, const float* __restrict__ slabs, float* __restrict__ out) {
   const long total = (long)Cout * 9 * Cin;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float v = slabs[i];
+    for (int z = 1; z < nslab; ++z) v += slabs[(long)z * total + i];
     const int ci = (int)(i % Cin); const long t = i / Cin;
     const int tap = (int)(t % 9); const int co = (int)(t / 9);
-    out[((long)co * Cin + ci) * 9 + tap] = wk[i];
+    out[((long)co * Cin + ci) * 9 + tap] = v;
   }
 }
 }  // namespace
 
+extern "C" long sw_conv3x3_wgrad_workspace_floats(int dtype, int nimg, int H, int W, int Cin, int Cout, int splitk) {
+  const int bk = dtype == SW_BF16 ? 64 : 32;
+  const long K = (long)nimg * H * W;
+  if (splitk < 1) splitk = 1;
+  long kps = (K + splitk - 1) / splitk;
+  kps = ((kps + bk - 1) / bk) * bk;
+  const long eff = (K + kps - 1) / kps;
+  return eff * Cout * 9L * Cin;
+}
+
 // conv3x3 weight gradient:  dW[co][ci][ty][tx] (OIHW, f32, overwritten)
 //   = sum_{img,y,x} dY[(img,y,x)][co] * X[img, y+(ty-1)d, x+(tx-1)d, ci]
-// Split-K partial tiles are accumulated with f32 atomics into workspace[co][tap][ci] — contiguous along ci, i.e.
-// 128-byte segments per half-wave, the shape the memory-side atomic units serve at full rate; a 36-byte-strided
-// OIHW scatter runs an order of magnitude slower — and permuted to OIHW by a small second kernel.
+// Every K-split stores its partial [co][tap][ci] tile into its own slab of the workspace with plain coalesced stores;
+// a second kernel adds the slabs in fixed order and permutes to OIHW.  (f32 atomics were measured 3-5x slower here:
+// the splits of one tile finish together and collide on the same addresses; this form is also deterministic.)
 extern "C" int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                                 const void* dy, float* dw_oihw, float* workspace, int splitk, hipStream_t stream) {
   const int epc = dtype == SW_BF16 ? 8 : 4;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
   if ((Cin % epc) || (Cout % epc)) return -5;
   if (check_align(x) || check_align(dy)) return -4;
-  const size_t nelem = (size_t)Cout * 9 * Cin;
-  hipError_t e = hipMemsetAsync(workspace, 0, nelem * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
+  if ((64 / W) + 1 > 2 * H) return -6;          // pixel-advance carry logic of the gather (tiny maps only)
+  const long nelem = (long)Cout * 9 * Cin;
+  const int nslab = (int)(sw_conv3x3_wgrad_workspace_floats(dtype, nimg, H, W, Cin, Cout, splitk) / nelem);
   GemmArgs g = {};
   g.A = dy; g.B = x; g.C = workspace; g.M = Cout; g.N = 9 * Cin; g.K = nimg * H * W; g.lda = Cout; g.ldb = 0;
-  g.ldc = 9L * Cin; g.cH = H; g.cW = W; g.cC = Cin; g.cDil = dilation; g.atomic = 1; g.oihw_cin = 0;
-  const int rc = dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, OP_KSTRIDED, OP_CONV_B, splitk, stream)
-                                  : dispatch_modes<float>(g, OP_KSTRIDED, OP_CONV_B, splitk, stream);
+  g.ldc = 9L * Cin; g.cH = H; g.cW = W; g.cC = Cin; g.cDil = dilation; g.atomic = 0; g.oihw_cin = 0;
+  g.slab_stride = nelem;
+  {
+    const long es = dtype == SW_BF16 ? 2 : 4;
+    const long ab = (long)nimg * H * W * Cout * es, bb = (long)nimg * H * W * Cin * es;
+    if (ab >= 0xFFFFFF00L || bb >= 0xFFFFFF00L) return -6;
+    g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+  }
+  const int rc = dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, OP_KSTRIDED, OP_CONV_B, nslab, stream)
+                                  : dispatch_modes<float>(g, OP_KSTRIDED, OP_CONV_B, nslab, stream);
   if (rc) return rc;
-  long blocks = ((long)nelem + 255) / 256;
+  long blocks = (nelem + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wk_to_oihw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, Cout, Cin, workspace, dw_oihw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, Cout, Cin, nslab, workspace, dw_oihw);
   SW_CHECK_LAUNCH();
   return 0;
 }

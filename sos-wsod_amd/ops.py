@@ -118,8 +118,9 @@ def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1, workspace=None, tag=None):
     _need_gpu(x, dy, dw_oihw)
     n, H, W, Cin = x.shape
     Cout = dy.shape[3]
-    if workspace is None:
-        workspace = torch.empty(Cout * 9 * Cin, device=x.device, dtype=torch.float32)
+    need = int(lib.sw_conv3x3_wgrad_workspace_floats(dt(x), n, H, W, Cin, Cout, splitk))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=x.device, dtype=torch.float32)
     check(_launch(tag, lambda: lib.sw_conv3x3_wgrad(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(dy), _p(dw_oihw),
                                                     _p(workspace), splitk, _stream())), "sw_conv3x3_wgrad")
     return dw_oihw

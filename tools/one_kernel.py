@@ -10,6 +10,10 @@ if which == "conv5_3":
     x = rnd(2, 63, 63, 512); wk = rnd(512, 9, 512); b = torch.zeros(512, device=dev); out = torch.empty(2, 63, 63, 512, device=dev, dtype=dt)
     ep = ops.make_epilogue(bias=b, relu=True, out_dtype=dt)
     f = lambda: ops.conv3x3(x, wk, out, 2, ep)
+elif which.startswith("wgrad"):
+    n_, H_, W_, cin, cout, dil, sk = {"wgrad5": (2, 63, 63, 512, 512, 2, 3), "wgrad3": (2, 128, 128, 256, 256, 1, 4)}[which]
+    x = rnd(n_, H_, W_, cin); dy = rnd(n_, H_, W_, cout); dw = torch.empty(cout, cin, 3, 3, device=dev); ws = torch.empty(cout * 9 * cin, device=dev)
+    f = lambda: ops.conv3x3_wgrad(x, dy, dw, dil, splitk=sk, workspace=ws)
 else:
     M, D0, D1 = 8000, 25088, 4096
     X = rnd(M, D0); W1 = rnd(D1, D0); dZ = rnd(M, D1)
