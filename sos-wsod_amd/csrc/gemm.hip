@@ -33,7 +33,7 @@ struct GemmArgs {
   const float* bias;               // per column n (or per row m when bias_on_m)
   const uint8_t* drop; long ldd; float drop_scale;
   const void* ref; long ldr; float ref_scale; int ref_bf16;
-  int relu, out_bf16, atomic, oihw_cin;
+  int relu, out_bf16, atomic, oihw_cin, staged_out;
   unsigned a_bytes, b_bytes;       // extents of the A / B operands (buffer descriptors' num_records)
   long slab_stride;                // > 0: split z stores its partial tile to C + z*slab_stride (plain stores, no atomics)
   float* absmax;                   // optional: atomicMax of |stored value| (IEEE bits of a non-negative float are monotone)
@@ -375,39 +375,52 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const int r = lane & 31, h = lane >> 5;
   float vmax = 0.f;
+  // bf16 outputs go through LDS (the ring is free now): the accumulator layout gives a lane one 2-byte element per
+  // store (64-byte segments); staged, every lane stores 16 contiguous bytes of one output row (8x fewer, full-line stores)
+  const bool staged = g.staged_out;                          // host: bf16 out, plain store, N % 8 == 0, ldc % 8 == 0
+  unsigned short* stile = (unsigned short*)smem + wave * (WTM * WTN);
+  if (staged) __syncthreads();                               // every wave is done reading the last K-tile
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n = n0t + wn * WTN + j * 32 + r;
-      if (n >= g.N) continue;
-      const float bcol = g.bias ? g.bias[n] : 0.f;
+      const bool nok = n < g.N;
+      const float bcol = (g.bias && nok) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= g.M) continue;
+        const int lrow = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = m0 + wm * WTM + lrow;
+        const bool ok = nok && m < g.M;
         float v = acc[i][j][e] + bcol;
         if (g.relu) v = fmaxf(v, 0.f);
-        if (g.drop) v = g.drop[(long)m * g.ldd + n] ? v * g.drop_scale : 0.f;
-        if (g.ref) {
+        if (g.drop && ok) v = g.drop[(long)m * g.ldd + n] ? v * g.drop_scale : 0.f;
+        if (g.ref && ok) {
           const float rv = g.ref_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.ref)[(long)m * g.ldr + n])
                                       : ((const float*)g.ref)[(long)m * g.ldr + n];
           v = rv > 0.f ? v * g.ref_scale : 0.f;
         }
-        long o;
-        if (g.oihw_cin > 0) {        // conv wgrad: n = tap*Cin + ci  ->  OIHW flat index
-          const int tap = n / g.oihw_cin, ci = n - tap * g.oihw_cin;
-          o = (long)m * g.ldc + (long)ci * 9 + tap;
-        } else {
-          o = (long)m * g.ldc + n;
-        }
-        vmax = fmaxf(vmax, fabsf(v));
+        if (ok) vmax = fmaxf(vmax, fabsf(v));
+        if (staged) { stile[lrow * WTN + j * 32 + r] = f32_to_bf16_bits(v); continue; }
+        if (!ok) continue;
+        const long o = (long)m * g.ldc + n;
         if (g.slab_stride > 0) ((float*)g.C)[o + (long)blockIdx.z * g.slab_stride] = v;
         else if (g.atomic) atomicAdd((float*)g.C + o, v);
         else if (g.out_bf16) ((unsigned short*)g.C)[o] = f32_to_bf16_bits(v);
         else ((float*)g.C)[o] = v;
       }
     }
+  if (staged) {
+    // the wave re-reads its own WTM x WTN tile: lane -> (row, 16-byte chunk); same-wave LDS write->read needs no barrier
+    constexpr int CPRW = WTN / 8;                            // chunks per tile row
+#pragma unroll
+    for (int q = 0; q < (WTM * CPRW) / 64; ++q) {
+      const int idx = q * 64 + lane, lrow = idx / CPRW, ch = idx % CPRW;
+      const int m = m0 + wm * WTM + lrow, n = n0t + wn * WTN + ch * 8;
+      if (m < g.M && n < g.N)
+        *(u32x4*)((unsigned short*)g.C + (long)m * g.ldc + n) = *(const u32x4*)(stile + lrow * WTN + ch * 8);
+    }
+  }
   if (g.absmax) {
     vmax = wave_reduce_max(vmax);
     if (lane == 0) atomicMax((unsigned int*)g.absmax, __float_as_uint(vmax));
@@ -431,6 +444,8 @@ int launch2(GemmArgs& g, int splitk, hipStream_t stream) {
   g.k_per_split = kps;
   splitk = (g.K + kps - 1) / kps;
   if (splitk > 1 && !g.atomic && g.slab_stride <= 0) return -2;
+  g.staged_out = (g.out_bf16 && !g.atomic && g.slab_stride <= 0 && (g.N % 8) == 0 && (g.ldc % 8) == 0 &&
+                  (((uintptr_t)g.C) & 15) == 0 && (long)NT / 64 * WTM * WTN * 2 <= (long)LDS) ? 1 : 0;
   dim3 grid(g.patches_m * patches_n * 64, 1, splitk), block(NT);
   auto kern = gemm2_kernel<T, AMODE, BMODE, BM, BN, STAGES, WTM, WTN>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
