@@ -9,7 +9,7 @@
 //   OP_CONV_A    : A(m,k) gathered from an NHWC tensor: m=(img,y,x), k=(tap,c)   (conv fwd / dgrad)
 //   OP_CONV_B    : B(k,n) gathered from an NHWC tensor: k=(img,y,x), n=(tap,c)   (conv wgrad)
 //
-// Tile 128x128 per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles),
+// Kernel structure, tile choice and the staging path are described at gemm2_kernel below.
 // K-step of 128 bytes per row (64 bf16 / 32 f32), LDS double buffered, register-staged global
 // loads issued before the MFMA block and written to the other LDS buffer after it (one barrier
 // per K-step).  bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact f32).
