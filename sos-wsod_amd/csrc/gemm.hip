@@ -163,14 +163,31 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
   constexpr int GROUP = A_SLOTS + B_SLOTS;                                        // LDS-DMA instructions per wave per K-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];                     // [STAGES][A | B]
 
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int swz = (bid & 7) * (nwg >> 3) + (bid >> 3);
-  const int patch = swz >> 6, within = swz & 63;
-  const int bm = (patch % g.patches_m) * 8 + (within & 7);
-  const int bn = (patch / g.patches_m) * 8 + (within >> 3);
-  if (bm >= g.tiles_m || bn >= g.tiles_n) return;
-  const int kbeg = blockIdx.z * g.k_per_split;
+  // Workgroup -> (tile, K-split).  The dispatcher deals workgroups round-robin to the 8 XCDs in flat launch order and
+  // every XCD has a private 4 MiB L2:
+  //  * no split-K: XCD x takes a contiguous run of 8x8-tile patches, so its 32 CUs share A rows / B columns in L2;
+  //  * split-K (few tiles, long K: the weight gradients): the grid holds valid tiles only and XCD x takes a contiguous
+  //    run of the split-major work list, i.e. ONE or two K-ranges for all tiles — its L2 then holds just that K-range
+  //    of both operands.  (With every XCD walking all of K the conv3 wgrad fetched 6x its operands from HBM; profiles/.)
+  int bm, bn, zsplit = 0;
+  if (gridDim.z > 1) {
+    const int ntv = gridDim.x, tot = ntv * (int)gridDim.z;
+    const int f = blockIdx.z * ntv + blockIdx.x;
+    const int x = f & 7, j = f >> 3;
+    const int w = x * (tot >> 3) + min(x, tot & 7) + j;
+    zsplit = w / ntv;
+    const int t = w - zsplit * ntv;
+    bm = t % g.tiles_m; bn = t / g.tiles_m;
+  } else {
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int swz = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int patch = swz >> 6, within = swz & 63;
+    bm = (patch % g.patches_m) * 8 + (within & 7);
+    bn = (patch / g.patches_m) * 8 + (within >> 3);
+    if (bm >= g.tiles_m || bn >= g.tiles_n) return;
+  }
+  const int kbeg = zsplit * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   if (kbeg >= kend) return;
   const int nt = (kend - kbeg + BK - 1) / BK;
@@ -447,7 +464,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
         if (staged) { stile[lrow * WTN + j * TS + r] = f32_to_bf16_bits(v); continue; }
         if (!ok) continue;
         const long o = (long)m * g.ldc + n;
-        if (g.slab_stride > 0) ((float*)g.C)[o + (long)blockIdx.z * g.slab_stride] = v;
+        if (g.slab_stride > 0) ((float*)g.C)[o + (long)zsplit * g.slab_stride] = v;
         else if (g.atomic) atomicAdd((float*)g.C + o, v);
         else if (g.out_bf16) ((unsigned short*)g.C)[o] = f32_to_bf16_bits(v);
         else ((float*)g.C)[o] = v;
@@ -489,7 +506,7 @@ int launch2(GemmArgs& g, int splitk, hipStream_t stream) {
   if (splitk > 1 && !g.atomic && g.slab_stride <= 0) return -2;
   g.staged_out = (g.out_bf16 && !g.atomic && g.slab_stride <= 0 && (g.N % 8) == 0 && (g.ldc % 8) == 0 &&
                   (((uintptr_t)g.C) & 15) == 0 && (long)NT / 64 * WTM * WTN * 2 <= (long)LDS) ? 1 : 0;
-  dim3 grid(g.patches_m * patches_n * 64, 1, splitk), block(NT);
+  dim3 grid(splitk > 1 ? g.tiles_m * g.tiles_n : g.patches_m * patches_n * 64, 1, splitk), block(NT);
   auto kern = gemm2_kernel<T, AMODE, BMODE, BM, BN, STAGES, WTM, WTN>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (e != hipSuccess) return (int)e;

@@ -91,6 +91,11 @@ class MultiInputRCNN(nn.Module):
             main = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream()
+                # the second scale's backward runs on the side stream while .grad lives on the main one: autograd orders
+                # the accumulation itself, the warning about it is noise here
+                warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                if warn_off is not None:
+                    warn_off(False)
             self.backbone.stage_all_weights(with_dgrad=torch.is_grad_enabled())
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):

@@ -341,8 +341,18 @@ class OICRPlusHeads(nn.Module):
         rois = [torch.cat([idx, boxes[2 * s:2 * s + 2].reshape(2 * R, 4)], 1).contiguous() for s in range(2)]
         if not hasattr(self, "_consts") or self._consts[0].device != device:
             self._consts = (torch.ones(2, device=device), torch.tensor([0, 1, 2, 2], dtype=torch.int32, device=device))
-        return dict(R=R, G=int(gt_int.numel()), boxes=boxes, obj=obj, rois=rois,
-                    gt_int32=gt_int.to(torch.int32).to(device), gt_onehot=gt_oh.view(-1).to(device),
+        # the image-level labels are the only host data of the step: stage them through pinned memory so that the copy is
+        # asynchronous (a pageable H2D copy blocks the host until the stream drains = one full pipeline bubble per step)
+        G = int(gt_int.numel())
+        if device.type == "cuda":
+            host = torch.empty(G + K, dtype=torch.float32, pin_memory=True)
+            host[:G].view(torch.int32).copy_(gt_int.to(torch.int32))
+            host[G:].copy_(gt_oh.view(-1))
+            devbuf = host.to(device, non_blocking=True)
+            gt_i32, gt_onehot = devbuf[:G].view(torch.int32), devbuf[G:]
+        else:
+            gt_i32, gt_onehot = gt_int.to(torch.int32), gt_oh.view(-1).clone()
+        return dict(R=R, G=G, boxes=boxes, obj=obj, rois=rois, gt_int32=gt_i32, gt_onehot=gt_onehot,
                     ones=self._consts[0], pred_view=self._consts[1], need_grad=need_grad)
 
     def forward(self, images_list, features_list, proposals_list, targets_list=(None, None, None, None)):

@@ -74,8 +74,10 @@ if "conv" in flt or not flt:
         dy = rnd(n, H, W, cout); dw = torch.empty(cout, cin, 3, 3, device=dev)
         npix = n * H * W
         tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
-        splitk = max(1, min(32, (512 + tiles - 1) // tiles, npix // 2048 if npix >= 4096 else 1))
-        t = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw, dil, splitk=splitk))
-        rows.append((name + f" wgrad sk{splitk}", t, fl, float("nan")))
+        for splitk in [int(v) for v in os.environ.get("SK", "0").split(",")]:
+            if splitk == 0:            # the backbone's policy (backbone_vgg.py)
+                splitk = max(1, min(8, (300 + tiles - 1) // tiles, max(1, npix // 1024)))
+            t = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw, dil, splitk=splitk))
+            rows.append((name + f" wgrad sk{splitk}", t, fl, float("nan")))
 for name, t, fl, err in rows:
     print(f"{name:42s} {t * 1e3:9.1f} us  {fl / t / 1e9:8.1f} TFLOP/s  relerr {err:.1e}")
