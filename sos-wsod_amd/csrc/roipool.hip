@@ -41,6 +41,18 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int P
   return g;
 }
 
+// argmax storage: int32 (the reference's tensor) or uint16 with 0xFFFF = "no pixel" (maps of < 65535 pixels; a third less
+// HBM traffic on the forward's output stream and half of the backward's index stream)
+template <typename IT> struct ArgIdx;
+template <> struct ArgIdx<int> {
+  __device__ static __forceinline__ int enc(int i) { return i; }
+  __device__ static __forceinline__ int dec(int v) { return v; }
+};
+template <> struct ArgIdx<unsigned short> {
+  __device__ static __forceinline__ unsigned short enc(int i) { return (unsigned short)(i < 0 ? 0xFFFF : i); }
+  __device__ static __forceinline__ int dec(unsigned short v) { return v == 0xFFFF ? -1 : (int)v; }
+};
+
 // Forward.  Workgroup = (roi, slab of 64*VEC channels), 4 waves split the PHxPW bins, lane = VEC adjacent channels
 // (bf16: one 4-byte load carries 2 channels => 256-byte wave loads).  The scan of a bin is latency bound (every NHWC
 // row segment is an L2 / Infinity-Cache hit), so a wave keeps 8 pixel loads in flight: the bin window is walked as a
@@ -58,11 +70,11 @@ template <> struct VecLoad<unsigned short, 2> {
   }
 };
 
-template <typename T, int VEC>
+template <typename T, int VEC, typename IT>
 __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, int PH, int PW, float scale,
                                                            const T* __restrict__ feat, const float* __restrict__ rois,
                                                            const float* __restrict__ row_scale, float row_scale_add,
-                                                           T* __restrict__ out, int* __restrict__ argmax) {
+                                                           T* __restrict__ out, IT* __restrict__ argmax) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CH = 64 * VEC;
   const int nb = PH * PW;
@@ -113,27 +125,24 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, 
   const int nch = min(CH, C - c0);
   const int total = nch * nb;
   const long obase = ((long)r * C + c0) * nb;
-#ifdef ROI_FWD_NOSTORE
-  if (total < 0)
-#endif
-  if ((total & 7) == 0 && ((obase * (long)sizeof(T)) & 15) == 0) {
+  if (sizeof(IT) == 4 && (total & 7) == 0 && ((obase * (long)sizeof(T)) & 15) == 0) {
     // 16-byte stores: 8 (bf16) / 4 (f32) values and 4 argmax words per lane
     constexpr int VPV = 16 / (int)sizeof(T);
     for (int i = threadIdx.x; i < total / VPV; i += blockDim.x)
       *(u32x4*)(out + obase + (long)i * VPV) = *(const u32x4*)(s_val + i * VPV);
     for (int i = threadIdx.x; i < total / 4; i += blockDim.x)
-      *(u32x4*)(argmax + obase + (long)i * 4) = *(const u32x4*)(s_arg + i * 4);
+      *(u32x4*)((int*)argmax + obase + (long)i * 4) = *(const u32x4*)(s_arg + i * 4);
   } else {
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
       out[obase + i] = s_val[i];
-      argmax[obase + i] = s_arg[i];
+      argmax[obase + i] = ArgIdx<IT>::enc(s_arg[i]);
     }
   }
 }
 
-template <typename T>
+template <typename T, typename IT>
 __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C, int nb, int CB,
-                                                            const T* __restrict__ dout, const int* __restrict__ argmax,
+                                                            const T* __restrict__ dout, const IT* __restrict__ argmax,
                                                             const float* __restrict__ rois, int R,
                                                             const float* __restrict__ row_scale, float row_scale_add,
                                                             const T* __restrict__ relu_ref, T* __restrict__ dfeat) {
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
         a[u] = -1; d[u] = 0.f;
         if (r < R && i < per_roi && (int)rois[(long)r * 5] == img) {
           const long base = ((long)r * C + c0) * nb;
-          a[u] = argmax[base + i];
+          a[u] = ArgIdx<IT>::dec(argmax[base + i]);
           d[u] = Elem<T>::load(dout + base + i);
         }
       }
@@ -190,9 +199,9 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
 // BITWISE REPRODUCIBLE and at least as accurate as f32 accumulation.
 // Workgroup = (image, slab of CB channels, CB % 4 == 0) owning H*W*CB int64 in LDS; a lane loads 4 gradients and 4
 // argmax words of 4 ROIs (16-byte aligned, 8 loads in flight) before scattering.
-template <typename T>
+template <typename T, typename IT>
 __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int C, int nb, int CB,
-                                                               const T* __restrict__ dout, const int* __restrict__ argmax,
+                                                               const T* __restrict__ dout, const IT* __restrict__ argmax,
                                                                const float* __restrict__ rois, int R,
                                                                const float* __restrict__ row_scale, float row_scale_add,
                                                                const float* __restrict__ dout_absmax,
@@ -216,13 +225,23 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   for (int r0 = wave * 4; r0 < R; r0 += nwave * 4) {
     for (int j = lane; j < nvec; j += 64) {
-      u32x4 a4[4]; float d[4][4]; bool on[4];
+      int a4[4][4]; float d[4][4]; bool on[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int r = r0 + u;
         on[u] = r < R && (int)rois[(long)r * 5] == img;
         const long base = ((long)(on[u] ? r : 0) * C + c0) * nb + (long)j * 4;
-        a4[u] = *(const u32x4*)(argmax + base);
+        if (sizeof(IT) == 4) {
+          const u32x4 av = *(const u32x4*)(argmax + base);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a4[u][e] = (int)av[e];
+        } else {
+          const u32x2 av = *(const u32x2*)(argmax + base);
+          a4[u][0] = ArgIdx<unsigned short>::dec((unsigned short)(av[0] & 0xFFFFu));
+          a4[u][1] = ArgIdx<unsigned short>::dec((unsigned short)(av[0] >> 16));
+          a4[u][2] = ArgIdx<unsigned short>::dec((unsigned short)(av[1] & 0xFFFFu));
+          a4[u][3] = ArgIdx<unsigned short>::dec((unsigned short)(av[1] >> 16));
+        }
         if (sizeof(T) == 2) {
           const u32x2 v = *(const u32x2*)(dout + base);
           d[u][0] = __uint_as_float(v[0] << 16); d[u][1] = __uint_as_float(v[0] & 0xFFFF0000u);
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
         const float mul = row_scale ? (row_scale[r0 + u] + row_scale_add) : 1.0f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int a = (int)a4[u][e];
+          const int a = a4[u][e];
           const int cc = (j * 4 + e) / nb;
           if (a >= 0) {
             const long long q = __float2ll_rn(scalbnf(__fmul_rn(d[u][e], mul), frac));
@@ -260,6 +279,159 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   }
 }
 
+// Forward, feature-stationary form (the one the hot path runs).  The gather form above re-reads every map pixel of a
+// ROI once per overlapping bin from L2 — ~5 GB of 256-byte L2 reads per 8000-ROI call, latency bound at ~5 TB/s.  Here
+// a workgroup owns CB channels of ONE image: it copies that H x W x CB slab of the map into LDS once (16 bytes per
+// pixel for CB = 8 bf16), then streams every ROI of that image in its ROI chunk through it.  Lane = one (roi, bin):
+// the bin window is walked in the reference's row-major order with one 16-byte LDS read per pixel carrying all CB
+// channels; strict '>' from -FLT_MAX keeps the first maximum exactly as the serial reference.  Results go straight to
+// the (R, C, PH, PW) output: for a fixed channel the PH*PW lanes of a ROI write one contiguous run.
+template <int PXB> struct PixWord;
+template <> struct PixWord<16> { typedef u32x4 type; };
+template <> struct PixWord<8> { typedef unsigned long long type; };
+template <> struct PixWord<4> { typedef unsigned int type; };
+
+template <typename T, int CB>
+__device__ __forceinline__ void pix_decode(const typename PixWord<CB * (int)sizeof(T)>::type& w, float* v) {
+  const unsigned int* u = (const unsigned int*)&w;
+  if (sizeof(T) == 2) {
+#pragma unroll
+    for (int q = 0; q < CB; q += 2) {
+      v[q] = __uint_as_float(u[q >> 1] << 16);
+      if (q + 1 < CB) v[q + 1] = __uint_as_float(u[q >> 1] & 0xFFFF0000u);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < CB; ++q) v[q] = __uint_as_float(u[q]);
+  }
+}
+
+// KEY = true (bf16 maps of < 65535 pixels): the LDS copy holds order-preserving 16-bit keys instead of bf16 bits
+// (positive: b ^ 0x8000, negative: ~b, +NaN -> 0 so that it never wins, as with the reference's '>'), and the running
+// maximum of a (bin, channel) is ONE u32  key << 16 | (0xFFFE - pixel): v_max_u32 then implements "larger value, else
+// earlier pixel" — 2 VALU instructions per channel and pixel instead of convert + compare + two selects.  The start
+// value key(-inf) << 16 | 0xFFFF can only be beaten by values > -inf, i.e. exactly those that beat -FLT_MAX.
+// (-0.0 shares +0.0's key, as they compare equal; a bin won by a -0.0 pixel then outputs +0.0.)
+template <typename T, int CB, int NT, typename IT, bool KEY>
+__global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, int C, int PH, int PW, float scale,
+                                                                const T* __restrict__ feat, const float* __restrict__ rois,
+                                                                int R, int chunk, const float* __restrict__ row_scale,
+                                                                float row_scale_add, T* __restrict__ out,
+                                                                IT* __restrict__ argmax) {
+  constexpr int PXB = CB * (int)sizeof(T);
+  constexpr int NWORD = PXB / 4;
+  typedef typename PixWord<PXB>::type word_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_cnt;
+  word_t* plane = (word_t*)smem;                                   // [H*W] pixels x CB channels
+  int* s_list = (int*)(smem + (((size_t)H * W * PXB + 15) & ~(size_t)15));   // [chunk] ROIs of this image
+  const int c0 = blockIdx.x * CB, img = blockIdx.y;
+  const int r0 = blockIdx.z * chunk, r1 = min(R, r0 + chunk);
+  const int tid = threadIdx.x;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int r = r0 + tid; r < r1; r += NT)
+    if ((int)rois[(long)r * 5] == img) s_list[atomicAdd(&s_cnt, 1)] = r;
+  __syncthreads();
+  const int cnt = s_cnt;
+  if (cnt == 0) return;
+  const int npx = H * W;
+  const T* fimg = feat + (long)img * npx * C + c0;
+  for (int px = tid; px < npx; px += NT) {
+    word_t w = *(const word_t*)(fimg + (long)px * C);
+    if (KEY) {
+      unsigned int* u = (unsigned int*)&w;
+#pragma unroll
+      for (int i = 0; i < NWORD; ++i) {
+        unsigned int k = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned int bts = (u[i] >> (16 * h)) & 0xFFFFu;
+          unsigned int key = (bts & 0x8000u) ? (bts ^ 0xFFFFu) : (bts | 0x8000u);
+          if (bts > 0x7F80u && bts < 0x8000u) key = 0;              // +NaN never wins
+          if (bts == 0x8000u) key = 0x8000u;                        // -0.0 == +0.0 under '>': the earlier pixel wins
+          k |= key << (16 * h);
+        }
+        u[i] = k;
+      }
+    }
+    plane[px] = w;
+  }
+  __syncthreads();
+  const int nb = PH * PW;
+  const int total = cnt * nb;
+  constexpr unsigned KEY_INIT = 0x007FFFFFu;                       // key(-inf) << 16 | 0xFFFF
+  for (int t = tid; t < total; t += NT) {
+    const int li = t / nb, b = t - li * nb;
+    const int r = s_list[li];
+    const RoiGeom g = roi_geom(rois + (long)r * 5, scale, PH, PW);
+    const int ph = b / PW, pw = b - ph * PW;
+    int hs = (int)floorf(__fmul_rn((float)ph, g.bin_h));
+    int ws = (int)floorf(__fmul_rn((float)pw, g.bin_w));
+    int he = (int)ceilf(__fmul_rn((float)(ph + 1), g.bin_h));
+    int we = (int)ceilf(__fmul_rn((float)(pw + 1), g.bin_w));
+    hs = min(max(hs + g.start_h, 0), H); he = min(max(he + g.start_h, 0), H);
+    ws = min(max(ws + g.start_w, 0), W); we = min(max(we + g.start_w, 0), W);
+    const bool empty = (he <= hs) || (we <= ws);
+    float mv[CB]; int mi[CB];
+    if (KEY) {
+      unsigned int best[CB];
+#pragma unroll
+      for (int q = 0; q < CB; ++q) best[q] = KEY_INIT;
+      if (!empty) {
+        const int bw = we - ws;
+        for (int hh = hs; hh < he; ++hh) {
+          const int rowi = hh * W + ws;
+          for (int x = 0; x < bw; ++x) {
+            const int idx = rowi + x;
+            const word_t w = plane[idx];
+            const unsigned int* u = (const unsigned int*)&w;
+            const unsigned int inv = 0xFFFEu - (unsigned)idx;
+#pragma unroll
+            for (int i = 0; i < NWORD; ++i) {
+              best[2 * i] = max(best[2 * i], (u[i] << 16) | inv);
+              best[2 * i + 1] = max(best[2 * i + 1], (u[i] & 0xFFFF0000u) | inv);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CB; ++q) {
+        const unsigned int hi = best[q] >> 16, lo = best[q] & 0xFFFFu;
+        const unsigned int bts = (hi & 0x8000u) ? (hi ^ 0x8000u) : (hi ^ 0xFFFFu);
+        const bool none = lo == 0xFFFFu;
+        mv[q] = empty ? 0.f : none ? -FLT_MAX : __uint_as_float(bts << 16);
+        mi[q] = (empty || none) ? -1 : (int)(0xFFFEu - lo);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < CB; ++q) { mv[q] = empty ? 0.f : -FLT_MAX; mi[q] = -1; }
+      if (!empty) {
+        const int bw = we - ws;
+        for (int hh = hs; hh < he; ++hh) {
+          const int rowi = hh * W + ws;
+          for (int x = 0; x < bw; ++x) {
+            const int idx = rowi + x;
+            float v[CB];
+            pix_decode<T, CB>(plane[idx], v);
+#pragma unroll
+            for (int q = 0; q < CB; ++q)
+              if (v[q] > mv[q]) { mv[q] = v[q]; mi[q] = idx; }
+          }
+        }
+      }
+    }
+    const float mul = row_scale ? (row_scale[r] + row_scale_add) : 1.0f;
+    const long o = ((long)r * C + c0) * nb + b;
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+      Elem<T>::store(out + o + (long)q * nb, __fmul_rn(mv[q], mul));
+      argmax[o + (long)q * nb] = ArgIdx<IT>::enc(mi[q]);
+    }
+  }
+}
+
+
 // max |x| over n elements -> out[0] (f32; caller zero-fills).  |x| as IEEE bits is monotone => integer atomicMax.
 template <typename T>
 __global__ void absmax_kernel(long n, const T* __restrict__ x, float* __restrict__ out) {
@@ -272,83 +444,132 @@ __global__ void absmax_kernel(long n, const T* __restrict__ x, float* __restrict
 
 }  // namespace
 
-extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale,
-                               const void* feat, const float* rois, int R, const float* row_scale,
-                               float row_scale_add, void* out, int32_t* argmax, hipStream_t stream) {
-  (void)nimg;
-  if (R <= 0) return 0;
-  if (dtype != SW_BF16 && dtype != SW_F32) return -1;
-  const int vec = dtype == SW_BF16 ? 2 : 1;
-  if (C % vec) return -5;
-  const int ch = 64 * vec;
-  const size_t lds = (size_t)ch * PH * PW * (4 + (dtype == SW_BF16 ? 2 : 4));
-  if (lds > 64 * 1024) return -6;
-  dim3 grid(R, (C + ch - 1) / ch), block(256);
-  if (dtype == SW_BF16)
-    hipLaunchKernelGGL((roi_pool_fwd_kernel<unsigned short, 2>), grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
-                       (const unsigned short*)feat, rois, row_scale, row_scale_add, (unsigned short*)out, argmax);
-  else
-    hipLaunchKernelGGL((roi_pool_fwd_kernel<float, 1>), grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
-                       (const float*)feat, rois, row_scale, row_scale_add, (float*)out, argmax);
+namespace {
+template <typename T, int CB, typename IT>
+int launch_fwd_plane(int nimg, int H, int W, int C, int PH, int PW, float scale, const void* feat, const float* rois, int R,
+                     const float* row_scale, float row_scale_add, void* out, void* argmax, hipStream_t stream) {
+  constexpr int NT = 1024, CHUNK = 256;
+  const size_t lds = (((size_t)H * W * CB * sizeof(T) + 15) & ~(size_t)15) + CHUNK * sizeof(int);
+  const bool key = sizeof(T) == 2 && (long)H * W < 65535;
+  auto kern = key ? roi_pool_fwd_plane_kernel<T, CB, NT, IT, (sizeof(T) == 2)> : roi_pool_fwd_plane_kernel<T, CB, NT, IT, false>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  dim3 grid(C / CB, nimg, (R + CHUNK - 1) / CHUNK), block(NT);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, H, W, C, PH, PW, scale, (const T*)feat, rois, R, CHUNK, row_scale,
+                     row_scale_add, (T*)out, (IT*)argmax);
   SW_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
-                               const int32_t* argmax, const float* rois, int R, const float* row_scale,
-                               float row_scale_add, const void* relu_ref, const float* dout_absmax, void* dfeat,
-                               hipStream_t stream) {
-  // channel slab per workgroup: power of two, H*W*CB*4 <= 64 KiB (two 1024-thread workgroups per CU) and enough
-  // slabs to give every CU work (C/CB * nimg >= 512 where the map allows)
+template <typename IT>
+int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale, const void* feat,
+                     const float* rois, int R, const float* row_scale, float row_scale_add, void* out, void* argmax,
+                     hipStream_t stream) {
+  // feature-stationary form: the widest channel slab (16 / 8 / 4 bytes per pixel) whose H*W plane fits LDS, two
+  // workgroups per CU when it can (<= 76 KiB each)
+  static const bool force_gather = getenv("SW_ROI_FWD_GATHER") != nullptr;    // development switch
+  const size_t es = dtype == SW_BF16 ? 2 : 4;
+  if (!force_gather && nimg > 0 && (((uintptr_t)feat) & 15) == 0) {
+    int pxb = 0;
+    for (int cand = 16; cand >= 4 && !pxb; cand >>= 1)
+      if ((C % (cand / (int)es)) == 0 && (size_t)H * W * cand <= 76 * 1024) pxb = cand;
+    for (int cand = 16; cand >= 4 && !pxb; cand >>= 1)
+      if ((C % (cand / (int)es)) == 0 && (size_t)H * W * cand <= 150 * 1024) pxb = cand;
+    if (pxb) {
+#define SW_FWD_PLANE(T, CB) return launch_fwd_plane<T, CB, IT>(nimg, H, W, C, PH, PW, spatial_scale, feat, rois, R, row_scale, \
+                                                               row_scale_add, out, argmax, stream)
+      if (dtype == SW_BF16) {
+        if (pxb == 16) SW_FWD_PLANE(unsigned short, 8);
+        if (pxb == 8) SW_FWD_PLANE(unsigned short, 4);
+        SW_FWD_PLANE(unsigned short, 2);
+      } else {
+        if (pxb == 16) SW_FWD_PLANE(float, 4);
+        if (pxb == 8) SW_FWD_PLANE(float, 2);
+        SW_FWD_PLANE(float, 1);
+      }
+#undef SW_FWD_PLANE
+    }
+  }
+  const int vec = dtype == SW_BF16 ? 2 : 1;
+  if (C % vec) return -5;
+  const int ch = 64 * vec;
+  const size_t lds = (size_t)ch * PH * PW * (4 + es);
+  if (lds > 64 * 1024) return -6;
+  dim3 grid(R, (C + ch - 1) / ch), block(256);
+  if (dtype == SW_BF16)
+    hipLaunchKernelGGL((roi_pool_fwd_kernel<unsigned short, 2, IT>), grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
+                       (const unsigned short*)feat, rois, row_scale, row_scale_add, (unsigned short*)out, (IT*)argmax);
+  else
+    hipLaunchKernelGGL((roi_pool_fwd_kernel<float, 1, IT>), grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
+                       (const float*)feat, rois, row_scale, row_scale_add, (float*)out, (IT*)argmax);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, typename IT>
+int roi_bwd_dispatch(int nimg, int H, int W, int C, int PH, int PW, const void* dout, const void* argmax, const float* rois,
+                     int R, const float* row_scale, float row_scale_add, const void* relu_ref, const float* dout_absmax,
+                     void* dfeat, hipStream_t stream) {
   // fixed-point path: CB in {8, 4} with H*W*CB*8 bytes of LDS; needs max|dout| (device scalar)
+  static const bool float_atomics = getenv("SW_ROI_FLOAT_ATOMICS") != nullptr;    // development switch
   int cbx = 8;
   while (cbx >= 4 && ((size_t)H * W * cbx * 8 > 128 * 1024 || (C % cbx))) cbx >>= 1;
-  if (cbx >= 4 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) &&
-      getenv("SW_ROI_FLOAT_ATOMICS") == nullptr) {
+  if (cbx >= 4 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) && !float_atomics) {
     const size_t ldsx = (size_t)H * W * cbx * 8;
     dim3 gridx(C / cbx, nimg), blockx(1024);
-    hipError_t ex;
-    if (dtype == SW_BF16) {
-      auto k = roi_pool_bwd_fx_kernel<unsigned short>;
-      ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
-      if (ex != hipSuccess) return (int)ex;
-      hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, PH * PW, cbx, (const unsigned short*)dout, argmax, rois, R,
-                         row_scale, row_scale_add, dout_absmax, (const unsigned short*)relu_ref, (unsigned short*)dfeat);
-    } else if (dtype == SW_F32) {
-      auto k = roi_pool_bwd_fx_kernel<float>;
-      ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
-      if (ex != hipSuccess) return (int)ex;
-      hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, PH * PW, cbx, (const float*)dout, argmax, rois, R, row_scale,
-                         row_scale_add, dout_absmax, (const float*)relu_ref, (float*)dfeat);
-    } else {
-      return -1;
-    }
+    auto k = roi_pool_bwd_fx_kernel<T, IT>;
+    hipError_t ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+    if (ex != hipSuccess) return (int)ex;
+    hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, PH * PW, cbx, (const T*)dout, (const IT*)argmax, rois, R,
+                       row_scale, row_scale_add, dout_absmax, (const T*)relu_ref, (T*)dfeat);
     SW_CHECK_LAUNCH();
     return 0;
   }
+  // float-atomic path: channel slab per workgroup a power of two, H*W*CB*4 <= 64 KiB (two 1024-thread workgroups per
+  // CU) and enough slabs to give every CU work (C/CB * nimg >= 512 where the map allows)
   int CB = 64;
   while (CB > 1 && ((size_t)H * W * CB * 4 > 64 * 1024 || (C % CB) || (C / CB) * nimg < 512)) CB >>= 1;
   const size_t lds = (size_t)H * W * CB * 4;
   if (lds > 160 * 1024) return -6;
   dim3 grid(C / CB, nimg), block(1024);
-  hipError_t e;
-  if (dtype == SW_BF16) {
-    auto k = roi_pool_bwd_kernel<unsigned short>;
-    e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, grid, block, lds, stream, H, W, C, PH * PW, CB, (const unsigned short*)dout, argmax, rois, R,
-                       row_scale, row_scale_add, (const unsigned short*)relu_ref, (unsigned short*)dfeat);
-  } else if (dtype == SW_F32) {
-    auto k = roi_pool_bwd_kernel<float>;
-    e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, grid, block, lds, stream, H, W, C, PH * PW, CB, (const float*)dout, argmax, rois, R, row_scale,
-                       row_scale_add, (const float*)relu_ref, (float*)dfeat);
-  } else {
-    return -1;
-  }
+  auto k = roi_pool_bwd_kernel<T, IT>;
+  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k, grid, block, lds, stream, H, W, C, PH * PW, CB, (const T*)dout, (const IT*)argmax, rois, R, row_scale,
+                     row_scale_add, (const T*)relu_ref, (T*)dfeat);
   SW_CHECK_LAUNCH();
   return 0;
+}
+}  // namespace
+
+extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale,
+                               const void* feat, const float* rois, int R, const float* row_scale,
+                               float row_scale_add, void* out, void* argmax, int argmax_bits, hipStream_t stream) {
+  if (R <= 0) return 0;
+  if (dtype != SW_BF16 && dtype != SW_F32) return -1;
+  if (argmax_bits == 32)
+    return roi_fwd_dispatch<int>(dtype, nimg, H, W, C, PH, PW, spatial_scale, feat, rois, R, row_scale, row_scale_add, out,
+                                 argmax, stream);
+  if (argmax_bits != 16) return -1;
+  if ((long)H * W >= 65535) return -6;
+  return roi_fwd_dispatch<unsigned short>(dtype, nimg, H, W, C, PH, PW, spatial_scale, feat, rois, R, row_scale,
+                                          row_scale_add, out, argmax, stream);
+}
+
+extern "C" int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
+                               const void* argmax, int argmax_bits, const float* rois, int R, const float* row_scale,
+                               float row_scale_add, const void* relu_ref, const float* dout_absmax, void* dfeat,
+                               hipStream_t stream) {
+  if (dtype != SW_BF16 && dtype != SW_F32) return -1;
+  if (argmax_bits != 32 && argmax_bits != 16) return -1;
+#define SW_BWD(T, IT) return roi_bwd_dispatch<T, IT>(nimg, H, W, C, PH, PW, dout, argmax, rois, R, row_scale, row_scale_add, \
+                                                     relu_ref, dout_absmax, dfeat, stream)
+  if (dtype == SW_BF16) { if (argmax_bits == 32) SW_BWD(unsigned short, int); SW_BWD(unsigned short, unsigned short); }
+  if (argmax_bits == 32) SW_BWD(float, int);
+  SW_BWD(float, unsigned short);
+#undef SW_BWD
 }
 
 extern "C" int sw_absmax(int dtype, long n, const void* x, float* out, hipStream_t stream) {

@@ -31,7 +31,7 @@ def oicr_inference(heads, features, proposals):
     C = feat.shape[3]
     rois = torch.cat([torch.zeros(R, 1, device=dev), boxes], 1).contiguous()
     pooled = torch.empty(R, C * P * P, device=dev, dtype=dt_)
-    argmax = torch.empty(R, C * P * P, device=dev, dtype=torch.int32)
+    argmax = torch.empty(R, C * P * P, device=dev, dtype=ops.roi_argmax_dtype(feat.shape[1], feat.shape[2]))
     ops.roi_pool_fwd(feat, rois, pooled, argmax, heads.box_pooler.scale, P, P, row_scale=obj, row_scale_add=1.0)
     h = heads.box_head(pooled)                                        # eval: no dropout
     params = [p.detach() for p in heads._flat_params()]

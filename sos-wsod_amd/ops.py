@@ -156,13 +156,35 @@ def preprocess(img_u8_chw, out_hwc, mean, std):
 
 
 def roi_pool_fwd(feat, rois, out, argmax, spatial_scale, PH, PW, row_scale=None, row_scale_add=0.0):
-    """feat [n][H][W][C], rois [R][5] f32, out [R][C*PH*PW], argmax int32 same shape"""
+    """feat [n][H][W][C], rois [R][5] f32, out [R][C*PH*PW]; argmax same shape, int32 (h*W+w or -1) or int16/uint16
+    storage holding uint16 (h*W+w or 0xFFFF; see argmax_to_int32)"""
     _need_gpu(feat, rois, out, argmax)
     n, H, W, C = feat.shape
     R = rois.shape[0]
     check(lib.sw_roi_pool_fwd(dt(feat), n, H, W, C, PH, PW, float(spatial_scale), _p(feat), _p(rois), R, _p(row_scale),
-                              float(row_scale_add), _p(out), _p(argmax), _stream()), "sw_roi_pool_fwd")
+                              float(row_scale_add), _p(out), _p(argmax), _argmax_bits(argmax), _stream()), "sw_roi_pool_fwd")
     return out, argmax
+
+
+def _argmax_bits(argmax):
+    if argmax.dtype == torch.int32:
+        return 32
+    if argmax.dtype in (torch.int16, torch.uint16):
+        return 16
+    raise TypeError(f"ROIPool argmax must be int32 or (u)int16, got {argmax.dtype}")
+
+
+def roi_argmax_dtype(H, W):
+    """compact index type for an H x W map: uint16 (int16 storage) below 65535 pixels, else int32"""
+    return torch.int16 if H * W < 65535 else torch.int32
+
+
+def argmax_to_int32(argmax):
+    """decode either storage to the reference's int32 convention (-1 = empty bin)"""
+    if argmax.dtype == torch.int32:
+        return argmax
+    a = argmax.view(torch.int16).to(torch.int32) & 0xFFFF
+    return torch.where(a == 0xFFFF, torch.full_like(a, -1), a)
 
 
 def absmax(x, out=None):
@@ -180,7 +202,7 @@ def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_ad
     R = rois.shape[0]
     if isinstance(dout_absmax, str):
         dout_absmax = absmax(dout)
-    check(lib.sw_roi_pool_bwd(dt(dfeat), n, H, W, C, PH, PW, _p(dout), _p(argmax), _p(rois), R, _p(row_scale),
+    check(lib.sw_roi_pool_bwd(dt(dfeat), n, H, W, C, PH, PW, _p(dout), _p(argmax), _argmax_bits(argmax), _p(rois), R, _p(row_scale),
                               float(row_scale_add), _p(relu_ref), _p(dout_absmax), _p(dfeat), _stream()), "sw_roi_pool_bwd")
     return dfeat
 

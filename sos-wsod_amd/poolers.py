@@ -22,7 +22,8 @@ class _RoIPoolFunction(torch.autograd.Function):
     def forward(ctx, feat_nhwc, rois, out_size, scale):
         R, C = rois.shape[0], feat_nhwc.shape[3]
         out = torch.empty(R, C * out_size * out_size, device=feat_nhwc.device, dtype=feat_nhwc.dtype)
-        arg = torch.empty(R, C * out_size * out_size, device=feat_nhwc.device, dtype=torch.int32)
+        arg = torch.empty(R, C * out_size * out_size, device=feat_nhwc.device,
+                          dtype=ops.roi_argmax_dtype(feat_nhwc.shape[1], feat_nhwc.shape[2]))
         ops.roi_pool_fwd(feat_nhwc, rois, out, arg, scale, out_size, out_size)
         ctx.save_for_backward(arg, rois)
         ctx.shape, ctx.out_size = feat_nhwc.shape, out_size

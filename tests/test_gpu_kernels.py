@@ -133,8 +133,9 @@ def test_maxpool_fwd_bwd(ops, dtype, stride):
 
 
 # ------------------------------------------------------------------------------------------ ROIPool
+@pytest.mark.parametrize("adt", [torch.int32, torch.int16])
 @pytest.mark.parametrize("dtype", DT)
-def test_roi_pool_bit_exact_and_backward(ops, dtype):
+def test_roi_pool_bit_exact_and_backward(ops, dtype, adt):
     n, C, H, W, R = 2, 96, 31, 40, 300
     feat = _rand((n, C, H, W), 30, dtype).float()
     views, _ = O.make_views(H * 8, W * 8, R, tag="rp")
@@ -147,19 +148,66 @@ def test_roi_pool_bit_exact_and_backward(ops, dtype):
     ref_scaled = torch.from_numpy(ref_out) * (torch.from_numpy(obj) + 1).view(-1, 1, 1, 1)
     f = _nhwc(feat).to(dtype).cuda()
     out = torch.empty(R, C * 49, device="cuda", dtype=dtype)
-    arg = torch.empty(R, C * 49, device="cuda", dtype=torch.int32)
+    arg = torch.empty(R, C * 49, device="cuda", dtype=adt)
     ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7, row_scale=torch.from_numpy(obj).cuda(),
                      row_scale_add=1.0)
-    assert np.array_equal(arg.cpu().numpy().reshape(ref_arg.shape), ref_arg)              # bit exact bins/argmax
+    assert np.array_equal(ops.argmax_to_int32(arg).cpu().numpy().reshape(ref_arg.shape), ref_arg)   # bit exact bins/argmax
     assert torch.equal(out.cpu().float().view(ref_scaled.shape), ref_scaled.to(dtype).float())   # values copied
     g = _rand((R, C, 7, 7), 31, dtype).float()
     ref_g = O.roi_pool_bwd((g * (torch.from_numpy(obj) + 1).view(-1, 1, 1, 1)).numpy(), ref_arg, rois, feat.shape)
     ref_g = _nhwc(torch.from_numpy(ref_g)) * (_nhwc(feat) > 0)
-    dfeat = torch.empty(n, H, W, C, device="cuda", dtype=dtype)
-    ops.roi_pool_bwd(g.to(dtype).view(R, -1).cuda(), arg, torch.from_numpy(rois).cuda(), dfeat, 7, 7,
-                     row_scale=torch.from_numpy(obj).cuda(), row_scale_add=1.0, relu_ref=f)
-    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
-    assert (dfeat.cpu().float() - ref_g).abs().max() <= tol * ref_g.abs().max()
+    for amax in ("auto", None):                                   # fixed-point and float-atomic accumulation
+        dfeat = torch.empty(n, H, W, C, device="cuda", dtype=dtype)
+        ops.roi_pool_bwd(g.to(dtype).view(R, -1).cuda(), arg, torch.from_numpy(rois).cuda(), dfeat, 7, 7,
+                         row_scale=torch.from_numpy(obj).cuda(), row_scale_add=1.0, relu_ref=f, dout_absmax=amax)
+        tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+        assert (dfeat.cpu().float() - ref_g).abs().max() <= tol * ref_g.abs().max()
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_roi_pool_ties_and_special_values(ops, dtype):
+    """first maximum in row-major order on plateaus; -0.0/+0.0, -inf, +-NaN and the most negative finite value follow
+    the reference's strict '>' from -FLT_MAX (ROILoopPool_cpu.cpp:60-72)"""
+    n, C, H, W, R = 1, 16, 24, 24, 120
+    rng = np.random.default_rng(5)
+    feat = rng.integers(-2, 3, size=(n, C, H, W)).astype(np.float32)      # many exact ties
+    feat[0, 0, :, :] = -np.inf
+    feat[0, 1, ::2, :] = np.nan
+    feat[0, 2, :, :] = np.where(rng.random((H, W)) < 0.5, -0.0, 0.0)
+    feat[0, 3, :, :] = float(torch.finfo(dtype).min)
+    feat[0, 4, :, ::3] = -np.nan
+    feat[0, 5, :, :] = np.inf
+    views, _ = O.make_views(H * 8, W * 8, R, tag="ties")
+    rois = np.concatenate([np.zeros((R, 1), np.float32), views[0]["boxes"]], 1).astype(np.float32)
+    ref_out, ref_arg = O.roi_pool_fwd(feat, rois, 1.0 / 8)
+    f = _nhwc(torch.from_numpy(feat)).to(dtype).cuda()
+    for adt in (torch.int32, torch.int16):
+        out = torch.empty(R, C * 49, device="cuda", dtype=dtype)
+        arg = torch.empty(R, C * 49, device="cuda", dtype=adt)
+        ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7)
+        got_arg = ops.argmax_to_int32(arg).cpu().numpy().reshape(ref_arg.shape)
+        assert np.array_equal(got_arg, ref_arg)
+        got = out.cpu().float().view(ref_out.shape).numpy()
+        want = torch.from_numpy(ref_out).to(dtype).float().numpy()
+        assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_roi_pool_large_map_uses_gather_form(ops):
+    """a map whose H*W plane does not fit LDS falls back to the gather kernel; > 65534 pixels needs int32 indices"""
+    n, C, H, W, R = 1, 8, 260, 256, 64
+    feat = _rand((n, C, H, W), 33, torch.float32)
+    views, _ = O.make_views(H * 8, W * 8, R, tag="big")
+    rois = np.concatenate([np.zeros((R, 1), np.float32), views[0]["boxes"]], 1).astype(np.float32)
+    ref_out, ref_arg = O.roi_pool_fwd(feat.numpy(), rois, 1.0 / 8)
+    f = _nhwc(feat).cuda()
+    out = torch.empty(R, C * 49, device="cuda"); arg = torch.empty(R, C * 49, device="cuda", dtype=torch.int32)
+    ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7)
+    assert np.array_equal(arg.cpu().numpy().reshape(ref_arg.shape), ref_arg)
+    assert np.array_equal(out.cpu().numpy().reshape(ref_out.shape), ref_out)
+    assert ops.roi_argmax_dtype(H, W) == torch.int32
+    with pytest.raises(Exception):
+        ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, torch.empty(R, C * 49, device="cuda", dtype=torch.int16),
+                         1.0 / 8, 7, 7)
 
 
 # ------------------------------------------------------------------------------------------ heads
