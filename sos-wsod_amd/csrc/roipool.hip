@@ -147,7 +147,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
                                                             const float* __restrict__ row_scale, float row_scale_add,
                                                             const T* __restrict__ relu_ref, T* __restrict__ dfeat) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* acc = (float*)smem;                   // [H*W][CB]
+  float* acc = (float*)smem;                   // [CB][H*W]
   const int img = blockIdx.y, c0 = blockIdx.x * CB;
   const int npix = H * W;
   for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) acc[i] = 0.f;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
       for (int u = 0; u < 4; ++u) {
         if (a[u] >= 0) {
           const float mul = row_scale ? (row_scale[r0 + u] + row_scale_add) : 1.0f;
-          atomicAdd(&acc[a[u] * CB + cc], __fmul_rn(d[u], mul));
+          atomicAdd(&acc[cc * npix + a[u]], __fmul_rn(d[u], mul));
         }
       }
     }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
   const T* rimg = relu_ref ? relu_ref + (long)img * npix * C : nullptr;
   for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) {
     const int p = i / CB, cc = i - p * CB;
-    float v = acc[i];
+    float v = acc[cc * npix + p];
     if (rimg && !(Elem<T>::load(rimg + (long)p * C + c0 + cc) > 0.f)) v = 0.f;
     Elem<T>::store(dimg + (long)p * C + c0 + cc, v);
   }
@@ -199,6 +199,8 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
 // BITWISE REPRODUCIBLE and at least as accurate as f32 accumulation.
 // Workgroup = (image, slab of CB channels, CB % 4 == 0) owning H*W*CB int64 in LDS; a lane loads 4 gradients and 4
 // argmax words of 4 ROIs (16-byte aligned, 8 loads in flight) before scattering.
+constexpr int FX_CHUNK = 1024;          // ROIs per compaction round of the fixed-point backward
+
 template <typename T, typename IT>
 __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int C, int nb, int CB,
                                                                const T* __restrict__ dout, const IT* __restrict__ argmax,
@@ -208,7 +210,10 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
                                                                const T* __restrict__ relu_ref, T* __restrict__ dfeat) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[32];
-  unsigned long long* acc = (unsigned long long*)smem;          // [H*W][CB] two's-complement fixed point
+  __shared__ int s_cnt;
+  unsigned long long* acc = (unsigned long long*)smem;          // [CB][H*W] two's-complement fixed point: the lanes of a wave
+                                                                // hold bins of ONE channel => neighbouring pixels => distinct banks
+                                                                // (pixel-major [H*W][CB] put them 64 B apart: 8-16-way conflicts)
   const int img = blockIdx.y, c0 = blockIdx.x * CB;
   const int npix = H * W;
   for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) acc[i] = 0ull;
@@ -221,48 +226,55 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   int frac = 0;
   if (bound > 0.f && bound < 3.0e38f) frac = 40 - (ilogbf(bound) + 1);
   __syncthreads();
+  // ROIs are taken in chunks of FX_CHUNK: the workgroup first compacts (roi, scale) of the ROIs of ITS image into LDS,
+  // then every wave streams 8 listed ROIs per step with all 16 loads issued before the first use — the only global
+  // loads in the loop are the two data streams (a per-ROI batch-index / scale lookup in front of them made every step
+  // three dependent memory latencies long and set the kernel's time).  List order is arbitrary; integer accumulation
+  // does not depend on it.
   const int nvec = (CB * nb) / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-  for (int r0 = wave * 4; r0 < R; r0 += nwave * 4) {
-    for (int j = lane; j < nvec; j += 64) {
-      int a4[4][4]; float d[4][4]; bool on[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int r = r0 + u;
-        on[u] = r < R && (int)rois[(long)r * 5] == img;
-        const long base = ((long)(on[u] ? r : 0) * C + c0) * nb + (long)j * 4;
-        if (sizeof(IT) == 4) {
-          const u32x4 av = *(const u32x4*)(argmax + base);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) a4[u][e] = (int)av[e];
-        } else {
-          const u32x2 av = *(const u32x2*)(argmax + base);
-          a4[u][0] = ArgIdx<unsigned short>::dec((unsigned short)(av[0] & 0xFFFFu));
-          a4[u][1] = ArgIdx<unsigned short>::dec((unsigned short)(av[0] >> 16));
-          a4[u][2] = ArgIdx<unsigned short>::dec((unsigned short)(av[1] & 0xFFFFu));
-          a4[u][3] = ArgIdx<unsigned short>::dec((unsigned short)(av[1] >> 16));
-        }
-        if (sizeof(T) == 2) {
-          const u32x2 v = *(const u32x2*)(dout + base);
-          d[u][0] = __uint_as_float(v[0] << 16); d[u][1] = __uint_as_float(v[0] & 0xFFFF0000u);
-          d[u][2] = __uint_as_float(v[1] << 16); d[u][3] = __uint_as_float(v[1] & 0xFFFF0000u);
-        } else {
-          const u32x4 v = *(const u32x4*)(dout + base);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) d[u][e] = __uint_as_float(v[e]);
-        }
+  int* s_r = (int*)(smem + (size_t)npix * CB * 8);
+  float* s_m = (float*)(s_r + FX_CHUNK);
+  for (int rc = 0; rc < R; rc += FX_CHUNK) {
+    __syncthreads();                            // previous chunk's list fully consumed (and acc zeroed, first time)
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for (int r = rc + threadIdx.x; r < min(R, rc + FX_CHUNK); r += blockDim.x)
+      if ((int)rois[(long)r * 5] == img) {
+        const int k = atomicAdd(&s_cnt, 1);
+        s_r[k] = r;
+        s_m[k] = row_scale ? (row_scale[r] + row_scale_add) : 1.0f;
       }
+    __syncthreads();
+    const int cnt = s_cnt;
+    for (int l0 = wave * 8; l0 < cnt; l0 += nwave * 8) {
+      for (int j = lane; j < nvec; j += 64) {
+        u32x4 av[8]; u32x4 dv[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (!on[u]) continue;
-        const float mul = row_scale ? (row_scale[r0 + u] + row_scale_add) : 1.0f;
+        for (int u = 0; u < 8; ++u) {
+          const int r = s_r[min(l0 + u, cnt - 1)];
+          const long base = ((long)r * C + c0) * nb + (long)j * 4;
+          if (sizeof(IT) == 4) av[u] = *(const u32x4*)(argmax + base);
+          else { const u32x2 t = *(const u32x2*)(argmax + base); av[u][0] = t[0]; av[u][1] = t[1]; }
+          if (sizeof(T) == 2) { const u32x2 t = *(const u32x2*)(dout + base); dv[u][0] = t[0]; dv[u][1] = t[1]; }
+          else dv[u] = *(const u32x4*)(dout + base);
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int a = a4[u][e];
-          const int cc = (j * 4 + e) / nb;
-          if (a >= 0) {
-            const long long q = __float2ll_rn(scalbnf(__fmul_rn(d[u][e], mul), frac));
-            atomicAdd(&acc[a * CB + cc], (unsigned long long)q);
+        for (int u = 0; u < 8; ++u) {
+          if (l0 + u >= cnt) continue;
+          const float mul = s_m[l0 + u];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int a; float d;
+            if (sizeof(IT) == 4) a = (int)av[u][e];
+            else a = ArgIdx<unsigned short>::dec((unsigned short)((av[u][e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
+            if (sizeof(T) == 2) d = __uint_as_float((e & 1) ? (dv[u][e >> 1] & 0xFFFF0000u) : (dv[u][e >> 1] << 16));
+            else d = __uint_as_float(dv[u][e]);
+            const int cc = (j * 4 + e) / nb;
+            if (a >= 0) {
+              const long long q = __float2ll_rn(scalbnf(__fmul_rn(d, mul), frac));
+              atomicAdd(&acc[cc * npix + a], (unsigned long long)q);
+            }
           }
         }
       }
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   const T* rimg = relu_ref ? relu_ref + (long)img * npix * C : nullptr;
   for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) {
     const int p = i / CB, cc = i - p * CB;
-    float v = scalbnf((float)(long long)acc[i], -frac);
+    float v = scalbnf((float)(long long)acc[cc * npix + p], -frac);
     if (rimg && !(Elem<T>::load(rimg + (long)p * C + c0 + cc) > 0.f)) v = 0.f;
     Elem<T>::store(dimg + (long)p * C + c0 + cc, v);
   }
@@ -517,7 +529,7 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, int PH, int PW, const void* 
   int cbx = 8;
   while (cbx >= 4 && ((size_t)H * W * cbx * 8 > 128 * 1024 || (C % cbx))) cbx >>= 1;
   if (cbx >= 4 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) && !float_atomics) {
-    const size_t ldsx = (size_t)H * W * cbx * 8;
+    const size_t ldsx = (size_t)H * W * cbx * 8 + FX_CHUNK * 8;
     dim3 gridx(C / cbx, nimg), blockx(1024);
     auto k = roi_pool_bwd_fx_kernel<T, IT>;
     hipError_t ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
