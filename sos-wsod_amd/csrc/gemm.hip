@@ -520,6 +520,8 @@ int launch2(GemmArgs& g, int splitk, hipStream_t stream) {
 //     LDS-DMA instructions per MFMA and bytes staged per FLOP are lowest here (0.25 / 128 FLOP per byte).
 //   * everything else (all convolutions at batch 2, split-K weight gradients, predictor GEMMs): 128x128, 8 waves of
 //     32x64, 2 stages = 64 KiB LDS so that TWO workgroups (also of two different kernels on two streams) share a CU.
+//   * N <= 64 (conv1_1 / conv1_2 at full resolution): 256x64, 8 waves of 32x64, 2 stages = 80 KiB; a 128-wide N tile
+//     would spend half of its MFMAs on zero columns.
 //     With ~250 tiles per conv4/conv5 launch, wave-level parallelism beat deeper prefetch: 2 stages == 4 stages in time.
 template <typename T, int AMODE, int BMODE>
 int launch_auto(GemmArgs& g, int splitk, hipStream_t s) {
@@ -528,6 +530,10 @@ int launch_auto(GemmArgs& g, int splitk, hipStream_t s) {
   auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * sk; };
   const bool big = (v && v[0] == '4') ? true : (v && v[0] == '8') ? false : (g.N > 128 && tiles(256, 256) >= 200);
   if (big) return launch2<T, AMODE, BMODE, 256, 256, 2>(g, splitk, s);
+  if (v && v[0] == '7') return launch2<T, AMODE, BMODE, 256, 128, 2, 32, 64>(g, splitk, s);
+  if (v && v[0] == '9') return launch2<T, AMODE, BMODE, 256, 128, 2, 64, 64>(g, splitk, s);
+  const bool narrow = (v && v[0] == '6') || (!v && g.N <= 64 && sk == 1);     // 64-wide outputs (conv1_x): no half-empty N tile
+  if (narrow) return launch2<T, AMODE, BMODE, 256, 64, 2, 32, 64>(g, splitk, s);
   return launch2<T, AMODE, BMODE, 128, 128, 2, 32, 64>(g, splitk, s);
 }
 
