@@ -108,45 +108,59 @@ int sw_absmax(int dtype, long n, const void* x, float* out, sw_stream_t stream);
  * logits f32 [V*R][ld]: cls logits at columns [cls_col, cls_col+K), det logits at [det_col, det_col+K);
  * per view v: scores[v][r][k] = softmax_k(cls) * softmax_r(det); loss_view[v] = BCE(clamp(sum_r scores), onehot)/K.
  * If dlogits != NULL (f32): dlogits[(v*R+r)*ld_d + col] = grad_scale[0]/V * d loss_view[v] / d logit, where
- * grad_scale is a DEVICE scalar (the cotangent of the mean-over-views loss) so that no host sync is needed. */
+ * grad_scale is a DEVICE scalar (the cotangent of the mean-over-views loss) so that no host sync is needed.
+ * mean_scores (may be NULL): [R] rows of pitch ld_mean, columns [0,K) = mean over views of scores, summed in view
+ * order (roi_heads_oicrplus.py:290-294) — the mining input of refinement round 0.
+ * workspace: >= sw_wsddn_workspace_floats(V, R, K) floats (chunk statistics; the softmax over proposals is cut into
+ * 256-row chunks that run on separate CUs).  Limits: V <= 8, K <= 128. */
+long sw_wsddn_workspace_floats(int V, int R, int K);
 int sw_wsddn_mil(int V, int R, int K, const float* logits, long ld, int cls_col, int det_col, const float* gt_onehot,
                  float* scores, float* loss_view, float* dlogits, long ld_d, const float* grad_scale,
-                 sw_stream_t stream);
+                 float* mean_scores, long ld_mean, float* workspace, sw_stream_t stream);
 
 /* ---- mean over V score matrices (reference: roi_heads_oicrplus.py:290-294,390-395) ----------------------- */
 int sw_mean_views(int V, long n, const float* in, float* out, sw_stream_t stream);
 
+/* ---- view-mean softmax scores of the refinement heads (reference: predict_probs fast_rcnn_oicr.py:702-716 +
+ *      the view average roi_heads_oicrplus.py:390-395) -------------------------------------------------------
+ * out[k][r][j] = mean_v softmax_j(logits[(v*R+r)*ld + cls_col0 + k*col_stride + j]), j in [0,K], k in [0,n_rounds).
+ * These are round k+1's mining scores; they depend on the logits only, so every round comes from one launch. */
+int sw_oicr_mean_probs(int V, int R, int K, int n_rounds, const float* logits, long ld, int cls_col0, int col_stride,
+                       float* out, sw_stream_t stream);
+
 /* ---- pseudo-GT mining + proposal labelling, all device side (reference: get_pgt_top_k
  *      roi_heads_oicrplus.py:607-757, get_pgt_mist :560-605 incl. torchvision batched_nms, pairwise_iou
  *      structures/boxes.py:329-361, Matcher matcher.py:63-111, label_and_sample_proposals roi_heads.py:266-375)
- * scores [R][ncol] f32; gt_classes [G] int32 sorted unique; boxes [R][4] f32.
- * Outputs: per proposal lab_class (class | K background | -1 ignore), lab_weight, lab_index; the kept pseudo-GT
- * list (score-descending): pgt_count[1], pgt_index/pgt_class/pgt_score [>= top_k*G].
+ * n_rounds independent problems (one workgroup each, concurrently), laid out back to back:
+ * scores [n_rounds][R][ncol] f32; gt_classes [G] int32 sorted unique; boxes [R][4] f32 (shared).
+ * Outputs per round: lab_class (class | K background | -1 ignore), lab_weight, lab_index [n_rounds][R]; the kept
+ * pseudo-GT list (score-descending): pgt_count [n_rounds], pgt_index/pgt_class/pgt_score [n_rounds][top_k*G].
  * top_k = max(int(R * MIST_P), 1) is computed by the host exactly as the reference does (:659-660).
- * workspace: >= sw_mine_workspace_bytes(top_k, G) bytes. Limits: R <= 16384, top_k*G <= 16384. */
+ * workspace: >= n_rounds * sw_mine_workspace_bytes(top_k, G) bytes. Limits: R <= 16384, top_k*G <= 16384. */
 long sw_mine_workspace_bytes(int top_k, int G);
-int sw_oicr_mine_label(int R, int ncol, int K, const float* scores, const int32_t* gt_classes, int G,
+int sw_oicr_mine_label(int R, int ncol, int K, int n_rounds, const float* scores, const int32_t* gt_classes, int G,
                        const float* boxes, int top_k, float score_thresh, float nms_thresh, float iou_bg,
                        float iou_fg, int32_t* lab_class, float* lab_weight, int32_t* lab_index, int32_t* pgt_count,
                        int32_t* pgt_index, int32_t* pgt_class, float* pgt_score, void* workspace,
                        sw_stream_t stream);
 
-/* ---- OICR refinement losses + gradient + next-round scores (reference: OICROutputs.__init__/
- *      softmax_cross_entropy_loss/box_reg_loss fast_rcnn_oicr.py:157-226,258-273,276-352; get_deltas
- *      box_regression.py:38-71; predict_probs fast_rcnn_oicr.py:702-716; cross-view targets and the
- *      predictions_k2 quirk roi_heads_oicrplus.py:327-381) ---------------------------------------------------
- * logits f32 [V*R][ld]: class logits at [cls_col, cls_col+K+1), box deltas at [box_col, box_col+4K).
- * boxes [V][R][4].  pred_view[v] = which view's predictions are paired with view v's targets ({0,1,2,2}).
- * loss_view [2][V] (cls then box, already divided by R).  probs [V][R][K+1] = softmax of each view's OWN logits.
- * dlogits (f32, may be NULL): the columns of this round are overwritten with
- * (grad_scale[0]*dcls + grad_scale[1]*dbox)/V; grad_scale is a DEVICE float[2]; reg_weights4 is a HOST float[4]
- * (BBOX_REG_WEIGHTS, a configuration constant passed by value into the launch); workspace: 2*V*R floats
- * (per-row loss terms, summed in fixed order => deterministic losses). */
-int sw_oicr_refine_loss(int V, int R, int K, const float* logits, long ld, int cls_col, int box_col,
-                        const float* boxes, const int32_t* lab_class, const float* lab_weight,
+/* ---- OICR refinement losses + gradient (reference: OICROutputs.__init__/softmax_cross_entropy_loss/
+ *      box_reg_loss fast_rcnn_oicr.py:157-226,258-273,276-352; get_deltas box_regression.py:38-71; cross-view
+ *      targets and the predictions_k2 quirk roi_heads_oicrplus.py:327-381) -----------------------------------
+ * n_rounds refinement heads in one launch.  logits f32 [V*R][ld]: round k has its class logits at
+ * [cls_col + k*col_stride, +K+1) and its box deltas at [box_col + k*col_stride, +4K).  boxes [V][R][4].
+ * lab_class / lab_weight / lab_index [n_rounds][R] (sw_oicr_mine_label's outputs).
+ * pred_view[v] = which view's predictions are paired with view v's targets ({0,1,2,2}).
+ * loss_view [n_rounds][2][V] (cls then box, already divided by R).
+ * dlogits (f32, may be NULL): the columns of every round are overwritten with
+ * (grad_scale[2k]*dcls + grad_scale[2k+1]*dbox)/V; grad_scale is a DEVICE float[2*n_rounds]; reg_weights4 is a HOST
+ * float[4] (BBOX_REG_WEIGHTS, a configuration constant passed by value into the launch); workspace:
+ * n_rounds*2*V*R floats (per-row loss terms, summed in fixed order => deterministic losses). */
+int sw_oicr_refine_loss(int V, int R, int K, int n_rounds, const float* logits, long ld, int cls_col, int box_col,
+                        int col_stride, const float* boxes, const int32_t* lab_class, const float* lab_weight,
                         const int32_t* lab_index, const int32_t* pred_view, const float* reg_weights4,
-                        float* loss_view, float* probs, float* dlogits, long ld_d,
-                        const float* grad_scale, float* workspace, sw_stream_t stream);
+                        float* loss_view, float* dlogits, long ld_d, const float* grad_scale, float* workspace,
+                        sw_stream_t stream);
 
 /* ---- inference (reference: OICRPlusHeads._forward_box_test roi_heads_oicrplus.py:432-475, predict_probs_K /
  *      predict_boxes_K fast_rcnn_oicr.py:674-735, Box2BoxTransform.apply_deltas box_regression.py:73-110,

@@ -46,15 +46,17 @@ SIGNATURES = {
     "sw_roi_pool_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                 c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_absmax": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    "sw_wsddn_workspace_floats": (c_long, [c_int, c_int, c_int]),
     "sw_wsddn_mil": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                             c_void_p, c_long, c_void_p, c_void_p]),
+                             c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_mean_views": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    "sw_oicr_mean_probs": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
     "sw_mine_workspace_bytes": (c_long, [c_int, c_int]),
-    "sw_oicr_mine_label": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float,
+    "sw_oicr_mine_label": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
-    "sw_oicr_refine_loss": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, _F4, c_void_p, c_void_p, c_void_p, c_long, c_void_p,
+    "sw_oicr_refine_loss": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, _F4, c_void_p, c_void_p, c_long, c_void_p,
                                     c_void_p, c_void_p]),
     "sw_oicr_predict": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, _F4, c_float, c_void_p,
                                 c_void_p, c_void_p]),

@@ -1,9 +1,11 @@
 // Fused per-proposal kernels of the WSDDN / OICR heads on gfx950 (all f32 arithmetic):
-//   sw_wsddn_mil        dual softmax (classes x proposals), image-level BCE and its gradient
-//   sw_oicr_refine_loss weighted CE + L1 box loss, gradients, next-round softmax scores
-//   sw_oicr_mine_label  top-p% mining, score threshold, class-agnostic NMS, IoU matching -> labels
-// They are latency-bound glue in the reference (dozens of tiny kernels + host syncs);
-// here each is ONE launch with wave64 shuffle reductions and no host round trip.
+//   sw_wsddn_mil        dual softmax (classes x proposals), image-level BCE and its gradient, view-mean scores
+//   sw_oicr_mean_probs  view-mean softmax scores of every refinement head (the next round's mining input)
+//   sw_oicr_mine_label  top-p% mining, score threshold, class-agnostic NMS, IoU matching -> labels (all rounds at once)
+//   sw_oicr_refine_loss weighted CE + L1 box loss and gradients (all rounds at once)
+// They are latency-bound glue in the reference (dozens of tiny kernels + host syncs); here the whole
+// chain is 8 launches with wave64 shuffle reductions, no host round trip, and the K refinement rounds side by side
+// (a round's mining scores depend on the logits only, not on the previous round's labels).
 #include <float.h>
 #include "common.h"
 #include "soswsod_hip.h"
@@ -14,101 +16,211 @@ constexpr int KMAX = 128;      // max classes (+1) held in LDS column accumulato
 constexpr int NWAVE = 16;      // 1024-thread workgroups
 
 // ------------------------------------------------------------------------------------------- WSDDN
-// column reduction helper: every wave reduces its 64 rows with shuffles and folds the result into its own
-// LDS row; rows are then combined in fixed wave order => deterministic.
-template <bool IS_MAX, typename F>
-__device__ __forceinline__ void column_reduce(int R, int K, float (*part)[KMAX], float* result, F f) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = lane; k < K; k += 64) part[wave][k] = IS_MAX ? -FLT_MAX : 0.f;
-  __syncthreads();
-  for (int r0 = wave * 64; r0 < R; r0 += NWAVE * 64) {
-    const int r = r0 + lane;
-    for (int k = 0; k < K; ++k) {
-      float v = (r < R) ? f(r, k) : (IS_MAX ? -FLT_MAX : 0.f);
-      v = IS_MAX ? wave_reduce_max(v) : wave_reduce_sum(v);
-      if (lane == 0) part[wave][k] = IS_MAX ? fmaxf(part[wave][k], v) : part[wave][k] + v;
-    }
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float a = part[0][k];
-    for (int w = 1; w < NWAVE; ++w) a = IS_MAX ? fmaxf(a, part[w][k]) : a + part[w][k];
-    result[k] = a;
-  }
-  __syncthreads();
+// The softmax over PROPOSALS couples all R rows of a view, the one over classes all K columns of a row.  A single
+// workgroup per view (the first version) spent 220 us on 4 CUs; here the rows are cut into chunks of WS_CH and the
+// coupling goes through a few hundred floats of workspace:
+//   1. wsddn_stats_kernel   (chunk, view): per detection column the chunk's max and sum exp(x - max)
+//   2. wsddn_scores_kernel  (chunk): merges the chunk statistics (fixed order), thread = proposal row over all views:
+//        scores, their mean over views (mining input), per-chunk column sums of the scores
+//   3. wsddn_grad_kernel    (chunk, view): image-level score -> clamped BCE, its gradient through both softmaxes
+// Every reduction has a fixed order => deterministic.
+constexpr int WS_CH = 256;     // rows per workgroup
+constexpr int WS_VMAX = 8;     // views held in registers by the scores kernel
+
+// block-wide column reduction of one value per thread and column index c (result[c] valid after the call)
+template <bool IS_MAX>
+__device__ __forceinline__ void chunk_reduce_store(float v, int c, float (*part)[KMAX]) {
+  v = IS_MAX ? wave_reduce_max(v) : wave_reduce_sum(v);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][c] = v;
 }
 
-__global__ __launch_bounds__(1024) void wsddn_kernel(int R, int K, const float* __restrict__ logits, long ld, int cls_col,
-                                                     int det_col, const float* __restrict__ onehot,
-                                                     float* __restrict__ scores, float* __restrict__ loss_view,
-                                                     float* __restrict__ dlogits, long ld_d,
-                                                     const float* __restrict__ grad_scale, int V) {
-  __shared__ float part[NWAVE][KMAX];
-  __shared__ float s_max[KMAX], s_sum[KMAX], s_S[KMAX], s_g[KMAX];
-  __shared__ float red[32];
-  const int v = blockIdx.x;
-  const float* L = logits + (long)v * R * ld;
-  float* S = scores + (long)v * R * K;
-
-  // softmax over proposals (dim 0) of the detection stream: column max, column sum of exp
-  column_reduce<true>(R, K, part, s_max, [&](int r, int k) { return L[(long)r * ld + det_col + k]; });
-  column_reduce<false>(R, K, part, s_sum, [&](int r, int k) { return expf(L[(long)r * ld + det_col + k] - s_max[k]); });
-
-  // scores = softmax_k(cls) * softmax_r(det); written once, column sums folded in the same sweep
-  for (int r = threadIdx.x; r < R; r += blockDim.x) {
-    const float* c = L + (long)r * ld + cls_col;
-    const float* d = L + (long)r * ld + det_col;
-    float m = -FLT_MAX;
-    for (int k = 0; k < K; ++k) m = fmaxf(m, c[k]);
-    float z = 0.f;
-    for (int k = 0; k < K; ++k) z += expf(c[k] - m);
-    for (int k = 0; k < K; ++k) {
-      const float p = expf(c[k] - m) / z;
-      const float q = expf(d[k] - s_max[k]) / s_sum[k];
-      S[(long)r * K + k] = p * q;
-    }
+__global__ __launch_bounds__(WS_CH) void wsddn_stats_kernel(int R, int K, const float* __restrict__ logits, long ld,
+                                                            int det_col, float* __restrict__ pm, float* __restrict__ ps) {
+  __shared__ float part[WS_CH / 64][KMAX];
+  __shared__ float s_m[KMAX];
+  const int chunk = blockIdx.x, v = blockIdx.y, nchunk = gridDim.x;
+  const int r = chunk * WS_CH + threadIdx.x;
+  const float* d = logits + ((long)v * R + min(r, R - 1)) * ld + det_col;
+  for (int k = 0; k < K; ++k) chunk_reduce_store<true>(r < R ? d[k] : -FLT_MAX, k, part);
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += WS_CH) {
+    float m = part[0][k];
+    for (int w = 1; w < WS_CH / 64; ++w) m = fmaxf(m, part[w][k]);
+    s_m[k] = m;
   }
   __syncthreads();
-  column_reduce<false>(R, K, part, s_S, [&](int r, int k) { return S[(long)r * K + k]; });
+  for (int k = 0; k < K; ++k) chunk_reduce_store<false>(r < R ? expf(d[k] - s_m[k]) : 0.f, k, part);
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += WS_CH) {
+    float z = part[0][k];
+    for (int w = 1; w < WS_CH / 64; ++w) z += part[w][k];
+    pm[((long)v * nchunk + chunk) * K + k] = s_m[k];
+    ps[((long)v * nchunk + chunk) * K + k] = z;
+  }
+}
 
+// merged column statistics of view v: max over chunks, sum rescaled to that max (chunk order)
+__device__ __forceinline__ void merge_stats(int nchunk, int K, int v, int k, const float* pm, const float* ps, float* m_out,
+                                            float* z_out) {
+  float m = -FLT_MAX;
+  for (int c = 0; c < nchunk; ++c) m = fmaxf(m, pm[((long)v * nchunk + c) * K + k]);
+  float z = 0.f;
+  for (int c = 0; c < nchunk; ++c) z += ps[((long)v * nchunk + c) * K + k] * expf(pm[((long)v * nchunk + c) * K + k] - m);
+  *m_out = m; *z_out = z;
+}
+
+__global__ __launch_bounds__(WS_CH) void wsddn_scores_kernel(int V, int R, int K, const float* __restrict__ logits, long ld,
+                                                             int cls_col, int det_col, const float* __restrict__ pm,
+                                                             const float* __restrict__ ps, float* __restrict__ cm,
+                                                             float* __restrict__ cz, float* __restrict__ pS,
+                                                             float* __restrict__ scores, float* __restrict__ mean_scores,
+                                                             long ld_mean) {
+  __shared__ float part[WS_CH / 64][KMAX];
+  __shared__ float s_max[WS_VMAX][KMAX], s_sum[WS_VMAX][KMAX];
+  const int chunk = blockIdx.x, nchunk = gridDim.x;
+  for (int i = threadIdx.x; i < V * K; i += WS_CH) {
+    const int v = i / K, k = i - v * K;
+    float m, z;
+    merge_stats(nchunk, K, v, k, pm, ps, &m, &z);
+    s_max[v][k] = m; s_sum[v][k] = z;
+    if (chunk == 0) { cm[i] = m; cz[i] = z; }
+  }
+  __syncthreads();
+  const int r = chunk * WS_CH + threadIdx.x;
+  const bool ok = r < R;
+  const int rr = ok ? r : R - 1;
+  float rm[WS_VMAX], rz[WS_VMAX];                        // row softmax over classes, per view
+#pragma unroll
+  for (int v = 0; v < WS_VMAX; ++v) {
+    rm[v] = 0.f; rz[v] = 1.f;
+    if (v < V) {
+      const float* c = logits + ((long)v * R + rr) * ld + cls_col;
+      float m = -FLT_MAX;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, c[k]);
+      float z = 0.f;
+      for (int k = 0; k < K; ++k) z += expf(c[k] - m);
+      rm[v] = m; rz[v] = z;
+    }
+  }
+  for (int v0 = 0; v0 < V; ++v0) {                       // column sums per view need one block reduction each
+    for (int k = 0; k < K; ++k) {
+      float sc = 0.f;
+#pragma unroll
+      for (int v = 0; v < WS_VMAX; ++v) {
+        if (v == v0) {
+          const float* row = logits + ((long)v * R + rr) * ld;
+          const float p = expf(row[cls_col + k] - rm[v]) / rz[v];
+          const float q = expf(row[det_col + k] - s_max[v][k]) / s_sum[v][k];
+          sc = p * q;
+        }
+      }
+      if (ok) scores[((long)v0 * R + r) * K + k] = sc;
+      chunk_reduce_store<false>(ok ? sc : 0.f, k, part);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += WS_CH) {
+      float a = part[0][k];
+      for (int w = 1; w < WS_CH / 64; ++w) a += part[w][k];
+      pS[((long)v0 * nchunk + chunk) * K + k] = a;
+    }
+    __syncthreads();
+  }
+  if (mean_scores && ok) {                               // ((s0+s1)+s2)+s3 then / V, as the reference adds the views
+    for (int k = 0; k < K; ++k) {
+      float a = scores[(long)r * K + k];
+      for (int v = 1; v < V; ++v) a += scores[((long)v * R + r) * K + k];
+      mean_scores[(long)r * ld_mean + k] = __fdiv_rn(a, (float)V);
+    }
+  }
+}
+
+__global__ __launch_bounds__(WS_CH) void wsddn_grad_kernel(int V, int R, int K, const float* __restrict__ logits, long ld,
+                                                           int cls_col, int det_col, const float* __restrict__ onehot,
+                                                           const float* __restrict__ cm, const float* __restrict__ cz,
+                                                           const float* __restrict__ pS, int nchunk,
+                                                           const float* __restrict__ scores, float* __restrict__ loss_view,
+                                                           float* __restrict__ dlogits, long ld_d,
+                                                           const float* __restrict__ grad_scale) {
+  __shared__ float s_S[KMAX], s_g[KMAX], s_max[KMAX], s_sum[KMAX];
+  __shared__ float red[32];
+  const int chunk = blockIdx.x, v = blockIdx.y;
   // BCE on the clamped image-level score (fast_rcnn_wsddn.py:340-375); gradient is zero where clamped
   float lpart = 0.f;
   const float gs = (dlogits && grad_scale) ? grad_scale[0] / (float)V : 0.f;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const float raw = s_S[k];
+  for (int k = threadIdx.x; k < K; k += WS_CH) {
+    float raw = 0.f;
+    for (int c = 0; c < nchunk; ++c) raw += pS[((long)v * nchunk + c) * K + k];
     const float y = fminf(fmaxf(raw, 1e-6f), 1.0f - 1e-6f);
     const float t = onehot[k];
     lpart += -(t * fmaxf(logf(y), -100.f) + (1.f - t) * fmaxf(logf(1.f - y), -100.f));
     const bool inside = (raw >= 1e-6f) && (raw <= 1.0f - 1e-6f);
+    s_S[k] = raw;
     s_g[k] = inside ? gs * (-(t / y - (1.f - t) / (1.f - y)) / (float)K) : 0.f;
+    s_max[k] = cm[v * K + k]; s_sum[k] = cz[v * K + k];
   }
   const float ltot = block_reduce_sum(lpart, red);
-  if (threadIdx.x == 0) loss_view[v] = ltot / (float)K;
+  if (chunk == 0 && threadIdx.x == 0) loss_view[v] = ltot / (float)K;
   __syncthreads();
   if (!dlogits) return;
-
+  const int r = chunk * WS_CH + threadIdx.x;
+  if (r >= R) return;
   // backward of the two softmaxes
-  float* DL = dlogits + (long)v * R * ld_d;
-  for (int r = threadIdx.x; r < R; r += blockDim.x) {
-    const float* c = L + (long)r * ld + cls_col;
-    const float* d = L + (long)r * ld + det_col;
-    float m = -FLT_MAX;
-    for (int k = 0; k < K; ++k) m = fmaxf(m, c[k]);
-    float z = 0.f;
-    for (int k = 0; k < K; ++k) z += expf(c[k] - m);
-    float dot = 0.f;                              // sum_j g_j s_rj
-    for (int k = 0; k < K; ++k) dot += s_g[k] * S[(long)r * K + k];
-    for (int k = 0; k < K; ++k) {
-      const float p = expf(c[k] - m) / z;
-      const float q = expf(d[k] - s_max[k]) / s_sum[k];
-      DL[(long)r * ld_d + cls_col + k] = p * (s_g[k] * q - dot);
-      DL[(long)r * ld_d + det_col + k] = s_g[k] * q * (p - s_S[k]);
+  const float* c = logits + ((long)v * R + r) * ld + cls_col;
+  const float* d = logits + ((long)v * R + r) * ld + det_col;
+  const float* S = scores + ((long)v * R + r) * K;
+  float* DL = dlogits + ((long)v * R + r) * ld_d;
+  float m = -FLT_MAX;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, c[k]);
+  float z = 0.f;
+  for (int k = 0; k < K; ++k) z += expf(c[k] - m);
+  float dot = 0.f;                              // sum_j g_j s_rj
+  for (int k = 0; k < K; ++k) dot += s_g[k] * S[k];
+  for (int k = 0; k < K; ++k) {
+    const float p = expf(c[k] - m) / z;
+    const float q = expf(d[k] - s_max[k]) / s_sum[k];
+    DL[cls_col + k] = p * (s_g[k] * q - dot);
+    DL[det_col + k] = s_g[k] * q * (p - s_S[k]);
+  }
+}
+
+// mean over views of every refinement head's own softmax:  out[k][r][j] = (((p0+p1)+p2)+p3)/V,
+// p_v = softmax_j(logits[v][r][cls_col0 + k*col_stride + j])   (predict_probs fast_rcnn_oicr.py:702-716, view
+// average roi_heads_oicrplus.py:390-395).  These are the mining scores of round k+1; they depend on the logits only,
+// so all rounds are produced by one launch and the rounds' mining runs concurrently.
+__global__ __launch_bounds__(256) void mean_probs_kernel(int V, int R, int K, const float* __restrict__ logits, long ld,
+                                                         int cls_col0, int col_stride, float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (r >= R) return;
+  const int K1 = K + 1;
+  float rm[WS_VMAX], rz[WS_VMAX];
+#pragma unroll
+  for (int v = 0; v < WS_VMAX; ++v) {
+    rm[v] = 0.f; rz[v] = 1.f;
+    if (v < V) {
+      const float* x = logits + ((long)v * R + r) * ld + cls_col0 + k * col_stride;
+      float m = -FLT_MAX;
+      for (int j = 0; j < K1; ++j) m = fmaxf(m, x[j]);
+      float z = 0.f;
+      for (int j = 0; j < K1; ++j) z += expf(x[j] - m);
+      rm[v] = m; rz[v] = z;
     }
+  }
+  float* o = out + ((long)k * R + r) * K1;
+  for (int j = 0; j < K1; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int v = 0; v < WS_VMAX; ++v) {
+      if (v < V) {
+        const float p = expf(logits[((long)v * R + r) * ld + cls_col0 + k * col_stride + j] - rm[v]) / rz[v];
+        a = v == 0 ? p : a + p;
+      }
+    }
+    o[j] = __fdiv_rn(a, (float)V);
   }
 }
 
 // ------------------------------------------------------------------------------------------- OICR refine loss
-// grid = (row chunks, prediction views).  A thread owns one proposal row of prediction view pv and serves every
+// grid = (row chunks, prediction views, refinement rounds).  A thread owns one proposal row of prediction view pv and serves every
 // target view v with pred_view[v] == pv in order, so the (reference-quirk) double use of view 2's logits needs no
 // atomics.  Per-row loss terms go to a scratch array and are summed in fixed order by refine_reduce_kernel
 // (deterministic, no float atomics).
@@ -119,13 +231,17 @@ __global__ __launch_bounds__(256) void refine_loss_kernel(int V, int R, int K, c
                                                           const int* __restrict__ lab_index,
                                                           const int* __restrict__ pred_view,
                                                           float wx, float wy, float ww, float wh,
-                                                          float* __restrict__ row_loss, float* __restrict__ probs,
+                                                          float* __restrict__ row_loss,
                                                           float* __restrict__ dlogits, long ld_d,
-                                                          const float* __restrict__ grad_scale) {
-  const int pv = blockIdx.y;
+                                                          const float* __restrict__ grad_scale, int col_stride) {
+  const int pv = blockIdx.y, round = blockIdx.z;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const int K1 = K + 1;
+  cls_col += round * col_stride; box_col += round * col_stride;
+  lab_class += (long)round * R; lab_weight += (long)round * R; lab_index += (long)round * R;
+  row_loss += (long)round * 2 * V * R;
+  if (grad_scale) grad_scale += 2 * round;
   const float* x = logits + ((long)pv * R + r) * ld + cls_col;
   float* DL = dlogits ? dlogits + ((long)pv * R + r) * ld_d : nullptr;
   const float gs_cls = (dlogits && grad_scale) ? grad_scale[0] / (float)V / (float)R : 0.f;
@@ -135,8 +251,6 @@ __global__ __launch_bounds__(256) void refine_loss_kernel(int V, int R, int K, c
   for (int j = 0; j < K1; ++j) m = fmaxf(m, x[j]);
   float z = 0.f;
   for (int j = 0; j < K1; ++j) z += expf(x[j] - m);
-  float* P = probs + ((long)pv * R + r) * K1;
-  for (int j = 0; j < K1; ++j) P[j] = expf(x[j] - m) / z;
   const float logz = logf(z);
   const int gt = lab_class[r];
   const float w = gt == -1 ? 0.f : lab_weight[r];                       // fast_rcnn_oicr.py:217-218
@@ -180,7 +294,7 @@ __global__ __launch_bounds__(256) void refine_loss_kernel(int V, int R, int K, c
   }
 }
 
-// loss_view[i] = sum_r row_loss[i][r] / R, fixed summation order (i = term * V + view)
+// loss_view[i] = sum_r row_loss[i][r] / R, fixed summation order (i = (round * 2 + term) * V + view)
 __global__ __launch_bounds__(256) void refine_reduce_kernel(int R, const float* __restrict__ row_loss,
                                                             float* __restrict__ loss_view) {
   __shared__ float red[32];
@@ -243,9 +357,17 @@ __global__ __launch_bounds__(1024) void mine_label_kernel(int R, int ncol, int K
                                                           int* __restrict__ lab_class, float* __restrict__ lab_weight,
                                                           int* __restrict__ lab_index, int* __restrict__ pgt_count,
                                                           int* __restrict__ pgt_index, int* __restrict__ pgt_class,
-                                                          float* __restrict__ pgt_score, char* __restrict__ ws) {
+                                                          float* __restrict__ pgt_score, char* __restrict__ ws,
+                                                          long ws_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n_slots = top_k * G;
+  {                                             // one workgroup per refinement round, rounds laid out back to back
+    const int round = blockIdx.x;
+    scores += (long)round * R * ncol;
+    lab_class += (long)round * R; lab_weight += (long)round * R; lab_index += (long)round * R;
+    pgt_count += round; pgt_index += (long)round * n_slots; pgt_class += (long)round * n_slots;
+    pgt_score += (long)round * n_slots; ws += (long)round * ws_stride;
+  }
   const int NP = next_pow2(R > n_slots ? R : n_slots);
   unsigned long long* keys = (unsigned long long*)smem;                 // [NP]
   unsigned char* sup = (unsigned char*)(smem + (size_t)NP * 8);          // [n_slots]
@@ -482,49 +604,76 @@ __global__ __launch_bounds__(1024) void det_merge_kernel(int K, int topk, float 
 
 }  // namespace
 
+extern "C" long sw_wsddn_workspace_floats(int V, int R, int K) {
+  const long nchunk = (R + WS_CH - 1) / WS_CH;
+  return 3L * V * nchunk * K + 2L * V * K;
+}
+
 extern "C" int sw_wsddn_mil(int V, int R, int K, const float* logits, long ld, int cls_col, int det_col,
                             const float* gt_onehot, float* scores, float* loss_view, float* dlogits, long ld_d,
-                            const float* grad_scale, hipStream_t stream) {
-  if (K > KMAX) return -6;
-  hipLaunchKernelGGL(wsddn_kernel, dim3(V), dim3(1024), 0, stream, R, K, logits, ld, cls_col, det_col, gt_onehot, scores,
-                     loss_view, dlogits, ld_d, grad_scale, V);
+                            const float* grad_scale, float* mean_scores, long ld_mean, float* workspace,
+                            hipStream_t stream) {
+  if (K > KMAX || V > WS_VMAX || V < 1 || R < 1) return -6;
+  const int nchunk = (R + WS_CH - 1) / WS_CH;
+  float* pm = workspace;
+  float* ps = pm + (long)V * nchunk * K;
+  float* pS = ps + (long)V * nchunk * K;
+  float* cm = pS + (long)V * nchunk * K;
+  float* cz = cm + (long)V * K;
+  hipLaunchKernelGGL(wsddn_stats_kernel, dim3(nchunk, V), dim3(WS_CH), 0, stream, R, K, logits, ld, det_col, pm, ps);
+  SW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(wsddn_scores_kernel, dim3(nchunk), dim3(WS_CH), 0, stream, V, R, K, logits, ld, cls_col, det_col, pm, ps,
+                     cm, cz, pS, scores, mean_scores, ld_mean);
+  SW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(wsddn_grad_kernel, dim3(dlogits ? nchunk : 1, V), dim3(WS_CH), 0, stream, V, R, K, logits, ld, cls_col,
+                     det_col, gt_onehot, cm, cz, pS, nchunk, scores, loss_view, dlogits, ld_d, grad_scale);
   SW_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int sw_oicr_refine_loss(int V, int R, int K, const float* logits, long ld, int cls_col, int box_col,
-                                   const float* boxes, const int32_t* lab_class, const float* lab_weight,
-                                   const int32_t* lab_index, const int32_t* pred_view, const float* reg_weights4,
-                                   float* loss_view, float* probs, float* dlogits, long ld_d,
+extern "C" int sw_oicr_mean_probs(int V, int R, int K, int n_rounds, const float* logits, long ld, int cls_col0,
+                                  int col_stride, float* out, hipStream_t stream) {
+  if (R <= 0 || n_rounds <= 0) return 0;
+  if (V > WS_VMAX || V < 1) return -6;
+  hipLaunchKernelGGL(mean_probs_kernel, dim3((R + 255) / 256, n_rounds), dim3(256), 0, stream, V, R, K, logits, ld, cls_col0,
+                     col_stride, out);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_oicr_refine_loss(int V, int R, int K, int n_rounds, const float* logits, long ld, int cls_col,
+                                   int box_col, int col_stride, const float* boxes, const int32_t* lab_class,
+                                   const float* lab_weight, const int32_t* lab_index, const int32_t* pred_view,
+                                   const float* reg_weights4, float* loss_view, float* dlogits, long ld_d,
                                    const float* grad_scale, float* workspace, hipStream_t stream) {
-  // reg_weights4: HOST pointer (configuration constants BBOX_REG_WEIGHTS); workspace: 2*V*R floats
-  if (R <= 0) return 0;
-  hipLaunchKernelGGL(refine_loss_kernel, dim3((R + 255) / 256, V), dim3(256), 0, stream, V, R, K, logits, ld, cls_col,
-                     box_col, boxes, lab_class, lab_weight, lab_index, pred_view, reg_weights4[0], reg_weights4[1],
-                     reg_weights4[2], reg_weights4[3], workspace, probs, dlogits, ld_d, grad_scale);
+  // reg_weights4: HOST pointer (configuration constants BBOX_REG_WEIGHTS); workspace: n_rounds*2*V*R floats
+  if (R <= 0 || n_rounds <= 0) return 0;
+  hipLaunchKernelGGL(refine_loss_kernel, dim3((R + 255) / 256, V, n_rounds), dim3(256), 0, stream, V, R, K, logits, ld,
+                     cls_col, box_col, boxes, lab_class, lab_weight, lab_index, pred_view, reg_weights4[0], reg_weights4[1],
+                     reg_weights4[2], reg_weights4[3], workspace, dlogits, ld_d, grad_scale, col_stride);
   SW_CHECK_LAUNCH();
-  hipLaunchKernelGGL(refine_reduce_kernel, dim3(2 * V), dim3(256), 0, stream, R, workspace, loss_view);
+  hipLaunchKernelGGL(refine_reduce_kernel, dim3(2 * V * n_rounds), dim3(256), 0, stream, R, workspace, loss_view);
   SW_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" long sw_mine_workspace_bytes(int top_k, int G) { return (long)top_k * G * 20 + 64; }
+extern "C" long sw_mine_workspace_bytes(int top_k, int G) { return (((long)top_k * G * 20 + 64) + 15) / 16 * 16; }
 
-extern "C" int sw_oicr_mine_label(int R, int ncol, int K, const float* scores, const int32_t* gt_classes, int G,
-                                  const float* boxes, int top_k, float score_thresh, float nms_thresh, float iou_bg,
-                                  float iou_fg, int32_t* lab_class, float* lab_weight, int32_t* lab_index,
-                                  int32_t* pgt_count, int32_t* pgt_index, int32_t* pgt_class, float* pgt_score,
-                                  void* workspace, hipStream_t stream) {
-  if (R > 16384 || (long)top_k * G > 16384 || top_k > R || G < 1) return -6;
+extern "C" int sw_oicr_mine_label(int R, int ncol, int K, int n_rounds, const float* scores, const int32_t* gt_classes,
+                                  int G, const float* boxes, int top_k, float score_thresh, float nms_thresh,
+                                  float iou_bg, float iou_fg, int32_t* lab_class, float* lab_weight,
+                                  int32_t* lab_index, int32_t* pgt_count, int32_t* pgt_index, int32_t* pgt_class,
+                                  float* pgt_score, void* workspace, hipStream_t stream) {
+  if (R > 16384 || (long)top_k * G > 16384 || top_k > R || G < 1 || n_rounds < 1) return -6;
   int np = 64;
   const int need = R > top_k * G ? R : top_k * G;
   while (np < need) np <<= 1;
   const size_t lds = (size_t)np * 8 + (size_t)top_k * G;
   hipError_t e = hipFuncSetAttribute((const void*)mine_label_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(mine_label_kernel, dim3(1), dim3(1024), lds, stream, R, ncol, K, scores, gt_classes, G, boxes, top_k,
-                     score_thresh, nms_thresh, iou_bg, iou_fg, lab_class, lab_weight, lab_index, pgt_count, pgt_index,
-                     pgt_class, pgt_score, (char*)workspace);
+  hipLaunchKernelGGL(mine_label_kernel, dim3(n_rounds), dim3(1024), lds, stream, R, ncol, K, scores, gt_classes, G, boxes,
+                     top_k, score_thresh, nms_thresh, iou_bg, iou_fg, lab_class, lab_weight, lab_index, pgt_count,
+                     pgt_index, pgt_class, pgt_score, (char*)workspace, sw_mine_workspace_bytes(top_k, G));
   SW_CHECK_LAUNCH();
   return 0;
 }

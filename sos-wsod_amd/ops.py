@@ -207,10 +207,15 @@ def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_ad
     return dfeat
 
 
-def wsddn_mil(logits, V, R, K, cls_col, det_col, gt_onehot, scores, loss_view, dlogits=None, grad_scale=None):
+def wsddn_mil(logits, V, R, K, cls_col, det_col, gt_onehot, scores, loss_view, dlogits=None, grad_scale=None,
+              mean_scores=None, workspace=None):
+    """mean_scores: optional [R][>=K] f32 (row pitch = its stride) receiving the view-mean scores"""
     _need_gpu(logits, gt_onehot, scores, loss_view)
+    if workspace is None:
+        workspace = torch.empty(int(lib.sw_wsddn_workspace_floats(V, R, K)), device=logits.device, dtype=torch.float32)
     check(lib.sw_wsddn_mil(V, R, K, _p(logits), logits.stride(0), cls_col, det_col, _p(gt_onehot), _p(scores),
                            _p(loss_view), _p(dlogits), 0 if dlogits is None else dlogits.stride(0), _p(grad_scale),
+                           _p(mean_scores), 0 if mean_scores is None else mean_scores.stride(-2), _p(workspace),
                            _stream()), "sw_wsddn_mil")
 
 
@@ -220,28 +225,40 @@ def mean_views(x, out):
     return out
 
 
-def mine_workspace_bytes(top_k, G):
-    return int(lib.sw_mine_workspace_bytes(top_k, G))
+def oicr_mean_probs(logits, V, R, K, n_rounds, cls_col0, col_stride, out):
+    """out [n_rounds][R][K+1] = view-mean softmax of each refinement head's class logits"""
+    _need_gpu(logits, out)
+    check(lib.sw_oicr_mean_probs(V, R, K, n_rounds, _p(logits), logits.stride(0), cls_col0, col_stride, _p(out), _stream()),
+          "sw_oicr_mean_probs")
+    return out
+
+
+def mine_workspace_bytes(top_k, G, n_rounds=1):
+    return int(lib.sw_mine_workspace_bytes(top_k, G)) * n_rounds
 
 
 def oicr_mine_label(scores, gt_classes_i32, boxes, K, top_k, thresh, nms_thresh, iou_bg, iou_fg, lab_class, lab_weight,
                     lab_index, pgt_count, pgt_index, pgt_class, pgt_score, workspace):
+    """scores [R][ncol] (one round) or [n_rounds][R][ncol]; the outputs carry the same leading dimension"""
     _need_gpu(scores, gt_classes_i32, boxes)
-    R, ncol = scores.shape
+    n_rounds = 1 if scores.dim() == 2 else scores.shape[0]
+    R, ncol = scores.shape[-2:]
     G = gt_classes_i32.numel()
-    check(lib.sw_oicr_mine_label(R, ncol, K, _p(scores), _p(gt_classes_i32), G, _p(boxes), int(top_k), float(thresh),
-                                 float(nms_thresh), float(iou_bg), float(iou_fg), _p(lab_class), _p(lab_weight),
-                                 _p(lab_index), _p(pgt_count), _p(pgt_index), _p(pgt_class), _p(pgt_score),
+    check(lib.sw_oicr_mine_label(R, ncol, K, n_rounds, _p(scores), _p(gt_classes_i32), G, _p(boxes), int(top_k),
+                                 float(thresh), float(nms_thresh), float(iou_bg), float(iou_fg), _p(lab_class),
+                                 _p(lab_weight), _p(lab_index), _p(pgt_count), _p(pgt_index), _p(pgt_class), _p(pgt_score),
                                  _p(workspace), _stream()), "sw_oicr_mine_label")
 
 
 def oicr_refine_loss(logits, V, R, K, cls_col, box_col, boxes, lab_class, lab_weight, lab_index, pred_view, reg_weights,
-                     loss_view, probs, dlogits=None, grad_scale=None, workspace=None):
+                     loss_view, dlogits=None, grad_scale=None, workspace=None, n_rounds=1, col_stride=0):
+    """n_rounds heads at columns cls_col/box_col + k*col_stride; lab_* [n_rounds][R]; loss_view [n_rounds][2][V];
+    grad_scale device float[2*n_rounds]"""
     rw = (ctypes.c_float * 4)(*[float(v) for v in reg_weights])
     if workspace is None:
-        workspace = torch.empty(2 * V * R, device=logits.device, dtype=torch.float32)
-    check(lib.sw_oicr_refine_loss(V, R, K, _p(logits), logits.stride(0), cls_col, box_col, _p(boxes), _p(lab_class),
-                                  _p(lab_weight), _p(lab_index), _p(pred_view), rw, _p(loss_view), _p(probs),
+        workspace = torch.empty(n_rounds * 2 * V * R, device=logits.device, dtype=torch.float32)
+    check(lib.sw_oicr_refine_loss(V, R, K, n_rounds, _p(logits), logits.stride(0), cls_col, box_col, col_stride, _p(boxes),
+                                  _p(lab_class), _p(lab_weight), _p(lab_index), _p(pred_view), rw, _p(loss_view),
                                   _p(dlogits), 0 if dlogits is None else dlogits.stride(0), _p(grad_scale), _p(workspace),
                                   _stream()), "sw_oicr_refine_loss")
 

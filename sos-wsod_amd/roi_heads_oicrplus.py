@@ -227,35 +227,37 @@ class OICRPlusHeads(nn.Module):
         logits = torch.empty(V * R, LD, device=dev, dtype=torch.float32)
         ops.gemm(h2, Wh, logits, V * R, LD, D2, ep=ops.make_epilogue(bias=bh, out_dtype=torch.float32))
         cols = self._col_layout()
-        # --- WSDDN MIL scores + loss (+ unit gradient), view average
+        # --- WSDDN MIL scores + loss (+ unit gradient) and the view-averaged scores = round 0's mining input
         n_loss = 1 + 2 * RK
+        K1 = K + 1
         loss_view = torch.zeros(n_loss, V, device=dev, dtype=torch.float32)
         dlogits = torch.zeros(V * R, LD, device=dev, dtype=torch.float32) if inp["need_grad"] else None
         ones = inp["ones"]
         scores = torch.empty(V, R, K, device=dev, dtype=torch.float32)
-        ops.wsddn_mil(logits, V, R, K, cols["cls"], cols["det"], inp["gt_onehot"], scores, loss_view[0], dlogits, ones)
-        prev = torch.empty(R, K, device=dev, dtype=torch.float32)
-        ops.mean_views(scores, prev)
-        # --- K refinement rounds: mine pseudo-GT on the averaged scores, label, losses, next scores
+        # mining scores of all rounds, one (R, K+1) matrix each: round 0 <- mean WSDDN scores (K columns used), round k+1
+        # <- mean softmax of refinement head k.  They depend on the logits only, so the rounds are mined side by side.
+        mine_scores = torch.zeros(RK, R, K1, device=dev, dtype=torch.float32)
+        ops.wsddn_mil(logits, V, R, K, cols["cls"], cols["det"], inp["gt_onehot"], scores, loss_view[0], dlogits, ones,
+                      mean_scores=mine_scores[0])
+        col_stride = 5 * K + 1
+        if RK > 1:
+            ops.oicr_mean_probs(logits, V, R, K, RK - 1, cols["cls_score0"], col_stride, mine_scores[1:])
+        # --- K refinement rounds: mine pseudo-GT, label (one workgroup per round), then all rounds' losses at once
         top_k = max(int(R * self.mist_p), 1)                      # roi_heads_oicrplus.py:659-660
         G = inp["G"]
-        ws = torch.empty(ops.mine_workspace_bytes(top_k, G), device=dev, dtype=torch.uint8)
-        aux = {"scores": scores, "rounds": []}
-        probs = torch.empty(V, R, K + 1, device=dev, dtype=torch.float32)
-        for k in range(RK):
-            lab_c = torch.empty(R, device=dev, dtype=torch.int32); lab_w = torch.empty(R, device=dev, dtype=torch.float32)
-            lab_i = torch.empty(R, device=dev, dtype=torch.int32); cnt = torch.zeros(1, device=dev, dtype=torch.int32)
-            pi = torch.empty(top_k * G, device=dev, dtype=torch.int32); pc = torch.empty_like(pi)
-            ps = torch.empty(top_k * G, device=dev, dtype=torch.float32)
-            ops.oicr_mine_label(prev, inp["gt_int32"], boxes[0], K, top_k, self.mist_thre, 0.01,
-                                self.iou_thresholds[0], self.iou_thresholds[1], lab_c, lab_w, lab_i, cnt, pi, pc, ps, ws)
-            lv = loss_view[1 + 2 * k:3 + 2 * k]
-            ops.oicr_refine_loss(logits, V, R, K, cols[f"cls_score{k}"], cols[f"bbox_pred{k}"], boxes, lab_c, lab_w, lab_i,
-                                 inp["pred_view"], self.bbox_reg_weights, lv, probs, dlogits, ones)
-            prev = torch.empty(R, K + 1, device=dev, dtype=torch.float32)
-            ops.mean_views(probs, prev)
-            aux["rounds"].append(dict(lab_class=lab_c, lab_weight=lab_w, lab_index=lab_i, pgt_count=cnt, pgt_index=pi,
-                                      pgt_class=pc, pgt_score=ps))
+        ws = torch.empty(ops.mine_workspace_bytes(top_k, G, RK), device=dev, dtype=torch.uint8)
+        lab_c = torch.empty(RK, R, device=dev, dtype=torch.int32); lab_w = torch.empty(RK, R, device=dev, dtype=torch.float32)
+        lab_i = torch.empty(RK, R, device=dev, dtype=torch.int32); cnt = torch.empty(RK, device=dev, dtype=torch.int32)
+        pi = torch.empty(RK, top_k * G, device=dev, dtype=torch.int32); pc = torch.empty_like(pi)
+        ps = torch.empty(RK, top_k * G, device=dev, dtype=torch.float32)
+        ops.oicr_mine_label(mine_scores, inp["gt_int32"], boxes[0], K, top_k, self.mist_thre, 0.01,
+                            self.iou_thresholds[0], self.iou_thresholds[1], lab_c, lab_w, lab_i, cnt, pi, pc, ps, ws)
+        ops.oicr_refine_loss(logits, V, R, K, cols["cls_score0"], cols["bbox_pred0"], boxes, lab_c, lab_w, lab_i,
+                             inp["pred_view"], self.bbox_reg_weights, loss_view[1:], dlogits, ones, n_rounds=RK,
+                             col_stride=col_stride)
+        aux = {"scores": scores, "rounds": [dict(lab_class=lab_c[k], lab_weight=lab_w[k], lab_index=lab_i[k],
+                                                 pgt_count=cnt[k:k + 1], pgt_index=pi[k], pgt_class=pc[k], pgt_score=ps[k])
+                                            for k in range(RK)]}
         losses = torch.empty(n_loss, device=dev, dtype=torch.float32)
         ops.loss_finalize(loss_view, losses)
         self.last_aux = aux
@@ -347,7 +349,8 @@ class OICRPlusHeads(nn.Module):
         idx = torch.cat([torch.zeros(R, 1, device=device), torch.ones(R, 1, device=device)], 0)
         rois = [torch.cat([idx, boxes[2 * s:2 * s + 2].reshape(2 * R, 4)], 1).contiguous() for s in range(2)]
         if not hasattr(self, "_consts") or self._consts[0].device != device:
-            self._consts = (torch.ones(2, device=device), torch.tensor([0, 1, 2, 2], dtype=torch.int32, device=device))
+            self._consts = (torch.ones(max(2, 2 * self.refine_K), device=device),
+                            torch.tensor([0, 1, 2, 2], dtype=torch.int32, device=device))
         # the image-level labels are the only host data of the step: stage them through pinned memory so that the copy is
         # asynchronous (a pageable H2D copy blocks the host until the stream drains = one full pipeline bubble per step)
         G = int(gt_int.numel())

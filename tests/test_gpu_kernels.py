@@ -258,6 +258,59 @@ def test_mining_and_labels_bit_exact_vs_golden(ops, case, golden_dir):
         assert np.array_equal(lab_w.cpu().numpy(), g[f"{variant}/gt_weights"])
 
 
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_mining_rounds_side_by_side(ops, golden_dir, case):
+    """n_rounds problems in one launch (one workgroup each) give exactly the single-round results"""
+    g = np.load(os.path.join(golden_dir, f"mining_{case}.npz"))
+    R, K = int(g["R"]), int(g["K"])
+    views, _ = O.make_views(256, 320, R, n_gt=len(g["gt"]), K=K, tag=str(g["boxes_tag"]))
+    boxes = torch.from_numpy(views[0]["boxes"]).cuda()
+    gt = torch.from_numpy(g["gt"].astype(np.int32)).cuda()
+    G = gt.numel(); top_k = max(int(R * 0.10), 1)
+    names = ["wsddn", "refine", "refine"]
+    sc = torch.zeros(3, R, K + 1)
+    sc[0, :, :K] = torch.from_numpy(g["wsddn/scores"]); sc[1] = torch.from_numpy(g["refine/scores"]); sc[2] = sc[1]
+    NR = 3
+    lab_c = torch.empty(NR, R, dtype=torch.int32, device="cuda"); lab_w = torch.empty(NR, R, device="cuda")
+    lab_i = torch.empty(NR, R, dtype=torch.int32, device="cuda"); cnt = torch.zeros(NR, dtype=torch.int32, device="cuda")
+    pi = torch.empty(NR, top_k * G, dtype=torch.int32, device="cuda"); pc = torch.empty_like(pi)
+    ps = torch.empty(NR, top_k * G, device="cuda")
+    ws = torch.empty(ops.mine_workspace_bytes(top_k, G, NR), dtype=torch.uint8, device="cuda")
+    ops.oicr_mine_label(sc.cuda(), gt, boxes, K, top_k, 0.05, 0.01, 0.5, 0.6, lab_c, lab_w, lab_i, cnt, pi, pc, ps, ws)
+    for k, variant in enumerate(names):
+        n = int(cnt[k].item())
+        assert np.array_equal(pi[k, :n].cpu().numpy(), g[f"{variant}/pgt_index"])
+        assert np.array_equal(pc[k, :n].cpu().numpy(), g[f"{variant}/pgt_classes"])
+        assert np.array_equal(ps[k, :n].cpu().numpy(), g[f"{variant}/pgt_scores"])
+        assert np.array_equal(lab_c[k].cpu().numpy(), g[f"{variant}/gt_classes"])
+        assert np.array_equal(lab_i[k].cpu().numpy(), g[f"{variant}/gt_index"])
+        assert np.array_equal(lab_w[k].cpu().numpy(), g[f"{variant}/gt_weights"])
+
+
+def test_refine_loss_rounds_side_by_side(ops):
+    """the batched launch (n_rounds heads at a column stride) equals n_rounds single launches bit for bit"""
+    V, R, K, NR = 4, 300, 20, 3
+    stride = 5 * K + 1
+    LD = (8 + NR * stride + 7) // 8 * 8
+    lg = _rand((V * R, LD), 52, scale=2.0).cuda()
+    views, _ = O.make_views(256, 320, R, tag="rl2")
+    boxes = torch.from_numpy(np.stack([v["boxes"] for v in views])).cuda()
+    gen = torch.Generator().manual_seed(53)
+    lab_c = torch.randint(-1, K + 1, (NR, R), generator=gen).to(torch.int32).cuda()
+    lab_i = torch.randint(0, R, (NR, R), generator=gen).to(torch.int32).cuda()
+    lab_w = torch.rand(NR, R, generator=gen).cuda()
+    gs = torch.rand(2 * NR, generator=gen).cuda() + 0.5
+    pvw = torch.tensor([0, 1, 2, 2], dtype=torch.int32).cuda()
+    lv = torch.empty(NR, 2, V, device="cuda"); dl = torch.zeros(V * R, LD, device="cuda")
+    ops.oicr_refine_loss(lg, V, R, K, 8, 8 + K + 1, boxes, lab_c, lab_w, lab_i, pvw, (10.0, 10.0, 5.0, 5.0), lv, dl, gs,
+                         n_rounds=NR, col_stride=stride)
+    lv1 = torch.empty(NR, 2, V, device="cuda"); dl1 = torch.zeros(V * R, LD, device="cuda")
+    for k in range(NR):
+        ops.oicr_refine_loss(lg, V, R, K, 8 + k * stride, 8 + K + 1 + k * stride, boxes, lab_c[k], lab_w[k], lab_i[k], pvw,
+                             (10.0, 10.0, 5.0, 5.0), lv1[k], dl1, gs[2 * k:2 * k + 2])
+    assert torch.equal(lv, lv1) and torch.equal(dl, dl1)
+
+
 def test_mining_ties_and_single_proposal(ops):
     """ties -> ascending index (the oracle's documented rule); R=1 edge case"""
     for R in (1, 70):
@@ -302,14 +355,15 @@ def test_refine_loss_and_grad(ops, R, K):
         lc.append(a); lb.append(b)
         probs.append(F.softmax(x[v * R:(v + 1) * R, cls_col:cls_col + K + 1].detach(), -1))
     (sum(lc) / V * gs[0] + sum(lb) / V * gs[1]).backward()
-    lv = torch.empty(2, V, device="cuda"); pr = torch.empty(V, R, K + 1, device="cuda")
+    lv = torch.empty(2, V, device="cuda"); pr = torch.empty(1, R, K + 1, device="cuda")
     dl = torch.full((V * R, LD), 7.0, device="cuda")
     ops.oicr_refine_loss(lg.cuda(), V, R, K, cls_col, box_col, torch.from_numpy(boxes).cuda(),
                          lab_class.to(torch.int32).cuda(), lab_weight.cuda(), lab_index.to(torch.int32).cuda(),
-                         torch.tensor([0, 1, 2, 2], dtype=torch.int32).cuda(), (10.0, 10.0, 5.0, 5.0), lv, pr, dl, gs.cuda())
+                         torch.tensor([0, 1, 2, 2], dtype=torch.int32).cuda(), (10.0, 10.0, 5.0, 5.0), lv, dl, gs.cuda())
     np.testing.assert_allclose(lv[0].cpu().numpy(), torch.stack(lc).detach().numpy(), rtol=2e-5)
     np.testing.assert_allclose(lv[1].cpu().numpy(), torch.stack(lb).detach().numpy(), rtol=2e-5)
-    np.testing.assert_allclose(pr.cpu().numpy(), torch.stack(probs).numpy(), rtol=2e-5, atol=1e-9)
+    ops.oicr_mean_probs(lg.cuda(), V, R, K, 1, cls_col, 0, pr)          # next round's mining scores: view-mean softmax
+    np.testing.assert_allclose(pr[0].cpu().numpy(), torch.stack(probs).mean(0).numpy(), rtol=2e-5, atol=1e-9)
     ref = x.grad[:, cls_col:box_col + 4 * K]
     got = dl.cpu()[:, cls_col:box_col + 4 * K]
     assert (got - ref).abs().max() <= 2e-5 * ref.abs().max()
