@@ -113,9 +113,7 @@ class MultiInputRCNN(nn.Module):
         gts = [[x[k]] if k in x else None for k in ("instances1", "instances1_flip", "instances2", "instances2_flip")]
         images_list = [None, None, None, None]       # the heads never read pixel data (roi_heads_oicrplus.py:149-188)
         _, detector_losses = self.roi_heads(images_list, [features1, features2], proposals_list, gts)
-        losses = {}
-        losses.update(detector_losses)
-        return losses
+        return detector_losses          # no proposal-generator losses to merge (PrecomputedProposals); keeps LossDict.total()
 
     @torch.no_grad()
     def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):

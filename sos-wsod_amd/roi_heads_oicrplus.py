@@ -56,6 +56,18 @@ def _padded(rows, cols, device, dtype, pad=128):
     return torch.empty(rows, cols + pad, device=device, dtype=dtype)[:, :cols]
 
 
+class LossDict(dict):
+    """The reference's dict of named scalar losses; every value is a view of ONE device vector, kept as `.vector`.
+    `total()` = sum of all losses as a single reduction (what train_net_multi.py:129 computes with Python's sum())."""
+
+    def __init__(self, names, vector):
+        super().__init__({n: vector[i] for i, n in enumerate(names)})
+        self.vector = vector
+
+    def total(self):
+        return self.vector.sum()
+
+
 def loss_names(refine_K):
     names = ["loss_cls"]
     for k in range(refine_K):
@@ -166,20 +178,48 @@ class OICRPlusHeads(nn.Module):
             cols[f"bbox_pred{k}"] = base + K + 1
         return cols
 
-    def _pack_head_weights(self, params, device):
-        """10 (out, 4096) f32 masters -> one (ld_head, 4096) compute-dtype operand + f32 bias vector."""
-        D = params[4].shape[1]
-        Wh = torch.zeros(self.ld_head, D, device=device, dtype=self.compute_dtype)
-        bh = torch.zeros(self.ld_head, device=device, dtype=torch.float32)
+    def _flatten_head_params(self, device):
+        """Re-home the 10 predictor weights / biases as row slices of ONE (ld_head, 4096) f32 matrix and ONE bias vector
+        (the way cuDNN RNNs / DDP buckets flatten weights): names, shapes, optimizer and state_dict are unchanged, but the
+        fused predictor GEMM's operand is then a single staging copy and its bias needs none.  Done lazily and re-done
+        whenever something (`.to()`, `load_state_dict(assign=True)`) gave the parameters new storage."""
+        ps = self._flat_params()[4:]
+        D = ps[0].shape[1]
+        flat_w = torch.zeros(self.ld_head, D, device=device, dtype=torch.float32)
+        flat_b = torch.zeros(self.ld_head, device=device, dtype=torch.float32)
         row = 0
+        with torch.no_grad():
+            for i in range(0, len(ps), 2):
+                w, b = ps[i], ps[i + 1]
+                n = w.shape[0]
+                flat_w[row:row + n].copy_(w); flat_b[row:row + n].copy_(b)
+                w.data = flat_w[row:row + n]; b.data = flat_b[row:row + n]
+                row += n
+        assert row == self.n_head_cols
+        self._head_flat = (flat_w, flat_b)
+        ops.PARAM_EPOCH += 1
+
+    def _head_flat_ok(self, params, device):
+        flat = getattr(self, "_head_flat", None)
+        if flat is None or flat[0].device != device:
+            return False
+        row, esz = 0, 4
         for i in range(4, len(params), 2):
             w, b = params[i], params[i + 1]
-            n = w.shape[0]
-            ops.convert_2d(w, Wh[row:row + n], n, D)
-            bh[row:row + n].copy_(b.detach())
-            row += n
-        assert row == self.n_head_cols
-        return Wh, bh
+            if w.dtype != torch.float32 or w.data_ptr() != flat[0].data_ptr() + row * flat[0].shape[1] * esz or \
+                    b.data_ptr() != flat[1].data_ptr() + row * esz:
+                return False
+            row += w.shape[0]
+        return True
+
+    def _pack_head_weights(self, params, device):
+        """10 (out, 4096) f32 masters -> one (ld_head, 4096) compute-dtype operand + f32 bias vector."""
+        if not self._head_flat_ok(params, device):
+            self._flatten_head_params(device)
+        flat_w, flat_b = self._head_flat
+        Wh = torch.empty(self.ld_head, flat_w.shape[1], device=device, dtype=self.compute_dtype)
+        ops.convert_2d(flat_w, Wh, self.ld_head, flat_w.shape[1])
+        return Wh, flat_b
 
     # ------------------------------------------------------------------ training forward (explicit)
     def _train_forward(self, inp, feat1, feat2, params):
@@ -377,7 +417,7 @@ class OICRPlusHeads(nn.Module):
         self.gt_classes_img_int = [inp["gt_int32"].to(torch.int64)]
         vec = _HeadsTrainFunction.apply(self, inp, f1, f2, *self._flat_params())
         names = loss_names(self.refine_K)
-        losses = {n: vec[i] for i, n in enumerate(names)}
+        losses = LossDict(names, vec)
         self.iter = self.iter + 1
         if has_event_storage():
             st = get_event_storage()

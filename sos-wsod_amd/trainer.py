@@ -58,7 +58,12 @@ class Trainer:
                 data = next(self.data_iter)
         with self.storage:
             loss_dict = self.model(data)
-            losses = sum(loss_dict.values()) / self.iter_size
+            # the 9 losses are views of one device vector (LossDict): one sum kernel forward, one expand backward instead
+            # of 8 adds + 9 select-backward (zeros + copy + add each); a plain dict falls back to the reference's sum()
+            total = getattr(loss_dict, "total", None)
+            losses = total() if callable(total) else sum(loss_dict.values())
+            if self.iter_size != 1:
+                losses = losses / self.iter_size
             losses.backward()
         if (self.iter + 1) % self.iter_size == 0:
             self.optimizer.step()
