@@ -204,6 +204,28 @@ int sw_dropout_mask(uint8_t* keep, long n, uint64_t seed, uint64_t offset, float
  * train_net_multi.py:157-164):  g += wd*p;  buf = first ? g : mom*buf + g;  p -= lr*buf. */
 int sw_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, long n, float lr, float momentum,
                          float weight_decay, int first_step, float grad_scale, sw_stream_t stream);
+/* The whole optimizer step in one launch per <= SW_SGD_MAX_TENSORS parameter tensors, with the compute-dtype kernel-layout
+ * copies the next forward needs ("weight staging") written from the freshly updated values in the same pass — the f32
+ * master is read once instead of once by the optimizer and once more by every staging kernel.
+ * tensors: HOST array (copied into the launch).  stage_kind 0: none.  1: the parameter is a (n/d0) x d0 matrix, stage0
+ * receives it in stage_dtype with row pitch ld0 (fc / predictor weights).  2: the parameter is an OIHW 3x3 conv weight
+ * (Cout=d0, Cin=d1): stage0 (may be NULL) = forward layout [co][tap][d2=cin_pad] and stage1 (may be NULL) = data-gradient
+ * layout [ci][8-tap][co], exactly what sw_conv_weight_prep modes 0 / 1 produce. */
+#define SW_SGD_MAX_TENSORS 24
+typedef struct {
+  float* param;
+  const float* grad;
+  float* momentum_buf;
+  long n;
+  float lr, weight_decay;
+  int first_step;
+  int stage_kind, stage_dtype;
+  void* stage0;
+  void* stage1;
+  int d0, d1, d2;
+  long ld0;
+} sw_sgd_tensor;
+int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float momentum, float grad_scale, sw_stream_t stream);
 /* out[i] = sum_v loss_view[i][v] / V   (loss assembly, roi_heads_oicrplus.py:283-288,384-388) */
 int sw_loss_finalize(int n_losses, int V, const float* loss_view, float* out, sw_stream_t stream);
 

@@ -185,7 +185,8 @@ class VGG16(nn.Module):
     def staged_weight(self, w, mode, cin_pad, dtype):
         """compute-dtype kernel-layout copy of an OIHW master weight (mode 0: forward [co][tap][ci], mode 1: data
         gradient [ci][8-tap][co]); rebuilt only when the parameter changed (the two backbone calls of an iteration and
-        the backward share one copy)."""
+        the backward share one copy).  The buffers are persistent and registered in ops.STAGING, so that HipSGD's fused
+        step rewrites them from the updated weights and this method finds them current (no staging kernels per step)."""
         key = (ops.param_key(w), mode, cin_pad, dtype)
         slot = (id(w), mode)
         hit = self._wk_cache.get(slot)
@@ -193,10 +194,30 @@ class VGG16(nn.Module):
             return hit[1]
         cout, cin = w.shape[:2]
         shape = (cout, 9, cin_pad) if mode == 0 else (cin, 9, cout)
-        wk = torch.empty(shape, device=w.device, dtype=dtype)
+        if hit is not None and tuple(hit[1].shape) == shape and hit[1].dtype == dtype and hit[1].device == w.device:
+            wk = hit[1]
+        else:
+            wk = torch.zeros(shape, device=w.device, dtype=dtype)
         ops.conv_weight_prep(w.detach(), wk, mode, cin_pad if mode == 0 else None)
         self._wk_cache[slot] = (key, wk)
+        if w.requires_grad:
+            self._register_staging(w, dtype)
         return wk
+
+    def _register_staging(self, w, dtype):
+        cout, cin = w.shape[:2]
+        s0, s1 = self._wk_cache.get((id(w), 0)), self._wk_cache.get((id(w), 1))
+        s0 = s0 if s0 is not None and s0[0][3] == dtype else None
+        s1 = s1 if s1 is not None and s1[0][3] == dtype else None
+
+        def stamp(pk, wid=id(w)):
+            for mode in (0, 1):
+                h = self._wk_cache.get((wid, mode))
+                if h is not None and h[0][3] == dtype:
+                    self._wk_cache[(wid, mode)] = ((pk, mode, h[0][2], dtype), h[1])
+
+        ops.register_staging(w, 2, dtype, stage0=None if s0 is None else s0[1], stage1=None if s1 is None else s1[1],
+                             d0=cout, d1=cin, d2=(s0[0][2] if s0 is not None else cin), stamp=stamp)
 
     def stage_all_weights(self, with_dgrad):
         """build every compute-dtype weight copy on the CURRENT stream (call before forking side streams)"""

@@ -181,6 +181,87 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
   }
 }
 
+// Multi-tensor SGD + weight staging.  blockIdx.x -> (tensor, 4096-element chunk) through a prefix table that travels in
+// the kernel arguments with the tensor descriptors.
+constexpr int SGD_CHUNK = 4096;
+struct SgdBatch {
+  sw_sgd_tensor t[SW_SGD_MAX_TENSORS];
+  int block_start[SW_SGD_MAX_TENSORS + 1];
+  int n;
+};
+
+template <typename T>
+__device__ __forceinline__ void sgd_stage(const sw_sgd_tensor& d, long i, float w) {
+  if (d.stage_kind == 1) {
+    const long r = i / d.d0; const int c = (int)(i - r * d.d0);
+    Elem<T>::store((T*)d.stage0 + r * d.ld0 + c, w);
+  } else {
+    const int tap = (int)(i % 9); const long t = i / 9;
+    const int ci = (int)(t % d.d1); const int co = (int)(t / d.d1);
+    if (d.stage0) Elem<T>::store((T*)d.stage0 + ((long)co * 9 + tap) * d.d2 + ci, w);
+    if (d.stage1) Elem<T>::store((T*)d.stage1 + ((long)ci * 9 + (8 - tap)) * d.d0 + co, w);
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_multi_kernel(SgdBatch b, float mom, float gscale) {
+  int ti = 0;
+  while (ti + 1 < b.n && (int)blockIdx.x >= b.block_start[ti + 1]) ++ti;
+  const sw_sgd_tensor& d = b.t[ti];
+  const long base = (long)((int)blockIdx.x - b.block_start[ti]) * SGD_CHUNK;
+  const long end = min(d.n, base + SGD_CHUNK);
+  const bool vec = ((((uintptr_t)d.param) | ((uintptr_t)d.grad) | ((uintptr_t)d.momentum_buf)) & 15) == 0;
+  if (vec) {
+    for (long i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
+      if (i + 4 <= end) {
+        const float4 w4 = *(const float4*)(d.param + i);
+        const float4 g4 = *(const float4*)(d.grad + i);
+        float4 m4 = d.first_step ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(d.momentum_buf + i);
+        float w[4] = {w4.x, w4.y, w4.z, w4.w}; const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float m[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dd = g[e] * gscale + d.weight_decay * w[e];
+          m[e] = d.first_step ? dd : mom * m[e] + dd;
+          w[e] = w[e] - d.lr * m[e];
+        }
+        *(float4*)(d.momentum_buf + i) = make_float4(m[0], m[1], m[2], m[3]);
+        *(float4*)(d.param + i) = make_float4(w[0], w[1], w[2], w[3]);
+        if (d.stage_kind == 1 && (d.d0 & 3) == 0 && d.stage_dtype == SW_BF16) {      // 4 columns of one row: one 8-byte store
+          const long r = i / d.d0; const int c = (int)(i - r * d.d0);
+          const unsigned lo = (unsigned)f32_to_bf16_bits(w[0]) | ((unsigned)f32_to_bf16_bits(w[1]) << 16);
+          const unsigned hi = (unsigned)f32_to_bf16_bits(w[2]) | ((unsigned)f32_to_bf16_bits(w[3]) << 16);
+          unsigned short* o = (unsigned short*)d.stage0 + r * d.ld0 + c;
+          if ((((uintptr_t)o) & 7) == 0) *(uint2*)o = make_uint2(lo, hi);
+          else { o[0] = (unsigned short)lo; o[1] = (unsigned short)(lo >> 16); o[2] = (unsigned short)hi; o[3] = (unsigned short)(hi >> 16); }
+        } else if (d.stage_kind) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (d.stage_dtype == SW_BF16) sgd_stage<unsigned short>(d, i + e, w[e]); else sgd_stage<float>(d, i + e, w[e]);
+          }
+        }
+      } else {
+        for (long j = i; j < end; ++j) {
+          const float w0 = d.param[j];
+          const float dd = d.grad[j] * gscale + d.weight_decay * w0;
+          const float m = d.first_step ? dd : mom * d.momentum_buf[j] + dd;
+          const float w1 = w0 - d.lr * m;
+          d.momentum_buf[j] = m; d.param[j] = w1;
+          if (d.stage_kind) { if (d.stage_dtype == SW_BF16) sgd_stage<unsigned short>(d, j, w1); else sgd_stage<float>(d, j, w1); }
+        }
+      }
+    }
+  } else {
+    for (long j = base + threadIdx.x; j < end; j += 256) {
+      const float w0 = d.param[j];
+      const float dd = d.grad[j] * gscale + d.weight_decay * w0;
+      const float m = d.first_step ? dd : mom * d.momentum_buf[j] + dd;
+      const float w1 = w0 - d.lr * m;
+      d.momentum_buf[j] = m; d.param[j] = w1;
+      if (d.stage_kind) { if (d.stage_dtype == SW_BF16) sgd_stage<unsigned short>(d, j, w1); else sgd_stage<float>(d, j, w1); }
+    }
+  }
+}
+
 // f32 NCHW -> dtype NHWC with channel padding (generic backbone entry; the fused path is sw_preprocess)
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(int N, int C, int H, int W, int cpad, const float* __restrict__ in, T* __restrict__ out) {
@@ -388,6 +469,34 @@ extern "C" int sw_sgd_momentum_step(float* param, const float* grad, float* buf,
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, param, grad, buf, n, lr, momentum, weight_decay,
                      first_step, grad_scale);
   SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float momentum, float grad_scale,
+                            hipStream_t stream) {
+  for (int t0 = 0; t0 < n_tensors; t0 += SW_SGD_MAX_TENSORS) {
+    SgdBatch b;
+    b.n = 0;
+    int blocks = 0;
+    for (int i = t0; i < n_tensors && i < t0 + SW_SGD_MAX_TENSORS; ++i) {
+      const sw_sgd_tensor& d = tensors[i];
+      if (d.n <= 0) continue;
+      if (d.stage_kind < 0 || d.stage_kind > 2) return -1;
+      if (d.stage_kind && d.stage_dtype != SW_BF16 && d.stage_dtype != SW_F32) return -1;
+      if (d.stage_kind == 1 && (d.d0 <= 0 || d.stage0 == nullptr)) return -5;
+      if (d.stage_kind == 2 && (long)d.d0 * d.d1 * 9 != d.n) return -5;
+      const long nb = (d.n + SGD_CHUNK - 1) / SGD_CHUNK;
+      if (nb > (1L << 30)) return -6;
+      b.t[b.n] = d;
+      b.block_start[b.n] = blocks;
+      blocks += (int)nb;
+      ++b.n;
+    }
+    b.block_start[b.n] = blocks;
+    if (b.n == 0) continue;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(blocks), dim3(256), 0, stream, b, momentum, grad_scale);
+    SW_CHECK_LAUNCH();
+  }
   return 0;
 }
 

@@ -55,8 +55,20 @@ PARAM_EPOCH = 0        # bumped by HipSGD.step (the kernel updates parameters be
 
 
 def param_key(p):
-    """cache key of a parameter's current value (compute-dtype weight copies are rebuilt only when it changes)"""
-    return (p.data_ptr(), p._version, PARAM_EPOCH)
+    """cache key of a parameter's current value (compute-dtype weight copies are rebuilt only when it changes); frozen
+    parameters are not touched by the optimizer, so its epoch does not invalidate their copies"""
+    return (p.data_ptr(), p._version, PARAM_EPOCH if p.requires_grad else -1)
+
+
+# Weight staging registry: id(parameter) -> dict(kind, dtype, stage0, stage1, d0, d1, d2, ld0, stamp).  Modules register the
+# persistent compute-dtype copies of their weights here; HipSGD's fused step (sw_sgd_multi) then rewrites those copies from
+# the freshly updated values and calls stamp(key) so that the module's cache sees them as current.
+STAGING = {}
+
+
+def register_staging(p, kind, dtype, stage0=None, stage1=None, d0=0, d1=0, d2=0, ld0=0, stamp=None):
+    STAGING[id(p)] = dict(param=p, kind=kind, dtype=dtype, stage0=stage0, stage1=stage1, d0=d0, d1=d1, d2=d2, ld0=ld0,
+                          stamp=stamp)
 
 
 def _launch(tag, fn):
@@ -217,6 +229,28 @@ def wsddn_mil(logits, V, R, K, cls_col, det_col, gt_onehot, scores, loss_view, d
                            _p(loss_view), _p(dlogits), 0 if dlogits is None else dlogits.stride(0), _p(grad_scale),
                            _p(mean_scores), 0 if mean_scores is None else mean_scores.stride(-2), _p(workspace),
                            _stream()), "sw_wsddn_mil")
+
+
+def sgd_multi(entries, momentum, grad_scale=1.0):
+    """entries: list of dict(param, grad, buf, lr, weight_decay, first, staging=None|STAGING entry).  One launch per 24."""
+    from ._lib import SgdTensor
+    n = len(entries)
+    if n == 0:
+        return
+    arr = (SgdTensor * n)()
+    for i, e in enumerate(entries):
+        p, d = e["param"], arr[i]
+        d.param, d.grad, d.momentum_buf, d.n = p.data_ptr(), e["grad"].data_ptr(), e["buf"].data_ptr(), p.numel()
+        d.lr, d.weight_decay, d.first_step = float(e["lr"]), float(e["weight_decay"]), int(e["first"])
+        st = e.get("staging")
+        if st is None:
+            d.stage_kind = 0
+        else:
+            d.stage_kind, d.stage_dtype = st["kind"], dt(st["dtype"])
+            d.stage0 = None if st["stage0"] is None else st["stage0"].data_ptr()
+            d.stage1 = None if st["stage1"] is None else st["stage1"].data_ptr()
+            d.d0, d.d1, d.d2, d.ld0 = st["d0"], st["d1"], st["d2"], st["ld0"]
+    check(lib.sw_sgd_multi(n, arr, float(momentum), float(grad_scale), _stream()), "sw_sgd_multi")
 
 
 def mean_views(x, out):

@@ -126,6 +126,7 @@ class OICRPlusHeads(nn.Module):
         self.iter = 0
         self.dropout_seed = 0x5051
         self._drop_counter = 0
+        self._stage_cache = {}            # name -> (key list, persistent compute-dtype weight copy)
         self.debug_drop_masks = None      # tests: [[m1, m2] per view] uint8 keep masks (A.2 #9)
         self.last_aux = None              # tests / metrics: device tensors of the last iteration
         K = num_classes
@@ -213,13 +214,46 @@ class OICRPlusHeads(nn.Module):
         return True
 
     def _pack_head_weights(self, params, device):
-        """10 (out, 4096) f32 masters -> one (ld_head, 4096) compute-dtype operand + f32 bias vector."""
+        """10 (out, 4096) f32 masters -> one (ld_head, 4096) compute-dtype operand + f32 bias vector.  The operand is a
+        persistent buffer registered in ops.STAGING per predictor weight (row slice), so after an optimizer step it is
+        already current."""
         if not self._head_flat_ok(params, device):
             self._flatten_head_params(device)
+            self._stage_cache.pop("heads", None)
         flat_w, flat_b = self._head_flat
+        ws = [params[i] for i in range(4, len(params), 2)]
+        keys = [ops.param_key(w) for w in ws]
+        hit = self._stage_cache.get("heads")
+        if hit is not None and hit[0] == keys and hit[1].dtype == self.compute_dtype:
+            return hit[1], flat_b
         Wh = torch.empty(self.ld_head, flat_w.shape[1], device=device, dtype=self.compute_dtype)
         ops.convert_2d(flat_w, Wh, self.ld_head, flat_w.shape[1])
+        self._stage_cache["heads"] = (keys, Wh)
+        row = 0
+        for j, w in enumerate(ws):
+            n = w.shape[0]
+            if w.requires_grad:
+                ops.register_staging(w, 1, self.compute_dtype, stage0=Wh[row:row + n], d0=Wh.shape[1], ld0=Wh.stride(0),
+                                     stamp=lambda pk, j=j, keys=keys: keys.__setitem__(j, pk))
+            row += n
         return Wh, flat_b
+
+    def _staged_matrix(self, name, w, device):
+        """persistent compute-dtype copy (padded row pitch) of an fc weight; see _pack_head_weights"""
+        dt_ = self.compute_dtype
+        key = [ops.param_key(w)]
+        hit = self._stage_cache.get(name)
+        if hit is not None and hit[0] == key and hit[1].dtype == dt_ and hit[1].device == device:
+            return hit[1]
+        rows, cols = w.shape
+        buf = hit[1] if (hit is not None and tuple(hit[1].shape) == (rows, cols) and hit[1].dtype == dt_ and
+                         hit[1].device == device) else _padded(rows, cols, device, dt_)
+        ops.convert_2d(w.detach(), buf, rows, cols)
+        self._stage_cache[name] = (key, buf)
+        if w.requires_grad:
+            ops.register_staging(w, 1, dt_, stage0=buf, d0=cols, ld0=buf.stride(0),
+                                 stamp=lambda pk, key=key: key.__setitem__(0, pk))
+        return buf
 
     # ------------------------------------------------------------------ training forward (explicit)
     def _train_forward(self, inp, feat1, feat2, params):
@@ -254,8 +288,8 @@ class OICRPlusHeads(nn.Module):
                     ops.dropout_mask(m, self.dropout_seed, self._drop_counter, 0.5)
                     self._drop_counter += m.numel()
                     masks[l] = m
-        W1 = _padded(D1, D0, dev, dt_); ops.convert_2d(fc1w, W1, D1, D0)
-        W2 = _padded(D2, D1, dev, dt_); ops.convert_2d(fc2w, W2, D2, D1)
+        W1 = self._staged_matrix("fc1", fc1w, dev)
+        W2 = self._staged_matrix("fc2", fc2w, dev)
         h1 = _padded(V * R, D1, dev, dt_)
         ops.gemm(pooled, W1, h1, V * R, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], out_dtype=dt_),
                  tag="fc6_fwd")

@@ -19,18 +19,39 @@ class HipSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
+        """One launch (sw_sgd_multi) per 24 parameter tensors.  Parameters whose module registered compute-dtype staging
+        copies (ops.STAGING) get those rewritten from the updated values in the same pass."""
         ops.PARAM_EPOCH += 1
+        by_mom = {}
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
                     continue
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise TypeError("HipSGD updates contiguous float32 master parameters")
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 st = self.state[p]
                 first = "momentum_buffer" not in st
                 if first:
                     st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
-                ops.sgd_momentum_step(p, g, st["momentum_buffer"], group["lr"], group["momentum"], group["weight_decay"],
-                                      first, grad_scale)
+                staging = ops.STAGING.get(id(p))
+                if staging is not None and (staging["param"] is not p or not self._staging_usable(staging, p)):
+                    staging = None
+                by_mom.setdefault(float(group["momentum"]), []).append(
+                    dict(param=p, grad=g, buf=st["momentum_buffer"], lr=group["lr"], weight_decay=group["weight_decay"],
+                         first=first, staging=staging))
+        for mom, entries in by_mom.items():
+            ops.sgd_multi(entries, mom, grad_scale)
+            for e in entries:
+                if e["staging"] is not None and e["staging"]["stamp"] is not None:
+                    e["staging"]["stamp"](ops.param_key(e["param"]))
+
+    @staticmethod
+    def _staging_usable(st, p):
+        for t in (st["stage0"], st["stage1"]):
+            if t is not None and t.device != p.device:
+                return False
+        return True
 
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none=set_to_none)

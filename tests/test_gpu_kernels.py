@@ -370,6 +370,44 @@ def test_refine_loss_and_grad(ops, R, K):
     assert torch.all(dl.cpu()[:, :cls_col] == 7.0)             # other columns untouched
 
 
+# ------------------------------------------------------------------------------------------ optimizer
+@pytest.mark.parametrize("sdt", DT)
+def test_sgd_multi_matches_single_tensor_steps_and_staging(ops, sdt):
+    """sw_sgd_multi == per-tensor sw_sgd_momentum_step + sw_conv_weight_prep / sw_convert_2d on the updated weights,
+    bit for bit (28 tensors -> two launches; odd sizes, unaligned views, first step and later steps)"""
+    gen = torch.Generator().manual_seed(70)
+    shapes = [(64, 32, 3, 3), (32,), (40, 24, 3, 3), (130, 72), (7,), (3, 1001)] + [(5 + i,) for i in range(22)]
+    ps = [torch.randn(*sh, generator=gen).cuda() for sh in shapes]
+    flat = torch.randn(11 * 72 + 3, generator=gen).cuda()
+    ps.append(flat[3:3 + 11 * 72].view(11, 72))                   # a row-slice style view at a 12-byte offset
+    for first in (True, False):
+        gs = [torch.randn(p.shape, generator=gen).cuda() for p in ps]
+        bufs = [torch.randn(p.shape, generator=gen).cuda() for p in ps]
+        ref_p = [p.clone() for p in ps]; ref_b = [b.clone() for b in bufs]
+        for i, (p, g, b) in enumerate(zip(ref_p, gs, ref_b)):
+            ops.sgd_momentum_step(p, g, b, 0.01 * (1 + i % 3), 0.9, 5e-4 * (i % 2), first, 0.5)
+        st = {}
+        wk0 = torch.zeros(64, 9, 32, device="cuda", dtype=sdt); wk1 = torch.zeros(32, 9, 64, device="cuda", dtype=sdt)
+        st[0] = dict(kind=2, dtype=sdt, stage0=wk0, stage1=wk1, d0=64, d1=32, d2=32, ld0=0)
+        wk2 = torch.zeros(40, 9, 24, device="cuda", dtype=sdt)
+        st[2] = dict(kind=2, dtype=sdt, stage0=wk2, stage1=None, d0=40, d1=24, d2=24, ld0=0)
+        m3 = torch.zeros(130, 72 + 8, device="cuda", dtype=sdt)[:, :72]
+        st[3] = dict(kind=1, dtype=sdt, stage0=m3, stage1=None, d0=72, d1=0, d2=0, ld0=m3.stride(0))
+        m5 = torch.zeros(3, 1001 + 3, device="cuda", dtype=sdt)[:, :1001]
+        st[5] = dict(kind=1, dtype=sdt, stage0=m5, stage1=None, d0=1001, d1=0, d2=0, ld0=m5.stride(0))
+        mv = torch.zeros(11, 72, device="cuda", dtype=sdt)
+        st[len(ps) - 1] = dict(kind=1, dtype=sdt, stage0=mv, stage1=None, d0=72, d1=0, d2=0, ld0=72)
+        entries = [dict(param=p, grad=g, buf=b, lr=0.01 * (1 + i % 3), weight_decay=5e-4 * (i % 2), first=first,
+                        staging=st.get(i)) for i, (p, g, b) in enumerate(zip(ps, gs, bufs))]
+        ops.sgd_multi(entries, 0.9, 0.5)
+        for p, rp, b, rb in zip(ps, ref_p, bufs, ref_b):
+            assert torch.equal(p, rp) and torch.equal(b, rb)
+        e0 = torch.empty_like(wk0); e1 = torch.empty_like(wk1); e2 = torch.empty_like(wk2)
+        ops.conv_weight_prep(ps[0], e0, 0, 32); ops.conv_weight_prep(ps[0], e1, 1, None); ops.conv_weight_prep(ps[2], e2, 0, 24)
+        assert torch.equal(wk0, e0) and torch.equal(wk1, e1) and torch.equal(wk2, e2)
+        assert torch.equal(m3, ps[3].to(sdt)) and torch.equal(m5, ps[5].to(sdt)) and torch.equal(mv, ps[-1].to(sdt))
+
+
 # ------------------------------------------------------------------------------------------ utilities
 def test_preprocess_colsum_sgd_dropout(ops):
     img = torch.randint(0, 256, (3, 37, 53), dtype=torch.uint8)
