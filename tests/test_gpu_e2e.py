@@ -166,3 +166,54 @@ def test_inference_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(inst.pred_boxes.tensor.cpu().numpy(), ref["pred_boxes"], rtol=1e-4, atol=1e-2)
     res, all_scores, all_boxes = model.inference([{"image": torch.from_numpy(v["image"]), "proposals": p}], do_postprocess=False)
     np.testing.assert_allclose(all_scores[0].cpu().numpy(), ref["all_scores"].reshape(all_scores[0].shape), rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_staging_keeps_weight_copies_current(golden_dir, dtype):
+    """The optimizer rewrites the persistent compute-dtype weight copies (ops.STAGING) in its update pass.  After 3 steps
+    every registered copy must equal, bit for bit, what the staging kernels make of the CURRENT f32 master, and the
+    modules' caches must report those copies as current (so the next forward launches no staging kernel)."""
+    import sos_wsod_amd.ops as ops
+    from sos_wsod_amd.solver import HipSGD
+    from sos_wsod_amd.trainer import Trainer
+    g, P, views, gt, masks, _ = _setup("s0", golden_dir, dtype)
+    data = to_batched_inputs(views, gt)
+    ops.STAGING.clear()
+    model = build_model(int(g["K"]), tuple(int(x) for x in g["dan"]), dtype)
+    load_params(model, P)
+    model.train()
+    model.roi_heads.debug_drop_masks = [[torch.from_numpy(m) for m in v] for v in masks]
+    w0 = {k: v.detach().clone() for k, v in model.named_parameters()}
+    opt = HipSGD([{"params": [p], "lr": 1e-3, "weight_decay": 5e-4} for p in model.parameters() if p.requires_grad],
+                 1e-3, momentum=0.9)
+    tr = Trainer(model, opt)
+    for _ in range(3):
+        tr.run_step(data)
+    torch.cuda.synchronize()
+    assert len(ops.STAGING) >= 9 + 2 + 10, len(ops.STAGING)        # conv3_1..conv5_3, fc6/fc7, 10 predictor matrices
+    n_checked = 0
+    for st in ops.STAGING.values():
+        p = st["param"]
+        if st["kind"] == 2:
+            for mode, buf in ((0, st["stage0"]), (1, st["stage1"])):
+                if buf is None:
+                    continue
+                want = torch.zeros_like(buf)
+                ops.conv_weight_prep(p.detach(), want, mode, st["d2"] if mode == 0 else None)
+                assert torch.equal(buf, want)
+                n_checked += 1
+        else:
+            assert torch.equal(st["stage0"], p.detach().to(dtype))
+            n_checked += 1
+    assert n_checked >= 9 + 8 + 2 + 10
+    for k, v in model.named_parameters():
+        if v.requires_grad:
+            assert not torch.equal(v.detach(), w0[k]), k               # the steps did move the weights
+    # caches are current: a forward after the steps must not rebuild anything
+    bb, hd = model.backbone, model.roi_heads
+    for (wid, mode), (key, buf) in bb._wk_cache.items():
+        w = next(c.weight for blk in bb.blocks for c in blk.convs() if id(c.weight) == wid)
+        assert key[0] == ops.param_key(w)
+    assert hd._stage_cache["fc1"][0] == [ops.param_key(hd.box_head.fc1.weight)]
+    assert hd._stage_cache["fc2"][0] == [ops.param_key(hd.box_head.fc2.weight)]
+    assert hd._stage_cache["heads"][0] == [ops.param_key(p) for p in hd._flat_params()[4::2]]
