@@ -113,9 +113,10 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cin, cout, dil):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C", [24, 6])
 @pytest.mark.parametrize("stride", [1, 2])
-def test_maxpool_fwd_bwd(ops, dtype, stride):
-    n, C, H, W = 2, 24, 11, 14
+def test_maxpool_fwd_bwd(ops, dtype, stride, C):
+    n, H, W = 2, 11, 14                                          # C=24: 16-byte channel vectors, C=6: scalar form
     x = F.relu(_rand((n, C, H, W), 20, dtype)).float()          # post-ReLU like the backbone (ties at 0)
     xr = x.clone().requires_grad_(True)
     y = F.max_pool2d(xr, 2, stride)
