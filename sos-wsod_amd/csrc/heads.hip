@@ -20,8 +20,8 @@ constexpr int NWAVE = 16;      // 1024-thread workgroups
 // workgroup per view (the first version) spent 220 us on 4 CUs; here the rows are cut into chunks of WS_CH and the
 // coupling goes through a few hundred floats of workspace:
 //   1. wsddn_stats_kernel   (chunk, view): per detection column the chunk's max and sum exp(x - max)
-//   2. wsddn_scores_kernel  (chunk): merges the chunk statistics (fixed order), thread = proposal row over all views:
-//        scores, their mean over views (mining input), per-chunk column sums of the scores
+//   2. wsddn_scores_kernel  (chunk, view): merges the chunk statistics (fixed order), thread = proposal row:
+//        scores, per-chunk column sums of the scores; mean_scores_kernel then averages the views (mining input)
 //   3. wsddn_grad_kernel    (chunk, view): image-level score -> clamped BCE, its gradient through both softmaxes
 // Every reduction has a fixed order => deterministic.
 constexpr int WS_CH = 256;     // rows per workgroup
@@ -69,68 +69,70 @@ __device__ __forceinline__ void merge_stats(int nchunk, int K, int v, int k, con
   *m_out = m; *z_out = z;
 }
 
+// one workgroup = 256 proposal rows of ONE view.  The 2 x K logits of a row are fetched by a flat, coalesced copy into LDS
+// (a thread walking its own row issued 2K dependent 4-byte loads: 100 us for 8 workgroups); the per-column sums of the
+// scores are taken from the LDS tile by K x 8 threads, 32 rows each, then 8 partials in fixed order.
 __global__ __launch_bounds__(WS_CH) void wsddn_scores_kernel(int V, int R, int K, const float* __restrict__ logits, long ld,
                                                              int cls_col, int det_col, const float* __restrict__ pm,
                                                              const float* __restrict__ ps, float* __restrict__ cm,
                                                              float* __restrict__ cz, float* __restrict__ pS,
-                                                             float* __restrict__ scores, float* __restrict__ mean_scores,
-                                                             long ld_mean) {
-  __shared__ float part[WS_CH / 64][KMAX];
-  __shared__ float s_max[WS_VMAX][KMAX], s_sum[WS_VMAX][KMAX];
-  const int chunk = blockIdx.x, nchunk = gridDim.x;
-  for (int i = threadIdx.x; i < V * K; i += WS_CH) {
-    const int v = i / K, k = i - v * K;
+                                                             float* __restrict__ scores) {
+  extern __shared__ float tile[];                        // [WS_CH][K]: class logits -> scores
+  __shared__ float s_max[KMAX], s_sum[KMAX], s_part[8][KMAX];
+  const int chunk = blockIdx.x, nchunk = gridDim.x, v = blockIdx.y;
+  const int row0 = chunk * WS_CH, nrow = min(WS_CH, R - row0);
+  float* tc = tile;
+  const float* L = logits + ((long)v * R + row0) * ld;
+  for (int i = threadIdx.x; i < nrow * K; i += WS_CH) {
+    const int r = i / K, k = i - r * K;
+    tc[i] = L[(long)r * ld + cls_col + k];
+  }
+  for (int k = threadIdx.x; k < K; k += WS_CH) {
     float m, z;
     merge_stats(nchunk, K, v, k, pm, ps, &m, &z);
-    s_max[v][k] = m; s_sum[v][k] = z;
-    if (chunk == 0) { cm[i] = m; cz[i] = z; }
+    s_max[k] = m; s_sum[k] = z;
+    if (chunk == 0) { cm[v * K + k] = m; cz[v * K + k] = z; }
   }
   __syncthreads();
-  const int r = chunk * WS_CH + threadIdx.x;
-  const bool ok = r < R;
-  const int rr = ok ? r : R - 1;
-  float rm[WS_VMAX], rz[WS_VMAX];                        // row softmax over classes, per view
-#pragma unroll
-  for (int v = 0; v < WS_VMAX; ++v) {
-    rm[v] = 0.f; rz[v] = 1.f;
-    if (v < V) {
-      const float* c = logits + ((long)v * R + rr) * ld + cls_col;
-      float m = -FLT_MAX;
-      for (int k = 0; k < K; ++k) m = fmaxf(m, c[k]);
-      float z = 0.f;
-      for (int k = 0; k < K; ++k) z += expf(c[k] - m);
-      rm[v] = m; rz[v] = z;
+  const int t = threadIdx.x;
+  if (t < nrow) {
+    float* c = tc + t * K; const float* d = L + (long)t * ld + det_col;
+    float m = -FLT_MAX;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, c[k]);
+    float z = 0.f;
+    for (int k = 0; k < K; ++k) z += expf(c[k] - m);
+    for (int k = 0; k < K; ++k) {
+      const float p = expf(c[k] - m) / z;
+      const float q = expf(d[k] - s_max[k]) / s_sum[k];
+      c[k] = p * q;
     }
   }
-  for (int v0 = 0; v0 < V; ++v0) {                       // column sums per view need one block reduction each
-    for (int k = 0; k < K; ++k) {
-      float sc = 0.f;
-#pragma unroll
-      for (int v = 0; v < WS_VMAX; ++v) {
-        if (v == v0) {
-          const float* row = logits + ((long)v * R + rr) * ld;
-          const float p = expf(row[cls_col + k] - rm[v]) / rz[v];
-          const float q = expf(row[det_col + k] - s_max[v][k]) / s_sum[v][k];
-          sc = p * q;
-        }
-      }
-      if (ok) scores[((long)v0 * R + r) * K + k] = sc;
-      chunk_reduce_store<false>(ok ? sc : 0.f, k, part);
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < K; k += WS_CH) {
-      float a = part[0][k];
-      for (int w = 1; w < WS_CH / 64; ++w) a += part[w][k];
-      pS[((long)v0 * nchunk + chunk) * K + k] = a;
-    }
-    __syncthreads();
+  __syncthreads();
+  float* S = scores + ((long)v * R + row0) * K;          // the tile is one contiguous run of the (V, R, K) score tensor
+  for (int i = threadIdx.x; i < nrow * K; i += WS_CH) S[i] = tc[i];
+  for (int i = threadIdx.x; i < K * 8; i += WS_CH) {     // column k, rows [part*32, part*32+32)
+    const int k = i % K, part = i / K;
+    float a = 0.f;
+    for (int r = part * 32; r < min(nrow, part * 32 + 32); ++r) a += tc[r * K + k];
+    s_part[part][k] = a;
   }
-  if (mean_scores && ok) {                               // ((s0+s1)+s2)+s3 then / V, as the reference adds the views
-    for (int k = 0; k < K; ++k) {
-      float a = scores[(long)r * K + k];
-      for (int v = 1; v < V; ++v) a += scores[((long)v * R + r) * K + k];
-      mean_scores[(long)r * ld_mean + k] = __fdiv_rn(a, (float)V);
-    }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += WS_CH) {
+    float a = s_part[0][k];
+    for (int w = 1; w < 8; ++w) a += s_part[w][k];
+    pS[((long)v * nchunk + chunk) * K + k] = a;
+  }
+}
+
+// out[r][k] = (((s0+s1)+s2)+s3)/V over the views' score matrices, rows of pitch ld_out (mining input of round 0)
+__global__ void mean_scores_kernel(int V, int R, int K, const float* __restrict__ scores, float* __restrict__ out,
+                                   long ld_out) {
+  const long n = (long)R * K;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float a = scores[i];
+    for (int v = 1; v < V; ++v) a += scores[(long)v * n + i];
+    const long r = i / K; const int k = (int)(i - r * K);
+    out[r * ld_out + k] = __fdiv_rn(a, (float)V);
   }
 }
 
@@ -187,35 +189,29 @@ __global__ __launch_bounds__(WS_CH) void wsddn_grad_kernel(int V, int R, int K, 
 // p_v = softmax_j(logits[v][r][cls_col0 + k*col_stride + j])   (predict_probs fast_rcnn_oicr.py:702-716, view
 // average roi_heads_oicrplus.py:390-395).  These are the mining scores of round k+1; they depend on the logits only,
 // so all rounds are produced by one launch and the rounds' mining runs concurrently.
-__global__ __launch_bounds__(256) void mean_probs_kernel(int V, int R, int K, const float* __restrict__ logits, long ld,
-                                                         int cls_col0, int col_stride, float* __restrict__ out) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-  if (r >= R) return;
-  const int K1 = K + 1;
-  float rm[WS_VMAX], rz[WS_VMAX];
-#pragma unroll
-  for (int v = 0; v < WS_VMAX; ++v) {
-    rm[v] = 0.f; rz[v] = 1.f;
-    if (v < V) {
-      const float* x = logits + ((long)v * R + r) * ld + cls_col0 + k * col_stride;
-      float m = -FLT_MAX;
-      for (int j = 0; j < K1; ++j) m = fmaxf(m, x[j]);
-      float z = 0.f;
-      for (int j = 0; j < K1; ++j) z += expf(x[j] - m);
-      rm[v] = m; rz[v] = z;
-    }
+constexpr int MP_ROWS = 64;      // rows per workgroup of mean_probs_kernel (x V views = threads)
+__global__ __launch_bounds__(MP_ROWS * WS_VMAX) void mean_probs_kernel(int V, int R, int K, const float* __restrict__ logits,
+                                                                       long ld, int cls_col0, int col_stride,
+                                                                       float* __restrict__ out) {
+  extern __shared__ float ptile[];                       // [V][MP_ROWS][K+1] softmax of every (view, row)
+  const int K1 = K + 1, k = blockIdx.y;
+  const int row0 = blockIdx.x * MP_ROWS, nrow = min(MP_ROWS, R - row0);
+  const int v = threadIdx.x / MP_ROWS, t = threadIdx.x % MP_ROWS;
+  if (v < V && t < nrow) {
+    const float* x = logits + ((long)v * R + row0 + t) * ld + cls_col0 + k * col_stride;
+    float* p = ptile + ((long)v * MP_ROWS + t) * K1;
+    float m = -FLT_MAX;
+    for (int j = 0; j < K1; ++j) { const float xv = x[j]; p[j] = xv; m = fmaxf(m, xv); }
+    float z = 0.f;
+    for (int j = 0; j < K1; ++j) z += expf(p[j] - m);
+    for (int j = 0; j < K1; ++j) p[j] = expf(p[j] - m) / z;
   }
-  float* o = out + ((long)k * R + r) * K1;
-  for (int j = 0; j < K1; ++j) {
-    float a = 0.f;
-#pragma unroll
-    for (int v = 0; v < WS_VMAX; ++v) {
-      if (v < V) {
-        const float p = expf(logits[((long)v * R + r) * ld + cls_col0 + k * col_stride + j] - rm[v]) / rz[v];
-        a = v == 0 ? p : a + p;
-      }
-    }
-    o[j] = __fdiv_rn(a, (float)V);
+  __syncthreads();
+  float* o = out + ((long)k * R + row0) * K1;            // contiguous run of the (rounds, R, K+1) output
+  for (int i = threadIdx.x; i < nrow * K1; i += blockDim.x) {
+    float a = ptile[i];
+    for (int vv = 1; vv < V; ++vv) a += ptile[(long)vv * MP_ROWS * K1 + i];
+    o[i] = __fdiv_rn(a, (float)V);
   }
 }
 
@@ -622,9 +618,19 @@ extern "C" int sw_wsddn_mil(int V, int R, int K, const float* logits, long ld, i
   float* cz = cm + (long)V * K;
   hipLaunchKernelGGL(wsddn_stats_kernel, dim3(nchunk, V), dim3(WS_CH), 0, stream, R, K, logits, ld, det_col, pm, ps);
   SW_CHECK_LAUNCH();
-  hipLaunchKernelGGL(wsddn_scores_kernel, dim3(nchunk), dim3(WS_CH), 0, stream, V, R, K, logits, ld, cls_col, det_col, pm, ps,
-                     cm, cz, pS, scores, mean_scores, ld_mean);
+  const size_t lds_sc = (size_t)WS_CH * K * sizeof(float);
+  if (lds_sc > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)wsddn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(wsddn_scores_kernel, dim3(nchunk, V), dim3(WS_CH), lds_sc, stream, V, R, K, logits, ld, cls_col, det_col,
+                     pm, ps, cm, cz, pS, scores);
   SW_CHECK_LAUNCH();
+  if (mean_scores) {
+    long blocks = ((long)R * K + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(mean_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, V, R, K, scores, mean_scores, ld_mean);
+    SW_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(wsddn_grad_kernel, dim3(dlogits ? nchunk : 1, V), dim3(WS_CH), 0, stream, V, R, K, logits, ld, cls_col,
                      det_col, gt_onehot, cm, cz, pS, nchunk, scores, loss_view, dlogits, ld_d, grad_scale);
   SW_CHECK_LAUNCH();
@@ -635,8 +641,14 @@ extern "C" int sw_oicr_mean_probs(int V, int R, int K, int n_rounds, const float
                                   int col_stride, float* out, hipStream_t stream) {
   if (R <= 0 || n_rounds <= 0) return 0;
   if (V > WS_VMAX || V < 1) return -6;
-  hipLaunchKernelGGL(mean_probs_kernel, dim3((R + 255) / 256, n_rounds), dim3(256), 0, stream, V, R, K, logits, ld, cls_col0,
-                     col_stride, out);
+  const size_t lds = (size_t)V * MP_ROWS * (K + 1) * sizeof(float);
+  if (lds > 150 * 1024) return -6;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)mean_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(mean_probs_kernel, dim3((R + MP_ROWS - 1) / MP_ROWS, n_rounds), dim3(MP_ROWS * V), lds, stream, V, R, K,
+                     logits, ld, cls_col0, col_stride, out);
   SW_CHECK_LAUNCH();
   return 0;
 }
