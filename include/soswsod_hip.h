@@ -187,6 +187,10 @@ int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, sw_st
 /* rows x cols copy/convert f32 -> dtype with independent leading dimensions (weight staging). */
 int sw_convert_2d(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
                   sw_stream_t stream);
+/* dst[c][r] = src[r][c] converted to dtype (rows x cols f32 source; dst has cols rows of pitch ld_dst): the eager form of
+ * sw_sgd_multi's stage_kind 3 transposed copy (first step / after a checkpoint load). */
+int sw_convert_2d_t(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
+                    sw_stream_t stream);
 /* f32 NCHW -> dtype NHWC, channels zero padded to cpad (generic backbone entry, vgg.py:216-223 takes NCHW). */
 int sw_nchw_to_nhwc(int dtype, int N, int C, int H, int W, int cpad, const float* in_nchw, void* out_nhwc,
                     sw_stream_t stream);
@@ -210,7 +214,9 @@ int sw_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, l
  * tensors: HOST array (copied into the launch).  stage_kind 0: none.  1: the parameter is a (n/d0) x d0 matrix, stage0
  * receives it in stage_dtype with row pitch ld0 (fc / predictor weights).  2: the parameter is an OIHW 3x3 conv weight
  * (Cout=d0, Cin=d1): stage0 (may be NULL) = forward layout [co][tap][d2=cin_pad] and stage1 (may be NULL) = data-gradient
- * layout [ci][8-tap][co], exactly what sw_conv_weight_prep modes 0 / 1 produce. */
+ * layout [ci][8-tap][co], exactly what sw_conv_weight_prep modes 0 / 1 produce.  3: as 1, plus stage1 = the TRANSPOSED
+ * matrix (d0 rows of pitch ld1) — fc6's weight is read K-contiguous by the forward AND by the data-gradient GEMM this
+ * way (a K-strided operand of 49 KiB pitch costs that GEMM 25 %); n/d0 and d0 must be multiples of 64. */
 #define SW_SGD_MAX_TENSORS 24
 typedef struct {
   float* param;
@@ -223,7 +229,7 @@ typedef struct {
   void* stage0;
   void* stage1;
   int d0, d1, d2;
-  long ld0;
+  long ld0, ld1;
 } sw_sgd_tensor;
 int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float momentum, float grad_scale, sw_stream_t stream);
 /* out[i] = sum_v loss_view[i][v] / V   (loss assembly, roi_heads_oicrplus.py:283-288,384-388) */

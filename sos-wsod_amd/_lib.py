@@ -29,7 +29,7 @@ class SgdTensor(ctypes.Structure):
     _fields_ = [
         ("param", c_void_p), ("grad", c_void_p), ("momentum_buf", c_void_p), ("n", c_long), ("lr", c_float),
         ("weight_decay", c_float), ("first_step", c_int), ("stage_kind", c_int), ("stage_dtype", c_int),
-        ("stage0", c_void_p), ("stage1", c_void_p), ("d0", c_int), ("d1", c_int), ("d2", c_int), ("ld0", c_long),
+        ("stage0", c_void_p), ("stage1", c_void_p), ("d0", c_int), ("d1", c_int), ("d2", c_int), ("ld0", c_long), ("ld1", c_long),
     ]
 
 
@@ -83,6 +83,7 @@ SIGNATURES = {
     "sw_dropout_mask": (c_int, [c_void_p, c_long, c_u64, c_u64, c_float, c_void_p]),
     "sw_sgd_momentum_step": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_int, c_float,
                                      c_void_p]),
+    "sw_convert_2d_t": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_sgd_multi": (c_int, [c_int, ctypes.POINTER(SgdTensor), c_float, c_float, c_void_p]),
     "sw_loss_finalize": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_version": (ctypes.c_char_p, []),

@@ -367,6 +367,66 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdBatch b, float mom, f
   }
 }
 
+// 64 x 64 tiles of a 2D parameter: SGD update (or plain conversion when grad == nullptr), row-major compute-dtype copy and
+// the transposed copy through an LDS tile, every global access a >= 128-byte run.
+template <typename T>
+__global__ __launch_bounds__(256) void sgd_tile_t_kernel(int rows, int cols, float* __restrict__ param,
+                                                         const float* __restrict__ grad, float* __restrict__ buf, long ld_src,
+                                                         float lr, float wd, int first, float mom, float gscale,
+                                                         T* __restrict__ st0, long ld0, T* __restrict__ st1, long ld1) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = tr + it * 16;
+    const long o = (long)(r0 + r) * ld_src + c0 + tc;
+    float4 w4 = *(const float4*)(param + o);
+    float w[4] = {w4.x, w4.y, w4.z, w4.w};
+    if (grad) {
+      const float4 g4 = *(const float4*)(grad + o);
+      const float4 m4 = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(buf + o);
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+      float m[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dd = g[e] * gscale + wd * w[e];
+        m[e] = first ? dd : mom * m[e] + dd;
+        w[e] = w[e] - lr * m[e];
+      }
+      *(float4*)(buf + o) = make_float4(m[0], m[1], m[2], m[3]);
+      *(float4*)(param + o) = make_float4(w[0], w[1], w[2], w[3]);
+    }
+    if (st0) {
+      T* d = st0 + (long)(r0 + r) * ld0 + c0 + tc;
+      if (sizeof(T) == 2 && (((uintptr_t)d) & 7) == 0) {
+        *(uint2*)d = make_uint2((unsigned)f32_to_bf16_bits(w[0]) | ((unsigned)f32_to_bf16_bits(w[1]) << 16),
+                                (unsigned)f32_to_bf16_bits(w[2]) | ((unsigned)f32_to_bf16_bits(w[3]) << 16));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Elem<T>::store(d + e, w[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[r][tc + e] = w[e];
+  }
+  __syncthreads();
+  // transposed write: output row c (= source column), 64 source rows = one 128-byte (bf16) / 256-byte (f32) run
+  const int oc = threadIdx.x >> 2, q = (threadIdx.x & 3) * 16;
+  T* d = st1 + (long)(c0 + oc) * ld1 + r0 + q;
+  if (sizeof(T) == 2 && (((uintptr_t)d) & 15) == 0) {
+    u32x4 o[2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e >> 2][e & 3] = (unsigned)f32_to_bf16_bits(tile[q + 2 * e][oc]) | ((unsigned)f32_to_bf16_bits(tile[q + 2 * e + 1][oc]) << 16);
+    *(u32x4*)d = o[0];
+    *(u32x4*)(d + 8) = o[1];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Elem<T>::store(d + e, tile[q + e][oc]);
+  }
+}
+
 // f32 NCHW -> dtype NHWC with channel padding (generic backbone entry; the fused path is sw_preprocess)
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(int N, int C, int H, int W, int cpad, const float* __restrict__ in, T* __restrict__ out) {
@@ -598,6 +658,20 @@ extern "C" int sw_sgd_momentum_step(float* param, const float* grad, float* buf,
   return 0;
 }
 
+extern "C" int sw_convert_2d_t(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
+                               hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if ((rows % 64) || (cols % 64) || (ld_src % 4) || (((uintptr_t)src) & 15)) return -5;
+  dim3 grid(cols / 64, rows / 64);
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(sgd_tile_t_kernel<unsigned short>, grid, dim3(256), 0, stream, rows, cols, (float*)src, (const float*)nullptr,
+                       (float*)nullptr, ld_src, 0.f, 0.f, 0, 0.f, 0.f, (unsigned short*)nullptr, 0L, (unsigned short*)dst, ld_dst),
+    hipLaunchKernelGGL(sgd_tile_t_kernel<float>, grid, dim3(256), 0, stream, rows, cols, (float*)src, (const float*)nullptr,
+                       (float*)nullptr, ld_src, 0.f, 0.f, 0, 0.f, 0.f, (float*)nullptr, 0L, (float*)dst, ld_dst));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float momentum, float grad_scale,
                             hipStream_t stream) {
   for (int t0 = 0; t0 < n_tensors; t0 += SW_SGD_MAX_TENSORS) {
@@ -607,7 +681,23 @@ extern "C" int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float m
     for (int i = t0; i < n_tensors && i < t0 + SW_SGD_MAX_TENSORS; ++i) {
       const sw_sgd_tensor& d = tensors[i];
       if (d.n <= 0) continue;
-      if (d.stage_kind < 0 || d.stage_kind > 2) return -1;
+      if (d.stage_kind < 0 || d.stage_kind > 3) return -1;
+      if (d.stage_kind == 3) {                 // own tiled launch (row-major + transposed copies)
+        const long rows = d.n / (d.d0 > 0 ? d.d0 : 1);
+        if (d.d0 <= 0 || (d.d0 % 64) || (rows % 64) || rows * d.d0 != d.n || d.stage1 == nullptr) return -5;
+        if (d.stage_dtype != SW_BF16 && d.stage_dtype != SW_F32) return -1;
+        dim3 grid(d.d0 / 64, (unsigned)(rows / 64));
+        if (d.stage_dtype == SW_BF16)
+          hipLaunchKernelGGL(sgd_tile_t_kernel<unsigned short>, grid, dim3(256), 0, stream, (int)rows, d.d0, d.param, d.grad,
+                             d.momentum_buf, (long)d.d0, d.lr, d.weight_decay, d.first_step, momentum, grad_scale,
+                             (unsigned short*)d.stage0, d.ld0, (unsigned short*)d.stage1, d.ld1);
+        else
+          hipLaunchKernelGGL(sgd_tile_t_kernel<float>, grid, dim3(256), 0, stream, (int)rows, d.d0, d.param, d.grad,
+                             d.momentum_buf, (long)d.d0, d.lr, d.weight_decay, d.first_step, momentum, grad_scale,
+                             (float*)d.stage0, d.ld0, (float*)d.stage1, d.ld1);
+        SW_CHECK_LAUNCH();
+        continue;
+      }
       if (d.stage_kind && d.stage_dtype != SW_BF16 && d.stage_dtype != SW_F32) return -1;
       if (d.stage_kind == 1 && (d.d0 <= 0 || d.stage0 == nullptr)) return -5;
       if (d.stage_kind == 2 && (long)d.d0 * d.d1 * 9 != d.n) return -5;

@@ -66,9 +66,9 @@ def param_key(p):
 STAGING = {}
 
 
-def register_staging(p, kind, dtype, stage0=None, stage1=None, d0=0, d1=0, d2=0, ld0=0, stamp=None):
+def register_staging(p, kind, dtype, stage0=None, stage1=None, d0=0, d1=0, d2=0, ld0=0, ld1=0, stamp=None):
     STAGING[id(p)] = dict(param=p, kind=kind, dtype=dtype, stage0=stage0, stage1=stage1, d0=d0, d1=d1, d2=d2, ld0=ld0,
-                          stamp=stamp)
+                          ld1=ld1, stamp=stamp)
 
 
 def _launch(tag, fn):
@@ -249,7 +249,7 @@ def sgd_multi(entries, momentum, grad_scale=1.0):
             d.stage_kind, d.stage_dtype = st["kind"], dt(st["dtype"])
             d.stage0 = None if st["stage0"] is None else st["stage0"].data_ptr()
             d.stage1 = None if st["stage1"] is None else st["stage1"].data_ptr()
-            d.d0, d.d1, d.d2, d.ld0 = st["d0"], st["d1"], st["d2"], st["ld0"]
+            d.d0, d.d1, d.d2, d.ld0, d.ld1 = st["d0"], st["d1"], st["d2"], st["ld0"], st.get("ld1", 0)
     check(lib.sw_sgd_multi(n, arr, float(momentum), float(grad_scale), _stream()), "sw_sgd_multi")
 
 
@@ -305,6 +305,13 @@ def colsum(X, M, N, out, ld=None):
 def convert_2d(src_f32, dst, rows, cols, ld_src=None, ld_dst=None):
     check(lib.sw_convert_2d(dt(dst), rows, cols, _p(src_f32), src_f32.stride(0) if ld_src is None else ld_src, _p(dst),
                             dst.stride(0) if ld_dst is None else ld_dst, _stream()), "sw_convert_2d")
+    return dst
+
+
+def convert_2d_t(src_f32, dst, rows, cols):
+    """dst[c][r] = src[r][c] in dst's dtype (rows, cols multiples of 64)"""
+    check(lib.sw_convert_2d_t(dt(dst), rows, cols, _p(src_f32), src_f32.stride(0), _p(dst), dst.stride(0), _stream()),
+          "sw_convert_2d_t")
     return dst
 
 

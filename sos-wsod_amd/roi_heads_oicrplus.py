@@ -238,22 +238,31 @@ class OICRPlusHeads(nn.Module):
             row += n
         return Wh, flat_b
 
-    def _staged_matrix(self, name, w, device):
-        """persistent compute-dtype copy (padded row pitch) of an fc weight; see _pack_head_weights"""
+    def _staged_matrix(self, name, w, device, transposed=False):
+        """persistent compute-dtype copy (padded row pitch) of an fc weight; see _pack_head_weights.  transposed=True
+        also keeps the (cols, rows) transposed copy: the data-gradient GEMM then reads the weight K-contiguous like the
+        forward does (as a K-strided operand of 49 KiB row pitch it ran 25 % slower).  Returns copy or (copy, copy^T)."""
         dt_ = self.compute_dtype
+        rows, cols = w.shape
+        transposed = transposed and rows % 64 == 0 and cols % 64 == 0
         key = [ops.param_key(w)]
         hit = self._stage_cache.get(name)
-        if hit is not None and hit[0] == key and hit[1].dtype == dt_ and hit[1].device == device:
-            return hit[1]
-        rows, cols = w.shape
-        buf = hit[1] if (hit is not None and tuple(hit[1].shape) == (rows, cols) and hit[1].dtype == dt_ and
-                         hit[1].device == device) else _padded(rows, cols, device, dt_)
+        if hit is not None and hit[0] == key and hit[1].dtype == dt_ and hit[1].device == device and \
+                (hit[2] is not None or not transposed):
+            return (hit[1], hit[2]) if transposed else hit[1]
+        reuse = hit is not None and tuple(hit[1].shape) == (rows, cols) and hit[1].dtype == dt_ and hit[1].device == device
+        buf = hit[1] if reuse else _padded(rows, cols, device, dt_)
         ops.convert_2d(w.detach(), buf, rows, cols)
-        self._stage_cache[name] = (key, buf)
+        buf_t = None
+        if transposed:
+            buf_t = hit[2] if (reuse and hit[2] is not None) else _padded(cols, rows, device, dt_)
+            ops.convert_2d_t(w.detach(), buf_t, rows, cols)
+        self._stage_cache[name] = (key, buf, buf_t)
         if w.requires_grad:
-            ops.register_staging(w, 1, dt_, stage0=buf, d0=cols, ld0=buf.stride(0),
+            ops.register_staging(w, 3 if transposed else 1, dt_, stage0=buf, stage1=buf_t, d0=cols, ld0=buf.stride(0),
+                                 ld1=0 if buf_t is None else buf_t.stride(0),
                                  stamp=lambda pk, key=key: key.__setitem__(0, pk))
-        return buf
+        return (buf, buf_t) if transposed else buf
 
     # ------------------------------------------------------------------ training forward (explicit)
     def _train_forward(self, inp, feat1, feat2, params):
@@ -288,7 +297,8 @@ class OICRPlusHeads(nn.Module):
                     ops.dropout_mask(m, self.dropout_seed, self._drop_counter, 0.5)
                     self._drop_counter += m.numel()
                     masks[l] = m
-        W1 = self._staged_matrix("fc1", fc1w, dev)
+        W1 = self._staged_matrix("fc1", fc1w, dev, transposed=inp["need_grad"])
+        W1, W1T = W1 if isinstance(W1, tuple) else (W1, None)
         W2 = self._staged_matrix("fc2", fc2w, dev)
         h1 = _padded(V * R, D1, dev, dt_)
         ops.gemm(pooled, W1, h1, V * R, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], out_dtype=dt_),
@@ -337,7 +347,7 @@ class OICRPlusHeads(nn.Module):
         self.last_aux = aux
         aux["fc7"] = h2
         aux["logits"] = logits
-        return dict(losses=losses, feats=feats, rois=rois, obj=obj, pooled=pooled, argmax=argmax, h1=h1, h2=h2, W1=W1, W2=W2,
+        return dict(losses=losses, feats=feats, rois=rois, obj=obj, pooled=pooled, argmax=argmax, h1=h1, h2=h2, W1=W1, W1T=W1T, W2=W2,
                     Wh=Wh, dlogits=dlogits, R=R, train_dropout=training_dropout)
 
     def _col_to_loss(self, device):
@@ -387,8 +397,12 @@ class OICRPlusHeads(nn.Module):
         if feat_req[0] or feat_req[1]:
             dpooled = torch.empty(M, D0, device=dev, dtype=dt_)
             amax = torch.zeros(1, device=dev, dtype=torch.float32)      # max|dpooled| -> fixed-point scale of the ROI scatter
-            ops.gemm(dz1, W1, dpooled, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt_, absmax_out=amax),
-                     tag="fc6_dgrad")
+            if st["W1T"] is not None:       # NT: B = W1^T (D0 x D1), K-contiguous
+                ops.gemm(dz1, st["W1T"], dpooled, M, D0, D1, ep=ops.make_epilogue(out_dtype=dt_, absmax_out=amax),
+                         tag="fc6_dgrad")
+            else:
+                ops.gemm(dz1, W1, dpooled, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt_, absmax_out=amax),
+                         tag="fc6_dgrad")
             P = self.box_pooler.output_size
             for s in range(2):
                 if not feat_req[s]:

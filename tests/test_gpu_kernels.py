@@ -377,7 +377,7 @@ def test_sgd_multi_matches_single_tensor_steps_and_staging(ops, sdt):
     """sw_sgd_multi == per-tensor sw_sgd_momentum_step + sw_conv_weight_prep / sw_convert_2d on the updated weights,
     bit for bit (28 tensors -> two launches; odd sizes, unaligned views, first step and later steps)"""
     gen = torch.Generator().manual_seed(70)
-    shapes = [(64, 32, 3, 3), (32,), (40, 24, 3, 3), (130, 72), (7,), (3, 1001)] + [(5 + i,) for i in range(22)]
+    shapes = [(64, 32, 3, 3), (32,), (40, 24, 3, 3), (130, 72), (7,), (3, 1001), (128, 192)] + [(5 + i,) for i in range(21)]
     ps = [torch.randn(*sh, generator=gen).cuda() for sh in shapes]
     flat = torch.randn(11 * 72 + 3, generator=gen).cuda()
     ps.append(flat[3:3 + 11 * 72].view(11, 72))                   # a row-slice style view at a 12-byte offset
@@ -396,6 +396,8 @@ def test_sgd_multi_matches_single_tensor_steps_and_staging(ops, sdt):
         st[3] = dict(kind=1, dtype=sdt, stage0=m3, stage1=None, d0=72, d1=0, d2=0, ld0=m3.stride(0))
         m5 = torch.zeros(3, 1001 + 3, device="cuda", dtype=sdt)[:, :1001]
         st[5] = dict(kind=1, dtype=sdt, stage0=m5, stage1=None, d0=1001, d1=0, d2=0, ld0=m5.stride(0))
+        m6 = torch.zeros(128, 192 + 8, device="cuda", dtype=sdt)[:, :192]; m6t = torch.zeros(192, 128 + 8, device="cuda", dtype=sdt)[:, :128]
+        st[6] = dict(kind=3, dtype=sdt, stage0=m6, stage1=m6t, d0=192, d1=0, d2=0, ld0=m6.stride(0), ld1=m6t.stride(0))
         mv = torch.zeros(11, 72, device="cuda", dtype=sdt)
         st[len(ps) - 1] = dict(kind=1, dtype=sdt, stage0=mv, stage1=None, d0=72, d1=0, d2=0, ld0=72)
         entries = [dict(param=p, grad=g, buf=b, lr=0.01 * (1 + i % 3), weight_decay=5e-4 * (i % 2), first=first,
@@ -407,6 +409,10 @@ def test_sgd_multi_matches_single_tensor_steps_and_staging(ops, sdt):
         ops.conv_weight_prep(ps[0], e0, 0, 32); ops.conv_weight_prep(ps[0], e1, 1, None); ops.conv_weight_prep(ps[2], e2, 0, 24)
         assert torch.equal(wk0, e0) and torch.equal(wk1, e1) and torch.equal(wk2, e2)
         assert torch.equal(m3, ps[3].to(sdt)) and torch.equal(m5, ps[5].to(sdt)) and torch.equal(mv, ps[-1].to(sdt))
+        assert torch.equal(m6, ps[6].to(sdt)) and torch.equal(m6t, ps[6].to(sdt).t())
+        e6 = torch.zeros(192, 128 + 8, device="cuda", dtype=sdt)[:, :128]
+        ops.convert_2d_t(ps[6], e6, 128, 192)                      # the eager form of the transposed copy
+        assert torch.equal(e6, m6t)
 
 
 # ------------------------------------------------------------------------------------------ utilities
