@@ -90,6 +90,9 @@ class _VGGFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         module, stage_info, params = ctx.module, ctx.stage_info, ctx.params
+        # the saved activations include this node's own output (ReLU mask of the last conv): node -> ctx -> tensor -> grad_fn
+        # is a reference cycle that only Python's cyclic GC would free, hundreds of MB per step later.  Drop it now.
+        ctx.stage_info = None
         dtype = stage_info[0][0][0][0].dtype
         grads = [None] * len(params)
         g = g.contiguous()
