@@ -19,12 +19,15 @@ elif which.startswith("wgrad"):
     x = rnd(n_, H_, W_, cin); dy = rnd(n_, H_, W_, cout); dw = torch.empty(cout, cin, 3, 3, device=dev); ws = torch.empty(cout * 9 * cin, device=dev)
     f = lambda: ops.conv3x3_wgrad(x, dy, dw, dil, splitk=sk, workspace=ws)
 else:
+    # the box head's matrices as the step holds them: row pitches padded by 128 elements (roi_heads_oicrplus._padded)
     M, D0, D1 = 8000, 25088, 4096
-    X = rnd(M, D0); W1 = rnd(D1, D0); dZ = rnd(M, D1)
+    pad = lambda r, c: rnd(r, c + 128)[:, :c]
+    X = rnd(M, D0); W1 = pad(D1, D0); dZ = pad(M, D1)
     if which == "fc6_fwd":
-        Y = torch.empty(M, D1, device=dev, dtype=dt); f = lambda: ops.gemm(X, W1, Y, M, D1, D0)
-    elif which == "fc6_dgrad":
-        dX = torch.empty(M, D0, device=dev, dtype=dt); f = lambda: ops.gemm(dZ, W1, dX, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt))
+        Y = torch.empty(M, D1 + 128, device=dev, dtype=dt)[:, :D1]; f = lambda: ops.gemm(X, W1, Y, M, D1, D0)
+    elif which == "fc6_dgrad":       # NT on the transposed weight copy
+        W1T = pad(D0, D1); dX = torch.empty(M, D0, device=dev, dtype=dt)
+        f = lambda: ops.gemm(dZ, W1T, dX, M, D0, D1, ep=ops.make_epilogue(out_dtype=dt))
     else:
         dW = torch.empty(D1, D0, device=dev); f = lambda: ops.gemm(dZ, X, dW, D1, D0, M, a_kstrided=True, b_kstrided=True)
 for _ in range(n): f()
