@@ -7,6 +7,10 @@ __graft_entry__.build().)
 import ctypes
 import os
 
+import torch  # noqa: F401  — FIRST: torch bundles its own HIP runtime (torch/lib/libamdhip64.so); loading our library before
+#                it would bind it to /opt/rocm's copy instead, and the process then holds two runtimes of which only torch's
+#                has an initialised device (every launch from this library then fails with hipErrorNoDevice = 100)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsoswsod_hip.so")
 

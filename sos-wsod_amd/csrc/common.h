@@ -69,6 +69,9 @@ __device__ __forceinline__ float block_reduce_max(float v, float* red) {
   return r;
 }
 
+// hipGetLastError() is a per-thread sticky value: a recoverable error of an unrelated earlier HIP call (e.g. torch probing a
+// device) would otherwise be reported by the first SW_CHECK_LAUNCH of this library.  Every entry point starts clean.
+#define SW_ENTER() (void)hipGetLastError()
 #define SW_CHECK_LAUNCH()                         \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \

@@ -481,6 +481,7 @@ __global__ void loss_finalize_kernel(int nl, int V, const float* __restrict__ lv
 
 extern "C" int sw_preprocess(int dtype, int H, int W, int cpad, const uint8_t* img, const float* mean3,
                              const float* std3, void* out, hipStream_t stream) {
+  SW_ENTER();
   // mean/std are HOST floats here? No: device pointers are the convention, but these 6 scalars are
   // configuration constants; they are passed by value through the launch instead of dereferenced on device.
   // => mean3/std3 are HOST pointers (documented exception).
@@ -496,6 +497,7 @@ extern "C" int sw_preprocess(int dtype, int H, int W, int cpad, const uint8_t* i
 
 extern "C" int sw_maxpool2x2_fwd(int dtype, int nimg, int H, int W, int C, int stride, const void* in, void* out,
                                  hipStream_t stream) {
+  SW_ENTER();
   const int OH = (H - 2) / stride + 1, OW = (W - 2) / stride + 1;
   const long n = (long)nimg * OH * OW * C;
   const int vn = dtype == SW_BF16 ? 8 : 4;
@@ -519,6 +521,7 @@ extern "C" int sw_maxpool2x2_fwd(int dtype, int nimg, int H, int W, int C, int s
 
 extern "C" int sw_maxpool2x2_bwd(int dtype, int nimg, int H, int W, int C, int stride, const void* in,
                                  const void* dout, void* din, int relu_mask, hipStream_t stream) {
+  SW_ENTER();
   const int OH = (H - 2) / stride + 1, OW = (W - 2) / stride + 1;
   const long n = (long)nimg * H * W * C;
   const int vn = dtype == SW_BF16 ? 8 : 4;
@@ -543,6 +546,7 @@ extern "C" int sw_maxpool2x2_bwd(int dtype, int nimg, int H, int W, int C, int s
 
 extern "C" int sw_conv_weight_prep(int dtype, int mode, int Cout, int Cin, int cin_pad, const float* w, void* wk,
                                    hipStream_t stream) {
+  SW_ENTER();
   if (mode != 0 && mode != 1) return -3;
   if (mode == 1 && cin_pad != Cin) return -3;
   const long n = mode == 0 ? (long)Cout * 9 * cin_pad : (long)Cin * 9 * Cout;
@@ -557,6 +561,7 @@ extern "C" int sw_conv_weight_prep(int dtype, int mode, int Cout, int Cin, int c
 
 extern "C" int sw_convert_2d(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
                              hipStream_t stream) {
+  SW_ENTER();
   const long n = (long)rows * cols;
   if (n <= 0) return 0;
   const long esz = dtype == SW_BF16 ? 2 : 4;
@@ -580,6 +585,7 @@ extern "C" int sw_convert_2d(int dtype, int rows, int cols, const float* src, lo
 }
 
 extern "C" int sw_to_f32(int dtype, long n, const void* src, float* dst, hipStream_t stream) {
+  SW_ENTER();
   if (n <= 0) return 0;
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(to_f32_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const unsigned short*)src, dst),
@@ -590,6 +596,7 @@ extern "C" int sw_to_f32(int dtype, long n, const void* src, float* dst, hipStre
 
 extern "C" int sw_nchw_to_nhwc(int dtype, int N, int C, int H, int W, int cpad, const float* in, void* out,
                                hipStream_t stream) {
+  SW_ENTER();
   const long n = (long)N * H * W * cpad;
   if (n <= 0) return 0;
   DISPATCH_T(dtype,
@@ -600,6 +607,7 @@ extern "C" int sw_nchw_to_nhwc(int dtype, int N, int C, int H, int W, int cpad, 
 }
 
 extern "C" int sw_relu_bwd(int dtype, long n, const void* ref, void* grad, hipStream_t stream) {
+  SW_ENTER();
   if (n <= 0) return 0;
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(relu_bwd_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const unsigned short*)ref, (unsigned short*)grad),
@@ -610,6 +618,7 @@ extern "C" int sw_relu_bwd(int dtype, long n, const void* ref, void* grad, hipSt
 
 extern "C" int sw_scale_cols(int dtype, int M, int N, const float* in, long ld_in, const float* colscale, void* out,
                              long ld_out, hipStream_t stream) {
+  SW_ENTER();
   const long n = (long)M * N;
   if (n <= 0) return 0;
   DISPATCH_T(dtype,
@@ -620,6 +629,7 @@ extern "C" int sw_scale_cols(int dtype, int M, int N, const float* in, long ld_i
 }
 
 extern "C" int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, hipStream_t stream) {
+  SW_ENTER();
   if (N <= 0) return 0;
   hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
@@ -638,11 +648,13 @@ extern "C" int sw_colsum(int dtype, int M, int N, const void* X, long ld, float*
 }
 
 extern "C" int sw_fill_zero(void* p, long bytes, hipStream_t stream) {
+  SW_ENTER();
   if (bytes <= 0) return 0;
   return (int)hipMemsetAsync(p, 0, (size_t)bytes, stream);
 }
 
 extern "C" int sw_dropout_mask(uint8_t* keep, long n, uint64_t seed, uint64_t offset, float p, hipStream_t stream) {
+  SW_ENTER();
   if (n <= 0) return 0;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, stream, keep, n, seed, offset, p);
   SW_CHECK_LAUNCH();
@@ -651,6 +663,7 @@ extern "C" int sw_dropout_mask(uint8_t* keep, long n, uint64_t seed, uint64_t of
 
 extern "C" int sw_sgd_momentum_step(float* param, const float* grad, float* buf, long n, float lr, float momentum,
                                     float weight_decay, int first_step, float grad_scale, hipStream_t stream) {
+  SW_ENTER();
   if (n <= 0) return 0;
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, param, grad, buf, n, lr, momentum, weight_decay,
                      first_step, grad_scale);
@@ -660,6 +673,7 @@ extern "C" int sw_sgd_momentum_step(float* param, const float* grad, float* buf,
 
 extern "C" int sw_convert_2d_t(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
                                hipStream_t stream) {
+  SW_ENTER();
   if (rows <= 0 || cols <= 0) return 0;
   if ((rows % 64) || (cols % 64) || (ld_src % 4) || (((uintptr_t)src) & 15)) return -5;
   dim3 grid(cols / 64, rows / 64);
@@ -674,6 +688,7 @@ extern "C" int sw_convert_2d_t(int dtype, int rows, int cols, const float* src, 
 
 extern "C" int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float momentum, float grad_scale,
                             hipStream_t stream) {
+  SW_ENTER();
   for (int t0 = 0; t0 < n_tensors; t0 += SW_SGD_MAX_TENSORS) {
     SgdBatch b;
     b.n = 0;
@@ -717,6 +732,7 @@ extern "C" int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float m
 }
 
 extern "C" int sw_mean_views(int V, long n, const float* in, float* out, hipStream_t stream) {
+  SW_ENTER();
   if (n <= 0) return 0;
   hipLaunchKernelGGL(mean_views_kernel, dim3(grid_for(n)), dim3(256), 0, stream, V, n, in, out);
   SW_CHECK_LAUNCH();
@@ -724,6 +740,7 @@ extern "C" int sw_mean_views(int V, long n, const float* in, float* out, hipStre
 }
 
 extern "C" int sw_loss_finalize(int n_losses, int V, const float* loss_view, float* out, hipStream_t stream) {
+  SW_ENTER();
   if (n_losses > 64) return -6;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, n_losses, V, loss_view, out);
   SW_CHECK_LAUNCH();

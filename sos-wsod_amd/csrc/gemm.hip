@@ -557,6 +557,7 @@ int check_align(const void* p) { return (((uintptr_t)p) & 15) ? -4 : 0; }
 extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, int K, const void* A, long lda,
                        const void* B, long ldb, void* C, long ldc, const sw_epilogue* ep, int splitk,
                        hipStream_t stream) {
+  SW_ENTER();
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int epc = dtype == SW_BF16 ? 8 : 4;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
@@ -589,6 +590,7 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
 //   out[(img,y,x)][co] = sum_{tap,ci} in[img, y+(ty-1)d, x+(tx-1)d, ci] * Wk[co][tap][ci]
 extern "C" int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in,
                                 const void* wk, void* out, const sw_epilogue* ep, hipStream_t stream) {
+  SW_ENTER();
   const int epc = dtype == SW_BF16 ? 8 : 4;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
   if (Cin % epc) return -5;
@@ -645,6 +647,7 @@ extern "C" long sw_conv3x3_wgrad_workspace_floats(int dtype, int nimg, int H, in
 // the splits of one tile finish together and collide on the same addresses; this form is also deterministic.)
 extern "C" int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                                 const void* dy, float* dw_oihw, float* workspace, int splitk, hipStream_t stream) {
+  SW_ENTER();
   const int epc = dtype == SW_BF16 ? 8 : 4;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
   if ((Cin % epc) || (Cout % epc)) return -5;

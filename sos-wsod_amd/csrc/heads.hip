@@ -609,6 +609,7 @@ extern "C" int sw_wsddn_mil(int V, int R, int K, const float* logits, long ld, i
                             const float* gt_onehot, float* scores, float* loss_view, float* dlogits, long ld_d,
                             const float* grad_scale, float* mean_scores, long ld_mean, float* workspace,
                             hipStream_t stream) {
+  SW_ENTER();
   if (K > KMAX || V > WS_VMAX || V < 1 || R < 1) return -6;
   const int nchunk = (R + WS_CH - 1) / WS_CH;
   float* pm = workspace;
@@ -639,6 +640,7 @@ extern "C" int sw_wsddn_mil(int V, int R, int K, const float* logits, long ld, i
 
 extern "C" int sw_oicr_mean_probs(int V, int R, int K, int n_rounds, const float* logits, long ld, int cls_col0,
                                   int col_stride, float* out, hipStream_t stream) {
+  SW_ENTER();
   if (R <= 0 || n_rounds <= 0) return 0;
   if (V > WS_VMAX || V < 1) return -6;
   const size_t lds = (size_t)V * MP_ROWS * (K + 1) * sizeof(float);
@@ -658,6 +660,7 @@ extern "C" int sw_oicr_refine_loss(int V, int R, int K, int n_rounds, const floa
                                    const float* lab_weight, const int32_t* lab_index, const int32_t* pred_view,
                                    const float* reg_weights4, float* loss_view, float* dlogits, long ld_d,
                                    const float* grad_scale, float* workspace, hipStream_t stream) {
+  SW_ENTER();
   // reg_weights4: HOST pointer (configuration constants BBOX_REG_WEIGHTS); workspace: n_rounds*2*V*R floats
   if (R <= 0 || n_rounds <= 0) return 0;
   hipLaunchKernelGGL(refine_loss_kernel, dim3((R + 255) / 256, V, n_rounds), dim3(256), 0, stream, V, R, K, logits, ld,
@@ -676,6 +679,7 @@ extern "C" int sw_oicr_mine_label(int R, int ncol, int K, int n_rounds, const fl
                                   float iou_bg, float iou_fg, int32_t* lab_class, float* lab_weight,
                                   int32_t* lab_index, int32_t* pgt_count, int32_t* pgt_index, int32_t* pgt_class,
                                   float* pgt_score, void* workspace, hipStream_t stream) {
+  SW_ENTER();
   if (R > 16384 || (long)top_k * G > 16384 || top_k > R || G < 1 || n_rounds < 1) return -6;
   int np = 64;
   const int need = R > top_k * G ? R : top_k * G;
@@ -693,6 +697,7 @@ extern "C" int sw_oicr_mine_label(int R, int ncol, int K, int n_rounds, const fl
 extern "C" int sw_oicr_predict(int R, int K, int refine_k, const float* logits, long ld, int base_col, int round_stride,
                                const float* boxes, const float* reg_weights4, float scale_clamp, float* all_scores,
                                float* all_boxes, hipStream_t stream) {
+  SW_ENTER();
   if (R <= 0) return 0;
   hipLaunchKernelGGL(predict_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, K, refine_k, logits, ld, base_col,
                      round_stride, boxes, reg_weights4[0], reg_weights4[1], reg_weights4[2], reg_weights4[3], scale_clamp,
@@ -707,6 +712,7 @@ extern "C" int sw_detect_postprocess(int R, int K, const float* all_scores, cons
                                      float score_thresh, float nms_thresh, int topk, int32_t* det_count, float* det_boxes,
                                      float* det_scores, int32_t* det_classes, int32_t* det_rows, void* workspace,
                                      hipStream_t stream) {
+  SW_ENTER();
   if (R > 16384 || (long)K * topk > 16384 || topk < 1) return -6;
   char* ws = (char*)workspace;
   float* maxcoord = (float*)ws;                                    // [1] (+pad)

@@ -559,6 +559,7 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, int PH, int PW, const void* 
 extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale,
                                const void* feat, const float* rois, int R, const float* row_scale,
                                float row_scale_add, void* out, void* argmax, int argmax_bits, hipStream_t stream) {
+  SW_ENTER();
   if (R <= 0) return 0;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
   if (argmax_bits == 32)
@@ -574,6 +575,7 @@ extern "C" int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH,
                                const void* argmax, int argmax_bits, const float* rois, int R, const float* row_scale,
                                float row_scale_add, const void* relu_ref, const float* dout_absmax, void* dfeat,
                                hipStream_t stream) {
+  SW_ENTER();
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
   if (argmax_bits != 32 && argmax_bits != 16) return -1;
 #define SW_BWD(T, IT) return roi_bwd_dispatch<T, IT>(nimg, H, W, C, PH, PW, dout, argmax, rois, R, row_scale, row_scale_add, \
@@ -585,6 +587,7 @@ extern "C" int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH,
 }
 
 extern "C" int sw_absmax(int dtype, long n, const void* x, float* out, hipStream_t stream) {
+  SW_ENTER();
   hipError_t e = hipMemsetAsync(out, 0, sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
   if (n <= 0) return 0;
