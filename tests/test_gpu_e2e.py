@@ -217,3 +217,127 @@ def test_fused_staging_keeps_weight_copies_current(golden_dir, dtype):
     assert hd._stage_cache["fc1"][0] == [ops.param_key(hd.box_head.fc1.weight)]
     assert hd._stage_cache["fc2"][0] == [ops.param_key(hd.box_head.fc2.weight)]
     assert hd._stage_cache["heads"][0] == [ops.param_key(p) for p in hd._flat_params()[4::2]]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's full size (4 views 512x512, R = 2000, K = 20, 4096-wide heads): too large for the CPU oracle inside a
+# test, so the check goes through size-independent properties and through an independent GPU implementation (torch's own
+# hipBLASLt matmul / conv for the contractions).
+def _full_size_model_and_data():
+    import bench
+    model = bench.build(torch.device("cuda", 0), torch.bfloat16)
+    model.train()
+    return model, bench.make_inputs(torch.device("cuda", 0), 7), bench
+
+
+def test_full_size_iteration_properties():
+    import sos_wsod_amd.ops as ops
+    from sos_wsod_amd.events import EventStorage
+    model, data, bench = _full_size_model_and_data()
+    R, K = bench.R, bench.K
+    with EventStorage(0):
+        losses = model(data)
+        losses.total().backward()
+    torch.cuda.synchronize()
+    vec = losses.vector.detach().cpu()
+    assert vec.shape == (9,) and torch.isfinite(vec).all() and (vec >= 0).all()
+    aux = model.roi_heads.last_aux
+    # WSDDN scores: product of a softmax over classes and one over proposals => every (view, class) column sums to <= 1
+    sc = aux["scores"]
+    assert sc.shape == (4, R, K) and (sc >= 0).all()
+    assert (sc.sum(1) <= 1 + 1e-4).all() and (sc.sum((1, 2)) > 0).all()
+    boxes = data[0]["proposals1"].proposal_boxes.tensor
+    gt = set(int(c) for c in data[0]["instances1"].gt_classes.tolist())
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    for rnd in aux["rounds"]:
+        n = int(rnd["pgt_count"].item())
+        idx = rnd["pgt_index"][:n].long(); cls = rnd["pgt_class"][:n]; s = rnd["pgt_score"][:n]
+        assert n >= len(gt) and set(cls.tolist()) <= gt and (idx >= 0).all() and (idx < R).all()
+        assert (s[:-1] >= s[1:]).all()                                   # kept list is score-descending
+        b = boxes[idx]                                                     # NMS 0.01: kept boxes barely overlap
+        lt = torch.max(b[:, None, :2], b[None, :, :2]); rb = torch.min(b[:, None, 2:], b[None, :, 2:])
+        inter = (rb - lt).clamp(min=0).prod(-1)
+        iou = inter / (area[idx][:, None] + area[idx][None, :] - inter)
+        iou.fill_diagonal_(0)
+        assert (iou <= 0.01 + 1e-6).all()
+        lab = rnd["lab_class"]; w = rnd["lab_weight"]; li = rnd["lab_index"].long()
+        assert ((lab >= -1) & (lab <= K)).all()
+        # labels follow the Matcher: recompute the best IoU against the kept list and the {0,-1,1} thresholds [0.5, 0.6]
+        ltp = torch.max(boxes[:, None, :2], b[None, :, :2]); rbp = torch.min(boxes[:, None, 2:], b[None, :, 2:])
+        ip = (rbp - ltp).clamp(min=0).prod(-1)
+        ioup = torch.where(ip > 0, ip / (area[:, None] + area[idx][None, :] - ip), torch.zeros_like(ip))
+        best, bj = ioup.max(1)
+        fg, bg = best >= 0.6, best < 0.5
+        clear = ((best - 0.6).abs() > 1e-5) & ((best - 0.5).abs() > 1e-5)  # away from the thresholds (f32 rounding of IoU)
+        assert (lab[fg & clear] == cls[bj][fg & clear]).all() and (lab[bg & clear] == K).all()
+        assert (lab[~fg & ~bg & clear] == -1).all()
+        assert torch.equal(w[clear & fg], s[bj][clear & fg]) and torch.equal(li[clear & fg], idx[bj][clear & fg])
+    # every trainable parameter received a finite gradient of its own shape; frozen ones none
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and p.grad.shape == p.shape and torch.isfinite(p.grad).all(), name
+        else:
+            assert p.grad is None, name
+    # ROIPool at full size: argmax points at a pixel that holds exactly the pooled value (before the objectness scale)
+    hd = model.roi_heads
+    f = torch.randn(2, 63, 63, 512, device="cuda").to(torch.bfloat16)
+    rois = torch.cat([(torch.arange(2 * R, device="cuda") >= R).float()[:, None], torch.cat([boxes, boxes], 0)], 1).contiguous()
+    out = torch.empty(2 * R, 512 * 49, device="cuda", dtype=torch.bfloat16)
+    arg = torch.empty(2 * R, 512 * 49, device="cuda", dtype=ops.roi_argmax_dtype(63, 63))
+    ops.roi_pool_fwd(f, rois, out, arg, hd.box_pooler.scale, 7, 7)
+    a = ops.argmax_to_int32(arg).view(2 * R, 512, 49)
+    img = (torch.arange(2 * R, device="cuda") >= R).long()
+    sel = torch.randperm(2 * R, device="cuda")[:200]
+    for r in sel.tolist():
+        ar = a[r]                                                          # (512, 49)
+        val = out[r].view(512, 49)
+        ok = ar >= 0
+        px = f[img[r]].view(63 * 63, 512)                                  # (pixels, C)
+        got = px[ar.clamp(min=0), torch.arange(512, device="cuda")[:, None].expand(512, 49)]
+        assert torch.equal(got[ok], val[ok]) and (val[~ok] == 0).all()
+
+
+def test_full_size_contractions_match_torch_matmul():
+    """fc6 forward / data gradient / weight gradient and conv5_3 at their benchmark sizes against torch's own GPU matmul
+    and conv2d (hipBLASLt / MIOpen: an independent implementation), bf16 inputs, f32 accumulation: <= 1e-2 of the max."""
+    import sos_wsod_amd.ops as ops
+    dt = torch.bfloat16
+    M, D0, D1 = 8000, 25088, 4096
+    g = torch.Generator(device="cuda").manual_seed(3)
+    X = (torch.randn(M, D0, device="cuda", generator=g) * 0.5).to(dt)
+    W = (torch.randn(D1, D0, device="cuda", generator=g) * 0.02).to(dt)
+    dZ = (torch.randn(M, D1, device="cuda", generator=g) * 0.5).to(dt)
+    rows = torch.arange(0, M, 37, device="cuda")
+
+    def close(got, ref):
+        return (got.float() - ref.float()).abs().max() <= 1e-2 * ref.float().abs().max()
+    Y = torch.empty(M, D1, device="cuda", dtype=dt)
+    ops.gemm(X, W, Y, M, D1, D0)
+    assert close(Y[rows], X[rows].float() @ W.float().t())
+    WT = W.t().contiguous()
+    dX = torch.empty(M, D0, device="cuda", dtype=dt)
+    ops.gemm(dZ, WT, dX, M, D0, D1, ep=ops.make_epilogue(out_dtype=dt))                       # NT on the transposed copy
+    assert close(dX[rows], dZ[rows].float() @ W.float())
+    dX2 = torch.empty(M, D0, device="cuda", dtype=dt)
+    ops.gemm(dZ, W, dX2, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt))      # NN, K-strided operand
+    assert close(dX2[rows], dZ[rows].float() @ W.float())
+    dW = torch.empty(D1, D0, device="cuda")
+    ops.gemm(dZ, X, dW, D1, D0, M, a_kstrided=True, b_kstrided=True)
+    cols = torch.arange(0, D1, 61, device="cuda")
+    assert close(dW[cols], dZ[:, cols].float().t() @ X.float())
+    del X, W, dZ, Y, dX, dX2, dW, WT
+    x = (torch.randn(2, 63, 63, 512, device="cuda", generator=g) * 0.5).to(dt)
+    w = (torch.randn(512, 512, 3, 3, device="cuda", generator=g) * 0.02)
+    wk = torch.empty(512, 9, 512, device="cuda", dtype=dt); ops.conv_weight_prep(w, wk, 0, 512)
+    b = torch.randn(512, device="cuda", generator=g)
+    out = torch.empty(2, 63, 63, 512, device="cuda", dtype=dt)
+    ops.conv3x3(x, wk, out, 2, ops.make_epilogue(bias=b, relu=True, out_dtype=dt))
+    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).float(), w.to(dt).float(), b, padding=2, dilation=2))
+    assert close(out.permute(0, 3, 1, 2), ref)
+    dy = (torch.randn(2, 63, 63, 512, device="cuda", generator=g) * 0.5).to(dt)
+    dw = torch.empty(512, 512, 3, 3, device="cuda")
+    ops.conv3x3_wgrad(x, dy, dw, 2, splitk=3)
+    xr = x.permute(0, 3, 1, 2).float().requires_grad_(False)
+    wr = w.to(dt).float().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, wr, None, padding=2, dilation=2).backward(dy.permute(0, 3, 1, 2).float())
+    assert close(dw, wr.grad)
