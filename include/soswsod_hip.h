@@ -89,16 +89,19 @@ int sw_preprocess(int dtype, int H, int W, int cpad, const uint8_t* img_chw, con
  * argmax [R][C][PH][PW]: argmax_bits == 32 -> int32 (h*W+w or -1, the reference's tensor); argmax_bits == 16 ->
  * uint16 (h*W+w or 0xFFFF; maps of < 65535 pixels, else -6): a third less output traffic, half the backward's index
  * traffic.  row_scale (may be NULL): out *= (row_scale[r] + row_scale_add) = the objectness prior of
- * roi_heads_oicrplus.py:200-221.  A +NaN map value never wins a bin (reference: 'val > maxval'). */
+ * roi_heads_oicrplus.py:200-221.  A +NaN map value never wins a bin (reference: 'val > maxval').
+ * ld_out: row pitch (elements) of out AND argmax, 0 = C*PH*PW.  The fc6 GEMM reads `out` fastest when the pitch is not a
+ * multiple of 1 KiB (HBM channel / L2 set spread): the hot path passes C*PH*PW + 64. */
 int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale, const void* feat,
                     const float* rois, int R, const float* row_scale, float row_scale_add, void* out,
-                    void* argmax, int argmax_bits, sw_stream_t stream);
+                    void* argmax, int argmax_bits, long ld_out, sw_stream_t stream);
 /* dfeat [nimg][H][W][C] (dtype, fully overwritten) = scatter-add of dout by argmax, times the same row scale,
  * times (relu_ref > 0) when relu_ref != NULL (relu_ref has feat's layout/dtype).
  * dout_absmax (device scalar >= max|dout|, e.g. from sw_absmax or a GEMM epilogue; may be NULL): selects the
- * 64-bit fixed-point LDS accumulation (bitwise reproducible, ~3x faster than LDS float atomics); NULL => f32 atomics. */
+ * 64-bit fixed-point LDS accumulation (bitwise reproducible, ~3x faster than LDS float atomics); NULL => f32 atomics.
+ * ld_in: row pitch (elements) of dout AND argmax, 0 = C*PH*PW. */
 int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
-                    const void* argmax, int argmax_bits, const float* rois, int R, const float* row_scale,
+                    const void* argmax, int argmax_bits, long ld_in, const float* rois, int R, const float* row_scale,
                     float row_scale_add, const void* relu_ref, const float* dout_absmax, void* dfeat, sw_stream_t stream);
 /* out[0] = max |x[i]| (f32 device scalar, overwritten). */
 int sw_absmax(int dtype, long n, const void* x, float* out, sw_stream_t stream);

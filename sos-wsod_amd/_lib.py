@@ -56,8 +56,8 @@ SIGNATURES = {
                                   c_void_p]),
     "sw_preprocess": (c_int, [c_int, c_int, c_int, c_int, c_void_p, _F4, _F4, c_void_p, c_void_p]),
     "sw_roi_pool_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
-                                c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),
-    "sw_roi_pool_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_void_p]),
+    "sw_roi_pool_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_long, c_void_p, c_int,
                                 c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_absmax": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "sw_wsddn_workspace_floats": (c_long, [c_int, c_int, c_int]),

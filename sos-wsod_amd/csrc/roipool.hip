@@ -71,7 +71,7 @@ template <> struct VecLoad<unsigned short, 2> {
 };
 
 template <typename T, int VEC, typename IT>
-__global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, int PH, int PW, float scale,
+__global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, long ld, int PH, int PW, float scale,
                                                            const T* __restrict__ feat, const float* __restrict__ rois,
                                                            const float* __restrict__ row_scale, float row_scale_add,
                                                            T* __restrict__ out, IT* __restrict__ argmax) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, 
   __syncthreads();
   const int nch = min(CH, C - c0);
   const int total = nch * nb;
-  const long obase = ((long)r * C + c0) * nb;
+  const long obase = (long)r * ld + (long)c0 * nb;
   if (sizeof(IT) == 4 && (total & 7) == 0 && ((obase * (long)sizeof(T)) & 15) == 0) {
     // 16-byte stores: 8 (bf16) / 4 (f32) values and 4 argmax words per lane
     constexpr int VPV = 16 / (int)sizeof(T);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(int H, int W, int C, 
 }
 
 template <typename T, typename IT>
-__global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C, int nb, int CB,
+__global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C, long ld, int nb, int CB,
                                                             const T* __restrict__ dout, const IT* __restrict__ argmax,
                                                             const float* __restrict__ rois, int R,
                                                             const float* __restrict__ row_scale, float row_scale_add,
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
         const int r = r0 + u;
         a[u] = -1; d[u] = 0.f;
         if (r < R && i < per_roi && (int)rois[(long)r * 5] == img) {
-          const long base = ((long)r * C + c0) * nb;
+          const long base = (long)r * ld + (long)c0 * nb;
           a[u] = ArgIdx<IT>::dec(argmax[base + i]);
           d[u] = Elem<T>::load(dout + base + i);
         }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
 constexpr int FX_CHUNK = 1024;          // ROIs per compaction round of the fixed-point backward
 
 template <typename T, typename IT>
-__global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int C, int nb, int CB,
+__global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int C, long ld, int nb, int CB,
                                                                const T* __restrict__ dout, const IT* __restrict__ argmax,
                                                                const float* __restrict__ rois, int R,
                                                                const float* __restrict__ row_scale, float row_scale_add,
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int r = s_r[min(l0 + u, cnt - 1)];
-          const long base = ((long)r * C + c0) * nb + (long)j * 4;
+          const long base = (long)r * ld + (long)c0 * nb + (long)j * 4;
           if (sizeof(IT) == 4) av[u] = *(const u32x4*)(argmax + base);
           else { const u32x2 t = *(const u32x2*)(argmax + base); av[u][0] = t[0]; av[u][1] = t[1]; }
           if (sizeof(T) == 2) { const u32x2 t = *(const u32x2*)(dout + base); dv[u][0] = t[0]; dv[u][1] = t[1]; }
@@ -325,7 +325,7 @@ __device__ __forceinline__ void pix_decode(const typename PixWord<CB * (int)size
 // value key(-inf) << 16 | 0xFFFF can only be beaten by values > -inf, i.e. exactly those that beat -FLT_MAX.
 // (-0.0 shares +0.0's key, as they compare equal; a bin won by a -0.0 pixel then outputs +0.0.)
 template <typename T, int CB, int NT, typename IT, bool KEY>
-__global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, int C, int PH, int PW, float scale,
+__global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, int C, long ld, int PH, int PW, float scale,
                                                                 const T* __restrict__ feat, const float* __restrict__ rois,
                                                                 int R, int chunk, const float* __restrict__ row_scale,
                                                                 float row_scale_add, T* __restrict__ out,
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
       }
     }
     const float mul = row_scale ? (row_scale[r] + row_scale_add) : 1.0f;
-    const long o = ((long)r * C + c0) * nb + b;
+    const long o = (long)r * ld + (long)c0 * nb + b;
 #pragma unroll
     for (int q = 0; q < CB; ++q) {
       Elem<T>::store(out + o + (long)q * nb, __fmul_rn(mv[q], mul));
@@ -458,7 +458,7 @@ __global__ void absmax_kernel(long n, const T* __restrict__ x, float* __restrict
 
 namespace {
 template <typename T, int CB, typename IT>
-int launch_fwd_plane(int nimg, int H, int W, int C, int PH, int PW, float scale, const void* feat, const float* rois, int R,
+int launch_fwd_plane(int nimg, int H, int W, int C, long ld, int PH, int PW, float scale, const void* feat, const float* rois, int R,
                      const float* row_scale, float row_scale_add, void* out, void* argmax, hipStream_t stream) {
   constexpr int NT = 1024, CHUNK = 256;
   const size_t lds = (((size_t)H * W * CB * sizeof(T) + 15) & ~(size_t)15) + CHUNK * sizeof(int);
@@ -469,14 +469,14 @@ int launch_fwd_plane(int nimg, int H, int W, int C, int PH, int PW, float scale,
     if (e != hipSuccess) return (int)e;
   }
   dim3 grid(C / CB, nimg, (R + CHUNK - 1) / CHUNK), block(NT);
-  hipLaunchKernelGGL(kern, grid, block, lds, stream, H, W, C, PH, PW, scale, (const T*)feat, rois, R, CHUNK, row_scale,
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, H, W, C, ld, PH, PW, scale, (const T*)feat, rois, R, CHUNK, row_scale,
                      row_scale_add, (T*)out, (IT*)argmax);
   SW_CHECK_LAUNCH();
   return 0;
 }
 
 template <typename IT>
-int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale, const void* feat,
+int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, long ld, int PH, int PW, float spatial_scale, const void* feat,
                      const float* rois, int R, const float* row_scale, float row_scale_add, void* out, void* argmax,
                      hipStream_t stream) {
   // feature-stationary form: the widest channel slab (16 / 8 / 4 bytes per pixel) whose H*W plane fits LDS, two
@@ -490,7 +490,7 @@ int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, int PH, int PW, f
     for (int cand = 16; cand >= 4 && !pxb; cand >>= 1)
       if ((C % (cand / (int)es)) == 0 && (size_t)H * W * cand <= 150 * 1024) pxb = cand;
     if (pxb) {
-#define SW_FWD_PLANE(T, CB) return launch_fwd_plane<T, CB, IT>(nimg, H, W, C, PH, PW, spatial_scale, feat, rois, R, row_scale, \
+#define SW_FWD_PLANE(T, CB) return launch_fwd_plane<T, CB, IT>(nimg, H, W, C, ld, PH, PW, spatial_scale, feat, rois, R, row_scale, \
                                                                row_scale_add, out, argmax, stream)
       if (dtype == SW_BF16) {
         if (pxb == 16) SW_FWD_PLANE(unsigned short, 8);
@@ -511,30 +511,31 @@ int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, int PH, int PW, f
   if (lds > 64 * 1024) return -6;
   dim3 grid(R, (C + ch - 1) / ch), block(256);
   if (dtype == SW_BF16)
-    hipLaunchKernelGGL((roi_pool_fwd_kernel<unsigned short, 2, IT>), grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
+    hipLaunchKernelGGL((roi_pool_fwd_kernel<unsigned short, 2, IT>), grid, block, lds, stream, H, W, C, ld, PH, PW, spatial_scale,
                        (const unsigned short*)feat, rois, row_scale, row_scale_add, (unsigned short*)out, (IT*)argmax);
   else
-    hipLaunchKernelGGL((roi_pool_fwd_kernel<float, 1, IT>), grid, block, lds, stream, H, W, C, PH, PW, spatial_scale,
+    hipLaunchKernelGGL((roi_pool_fwd_kernel<float, 1, IT>), grid, block, lds, stream, H, W, C, ld, PH, PW, spatial_scale,
                        (const float*)feat, rois, row_scale, row_scale_add, (float*)out, (IT*)argmax);
   SW_CHECK_LAUNCH();
   return 0;
 }
 
 template <typename T, typename IT>
-int roi_bwd_dispatch(int nimg, int H, int W, int C, int PH, int PW, const void* dout, const void* argmax, const float* rois,
+int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, const void* dout, const void* argmax, const float* rois,
                      int R, const float* row_scale, float row_scale_add, const void* relu_ref, const float* dout_absmax,
                      void* dfeat, hipStream_t stream) {
   // fixed-point path: CB in {8, 4} with H*W*CB*8 bytes of LDS; needs max|dout| (device scalar)
   static const bool float_atomics = getenv("SW_ROI_FLOAT_ATOMICS") != nullptr;    // development switch
   int cbx = 8;
   while (cbx >= 4 && ((size_t)H * W * cbx * 8 > 128 * 1024 || (C % cbx))) cbx >>= 1;
-  if (cbx >= 4 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) && !float_atomics) {
+  if (cbx >= 4 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) && (ld % 4) == 0 &&
+      !float_atomics) {
     const size_t ldsx = (size_t)H * W * cbx * 8 + FX_CHUNK * 8;
     dim3 gridx(C / cbx, nimg), blockx(1024);
     auto k = roi_pool_bwd_fx_kernel<T, IT>;
     hipError_t ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
     if (ex != hipSuccess) return (int)ex;
-    hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, PH * PW, cbx, (const T*)dout, (const IT*)argmax, rois, R,
+    hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, ld, PH * PW, cbx, (const T*)dout, (const IT*)argmax, rois, R,
                        row_scale, row_scale_add, dout_absmax, (const T*)relu_ref, (T*)dfeat);
     SW_CHECK_LAUNCH();
     return 0;
@@ -549,7 +550,7 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, int PH, int PW, const void* 
   auto k = roi_pool_bwd_kernel<T, IT>;
   hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k, grid, block, lds, stream, H, W, C, PH * PW, CB, (const T*)dout, (const IT*)argmax, rois, R, row_scale,
+  hipLaunchKernelGGL(k, grid, block, lds, stream, H, W, C, ld, PH * PW, CB, (const T*)dout, (const IT*)argmax, rois, R, row_scale,
                      row_scale_add, (const T*)relu_ref, (T*)dfeat);
   SW_CHECK_LAUNCH();
   return 0;
@@ -558,27 +559,32 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, int PH, int PW, const void* 
 
 extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale,
                                const void* feat, const float* rois, int R, const float* row_scale,
-                               float row_scale_add, void* out, void* argmax, int argmax_bits, hipStream_t stream) {
+                               float row_scale_add, void* out, void* argmax, int argmax_bits, long ld_out,
+                               hipStream_t stream) {
   SW_ENTER();
   if (R <= 0) return 0;
+  const long ld = ld_out > 0 ? ld_out : (long)C * PH * PW;
+  if (ld < (long)C * PH * PW) return -5;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
   if (argmax_bits == 32)
-    return roi_fwd_dispatch<int>(dtype, nimg, H, W, C, PH, PW, spatial_scale, feat, rois, R, row_scale, row_scale_add, out,
+    return roi_fwd_dispatch<int>(dtype, nimg, H, W, C, ld, PH, PW, spatial_scale, feat, rois, R, row_scale, row_scale_add, out,
                                  argmax, stream);
   if (argmax_bits != 16) return -1;
   if ((long)H * W >= 65535) return -6;
-  return roi_fwd_dispatch<unsigned short>(dtype, nimg, H, W, C, PH, PW, spatial_scale, feat, rois, R, row_scale,
+  return roi_fwd_dispatch<unsigned short>(dtype, nimg, H, W, C, ld, PH, PW, spatial_scale, feat, rois, R, row_scale,
                                           row_scale_add, out, argmax, stream);
 }
 
 extern "C" int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
-                               const void* argmax, int argmax_bits, const float* rois, int R, const float* row_scale,
-                               float row_scale_add, const void* relu_ref, const float* dout_absmax, void* dfeat,
-                               hipStream_t stream) {
+                               const void* argmax, int argmax_bits, long ld_in, const float* rois, int R,
+                               const float* row_scale, float row_scale_add, const void* relu_ref,
+                               const float* dout_absmax, void* dfeat, hipStream_t stream) {
   SW_ENTER();
+  const long ld = ld_in > 0 ? ld_in : (long)C * PH * PW;
+  if (ld < (long)C * PH * PW) return -5;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
   if (argmax_bits != 32 && argmax_bits != 16) return -1;
-#define SW_BWD(T, IT) return roi_bwd_dispatch<T, IT>(nimg, H, W, C, PH, PW, dout, argmax, rois, R, row_scale, row_scale_add, \
+#define SW_BWD(T, IT) return roi_bwd_dispatch<T, IT>(nimg, H, W, C, ld, PH, PW, dout, argmax, rois, R, row_scale, row_scale_add, \
                                                      relu_ref, dout_absmax, dfeat, stream)
   if (dtype == SW_BF16) { if (argmax_bits == 32) SW_BWD(unsigned short, int); SW_BWD(unsigned short, unsigned short); }
   if (argmax_bits == 32) SW_BWD(float, int);

@@ -174,8 +174,15 @@ def roi_pool_fwd(feat, rois, out, argmax, spatial_scale, PH, PW, row_scale=None,
     n, H, W, C = feat.shape
     R = rois.shape[0]
     check(lib.sw_roi_pool_fwd(dt(feat), n, H, W, C, PH, PW, float(spatial_scale), _p(feat), _p(rois), R, _p(row_scale),
-                              float(row_scale_add), _p(out), _p(argmax), _argmax_bits(argmax), _stream()), "sw_roi_pool_fwd")
+                              float(row_scale_add), _p(out), _p(argmax), _argmax_bits(argmax), _roi_pitch(out, argmax),
+                              _stream()), "sw_roi_pool_fwd")
     return out, argmax
+
+
+def _roi_pitch(vals, argmax):
+    if vals.stride(0) != argmax.stride(0) or vals.stride(-1) != 1 or argmax.stride(-1) != 1:
+        raise ValueError("ROIPool values and argmax must share one row pitch (unit inner stride)")
+    return vals.stride(0)
 
 
 def _argmax_bits(argmax):
@@ -214,7 +221,8 @@ def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_ad
     R = rois.shape[0]
     if isinstance(dout_absmax, str):
         dout_absmax = absmax(dout)
-    check(lib.sw_roi_pool_bwd(dt(dfeat), n, H, W, C, PH, PW, _p(dout), _p(argmax), _argmax_bits(argmax), _p(rois), R, _p(row_scale),
+    check(lib.sw_roi_pool_bwd(dt(dfeat), n, H, W, C, PH, PW, _p(dout), _p(argmax), _argmax_bits(argmax), _roi_pitch(dout, argmax),
+                              _p(rois), R, _p(row_scale),
                               float(row_scale_add), _p(relu_ref), _p(dout_absmax), _p(dfeat), _stream()), "sw_roi_pool_bwd")
     return dfeat
 

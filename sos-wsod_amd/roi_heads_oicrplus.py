@@ -277,8 +277,10 @@ class OICRPlusHeads(nn.Module):
         P = self.box_pooler.output_size
         D0 = C * P * P
         # --- ROIPool (+ objectness prior fused) straight into the stacked fc6 operand
-        pooled = torch.empty(V * R, D0, device=dev, dtype=dt_)
-        argmax = torch.empty(V * R, D0, device=dev, dtype=ops.roi_argmax_dtype(max(f.shape[1] for f in feats), max(f.shape[2] for f in feats)))
+        # row pitch D0 + 64: with the natural 49 KiB pitch the rows of an fc6 operand tile start on 4 of the 16 L2 channels
+        pooled = _padded(V * R, D0, dev, dt_, pad=64)
+        argmax = _padded(V * R, D0, dev, ops.roi_argmax_dtype(max(f.shape[1] for f in feats), max(f.shape[2] for f in feats)),
+                         pad=64)
         rois = inp["rois"]                        # [2] x (2R, 5): batch index 0 = view, 1 = flipped view
         for s in range(2):
             ops.roi_pool_fwd(feats[s], rois[s], pooled[2 * s * R:(2 * s + 2) * R], argmax[2 * s * R:(2 * s + 2) * R],
@@ -395,7 +397,7 @@ class OICRPlusHeads(nn.Module):
         ops.gemm(dz1, pooled, dW1, D1, D0, M, a_kstrided=True, b_kstrided=True, tag="fc6_wgrad")
         dfeats = [None, None]
         if feat_req[0] or feat_req[1]:
-            dpooled = torch.empty(M, D0, device=dev, dtype=dt_)
+            dpooled = _padded(M, D0, dev, dt_, pad=64)          # same pitch as argmax (one pitch per ROIPool call)
             amax = torch.zeros(1, device=dev, dtype=torch.float32)      # max|dpooled| -> fixed-point scale of the ROI scatter
             if st["W1T"] is not None:       # NT: B = W1^T (D0 x D1), K-contiguous
                 ops.gemm(dz1, st["W1T"], dpooled, M, D0, D1, ep=ops.make_epilogue(out_dtype=dt_, absmax_out=amax),

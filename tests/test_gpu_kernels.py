@@ -148,18 +148,23 @@ def test_roi_pool_bit_exact_and_backward(ops, dtype, adt):
     ref_out, ref_arg = O.roi_pool_fwd(feat.numpy(), rois, 1.0 / 8)
     ref_scaled = torch.from_numpy(ref_out) * (torch.from_numpy(obj) + 1).view(-1, 1, 1, 1)
     f = _nhwc(feat).to(dtype).cuda()
-    out = torch.empty(R, C * 49, device="cuda", dtype=dtype)
-    arg = torch.empty(R, C * 49, device="cuda", dtype=adt)
+    pad = 8 if adt == torch.int16 else 0                          # padded row pitch (shared by values and argmax)
+    out = torch.full((R, C * 49 + pad), 7.0, device="cuda", dtype=dtype)[:, :C * 49]
+    arg = torch.empty(R, C * 49 + pad, device="cuda", dtype=adt)[:, :C * 49]
     ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7, row_scale=torch.from_numpy(obj).cuda(),
                      row_scale_add=1.0)
-    assert np.array_equal(ops.argmax_to_int32(arg).cpu().numpy().reshape(ref_arg.shape), ref_arg)   # bit exact bins/argmax
-    assert torch.equal(out.cpu().float().view(ref_scaled.shape), ref_scaled.to(dtype).float())   # values copied
+    assert np.array_equal(ops.argmax_to_int32(arg.contiguous()).cpu().numpy().reshape(ref_arg.shape), ref_arg)   # bit exact bins/argmax
+    assert torch.equal(out.cpu().float().reshape(ref_scaled.shape), ref_scaled.to(dtype).float())   # values copied
+    if pad:
+        assert torch.all(out.as_strided((R, pad), (C * 49 + pad, 1), C * 49) == 7.0)       # the pitch gap is not written
     g = _rand((R, C, 7, 7), 31, dtype).float()
     ref_g = O.roi_pool_bwd((g * (torch.from_numpy(obj) + 1).view(-1, 1, 1, 1)).numpy(), ref_arg, rois, feat.shape)
     ref_g = _nhwc(torch.from_numpy(ref_g)) * (_nhwc(feat) > 0)
     for amax in ("auto", None):                                   # fixed-point and float-atomic accumulation
         dfeat = torch.empty(n, H, W, C, device="cuda", dtype=dtype)
-        ops.roi_pool_bwd(g.to(dtype).view(R, -1).cuda(), arg, torch.from_numpy(rois).cuda(), dfeat, 7, 7,
+        gg = torch.zeros(R, C * 49 + pad, device="cuda", dtype=dtype)[:, :C * 49]
+        gg.copy_(g.to(dtype).view(R, -1))
+        ops.roi_pool_bwd(gg, arg, torch.from_numpy(rois).cuda(), dfeat, 7, 7,
                          row_scale=torch.from_numpy(obj).cuda(), row_scale_add=1.0, relu_ref=f, dout_absmax=amax)
         tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
         assert (dfeat.cpu().float() - ref_g).abs().max() <= tol * ref_g.abs().max()
