@@ -211,11 +211,16 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[32];
   __shared__ int s_cnt;
+  // large maps: the workgroup owns only the pixel range [p0, p1) of the plane (blockIdx.z); gradients whose argmax falls
+  // outside are skipped (the other ranges' workgroups stream the same ROI data again)
+  const int npix_all = H * W;
+  const int px_per = (npix_all + gridDim.z - 1) / gridDim.z;
+  const int p0 = blockIdx.z * px_per, p1 = min(npix_all, p0 + px_per);
   unsigned long long* acc = (unsigned long long*)smem;          // [CB][H*W] two's-complement fixed point: the lanes of a wave
                                                                 // hold bins of ONE channel => neighbouring pixels => distinct banks
                                                                 // (pixel-major [H*W][CB] put them 64 B apart: 8-16-way conflicts)
   const int img = blockIdx.y, c0 = blockIdx.x * CB;
-  const int npix = H * W;
+  const int npix = max(p1 - p0, 0);
   for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) acc[i] = 0ull;
   float smax = 0.f;                                             // max |row_scale + add| (wave/block reduce, tiny)
   if (row_scale) { for (int r = threadIdx.x; r < R; r += blockDim.x) smax = fmaxf(smax, fabsf(row_scale[r] + row_scale_add)); }
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   // does not depend on it.
   const int nvec = (CB * nb) / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-  int* s_r = (int*)(smem + (size_t)npix * CB * 8);
+  int* s_r = (int*)(smem + (size_t)px_per * CB * 8);
   float* s_m = (float*)(s_r + FX_CHUNK);
   for (int rc = 0; rc < R; rc += FX_CHUNK) {
     __syncthreads();                            // previous chunk's list fully consumed (and acc zeroed, first time)
@@ -271,9 +276,9 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
             if (sizeof(T) == 2) d = __uint_as_float((e & 1) ? (dv[u][e >> 1] & 0xFFFF0000u) : (dv[u][e >> 1] << 16));
             else d = __uint_as_float(dv[u][e]);
             const int cc = (j * 4 + e) / nb;
-            if (a >= 0) {
+            if (a >= p0 && a < p1) {
               const long long q = __float2ll_rn(scalbnf(__fmul_rn(d, mul), frac));
-              atomicAdd(&acc[cc * npix + a], (unsigned long long)q);
+              atomicAdd(&acc[cc * npix + (a - p0)], (unsigned long long)q);
             }
           }
         }
@@ -281,8 +286,8 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
     }
   }
   __syncthreads();
-  T* dimg = dfeat + (long)img * npix * C;
-  const T* rimg = relu_ref ? relu_ref + (long)img * npix * C : nullptr;
+  T* dimg = dfeat + ((long)img * npix_all + p0) * C;
+  const T* rimg = relu_ref ? relu_ref + ((long)img * npix_all + p0) * C : nullptr;
   for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) {
     const int p = i / CB, cc = i - p * CB;
     float v = scalbnf((float)(long long)acc[cc * npix + p], -frac);
@@ -527,11 +532,14 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, con
   // fixed-point path: CB in {8, 4} with H*W*CB*8 bytes of LDS; needs max|dout| (device scalar)
   static const bool float_atomics = getenv("SW_ROI_FLOAT_ATOMICS") != nullptr;    // development switch
   int cbx = 8;
-  while (cbx >= 4 && ((size_t)H * W * cbx * 8 > 128 * 1024 || (C % cbx))) cbx >>= 1;
-  if (cbx >= 4 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) && (ld % 4) == 0 &&
+  while (cbx > 4 && ((size_t)H * W * cbx * 8 > 128 * 1024 || (C % cbx))) cbx >>= 1;
+  if (C % cbx) cbx = 0;
+  const int nsplit = cbx ? (int)(((size_t)H * W * cbx * 8 + 128 * 1024 - 1) / (128 * 1024)) : 1;   // pixel ranges per plane
+  if (cbx >= 4 && nsplit <= 16 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) && (ld % 4) == 0 &&
       !float_atomics) {
-    const size_t ldsx = (size_t)H * W * cbx * 8 + FX_CHUNK * 8;
-    dim3 gridx(C / cbx, nimg), blockx(1024);
+    const int px_per = (H * W + nsplit - 1) / nsplit;
+    const size_t ldsx = (size_t)px_per * cbx * 8 + FX_CHUNK * 8;
+    dim3 gridx(C / cbx, nimg, nsplit), blockx(1024);
     auto k = roi_pool_bwd_fx_kernel<T, IT>;
     hipError_t ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
     if (ex != hipSuccess) return (int)ex;

@@ -341,3 +341,24 @@ def test_full_size_contractions_match_torch_matmul():
     wr = w.to(dt).float().requires_grad_(True)
     torch.nn.functional.conv2d(xr, wr, None, padding=2, dilation=2).backward(dy.permute(0, 3, 1, 2).float())
     assert close(dw, wr.grad)
+
+
+def test_voc_sized_nonsquare_views_run(monkeypatch):
+    """a VOC-scale multi-scale pair is not square and not 512: 608x912 views (76x114 maps: the ROIPool plane no longer fits
+    two workgroups per CU, the backward's fixed-point slab does not fit at all -> the other code paths) must train too"""
+    import bench
+    from sos_wsod_amd.events import EventStorage
+    monkeypatch.setattr(bench, "H", 608); monkeypatch.setattr(bench, "W", 912); monkeypatch.setattr(bench, "R", 1500)
+    dev = torch.device("cuda", 0)
+    model = bench.build(dev, torch.bfloat16); model.train()
+    data = bench.make_inputs(dev, 11)
+    with EventStorage(0):
+        losses = model(data)
+        losses.total().backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(losses.vector).all()
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    g3 = model.backbone.blocks[2].convs()[0].weight.grad
+    assert g3.abs().max() > 0                                      # the gradient reached the first trainable conv

@@ -216,6 +216,26 @@ def test_roi_pool_large_map_uses_gather_form(ops):
                          1.0 / 8, 7, 7)
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_roi_pool_backward_on_a_map_larger_than_lds(ops, dtype):
+    """130x130 map: the fixed-point backward owns the plane in 5 pixel ranges (one workgroup each per channel slab)"""
+    n, C, H, W, R = 2, 8, 130, 130, 96
+    feat = _rand((n, C, H, W), 34, dtype).float()
+    views, _ = O.make_views(H * 8, W * 8, R, tag="bigbwd")
+    rois = np.concatenate([(np.arange(R) % n)[:, None].astype(np.float32), views[0]["boxes"]], 1).astype(np.float32)
+    ref_out, ref_arg = O.roi_pool_fwd(feat.numpy(), rois, 1.0 / 8)
+    f = _nhwc(feat).to(dtype).cuda()
+    out = torch.empty(R, C * 49, device="cuda", dtype=dtype); arg = torch.empty(R, C * 49, device="cuda", dtype=torch.int16)
+    ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7)
+    assert np.array_equal(ops.argmax_to_int32(arg).cpu().numpy().reshape(ref_arg.shape), ref_arg)
+    g = _rand((R, C, 7, 7), 35, dtype).float()
+    ref_g = _nhwc(torch.from_numpy(O.roi_pool_bwd(g.numpy(), ref_arg, rois, feat.shape)))
+    dfeat = torch.empty(n, H, W, C, device="cuda", dtype=dtype)
+    ops.roi_pool_bwd(g.to(dtype).view(R, -1).cuda(), arg, torch.from_numpy(rois).cuda(), dfeat, 7, 7)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert (dfeat.cpu().float() - ref_g).abs().max() <= tol * ref_g.abs().max()
+
+
 # ------------------------------------------------------------------------------------------ heads
 @pytest.mark.parametrize("R,K", [(37, 20), (2000, 20), (700, 80)])
 def test_wsddn_mil_loss_and_grad(ops, R, K):
