@@ -1,0 +1,259 @@
+// Direct 3x3 convolution (stride 1, pad = dilation, NHWC, bf16) for gfx950: forward and data gradient of conv3..conv5.
+//
+// Why a second conv kernel.  The implicit GEMM (gemm.hip) re-fetches every input pixel once per tap: a 128x128 output tile
+// streams 128 x 9*Cin input elements + 128 x 9*Cin weights through the CU.  With 63x63 / 64x64 maps a launch has only
+// ~250 tiles, so tiles cannot grow, and the measured limit is the XCD's L2: conv5_3 issues 4.7 M 128-byte L2 reads per
+// launch (600 MB in 54 us = 11 TB/s, TCC busy 73 %, profiles/) while the MFMA pipe idles at 28 %.
+// Here a workgroup owns an 8 x 32 pixel patch of ONE image x 64 output channels and walks the input channels in chunks of
+// 32: the (8+2d) x (32+2d) input patch of a chunk is staged ONCE and serves all 9 taps as shifted row windows of the same
+// LDS image; the weights of a chunk are staged one tap row (3 taps) at a time.  Per 256 x 64 outputs the CU now pulls
+// 432 x Cin + 64 x 9 Cin elements instead of 2 x 128 x 9 Cin + ... : 2.3x fewer L2 bytes, and the grid is still 256
+// workgroups for a 64 x 64 x 512 layer.
+//
+// Structure: 4 waves, wave w = tile rows 2w, 2w+1 (64 pixels) x 64 channels = 4 x 4 MFMA tiles (v_mfma_f32_16x16x32_bf16,
+// one MFMA consumes the whole 32-channel chunk of a tap).  LDS: input patch double buffered per chunk, weights double
+// buffered per (chunk, tap row); both staged with LDS-DMA buffer loads whose per-lane offsets are fixed for the whole
+// kernel (image border / ragged edge = offset beyond num_records -> zero fill), the chunk / tap row advance is the
+// wave-uniform SGPR offset.  One barrier per 3 taps (48 MFMAs per wave).  79.9 KiB LDS -> two workgroups per CU.
+// vmcnt accounting (DEPTH >= 3): per wave the issue order is  prologue: patch(0), weights(0..DEPTH-2);  step t: weights
+// (t+DEPTH-1), then patch(chunk+1) if t opens a chunk — every wave issues the same counts (3 per tap row, APW per patch).
+// Loads complete in order, so the data of step s is complete once at most the instructions issued after weights(s) remain:
+// 3 per step in between, + APW for every chunk-opening step among them, + APW if the step that issued weights(s) opened a
+// chunk and that patch belongs to a LATER chunk than s (true for DEPTH 3, false for DEPTH 4 at tap row 0).
+// 64-byte LDS rows (one pixel or one output channel x 32 input channels) are XOR-swizzled by (row >> 2) & 3 so that the 16
+// consecutive rows of a fragment, at any tap shift, hit 64 distinct banks.
+#include <stdlib.h>
+#include "common.h"
+#include "soswsod_hip.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32, TN = 64, CK = 32;          // pixel tile, output channels, input channels per chunk
+constexpr unsigned INVALID = 0xFFFFFF00u;
+
+struct DirectArgs {
+  const void* in; const void* wk; void* out;
+  const float* bias; const void* ref;
+  int nimg, H, W, Cin, Cout, relu;
+  int tiles_x, tiles_y, n_px_tiles, n_co_blocks, total;
+  unsigned in_bytes, wk_bytes;
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// DEPTH = weight tap-row buffers (prefetch distance DEPTH-1 steps).  2: 80 KiB LDS, two workgroups per CU (layers with >= 2
+// workgroups per CU); 4: 104 KiB, for the 63x63 / 64x64 layers whose 256 workgroups leave one per CU — there a step (48
+// MFMAs ~ 800 cycles) is shorter than a loaded L2 round trip and distance 1 made every step wait for its weights.
+template <int DIL, int DEPTH>
+__global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel(DirectArgs g) {
+  constexpr int PH = TH + 2 * DIL, PW = TW + 2 * DIL, P = PH * PW;
+  constexpr int A_INSTR = (P * 4 + 63) / 64;               // 1 KiB LDS-DMA instructions per input patch
+  constexpr int A_PER_WAVE = (A_INSTR + 3) / 4;             // every wave issues this many (uniform vmcnt accounting);
+  constexpr int A_BYTES = A_PER_WAVE * 4 * 1024;            //   the surplus ones zero-fill the padding of the image
+  constexpr int B_BYTES = 3 * TN * 64;                      // one tap row: 3 taps x 64 channels x 64 B
+  typedef __attribute__((address_space(3))) void* lvoid;
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // A[2] | B[2]
+  char* const sA = smem;
+  char* const sB = smem + 2 * A_BYTES;                     // [DEPTH] tap-row buffers
+
+  // workgroup -> (pixel tile, channel block): XCD x (= blockIdx & 7) takes a contiguous run of the work list in which the
+  // channel block runs fastest, so the 8 channel blocks of a pixel tile share its input patch in that XCD's L2
+  const int per_xcd = (g.total + 7) >> 3;
+  const int f = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || f >= g.total) return;
+  const int px_tile = f / g.n_co_blocks, co_blk = f - px_tile * g.n_co_blocks;
+  const int img = px_tile / (g.tiles_x * g.tiles_y);
+  const int trem = px_tile - img * (g.tiles_x * g.tiles_y);
+  const int ty0 = (trem / g.tiles_x) * TH, tx0 = (trem % g.tiles_x) * TW;
+  const int co0 = co_blk * TN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.in, 0, (int)g.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.wk, 0, (int)g.wk_bytes, 0x00020000);
+
+  // ---- fixed per-lane DMA offsets
+  unsigned a_v[A_PER_WAVE];
+#pragma unroll
+  for (int s = 0; s < A_PER_WAVE; ++s) {
+    const int q = wave + 4 * s;                             // instruction index inside the patch image
+    const int idx = q * 64 + lane;
+    const int prow = idx >> 2, p = idx & 3;
+    const int src = p ^ ((prow >> 2) & 3);                  // LDS position p of row prow holds source chunk src
+    const int py = prow / PW, px = prow - py * PW;
+    const int y = ty0 - DIL + py, x = tx0 - DIL + px;
+    const bool ok = prow < P && y >= 0 && y < g.H && x >= 0 && x < g.W;
+    a_v[s] = ok ? (unsigned)(((((long)img * g.H + y) * g.W + x) * g.Cin + src * 8) * 2) : INVALID;
+  }
+  unsigned b_v[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int idx = (wave + 4 * s) * 64 + lane;             // [0, 768): row r = tap_x * 64 + co, position p
+    const int r = idx >> 2, p = idx & 3;
+    const int tap_x = r >> 6, co = r & 63;
+    const int src = p ^ ((co >> 2) & 3);
+    const bool ok = co0 + co < g.Cout;
+    b_v[s] = ok ? (unsigned)((((long)(co0 + co) * 9 + tap_x) * g.Cin + src * 8) * 2) : INVALID;
+  }
+  auto issue_a = [&](int chunk) {
+    char* dst = sA + (chunk & 1) * A_BYTES;
+    const unsigned soff = (unsigned)chunk * (CK * 2);
+#pragma unroll
+    for (int s = 0; s < A_PER_WAVE; ++s)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lvoid)(dst + (wave + 4 * s) * 1024), 16, (int)a_v[s], (int)soff, 0, 0);
+  };
+  auto issue_b = [&](int step) {                            // step = chunk * 3 + tap row
+    const int chunk = step / 3, ty = step - chunk * 3;
+    char* dst = sB + (step % DEPTH) * B_BYTES;
+    const unsigned soff = (unsigned)((ty * 3 * g.Cin + chunk * CK) * 2);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lvoid)(dst + (wave + 4 * s) * 1024), 16, (int)b_v[s], (int)soff, 0, 0);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = g.Cin / CK, nstep = nchunk * 3;
+  const int l15 = lane & 15, kq = lane >> 4;                // fragment row, 16-byte K position
+  // B fragment byte offsets inside a tap (fixed): channel j*16 + l15
+  int b_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int co = j * 16 + l15;
+    b_off[j] = co * 64 + ((kq ^ ((co >> 2) & 3)) << 4);
+  }
+  // Issue order inside a step: weights of step + DEPTH - 1, then (first tap row of a chunk) the next chunk's patch.  Loads
+  // complete in order, so "weights of this step landed" = at most the instructions issued after them still outstanding:
+  //   sum over the DEPTH-2 steps in between of (3 + patch if that step opened a chunk) + patch if the issuing step did.
+  issue_a(0);
+#pragma unroll
+  for (int s0 = 0; s0 < DEPTH - 1; ++s0)
+    if (s0 < nstep) issue_b(s0);
+  auto compute_step = [&](int step, int chunk, int ty) {
+    const char* A = sA + (chunk & 1) * A_BYTES;
+    const char* B = sB + (step % DEPTH) * B_BYTES;
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      u32x4 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int prow = (2 * wave + (i >> 1) + ty * DIL) * PW + (i & 1) * 16 + tx * DIL + l15;
+        fa[i] = *(const u32x4*)(A + prow * 64 + ((kq ^ ((prow >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(B + tx * (TN * 64) + b_off[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+  };
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const int step = chunk * 3 + ty;
+      // outstanding instructions allowed while the data of `step` is complete (steady state; derivation in the header):
+      //   DEPTH 3: {3, 3+APW, 3+APW}     DEPTH 4: {6, 6+APW, 6+APW}     (tap row 0 of DEPTH 4 needs the patch issued in the
+      //   same step as its weights, so that patch may NOT stay outstanding)
+      constexpr int APW = A_PER_WAVE;
+      if (DEPTH == 2 || step + DEPTH - 1 >= nstep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: fewer loads issued
+      else if (ty == 0) wait_vm<3 * (DEPTH - 2)>();
+      else wait_vm<3 * (DEPTH - 2) + APW>();
+      __builtin_amdgcn_s_barrier();
+      if (step + DEPTH - 1 < nstep) issue_b(step + DEPTH - 1);
+      if (ty == 0 && chunk + 1 < nchunk) issue_a(chunk + 1);
+      compute_step(step, chunk, ty);
+    }
+  }
+  __syncthreads();                                          // every wave is done with the staging buffers
+
+  // ---- epilogue: bias / ReLU in registers, bf16 tile through LDS, 16-byte stores with the ReLU-backward mask
+  unsigned short* S = (unsigned short*)(smem + wave * (64 * 64 * 2));        // [64 pixels][64 channels]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = j * 16 + l15;
+    const float bv = (g.bias && co0 + col < g.Cout) ? g.bias[co0 + col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[i][j][e] + bv;
+        if (g.relu) v = fmaxf(v, 0.f);
+        const int pl = i * 16 + kq * 4 + e;                 // C/D map: row = (lane>>4)*4 + e, col = lane&15
+        S[pl * 64 + (col ^ ((pl & 7) << 3))] = f32_to_bf16_bits(v);      // 16-byte groups XOR-swizzled by the row
+      }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): own LDS writes visible to own reads (same wave)
+  unsigned short* out = (unsigned short*)g.out;
+  const unsigned short* ref = (const unsigned short*)g.ref;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = it * 64 + lane;
+    const int pl = idx >> 3, ch = idx & 7;                  // pixel of this wave's 64, 16-byte channel group
+    const int y = ty0 + 2 * wave + (pl >> 5), x = tx0 + (pl & 31);
+    const int co = co0 + ch * 8;
+    if (y < g.H && x < g.W && co < g.Cout) {
+      u32x4 v = *(const u32x4*)(S + pl * 64 + ((ch ^ (pl & 7)) << 3));
+      const long o = (((long)img * g.H + y) * g.W + x) * g.Cout + co;
+      if (ref) {
+        const u32x4 r = *(const u32x4*)(ref + o);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool lo = __uint_as_float(r[t] << 16) > 0.f, hi = __uint_as_float(r[t] & 0xFFFF0000u) > 0.f;
+          v[t] = (lo ? (v[t] & 0xFFFFu) : 0u) | (hi ? (v[t] & 0xFFFF0000u) : 0u);
+        }
+      }
+      *(u32x4*)(out + o) = v;
+    }
+  }
+}
+
+}  // namespace
+
+// Returns 1 if the direct kernel took the launch, 0 if the shape is not covered (caller falls back), < 0 on error.
+int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in, const void* wk, void* out,
+                          const sw_epilogue* ep, hipStream_t stream) {
+  static const char* sw = getenv("SW_CONV_DIRECT");          // development switch: "0" off, "1" every covered shape
+  if (sw && sw[0] == '0') return 0;
+  if ((Cin % CK) || (Cout % 8) || (dilation != 1 && dilation != 2)) return 0;
+  if (ep && (ep->out_dtype != SW_BF16 || ep->drop_mask || ep->accumulate_atomic || ep->absmax_out)) return 0;
+  if (!ep) return 0;
+  if (ep->relu_ref && (ep->ref_dtype != SW_BF16 || ep->ld_ref != Cout || ep->ref_scale != 1.0f)) return 0;
+  if ((((uintptr_t)in | (uintptr_t)wk | (uintptr_t)out | (uintptr_t)ep->relu_ref) & 15)) return 0;
+  if (!(sw && sw[0] == '1') && Cin < 128) return 0;          // conv1/conv2 inputs: few channels, huge maps -> implicit GEMM
+  DirectArgs g = {};
+  g.in = in; g.wk = wk; g.out = out; g.bias = ep->bias; g.ref = ep->relu_ref; g.relu = ep->relu;
+  g.nimg = nimg; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+  g.tiles_x = (W + TW - 1) / TW; g.tiles_y = (H + TH - 1) / TH;
+  g.n_px_tiles = g.tiles_x * g.tiles_y * nimg; g.n_co_blocks = (Cout + TN - 1) / TN;
+  g.total = g.n_px_tiles * g.n_co_blocks;
+  const long ib = (long)nimg * H * W * Cin * 2, wb = (long)Cout * 9 * Cin * 2;
+  if (ib >= 0xFFFFFF00L || wb >= 0xFFFFFF00L) return 0;
+  g.in_bytes = (unsigned)ib; g.wk_bytes = (unsigned)wb;
+  const int per_xcd = (g.total + 7) / 8;
+  const int d = dilation;
+  const int P = (TH + 2 * d) * (TW + 2 * d);
+  const int apw = ((P * 4 + 63) / 64 + 3) / 4;
+  static const char* dsw = getenv("SW_CONV_DIRECT_DEPTH");      // development switch
+  const int depth = dsw ? atoi(dsw) : (g.total <= 384 ? 4 : 2);  // one workgroup per CU anyway -> deep weight ring
+  const size_t lds = (size_t)2 * apw * 4096 + (size_t)depth * (3 * TN * 64);
+  hipError_t e = hipSuccess;
+#define SW_LAUNCH_DIRECT(D, DEP)                                                                                          \
+  do {                                                                                                                     \
+    e = hipFuncSetAttribute((const void*)conv3x3_direct_kernel<D, DEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return -(int)e;                                                                                   \
+    hipLaunchKernelGGL((conv3x3_direct_kernel<D, DEP>), dim3(per_xcd * 8), dim3(256), lds, stream, g);                    \
+  } while (0)
+  if (d == 1) { if (depth == 2) SW_LAUNCH_DIRECT(1, 2); else if (depth == 3) SW_LAUNCH_DIRECT(1, 3); else SW_LAUNCH_DIRECT(1, 4); }
+  else { if (depth == 2) SW_LAUNCH_DIRECT(2, 2); else if (depth == 3) SW_LAUNCH_DIRECT(2, 3); else SW_LAUNCH_DIRECT(2, 4); }
+#undef SW_LAUNCH_DIRECT
+  e = hipGetLastError();
+  if (e != hipSuccess) return -(int)e;
+  return 1;
+}

@@ -626,6 +626,10 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
                           : dispatch_modes<float>(g, am, bmo, splitk, stream);
 }
 
+// conv_direct.hip: halo-reusing direct kernel for the bf16 conv3..conv5 shapes (1 = launched, 0 = not covered, < 0 error)
+int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in, const void* wk, void* out,
+                          const sw_epilogue* ep, hipStream_t stream);
+
 // conv3x3 (stride 1, pad = dilation) forward / data-gradient as an implicit GEMM over an NHWC tensor:
 //   out[(img,y,x)][co] = sum_{tap,ci} in[img, y+(ty-1)d, x+(tx-1)d, ci] * Wk[co][tap][ci]
 extern "C" int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in,
@@ -635,6 +639,10 @@ extern "C" int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int 
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
   if (Cin % epc) return -5;
   if (check_align(in) || check_align(wk)) return -4;
+  if (dtype == SW_BF16) {
+    const int rc = sw_conv3x3_direct_try(nimg, H, W, Cin, Cout, dilation, in, wk, out, ep, stream);
+    if (rc != 0) return rc < 0 ? -rc : 0;
+  }
   GemmArgs g = {};
   g.A = in; g.B = wk; g.C = out; g.M = nimg * H * W; g.N = Cout; g.K = 9 * Cin; g.lda = 0; g.ldb = 9L * Cin; g.ldc = Cout;
   g.cH = H; g.cW = W; g.cC = Cin; g.cDil = dilation;
