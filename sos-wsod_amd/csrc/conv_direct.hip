@@ -30,7 +30,7 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 32, TN = 64, CK = 32;          // pixel tile, output channels, input channels per chunk
+constexpr int TH = 8, TW = 32, CK = 32;                   // pixel tile, input channels per chunk (output channels: template TN)
 constexpr unsigned INVALID = 0xFFFFFF00u;
 
 struct DirectArgs {
@@ -46,8 +46,10 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // DEPTH = weight tap-row buffers (prefetch distance DEPTH-1 steps).  2: 80 KiB LDS, two workgroups per CU (layers with >= 2
 // workgroups per CU); 4: 104 KiB, for the 63x63 / 64x64 layers whose 256 workgroups leave one per CU — there a step (48
 // MFMAs ~ 800 cycles) is shorter than a loaded L2 round trip and distance 1 made every step wait for its weights.
-template <int DIL, int DEPTH>
+template <int DIL, int DEPTH, int TN>
 __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel(DirectArgs g) {
+  constexpr int NI = TN / 16;                              // MFMA tiles along the output channels
+  constexpr int B_INSTR = 3 * TN * 4 / 64, B_PER_WAVE = (B_INSTR + 3) / 4;
   constexpr int PH = TH + 2 * DIL, PW = TW + 2 * DIL, P = PH * PW;
   constexpr int A_INSTR = (P * 4 + 63) / 64;               // 1 KiB LDS-DMA instructions per input patch
   constexpr int A_PER_WAVE = (A_INSTR + 3) / 4;             // every wave issues this many (uniform vmcnt accounting);
@@ -87,14 +89,14 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
     const bool ok = prow < P && y >= 0 && y < g.H && x >= 0 && x < g.W;
     a_v[s] = ok ? (unsigned)(((((long)img * g.H + y) * g.W + x) * g.Cin + src * 8) * 2) : INVALID;
   }
-  unsigned b_v[3];
+  unsigned b_v[B_PER_WAVE];
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int idx = (wave + 4 * s) * 64 + lane;             // [0, 768): row r = tap_x * 64 + co, position p
+  for (int s = 0; s < B_PER_WAVE; ++s) {
+    const int idx = (wave + 4 * s) * 64 + lane;             // row r = tap_x * TN + co, position p
     const int r = idx >> 2, p = idx & 3;
-    const int tap_x = r >> 6, co = r & 63;
+    const int tap_x = r / TN, co = r - tap_x * TN;
     const int src = p ^ (((co >> 2) & 1) << 1);
-    const bool ok = co0 + co < g.Cout;
+    const bool ok = tap_x < 3 && co0 + co < g.Cout;
     b_v[s] = ok ? (unsigned)((((long)(co0 + co) * 9 + tap_x) * g.Cin + src * 8) * 2) : INVALID;
   }
   auto issue_a = [&](int chunk) {
@@ -109,22 +111,23 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
     char* dst = sB + (step % DEPTH) * B_BYTES;
     const unsigned soff = (unsigned)((ty * 3 * g.Cin + chunk * CK) * 2);
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lvoid)(dst + (wave + 4 * s) * 1024), 16, (int)b_v[s], (int)soff, 0, 0);
+    for (int s = 0; s < B_PER_WAVE; ++s)
+      if (wave + 4 * s < B_INSTR)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lvoid)(dst + (wave + 4 * s) * 1024), 16, (int)b_v[s], (int)soff, 0, 0);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NI];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nchunk = g.Cin / CK, nstep = nchunk * 3;
   const int l15 = lane & 15, kq = lane >> 4;                // fragment row, 16-byte K position
   // B fragment byte offsets inside a tap (fixed): channel j*16 + l15
-  int b_off[4];
+  int b_off[NI];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NI; ++j) {
     const int co = j * 16 + l15;
     b_off[j] = co * 64 + ((kq ^ (((co >> 2) & 1) << 1)) << 4);
   }
@@ -140,18 +143,18 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
     const char* B = sB + (step % DEPTH) * B_BYTES;
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx) {
-      u32x4 fa[4], fb[4];
+      u32x4 fa[4], fb[NI];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int prow = (2 * wave + (i >> 1) + ty * DIL) * PW + (i & 1) * 16 + tx * DIL + l15;
         fa[i] = *(const u32x4*)(A + prow * 64 + ((kq ^ (((prow >> 2) & 1) << 1)) << 4));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(B + tx * (TN * 64) + b_off[j]);
+      for (int j = 0; j < NI; ++j) fb[j] = *(const u32x4*)(B + tx * (TN * 64) + b_off[j]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
                                                               acc[i][j], 0, 0, 0);
     }
@@ -164,6 +167,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
       //   DEPTH 3: {3, 3+APW, 3+APW}     DEPTH 4: {6, 6+APW, 6+APW}     (tap row 0 of DEPTH 4 needs the patch issued in the
       //   same step as its weights, so that patch may NOT stay outstanding)
       constexpr int APW = A_PER_WAVE;
+      static_assert(DEPTH == 2 || B_INSTR == 12, "counted vmcnt assumes 3 weight instructions per wave and step");
       if (DEPTH == 2 || step + DEPTH - 1 >= nstep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: fewer loads issued
       else if (ty == 0) wait_vm<3 * (DEPTH - 2)>();
       else wait_vm<3 * (DEPTH - 2) + APW>();
@@ -176,9 +180,9 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
   __syncthreads();                                          // every wave is done with the staging buffers
 
   // ---- epilogue: bias / ReLU in registers, bf16 tile through LDS, 16-byte stores with the ReLU-backward mask
-  unsigned short* S = (unsigned short*)(smem + wave * (64 * 64 * 2));        // [64 pixels][64 channels]
+  unsigned short* S = (unsigned short*)(smem + wave * (64 * TN * 2));        // [64 pixels][TN channels]
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NI; ++j) {
     const int col = j * 16 + l15;
     const float bv = (g.bias && co0 + col < g.Cout) ? g.bias[co0 + col] : 0.f;
 #pragma unroll
@@ -188,20 +192,20 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
         float v = acc[i][j][e] + bv;
         if (g.relu) v = fmaxf(v, 0.f);
         const int pl = i * 16 + kq * 4 + e;                 // C/D map: row = (lane>>4)*4 + e, col = lane&15
-        S[pl * 64 + (col ^ ((pl & 7) << 3))] = f32_to_bf16_bits(v);      // 16-byte groups XOR-swizzled by the row
+        S[pl * TN + (col ^ ((pl & (TN / 8 - 1)) << 3))] = f32_to_bf16_bits(v);      // 16-byte groups XOR-swizzled by the row
       }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): own LDS writes visible to own reads (same wave)
   unsigned short* out = (unsigned short*)g.out;
   const unsigned short* ref = (const unsigned short*)g.ref;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < TN / 8; ++it) {
     const int idx = it * 64 + lane;
-    const int pl = idx >> 3, ch = idx & 7;                  // pixel of this wave's 64, 16-byte channel group
+    const int pl = idx / (TN / 8), ch = idx % (TN / 8);     // pixel of this wave's 64, 16-byte channel group
     const int y = ty0 + 2 * wave + (pl >> 5), x = tx0 + (pl & 31);
     const int co = co0 + ch * 8;
     if (y < g.H && x < g.W && co < g.Cout) {
-      u32x4 v = *(const u32x4*)(S + pl * 64 + ((ch ^ (pl & 7)) << 3));
+      u32x4 v = *(const u32x4*)(S + pl * TN + ((ch ^ (pl & (TN / 8 - 1))) << 3));
       const long o = (((long)img * g.H + y) * g.W + x) * g.Cout + co;
       if (ref) {
         const u32x4 r = *(const u32x4*)(ref + o);
@@ -233,7 +237,12 @@ int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilatio
   g.in = in; g.wk = wk; g.out = out; g.bias = ep->bias; g.ref = ep->relu_ref; g.relu = ep->relu;
   g.nimg = nimg; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
   g.tiles_x = (W + TW - 1) / TW; g.tiles_y = (H + TH - 1) / TH;
-  g.n_px_tiles = g.tiles_x * g.tiles_y * nimg; g.n_co_blocks = (Cout + TN - 1) / TN;
+  g.n_px_tiles = g.tiles_x * g.tiles_y * nimg;
+  // 64 output channels per workgroup, or 32 when that leaves less than 1.5 workgroups per CU (63x63 / 64x64 maps): twice the
+  // workgroups = two per CU = two waves per SIMD to overlap LDS latency with MFMAs
+  static const char* tsw = getenv("SW_CONV_DIRECT_TN");       // development switch
+  const int tn = tsw ? atoi(tsw) : (g.n_px_tiles * ((Cout + 63) / 64) <= 384 ? 32 : 64);
+  g.n_co_blocks = (Cout + tn - 1) / tn;
   g.total = g.n_px_tiles * g.n_co_blocks;
   const long ib = (long)nimg * H * W * Cin * 2, wb = (long)Cout * 9 * Cin * 2;
   if (ib >= 0xFFFFFF00L || wb >= 0xFFFFFF00L) return 0;
@@ -243,17 +252,18 @@ int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilatio
   const int P = (TH + 2 * d) * (TW + 2 * d);
   const int apw = ((P * 4 + 63) / 64 + 3) / 4;
   static const char* dsw = getenv("SW_CONV_DIRECT_DEPTH");      // development switch
-  const int depth = dsw ? atoi(dsw) : (g.total <= 384 ? 4 : 2);  // one workgroup per CU anyway -> deep weight ring
-  const size_t lds = (size_t)2 * apw * 4096 + (size_t)depth * (3 * TN * 64);
+  const int depth = (dsw && tn == 64) ? atoi(dsw) : 2;
+  const size_t lds = (size_t)2 * apw * 4096 + (size_t)depth * (3 * tn * 64);
   hipError_t e = hipSuccess;
-#define SW_LAUNCH_DIRECT(D, DEP)                                                                                          \
+#define SW_LAUNCH_DIRECT(D, DEP, TNV)                                                                                    \
   do {                                                                                                                     \
-    e = hipFuncSetAttribute((const void*)conv3x3_direct_kernel<D, DEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    e = hipFuncSetAttribute((const void*)conv3x3_direct_kernel<D, DEP, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return -(int)e;                                                                                   \
-    hipLaunchKernelGGL((conv3x3_direct_kernel<D, DEP>), dim3(per_xcd * 8), dim3(256), lds, stream, g);                    \
+    hipLaunchKernelGGL((conv3x3_direct_kernel<D, DEP, TNV>), dim3(per_xcd * 8), dim3(256), lds, stream, g);               \
   } while (0)
-  if (d == 1) { if (depth == 2) SW_LAUNCH_DIRECT(1, 2); else if (depth == 3) SW_LAUNCH_DIRECT(1, 3); else SW_LAUNCH_DIRECT(1, 4); }
-  else { if (depth == 2) SW_LAUNCH_DIRECT(2, 2); else if (depth == 3) SW_LAUNCH_DIRECT(2, 3); else SW_LAUNCH_DIRECT(2, 4); }
+  if (tn == 32) { if (d == 1) SW_LAUNCH_DIRECT(1, 2, 32); else SW_LAUNCH_DIRECT(2, 2, 32); }
+  else if (d == 1) { if (depth == 2) SW_LAUNCH_DIRECT(1, 2, 64); else if (depth == 3) SW_LAUNCH_DIRECT(1, 3, 64); else SW_LAUNCH_DIRECT(1, 4, 64); }
+  else { if (depth == 2) SW_LAUNCH_DIRECT(2, 2, 64); else if (depth == 3) SW_LAUNCH_DIRECT(2, 3, 64); else SW_LAUNCH_DIRECT(2, 4, 64); }
 #undef SW_LAUNCH_DIRECT
   e = hipGetLastError();
   if (e != hipSuccess) return -(int)e;

@@ -1,0 +1,88 @@
+"""Checkpoint I/O with the reference's key names and file formats — host logic, runs without a GPU."""
+import pickle
+
+import numpy as np
+import torch
+
+
+def _model():
+    from sos_wsod_amd.config import add_wsl_config, get_cfg
+    from sos_wsod_amd.rcnn_multi import build_model
+    cfg = add_wsl_config(get_cfg())
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.META_ARCHITECTURE", "MultiInputRCNN", "MODEL.BACKBONE.NAME",
+                         "build_vgg_backbone", "MODEL.VGG.CONV5_DILATION", 2, "MODEL.ROI_HEADS.NAME", "OICRPlusHeads",
+                         "MODEL.ROI_HEADS.IN_FEATURES", ["plain5"], "MODEL.ROI_HEADS.NUM_CLASSES", 20,
+                         "MODEL.ROI_HEADS.IOU_THRESHOLDS", [0.5, 0.6], "MODEL.ROI_HEADS.IOU_LABELS", [0, -1, 1],
+                         "MODEL.ROI_BOX_HEAD.NAME", "DiscriminativeAdaptionNeck", "MODEL.ROI_BOX_HEAD.POOLER_TYPE", "ROIPool",
+                         "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7, "MODEL.ROI_BOX_HEAD.DAN_DIM", [32, 32],
+                         "MODEL.PROPOSAL_GENERATOR.NAME", "PrecomputedProposals", "WSL.REFINE_NUM", 4,
+                         "WSL.REFINE_REG", [True] * 4, "WSL.REFINE_MIST", True])
+    return build_model(cfg)
+
+
+def test_pth_roundtrip_with_optimizer_scheduler_and_iteration(tmp_path):
+    import sos_wsod_amd.ops as ops
+    from sos_wsod_amd.checkpoint import DetectionCheckpointer
+    from sos_wsod_amd.solver import WarmupMultiStepLR
+    torch.manual_seed(0)
+    m1 = _model()
+    opt1 = torch.optim.SGD(m1.parameters(), lr=0.01, momentum=0.9)
+    sch1 = WarmupMultiStepLR(opt1, [5, 8], warmup_iters=3)
+    for _ in range(4):
+        opt1.step(); sch1.step()
+    ck = DetectionCheckpointer(m1, str(tmp_path), optimizer=opt1, scheduler=sch1)
+    path = ck.save("model_0000003", iteration=3)
+    assert path.endswith("model_0000003.pth") and ck.has_checkpoint() and ck.get_checkpoint_file() == path
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) == {"model", "optimizer", "scheduler", "iteration"}
+    assert "backbone.plain3.0.conv2.weight" in raw["model"] and "roi_heads.box_refinery_2.bbox_pred.bias" in raw["model"]
+    torch.manual_seed(1)
+    m2 = _model()
+    opt2 = torch.optim.SGD(m2.parameters(), lr=0.5, momentum=0.9)
+    sch2 = WarmupMultiStepLR(opt2, [5, 8], warmup_iters=3)
+    epoch = ops.PARAM_EPOCH
+    extra = DetectionCheckpointer(m2, str(tmp_path), optimizer=opt2, scheduler=sch2).resume_or_load("", resume=True)
+    assert extra == {"iteration": 3} and ops.PARAM_EPOCH > epoch          # cached weight copies are invalidated
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert sch2.last_epoch == sch1.last_epoch and opt2.param_groups[0]["lr"] == opt1.param_groups[0]["lr"]
+
+
+def test_model_zoo_pkl_with_name_matching_fills_the_backbone_only(tmp_path):
+    """the recipe's MODEL.WEIGHTS is a Detectron2-zoo pickle of numpy arrays holding ImageNet VGG16 convs only"""
+    from sos_wsod_amd.checkpoint import DetectionCheckpointer
+    torch.manual_seed(2)
+    m = _model()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(0)
+    zoo = {}
+    for k, v in before.items():
+        if k.startswith("backbone."):
+            zoo[k[len("backbone."):]] = rng.standard_normal(tuple(v.shape)).astype(np.float32)      # keys without the prefix
+    zoo["fc8.weight"] = np.zeros((1000, 4096), np.float32)                                          # a head the model lacks
+    p = tmp_path / "VGG_ILSVRC_16_layers_v1_d2.pkl"
+    with open(p, "wb") as f:
+        pickle.dump({"model": zoo, "__author__": "someone", "matching_heuristics": True}, f)
+    ck = DetectionCheckpointer(m)
+    ck.resume_or_load(str(p), resume=False)
+    after = m.state_dict()
+    for k in before:
+        if k.startswith("backbone."):
+            assert np.array_equal(after[k].numpy(), zoo[k[len("backbone."):]]), k
+        elif k not in ("pixel_mean", "pixel_std"):
+            assert torch.equal(after[k], before[k]), k                                             # heads untouched
+    assert any(k.startswith("roi_heads.") for k in ck.last_incompatible.missing_keys)
+    assert not ck.last_incompatible.unexpected_keys                    # unmatched zoo entries are dropped by the heuristic
+
+
+def test_shape_mismatch_is_reported_not_loaded(tmp_path):
+    from sos_wsod_amd.checkpoint import DetectionCheckpointer
+    m = _model()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["roi_heads.box_predictor.cls.weight"] = torch.zeros(81, 32)     # a COCO head into a VOC model
+    torch.save({"model": sd}, tmp_path / "x.pth")
+    keep = m.state_dict()["roi_heads.box_predictor.cls.weight"].clone()
+    ck = DetectionCheckpointer(m)
+    ck.load(str(tmp_path / "x.pth"))
+    assert ck.last_incompatible.incorrect_shapes == [("roi_heads.box_predictor.cls.weight", (81, 32), (20, 32))]
+    assert torch.equal(m.state_dict()["roi_heads.box_predictor.cls.weight"], keep)

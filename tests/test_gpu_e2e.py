@@ -362,3 +362,41 @@ def test_voc_sized_nonsquare_views_run(monkeypatch):
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
     g3 = model.backbone.blocks[2].convs()[0].weight.grad
     assert g3.abs().max() > 0                                      # the gradient reached the first trainable conv
+
+
+def test_checkpoint_load_invalidates_the_compute_copies(golden_dir, tmp_path):
+    """weights loaded from a checkpoint (copy into the existing storage) must reach the next forward: the persistent
+    compute-dtype copies are rebuilt, and the predictor weights stay row slices of their flat master"""
+    import sos_wsod_amd.ops as ops
+    from sos_wsod_amd.checkpoint import DetectionCheckpointer
+    from sos_wsod_amd.events import EventStorage
+    from sos_wsod_amd.solver import HipSGD
+    from sos_wsod_amd.trainer import Trainer
+    dtype = torch.bfloat16
+    g, P, views, gt, masks, model = _setup("s0", golden_dir, dtype)
+    data = to_batched_inputs(views, gt)
+    opt = HipSGD([{"params": [p], "lr": 1e-3, "weight_decay": 5e-4} for p in model.parameters() if p.requires_grad],
+                 1e-3, momentum=0.9)
+    tr = Trainer(model, opt)
+    tr.run_step(data); tr.run_step(data)
+    other = build_model(int(g["K"]), tuple(int(x) for x in g["dan"]), dtype)
+    load_params(other, O.make_params(int(g["K"]), tuple(int(x) for x in g["dan"]), tag="other", head_scale=float(g["head_scale"])))
+    DetectionCheckpointer(other, str(tmp_path)).save("m", iteration=7)
+    extra = DetectionCheckpointer(model, str(tmp_path)).resume_or_load("", resume=True)
+    assert extra["iteration"] == 7
+    hd = model.roi_heads
+    with EventStorage(0), torch.no_grad():
+        model.eval()
+        model.train()
+        losses = model(data)
+    torch.cuda.synchronize()
+    ref_sd = other.state_dict()
+    assert torch.equal(hd._stage_cache["fc1"][1], ref_sd["roi_heads.box_head.fc1.weight"].to(dtype))
+    flat_w, _ = hd._head_flat
+    assert hd.box_predictor.cls.weight.data_ptr() == flat_w.data_ptr()                 # still a view of the flat master
+    assert torch.equal(flat_w[:int(g["K"])], ref_sd["roi_heads.box_predictor.cls.weight"])
+    wk = model.backbone._wk_cache[(id(model.backbone.blocks[4].convs()[2].weight), 0)][1]
+    want = torch.zeros_like(wk)
+    ops.conv_weight_prep(ref_sd["backbone.plain5.0.conv3.weight"], want, 0, 512)
+    assert torch.equal(wk, want)
+    assert torch.isfinite(losses.vector).all()
