@@ -52,3 +52,60 @@ def oicr_inference(heads, features, proposals):
     result.scores = dscores[:n]
     result.pred_classes = dclasses[:n].to(torch.int64)
     return [result], all_scores.unsqueeze(0), all_boxes.unsqueeze(0)
+
+
+def detector_postprocess(results, output_height, output_width):
+    """modeling/postprocessing.py:9-44 (boxes only): scale the detections from the network's input resolution to the
+    requested output resolution, clip, drop empty boxes."""
+    from .structures import Instances
+    scale_x, scale_y = output_width / results.image_size[1], output_height / results.image_size[0]
+    out = Instances((int(output_height), int(output_width)), **results.get_fields())
+    if out.has("pred_boxes"):
+        boxes = out.pred_boxes.clone()
+        boxes.scale(scale_x, scale_y)
+        boxes.clip(out.image_size)
+        out.pred_boxes = boxes
+        out = out[boxes.nonempty()]
+    return out
+
+
+class VOCDetectionWriter:
+    """The detection-result wire format of the reference's evaluator (evaluation/pascal_voc_evaluation.py:57-118), which
+    Stage 2 (`tools/pgf.py`) consumes: per detection the text line `image_id score xmin+1 ymin+1 xmax ymax` (score %.3f,
+    coordinates %.1f) grouped by class, and the JSON list of
+    {"image_id": int, "category_id": class+1, "score": float, "bbox": [x1, y1, x2, y2]} parsed back from those lines."""
+
+    def __init__(self, num_classes):
+        self.num_classes = num_classes
+        self.reset()
+
+    def reset(self):
+        self._predictions = {c: [] for c in range(self.num_classes)}
+
+    def process(self, inputs, outputs):
+        for inp, outp in zip(inputs, outputs):
+            image_id = inp["image_id"]
+            inst = outp["instances"].to("cpu")
+            boxes = inst.pred_boxes.tensor.numpy()
+            for box, score, cls in zip(boxes, inst.scores.tolist(), inst.pred_classes.tolist()):
+                xmin, ymin, xmax, ymax = box
+                xmin += 1                                       # the inverse of the VOC loader's 0-based shift
+                ymin += 1
+                self._predictions[cls].append(f"{image_id} {score:.3f} {xmin:.1f} {ymin:.1f} {xmax:.1f} {ymax:.1f}")
+
+    def lines(self):
+        return self._predictions
+
+    def records(self):
+        out = []
+        for cls_id in range(self.num_classes):
+            for line in self._predictions[cls_id]:
+                m = line.split(" ")
+                out.append({"image_id": int(m[0]), "category_id": cls_id + 1, "score": float(m[1]),
+                            "bbox": [float(m[2]), float(m[3]), float(m[4]), float(m[5])]})
+        return out
+
+    def dump(self, path):
+        import json
+        with open(path, "w") as f:
+            json.dump(self.records(), f)

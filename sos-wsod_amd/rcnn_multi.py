@@ -124,5 +124,15 @@ class MultiInputRCNN(nn.Module):
         proposals = [x["proposals"]]
         results, _, all_scores, all_boxes = self.roi_heads(None, features, proposals, None)
         if do_postprocess:
-            return [{"instances": r} for r in results]
+            image_sizes = [tuple(x["image"].shape[-2:])]
+            return MultiInputRCNN._postprocess(results, batched_inputs, image_sizes)
         return results, all_scores, all_boxes
+
+    @staticmethod
+    def _postprocess(instances, batched_inputs, image_sizes):
+        """rcnn_multi.py:276-291: rescale the detections to the dataset image size (`height`/`width` of the input dict)"""
+        from .inference import detector_postprocess
+        out = []
+        for res, inp, size in zip(instances, batched_inputs, image_sizes):
+            out.append({"instances": detector_postprocess(res, inp.get("height", size[0]), inp.get("width", size[1]))})
+        return out

@@ -40,6 +40,11 @@ class Boxes:
         self.tensor[:, 0].clamp_(min=0, max=w); self.tensor[:, 1].clamp_(min=0, max=h)
         self.tensor[:, 2].clamp_(min=0, max=w); self.tensor[:, 3].clamp_(min=0, max=h)
 
+    def scale(self, scale_x: float, scale_y: float) -> None:
+        """structures/boxes.py:296-302 (in place)"""
+        self.tensor[:, 0::2] *= scale_x
+        self.tensor[:, 1::2] *= scale_y
+
     def nonempty(self, threshold: float = 0.0):
         b = self.tensor
         return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)

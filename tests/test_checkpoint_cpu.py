@@ -86,3 +86,25 @@ def test_shape_mismatch_is_reported_not_loaded(tmp_path):
     ck.load(str(tmp_path / "x.pth"))
     assert ck.last_incompatible.incorrect_shapes == [("roi_heads.box_predictor.cls.weight", (81, 32), (20, 32))]
     assert torch.equal(m.state_dict()["roi_heads.box_predictor.cls.weight"], keep)
+
+
+def test_detection_wire_format_and_postprocess(tmp_path):
+    """§8f row 2: `image_id score x1+1 y1+1 x2 y2` lines and the JSON records of pascal_voc_evaluation.py:57-118, after the
+    rescale / clip / drop-empty of detector_postprocess"""
+    import json
+    from sos_wsod_amd.inference import VOCDetectionWriter, detector_postprocess
+    from sos_wsod_amd.structures import Boxes, Instances
+    r = Instances((100, 200))
+    r.pred_boxes = Boxes(torch.tensor([[10.0, 20.0, 50.0, 60.0], [190.0, 90.0, 260.0, 140.0], [5.0, 5.0, 5.0, 9.0]]))
+    r.scores = torch.tensor([0.98765, 0.5, 0.25])
+    r.pred_classes = torch.tensor([3, 0, 3])
+    out = detector_postprocess(r, 200, 400)                       # network saw 100x200, the dataset image is 200x400
+    assert out.image_size == (200, 400) and len(out) == 2        # the zero-width box is dropped
+    assert torch.equal(out.pred_boxes.tensor, torch.tensor([[20.0, 40.0, 100.0, 120.0], [380.0, 180.0, 400.0, 200.0]]))
+    w = VOCDetectionWriter(20)
+    w.process([{"image_id": "000012"}], [{"instances": out}])
+    assert w.lines()[3] == ["000012 0.988 21.0 41.0 100.0 120.0"] and w.lines()[0] == ["000012 0.500 381.0 181.0 400.0 200.0"]
+    w.dump(tmp_path / "det.json")
+    assert json.load(open(tmp_path / "det.json")) == [
+        {"image_id": 12, "category_id": 1, "score": 0.5, "bbox": [381.0, 181.0, 400.0, 200.0]},
+        {"image_id": 12, "category_id": 4, "score": 0.988, "bbox": [21.0, 41.0, 100.0, 120.0]}]
