@@ -1,0 +1,124 @@
+"""Test-time augmentation with score / box averaging (SURVEY §8f row 2;
+uwsod/projects/WSL/wsl/modeling/test_time_augmentation_avg.py:199-427, boxes only — the path has no mask head).
+
+For every augmented view (resize to a TEST.AUG min size, optional horizontal flip) the detector runs WITHOUT its
+post-processing and returns the per-proposal score matrix (R, K+1) and class-wise boxes (R, 4K) in the view's
+coordinates; the boxes are mapped back through the inverse transforms (un-flip in the resized frame, then un-resize), both
+are averaged over the views (the proposals are index aligned across views), and the averaged set goes through the usual
+threshold / per-class NMS / top-k (`sw_detect_postprocess`).
+
+The reference builds the views on the CPU (`DatasetMapperTTAAVG`: PIL resize, numpy flip, `transform_proposals`); that
+input side is SURVEY §8f row 3 and out of scope.  `DeviceTTAMapper` is the device-side stand-in: bilinear resize of the
+CHW tensor with `torch.nn.functional.interpolate` (not bit-identical to PIL's resampling — documented, not claimed as
+parity) and the same affine maps on the proposal boxes.
+"""
+from typing import List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .structures import Boxes, Instances
+
+
+class ViewTransform:
+    """resize (orig h,w -> new h,w) followed by an optional horizontal flip in the resized frame"""
+
+    def __init__(self, orig_hw: Tuple[int, int], new_hw: Tuple[int, int], flip: bool):
+        self.orig_hw, self.new_hw, self.flip = tuple(orig_hw), tuple(new_hw), bool(flip)
+
+    def apply_box(self, boxes: torch.Tensor) -> torch.Tensor:
+        sx, sy = self.new_hw[1] / self.orig_hw[1], self.new_hw[0] / self.orig_hw[0]
+        b = boxes * boxes.new_tensor([sx, sy, sx, sy])
+        if self.flip:                                        # HFlipTransform.apply_box: x -> W - x, corners re-sorted
+            w = float(self.new_hw[1])
+            b = torch.stack([w - b[:, 2], b[:, 1], w - b[:, 0], b[:, 3]], 1)
+        return b
+
+    def inverse_box(self, boxes: torch.Tensor) -> torch.Tensor:
+        b = boxes
+        if self.flip:
+            w = float(self.new_hw[1])
+            b = torch.stack([w - b[:, 2], b[:, 1], w - b[:, 0], b[:, 3]], 1)
+        sx, sy = self.orig_hw[1] / self.new_hw[1], self.orig_hw[0] / self.new_hw[0]
+        return b * b.new_tensor([sx, sy, sx, sy])
+
+
+class DeviceTTAMapper:
+    """dataset dict -> list of (augmented dict, ViewTransform) for TEST.AUG.{MIN_SIZES, MAX_SIZE, FLIP}"""
+
+    def __init__(self, min_sizes=(480, 576, 688, 864, 1000, 1200), max_size=4000, flip=True):
+        self.min_sizes, self.max_size, self.flip = tuple(min_sizes), max_size, flip
+
+    @staticmethod
+    def _shortest_edge(h, w, size, max_size):                # ResizeShortestEdge.get_output_shape
+        scale = size * 1.0 / min(h, w)
+        nh, nw = (size, scale * w) if h < w else (scale * h, size)
+        if max(nh, nw) > max_size:
+            s = max_size * 1.0 / max(nh, nw)
+            nh, nw = nh * s, nw * s
+        return int(nh + 0.5), int(nw + 0.5)
+
+    def __call__(self, d):
+        img = d["image"]                                     # (3, h, w) uint8
+        h, w = img.shape[-2:]
+        prop = d["proposals"]
+        out = []
+        for size in self.min_sizes:
+            nh, nw = self._shortest_edge(h, w, size, self.max_size)
+            r = F.interpolate(img[None].float(), size=(nh, nw), mode="bilinear", align_corners=False)[0]
+            r = r.round().clamp(0, 255).to(torch.uint8)
+            for flip in ((False, True) if self.flip else (False,)):
+                t = ViewTransform((h, w), (nh, nw), flip)
+                p = Instances((nh, nw))
+                p.proposal_boxes = Boxes(t.apply_box(prop.proposal_boxes.tensor.float()))
+                p.objectness_logits = prop.objectness_logits
+                view = {"image": r.flip(-1).contiguous() if flip else r, "proposals": p, "height": d.get("height", h),
+                        "width": d.get("width", w)}
+                out.append((view, t))
+        return out
+
+
+class GeneralizedRCNNWithTTAAVG(torch.nn.Module):
+    """same call interface as the model's inference forward; `tta_mapper(dict) -> [(view dict, ViewTransform)]`"""
+
+    def __init__(self, model, tta_mapper=None):
+        super().__init__()
+        if isinstance(model, torch.nn.parallel.DistributedDataParallel):
+            model = model.module
+        self.model = model
+        self.tta_mapper = tta_mapper if tta_mapper is not None else DeviceTTAMapper()
+
+    @torch.no_grad()
+    def __call__(self, batched_inputs: List[dict]):
+        return [self._inference_one_image(x) for x in batched_inputs]
+
+    def _inference_one_image(self, inp):
+        from . import ops
+        assert not self.model.training
+        h, w = inp["image"].shape[-2:]
+        orig = (inp.get("height", h), inp.get("width", w))
+        views = self.tta_mapper(dict(inp, height=orig[0], width=orig[1]))
+        heads = self.model.roi_heads
+        K = heads.num_classes
+        sum_scores = sum_boxes = None
+        for view, tfm in views:
+            _, scores, boxes = self.model.inference([view], do_postprocess=False)       # (1, R, K+1), (1, R, 4K), view coordinates
+            scores, boxes = scores[0], boxes[0]
+            R = boxes.shape[0]
+            back = tfm.inverse_box(boxes.reshape(R * K, 4)).reshape(R, 4 * K)
+            if (tfm.orig_hw != orig):                        # the mapper resized from the tensor's size, not the dataset's
+                sx, sy = orig[1] / tfm.orig_hw[1], orig[0] / tfm.orig_hw[0]
+                back = (back.reshape(R * K, 4) * back.new_tensor([sx, sy, sx, sy])).reshape(R, 4 * K)
+            sum_scores = scores.clone() if sum_scores is None else sum_scores + scores
+            sum_boxes = back if sum_boxes is None else sum_boxes + back
+        n = float(len(views))
+        all_scores, all_boxes = (sum_scores / n).contiguous(), (sum_boxes / n).contiguous()
+        cnt, dboxes, dscores, dclasses, _ = ops.detect_postprocess(all_scores, all_boxes, int(orig[0]), int(orig[1]),
+                                                                   heads.test_score_thresh, heads.test_nms_thresh,
+                                                                   heads.test_topk_per_image)
+        n_det = int(cnt.item())
+        res = Instances((int(orig[0]), int(orig[1])))
+        res.pred_boxes = Boxes(dboxes[:n_det])
+        res.scores = dscores[:n_det]
+        res.pred_classes = dclasses[:n_det].to(torch.int64)
+        return {"instances": res}

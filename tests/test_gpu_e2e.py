@@ -400,3 +400,35 @@ def test_checkpoint_load_invalidates_the_compute_copies(golden_dir, tmp_path):
     ops.conv_weight_prep(ref_sd["backbone.plain5.0.conv3.weight"], want, 0, 512)
     assert torch.equal(wk, want)
     assert torch.isfinite(losses.vector).all()
+
+
+def test_tta_avg_merge(golden_dir):
+    """TTA-avg (test_time_augmentation_avg.py:311-393): one identity view == plain inference; flip / resize views are mapped
+    back by the inverse transforms (checked against a float64 restatement) and averaged before the final NMS"""
+    from sos_wsod_amd.structures import Boxes, Instances
+    from sos_wsod_amd.tta import DeviceTTAMapper, GeneralizedRCNNWithTTAAVG, ViewTransform
+    g, P, views, gt, masks, model = _setup("s0", golden_dir, torch.float32)
+    model.eval()
+    v = views[0]
+    h, w = v["image"].shape[1:]
+    prop = Instances((h, w)); prop.proposal_boxes = Boxes(torch.from_numpy(v["boxes"]).cuda())
+    prop.objectness_logits = torch.from_numpy(v["obj"]).cuda()
+    inp = {"image": torch.from_numpy(np.ascontiguousarray(v["image"])).cuda(), "proposals": prop}
+    plain = model.inference([inp])[0]["instances"]
+    ident = GeneralizedRCNNWithTTAAVG(model, lambda d: [(d, ViewTransform((h, w), (h, w), False))])([inp])[0]["instances"]
+    assert torch.equal(plain.pred_boxes.tensor, ident.pred_boxes.tensor) and torch.equal(plain.scores, ident.scores)
+    assert torch.equal(plain.pred_classes, ident.pred_classes)
+    # inverse transforms: resize (h,w)->(nh,nw) then flip; float64 restatement
+    t = ViewTransform((h, w), (2 * h, 3 * w), True)
+    b = torch.from_numpy(v["boxes"]).double()
+    fwd = b * torch.tensor([3.0, 2.0, 3.0, 2.0], dtype=torch.float64)
+    fwd = torch.stack([3.0 * w - fwd[:, 2], fwd[:, 1], 3.0 * w - fwd[:, 0], fwd[:, 3]], 1)
+    assert torch.allclose(t.apply_box(torch.from_numpy(v["boxes"])).double(), fwd, atol=1e-3)
+    assert torch.allclose(t.inverse_box(t.apply_box(torch.from_numpy(v["boxes"]))), torch.from_numpy(v["boxes"]), atol=1e-3)
+    # several device-built views run end to end, detections stay inside the original image and sorted per the final NMS
+    tta = GeneralizedRCNNWithTTAAVG(model, DeviceTTAMapper(min_sizes=(h, h + 32), max_size=4000, flip=True))
+    out = tta([inp])[0]["instances"]
+    assert out.image_size == (h, w) and len(out) > 0
+    bx = out.pred_boxes.tensor
+    assert (bx[:, 0] >= 0).all() and (bx[:, 2] <= w).all() and (bx[:, 1] >= 0).all() and (bx[:, 3] <= h).all()
+    assert (out.scores[:-1] >= out.scores[1:]).all()
