@@ -19,7 +19,7 @@ for shape in ("fc6_fwd", "fc6_dgrad", "fc6_wgrad"):
         for f in glob.glob(f"gpurun_out/pmct_{shape}_{c}/*/*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 if "gemm2_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c: vals.append(float(r["Counter_Value"]))
-        v[c] = sum(vals) / max(len(vals), 1)
+        v[c] = sum(vals) / 3.0          # per CALL (one_kernel.py runs the shape 3 times; the peeled wgrad is two launches per call)
     out[shape] = {"hbm_bytes_per_launch": round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "fetch_size_kb_raw": round(v["FETCH_SIZE"]),
                   "write_size_kb_raw": round(v["WRITE_SIZE"]), "algorithmic_bytes": alg[shape]}
 json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
