@@ -158,7 +158,9 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
   using MM = Mma<T>;
   constexpr int TS = MM::TS, NSTEP = MM::NSTEP, NACC = MM::NACC;
   constexpr int MI = WTM / TS, NI = WTN / TS;
-  constexpr bool PREFETCH_FRAGS = (NW <= 8);       // 16-wave tiles run 4 waves per SIMD under a 128-VGPR cap
+  constexpr bool PREFETCH_FRAGS = (NW <= 8);       // 16-wave tiles run 4 waves per SIMD under a 128-VGPR cap:
+  constexpr bool PREFETCH_A = (NW > 8) && sizeof(T) == 2 && BMODE != OP_CONV_B;   // there only the next sub-step's A fragments
+                                                                                   // fit (111-126 VGPRs, no spill): +1-2 %
   constexpr int A_SLOTS = GA::BYTES / 16 / NT, B_SLOTS = GB::BYTES / 16 / NT;     // 16-byte chunks per thread per K-tile
   constexpr int STAGE_BYTES = GA::BYTES + GB::BYTES;
   constexpr int GROUP = A_SLOTS + B_SLOTS;                                        // LDS-DMA instructions per wave per K-tile
@@ -391,6 +393,10 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
     for (int j = 0; j < NI; ++j) fb[j] = load_frag2<T, GB::KS, GB::ROW_BYTES>(sb, wn * WTN + j * TS, 0, lane);
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
+      if (PREFETCH_A && s < NSTEP - 1) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) na[i] = load_frag2<T, GA::KS, GA::ROW_BYTES>(sa, wm * WTM + i * TS, s + 1, lane);
+      }
       if (PREFETCH_FRAGS && s < NSTEP - 1) {   // fragments of the next K sub-step are in flight while these MFMAs issue
 #pragma unroll
         for (int i = 0; i < MI; ++i) na[i] = load_frag2<T, GA::KS, GA::ROW_BYTES>(sa, wm * WTM + i * TS, s + 1, lane);
@@ -408,6 +414,11 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
           for (int i = 0; i < MI; ++i) fa[i] = na[i];
 #pragma unroll
           for (int j = 0; j < NI; ++j) fb[j] = nb[j];
+        } else if (PREFETCH_A) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) fa[i] = na[i];
+#pragma unroll
+          for (int j = 0; j < NI; ++j) fb[j] = load_frag2<T, GB::KS, GB::ROW_BYTES>(sb, wn * WTN + j * TS, s + 1, lane);
         } else {
 #pragma unroll
           for (int i = 0; i < MI; ++i) fa[i] = load_frag2<T, GA::KS, GA::ROW_BYTES>(sa, wm * WTM + i * TS, s + 1, lane);
