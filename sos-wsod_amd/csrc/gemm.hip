@@ -547,14 +547,7 @@ int launch_auto(GemmArgs& g, int splitk, hipStream_t s) {
   const long sk = splitk < 1 ? 1 : splitk;
   auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * sk; };
   const bool big = (v && v[0] == '4') ? true : (v && v[0] == '8') ? false : (g.N > 128 && tiles(256, 256) >= 200);
-  if (v && v[0] == 'c') return launch2<T, AMODE, BMODE, 128, 128, 3, 32, 64>(g, splitk, s);
-  if (v && v[0] == 'd') return launch2<T, AMODE, BMODE, 128, 128, 4, 32, 64>(g, splitk, s);
-  if (v && v[0] == 'e') return launch2<T, AMODE, BMODE, 128, 128, 4, 64, 64>(g, splitk, s);
-  if (v && v[0] == 'a') return launch2<T, AMODE, BMODE, 256, 256, 2, 128, 64>(g, splitk, s);
-  if (v && v[0] == 'b') return launch2<T, AMODE, BMODE, 256, 256, 2, 64, 128>(g, splitk, s);
   if (big) return launch2<T, AMODE, BMODE, 256, 256, 2>(g, splitk, s);
-  if (v && v[0] == '7') return launch2<T, AMODE, BMODE, 256, 128, 2, 32, 64>(g, splitk, s);
-  if (v && v[0] == '9') return launch2<T, AMODE, BMODE, 256, 128, 2, 64, 64>(g, splitk, s);
   const bool narrow = (v && v[0] == '6') || (!v && g.N <= 64 && sk == 1);     // 64-wide outputs (conv1_x): no half-empty N tile
   if (narrow) return launch2<T, AMODE, BMODE, 256, 64, 2, 32, 64>(g, splitk, s);
   return launch2<T, AMODE, BMODE, 128, 128, 2, 32, 64>(g, splitk, s);
