@@ -308,10 +308,58 @@ __device__ __forceinline__ void sgd_stage(const sw_sgd_tensor& d, long i, float 
   }
 }
 
+// conv weights whose Cout and Cin are multiples of 32: one block = a 32 (co) x 32 (ci) x 9 (tap) tile.  The OIHW master is
+// read / written in 1152-byte runs, the updated values pass through an LDS tile, and both compute layouts leave as 64-byte
+// runs ([co][tap][ci]: 32 ci, [ci][8-tap][co]: 32 co).  The element-wise form scattered 2-byte stores 2 x Cin / Cout apart
+// and spent 0.2 ms per step on 14.7 M conv weights.
+__device__ __forceinline__ bool sgd_conv_tileable(const sw_sgd_tensor& d) {
+  return d.stage_kind == 2 && (d.d0 % 32) == 0 && (d.d1 % 32) == 0;
+}
+
+template <typename T>
+__device__ __forceinline__ void sgd_conv_tile(const sw_sgd_tensor& d, int blk, float mom, float gscale, float (*tile)[289]) {
+  const int cib = d.d1 / 32;
+  const int co0 = (blk / cib) * 32, ci0 = (blk % cib) * 32;
+  const int Cin = d.d1, Cout = d.d0;
+  for (int idx = threadIdx.x; idx < 32 * 288; idx += 256) {
+    const int co_l = idx / 288, rem = idx - co_l * 288;                 // rem = ci_l * 9 + tap
+    const long o = ((long)(co0 + co_l) * Cin + ci0) * 9 + rem;
+    const float w0 = d.param[o];
+    const float dd = d.grad[o] * gscale + d.weight_decay * w0;
+    const float m = d.first_step ? dd : mom * d.momentum_buf[o] + dd;
+    const float w1 = w0 - d.lr * m;
+    d.momentum_buf[o] = m; d.param[o] = w1;
+    tile[co_l][rem] = w1;
+  }
+  __syncthreads();
+  if (d.stage0) {
+    T* s0 = (T*)d.stage0;
+    for (int idx = threadIdx.x; idx < 32 * 288; idx += 256) {
+      const int co_l = idx / 288, r2 = idx - co_l * 288;
+      const int tap = r2 >> 5, ci_l = r2 & 31;
+      Elem<T>::store(s0 + ((long)(co0 + co_l) * 9 + tap) * d.d2 + ci0 + ci_l, tile[co_l][ci_l * 9 + tap]);
+    }
+  }
+  if (d.stage1) {
+    T* s1 = (T*)d.stage1;
+    for (int idx = threadIdx.x; idx < 32 * 288; idx += 256) {
+      const int ci_l = idx / 288, r3 = idx - ci_l * 288;
+      const int tapf = r3 >> 5, co_l = r3 & 31;
+      Elem<T>::store(s1 + ((long)(ci0 + ci_l) * 9 + tapf) * Cout + co0 + co_l, tile[co_l][ci_l * 9 + (8 - tapf)]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdBatch b, float mom, float gscale) {
+  __shared__ float conv_tile[32][289];
   int ti = 0;
   while (ti + 1 < b.n && (int)blockIdx.x >= b.block_start[ti + 1]) ++ti;
   const sw_sgd_tensor& d = b.t[ti];
+  if (sgd_conv_tileable(d)) {
+    if (d.stage_dtype == SW_BF16) sgd_conv_tile<unsigned short>(d, (int)blockIdx.x - b.block_start[ti], mom, gscale, conv_tile);
+    else sgd_conv_tile<float>(d, (int)blockIdx.x - b.block_start[ti], mom, gscale, conv_tile);
+    return;
+  }
   const long base = (long)((int)blockIdx.x - b.block_start[ti]) * SGD_CHUNK;
   const long end = min(d.n, base + SGD_CHUNK);
   const bool vec = ((((uintptr_t)d.param) | ((uintptr_t)d.grad) | ((uintptr_t)d.momentum_buf)) & 15) == 0;
@@ -716,7 +764,8 @@ extern "C" int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float m
       if (d.stage_kind && d.stage_dtype != SW_BF16 && d.stage_dtype != SW_F32) return -1;
       if (d.stage_kind == 1 && (d.d0 <= 0 || d.stage0 == nullptr)) return -5;
       if (d.stage_kind == 2 && (long)d.d0 * d.d1 * 9 != d.n) return -5;
-      const long nb = (d.n + SGD_CHUNK - 1) / SGD_CHUNK;
+      const bool conv_tiles = d.stage_kind == 2 && (d.d0 % 32) == 0 && (d.d1 % 32) == 0;
+      const long nb = conv_tiles ? (long)(d.d0 / 32) * (d.d1 / 32) : (d.n + SGD_CHUNK - 1) / SGD_CHUNK;
       if (nb > (1L << 30)) return -6;
       b.t[b.n] = d;
       b.block_start[b.n] = blocks;
