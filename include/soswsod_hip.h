@@ -45,6 +45,10 @@ typedef struct sw_epilogue {
   int out_dtype;              /* dtype of C */
   int accumulate_atomic;      /* C is f32 and is atomically accumulated (required when splitk > 1) */
   float* absmax_out;          /* optional device scalar (caller zero-fills): atomicMax of |stored value| (sw_gemm only) */
+  /* in-epilogue dropout (drop_mask == NULL, drop_hash_p > 0): element (m, n) is kept iff the keep mask that
+   * sw_dropout_mask(seed, offset, p) writes at index m*N + n is 1 — the same Bernoulli stream without the mask tensor */
+  uint64_t drop_seed, drop_offset;
+  float drop_hash_p;
 } sw_epilogue;
 
 /* ---- dense contractions (reference: cuBLAS via torch Linear — box_head.py:88-90,

@@ -25,6 +25,7 @@ class Epilogue(ctypes.Structure):
         ("bias", c_void_p), ("relu", c_int), ("drop_mask", c_void_p), ("ld_drop", c_long), ("drop_scale", c_float),
         ("relu_ref", c_void_p), ("ld_ref", c_long), ("ref_scale", c_float), ("ref_dtype", c_int),
         ("out_dtype", c_int), ("accumulate_atomic", c_int), ("absmax_out", c_void_p),
+        ("drop_seed", c_u64), ("drop_offset", c_u64), ("drop_hash_p", c_float),
     ]
 
 

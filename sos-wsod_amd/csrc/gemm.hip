@@ -32,6 +32,7 @@ struct GemmArgs {
   int cH, cW, cC, cDil;            // geometry of the gathered NHWC tensor (conv modes)
   const float* bias;               // per column n (or per row m when bias_on_m)
   const uint8_t* drop; long ldd; float drop_scale;
+  unsigned long long drop_seed_mixed, drop_offset; float drop_p;   // hash dropout: splitmix64(seed) pre-mixed on the host side
   const void* ref; long ldr; float ref_scale; int ref_bf16;
   int relu, out_bf16, atomic, oihw_cin, staged_out;
   unsigned a_bytes, b_bytes;       // extents of the A / B operands (buffer descriptors' num_records)
@@ -473,6 +474,15 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
         float v = acc[i][j][e] + bcol;
         if (g.relu) v = fmaxf(v, 0.f);
         if (g.drop && ok) v = g.drop[(long)m * g.ldd + n] ? v * g.drop_scale : 0.f;
+        if (g.drop_p > 0.f && ok) {                        // identical Bernoulli stream to dropout_mask_kernel (elementwise.hip)
+          unsigned long long z = g.drop_seed_mixed + g.drop_offset + (unsigned long long)((long)m * g.N + n);
+          z += 0x9E3779B97F4A7C15ull;
+          z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+          z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+          z ^= z >> 31;
+          const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+          v = u >= g.drop_p ? v * g.drop_scale : 0.f;
+        }
         if (g.ref && ok) {
           const float rv = g.ref_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.ref)[(long)m * g.ldr + n])
                                       : ((const float*)g.ref)[(long)m * g.ldr + n];
@@ -588,7 +598,7 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
   // launch with split-K sized to fill the chip once, accumulating with f32 atomics into the zeroed column block.
   {
     static const bool no_peel = getenv("SW_GEMM_NO_PEEL") != nullptr;    // development switch
-    const bool plain = (!ep || (ep->out_dtype == SW_F32 && !ep->bias && !ep->relu && !ep->drop_mask && !ep->relu_ref &&
+    const bool plain = (!ep || (ep->out_dtype == SW_F32 && !ep->bias && !ep->relu && !ep->drop_mask && !(ep->drop_hash_p > 0.f) && !ep->relu_ref &&
                                 !ep->accumulate_atomic && !ep->absmax_out));
     const long tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn;
     if (!no_peel && plain && splitk <= 1 && tiles >= 512 && (tiles % 256) != 0 && (tiles % 256) <= 160) {
@@ -618,6 +628,14 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
     g.bias = ep->bias; g.drop = ep->drop_mask; g.ldd = ep->ld_drop; g.drop_scale = ep->drop_scale;
     g.ref = ep->relu_ref; g.ldr = ep->ld_ref; g.ref_scale = ep->ref_scale; g.ref_bf16 = ep->ref_dtype == SW_BF16;
     g.relu = ep->relu; g.out_bf16 = ep->out_dtype == SW_BF16; g.atomic = ep->accumulate_atomic; g.absmax = ep->absmax_out;
+    if (!ep->drop_mask && ep->drop_hash_p > 0.f) {
+      unsigned long long x = ep->drop_seed;                  // splitmix64(seed), as the mask kernel mixes it
+      x += 0x9E3779B97F4A7C15ull;
+      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+      x ^= x >> 31;
+      g.drop_seed_mixed = x; g.drop_offset = ep->drop_offset; g.drop_p = ep->drop_hash_p;
+    }
   }
   {
     const long es = dtype == SW_BF16 ? 2 : 4;

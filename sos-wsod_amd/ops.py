@@ -84,7 +84,8 @@ def _need_gpu(*ts):
 
 
 def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_ref=None, ref_scale=1.0,
-                  out_dtype=torch.float32, atomic=False, absmax_out=None):
+                  out_dtype=torch.float32, atomic=False, absmax_out=None, drop_hash=None):
+    """drop_hash=(seed, offset, p): dropout decided in the epilogue by the hash that sw_dropout_mask uses (no mask tensor)"""
     ep = Epilogue()
     ep.bias = None if bias is None else bias.data_ptr()
     ep.relu = int(relu)
@@ -98,6 +99,8 @@ def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_re
     ep.out_dtype = dt(out_dtype)
     ep.accumulate_atomic = int(atomic)
     ep.absmax_out = None if absmax_out is None else absmax_out.data_ptr()
+    if drop_hash is not None and drop_mask is None:
+        ep.drop_seed, ep.drop_offset, ep.drop_hash_p = int(drop_hash[0]) & (2 ** 64 - 1), int(drop_hash[1]), float(drop_hash[2])
     ep._keepalive = (bias, drop_mask, relu_ref, absmax_out)     # the struct holds raw pointers only
     return ep
 

@@ -290,23 +290,23 @@ class OICRPlusHeads(nn.Module):
         D1, D2 = fc1w.shape[0], fc2w.shape[0]
         training_dropout = self.training
         masks = [None, None]
+        hashes = [None, None]
         if training_dropout:
             if self.debug_drop_masks is not None:
                 masks = [torch.cat([self.debug_drop_masks[v][l].to(dev) for v in range(V)], 0).contiguous() for l in range(2)]
-            else:
+            else:                                     # decided inside the fc6 / fc7 epilogues: same stream, no mask tensors
                 for l, d in enumerate((D1, D2)):
-                    m = torch.empty(V * R, d, device=dev, dtype=torch.uint8)
-                    ops.dropout_mask(m, self.dropout_seed, self._drop_counter, 0.5)
-                    self._drop_counter += m.numel()
-                    masks[l] = m
+                    hashes[l] = (self.dropout_seed, self._drop_counter, 0.5)
+                    self._drop_counter += V * R * d
         W1 = self._staged_matrix("fc1", fc1w, dev, transposed=inp["need_grad"])
         W1, W1T = W1 if isinstance(W1, tuple) else (W1, None)
         W2 = self._staged_matrix("fc2", fc2w, dev)
         h1 = _padded(V * R, D1, dev, dt_)
-        ops.gemm(pooled, W1, h1, V * R, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], out_dtype=dt_),
+        ops.gemm(pooled, W1, h1, V * R, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], drop_hash=hashes[0], out_dtype=dt_),
                  tag="fc6_fwd")
         h2 = _padded(V * R, D2, dev, dt_)
-        ops.gemm(h1, W2, h2, V * R, D2, D1, ep=ops.make_epilogue(bias=fc2b, relu=True, drop_mask=masks[1], out_dtype=dt_))
+        ops.gemm(h1, W2, h2, V * R, D2, D1, ep=ops.make_epilogue(bias=fc2b, relu=True, drop_mask=masks[1], drop_hash=hashes[1],
+                                                               out_dtype=dt_))
         # --- all 10 predictor matrices as one GEMM, f32 logits
         Wh, bh = self._pack_head_weights(params, dev)
         LD = self.ld_head

@@ -396,6 +396,21 @@ def test_refine_loss_and_grad(ops, R, K):
     assert torch.all(dl.cpu()[:, :cls_col] == 7.0)             # other columns untouched
 
 
+def test_gemm_hash_dropout_equals_mask_dropout(ops):
+    """dropout decided inside the epilogue (seed, offset, p) == the same GEMM with the keep mask sw_dropout_mask writes"""
+    dt = torch.bfloat16
+    M, N, K = 300, 264, 128
+    A = _rand((M, K), 80, dt).cuda(); B = _rand((N, K), 81, dt).cuda(); bias = _rand((N,), 82).cuda()
+    seed, off = 0x1234567, 777
+    mask = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+    ops.dropout_mask(mask, seed, off, 0.5)
+    assert 0.45 < mask.float().mean().item() < 0.55
+    C1 = torch.empty(M, N, device="cuda", dtype=dt); C2 = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm(A, B, C1, M, N, K, ep=ops.make_epilogue(bias=bias, relu=True, drop_mask=mask, out_dtype=dt))
+    ops.gemm(A, B, C2, M, N, K, ep=ops.make_epilogue(bias=bias, relu=True, drop_hash=(seed, off, 0.5), out_dtype=dt))
+    assert torch.equal(C1, C2)
+
+
 # ------------------------------------------------------------------------------------------ optimizer
 @pytest.mark.parametrize("sdt", DT)
 def test_sgd_multi_matches_single_tensor_steps_and_staging(ops, sdt):
