@@ -85,6 +85,11 @@ class MultiInputRCNN(nn.Module):
             assert k in x
         # the two scales are independent until the ROI heads: run them on two HIP streams so that their ~250-workgroup
         # conv4/conv5 launches (one workgroup per CU each) share the CUs (64 KiB LDS per workgroup -> two per CU)
+        proposals_list = [[x["proposals1"]], [x["proposals1_flip"]], [x["proposals2"]], [x["proposals2_flip"]]]
+        gts = [[x[k]] if k in x else None for k in ("instances1", "instances1_flip", "instances2", "instances2_flip")]
+        prepared = None
+        if hasattr(self.roi_heads, "_prepare_inputs"):
+            prepared = self.roi_heads._prepare_inputs(proposals_list, gts[0], self.device, need_grad=torch.is_grad_enabled())
         x1 = self._views_to_nhwc([x["image1"], x["image1_flip"]])
         x2 = self._views_to_nhwc([x["image2"], x["image2_flip"]])
         if self.dual_stream:
@@ -109,10 +114,11 @@ class MultiInputRCNN(nn.Module):
             f2 = self.backbone.forward_nhwc(x2)
         features1 = {"plain5": f1.permute(0, 3, 1, 2)}
         features2 = {"plain5": f2.permute(0, 3, 1, 2)}
-        proposals_list = [[x["proposals1"]], [x["proposals1_flip"]], [x["proposals2"]], [x["proposals2_flip"]]]
-        gts = [[x[k]] if k in x else None for k in ("instances1", "instances1_flip", "instances2", "instances2_flip")]
         images_list = [None, None, None, None]       # the heads never read pixel data (roi_heads_oicrplus.py:149-188)
-        _, detector_losses = self.roi_heads(images_list, [features1, features2], proposals_list, gts)
+        if prepared is not None:
+            _, detector_losses = self.roi_heads(images_list, [features1, features2], proposals_list, gts, prepared=prepared)
+        else:
+            _, detector_losses = self.roi_heads(images_list, [features1, features2], proposals_list, gts)
         return detector_losses          # no proposal-generator losses to merge (PrecomputedProposals); keeps LossDict.total()
 
     @torch.no_grad()

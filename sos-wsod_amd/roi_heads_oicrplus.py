@@ -455,7 +455,7 @@ class OICRPlusHeads(nn.Module):
         return dict(R=R, G=G, boxes=boxes, obj=obj, rois=rois, gt_int32=gt_i32, gt_onehot=gt_onehot,
                     ones=self._consts[0], pred_view=self._consts[1], need_grad=need_grad)
 
-    def forward(self, images_list, features_list, proposals_list, targets_list=(None, None, None, None)):
+    def forward(self, images_list, features_list, proposals_list, targets_list=(None, None, None, None), prepared=None):
         if not self.training:
             pred_instances, all_scores, all_boxes = self._forward_box_test(features_list, proposals_list, targets_list)
             return pred_instances, {}, all_scores, all_boxes
@@ -463,7 +463,10 @@ class OICRPlusHeads(nn.Module):
         f1 = features1[self.box_in_features[0]]
         f2 = features2[self.box_in_features[0]]
         targets1 = targets_list[0]
-        inp = self._prepare_inputs(proposals_list, targets1, f1.device, need_grad=torch.is_grad_enabled())
+        # `prepared`: the meta-architecture may build the (feature independent) ROI / label tensors before it queues the
+        # backbone, so that those ~10 tiny kernels do not sit between the backbone and ROIPool on the critical path
+        inp = prepared if prepared is not None else self._prepare_inputs(proposals_list, targets1, f1.device,
+                                                                         need_grad=torch.is_grad_enabled())
         self.gt_classes_img_int = [inp["gt_int32"].to(torch.int64)]
         vec = _HeadsTrainFunction.apply(self, inp, f1, f2, *self._flat_params())
         names = loss_names(self.refine_K)
