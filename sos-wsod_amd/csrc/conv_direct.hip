@@ -1,4 +1,4 @@
-// Direct 3x3 convolution (stride 1, pad = dilation, NHWC, bf16) for gfx950: forward and data gradient of conv3..conv5.
+// Direct 3x3 convolution (stride 1, pad = dilation, NHWC, bf16) for gfx950: forward and data gradient of conv1_2..conv5_3.
 //
 // Why a second conv kernel.  The implicit GEMM (gemm.hip) re-fetches every input pixel once per tap: a 128x128 output tile
 // streams 128 x 9*Cin input elements + 128 x 9*Cin weights through the CU.  With 63x63 / 64x64 maps a launch has only
@@ -232,7 +232,7 @@ int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilatio
   if (!ep) return 0;
   if (ep->relu_ref && (ep->ref_dtype != SW_BF16 || ep->ld_ref != Cout || ep->ref_scale != 1.0f)) return 0;
   if ((((uintptr_t)in | (uintptr_t)wk | (uintptr_t)out | (uintptr_t)ep->relu_ref) & 15)) return 0;
-  if (!(sw && sw[0] == '1') && Cin < 128) return 0;          // conv1/conv2 inputs: few channels, huge maps -> implicit GEMM
+  if (!(sw && sw[0] == '1') && Cin < 64) return 0;           // (Cin % 32 == 0 leaves only conv1_1 to the implicit GEMM)
   DirectArgs g = {};
   g.in = in; g.wk = wk; g.out = out; g.bias = ep->bias; g.ref = ep->relu_ref; g.relu = ep->relu;
   g.nimg = nimg; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
