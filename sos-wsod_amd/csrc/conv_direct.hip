@@ -220,6 +220,84 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
   }
 }
 
+// First layer (conv1_1: 3 real input channels padded to 8, 64 output channels, forward only).  As an implicit GEMM its K is
+// 72 and nearly all time went into per-chunk tap arithmetic of the generic loader (100 us for 2 x 512 x 512 pixels whose
+// output alone is 67 MB = 13 us of HBM).  Here K = 9 taps x 8 channels is laid out as 3 MFMA K-steps of 4 taps: the A
+// fragment of (16 pixels, K-step s) is ONE 16-byte load per lane — the 8 channels of the pixel shifted by tap 4s + (lane>>4)
+// (taps 9..11 and out-of-image pixels read as zero) — straight from global memory (the 4 MB input sits in L2), no LDS for
+// the operands; the 12 weight fragments live in registers for the whole kernel.  A wave computes 64 pixels x 64 channels
+// per iteration and writes them as 128-byte pixel rows through a private 8 KiB LDS tile.
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(int nimg, int H, int W, const unsigned short* __restrict__ in,
+                                                            const unsigned short* __restrict__ wk,      // [64][9][8]
+                                                            const float* __restrict__ bias, int relu,
+                                                            unsigned short* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) unsigned short S_all[4][64 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  unsigned short* S = S_all[wave];
+  u32x4 fb[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const int tap = s3 * 4 + kq;
+      fb[j][s3] = tap < 9 ? *(const u32x4*)(wk + ((long)(j * 16 + l15) * 9 + tap) * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+  float bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = bias ? bias[j * 16 + l15] : 0.f;
+  int dy[3], dx[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) { const int tap = s3 * 4 + kq; dy[s3] = tap / 3 - 1; dx[s3] = tap % 3 - 1; }
+  const int segs = (W + 63) / 64;                            // 64-pixel row segments
+  const long nseg = (long)nimg * H * segs;
+  for (long sg = (long)blockIdx.x * 4 + wave; sg < nseg; sg += (long)gridDim.x * 4) {
+    const int xs = (int)(sg % segs) * 64; const long t = sg / segs;
+    const int y = (int)(t % H), img = (int)(t / H);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = xs + i * 16 + l15;
+      u32x4 fa[3];
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int yy = y + dy[s3], xx = x + dx[s3];
+        const bool ok = s3 * 4 + kq < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        fa[s3] = ok ? *(const u32x4*)(in + (((long)img * H + yy) * W + xx) * 8) : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s3]), __builtin_bit_cast(bf16x8, fb[j][s3]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][e] + bv[j];
+          if (relu) v = fmaxf(v, 0.f);
+          const int pl = i * 16 + kq * 4 + e, col = j * 16 + l15;
+          S[pl * 64 + (col ^ ((pl & 7) << 3))] = f32_to_bf16_bits(v);
+        }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * 64 + lane;
+      const int pl = idx >> 3, ch = idx & 7;
+      const int x = xs + pl;
+      if (x < W)
+        *(u32x4*)(out + (((long)img * H + y) * W + x) * 64 + ch * 8) = *(const u32x4*)(S + pl * 64 + ((ch ^ (pl & 7)) << 3));
+    }
+  }
+}
+
 }  // namespace
 
 // Returns 1 if the direct kernel took the launch, 0 if the shape is not covered (caller falls back), < 0 on error.
@@ -227,6 +305,17 @@ int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilatio
                           const sw_epilogue* ep, hipStream_t stream) {
   static const char* sw = getenv("SW_CONV_DIRECT");          // development switch: "0" off, "1" every covered shape
   if (sw && sw[0] == '0') return 0;
+  if (Cin == 8 && Cout == 64 && dilation == 1 && ep && ep->out_dtype == SW_BF16 && !ep->drop_mask && !ep->relu_ref &&
+      !ep->accumulate_atomic && !ep->absmax_out && !(ep->drop_hash_p > 0.f) && !(sw && sw[0] == '2') &&
+      (((uintptr_t)in | (uintptr_t)wk | (uintptr_t)out) & 15) == 0) {
+    const long nseg = (long)nimg * H * ((W + 63) / 64);
+    long blocks = (nseg + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv3x3_first_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, nimg, H, W, (const unsigned short*)in,
+                       (const unsigned short*)wk, ep->bias, ep->relu, (unsigned short*)out);
+    hipError_t e1 = hipGetLastError();
+    return e1 == hipSuccess ? 1 : -(int)e1;
+  }
   if ((Cin % CK) || (Cout % 8) || (dilation != 1 && dilation != 2)) return 0;
   if (ep && (ep->out_dtype != SW_BF16 || ep->drop_mask || ep->accumulate_atomic || ep->absmax_out)) return 0;
   if (!ep) return 0;
