@@ -15,7 +15,7 @@ elif which == "conv3_2":
     ep = ops.make_epilogue(bias=b, relu=True, out_dtype=dt)
     f = lambda: ops.conv3x3(x, wk, out, 1, ep)
 elif which.startswith("wgrad"):
-    n_, H_, W_, cin, cout, dil, sk = {"wgrad5": (2, 63, 63, 512, 512, 2, 3), "wgrad3": (2, 128, 128, 256, 256, 1, 8), "wgrad3s16": (2, 128, 128, 256, 256, 1, 16), "wgrad4": (2, 64, 64, 512, 512, 1, 3)}[which]
+    n_, H_, W_, cin, cout, dil, sk = {"wgrad5": (2, 63, 63, 512, 512, 2, 3), "wgrad3": (2, 128, 128, 256, 256, 1, 8), "wgrad3s16": (2, 128, 128, 256, 256, 1, 16), "wgrad4": (2, 64, 64, 512, 512, 1, 3), "wgrad4s8": (2, 64, 64, 512, 512, 1, 8)}[which]
     x = rnd(n_, H_, W_, cin); dy = rnd(n_, H_, W_, cout); dw = torch.empty(cout, cin, 3, 3, device=dev); ws = torch.empty(cout * 9 * cin, device=dev)
     f = lambda: ops.conv3x3_wgrad(x, dy, dw, dil, splitk=sk, workspace=ws)
 else:

@@ -10,7 +10,7 @@ for sub in ("a","b"):
     for f in glob.glob("$out/%s/*/*counter_collection.csv" % sub):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "gemm" in r["Kernel_Name"] or "conv3x3_direct" in r["Kernel_Name"]:
+            if "gemm" in r["Kernel_Name"] or "conv3x3" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in sorted(acc.items()):
             print(f"{k:28s} {sum(v)/len(v):16.0f}  (n={len(v)})")

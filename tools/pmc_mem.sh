@@ -13,7 +13,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$out/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "gemm" in r["Kernel_Name"] or "conv3x3_direct" in r["Kernel_Name"]:
+        if "gemm" in r["Kernel_Name"] or "conv3x3" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:36s} {sum(v)/len(v):18.0f}  (n={len(v)})")
