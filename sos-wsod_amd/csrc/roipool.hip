@@ -342,6 +342,8 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
   __shared__ int s_cnt;
   word_t* plane = (word_t*)smem;                                   // [H*W] pixels x CB channels
   int* s_list = (int*)(smem + (((size_t)H * W * PXB + 15) & ~(size_t)15));   // [chunk] ROIs of this image
+  unsigned short* s_hb = (unsigned short*)(s_list + chunk);        // [chunk][PH] bin row range  start | end << 8  (H, W <= 255)
+  unsigned short* s_wb = s_hb + chunk * PH;                        // [chunk][PW] bin column range
   const int c0 = blockIdx.x * CB, img = blockIdx.y;
   const int r0 = blockIdx.z * chunk, r1 = min(R, r0 + chunk);
   const int tid = threadIdx.x;
@@ -375,20 +377,32 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
     plane[px] = w;
   }
   __syncthreads();
+  // bin ranges once per (ROI, bin row / column) instead of once per (ROI, bin, channel slab lane): the scan below is
+  // VALU-issue bound (rocprof: 31 VALU instructions per window pixel, a third of them this per-task geometry)
+  for (int i = tid; i < cnt * (PH + PW); i += NT) {
+    const int li = i / (PH + PW), k = i - li * (PH + PW);
+    const RoiGeom g = roi_geom(rois + (long)s_list[li] * 5, scale, PH, PW);
+    if (k < PH) {
+      int hs = (int)floorf(__fmul_rn((float)k, g.bin_h)), he = (int)ceilf(__fmul_rn((float)(k + 1), g.bin_h));
+      hs = min(max(hs + g.start_h, 0), H); he = min(max(he + g.start_h, 0), H);
+      s_hb[li * PH + k] = (unsigned short)(hs | (he << 8));
+    } else {
+      const int pw = k - PH;
+      int ws = (int)floorf(__fmul_rn((float)pw, g.bin_w)), we = (int)ceilf(__fmul_rn((float)(pw + 1), g.bin_w));
+      ws = min(max(ws + g.start_w, 0), W); we = min(max(we + g.start_w, 0), W);
+      s_wb[li * PW + pw] = (unsigned short)(ws | (we << 8));
+    }
+  }
+  __syncthreads();
   const int nb = PH * PW;
   const int total = cnt * nb;
   constexpr unsigned KEY_INIT = 0x007FFFFFu;                       // key(-inf) << 16 | 0xFFFF
   for (int t = tid; t < total; t += NT) {
     const int li = t / nb, b = t - li * nb;
     const int r = s_list[li];
-    const RoiGeom g = roi_geom(rois + (long)r * 5, scale, PH, PW);
     const int ph = b / PW, pw = b - ph * PW;
-    int hs = (int)floorf(__fmul_rn((float)ph, g.bin_h));
-    int ws = (int)floorf(__fmul_rn((float)pw, g.bin_w));
-    int he = (int)ceilf(__fmul_rn((float)(ph + 1), g.bin_h));
-    int we = (int)ceilf(__fmul_rn((float)(pw + 1), g.bin_w));
-    hs = min(max(hs + g.start_h, 0), H); he = min(max(he + g.start_h, 0), H);
-    ws = min(max(ws + g.start_w, 0), W); we = min(max(we + g.start_w, 0), W);
+    const int hb = s_hb[li * PH + ph], wb = s_wb[li * PW + pw];
+    const int hs = hb & 0xFF, he = hb >> 8, ws = wb & 0xFF, we = wb >> 8;
     const bool empty = (he <= hs) || (we <= ws);
     float mv[CB]; int mi[CB];
     if (KEY) {
@@ -466,7 +480,7 @@ template <typename T, int CB, typename IT>
 int launch_fwd_plane(int nimg, int H, int W, int C, long ld, int PH, int PW, float scale, const void* feat, const float* rois, int R,
                      const float* row_scale, float row_scale_add, void* out, void* argmax, hipStream_t stream) {
   constexpr int NT = 1024, CHUNK = 256;
-  const size_t lds = (((size_t)H * W * CB * sizeof(T) + 15) & ~(size_t)15) + CHUNK * sizeof(int);
+  const size_t lds = (((size_t)H * W * CB * sizeof(T) + 15) & ~(size_t)15) + (size_t)CHUNK * (4 + 2 * (PH + PW));
   const bool key = sizeof(T) == 2 && (long)H * W < 65535;
   auto kern = key ? roi_pool_fwd_plane_kernel<T, CB, NT, IT, (sizeof(T) == 2)> : roi_pool_fwd_plane_kernel<T, CB, NT, IT, false>;
   if (lds > 64 * 1024) {
@@ -488,10 +502,10 @@ int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, long ld, int PH, 
   // workgroups per CU when it can (<= 76 KiB each)
   static const bool force_gather = getenv("SW_ROI_FWD_GATHER") != nullptr;    // development switch
   const size_t es = dtype == SW_BF16 ? 2 : 4;
-  if (!force_gather && nimg > 0 && (((uintptr_t)feat) & 15) == 0) {
+  if (!force_gather && nimg > 0 && (((uintptr_t)feat) & 15) == 0 && H <= 255 && W <= 255) {      // 8-bit bin tables
     int pxb = 0;
     for (int cand = 16; cand >= 4 && !pxb; cand >>= 1)
-      if ((C % (cand / (int)es)) == 0 && (size_t)H * W * cand <= 76 * 1024) pxb = cand;
+      if ((C % (cand / (int)es)) == 0 && (size_t)H * W * cand <= 71 * 1024) pxb = cand;   // + 8 KiB of ROI tables: two workgroups per CU
     for (int cand = 16; cand >= 4 && !pxb; cand >>= 1)
       if ((C % (cand / (int)es)) == 0 && (size_t)H * W * cand <= 150 * 1024) pxb = cand;
     if (pxb) {
