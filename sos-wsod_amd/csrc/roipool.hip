@@ -347,10 +347,25 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
   const int c0 = blockIdx.x * CB, img = blockIdx.y;
   const int r0 = blockIdx.z * chunk, r1 = min(R, r0 + chunk);
   const int tid = threadIdx.x;
+  // ROIs of this image, grouped by bin-window size class (counting sort over 8 classes): a wave holds the 49 bins of one
+  // ROI plus 15 of the next, and walks every lane's window to the longest one — neighbours of similar size waste less
+  __shared__ int s_hist[9];
+  if (tid < 9) s_hist[tid] = 0;
   if (tid == 0) s_cnt = 0;
   __syncthreads();
+  int my_cls = -1;                                            // chunk <= NT: at most one ROI per thread
   for (int r = r0 + tid; r < r1; r += NT)
-    if ((int)rois[(long)r * 5] == img) s_list[atomicAdd(&s_cnt, 1)] = r;
+    if ((int)rois[(long)r * 5] == img) {
+      const RoiGeom g0 = roi_geom(rois + (long)r * 5, scale, PH, PW);
+      const float a = g0.bin_h * g0.bin_w;                    // window area in pixels ~ trip count
+      my_cls = a < 2.f ? 0 : a < 4.f ? 1 : a < 8.f ? 2 : a < 14.f ? 3 : a < 22.f ? 4 : a < 34.f ? 5 : a < 52.f ? 6 : 7;
+      atomicAdd(&s_hist[my_cls + 1], 1);
+      atomicAdd(&s_cnt, 1);
+    }
+  __syncthreads();
+  if (tid == 0) { for (int c = 1; c < 9; ++c) s_hist[c] += s_hist[c - 1]; }
+  __syncthreads();
+  if (my_cls >= 0) s_list[atomicAdd(&s_hist[my_cls], 1)] = r0 + tid;
   __syncthreads();
   const int cnt = s_cnt;
   if (cnt == 0) return;
