@@ -201,7 +201,11 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
 // argmax words of 4 ROIs (16-byte aligned, 8 loads in flight) before scattering.
 constexpr int FX_CHUNK = 1024;          // ROIs per compaction round of the fixed-point backward
 
-template <typename T, typename IT>
+// ACC = unsigned long long: 40 fractional-range bits per term (fp32 mode).  ACC = unsigned int (bf16 mode): a pixel-channel
+// receives at most 4 bins of every ROI, so with bits = ceil(log2(4R)) a term may use 30 - bits bits (16 for R = 4000: 2^-16 of
+// the largest term, against bf16's 2^-8 outputs) and the sum cannot overflow; the conversion is then ONE v_cvt_i32_f32 instead
+// of an emulated f32 -> i64 (the kernel is VALU-issue bound: 88 M wave instructions per 4000 ROIs).
+template <typename T, typename IT, typename ACC>
 __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int C, long ld, int nb, int CB,
                                                                const T* __restrict__ dout, const IT* __restrict__ argmax,
                                                                const float* __restrict__ rois, int R,
@@ -216,12 +220,12 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   const int npix_all = H * W;
   const int px_per = (npix_all + gridDim.z - 1) / gridDim.z;
   const int p0 = blockIdx.z * px_per, p1 = min(npix_all, p0 + px_per);
-  unsigned long long* acc = (unsigned long long*)smem;          // [CB][H*W] two's-complement fixed point: the lanes of a wave
+  ACC* acc = (ACC*)smem;          // [CB][H*W] two's-complement fixed point: the lanes of a wave
                                                                 // hold bins of ONE channel => neighbouring pixels => distinct banks
                                                                 // (pixel-major [H*W][CB] put them 64 B apart: 8-16-way conflicts)
   const int img = blockIdx.y, c0 = blockIdx.x * CB;
   const int npix = max(p1 - p0, 0);
-  for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) acc[i] = 0ull;
+  for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) acc[i] = (ACC)0;
   float smax = 0.f;                                             // max |row_scale + add| (wave/block reduce, tiny)
   if (row_scale) { for (int r = threadIdx.x; r < R; r += blockDim.x) smax = fmaxf(smax, fabsf(row_scale[r] + row_scale_add)); }
   else smax = 1.f;
@@ -229,7 +233,8 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   smax = __shfl(smax, 0, 64);
   const float bound = dout_absmax[0] * smax;
   int frac = 0;
-  if (bound > 0.f && bound < 3.0e38f) frac = 40 - (ilogbf(bound) + 1);
+  const int term_bits = sizeof(ACC) == 8 ? 40 : 30 - (32 - __clz(4 * R));
+  if (bound > 0.f && bound < 3.0e38f) frac = term_bits - (ilogbf(bound) + 1);
   __syncthreads();
   // ROIs are taken in chunks of FX_CHUNK: the workgroup first compacts (roi, scale) of the ROIs of ITS image into LDS,
   // then every wave streams 8 listed ROIs per step with all 16 loads issued before the first use — the only global
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   // does not depend on it.
   const int nvec = (CB * nb) / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-  int* s_r = (int*)(smem + (size_t)px_per * CB * 8);
+  int* s_r = (int*)(smem + (size_t)px_per * CB * sizeof(ACC));
   float* s_m = (float*)(s_r + FX_CHUNK);
   for (int rc = 0; rc < R; rc += FX_CHUNK) {
     __syncthreads();                            // previous chunk's list fully consumed (and acc zeroed, first time)
@@ -277,8 +282,13 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
             else d = __uint_as_float(dv[u][e]);
             const int cc = (j * 4 + e) / nb;
             if (a >= p0 && a < p1) {
-              const long long q = __float2ll_rn(scalbnf(__fmul_rn(d, mul), frac));
-              atomicAdd(&acc[cc * npix + (a - p0)], (unsigned long long)q);
+              if (sizeof(ACC) == 8) {
+                const long long q = __float2ll_rn(scalbnf(__fmul_rn(d, mul), frac));
+                atomicAdd((unsigned long long*)&acc[cc * npix + (a - p0)], (unsigned long long)q);
+              } else {
+                const int q = __float2int_rn(scalbnf(__fmul_rn(d, mul), frac));
+                atomicAdd((unsigned int*)&acc[cc * npix + (a - p0)], (unsigned int)q);
+              }
             }
           }
         }
@@ -290,7 +300,8 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   const T* rimg = relu_ref ? relu_ref + ((long)img * npix_all + p0) * C : nullptr;
   for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) {
     const int p = i / CB, cc = i - p * CB;
-    float v = scalbnf((float)(long long)acc[cc * npix + p], -frac);
+    float v = sizeof(ACC) == 8 ? scalbnf((float)(long long)acc[cc * npix + p], -frac)
+                               : scalbnf((float)(int)acc[cc * npix + p], -frac);
     if (rimg && !(Elem<T>::load(rimg + (long)p * C + c0 + cc) > 0.f)) v = 0.f;
     Elem<T>::store(dimg + (long)p * C + c0 + cc, v);
   }
@@ -560,20 +571,32 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, con
                      void* dfeat, hipStream_t stream) {
   // fixed-point path: CB in {8, 4} with H*W*CB*8 bytes of LDS; needs max|dout| (device scalar)
   static const bool float_atomics = getenv("SW_ROI_FLOAT_ATOMICS") != nullptr;    // development switch
+  // bf16: 32-bit accumulators (see the kernel) when 4R terms leave >= 12 bits per term; fp32: 64-bit
+  const bool acc32 = sizeof(T) == 2 && R > 0 && (30 - (32 - __builtin_clz((unsigned)(4 * R)))) >= 12;
+  const size_t ab = acc32 ? 4 : 8;
   int cbx = 8;
-  while (cbx > 4 && ((size_t)H * W * cbx * 8 > 128 * 1024 || (C % cbx))) cbx >>= 1;
+  while (cbx > 4 && ((size_t)H * W * cbx * ab > 128 * 1024 || (C % cbx) || (C / cbx) * nimg < 256)) cbx >>= 1;
   if (C % cbx) cbx = 0;
-  const int nsplit = cbx ? (int)(((size_t)H * W * cbx * 8 + 128 * 1024 - 1) / (128 * 1024)) : 1;   // pixel ranges per plane
+  const int nsplit = cbx ? (int)(((size_t)H * W * cbx * ab + 128 * 1024 - 1) / (128 * 1024)) : 1;   // pixel ranges per plane
   if (cbx >= 4 && nsplit <= 16 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) && (ld % 4) == 0 &&
       !float_atomics) {
     const int px_per = (H * W + nsplit - 1) / nsplit;
-    const size_t ldsx = (size_t)px_per * cbx * 8 + FX_CHUNK * 8;
+    const size_t ldsx = (size_t)px_per * cbx * ab + FX_CHUNK * 8;
     dim3 gridx(C / cbx, nimg, nsplit), blockx(1024);
-    auto k = roi_pool_bwd_fx_kernel<T, IT>;
-    hipError_t ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
-    if (ex != hipSuccess) return (int)ex;
-    hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, ld, PH * PW, cbx, (const T*)dout, (const IT*)argmax, rois, R,
-                       row_scale, row_scale_add, dout_absmax, (const T*)relu_ref, (T*)dfeat);
+    hipError_t ex;
+    if (acc32) {
+      auto k = roi_pool_bwd_fx_kernel<T, IT, unsigned int>;
+      ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+      if (ex != hipSuccess) return (int)ex;
+      hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, ld, PH * PW, cbx, (const T*)dout, (const IT*)argmax, rois, R,
+                         row_scale, row_scale_add, dout_absmax, (const T*)relu_ref, (T*)dfeat);
+    } else {
+      auto k = roi_pool_bwd_fx_kernel<T, IT, unsigned long long>;
+      ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+      if (ex != hipSuccess) return (int)ex;
+      hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, ld, PH * PW, cbx, (const T*)dout, (const IT*)argmax, rois, R,
+                         row_scale, row_scale_add, dout_absmax, (const T*)relu_ref, (T*)dfeat);
+    }
     SW_CHECK_LAUNCH();
     return 0;
   }
