@@ -2,7 +2,7 @@
 (/root/reference, imported through ref_shim.py) on closed-form inputs.
 
 Run in the build container only:   python tests/golden/make_golden.py
-Outputs: tests/golden/e2e_<case>.npz, tests/golden/mining_<case>.npz, tests/golden/infer_s0.npz
+Outputs: tests/golden/e2e_<case>.npz, tests/golden/mining_<case>.npz, tests/golden/infer_s0.npz, tests/golden/input_a.npz
 
 The fixtures hold inputs' recipe (detgen tags/shapes -> regenerated, not stored), the
 reference's outputs (losses, mined pseudo-GT, labels, scores, gradient samples) and nothing
@@ -218,9 +218,55 @@ def run_infer(case="s0"):
           f"max|score diff| {np.abs(np.sort(o['scores'])[::-1][:n] - np.sort(out['scores'])[::-1]).max():.2e}")
 
 
+def input_case_boxes(seed=0, n=600, h=375, w=500):
+    """synthetic proposal list in an (h, w) image: integer-cornered boxes (selective-search style) with exact duplicates,
+    sub-pixel near-duplicates that only collide after a resize, zero-area boxes and boxes on the border"""
+    rng = np.random.RandomState(seed)
+    x1 = rng.randint(0, w - 2, n); y1 = rng.randint(0, h - 2, n)
+    x2 = np.minimum(x1 + rng.randint(1, w, n), w - 1); y2 = np.minimum(y1 + rng.randint(1, h, n), h - 1)
+    b = np.stack([x1, y1, x2, y2], 1).astype(np.float32)
+    b[50:80] = b[10:40]                                   # exact duplicates
+    b[100:120] = b[200:220] + np.float32(0.24)            # collide after rounding
+    b[130:140, 2] = b[130:140, 0]                         # zero width
+    b[140:150, 3] = b[140:150, 1]                         # zero height
+    b[150:155] = [0, 0, w - 1, h - 1]                     # whole image, repeated
+    b[160:170, 2] = b[160:170, 0] + 1                     # 1 px wide: may collapse under a down-scale + round
+    logits = rng.rand(n).astype(np.float32)
+    return b, logits
+
+
+def run_input(case="a"):
+    """masks of the reference's own `Boxes.clip / unique_boxes / nonempty` (structures/boxes.py) on the four views of
+    `DatasetMapperMultiInput`; the fvcore box transforms are the restated rule (oracle/input_oracle.py)."""
+    from oracle import input_oracle as IO
+    if not hasattr(np, "int"):
+        np.int = int                                       # boxes.py:224 uses the alias numpy 2 removed
+    h, w = 375, 500
+    boxes, logits = input_case_boxes(0, 600, h, w)
+    hw1 = IO.shortest_edge_shape(h, w, 480, 2000)
+    hw2 = IO.shortest_edge_shape(h, w, 1200, sys.maxsize)
+    out = {"orig_hw": np.array([h, w]), "hw1": np.array(hw1), "hw2": np.array(hw2), "boxes": boxes, "logits": logits}
+    joint = None
+    for name, hw, flip in (("1", hw1, False), ("2", hw2, False), ("1_flip", hw1, True), ("2_flip", hw2, True)):
+        tb = Boxes(torch.from_numpy(IO.apply_box(boxes, (h, w), hw, flip)))
+        tb.clip(hw)
+        final_keep = torch.zeros(len(tb)).bool()
+        final_keep[tb.unique_boxes()] = True
+        final_keep = final_keep & tb.nonempty(threshold=0)
+        out["boxes" + name] = tb.tensor.numpy().copy()
+        out["keep" + name] = final_keep.numpy().copy()
+        joint = final_keep if joint is None else joint & final_keep
+    out["keep"] = joint.numpy()
+    np.savez_compressed(os.path.join(HERE, f"input_{case}.npz"), **out)
+    print(f"[input {case}] views {hw1} {hw2}; kept {int(joint.sum())} of {len(boxes)}; "
+          + " ".join(f"{k}={int(out['keep' + k].sum())}" for k in ("1", "2", "1_flip", "2_flip")))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["e2e", "mining", "infer"]
+    which = sys.argv[1:] or ["e2e", "mining", "infer", "input"]
+    if "input" in which:
+        run_input("a")
     if "mining" in which:
         run_mining("a", 500, 20, 3, 0)
         run_mining("b", 2000, 80, 5, 1)

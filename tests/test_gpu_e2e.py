@@ -432,3 +432,35 @@ def test_tta_avg_merge(golden_dir):
     bx = out.pred_boxes.tensor
     assert (bx[:, 0] >= 0).all() and (bx[:, 2] <= w).all() and (bx[:, 1] >= 0).all() and (bx[:, 3] <= h).all()
     assert (out.scores[:-1] >= out.scores[1:]).all()
+
+
+def test_multi_input_mapper_device(golden_dir):
+    """the multi-view training mapper (dataset_mapper.py:272-425) on the device: proposal boxes / keep masks bit-exact
+    against the masks of the reference's own Boxes class (tests/golden/input_a.npz), and its output feeds one training
+    iteration directly (VOC-sized image, two drawn scales, four index-aligned proposal sets)"""
+    from test_mapper_cpu import check_mapper_against_golden
+    from sos_wsod_amd.events import EventStorage
+    from sos_wsod_amd.mapper import DeviceMultiInputMapper
+    check_mapper_against_golden("cuda")
+    g = np.load(os.path.join(golden_dir, "input_a.npz"))
+    h, w = (int(v) for v in g["orig_hw"])
+    dev = torch.device("cuda", 0)
+    img = torch.randint(0, 256, (3, h, w), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).to(dev)
+    d = {"image": img, "proposal_boxes": g["boxes"], "proposal_objectness_logits": g["logits"],
+         "annotations": [{"bbox": [30.0, 40.0, 300.0, 330.0], "category_id": 4},
+                         {"bbox": [200.0, 10.0, 480.0, 200.0], "category_id": 17}]}
+    mapper = DeviceMultiInputMapper(min_sizes=(480, 576, 688), max_size=2000, seed=5)
+    data = [mapper(d)]
+    n = len(data[0]["proposals1"].proposal_boxes)
+    assert all(len(data[0]["proposals" + k].proposal_boxes) == n for k in ("1", "2", "1_flip", "2_flip"))
+    assert data[0]["image1"].shape != data[0]["image2"].shape and data[0]["image1"].is_cuda
+    model = build_model(20, (256, 256), torch.bfloat16)
+    model.train()
+    with EventStorage(0):
+        losses = model(data)
+        losses.total().backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(losses.vector).all()
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name

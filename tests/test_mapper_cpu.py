@@ -1,0 +1,105 @@
+"""Multi-view training mapper, box side: the numpy restatement against the golden masks produced by the
+reference's own `Boxes` class, and the package's tensor implementation against both.  Host logic — runs without a GPU
+(the same checks run on the device in tests/test_gpu_e2e.py::test_multi_input_mapper_device)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "input_a.npz")
+VIEWS = (("1", "hw1", False), ("2", "hw2", False), ("1_flip", "hw1", True), ("2_flip", "hw2", True))
+
+
+def test_oracle_matches_reference_masks():
+    from oracle import input_oracle as IO
+    g = np.load(GOLD)
+    ohw = tuple(g["orig_hw"])
+    assert IO.shortest_edge_shape(*ohw, 480, 2000) == tuple(g["hw1"])
+    joint = None
+    for name, hwk, flip in VIEWS:
+        b, _, keep = IO.transform_proposals_multi(g["boxes"], g["logits"], ohw, tuple(g[hwk]), flip, topk=10 ** 6)
+        assert np.array_equal(b, g["boxes" + name])
+        assert np.array_equal(keep, g["keep" + name])
+        joint = keep if joint is None else joint & keep
+    assert np.array_equal(joint, g["keep"])
+    assert 0 < joint.sum() < len(joint)                         # the case does exercise the masks
+
+
+def check_mapper_against_golden(device):
+    from sos_wsod_amd.mapper import DeviceMultiInputMapper
+    g = np.load(GOLD)
+    h, w = (int(v) for v in g["orig_hw"])
+    img = torch.randint(0, 256, (3, h, w), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(device)
+    d = {"image": img, "proposal_boxes": g["boxes"], "proposal_objectness_logits": g["logits"], "image_id": 7,
+         "annotations": [{"bbox": [10.5, 20.0, 200.25, 300.0], "category_id": 3},
+                         {"bbox": [0.0, 0.0, 499.0, 374.0], "category_id": 11, "iscrowd": 0},
+                         {"bbox": [5.0, 5.0, 50.0, 50.0], "category_id": 1, "iscrowd": 1}]}
+    m = DeviceMultiInputMapper(proposal_topk=2000)
+    out = m(d, shapes=(tuple(int(v) for v in g["hw1"]), tuple(int(v) for v in g["hw2"])))
+    keep = g["keep"]
+    for name, hwk, flip in VIEWS:
+        p = out["proposals" + name]
+        assert tuple(p.image_size) == tuple(g[hwk])
+        assert p.proposal_boxes.tensor.device.type == torch.device(device).type
+        assert np.array_equal(p.proposal_boxes.tensor.cpu().numpy(), g["boxes" + name][keep])       # bit-exact float32
+        assert np.array_equal(p.objectness_logits.cpu().numpy(), g["logits"][keep])
+        im = out["image" + name]
+        assert im.dtype == torch.uint8 and tuple(im.shape) == (3, *g[hwk])
+        inst = out["instances" + name]
+        assert inst.gt_classes.tolist() == [3, 11]                                                   # crowd dropped
+    assert torch.equal(out["image1_flip"], out["image1"].flip(-1)) and torch.equal(out["image2_flip"], out["image2"].flip(-1))
+    assert out["image_id"] == 7 and "proposal_boxes" not in out and "annotations" not in out
+    # annotation boxes against the float64 restatement
+    from oracle import input_oracle as IO
+    gt = np.array([[10.5, 20.0, 200.25, 300.0], [0.0, 0.0, 499.0, 374.0]])
+    for name, hwk, flip in VIEWS:
+        want = IO.transform_annotation_boxes(gt, (h, w), tuple(g[hwk]), flip)
+        assert np.array_equal(out["instances" + name].gt_boxes.tensor.cpu().numpy(), want)
+    # flipped view: x-mirror of the plain view, row for row
+    b1, b1f = out["proposals1"].proposal_boxes.tensor, out["proposals1_flip"].proposal_boxes.tensor
+    W1 = float(g["hw1"][1])
+    assert torch.equal(b1f[:, 0], W1 - b1[:, 2]) and torch.equal(b1f[:, 2], W1 - b1[:, 0]) and torch.equal(b1f[:, 1], b1[:, 1])
+
+
+def test_mapper_matches_reference_masks_cpu():
+    check_mapper_against_golden("cpu")
+
+
+def test_unique_mask_against_oracle_random():
+    from oracle import input_oracle as IO
+    from sos_wsod_amd.mapper import unique_boxes_mask
+    rng = np.random.RandomState(3)
+    for n in (0, 1, 5, 1000):
+        b = (rng.randint(0, 40, (n, 4)) + rng.choice([0.0, 0.5, 0.49, 0.51], (n, 4))).astype(np.float32)
+        assert np.array_equal(unique_boxes_mask(torch.from_numpy(b)).numpy(), IO.unique_mask(b) if n else np.zeros(0, bool))
+
+
+def test_scale_draw_rules():
+    from sos_wsod_amd.mapper import DeviceMultiInputMapper
+    m = DeviceMultiInputMapper(seed=0)
+    seen = set()
+    for _ in range(200):
+        hw1, hw2 = m._draw_shapes(375, 500)
+        assert hw1 != hw2 and min(hw1) in m.min_sizes and min(hw2) in m.min_sizes
+        seen.add((min(hw1), min(hw2)))
+    assert len(seen) > 20                                       # both draws cover the size list
+    # first view honours max_size, the second is uncapped like the reference's rebuilt ResizeShortestEdge
+    m2 = DeviceMultiInputMapper(min_sizes=(800, 1200), max_size=1000, seed=1)
+    hw1, hw2 = m2._draw_shapes(300, 900)
+    assert max(hw1) <= 1000 and max(hw2) > 1000
+    with pytest.raises(AssertionError):
+        DeviceMultiInputMapper(min_sizes=(480,))
+
+
+def test_topk_slice_keeps_alignment():
+    from sos_wsod_amd.mapper import DeviceMultiInputMapper
+    g = np.load(GOLD)
+    h, w = (int(v) for v in g["orig_hw"])
+    d = {"image": torch.zeros(3, h, w, dtype=torch.uint8), "proposal_boxes": g["boxes"],
+         "proposal_objectness_logits": g["logits"]}
+    out = DeviceMultiInputMapper(proposal_topk=100)(d, shapes=((480, 640), (1200, 1600)))
+    n = int(g["keep"][:100].sum())
+    for name, _, _ in VIEWS:
+        assert len(out["proposals" + name].proposal_boxes) == n
+        assert np.array_equal(out["proposals" + name].objectness_logits.numpy(), g["logits"][:100][g["keep"][:100]])
