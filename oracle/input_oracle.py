@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY (see oracle/README.md): numpy restatement of the box side of the reference's multi-view
+"""TEST INFRASTRUCTURE ONLY: numpy restatement of the box side of the reference's multi-view
 training mapper.  Only tests/ may import this file.
 
 Follows
