@@ -119,8 +119,10 @@ class _VGGFunction(torch.autograd.Function):
                     dw = torch.empty(blk.out_channels, cin, 3, 3, device=g.device, dtype=torch.float32)
                     npix = n * H * W
                     tiles = ((blk.out_channels + 127) // 128) * ((9 * cin + 127) // 128)
-                    # ~300 workgroups per launch, at most 8 K-splits (tools/wgrad_sweep.py: more splits only add atomics)
-                    splitk = max(1, min(8, (300 + tiles - 1) // tiles, max(1, npix // 1024)))
+                    # one resident wave of workgroups: 256 CUs x 2 (64 KiB LDS each) = 512 slots; tiles * splits just under
+                    # that was the optimum for every conv3..conv5 shape (tools/wgrad_sweep.py: 3 / 7 / 14 / 28 splits), one
+                    # more split starts a second, mostly empty wave (+30 %)
+                    splitk = max(1, min(32, 512 // tiles, max(1, npix // 1024)))
                     ops.conv3x3_wgrad(x_in, dz, dw, blk.dilation, splitk=splitk)
                     grads[pidx] = dw[:, : w.shape[1]].contiguous() if cin != w.shape[1] else dw
                     db = torch.empty(blk.out_channels, device=g.device, dtype=torch.float32)

@@ -11,7 +11,7 @@ for name, n, H, W, cin, cout, dil in [("conv5_3", 2, 63, 63, 512, 512, 2), ("con
     dw = torch.empty(cout, cin, 3, 3, device=dev); ws = torch.empty(32 * cout * 9 * cin, device=dev)
     fl = 2.0 * n * H * W * cout * 9 * cin
     res = []
-    for sk in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+    for sk in [int(s) for s in os.environ.get("SKS", "1,2,3,4,6,8,12,16,24,32").split(",")]:
         t = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw, dil, splitk=sk, workspace=ws))
         res.append(f"sk{sk}:{t*1e3:.0f}us")
     print(name, f"{fl/1e9:.1f}GF", " ".join(res))
