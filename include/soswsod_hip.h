@@ -189,8 +189,12 @@ int sw_detect_postprocess(int R, int K, const float* all_scores, const float* al
                           sw_stream_t stream);
 
 /* ---- small utilities ------------------------------------------------------------------------------------ */
-/* out[n] = sum_m X[m][ld..] (column sums; bias gradients).  out f32, overwritten. */
-int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, sw_stream_t stream);
+/* out[n] = sum_m X[m][ld..] (column sums; the bias gradients of the reference's conv / Linear backward).  out f32,
+ * overwritten.  With `workspace` (sw_colsum_workspace_floats floats) the sum is deterministic: partial rows per row chunk,
+ * then an ordered fold.  workspace NULL (or N / ld not a multiple of 16 bytes): zero fill + one f32 atomic per column and
+ * row chunk. */
+long sw_colsum_workspace_floats(int dtype, int M, int N);
+int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, float* workspace, sw_stream_t stream);
 /* rows x cols copy/convert f32 -> dtype with independent leading dimensions (weight staging). */
 int sw_convert_2d(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
                   sw_stream_t stream);

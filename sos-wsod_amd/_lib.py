@@ -78,7 +78,8 @@ SIGNATURES = {
     "sw_detect_workspace_bytes": (c_long, [c_int, c_int]),
     "sw_detect_postprocess": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "sw_colsum": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p]),
+    "sw_colsum": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "sw_colsum_workspace_floats": (c_long, [c_int, c_int, c_int]),
     "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_relu_bwd": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),

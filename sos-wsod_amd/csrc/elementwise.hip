@@ -259,6 +259,66 @@ __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, int rows_per_
     atomicAdd(out + col, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
+// Workspace form (the one the training step uses): no zero fill, no atomics, deterministic.  Two launches:
+//  1. grid = (column slabs of 32 x 16 bytes, row chunks).  A thread streams 16-byte row pieces (8 bf16 / 4 f32 columns) of
+//     every 8th row of its chunk; the workgroup folds its 8 row-lanes through LDS and stores one partial row of the slab
+//     into workspace[chunk][N];
+//  2. colsum_fold_kernel adds the partial rows in fixed order.
+// (A single launch whose last workgroup folds — ticket counter + __threadfence — was measured 20 us SLOWER per call: an
+// agent-scope release on this part writes the XCD's whole L2 back, once per workgroup.)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_ws_kernel(int M, int N, int rows_per_chunk, const T* __restrict__ X, long ld,
+                                                        float* __restrict__ ws) {
+  constexpr int VEC = 16 / (int)sizeof(T), SLAB = 32 * VEC;
+  __shared__ float part[8][SLAB + 4];
+  const int tid = threadIdx.x, l32 = tid & 31, rsub = tid >> 5;
+  const int slab = blockIdx.x, chunk = blockIdx.y;
+  const int c0 = slab * SLAB + l32 * VEC;
+  const int m0 = chunk * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  if (c0 < N) {                                              // N % VEC == 0 (host): a 16-byte piece is all in or all out
+    const T* col = X + c0;
+#pragma unroll 4
+    for (int m = m0 + rsub; m < m1; m += 8) {
+      const u32x4 q = *(const u32x4*)(col + (long)m * ld);
+      if (sizeof(T) == 2) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          acc[2 * v] += __uint_as_float(q[v] << 16);
+          acc[2 * v + 1] += __uint_as_float(q[v] & 0xFFFF0000u);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] += __uint_as_float(q[v]);
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) part[rsub][l32 * VEC + v] = acc[v];
+  __syncthreads();
+  for (int c = tid; c < SLAB; c += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += part[r][c];
+    if (slab * SLAB + c < N) ws[(long)chunk * N + slab * SLAB + c] = s;
+  }
+}
+
+// out[n] = sum_c ws[c][n]: a workgroup owns 64 columns; 4 chunk-lanes x 64 columns, chunks in fixed order per lane, lanes in
+// fixed order
+__global__ __launch_bounds__(256) void colsum_fold_kernel(int N, int nchunk, const float* __restrict__ ws, float* __restrict__ out) {
+  __shared__ float fold[4][64];
+  const int tid = threadIdx.x, cl = tid >> 6, col = blockIdx.x * 64 + (tid & 63);
+  float f = 0.f;
+  if (col < N)
+    for (int c = cl; c < nchunk; c += 4) f += ws[(long)c * N + col];
+  fold[cl][tid & 63] = f;
+  __syncthreads();
+  if (cl == 0 && col < N) out[col] = (fold[0][tid] + fold[1][tid]) + (fold[2][tid] + fold[3][tid]);
+}
+
 // ---------------------------------------------------------------- dropout keep mask
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -676,9 +736,46 @@ extern "C" int sw_scale_cols(int dtype, int M, int N, const float* in, long ld_i
   return 0;
 }
 
-extern "C" int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, hipStream_t stream) {
+namespace {
+// (slabs, chunks) of the workspace form: ~512 workgroups, >= 32 rows per chunk and <= 128 partial rows
+void colsum_ws_geometry(int dtype, int M, int N, int* slabs, int* chunks, int* rpc) {
+  const int slab_cols = dtype == SW_BF16 ? 256 : 128;
+  *slabs = (N + slab_cols - 1) / slab_cols;
+  int c = 512 / *slabs;
+  c = c < 1 ? 1 : (c > 128 ? 128 : c);
+  int r = (M + c - 1) / c;
+  if (r < 32) r = 32;
+  *rpc = r;
+  *chunks = (M + r - 1) / r;
+}
+}  // namespace
+
+extern "C" long sw_colsum_workspace_floats(int dtype, int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  int slabs, chunks, rpc;
+  colsum_ws_geometry(dtype, M, N, &slabs, &chunks, &rpc);
+  return (long)chunks * N;
+}
+
+extern "C" int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, float* workspace, hipStream_t stream) {
   SW_ENTER();
   if (N <= 0) return 0;
+  if (dtype != SW_BF16 && dtype != SW_F32) return -1;
+  const int vec = dtype == SW_BF16 ? 8 : 4;
+  const bool ws_form = workspace && M > 0 && (N % vec) == 0 && (ld % vec) == 0 && (((uintptr_t)X) & 15) == 0;
+  if (ws_form) {
+    int slabs, chunks, rpc;
+    colsum_ws_geometry(dtype, M, N, &slabs, &chunks, &rpc);
+    dim3 grid(slabs, chunks);
+    DISPATCH_T(dtype,
+      hipLaunchKernelGGL(colsum_ws_kernel<unsigned short>, grid, dim3(256), 0, stream, M, N, rpc, (const unsigned short*)X, ld,
+                         workspace),
+      hipLaunchKernelGGL(colsum_ws_kernel<float>, grid, dim3(256), 0, stream, M, N, rpc, (const float*)X, ld, workspace));
+    SW_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, N, chunks, workspace, out);
+    SW_CHECK_LAUNCH();
+    return 0;
+  }
   hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
   if (M <= 0) return 0;

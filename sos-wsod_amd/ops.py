@@ -309,7 +309,10 @@ def oicr_refine_loss(logits, V, R, K, cls_col, box_col, boxes, lab_class, lab_we
 
 
 def colsum(X, M, N, out, ld=None):
-    check(lib.sw_colsum(dt(X), M, N, _p(X), X.stride(0) if ld is None else ld, _p(out), _stream()), "sw_colsum")
+    """out[n] = sum_m X[m, n] (f32), deterministic: partial rows per row chunk + an ordered fold (no zero fill, no atomics)"""
+    need = int(lib.sw_colsum_workspace_floats(dt(X), M, N))
+    ws = torch.empty(max(need, 4), device=X.device, dtype=torch.float32)
+    check(lib.sw_colsum(dt(X), M, N, _p(X), X.stride(0) if ld is None else ld, _p(out), _p(ws), _stream()), "sw_colsum")
     return out
 
 

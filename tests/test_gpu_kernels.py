@@ -500,3 +500,35 @@ def test_detect_postprocess_vs_oracle(ops, R, K):
     assert n == len(keep)
     assert np.array_equal(dclasses[:n].cpu().numpy(), c_idx[keep]) and np.array_equal(drows[:n].cpu().numpy(), r_idx[keep])
     assert np.array_equal(dscores[:n].cpu().numpy(), ssel[keep]) and np.array_equal(dboxes[:n].cpu().numpy(), bsel[keep])
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,pad", [(8192, 512, 0), (8000, 4096, 128), (32768, 256, 0), (1, 64, 0), (33, 264, 8), (1001, 130, 0),
+                                     (700, 24, 4), (5000, 20000, 0)])
+def test_colsum_workspace_form(ops, dtype, M, N, pad):
+    """bias gradients: deterministic partial-row form (16-byte loads, ordered fold) and the atomic fallback for shapes it
+    does not cover (N or the row pitch not a multiple of 16 bytes), repeated and on a second stream"""
+    X = (torch.randn(M, N + pad, generator=torch.Generator().manual_seed(M + N)) * 2).to(dtype).cuda()[:, :N]
+    want = X.double().sum(0).cpu().numpy()
+    tol = dict(rtol=2e-5, atol=2e-5 * float(np.sqrt(M)) * 4)
+    outs = []
+    for rep in range(3):
+        cs = torch.full((N,), float("nan"), device="cuda")
+        ops.colsum(X, M, N, cs)
+        np.testing.assert_allclose(cs.cpu().numpy(), want, **tol)
+        outs.append(cs)
+    vec = 8 if dtype == torch.bfloat16 else 4
+    if N % vec == 0 and (N + pad) % vec == 0:
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])          # deterministic
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    cs_a = torch.empty(N, device="cuda"); cs_b = torch.empty(N, device="cuda")
+    with torch.cuda.stream(side):
+        for _ in range(4):
+            ops.colsum(X, M, N, cs_b)
+    for _ in range(4):
+        ops.colsum(X, M, N, cs_a)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(cs_a.cpu().numpy(), want, **tol)
+    np.testing.assert_allclose(cs_b.cpu().numpy(), want, **tol)
