@@ -205,6 +205,20 @@ def main():
             entry = json.load(open(pmc)).get(dom)                     # HBM bytes per launch: (2*FETCH_SIZE + WRITE_SIZE)*1024
             roofline["traffic"] = entry["hbm_bytes_per_launch"] if entry else None
             roofline["algorithmic_bytes"] = entry["algorithmic_bytes"] if entry else None
+        # counter-based MFMA utilisation of the same kernels run alone (tools/pmc_mfma.sh, committed under profiles/):
+        # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32).  The FLOP-based `frac` prices against the 2.4 GHz peak;
+        # under MFMA load the chip runs 1.6-2.0 GHz (DVFS), so the pipe is busier than `frac` says.
+        busy_path = os.path.join(ROOT, "profiles", "r01_mfma_busy.json")
+        busy = json.load(open(busy_path)) if os.path.exists(busy_path) else {}
+
+        def busy_of(shape):
+            ent = busy.get(shape) or {}
+            if not ent:
+                return None
+            k = max(ent, key=lambda n: ent[n]["SQ_VALU_MFMA_BUSY_CYCLES"])       # the main launch (not a split-K tail)
+            return {"mfma_busy_frac": ent[k]["mfma_busy_frac"], "effective_clock_GHz": ent[k]["effective_clock_GHz"],
+                    "source": "profiles/r01_mfma_busy.json (rocprofv3 --pmc, kernel alone)"}
+        roofline["mfma_busy_counter"] = busy_of(dom)
         out = {
             "metric": "images/s (1/2/4/8 MI355X) VGG16+OICR 2000-prop; conv5_3 MFMA-util %",
             "value": round(4.0 * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -220,7 +234,7 @@ def main():
                                        "achieved": round(flops["plain5.conv3_fwd"] / (conv_alone_ms * 1e-3) / 1e12, 2),
                                        "peak": peak, "unit": "TFLOP/s",
                                        "frac": round(flops["plain5.conv3_fwd"] / (conv_alone_ms * 1e-3) / 1e12 / peak, 4),
-                                       "avg_ms": round(conv_alone_ms, 4)},
+                                       "avg_ms": round(conv_alone_ms, 4), "mfma_busy_counter": busy_of("conv5_3")},
             "kernel_ms_per_step": {t: round(v, 3) for t, v in tot_ms.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -15,11 +15,6 @@
 // buffered per (chunk, tap row); both staged with LDS-DMA buffer loads whose per-lane offsets are fixed for the whole
 // kernel (image border / ragged edge = offset beyond num_records -> zero fill), the chunk / tap row advance is the
 // wave-uniform SGPR offset.  One barrier per 3 taps (48 MFMAs per wave).  79.9 KiB LDS -> two workgroups per CU.
-// vmcnt accounting (DEPTH >= 3): per wave the issue order is  prologue: patch(0), weights(0..DEPTH-2);  step t: weights
-// (t+DEPTH-1), then patch(chunk+1) if t opens a chunk — every wave issues the same counts (3 per tap row, APW per patch).
-// Loads complete in order, so the data of step s is complete once at most the instructions issued after weights(s) remain:
-// 3 per step in between, + APW for every chunk-opening step among them, + APW if the step that issued weights(s) opened a
-// chunk and that patch belongs to a LATER chunk than s (true for DEPTH 3, false for DEPTH 4 at tap row 0).
 // 64-byte LDS rows (one pixel or one output channel x 32 input channels): 16-byte position = K chunk ^ (((row >> 2) & 1) << 1).
 // ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md): with this
 // XOR the 16 lanes of every group hit 64 distinct banks for ANY start row, i.e. for every tap shift (found by exhaustive
@@ -43,11 +38,20 @@ struct DirectArgs {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// DEPTH = weight tap-row buffers (prefetch distance DEPTH-1 steps).  2: 80 KiB LDS, two workgroups per CU (layers with >= 2
-// workgroups per CU); 4: 104 KiB, for the 63x63 / 64x64 layers whose 256 workgroups leave one per CU — there a step (48
-// MFMAs ~ 800 cycles) is shorter than a loaded L2 round trip and distance 1 made every step wait for its weights.
-template <int DIL, int DEPTH, int TN>
-__global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel(DirectArgs g) {
+// (Deeper weight rings — 3 / 4 tap-row buffers with counted vmcnt — were tried for the one-workgroup-per-CU layers and
+// dropped: equal or slower than two waves per SIMD, and the K-group form below needs the LDS.)
+//
+// KG = 2 (the 63x63 / 64x64 layers, conv4_x / conv5_x at a 512x512 input): EIGHT waves, two groups of four; group k walks the
+// input-channel chunks 2c + k with its own staging buffers (exactly the four-wave kernel, on alternate chunks, sharing the
+// barriers), and the two partial accumulators are exchanged through LDS at the end (group k finishes tile row 2w + k of its
+// wave pair).  Those layers have only ~256 tiles of 256 pixels x 64 channels: one four-wave workgroup per CU leaves one wave
+// per SIMD (nothing to overlap LDS latency with), 32-channel tiles give two waves per SIMD but read 0.75 KiB of LDS per MFMA
+// (6 fragments per 8 MFMAs; the LDS pipe delivers 0.5 KiB in the time of one MFMA per SIMD).  Splitting K inside the
+// workgroup gives two waves per SIMD at 0.5 KiB per MFMA and 30 % fewer bytes staged per output.  160 KiB LDS at dilation 2.
+template <int DIL, int TN, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_direct_kernel(DirectArgs g) {
+  static_assert(KG == 1 || (KG == 2 && TN == 64), "K groups: two groups of four waves, 64-channel tiles");
+  constexpr int DEPTH = 2;                                  // weight tap-row buffers
   constexpr int NI = TN / 16;                              // MFMA tiles along the output channels
   constexpr int B_INSTR = 3 * TN * 4 / 64, B_PER_WAVE = (B_INSTR + 3) / 4;
   constexpr int PH = TH + 2 * DIL, PW = TW + 2 * DIL, P = PH * PW;
@@ -57,8 +61,11 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
   constexpr int B_BYTES = 3 * TN * 64;                      // one tap row: 3 taps x 64 channels x 64 B
   typedef __attribute__((address_space(3))) void* lvoid;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // A[2] | B[2]
-  char* const sA = smem;
-  char* const sB = smem + 2 * A_BYTES;                     // [DEPTH] tap-row buffers
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KG == 1 ? 0 : (wave_all >> 2), wave = wave_all & 3;     // K group, wave inside the group (= pixel rows 2w, 2w+1)
+  char* const sA = smem + grp * (2 * A_BYTES);             // per group: A[2]
+  char* const sB = smem + KG * 2 * A_BYTES + grp * (DEPTH * B_BYTES);     // per group: [DEPTH] tap-row buffers
 
   // workgroup -> (pixel tile, channel block): XCD x (= blockIdx & 7) takes a contiguous run of the work list in which the
   // channel block runs fastest, so the 8 channel blocks of a pixel tile share its input patch in that XCD's L2
@@ -71,8 +78,6 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
   const int ty0 = (trem / g.tiles_x) * TH, tx0 = (trem % g.tiles_x) * TW;
   const int co0 = co_blk * TN;
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.in, 0, (int)g.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.wk, 0, (int)g.wk_bytes, 0x00020000);
 
@@ -99,9 +104,9 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
     const bool ok = tap_x < 3 && co0 + co < g.Cout;
     b_v[s] = ok ? (unsigned)((((long)(co0 + co) * 9 + tap_x) * g.Cin + src * 8) * 2) : INVALID;
   }
-  auto issue_a = [&](int chunk) {
+  auto issue_a = [&](int chunk) {                           // chunk = the group's local chunk index
     char* dst = sA + (chunk & 1) * A_BYTES;
-    const unsigned soff = (unsigned)chunk * (CK * 2);
+    const unsigned soff = (unsigned)(chunk * KG + grp) * (CK * 2);
 #pragma unroll
     for (int s = 0; s < A_PER_WAVE; ++s)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lvoid)(dst + (wave + 4 * s) * 1024), 16, (int)a_v[s], (int)soff, 0, 0);
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
   auto issue_b = [&](int step) {                            // step = chunk * 3 + tap row
     const int chunk = step / 3, ty = step - chunk * 3;
     char* dst = sB + (step % DEPTH) * B_BYTES;
-    const unsigned soff = (unsigned)((ty * 3 * g.Cin + chunk * CK) * 2);
+    const unsigned soff = (unsigned)((ty * 3 * g.Cin + (chunk * KG + grp) * CK) * 2);
 #pragma unroll
     for (int s = 0; s < B_PER_WAVE; ++s)
       if (wave + 4 * s < B_INSTR)
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nchunk = g.Cin / CK, nstep = nchunk * 3;
+  const int nchunk = g.Cin / (CK * KG), nstep = nchunk * 3;     // per group
   const int l15 = lane & 15, kq = lane >> 4;                // fragment row, 16-byte K position
   // B fragment byte offsets inside a tap (fixed): channel j*16 + l15
   int b_off[NI];
@@ -131,16 +136,15 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
     const int co = j * 16 + l15;
     b_off[j] = co * 64 + ((kq ^ (((co >> 2) & 1) << 1)) << 4);
   }
-  // Issue order inside a step: weights of step + DEPTH - 1, then (first tap row of a chunk) the next chunk's patch.  Loads
-  // complete in order, so "weights of this step landed" = at most the instructions issued after them still outstanding:
-  //   sum over the DEPTH-2 steps in between of (3 + patch if that step opened a chunk) + patch if the issuing step did.
+  // Per step (= 3 taps of one chunk): all loads of the step landed (issued one step earlier) -> barrier -> issue the next
+  // step's weights (and, opening a chunk, the next chunk's patch) -> 3 x (4 + NI fragment reads, 4 x NI MFMAs); the
+  // compiler interleaves the reads of a tap with the MFMAs of the previous one.  (An explicit one-tap-ahead register
+  // pipeline with the barrier moved into the last tap was measured 4-12 % slower: 256 VGPRs, longer dependency stalls.)
   issue_a(0);
-#pragma unroll
-  for (int s0 = 0; s0 < DEPTH - 1; ++s0)
-    if (s0 < nstep) issue_b(s0);
+  issue_b(0);
   auto compute_step = [&](int step, int chunk, int ty) {
     const char* A = sA + (chunk & 1) * A_BYTES;
-    const char* B = sB + (step % DEPTH) * B_BYTES;
+    const char* B = sB + (step & 1) * B_BYTES;
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx) {
       u32x4 fa[4], fb[NI];
@@ -163,22 +167,78 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty) {
       const int step = chunk * 3 + ty;
-      // outstanding instructions allowed while the data of `step` is complete (steady state; derivation in the header):
-      //   DEPTH 3: {3, 3+APW, 3+APW}     DEPTH 4: {6, 6+APW, 6+APW}     (tap row 0 of DEPTH 4 needs the patch issued in the
-      //   same step as its weights, so that patch may NOT stay outstanding)
-      constexpr int APW = A_PER_WAVE;
-      static_assert(DEPTH == 2 || B_INSTR == 12, "counted vmcnt assumes 3 weight instructions per wave and step");
-      if (DEPTH == 2 || step + DEPTH - 1 >= nstep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: fewer loads issued
-      else if (ty == 0) wait_vm<3 * (DEPTH - 2)>();
-      else wait_vm<3 * (DEPTH - 2) + APW>();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (step + DEPTH - 1 < nstep) issue_b(step + DEPTH - 1);
+      if (step + 1 < nstep) issue_b(step + 1);
       if (ty == 0 && chunk + 1 < nchunk) issue_a(chunk + 1);
       compute_step(step, chunk, ty);
     }
   }
   __syncthreads();                                          // every wave is done with the staging buffers
 
+  unsigned short* out = (unsigned short*)g.out;
+  const unsigned short* ref = (const unsigned short*)g.ref;
+  if (KG == 2) {
+    // ---- two K groups: exchange halves through LDS.  Wave (grp, w) keeps the 16-pixel sub-tiles i = 2*grp, 2*grp+1 (tile row
+    // 2w + grp) and hands the other two to its partner wave (1 - grp, w).
+    f32x4* X = (f32x4*)smem;                                  // [8 waves][2][NI][64 lanes], 8 KiB per wave
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const f32x4 give = grp == 0 ? acc[2 + i2][j] : acc[i2][j];
+        X[((wave_all * 2 + i2) * NI + j) * 64 + lane] = give;
+      }
+    __syncthreads();
+    f32x4 fin[2][NI];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const f32x4 got = X[(((wave_all ^ 4) * 2 + i2) * NI + j) * 64 + lane];
+        const f32x4 mine = grp == 0 ? acc[i2][j] : acc[2 + i2][j];
+        // group 0's partial first: the sum does not depend on which wave finishes it
+        fin[i2][j] = grp == 0 ? f32x4{mine[0] + got[0], mine[1] + got[1], mine[2] + got[2], mine[3] + got[3]}
+                              : f32x4{got[0] + mine[0], got[1] + mine[1], got[2] + mine[2], got[3] + mine[3]};
+      }
+    unsigned short* S = (unsigned short*)(smem + 8 * 2 * NI * 64 * 16 + wave_all * (32 * TN * 2));      // [32 pixels][TN]
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = j * 16 + l15;
+      const float bv = (g.bias && co0 + col < g.Cout) ? g.bias[co0 + col] : 0.f;
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = fin[i2][j][e] + bv;
+          if (g.relu) v = fmaxf(v, 0.f);
+          const int pl = i2 * 16 + kq * 4 + e;
+          S[pl * TN + (col ^ ((pl & (TN / 8 - 1)) << 3))] = f32_to_bf16_bits(v);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int it = 0; it < TN / 16; ++it) {
+      const int idx = it * 64 + lane;
+      const int pl = idx / (TN / 8), ch = idx % (TN / 8);
+      const int y = ty0 + 2 * wave + grp, x = tx0 + pl;
+      const int co = co0 + ch * 8;
+      if (y < g.H && x < g.W && co < g.Cout) {
+        u32x4 v = *(const u32x4*)(S + pl * TN + ((ch ^ (pl & (TN / 8 - 1))) << 3));
+        const long o = (((long)img * g.H + y) * g.W + x) * g.Cout + co;
+        if (ref) {
+          const u32x4 r = *(const u32x4*)(ref + o);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bool lo = __uint_as_float(r[t] << 16) > 0.f, hi = __uint_as_float(r[t] & 0xFFFF0000u) > 0.f;
+            v[t] = (lo ? (v[t] & 0xFFFFu) : 0u) | (hi ? (v[t] & 0xFFFF0000u) : 0u);
+          }
+        }
+        *(u32x4*)(out + o) = v;
+      }
+    }
+    return;
+  }
   // ---- epilogue: bias / ReLU in registers, bf16 tile through LDS, 16-byte stores with the ReLU-backward mask
   unsigned short* S = (unsigned short*)(smem + wave * (64 * TN * 2));        // [64 pixels][TN channels]
 #pragma unroll
@@ -196,8 +256,6 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 2 : 1) void conv3x3_direct_kernel
       }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): own LDS writes visible to own reads (same wave)
-  unsigned short* out = (unsigned short*)g.out;
-  const unsigned short* ref = (const unsigned short*)g.ref;
 #pragma unroll
   for (int it = 0; it < TN / 8; ++it) {
     const int idx = it * 64 + lane;
@@ -330,7 +388,11 @@ int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilatio
   // 64 output channels per workgroup, or 32 when that leaves less than 1.5 workgroups per CU (63x63 / 64x64 maps): twice the
   // workgroups = two per CU = two waves per SIMD to overlap LDS latency with MFMAs
   static const char* tsw = getenv("SW_CONV_DIRECT_TN");       // development switch
-  const int tn = tsw ? atoi(tsw) : (g.n_px_tiles * ((Cout + 63) / 64) <= 384 ? 32 : 64);
+  static const char* ksw = getenv("SW_CONV_DIRECT_KG");       // development switch: "1" = never split K inside the workgroup
+  const bool few = g.n_px_tiles * ((Cout + 63) / 64) <= 384;
+  // few tiles: two K groups of four waves on 64-channel tiles (header); needs an even number of 32-channel chunks
+  const int kg = (few && !tsw && !(ksw && ksw[0] == '1') && (Cin % (2 * CK)) == 0) ? 2 : 1;
+  const int tn = tsw ? atoi(tsw) : ((few && kg == 1) ? 32 : 64);
   g.n_co_blocks = (Cout + tn - 1) / tn;
   g.total = g.n_px_tiles * g.n_co_blocks;
   const long ib = (long)nimg * H * W * Cin * 2, wb = (long)Cout * 9 * Cin * 2;
@@ -340,19 +402,19 @@ int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilatio
   const int d = dilation;
   const int P = (TH + 2 * d) * (TW + 2 * d);
   const int apw = ((P * 4 + 63) / 64 + 3) / 4;
-  static const char* dsw = getenv("SW_CONV_DIRECT_DEPTH");      // development switch
-  const int depth = (dsw && tn == 64) ? atoi(dsw) : 2;
-  const size_t lds = (size_t)2 * apw * 4096 + (size_t)depth * (3 * tn * 64);
+  const size_t lds = (size_t)kg * ((size_t)2 * apw * 4096 + (size_t)2 * (3 * tn * 64));
   hipError_t e = hipSuccess;
-#define SW_LAUNCH_DIRECT(D, DEP, TNV)                                                                                    \
+#define SW_LAUNCH_DIRECT(D, TNV, KGV)                                                                                     \
   do {                                                                                                                     \
-    e = hipFuncSetAttribute((const void*)conv3x3_direct_kernel<D, DEP, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    auto kern = conv3x3_direct_kernel<D, TNV, KGV>;                                                                        \
+    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
     if (e != hipSuccess) return -(int)e;                                                                                   \
-    hipLaunchKernelGGL((conv3x3_direct_kernel<D, DEP, TNV>), dim3(per_xcd * 8), dim3(256), lds, stream, g);               \
+    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256 * kg), lds, stream, g);                                           \
   } while (0)
-  if (tn == 32) { if (d == 1) SW_LAUNCH_DIRECT(1, 2, 32); else SW_LAUNCH_DIRECT(2, 2, 32); }
-  else if (d == 1) { if (depth == 2) SW_LAUNCH_DIRECT(1, 2, 64); else if (depth == 3) SW_LAUNCH_DIRECT(1, 3, 64); else SW_LAUNCH_DIRECT(1, 4, 64); }
-  else { if (depth == 2) SW_LAUNCH_DIRECT(2, 2, 64); else if (depth == 3) SW_LAUNCH_DIRECT(2, 3, 64); else SW_LAUNCH_DIRECT(2, 4, 64); }
+  if (kg == 2) { if (d == 1) SW_LAUNCH_DIRECT(1, 64, 2); else SW_LAUNCH_DIRECT(2, 64, 2); }
+  else if (tn == 32) { if (d == 1) SW_LAUNCH_DIRECT(1, 32, 1); else SW_LAUNCH_DIRECT(2, 32, 1); }
+  else if (tn == 64) { if (d == 1) SW_LAUNCH_DIRECT(1, 64, 1); else SW_LAUNCH_DIRECT(2, 64, 1); }
+  else return 0;
 #undef SW_LAUNCH_DIRECT
   e = hipGetLastError();
   if (e != hipSuccess) return -(int)e;
