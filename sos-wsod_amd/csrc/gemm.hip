@@ -690,27 +690,37 @@ extern "C" int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int 
 
 namespace {
 // sum the split-K slabs [z][co][tap][ci] in a fixed order and permute to OIHW [co][ci][tap] (deterministic, no atomics).
-// A thread owns 4 consecutive ci of one (co, tap): one 16-byte load per slab, four slabs in flight per iteration (the scalar
-// one-slab-at-a-time loop was latency bound once the launches grew to 14-28 slabs: 24 us for 33 MB).  Requires Cin % 4 == 0.
+// One workgroup per output channel: its 9*Cin partial sums are read as 16-byte pieces (four slabs in flight per iteration; a
+// scalar one-slab-at-a-time loop was latency bound once the launches grew to 14-28 slabs), folded, transposed through LDS and
+// written as ONE contiguous run of 16-byte stores (the direct form scattered 4-byte stores 36 bytes apart: 2.4 M write
+// transactions per conv4 layer).  Requires Cin % 4 == 0 and 36*Cin bytes of LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int Cout, int Cin, int nslab, const float* __restrict__ slabs,
                                                            float* __restrict__ out) {
-  const long total = (long)Cout * 9 * Cin, nvec = total >> 2;
-  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nvec; q += (long)gridDim.x * blockDim.x) {
-    const f32x4* src = (const f32x4*)slabs + q;
+  extern __shared__ __attribute__((aligned(16))) float s_t[];       // [9][Cin]
+  const int co = blockIdx.x, n = 9 * Cin, nv = n >> 2;
+  const long slab_v = ((long)Cout * n) >> 2;
+  const f32x4* src = (const f32x4*)(slabs + (long)co * n);
+  for (int q = threadIdx.x; q < nv; q += 256) {
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     int z = 0;
     for (; z + 4 <= nslab; z += 4) {
-      const f32x4 v0 = src[(long)z * nvec], v1 = src[(long)(z + 1) * nvec], v2 = src[(long)(z + 2) * nvec],
-                  v3 = src[(long)(z + 3) * nvec];
+      const f32x4 v0 = src[(long)z * slab_v + q], v1 = src[(long)(z + 1) * slab_v + q], v2 = src[(long)(z + 2) * slab_v + q],
+                  v3 = src[(long)(z + 3) * slab_v + q];
       a0 += v0; a1 += v1; a2 += v2; a3 += v3;
     }
-    for (; z < nslab; ++z) a0 += src[(long)z * nvec];
-    const f32x4 v = (a0 + a1) + (a2 + a3);
-    const long i = q << 2;
-    const int ci = (int)(i % Cin); const long t = i / Cin;
-    const int tap = (int)(t % 9); const int co = (int)(t / 9);
-    float* o = out + ((long)co * Cin + ci) * 9 + tap;
-    o[0] = v[0]; o[9] = v[1]; o[18] = v[2]; o[27] = v[3];
+    for (; z < nslab; ++z) a0 += src[(long)z * slab_v + q];
+    ((f32x4*)s_t)[q] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  f32x4* dst = (f32x4*)(out + (long)co * n);
+  for (int q = threadIdx.x; q < nv; q += 256) {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = 4 * q + j, ci = e / 9, tap = e - 9 * ci;
+      o[j] = s_t[tap * Cin + ci];
+    }
+    dst[q] = o;
   }
 }
 
@@ -754,11 +764,8 @@ extern "C" int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int 
   const int rc = dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, OP_KSTRIDED, OP_CONV_B, nslab, stream)
                                   : dispatch_modes<float>(g, OP_KSTRIDED, OP_CONV_B, nslab, stream);
   if (rc) return rc;
-  // (a per-channel LDS transposition with contiguous OIHW writes was measured slower: 19 vs 13 us per launch — the slab reads
-  // dominate and want the full-grid, grid-stride form)
-  long blocks = (nelem / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, Cout, Cin, nslab, workspace, dw_oihw);
+  if ((size_t)36 * Cin > 65536 || (((uintptr_t)dw_oihw) & 15)) return -5;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cout), dim3(256), (size_t)36 * Cin, stream, Cout, Cin, nslab, workspace, dw_oihw);
   SW_CHECK_LAUNCH();
   return 0;
 }
