@@ -690,35 +690,40 @@ extern "C" int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int 
 
 namespace {
 // sum the split-K slabs [z][co][tap][ci] in a fixed order and permute to OIHW [co][ci][tap] (deterministic, no atomics).
-// One workgroup per output channel: its 9*Cin partial sums are read as 16-byte pieces (four slabs in flight per iteration; a
-// scalar one-slab-at-a-time loop was latency bound once the launches grew to 14-28 slabs), folded, transposed through LDS and
-// written as ONE contiguous run of 16-byte stores (the direct form scattered 4-byte stores 36 bytes apart: 2.4 M write
-// transactions per conv4 layer).  Requires Cin % 4 == 0 and 36*Cin bytes of LDS.
+// A workgroup owns one output channel and one of gridDim.y input-channel ranges: its 9 x CI partial sums are read as 16-byte
+// pieces (eight slabs in flight per iteration; a scalar one-slab-at-a-time loop was latency bound once the launches grew to
+// 14-28 slabs), folded, transposed through LDS and written as ONE contiguous run of 16-byte stores (the direct form
+// scattered 4-byte stores 36 bytes apart: 2.4 M write transactions per conv4 layer).  Requires (Cin / gridDim.y) % 4 == 0.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int Cout, int Cin, int nslab, const float* __restrict__ slabs,
                                                            float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float s_t[];       // [9][Cin]
-  const int co = blockIdx.x, n = 9 * Cin, nv = n >> 2;
-  const long slab_v = ((long)Cout * n) >> 2;
-  const f32x4* src = (const f32x4*)(slabs + (long)co * n);
+  extern __shared__ __attribute__((aligned(16))) float s_t[];       // [9][CI]
+  const int co = blockIdx.x, CI = Cin / (int)gridDim.y, ci0 = blockIdx.y * CI;
+  const int cv = CI >> 2, nv = 9 * cv;                              // 16-byte pieces per tap / per workgroup
+  const long slab_f = (long)Cout * 9 * Cin;
+  const float* src = slabs + (long)co * 9 * Cin + ci0;
   for (int q = threadIdx.x; q < nv; q += 256) {
+    const int tap = q / cv, c4 = q - tap * cv;
+    const float* p = src + (long)tap * Cin + c4 * 4;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     int z = 0;
-    for (; z + 4 <= nslab; z += 4) {
-      const f32x4 v0 = src[(long)z * slab_v + q], v1 = src[(long)(z + 1) * slab_v + q], v2 = src[(long)(z + 2) * slab_v + q],
-                  v3 = src[(long)(z + 3) * slab_v + q];
-      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    for (; z + 8 <= nslab; z += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(p + (long)(z + u) * slab_f);
+      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+      a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
     }
-    for (; z < nslab; ++z) a0 += src[(long)z * slab_v + q];
-    ((f32x4*)s_t)[q] = (a0 + a1) + (a2 + a3);
+    for (; z < nslab; ++z) a0 += *(const f32x4*)(p + (long)z * slab_f);
+    *(f32x4*)(s_t + tap * CI + c4 * 4) = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
-  f32x4* dst = (f32x4*)(out + (long)co * n);
+  f32x4* dst = (f32x4*)(out + ((long)co * Cin + ci0) * 9);
   for (int q = threadIdx.x; q < nv; q += 256) {
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e = 4 * q + j, ci = e / 9, tap = e - 9 * ci;
-      o[j] = s_t[tap * Cin + ci];
+      o[j] = s_t[tap * CI + ci];
     }
     dst[q] = o;
   }
@@ -765,7 +770,10 @@ extern "C" int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int 
                                   : dispatch_modes<float>(g, OP_KSTRIDED, OP_CONV_B, nslab, stream);
   if (rc) return rc;
   if ((size_t)36 * Cin > 65536 || (((uintptr_t)dw_oihw) & 15)) return -5;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cout), dim3(256), (size_t)36 * Cin, stream, Cout, Cin, nslab, workspace, dw_oihw);
+  int parts = 1;                                              // input-channel ranges per output channel: >= 1024 workgroups
+  while (Cout * parts < 1024 && (Cin % (parts * 2 * 4)) == 0 && Cin / (parts * 2) >= 32) parts *= 2;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cout, (unsigned)parts), dim3(256), (size_t)36 * Cin / parts, stream, Cout, Cin,
+                     nslab, workspace, dw_oihw);
   SW_CHECK_LAUNCH();
   return 0;
 }
