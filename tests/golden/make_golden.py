@@ -28,6 +28,7 @@ E2E_CASES = {
     # name: (H, W, R, n_gt, dan_dim, head_scale)
     "s0": (96, 128, 37, 2, (256, 256), 30.0),
     "s1": (128, 160, 64, 3, (256, 256), 60.0),
+    "c0": (112, 144, 150, 5, (256, 256), 6.0, 80),       # COCO-shaped head: 80 classes, top-p% = 15 proposals per class
 }
 GRAD_KEYS_FULL = ["roi_heads.box_predictor.cls.weight", "roi_heads.box_predictor.det.bias",
                   "roi_heads.box_refinery_3.bbox_pred.weight", "roi_heads.box_refinery_0.cls_score.weight",
@@ -82,8 +83,8 @@ class DropoutPatch:
 
 
 def run_e2e(case):
-    H, W, R, n_gt, dan, hs = E2E_CASES[case]
-    K = 20
+    H, W, R, n_gt, dan, hs = E2E_CASES[case][:6]
+    K = E2E_CASES[case][6] if len(E2E_CASES[case]) > 6 else 20
     P = O.make_params(K, dan, tag="p" + case, head_scale=hs)
     views, gt = O.make_views(H, W, R, n_gt=n_gt, K=K, tag="v" + case)
     masks = O.make_masks(R, dan, tag="m" + case)
@@ -272,6 +273,7 @@ if __name__ == "__main__":
         run_mining("b", 2000, 80, 5, 1)
     if "e2e" in which:
         for c in E2E_CASES:
-            run_e2e(c)
+            if c in which or not any(w in E2E_CASES for w in which):
+                run_e2e(c)
     if "infer" in which:
         run_infer("s0")

@@ -31,7 +31,7 @@ def _setup(case, golden_dir, dtype):
     return g, P, views, gt, masks, model
 
 
-@pytest.mark.parametrize("case", ["s0", "s1"])
+@pytest.mark.parametrize("case", ["s0", "s1", "c0"])
 def test_fp32_iteration_matches_reference_golden(case, golden_dir):
     from sos_wsod_amd.events import EventStorage
     g, P, views, gt, masks, model = _setup(case, golden_dir, torch.float32)
@@ -77,7 +77,7 @@ def test_fp32_iteration_matches_reference_golden(case, golden_dir):
         assert sd[str(name)].grad is None
 
 
-@pytest.mark.parametrize("case", ["s0"])
+@pytest.mark.parametrize("case", ["s0", "c0"])
 def test_bf16_iteration_close_to_bf16_emulating_oracle(case, golden_dir):
     from sos_wsod_amd.events import EventStorage
     g, P, views, gt, masks, model = _setup(case, golden_dir, torch.bfloat16)

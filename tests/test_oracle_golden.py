@@ -9,7 +9,7 @@ import torch
 from oracle import oicr_oracle as O
 
 
-@pytest.mark.parametrize("case", ["s0", "s1"])
+@pytest.mark.parametrize("case", ["s0", "s1", "c0"])
 def test_e2e_losses_grads_and_integer_outputs(case, golden_dir):
     g = np.load(os.path.join(golden_dir, f"e2e_{case}.npz"), allow_pickle=False)
     K, R, H, W = int(g["K"]), int(g["R"]), int(g["H"]), int(g["W"])
