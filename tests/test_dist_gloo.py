@@ -47,7 +47,7 @@ class _Toy(torch.nn.Module):
         return {"loss_cls": (y ** 2).mean(), "loss_box_reg_r0": y.abs().mean()}
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, compress=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import sos_wsod_amd  # noqa: F401
@@ -56,7 +56,7 @@ def _worker(rank, world, port, out):
     assert (r, w) == (rank, world)
     model = _Toy()
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
-    tr = Trainer(model, opt, iter_size=2)
+    tr = Trainer(model, opt, iter_size=2, grad_compress=compress)
     assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
     tr.model.train()
     g = torch.Generator().manual_seed(100 + rank)
@@ -96,3 +96,17 @@ def test_ddp_step_loop_world2_gloo(tmp_path):
             opt.step(); opt.zero_grad()
     ref = torch.cat([p.detach().flatten() for p in model.parameters()])
     assert torch.allclose(res["params"], ref, rtol=1e-5, atol=1e-6)
+
+
+def test_ddp_bf16_gradient_compression_opt_in(tmp_path):
+    """opt-in bf16 all-reduce of the gradient buckets (Trainer(grad_compress="bf16") / SW_DDP_GRAD_COMPRESS): ranks stay in
+    lock step, the result is the f32 run's up to bf16 rounding of the summed gradients"""
+    out = str(tmp_path / "r0c.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, "bf16"), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["same"] and res["iters"] == 4
+    out2 = str(tmp_path / "r0f.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out2), nprocs=2, join=True)
+    ref = torch.load(out2)
+    assert not torch.equal(res["params"], ref["params"])                      # the hook did run
+    assert torch.allclose(res["params"], ref["params"], rtol=2e-2, atol=2e-3)
