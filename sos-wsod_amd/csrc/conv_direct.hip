@@ -391,7 +391,7 @@ int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilatio
   static const char* ksw = getenv("SW_CONV_DIRECT_KG");       // development switch: "1" = never split K inside the workgroup
   const bool few = g.n_px_tiles * ((Cout + 63) / 64) <= 384;
   // few tiles: two K groups of four waves on 64-channel tiles (header); needs an even number of 32-channel chunks
-  const int kg = (few && !tsw && !(ksw && ksw[0] == '1') && (Cin % (2 * CK)) == 0) ? 2 : 1;
+  const int kg = ((few || (ksw && ksw[0] == '2')) && !tsw && !(ksw && ksw[0] == '1') && (Cin % (2 * CK)) == 0) ? 2 : 1;
   const int tn = tsw ? atoi(tsw) : ((few && kg == 1) ? 32 : 64);
   g.n_co_blocks = (Cout + tn - 1) / tn;
   g.total = g.n_px_tiles * g.n_co_blocks;

@@ -9,7 +9,8 @@ def timeit(fn, n=20):
     torch.cuda.synchronize(); a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record(); [fn() for _ in range(n)]; b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / n
 for name, n, H, W, cin, cout, dil in [("conv5_3", 2, 63, 63, 512, 512, 2), ("conv4_2", 2, 64, 64, 512, 512, 1), ("conv4_1", 2, 64, 64, 256, 512, 1),
-                                      ("conv3_2", 2, 128, 128, 256, 256, 1)]:
+                                      ("conv3_2", 2, 128, 128, 256, 256, 1), ("conv2_2", 2, 256, 256, 128, 128, 1),
+                                      ("conv1_2", 2, 512, 512, 64, 64, 1)]:
     x = rnd(n, H, W, cin); wk = rnd(cout, 9, cin); b = torch.zeros(cout, device=dev); out = torch.empty(n, H, W, cout, device=dev, dtype=dt)
     ep = ops.make_epilogue(bias=b, relu=True, out_dtype=dt)
     t = timeit(lambda: ops.conv3x3(x, wk, out, dil, ep))
