@@ -115,8 +115,9 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cin, cout, dil):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("C", [24, 6])
 @pytest.mark.parametrize("stride", [1, 2])
-def test_maxpool_fwd_bwd(ops, dtype, stride, C):
-    n, H, W = 2, 11, 14                                          # C=24: 16-byte channel vectors, C=6: scalar form
+@pytest.mark.parametrize("H,W", [(11, 14), (9, 13), (8, 8)])       # odd sizes: the last row / column belongs to no stride-2 window
+def test_maxpool_fwd_bwd(ops, dtype, stride, C, H, W):
+    n = 2                                                        # C=24: 16-byte channel vectors, C=6: scalar form
     x = F.relu(_rand((n, C, H, W), 20, dtype)).float()          # post-ReLU like the backbone (ties at 0)
     xr = x.clone().requires_grad_(True)
     y = F.max_pool2d(xr, 2, stride)
@@ -126,7 +127,7 @@ def test_maxpool_fwd_bwd(ops, dtype, stride, C):
     out = torch.empty(n, y.shape[2], y.shape[3], C, device="cuda", dtype=dtype)
     ops.maxpool_fwd(xin, out, stride)
     assert torch.equal(out.cpu().float(), _nhwc(y.detach()))
-    din = torch.empty_like(xin)
+    din = torch.full_like(xin, float("nan"))
     ops.maxpool_bwd(xin, _nhwc(gy).to(dtype).cuda(), din, stride, relu_mask=True)
     ref = _nhwc(xr.grad) * (_nhwc(x) > 0)
     tol = 1e-2 if dtype == torch.bfloat16 else 1e-6
