@@ -55,8 +55,9 @@ def transform_proposals_multi(boxes: torch.Tensor, tfm: ViewTransform, min_box_s
 class DeviceMultiInputMapper:
     """`mapper(dataset_dict) -> dict` with the keys the detector's training forward reads (rcnn_multi.py).
 
-    dataset_dict: "image" (3, h, w) uint8 tensor (any device), "proposal_boxes" (N, 4) XYXY_ABS, "proposal_objectness_logits"
-    (N,), optional "annotations" = list of {"bbox": XYXY_ABS, "category_id": int, "iscrowd": 0/1}.
+    dataset_dict: "image" (3, h, w) uint8 tensor (any device), "proposal_boxes" (N, 4) in "proposal_bbox_mode" (XYXY_ABS = 0
+    default, XYWH_ABS = 1; `proposals.load_proposals_into_dataset` fills all three), "proposal_objectness_logits" (N,), optional
+    "annotations" = list of {"bbox": XYXY_ABS, "category_id": int, "iscrowd": 0/1}.
     """
 
     def __init__(self, min_sizes: Sequence[int] = (480, 576, 688, 864, 1000, 1200), max_size: int = 2000,
@@ -100,6 +101,8 @@ class DeviceMultiInputMapper:
 
         if "proposal_boxes" in d:
             boxes = torch.as_tensor(d["proposal_boxes"], dtype=torch.float32, device=dev).reshape(-1, 4)
+            if int(d.get("proposal_bbox_mode", 0)) == 1:                 # XYWH_ABS -> XYXY_ABS (BoxMode.convert)
+                boxes = torch.cat([boxes[:, :2], boxes[:, :2] + boxes[:, 2:]], 1)
             logits = torch.as_tensor(d["proposal_objectness_logits"], dtype=torch.float32, device=dev).reshape(-1)
             per_view, keep = {}, None
             for name, t in tfms.items():

@@ -103,3 +103,35 @@ def test_topk_slice_keeps_alignment():
     for name, _, _ in VIEWS:
         assert len(out["proposals" + name].proposal_boxes) == n
         assert np.array_equal(out["proposals" + name].objectness_logits.numpy(), g["logits"][:100][g["keep"][:100]])
+
+
+def test_proposal_file_reader(tmp_path):
+    """`load_proposals_into_dataset` (data/build.py:100-161): both key spellings, ids compared as strings, descending score
+    order, bbox_mode default / XYWH carried to the mapper"""
+    import pickle
+    from sos_wsod_amd.mapper import DeviceMultiInputMapper
+    from sos_wsod_amd.proposals import load_proposals_into_dataset
+    rng = np.random.RandomState(0)
+    ids = [7, "000012", 99]
+    boxes = [np.concatenate([rng.rand(n, 2) * 100, 20 + rng.rand(n, 2) * 100], 1).astype(np.float32) for n in (5, 8, 3)]
+    scores = [rng.rand(n).astype(np.float32) for n in (5, 8, 3)]
+    f1, f2 = str(tmp_path / "d2.pkl"), str(tmp_path / "d1.pkl")
+    pickle.dump({"ids": ids, "boxes": boxes, "objectness_logits": scores}, open(f1, "wb"))
+    pickle.dump({"indexes": ids, "boxes": boxes, "scores": scores, "bbox_mode": 1}, open(f2, "wb"))
+    for path, mode in ((f1, 0), (f2, 1)):
+        ds = load_proposals_into_dataset([{"image_id": "7"}, {"image_id": "000012"}], path)
+        for rec, k in zip(ds, (0, 1)):
+            order = scores[k].argsort()[::-1]
+            assert np.array_equal(rec["proposal_boxes"], boxes[k][order])
+            assert np.array_equal(rec["proposal_objectness_logits"], scores[k][order])
+            assert (np.diff(rec["proposal_objectness_logits"]) <= 0).all() and rec["proposal_bbox_mode"] == mode
+    with pytest.raises(KeyError):
+        load_proposals_into_dataset([{"image_id": 1234}], f1)
+    # XYWH proposals reach the views as XYXY
+    rec = dict(ds[0], image=torch.zeros(3, 200, 300, dtype=torch.uint8))
+    out = DeviceMultiInputMapper(proposal_topk=100)(rec, shapes=((200, 300), (400, 600)))
+    b = rec["proposal_boxes"]
+    want = np.concatenate([b[:, :2], b[:, :2] + b[:, 2:]], 1)
+    want[:, 0::2] = want[:, 0::2].clip(0, 300); want[:, 1::2] = want[:, 1::2].clip(0, 200)
+    got = out["proposals1"].proposal_boxes.tensor.numpy()
+    assert got.shape[0] <= len(b) and all(any(np.allclose(g, w_) for w_ in want) for g in got)
