@@ -229,6 +229,10 @@ def main():
                                    "fwd+bwd+SGD(momentum, wd)", "views_per_step_per_gpu": 4, "image": "one view",
                        "oicr_iterations_per_s": round(world * args.steps / dt, 3), "parallelism": f"dp{world}"},
             "roofline": roofline,
+            # the other two launches of the same GEMM family (`roofline` above is the costliest of the three)
+            "roofline_fc6": {t: dict({k: v for k, v in roof(t).items() if k in ("achieved", "frac", "avg_ms")},
+                                     mfma_busy_counter=(busy_of(t) or {}).get("mfma_busy_frac"))
+                             for t in ("fc6_fwd", "fc6_dgrad", "fc6_wgrad")},
             "roofline_conv5_3": dict(roof("plain5.conv3_fwd"), note="inside the step: two streams share the CUs"),
             "roofline_conv5_3_alone": {"kernel": "conv5_3 fwd, batch 2, 63x63, 512->512, dilation 2", "bound": "mfma",
                                        "achieved": round(flops["plain5.conv3_fwd"] / (conv_alone_ms * 1e-3) / 1e12, 2),
