@@ -595,7 +595,7 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
   // Tail peel (plain f32-output GEMMs on the 256x256 tile, i.e. the fc weight gradients): with T tiles on 256 CUs the last
   // ceil(T/256)-th round runs (T mod 256)/256 full — fc6's weight gradient has 16 x 98 = 1568 tiles = 6.125 rounds and paid
   // for 7.  The last r tile columns (r <= 4, chosen so that the rest is a whole number of rounds) are computed by a second
-  // launch with split-K sized to fill the chip once, accumulating with f32 atomics into the zeroed column block.
+  // launch on 128x128 tiles with split-K sized to fill the chip once, accumulating with f32 atomics into the zeroed column block.
   {
     static const bool no_peel = getenv("SW_GEMM_NO_PEEL") != nullptr;    // development switch
     const bool plain = (!ep || (ep->out_dtype == SW_F32 && !ep->bias && !ep->relu && !ep->drop_mask && !(ep->drop_hash_p > 0.f) && !ep->relu_ref &&
@@ -616,8 +616,12 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
         const char* B2 = (const char*)B + (b_kstrided ? (long)N1 * es : (long)N1 * ldb * es);
         sw_epilogue ep2 = {};
         ep2.out_dtype = SW_F32; ep2.accumulate_atomic = 1; ep2.drop_scale = 1.f; ep2.ref_scale = 1.f;
-        long sk = 256 / (tm * r);
+        // the tail runs on 128x128 tiles, two workgroups per CU: K-splits to ~512 workgroups (fc6: 4 splits of 128 tiles =
+        // 60 us; 8 splits put it on 256x256 tiles: 81 us; tools/wgrad_tail.py)
+        const long t128 = ((M + 127) / 128) * ((N2 + 127) / 128);
+        long sk = 512 / t128;
         sk = sk < 1 ? 1 : (sk > 8 ? 8 : sk);
+        while (sk > 1 && tm * r * sk >= 200) --sk;              // stay below launch_auto's switch to the 256x256 tile
         return sw_gemm(dtype, a_kstrided, b_kstrided, M, N2, K, A, lda, B2, ldb, C2, ldc, &ep2, (int)sk, stream);
       }
     }
