@@ -37,6 +37,7 @@ struct GemmArgs {
   int relu, out_bf16, atomic, oihw_cin, staged_out;
   unsigned a_bytes, b_bytes;       // extents of the A / B operands (buffer descriptors' num_records)
   long slab_stride;                // > 0: split z stores its partial tile to C + z*slab_stride (plain stores, no atomics)
+  int vgrid;                       // persistent form: virtual workgroup count walked by gridDim.x resident workgroups (0 = off)
   int krot;                        // conv: rotate the channel-chunk order by the M-tile index (L2 channel spread)
   float* absmax;                   // optional: atomicMax of |stored value| (IEEE bits of a non-negative float are monotone)
 };
@@ -173,6 +174,8 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
   //  * split-K (few tiles, long K: the weight gradients): the grid holds valid tiles only and XCD x takes a contiguous
   //    run of the split-major work list, i.e. ONE or two K-ranges for all tiles — its L2 then holds just that K-range
   //    of both operands.  (With every XCD walking all of K the conv3 wgrad fetched 6x its operands from HBM; profiles/.)
+  const int vgrid = (g.vgrid > 0 && gridDim.z == 1) ? g.vgrid : (int)gridDim.x;
+  for (int vbid = blockIdx.x; vbid < vgrid; vbid += gridDim.x) {
   int bm, bn, zsplit = 0;
   if (gridDim.z > 1) {
     const int ntv = gridDim.x, tot = ntv * (int)gridDim.z;
@@ -183,17 +186,17 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
     const int t = w - zsplit * ntv;
     bm = t % g.tiles_m; bn = t / g.tiles_m;
   } else {
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
+    const int nwg = vgrid;
+    const int bid = vbid;
     const int swz = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int patch = swz >> 6, within = swz & 63;
     bm = (patch % g.patches_m) * 8 + (within & 7);
     bn = (patch / g.patches_m) * 8 + (within >> 3);
-    if (bm >= g.tiles_m || bn >= g.tiles_n) return;
+    if (bm >= g.tiles_m || bn >= g.tiles_n) continue;
   }
   const int kbeg = zsplit * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
-  if (kbeg >= kend) return;
+  if (kbeg >= kend) continue;
   const int nt = (kend - kbeg + BK - 1) / BK;
   const int m0 = bm * BM, n0t = bn * BN;
 
@@ -513,6 +516,8 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
     vmax = wave_reduce_max(vmax);
     if (lane == 0) atomicMax((unsigned int*)g.absmax, __float_as_uint(vmax));
   }
+  if (vbid + (int)gridDim.x < vgrid) __syncthreads();       // persistent form: the staged epilogue is done with the LDS ring
+  }
 }
 
 template <typename T, int AMODE, int BMODE, int BM, int BN, int STAGES, int WTM = 64, int WTN = 64>
@@ -535,6 +540,20 @@ int launch2(GemmArgs& g, int splitk, hipStream_t stream) {
   g.staged_out = (g.out_bf16 && !g.atomic && g.slab_stride <= 0 && (g.N % 8) == 0 && (g.ldc % 8) == 0 &&
                   (((uintptr_t)g.C) & 15) == 0 && (long)NT / 64 * WTM * WTN * 2 <= (long)LDS) ? 1 : 0;
   dim3 grid(splitk > 1 ? g.tiles_m * g.tiles_n : g.patches_m * patches_n * 64, 1, splitk), block(NT);
+  // Persistent form for the one-workgroup-per-CU tile (256x256, 128 KiB LDS) when there is more than one round of tiles: one
+  // workgroup per CU walks the tile list (same XCD: virtual id = resident id + k * CUs keeps id & 7) instead of being
+  // re-dispatched per tile — fc6's data gradient (12.25 rounds of 64 K-tiles) -2 %, the step -0.08 ms.
+  {
+    static const char* ps = getenv("SW_GEMM_PERSIST");          // development switch: resident workgroups, "0" = off
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
+      else ncu = 256;
+    }
+    const int np = ps ? atoi(ps) : ((ncu % 8) == 0 ? ncu : 0);
+    if (np > 0 && splitk == 1 && BM == 256 && BN == 256 && (int)grid.x > np) { g.vgrid = (int)grid.x; grid.x = np; }
+  }
   auto kern = gemm2_kernel<T, AMODE, BMODE, BM, BN, STAGES, WTM, WTN>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (e != hipSuccess) return (int)e;
