@@ -49,6 +49,10 @@ typedef struct sw_epilogue {
    * sw_dropout_mask(seed, offset, p) writes at index m*N + n is 1 — the same Bernoulli stream without the mask tensor */
   uint64_t drop_seed, drop_offset;
   float drop_hash_p;
+  /* deterministic split-K (sw_gemm, f32 C, no other epilogue option): every K-split stores its partial tile into its own
+   * slab of this workspace (sw_gemm_splitk_workspace_floats floats), a second kernel adds the slabs in fixed order into C
+   * (overwritten) — no atomics.  Also used, when given, for the tail peel of the large f32-output GEMMs (see sw_gemm). */
+  float* splitk_workspace;
 } sw_epilogue;
 
 /* ---- dense contractions (reference: cuBLAS via torch Linear — box_head.py:88-90,
@@ -57,6 +61,8 @@ typedef struct sw_epilogue {
  * Supported (a,b): (0,0) forward, (0,1) data gradient, (1,1) weight gradient. */
 int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, int K, const void* A, long lda, const void* B,
             long ldb, void* C, long ldc, const sw_epilogue* ep, int splitk, sw_stream_t stream);
+/* floats of sw_epilogue.splitk_workspace that sw_gemm(M, N, K, splitk) may use (its own tail peel included) */
+long sw_gemm_splitk_workspace_floats(int M, int N, int K, int splitk);
 
 /* ---- 3x3 convolution, stride 1, padding = dilation (reference: torch Conv2d/cuDNN, wsl/modeling/backbone/vgg.py:44-97,104-122)
  * in  [nimg][H][W][Cin], wk [Cout][3*3][Cin] (see sw_conv_weight_prep), out [nimg][H][W][Cout].

@@ -25,7 +25,7 @@ class Epilogue(ctypes.Structure):
         ("bias", c_void_p), ("relu", c_int), ("drop_mask", c_void_p), ("ld_drop", c_long), ("drop_scale", c_float),
         ("relu_ref", c_void_p), ("ld_ref", c_long), ("ref_scale", c_float), ("ref_dtype", c_int),
         ("out_dtype", c_int), ("accumulate_atomic", c_int), ("absmax_out", c_void_p),
-        ("drop_seed", c_u64), ("drop_offset", c_u64), ("drop_hash_p", c_float),
+        ("drop_seed", c_u64), ("drop_offset", c_u64), ("drop_hash_p", c_float), ("splitk_workspace", c_void_p),
     ]
 
 
@@ -46,6 +46,7 @@ _F4 = ctypes.POINTER(c_float)
 SIGNATURES = {
     "sw_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long,
                         _EP, c_int, c_void_p]),
+    "sw_gemm_splitk_workspace_floats": (c_long, [c_int, c_int, c_int, c_int]),
     "sw_conv3x3_igemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, _EP,
                                  c_void_p]),
     "sw_conv3x3_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -593,6 +593,62 @@ int dispatch_modes(GemmArgs& g, int amode, int bmode, int splitk, hipStream_t s)
   return -3;
 }
 
+// deterministic split-K: C[m][n] = sum_z ws[z][m][n], slabs added in a fixed order (pairs of four partial sums)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int nslab, const float* __restrict__ ws,
+                                                            float* __restrict__ C, long ldc, int vec) {
+  const long slab = (long)M * N;
+  if (vec) {
+    const long nv = slab >> 2;
+    const int nq = N >> 2;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nv; q += (long)gridDim.x * blockDim.x) {
+      const f32x4* src = (const f32x4*)ws + q;
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+      int z = 0;
+      for (; z + 4 <= nslab; z += 4) {
+        const f32x4 v0 = src[(long)z * nv], v1 = src[(long)(z + 1) * nv], v2 = src[(long)(z + 2) * nv], v3 = src[(long)(z + 3) * nv];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+      }
+      for (; z < nslab; ++z) a0 += src[(long)z * nv];
+      const long m = q / nq; const int n4 = (int)(q - m * nq);
+      *(f32x4*)(C + m * ldc + n4 * 4) = (a0 + a1) + (a2 + a3);
+    }
+  } else {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < slab; i += (long)gridDim.x * blockDim.x) {
+      float a = 0.f;
+      for (int z = 0; z < nslab; ++z) a += ws[(long)z * slab + i];
+      const long m = i / N;
+      C[m * ldc + (i - m * N)] = a;
+    }
+  }
+}
+
+// tail peel geometry of the plain f32-output GEMMs on the 256x256 tile (see sw_gemm): r peeled tile columns, sk K-splits
+bool peel_geometry(int M, int N, int* r_out, long* sk_out) {
+  const long tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn;
+  if (!(tiles >= 512 && (tiles % 256) != 0 && (tiles % 256) <= 160)) return false;
+  int r = 0;
+  for (int c = 1; c <= 4 && !r; ++c)
+    if (tn - c >= 2 && (tm * (tn - c)) % 256 == 0) r = c;
+  if (!r) return false;
+  const int N2 = N - (int)((tn - r) * 256);
+  // the tail runs on 128x128 tiles, two workgroups per CU: K-splits to ~512 workgroups (fc6: 4 splits of 128 tiles =
+  // 60 us; 8 splits put it on 256x256 tiles: 81 us; tools/wgrad_tail.py)
+  const long t128 = ((M + 127) / 128) * ((N2 + 127) / 128);
+  long sk = 512 / t128;
+  sk = sk < 1 ? 1 : (sk > 8 ? 8 : sk);
+  while (sk > 1 && tm * r * sk >= 200) --sk;              // stay below launch_auto's switch to the 256x256 tile
+  *r_out = r; *sk_out = sk;
+  return true;
+}
+
+int effective_splits(int dtype, int K, int splitk) {
+  const int bk = dtype == SW_BF16 ? 64 : 32;
+  if (splitk < 1) splitk = 1;
+  int kps = (K + splitk - 1) / splitk;
+  kps = ((kps + bk - 1) / bk) * bk;
+  return (K + kps - 1) / kps;
+}
+
 int check_align(const void* p) { return (((uintptr_t)p) & 15) ? -4 : 0; }
 
 }  // namespace
@@ -614,37 +670,37 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
   // Tail peel (plain f32-output GEMMs on the 256x256 tile, i.e. the fc weight gradients): with T tiles on 256 CUs the last
   // ceil(T/256)-th round runs (T mod 256)/256 full — fc6's weight gradient has 16 x 98 = 1568 tiles = 6.125 rounds and paid
   // for 7.  The last r tile columns (r <= 4, chosen so that the rest is a whole number of rounds) are computed by a second
-  // launch on 128x128 tiles with split-K sized to fill the chip once, accumulating with f32 atomics into the zeroed column block.
+  // launch on 128x128 tiles with split-K sized to fill the chip once: deterministic slabs + ordered fold when the caller
+  // gave a split-K workspace, else f32 atomics into the zeroed column block.
+  const bool plain = (!ep || (ep->out_dtype == SW_F32 && !ep->bias && !ep->relu && !ep->drop_mask && !(ep->drop_hash_p > 0.f) && !ep->relu_ref &&
+                              !ep->accumulate_atomic && !ep->absmax_out));
+  float* const det_ws = (ep && plain) ? ep->splitk_workspace : nullptr;
   {
     static const bool no_peel = getenv("SW_GEMM_NO_PEEL") != nullptr;    // development switch
-    const bool plain = (!ep || (ep->out_dtype == SW_F32 && !ep->bias && !ep->relu && !ep->drop_mask && !(ep->drop_hash_p > 0.f) && !ep->relu_ref &&
-                                !ep->accumulate_atomic && !ep->absmax_out));
-    const long tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn;
-    if (!no_peel && plain && splitk <= 1 && tiles >= 512 && (tiles % 256) != 0 && (tiles % 256) <= 160) {
-      int r = 0;
-      for (int c = 1; c <= 4 && !r; ++c)
-        if (tn - c >= 2 && (tm * (tn - c)) % 256 == 0) r = c;
-      if (r) {
-        const long es = dtype == SW_BF16 ? 2 : 4;
-        const int N1 = (int)((tn - r) * 256), N2 = N - N1;
-        int rc = sw_gemm(dtype, a_kstrided, b_kstrided, M, N1, K, A, lda, B, ldb, C, ldc, ep, 1, stream);
-        if (rc) return rc;
-        float* C2 = (float*)C + N1;
+    int r = 0; long sk = 1;
+    if (!no_peel && plain && splitk <= 1 && peel_geometry(M, N, &r, &sk)) {
+      const long es = dtype == SW_BF16 ? 2 : 4;
+      const long tn = (N + 255) / 256;
+      const int N1 = (int)((tn - r) * 256), N2 = N - N1;
+      sw_epilogue ep1 = {};
+      ep1.out_dtype = SW_F32; ep1.drop_scale = 1.f; ep1.ref_scale = 1.f;
+      int rc = sw_gemm(dtype, a_kstrided, b_kstrided, M, N1, K, A, lda, B, ldb, C, ldc, &ep1, 1, stream);
+      if (rc) return rc;
+      float* C2 = (float*)C + N1;
+      const char* B2 = (const char*)B + (b_kstrided ? (long)N1 * es : (long)N1 * ldb * es);
+      sw_epilogue ep2 = ep1;
+      if (det_ws) ep2.splitk_workspace = det_ws;
+      else if (sk > 1) {
         hipError_t e = hipMemset2DAsync(C2, (size_t)ldc * 4, 0, (size_t)N2 * 4, (size_t)M, stream);
         if (e != hipSuccess) return (int)e;
-        const char* B2 = (const char*)B + (b_kstrided ? (long)N1 * es : (long)N1 * ldb * es);
-        sw_epilogue ep2 = {};
-        ep2.out_dtype = SW_F32; ep2.accumulate_atomic = 1; ep2.drop_scale = 1.f; ep2.ref_scale = 1.f;
-        // the tail runs on 128x128 tiles, two workgroups per CU: K-splits to ~512 workgroups (fc6: 4 splits of 128 tiles =
-        // 60 us; 8 splits put it on 256x256 tiles: 81 us; tools/wgrad_tail.py)
-        const long t128 = ((M + 127) / 128) * ((N2 + 127) / 128);
-        long sk = 512 / t128;
-        sk = sk < 1 ? 1 : (sk > 8 ? 8 : sk);
-        while (sk > 1 && tm * r * sk >= 200) --sk;              // stay below launch_auto's switch to the 256x256 tile
-        return sw_gemm(dtype, a_kstrided, b_kstrided, M, N2, K, A, lda, B2, ldb, C2, ldc, &ep2, (int)sk, stream);
+        ep2.accumulate_atomic = 1;
       }
+      return sw_gemm(dtype, a_kstrided, b_kstrided, M, N2, K, A, lda, B2, ldb, C2, ldc, &ep2, (int)sk, stream);
     }
   }
+  const int eff = effective_splits(dtype, K, splitk);
+  const bool det = det_ws != nullptr && eff > 1;
+  if (det && (((uintptr_t)det_ws) & 15)) return -4;
   GemmArgs g = {};
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   if (ep) {
@@ -667,8 +723,30 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
   }
   const int am = a_kstrided ? OP_KSTRIDED : OP_KCONTIG, bmo = b_kstrided ? OP_KSTRIDED : OP_KCONTIG;
-  return dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, am, bmo, splitk, stream)
-                          : dispatch_modes<float>(g, am, bmo, splitk, stream);
+  if (det) {                                   // every K-split stores into its own slab [z][M][N]; ordered fold into C below
+    g.C = det_ws; g.ldc = N; g.slab_stride = (long)M * N; g.atomic = 0;
+  }
+  const int rc = dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, am, bmo, det ? eff : splitk, stream)
+                                  : dispatch_modes<float>(g, am, bmo, det ? eff : splitk, stream);
+  if (rc || !det) return rc;
+  const int vec = ((N % 4) == 0 && (ldc % 4) == 0 && (((uintptr_t)C) & 15) == 0) ? 1 : 0;
+  long blocks = (((long)M * N >> (vec ? 2 : 0)) + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, M, N, eff, det_ws, (float*)C, ldc, vec);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" long sw_gemm_splitk_workspace_floats(int M, int N, int K, int splitk) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (splitk > 1) return (long)splitk * M * N;
+  int r = 0; long sk = 1;
+  if (peel_geometry(M, N, &r, &sk) && sk > 1) {
+    const long tn = (N + 255) / 256;
+    const int N2 = N - (int)((tn - r) * 256);
+    return sk * (long)M * N2;
+  }
+  return 0;
 }
 
 // conv_direct.hip: halo-reusing direct kernel for the bf16 conv3..conv5 shapes (1 = launched, 0 = not covered, < 0 error)

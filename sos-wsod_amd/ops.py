@@ -84,7 +84,7 @@ def _need_gpu(*ts):
 
 
 def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_ref=None, ref_scale=1.0,
-                  out_dtype=torch.float32, atomic=False, absmax_out=None, drop_hash=None):
+                  out_dtype=torch.float32, atomic=False, absmax_out=None, drop_hash=None, splitk_workspace=None):
     """drop_hash=(seed, offset, p): dropout decided in the epilogue by the hash that sw_dropout_mask uses (no mask tensor)"""
     ep = Epilogue()
     ep.bias = None if bias is None else bias.data_ptr()
@@ -99,9 +99,10 @@ def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_re
     ep.out_dtype = dt(out_dtype)
     ep.accumulate_atomic = int(atomic)
     ep.absmax_out = None if absmax_out is None else absmax_out.data_ptr()
+    ep.splitk_workspace = None if splitk_workspace is None else splitk_workspace.data_ptr()
     if drop_hash is not None and drop_mask is None:
         ep.drop_seed, ep.drop_offset, ep.drop_hash_p = int(drop_hash[0]) & (2 ** 64 - 1), int(drop_hash[1]), float(drop_hash[2])
-    ep._keepalive = (bias, drop_mask, relu_ref, absmax_out)     # the struct holds raw pointers only
+    ep._keepalive = (bias, drop_mask, relu_ref, absmax_out, splitk_workspace)     # the struct holds raw pointers only
     return ep
 
 
@@ -113,6 +114,14 @@ def gemm(A, B, C, M, N, K, a_kstrided=False, b_kstrided=False, lda=None, ldb=Non
     ldc = C.stride(0) if ldc is None else ldc
     if ep is None:
         ep = make_epilogue(out_dtype=C.dtype)
+    if C.dtype == torch.float32 and not ep.accumulate_atomic and not ep.splitk_workspace:
+        # split-K (explicit, or the tail peel of the large weight-gradient GEMMs) through slabs + an ordered fold: no atomics,
+        # bitwise reproducible
+        need = int(lib.sw_gemm_splitk_workspace_floats(M, N, K, splitk))
+        if need > 0:
+            ws = torch.empty(need, device=C.device, dtype=torch.float32)
+            ep.splitk_workspace = ws.data_ptr()
+            ep._keepalive = ep._keepalive + (ws,)
     check(_launch(tag, lambda: lib.sw_gemm(dt(A), int(a_kstrided), int(b_kstrided), M, N, K, _p(A), lda, _p(B), ldb, _p(C),
                                            ldc, ctypes.byref(ep), splitk, _stream())), "sw_gemm")
     return C

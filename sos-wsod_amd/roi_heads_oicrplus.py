@@ -381,8 +381,8 @@ class OICRPlusHeads(nn.Module):
         rs = 2.0 if st["train_dropout"] else 1.0
         # predictor matrices
         dbh = torch.empty(LD, device=dev, dtype=torch.float32); ops.colsum(dl, M, LD, dbh)
-        dWh = torch.zeros(LD, D2, device=dev, dtype=torch.float32)
-        ops.gemm(dl, h2, dWh, LD, D2, M, a_kstrided=True, b_kstrided=True, ep=ops.make_epilogue(atomic=True), splitk=4)
+        dWh = torch.empty(LD, D2, device=dev, dtype=torch.float32)
+        ops.gemm(dl, h2, dWh, LD, D2, M, a_kstrided=True, b_kstrided=True, splitk=4)      # slabs + ordered fold (deterministic)
         dz2 = _padded(M, D2, dev, dt_)
         ops.gemm(dl, Wh, dz2, M, D2, LD, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h2, ref_scale=rs, out_dtype=dt_))
         # fc7

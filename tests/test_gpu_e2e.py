@@ -464,3 +464,24 @@ def test_multi_input_mapper_device(golden_dir):
     for name, p in model.named_parameters():
         if p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
+
+
+def test_full_size_iteration_is_reproducible():
+    """two runs of the same iteration from the same state: every loss and every gradient is bitwise identical — slab split-K
+    with ordered folds (conv and fc weight gradients, the GEMM tail peel), ordered bias sums, integer fixed-point ROI scatter,
+    hash dropout: no floating-point atomics anywhere in the step"""
+    from sos_wsod_amd.events import EventStorage
+    model, data, bench = _full_size_model_and_data()
+    runs = []
+    for _ in range(2):
+        model.roi_heads._drop_counter = 0                       # same dropout stream
+        for p in model.parameters():
+            p.grad = None
+        with EventStorage(0):
+            losses = model(data)
+            losses.total().backward()
+        torch.cuda.synchronize()
+        runs.append((losses.vector.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    diff = [n for n, g0 in runs[0][1].items() if not torch.equal(g0, runs[1][1][n])]
+    assert not diff, diff

@@ -67,6 +67,23 @@ def test_gemm_epilogue_bias_relu_dropout_and_splitk_atomic(ops, dtype):
     assert ((C2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K,pad,sk", [(200, 256, 1024, 0, 4), (136, 104, 777 * 8, 10, 7), (256, 4096, 8000, 0, 4)])
+def test_gemm_splitk_deterministic_slabs(ops, dtype, M, N, K, pad, sk):
+    """split-K through per-split slabs + an ordered fold (sw_epilogue.splitk_workspace; ops.gemm attaches it): the result
+    overwrites C (no zero fill), equals the contraction, and is bitwise identical run to run (weight-gradient form, TN)"""
+    a = _rand((K, M), 31, dtype).cuda(); b = _rand((K, N), 32, dtype).cuda()
+    want = a.double().t() @ b.double()
+    outs = []
+    for _ in range(3):
+        C = torch.full((M, N + pad), float("nan"), device="cuda")[:, :N]
+        ops.gemm(a, b, C, M, N, K, a_kstrided=True, b_kstrided=True, splitk=sk)
+        assert torch.isfinite(C).all()
+        assert ((C.double() - want).abs().max() / want.abs().max()) < (2e-5 if dtype == torch.float32 else 2e-5)
+        outs.append(C.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
 # ------------------------------------------------------------------------------------------ conv
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
