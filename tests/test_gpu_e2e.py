@@ -485,3 +485,58 @@ def test_full_size_iteration_is_reproducible():
     assert torch.equal(runs[0][0], runs[1][0])
     diff = [n for n, g0 in runs[0][1].items() if not torch.equal(g0, runs[1][1][n])]
     assert not diff, diff
+
+
+def test_train_loop_from_proposal_file_to_checkpoint(tmp_path):
+    """the pieces of §8f in one loop, as train_net_multi.py wires them: proposal pickle -> device mapper -> Trainer.run_step
+    (HipSGD + WarmupMultiStepLR) -> DetectionCheckpointer.save -> resume into a fresh model -> identical next iteration"""
+    import pickle
+    from sos_wsod_amd.checkpoint import DetectionCheckpointer
+    from sos_wsod_amd.mapper import DeviceMultiInputMapper
+    from sos_wsod_amd.proposals import load_proposals_into_dataset
+    from sos_wsod_amd.solver import HipSGD, WarmupMultiStepLR
+    from sos_wsod_amd.trainer import Trainer
+    rng = np.random.RandomState(0)
+    dev = torch.device("cuda", 0)
+    h, w, n = 120, 160, 90
+    ids, boxes, scores, records = [], [], [], []
+    for i in range(3):
+        x1 = rng.randint(0, w - 30, n); y1 = rng.randint(0, h - 30, n)
+        b = np.stack([x1, y1, np.minimum(x1 + rng.randint(16, 90, n), w - 1), np.minimum(y1 + rng.randint(16, 70, n), h - 1)], 1)
+        ids.append(f"{i:06d}"); boxes.append(b.astype(np.float32)); scores.append(rng.rand(n).astype(np.float32))
+        records.append({"image_id": f"{i:06d}", "image": torch.randint(0, 256, (3, h, w), dtype=torch.uint8, device=dev),
+                        "annotations": [{"bbox": [10.0, 10.0, 100.0, 90.0], "category_id": int(rng.randint(0, 20))}]})
+    pkl = str(tmp_path / "props.pkl")
+    pickle.dump({"indexes": ids, "boxes": boxes, "scores": scores}, open(pkl, "wb"))
+    records = load_proposals_into_dataset(records, pkl)
+    mapper = DeviceMultiInputMapper(min_sizes=(96, 128, 160), max_size=400, proposal_topk=80, seed=3)
+
+    def make(seed):
+        torch.manual_seed(seed)
+        model = build_model(20, (256, 256), torch.bfloat16); model.train()
+        groups = [{"params": [p], "lr": 2e-3 if nm.endswith(".bias") else 1e-3, "weight_decay": 0.0 if nm.endswith(".bias") else 5e-4}
+                  for nm, p in model.named_parameters() if p.requires_grad]
+        opt = HipSGD(groups, 1e-3, momentum=0.9)
+        sch = WarmupMultiStepLR(opt, [3, 5], warmup_iters=2)
+        return model, opt, sch
+    model, opt, sch = make(0)
+    batches = [[mapper(records[i % 3])] for i in range(5)]
+    tr = Trainer(model, opt, scheduler=sch)
+    for i in range(3):
+        ld = tr.run_step(batches[i])
+        assert torch.isfinite(ld.vector).all()
+    ck = DetectionCheckpointer(model, str(tmp_path), optimizer=opt, scheduler=sch)
+    ck.save("model_0000002", iteration=2)
+    model.roi_heads._drop_counter = 1000
+    ref = tr.run_step(batches[3]).vector.detach().clone()
+    ref_w = model.roi_heads.box_head.fc1.weight.detach().clone()
+    # a fresh process would do exactly this
+    model2, opt2, sch2 = make(1)
+    ck2 = DetectionCheckpointer(model2, str(tmp_path), optimizer=opt2, scheduler=sch2)
+    extra = ck2.resume_or_load("", resume=True)
+    assert extra["iteration"] == 2 and sch2.last_epoch == 3
+    model2.roi_heads._drop_counter = 1000
+    tr2 = Trainer(model2, opt2, scheduler=sch2)
+    got = tr2.run_step(batches[3]).vector.detach()
+    assert torch.equal(got, ref)                                   # resumed run reproduces the original bit for bit
+    assert torch.equal(model2.roi_heads.box_head.fc1.weight.detach(), ref_w)
