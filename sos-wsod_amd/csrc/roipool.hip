@@ -358,23 +358,26 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
   const int c0 = blockIdx.x * CB, img = blockIdx.y;
   const int r0 = blockIdx.z * chunk, r1 = min(R, r0 + chunk);
   const int tid = threadIdx.x;
-  // ROIs of this image, grouped by bin-window size class (counting sort over 8 classes): a wave holds the 49 bins of one
+  // ROIs of this image, grouped by bin-window size class (counting sort): a wave holds the 49 bins of one
   // ROI plus 15 of the next, and walks every lane's window to the longest one — neighbours of similar size waste less
-  __shared__ int s_hist[9];
-  if (tid < 9) s_hist[tid] = 0;
+  // The scan below runs every lane of a wave max(window rows) x max(window columns) times, so the classes are 2-D: 7 classes
+  // of the window height x 7 of its width (an area class put 2x8 and 8x2 windows side by side: 64 iterations for 16 pixels).
+  constexpr int NC1 = 7, NCLS = NC1 * NC1;
+  __shared__ int s_hist[NCLS + 1];
+  if (tid <= NCLS) s_hist[tid] = 0;
   if (tid == 0) s_cnt = 0;
   __syncthreads();
   int my_cls = -1;                                            // chunk <= NT: at most one ROI per thread
   for (int r = r0 + tid; r < r1; r += NT)
     if ((int)rois[(long)r * 5] == img) {
       const RoiGeom g0 = roi_geom(rois + (long)r * 5, scale, PH, PW);
-      const float a = g0.bin_h * g0.bin_w;                    // window area in pixels ~ trip count
-      my_cls = a < 2.f ? 0 : a < 4.f ? 1 : a < 8.f ? 2 : a < 14.f ? 3 : a < 22.f ? 4 : a < 34.f ? 5 : a < 52.f ? 6 : 7;
+      auto cls1 = [](float b) { return b < 1.f ? 0 : b < 2.f ? 1 : b < 3.f ? 2 : b < 4.f ? 3 : b < 6.f ? 4 : b < 8.f ? 5 : 6; };
+      my_cls = cls1(g0.bin_h) * NC1 + cls1(g0.bin_w);          // window ~ (ceil(bin_h) + 1) x (ceil(bin_w) + 1) pixels
       atomicAdd(&s_hist[my_cls + 1], 1);
       atomicAdd(&s_cnt, 1);
     }
   __syncthreads();
-  if (tid == 0) { for (int c = 1; c < 9; ++c) s_hist[c] += s_hist[c - 1]; }
+  if (tid == 0) { for (int c = 1; c <= NCLS; ++c) s_hist[c] += s_hist[c - 1]; }
   __syncthreads();
   if (my_cls >= 0) s_list[atomicAdd(&s_hist[my_cls], 1)] = r0 + tid;
   __syncthreads();
