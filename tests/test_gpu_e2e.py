@@ -540,3 +540,35 @@ def test_train_loop_from_proposal_file_to_checkpoint(tmp_path):
     got = tr2.run_step(batches[3]).vector.detach()
     assert torch.equal(got, ref)                                   # resumed run reproduces the original bit for bit
     assert torch.equal(model2.roi_heads.box_head.fc1.weight.detach(), ref_w)
+
+
+def test_baseline_config1_fp32_parity_against_the_oracle():
+    """BASELINE.json configs[0] / SURVEY §8d #1: one view set, 512x512 (+ 640x640 second scale), 500 proposals, K = 20, fp32 —
+    the CPU oracle against the HIP path at full image size: losses within 1e-4 relative (north_star's bar), pseudo-label
+    indices / classes and proposal labels bit exact.  (dan 1024: the contraction width does not change what is tested;
+    the CPU side stays at a few seconds)"""
+    from sos_wsod_amd.events import EventStorage
+    K, R, H, W, dan = 20, 500, 512, 512, (1024, 1024)
+    P = O.make_params(K, dan, tag="pcfg1", head_scale=30.0)
+    views, gt = O.make_views(H, W, R, n_gt=2, K=K, scale2=1.25, tag="vcfg1")
+    masks = O.make_masks(R, dan, tag="mcfg1")
+    assert views[2]["image"].shape[1:] == (640, 640)
+    ol, oaux, _ = O.oicr_plus_iteration(P, views, gt, masks, K=K)
+    model = build_model(K, dan, torch.float32)
+    load_params(model, P)
+    model.train()
+    model.roi_heads.debug_drop_masks = [[torch.from_numpy(m) for m in v] for v in masks]
+    with EventStorage(0):
+        losses = model(to_batched_inputs(views, gt))
+        sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    for k, v in losses.items():
+        assert abs(v.item() - ol[k]) <= 1e-4 * abs(ol[k]) + 1e-7, (k, v.item(), ol[k])
+    aux = model.roi_heads.last_aux
+    for k in range(4):
+        r, o = aux["rounds"][k], oaux["rounds"][k]
+        n = int(r["pgt_count"].item())
+        assert np.array_equal(r["pgt_index"][:n].cpu().numpy(), o["pgt"]["index"])
+        assert np.array_equal(r["pgt_class"][:n].cpu().numpy(), o["pgt"]["classes"])
+        assert np.array_equal(r["lab_class"].cpu().numpy(), o["labels"]["gt_classes"])
+        assert np.array_equal(r["lab_index"].cpu().numpy(), o["labels"]["gt_index"])
