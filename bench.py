@@ -31,16 +31,19 @@ K = 20
 DAN = (4096, 4096)
 
 
-def make_inputs(device, seed):
-    """Synthetic VOC-shaped 4-view input: u8 images, proposals sorted by objectness, flipped views mirror x."""
+def make_inputs(device, seed, H=None, W=None, R=None, K=None, n_gt=2):
+    """Synthetic VOC-shaped 4-view input: u8 images, proposals sorted by objectness, flipped views mirror x.
+    Sizes default to the module constants (BASELINE config #2); config #4 = make_inputs(dev, s, 800, 1333, 4000, 80)."""
     from sos_wsod_amd.structures import Boxes, Instances
+    H = globals()["H"] if H is None else H; W = globals()["W"] if W is None else W
+    R = globals()["R"] if R is None else R; K = globals()["K"] if K is None else K
     g = torch.Generator().manual_seed(seed)
     d = {}
     x1 = torch.rand(R, generator=g) * (W - 32); y1 = torch.rand(R, generator=g) * (H - 32)
     bw = 24 + torch.rand(R, generator=g) * (W - x1 - 24); bh = 24 + torch.rand(R, generator=g) * (H - y1 - 24)
     boxes = torch.stack([x1, y1, torch.minimum(x1 + bw, torch.tensor(float(W))), torch.minimum(y1 + bh, torch.tensor(float(H)))], 1)
     obj = torch.sort(torch.rand(R, generator=g), descending=True).values
-    gt = torch.unique(torch.randint(0, K, (2,), generator=g))
+    gt = torch.unique(torch.randint(0, K, (n_gt,), generator=g))
     for scale in ("1", "2"):
         img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
         for flip in ("", "_flip"):
@@ -57,7 +60,8 @@ def make_inputs(device, seed):
     return [d]
 
 
-def build(device, dtype):
+def build(device, dtype, K=None, freeze_at=2):
+    K = globals()["K"] if K is None else K
     from sos_wsod_amd.backbone_vgg import VGG16
     from sos_wsod_amd.box_head import DiscriminativeAdaptionNeck
     from sos_wsod_amd.fast_rcnn_oicr import OICROutputLayers
@@ -68,7 +72,7 @@ def build(device, dtype):
     from sos_wsod_amd.structures import ShapeSpec
     torch.manual_seed(1234)
     with torch.device(device):
-        backbone = VGG16(conv5_dilation=2, freeze_at=2, out_features=["plain5"], compute_dtype=dtype)
+        backbone = VGG16(conv5_dilation=2, freeze_at=freeze_at, out_features=["plain5"], compute_dtype=dtype)
         pooler = ROIPooler(output_size=7, scales=(1.0 / 8,), sampling_ratio=0, pooler_type="ROIPool")
         head = DiscriminativeAdaptionNeck(ShapeSpec(channels=512, height=7, width=7), conv_dims=[], fc_dims=list(DAN),
                                           compute_dtype=dtype)

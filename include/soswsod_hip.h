@@ -149,8 +149,10 @@ int sw_oicr_mean_probs(int V, int R, int K, int n_rounds, const float* logits, l
  * Outputs per round: lab_class (class | K background | -1 ignore), lab_weight, lab_index [n_rounds][R]; the kept
  * pseudo-GT list (score-descending): pgt_count [n_rounds], pgt_index/pgt_class/pgt_score [n_rounds][top_k*G].
  * top_k = max(int(R * MIST_P), 1) is computed by the host exactly as the reference does (:659-660).
- * workspace: >= n_rounds * sw_mine_workspace_bytes(top_k, G) bytes. Limits: R <= 16384, top_k*G <= 16384. */
-long sw_mine_workspace_bytes(int top_k, int G);
+ * workspace: >= n_rounds * sw_mine_workspace_bytes(R, top_k, G) bytes.  The sort keys live in LDS while R and top_k*G
+ * are <= 16384; beyond that (COCO: PRECOMPUTED_PROPOSAL_TOPK_TRAIN 10000 with >= 17 image-level classes,
+ * coco_oicr_plus.yaml:67) the workspace carries them.  Limits: R, top_k*G <= 2^22, top_k*G bytes of LDS (<= 144 KiB). */
+long sw_mine_workspace_bytes(int R, int top_k, int G);
 int sw_oicr_mine_label(int R, int ncol, int K, int n_rounds, const float* scores, const int32_t* gt_classes, int G,
                        const float* boxes, int top_k, float score_thresh, float nms_thresh, float iou_bg,
                        float iou_fg, int32_t* lab_class, float* lab_weight, int32_t* lab_index, int32_t* pgt_count,

@@ -67,7 +67,7 @@ SIGNATURES = {
                              c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_mean_views": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "sw_oicr_mean_probs": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
-    "sw_mine_workspace_bytes": (c_long, [c_int, c_int]),
+    "sw_mine_workspace_bytes": (c_long, [c_int, c_int, c_int]),
     "sw_oicr_mine_label": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(1024) void mine_label_kernel(int R, int ncol, int K
                                                           int* __restrict__ lab_index, int* __restrict__ pgt_count,
                                                           int* __restrict__ pgt_index, int* __restrict__ pgt_class,
                                                           float* __restrict__ pgt_score, char* __restrict__ ws,
-                                                          long ws_stride) {
+                                                          long ws_stride, int keys_in_ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n_slots = top_k * G;
   {                                             // one workgroup per refinement round, rounds laid out back to back
@@ -365,8 +365,11 @@ __global__ __launch_bounds__(1024) void mine_label_kernel(int R, int ncol, int K
     pgt_score += (long)round * n_slots; ws += (long)round * ws_stride;
   }
   const int NP = next_pow2(R > n_slots ? R : n_slots);
-  unsigned long long* keys = (unsigned long long*)smem;                 // [NP]
-  unsigned char* sup = (unsigned char*)(smem + (size_t)NP * 8);          // [n_slots]
+  // sort keys: LDS while NP * 8 B + the suppression bytes fit (R, top_k*G <= 16384: every VOC / COCO recipe with up to 16
+  // image-level classes), else a key array at the end of this round's workspace (COCO's 10000 proposals with >= 17 classes:
+  // one workgroup sorts through its CU's write-through L1, __syncthreads() orders the passes)
+  unsigned long long* keys = keys_in_ws ? (unsigned long long*)(ws + ws_stride - (long)NP * 8) : (unsigned long long*)smem;
+  unsigned char* sup = (unsigned char*)(smem + (keys_in_ws ? 0 : (size_t)NP * 8));   // [n_slots]
   __shared__ int s_scan[1024];
   __shared__ int s_nk;
   float* slot_score = (float*)ws;                                        // [n_slots]  rank-major, class-minor
@@ -672,7 +675,20 @@ extern "C" int sw_oicr_refine_loss(int V, int R, int K, int n_rounds, const floa
   return 0;
 }
 
-extern "C" long sw_mine_workspace_bytes(int top_k, int G) { return (((long)top_k * G * 20 + 64) + 15) / 16 * 16; }
+static int mine_np(int R, int top_k, int G) {
+  const long need = R > (long)top_k * G ? R : (long)top_k * G;
+  int np = 64;
+  while (np < need) np <<= 1;
+  return np;
+}
+static bool mine_keys_in_ws(int R, int top_k, int G) {
+  return (size_t)mine_np(R, top_k, G) * 8 + (size_t)top_k * G > 144 * 1024;
+}
+extern "C" long sw_mine_workspace_bytes(int R, int top_k, int G) {
+  long b = (((long)top_k * G * 20 + 64) + 15) / 16 * 16;
+  if (mine_keys_in_ws(R, top_k, G)) b += (long)mine_np(R, top_k, G) * 8;
+  return b;
+}
 
 extern "C" int sw_oicr_mine_label(int R, int ncol, int K, int n_rounds, const float* scores, const int32_t* gt_classes,
                                   int G, const float* boxes, int top_k, float score_thresh, float nms_thresh,
@@ -680,16 +696,16 @@ extern "C" int sw_oicr_mine_label(int R, int ncol, int K, int n_rounds, const fl
                                   int32_t* lab_index, int32_t* pgt_count, int32_t* pgt_index, int32_t* pgt_class,
                                   float* pgt_score, void* workspace, hipStream_t stream) {
   SW_ENTER();
-  if (R > 16384 || (long)top_k * G > 16384 || top_k > R || G < 1 || n_rounds < 1) return -6;
-  int np = 64;
-  const int need = R > top_k * G ? R : top_k * G;
-  while (np < need) np <<= 1;
-  const size_t lds = (size_t)np * 8 + (size_t)top_k * G;
+  if (R > (1 << 22) || (long)top_k * G > (1 << 22) || top_k > R || G < 1 || n_rounds < 1) return -6;
+  const int np = mine_np(R, top_k, G);
+  const int in_ws = mine_keys_in_ws(R, top_k, G) ? 1 : 0;
+  const size_t lds = (in_ws ? 0 : (size_t)np * 8) + (size_t)top_k * G;
+  if (lds > 144 * 1024) return -6;
   hipError_t e = hipFuncSetAttribute((const void*)mine_label_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(mine_label_kernel, dim3(n_rounds), dim3(1024), lds, stream, R, ncol, K, scores, gt_classes, G, boxes,
                      top_k, score_thresh, nms_thresh, iou_bg, iou_fg, lab_class, lab_weight, lab_index, pgt_count,
-                     pgt_index, pgt_class, pgt_score, (char*)workspace, sw_mine_workspace_bytes(top_k, G));
+                     pgt_index, pgt_class, pgt_score, (char*)workspace, sw_mine_workspace_bytes(R, top_k, G), in_ws);
   SW_CHECK_LAUNCH();
   return 0;
 }

@@ -287,8 +287,8 @@ def oicr_mean_probs(logits, V, R, K, n_rounds, cls_col0, col_stride, out):
     return out
 
 
-def mine_workspace_bytes(top_k, G, n_rounds=1):
-    return int(lib.sw_mine_workspace_bytes(top_k, G)) * n_rounds
+def mine_workspace_bytes(R, top_k, G, n_rounds=1):
+    return int(lib.sw_mine_workspace_bytes(R, top_k, G)) * n_rounds
 
 
 def oicr_mine_label(scores, gt_classes_i32, boxes, K, top_k, thresh, nms_thresh, iou_bg, iou_fg, lab_class, lab_weight,

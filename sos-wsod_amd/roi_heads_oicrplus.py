@@ -331,7 +331,7 @@ class OICRPlusHeads(nn.Module):
         # --- K refinement rounds: mine pseudo-GT, label (one workgroup per round), then all rounds' losses at once
         top_k = max(int(R * self.mist_p), 1)                      # roi_heads_oicrplus.py:659-660
         G = inp["G"]
-        ws = torch.empty(ops.mine_workspace_bytes(top_k, G, RK), device=dev, dtype=torch.uint8)
+        ws = torch.empty(ops.mine_workspace_bytes(R, top_k, G, RK), device=dev, dtype=torch.uint8)
         lab_c = torch.empty(RK, R, device=dev, dtype=torch.int32); lab_w = torch.empty(RK, R, device=dev, dtype=torch.float32)
         lab_i = torch.empty(RK, R, device=dev, dtype=torch.int32); cnt = torch.empty(RK, device=dev, dtype=torch.int32)
         pi = torch.empty(RK, top_k * G, device=dev, dtype=torch.int32); pc = torch.empty_like(pi)
@@ -349,6 +349,7 @@ class OICRPlusHeads(nn.Module):
         self.last_aux = aux
         aux["fc7"] = h2
         aux["logits"] = logits
+        aux["mine_scores"] = mine_scores
         return dict(losses=losses, feats=feats, rois=rois, obj=obj, pooled=pooled, argmax=argmax, h1=h1, h2=h2, W1=W1, W1T=W1T, W2=W2,
                     Wh=Wh, dlogits=dlogits, R=R, train_dropout=training_dropout)
 

@@ -291,7 +291,7 @@ def test_mining_and_labels_bit_exact_vs_golden(ops, case, golden_dir):
         lab_i = torch.empty(R, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         pi = torch.empty(top_k * G, dtype=torch.int32, device="cuda"); pc = torch.empty_like(pi)
         ps = torch.empty(top_k * G, device="cuda")
-        ws = torch.empty(ops.mine_workspace_bytes(top_k, G), dtype=torch.uint8, device="cuda")
+        ws = torch.empty(ops.mine_workspace_bytes(R, top_k, G), dtype=torch.uint8, device="cuda")
         ops.oicr_mine_label(sc, gt, boxes, K, top_k, 0.05, 0.01, 0.5, 0.6, lab_c, lab_w, lab_i, cnt, pi, pc, ps, ws)
         n = int(cnt.item())
         assert np.array_equal(pi[:n].cpu().numpy(), g[f"{variant}/pgt_index"])
@@ -319,7 +319,7 @@ def test_mining_rounds_side_by_side(ops, golden_dir, case):
     lab_i = torch.empty(NR, R, dtype=torch.int32, device="cuda"); cnt = torch.zeros(NR, dtype=torch.int32, device="cuda")
     pi = torch.empty(NR, top_k * G, dtype=torch.int32, device="cuda"); pc = torch.empty_like(pi)
     ps = torch.empty(NR, top_k * G, device="cuda")
-    ws = torch.empty(ops.mine_workspace_bytes(top_k, G, NR), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(ops.mine_workspace_bytes(R, top_k, G, NR), dtype=torch.uint8, device="cuda")
     ops.oicr_mine_label(sc.cuda(), gt, boxes, K, top_k, 0.05, 0.01, 0.5, 0.6, lab_c, lab_w, lab_i, cnt, pi, pc, ps, ws)
     for k, variant in enumerate(names):
         n = int(cnt[k].item())
@@ -367,7 +367,7 @@ def test_mining_ties_and_single_proposal(ops):
         lab_c = torch.empty(R, dtype=torch.int32, device="cuda"); lab_w = torch.empty(R, device="cuda")
         lab_i = torch.empty(R, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
         pi = torch.empty(top_k * G, dtype=torch.int32, device="cuda"); pc = torch.empty_like(pi); ps = torch.empty(top_k * G, device="cuda")
-        ws = torch.empty(ops.mine_workspace_bytes(top_k, G), dtype=torch.uint8, device="cuda")
+        ws = torch.empty(ops.mine_workspace_bytes(R, top_k, G), dtype=torch.uint8, device="cuda")
         ops.oicr_mine_label(torch.from_numpy(sc).cuda(), torch.from_numpy(gt.astype(np.int32)).cuda(),
                             torch.from_numpy(views[0]["boxes"]).cuda(), K, top_k, 0.05, 0.01, 0.5, 0.6, lab_c, lab_w, lab_i,
                             cnt, pi, pc, ps, ws)

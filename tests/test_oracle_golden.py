@@ -61,6 +61,19 @@ def test_mining_and_labels_bit_exact(case, golden_dir):
         assert np.array_equal(l["gt_boxes"], g[f"{variant}/gt_boxes"])
 
 
+def test_vector_nms_equals_the_line_by_line_restatement():
+    """nms_keep (numpy vector form used at full size) == nms_keep_scalar (nms_cpu.cpp restated pair by pair), incl. ties,
+    degenerate boxes and both thresholds of the path (0.01 mining, 0.3 inference)"""
+    rng = np.random.RandomState(3)
+    for n, thr in ((1, 0.01), (37, 0.01), (300, 0.3), (300, 0.01), (64, 0.5)):
+        xy = rng.rand(n, 2).astype(np.float32) * 200
+        wh = rng.rand(n, 2).astype(np.float32) * 120
+        wh[rng.rand(n) < 0.1] = 0                                   # zero-area boxes (0/0 -> NaN > thr is False)
+        b = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        s = np.round(rng.rand(n).astype(np.float32), 1)             # many exact ties
+        assert np.array_equal(O.nms_keep(b, s, thr), O.nms_keep_scalar(b, s, thr)), (n, thr)
+
+
 def test_inference_matches_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "infer_s0.npz"))
     e = np.load(os.path.join(golden_dir, "e2e_s0.npz"))
