@@ -127,7 +127,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--images-per-gpu", type=int, default=1,
+                    help="images (4-view sets) per GPU per step; BASELINE config #3 = --gpus 8 --images-per-gpu 2")
+    ap.add_argument("--no-fp32-line", action="store_true", help="skip the short fp32 timing (extra key fp32_ms_per_step)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (launch.py:55-73 does mp.spawn).  Fresh children
+        # through torch.distributed.run; this process has not touched the GPU and only waits for them.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
     import sos_wsod_amd  # noqa: F401  (fails loudly if the HIP extension is missing)
     import sos_wsod_amd.ops as ops
@@ -151,7 +167,8 @@ def main():
                            "weight_decay": 0.0 if name.endswith(".bias") else 5e-4})
     opt = HipSGD(groups, 1e-3, momentum=0.9)
     trainer = Trainer(model, opt)
-    batches = [make_inputs(device, 100 + rank * 17 + i) for i in range(2)]
+    B = args.images_per_gpu
+    batches = [sum((make_inputs(device, 100 + rank * 17 + 2 * i + 1000 * b) for b in range(B)), []) for i in range(2)]
 
     def sync():
         if world > 1:
@@ -176,7 +193,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        M = 4 * R
+        M = 4 * R * B
         flops = {"fc6_fwd": 2.0 * M * 25088 * DAN[0], "fc6_dgrad": 2.0 * M * 25088 * DAN[0], "fc6_wgrad": 2.0 * M * 25088 * DAN[0],
                  "plain5.conv3_fwd": 2.0 * (2 * 63 * 63) * 512 * 4608}
         avg_ms = {t: (sum(v) / len(v) if v else None) for t, v in times.items()}
@@ -225,13 +242,13 @@ def main():
         roofline["mfma_busy_counter"] = busy_of(dom)
         out = {
             "metric": "images/s (1/2/4/8 MI355X) VGG16+OICR 2000-prop; conv5_3 MFMA-util %",
-            "value": round(4.0 * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "value": round(4.0 * B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"OICR+ training iteration: 4 views/step/GPU (2 scales x h-flip, every view {H}x{W}), "
+            "config": {"workload": f"OICR+ training iteration: {4 * B} views/step/GPU ({B} image(s) x 2 scales x h-flip, every view {H}x{W}), "
                                    f"R={R} proposals/view, K={K}, VGG16 dilated-C5 + ROIPool 7x7 + fc6/fc7 4096 + WSDDN + 4 OICR heads, "
-                                   "fwd+bwd+SGD(momentum, wd)", "views_per_step_per_gpu": 4, "image": "one view",
-                       "oicr_iterations_per_s": round(world * args.steps / dt, 3), "parallelism": f"dp{world}"},
+                                   "fwd+bwd+SGD(momentum, wd)", "views_per_step_per_gpu": 4 * B, "image": "one view",
+                       "oicr_iterations_per_s": round(B * world * args.steps / dt, 3), "parallelism": f"dp{world}"},
             "roofline": roofline,
             # the other two launches of the same GEMM family (`roofline` above is the costliest of the three)
             "roofline_fc6": {t: dict({k: v for k, v in roof(t).items() if k in ("achieved", "frac", "avg_ms")},
@@ -245,6 +262,22 @@ def main():
                                        "avg_ms": round(conv_alone_ms, 4), "mfma_busy_counter": busy_of("conv5_3")},
             "kernel_ms_per_step": {t: round(v, 3) for t, v in tot_ms.items()},
         }
+        if world == 1 and dtype == torch.bfloat16 and not args.no_fp32_line:
+            # the reference's own precision (fp32 storage, exact-f32 MFMA: 1/16 of the bf16 rate), a short run for the record
+            del trainer, opt, model
+            torch.cuda.empty_cache()
+            m32 = build(device, torch.float32); m32.train()
+            g32 = [{"params": [p], "lr": 2e-3 if n.endswith(".bias") else 1e-3, "weight_decay": 0.0 if n.endswith(".bias") else 5e-4}
+                   for n, p in m32.named_parameters() if p.requires_grad]
+            t32 = Trainer(m32, HipSGD(g32, 1e-3, momentum=0.9))
+            for i in range(2):
+                t32.run_step(batches[i % 2])
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for i in range(5):
+                t32.run_step(batches[i % 2])
+            torch.cuda.synchronize()
+            out["fp32_ms_per_step"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+            del t32, m32
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -75,6 +75,13 @@ int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int Cout, int d
 long sw_conv3x3_wgrad_workspace_floats(int dtype, int nimg, int H, int W, int Cin, int Cout, int splitk);
 int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                      const void* dy, float* dw_oihw, float* workspace, int splitk, sw_stream_t stream);
+/* The two halves of sw_conv3x3_wgrad on their own: `_slabs` writes this problem's workspace_floats / (Cout*9*Cin) partial
+ * slabs at `workspace`; `_fold` adds `nslab` consecutive slabs in fixed order into dW (OIHW).  Several problems with the same
+ * weight (the views of one iteration, possibly running on different streams) put their slabs back to back and share ONE
+ * fold: the sum over views that autograd would otherwise form with one add per parameter. */
+int sw_conv3x3_wgrad_slabs(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
+                           const void* dy, float* workspace, int splitk, sw_stream_t stream);
+int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, sw_stream_t stream);
 /* OIHW f32 master weights -> kernel layout.  mode 0: wk[co][tap][ci_pad] (forward, ci zero padded to cin_pad);
  * mode 1: wk[ci][8-tap][co] (data gradient: taps flipped, in/out swapped). */
 int sw_conv_weight_prep(int dtype, int mode, int Cout, int Cin, int cin_pad, const float* w_oihw, void* wk,
@@ -203,6 +210,10 @@ int sw_detect_postprocess(int R, int K, const float* all_scores, const float* al
  * row chunk. */
 long sw_colsum_workspace_floats(int dtype, int M, int N);
 int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, float* workspace, sw_stream_t stream);
+/* halves of the workspace form: `_partial` writes sw_colsum_workspace_floats(dtype, M, N) / N partial rows at `workspace`,
+ * `_fold` adds n_partial_rows consecutive rows (of one or several matrices) in fixed order */
+int sw_colsum_partial(int dtype, int M, int N, const void* X, long ld, float* workspace, sw_stream_t stream);
+int sw_colsum_fold(int N, int n_partial_rows, const float* workspace, float* out, sw_stream_t stream);
 /* rows x cols copy/convert f32 -> dtype with independent leading dimensions (weight staging). */
 int sw_convert_2d(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
                   sw_stream_t stream);
@@ -251,8 +262,22 @@ typedef struct {
   long ld0, ld1;
 } sw_sgd_tensor;
 int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float momentum, float grad_scale, sw_stream_t stream);
-/* out[i] = sum_v loss_view[i][v] / V   (loss assembly, roi_heads_oicrplus.py:283-288,384-388) */
-int sw_loss_finalize(int n_losses, int V, const float* loss_view, float* out, sw_stream_t stream);
+/* out[i] = mean over the n_images images of (sum_v loss_view[b][i][v] / V)   (loss assembly, roi_heads_oicrplus.py:283-288,
+ * 384-388; the reference runs one image per GPU, n_images > 1 is the mean DDP would form over as many ranks);
+ * total (optional, 2 floats): [0] = sum_i out[i] in index order (train_net_multi.py:129 sum(loss_dict.values())),
+ * [1] = 1.0 if that sum is finite else 0.0 (train_loop.py:253-259 _detect_anomaly without a host round trip). */
+int sw_loss_finalize(int n_losses, int V, int n_images, const float* loss_view, float* out, float* total,
+                     sw_stream_t stream);
+/* sw_scale_cols with the column scale formed from the cotangents: ((g_losses ? g_losses[col_to_loss[n]] : 0) +
+ * (g_total ? g_total[0] : 0)) * mul for n < n_valid, 0 for the padding columns (never read from `in`). */
+int sw_scale_cols_loss(int dtype, int M, int N, int n_valid, const float* in, long ld_in, const float* g_losses,
+                       const float* g_total, const int32_t* col_to_loss, float mul, void* out, long ld_out,
+                       sw_stream_t stream);
+/* The four views' (R,4) proposal boxes and (R,) objectness logits of one image (box_ptrs4 / obj_ptrs4: HOST arrays of 4
+ * device pointers) -> boxes [4][R][4], obj [4][R], rois [2][2R][5] = (batch index 0 | 1, box) per scale
+ * (poolers.py:81-108 convert_boxes_to_pooler_format for the view / flipped-view pair of a scale). */
+int sw_pack_views(int R, const float* const* box_ptrs4, const float* const* obj_ptrs4, float* boxes, float* obj,
+                  float* rois, sw_stream_t stream);
 
 const char* sw_version(void);
 

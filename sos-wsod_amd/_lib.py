@@ -81,6 +81,11 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_colsum": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "sw_colsum_workspace_floats": (c_long, [c_int, c_int, c_int]),
+    "sw_colsum_partial": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p]),
+    "sw_colsum_fold": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_conv3x3_wgrad_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p]),
+    "sw_conv3x3_wgrad_fold": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_relu_bwd": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
@@ -92,7 +97,11 @@ SIGNATURES = {
                                      c_void_p]),
     "sw_convert_2d_t": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_sgd_multi": (c_int, [c_int, ctypes.POINTER(SgdTensor), c_float, c_float, c_void_p]),
-    "sw_loss_finalize": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_loss_finalize": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sw_scale_cols_loss": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_float,
+                                   c_void_p, c_long, c_void_p]),
+    "sw_pack_views": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
+                              c_void_p]),
     "sw_version": (ctypes.c_char_p, []),
 }
 

@@ -50,17 +50,52 @@ class PlainBlock(nn.Module):
         return self
 
 
+def _wgrad_splitk(cout, cin, npix):
+    """K-splits of a conv weight gradient: tiles x splits just under one resident wave of workgroups (256 CUs x 2 at 64 KiB
+    LDS each = 512 slots) was the optimum for every conv3..conv5 shape (tools/wgrad_sweep.py: 3 / 7 / 14 / 28 splits); one
+    more split starts a second, mostly empty wave (+30 %)"""
+    tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
+    return max(1, min(32, 512 // tiles, max(1, npix // 1024)))
+
+
 class _VGGFunction(torch.autograd.Function):
-    """x: NHWC (N,H,W,cpad) compute-dtype tensor (no grad).  Returns plain5 NHWC."""
+    """(x_0 .. x_{n-1}, *params) -> (plain5_0 .. plain5_{n-1}); every x_i is an NHWC (N_i, H_i, W_i, cpad) compute-dtype
+    batch without grad (one scale of one image: the view and its flipped copy), sizes may differ between the x_i.
+
+    ONE autograd node for all view batches of an iteration: the batches alternate between the current stream and a side
+    stream (their ~250-workgroup conv4 / conv5 launches share the CUs: 64 KiB LDS per workgroup -> two per CU) in forward
+    AND backward, and the weight / bias gradients of all batches meet in shared split-K workspaces that ONE ordered fold
+    per parameter sums — the sum over views never becomes an autograd accumulation (18 ATen adds per step before), the
+    result is deterministic, and autograd sees a single-stream node."""
 
     @staticmethod
-    def forward(ctx, module, x, *params):
+    def forward(ctx, module, n_in, *args):
+        xs, params = args[:n_in], args[n_in:]
+        main = torch.cuda.current_stream()
+        side = module.side_stream() if n_in > 1 else None
+        if side is not None:
+            side.wait_stream(main)
+        infos, outs = [], []
+        for i, x in enumerate(xs):
+            st = side if (side is not None and i % 2 == 1) else main
+            with torch.cuda.stream(st):
+                if st is not main:
+                    x.record_stream(st)
+                out, info = _VGGFunction._forward_one(module, x, params)
+                if st is not main:
+                    out.record_stream(main)                 # allocated on the side stream's pool, consumed on the main one
+            infos.append(info); outs.append(out)
+        if side is not None:
+            main.wait_stream(side)
+        ctx.module, ctx.infos, ctx.params = module, infos, params
+        return tuple(outs)
+
+    @staticmethod
+    def _forward_one(module, x, params):
         dtype = x.dtype
-        acts = []          # per conv: (input activation, output activation)
-        pools = []         # per stage: (pre-pool act, stride) or None
         cur = x
         pi = 0
-        stage_info = []
+        stage_info = []     # per stage: ([(input act, output act) per conv], pre-pool act or None)
         for blk in module.blocks:
             conv_io = []
             for ci in range(blk.num_conv):
@@ -82,31 +117,83 @@ class _VGGFunction(torch.autograd.Function):
                 ops.maxpool_fwd(cur, pooled, s)
                 cur = pooled
             stage_info.append((conv_io, pre_pool))
-        ctx.module = module
-        ctx.stage_info = stage_info
-        ctx.params = params
-        return cur
+        return cur, stage_info
 
     @staticmethod
-    def backward(ctx, g):
-        module, stage_info, params = ctx.module, ctx.stage_info, ctx.params
-        # the saved activations include this node's own output (ReLU mask of the last conv): node -> ctx -> tensor -> grad_fn
+    def backward(ctx, *gs):
+        module, infos, params = ctx.module, ctx.infos, ctx.params
+        # the saved activations include this node's own outputs (ReLU mask of the last conv): node -> ctx -> tensor -> grad_fn
         # is a reference cycle that only Python's cyclic GC would free, hundreds of MB per step later.  Drop it now.
-        ctx.stage_info = None
-        dtype = stage_info[0][0][0][0].dtype
+        ctx.infos = None
+        n_in = len(infos)
         grads = [None] * len(params)
+        first_trainable = module.first_trainable_conv()      # (stage idx, conv idx) or None
+        live = [i for i in range(n_in) if gs[i] is not None]
+        if first_trainable is None or not live:
+            return (None, None) + (None,) * n_in + tuple(grads)
+        dev = gs[live[0]].device
+        dtype = infos[0][0][0][0][0].dtype
+        main = torch.cuda.current_stream()
+        side = module.side_stream() if len(live) > 1 else None
+        # ---- plan: per trainable conv one slab workspace / one partial-row workspace shared by all view batches
+        plan = {}            # pidx -> dict(ws, rows, per-batch offsets, totals, dw, db)
+        pidx = len(params)
+        for si in range(len(module.blocks) - 1, -1, -1):
+            blk = module.blocks[si]
+            for ci in range(blk.num_conv - 1, -1, -1):
+                pidx -= 2
+                w = params[pidx]
+                if w.requires_grad:
+                    cout = blk.out_channels
+                    slab_off, row_off, nslab, nrow, splits = {}, {}, 0, 0, {}
+                    for i in live:
+                        x_in = infos[i][si][0][ci][0]
+                        n, H, W, cin = x_in.shape
+                        splits[i] = _wgrad_splitk(cout, cin, n * H * W)
+                        slab_off[i], row_off[i] = nslab, nrow
+                        nslab += ops.conv3x3_wgrad_nslab(x_in, cout, splits[i])
+                        nrow += ops.colsum_nrows(dtype, n * H * W, cout)
+                    cin = infos[live[0]][si][0][ci][0].shape[3]
+                    plan[pidx] = dict(ws=torch.empty(nslab, cout * 9 * cin, device=dev, dtype=torch.float32),
+                                      rows=torch.empty(nrow, cout, device=dev, dtype=torch.float32), slab_off=slab_off,
+                                      row_off=row_off, nslab=nslab, nrow=nrow, splits=splits, cin=cin,
+                                      dw=torch.empty(cout, cin, 3, 3, device=dev, dtype=torch.float32),
+                                      db=torch.empty(cout, device=dev, dtype=torch.float32))
+                if (si, ci) == first_trainable:
+                    break
+            if si == first_trainable[0]:
+                break
+        if side is not None:
+            side.wait_stream(main)
+        for k, i in enumerate(live):
+            st = side if (side is not None and k % 2 == 1) else main
+            with torch.cuda.stream(st):
+                g = gs[i]
+                if st is not main:
+                    g.record_stream(st)
+                _VGGFunction._backward_one(module, infos[i], params, g, dtype, plan, i, first_trainable)
+            infos[i] = None
+        if side is not None:
+            main.wait_stream(side)
+        # ---- one ordered fold per parameter over the slabs / partial rows of every view batch
+        for pidx, pl in plan.items():
+            w = params[pidx]
+            ops.conv3x3_wgrad_fold(pl["ws"], pl["nslab"], pl["dw"])
+            grads[pidx] = pl["dw"][:, : w.shape[1]].contiguous() if pl["cin"] != w.shape[1] else pl["dw"]
+            ops.colsum_fold(pl["rows"], pl["nrow"], pl["db"])
+            grads[pidx + 1] = pl["db"]
+        return (None, None) + (None,) * n_in + tuple(grads)
+
+    @staticmethod
+    def _backward_one(module, stage_info, params, g, dtype, plan, i, first_trainable):
         g = g.contiguous()
         if g.dtype != dtype:
             g = g.to(dtype)
-        first_trainable = module.first_trainable_conv()      # (stage idx, conv idx) or None
-        if first_trainable is None:
-            return (None, None) + tuple(grads)
         # dz of the last conv: ReLU backward of the output feature (idempotent if the producer already masked)
         last_out = stage_info[-1][0][-1][1]
         assert stage_info[-1][1] is None, "backward expects the last stage to have no pool (vgg.py:197)"
         dz = ops.relu_bwd(last_out, g.clone())
         pidx = len(params)
-        done = False
         for si in range(len(stage_info) - 1, -1, -1):
             blk = module.blocks[si]
             conv_io, _ = stage_info[si]
@@ -115,22 +202,13 @@ class _VGGFunction(torch.autograd.Function):
                 x_in, _ = conv_io[ci]
                 w = params[pidx]
                 n, H, W, cin = x_in.shape
-                if w.requires_grad:
-                    dw = torch.empty(blk.out_channels, cin, 3, 3, device=g.device, dtype=torch.float32)
+                pl = plan.get(pidx)
+                if pl is not None:
                     npix = n * H * W
-                    tiles = ((blk.out_channels + 127) // 128) * ((9 * cin + 127) // 128)
-                    # one resident wave of workgroups: 256 CUs x 2 (64 KiB LDS each) = 512 slots; tiles * splits just under
-                    # that was the optimum for every conv3..conv5 shape (tools/wgrad_sweep.py: 3 / 7 / 14 / 28 splits), one
-                    # more split starts a second, mostly empty wave (+30 %)
-                    splitk = max(1, min(32, 512 // tiles, max(1, npix // 1024)))
-                    ops.conv3x3_wgrad(x_in, dz, dw, blk.dilation, splitk=splitk)
-                    grads[pidx] = dw[:, : w.shape[1]].contiguous() if cin != w.shape[1] else dw
-                    db = torch.empty(blk.out_channels, device=g.device, dtype=torch.float32)
-                    ops.colsum(dz.view(npix, blk.out_channels), npix, blk.out_channels, db)
-                    grads[pidx + 1] = db
+                    ops.conv3x3_wgrad_slabs(x_in, dz, pl["ws"][pl["slab_off"][i]:], blk.dilation, splitk=pl["splits"][i])
+                    ops.colsum_partial(dz.view(npix, blk.out_channels), npix, blk.out_channels, pl["rows"][pl["row_off"][i]:])
                 if (si, ci) == first_trainable:
-                    done = True
-                    break
+                    return
                 # data gradient: conv with flipped/transposed weights; ReLU mask of the producer fused when the
                 # input is a direct conv output (ci > 0); stage inputs go through the pool backward instead
                 wkd = module.staged_weight(w, 1, cin, dtype)
@@ -138,15 +216,12 @@ class _VGGFunction(torch.autograd.Function):
                 ref = x_in.view(n * H * W, cin) if ci > 0 else None
                 ops.conv3x3(dz, wkd, dx, blk.dilation, ops.make_epilogue(relu_ref=ref, out_dtype=dtype))
                 dz = dx
-            if done:
-                break
             # dz is now the gradient wrt this stage's input = previous stage's pooled output
             prev_pre_pool = stage_info[si - 1][1]
             pblk = module.blocks[si - 1]
             din = torch.empty_like(prev_pre_pool)
             ops.maxpool_bwd(prev_pre_pool, dz, din, pblk.pool_stride, relu_mask=True)
             dz = din
-        return (None, None) + tuple(grads)
 
 
 class VGG16(nn.Module):
@@ -156,6 +231,8 @@ class VGG16(nn.Module):
         super().__init__()
         self.num_classes = num_classes
         self.compute_dtype = compute_dtype
+        self.dual_stream = True           # alternate the view batches of forward_views between two HIP streams
+        self._side = None
         self._wk_cache = {}
         self._out_feature_strides, self._out_feature_channels = {}, {}
         self.stages_and_names = []
@@ -250,9 +327,22 @@ class VGG16(nn.Module):
                 out += [c.weight, c.bias]
         return out
 
+    def side_stream(self):
+        if not self.dual_stream:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
     def forward_nhwc(self, x_nhwc):
         """x_nhwc: (N,H,W,cpad) compute-dtype, channels >= 3 zero.  Returns NHWC plain5."""
-        return _VGGFunction.apply(self, x_nhwc, *self._flat_params())
+        return _VGGFunction.apply(self, 1, x_nhwc, *self._flat_params())[0]
+
+    def forward_views(self, xs):
+        """xs: list of NHWC view batches of possibly different sizes (rcnn_multi.py:153-154,174-175 calls the backbone once per
+        scale).  One autograd node; the batches alternate between two HIP streams.  Returns the list of NHWC plain5 maps."""
+        self.stage_all_weights(with_dgrad=torch.is_grad_enabled())      # on the current stream, before the fork
+        return list(_VGGFunction.apply(self, len(xs), *xs, *self._flat_params()))
 
     def forward(self, x):
         """x: (N,3,H,W) float32 normalised image batch (reference call shape) -> {"plain5": (N,512,h,w) view}"""

@@ -57,6 +57,11 @@ class DetectionCheckpointer:
             model = model.module
         self.model = model
         self.checkpointables = dict(checkpointables)          # e.g. optimizer=..., scheduler=...
+        # the heads' dropout stream position (seed drawn from SEED + rank, element counter): a resumed run continues the
+        # stream instead of replaying it.  Kept beside "model" so that the model's state dict has the reference's keys only.
+        ds = getattr(getattr(model, "roi_heads", None), "dropout_stream", None)
+        if ds is not None:
+            self.checkpointables.setdefault("dropout_stream", ds)
         self.save_dir = save_dir
         if save_to_disk is None:
             import torch.distributed as dist

@@ -617,6 +617,41 @@ __global__ void scale_cols_kernel(int M, int N, const float* __restrict__ in, lo
   }
 }
 
+// scale_cols with the per-column scale formed in place from the cotangents of the loss vector and of the total:
+//   cs[n] = ((g_losses ? g_losses[col_to_loss[n]] : 0) + (g_total ? g_total[0] : 0)) * mul   for n < n_valid, 0 beyond
+// (the padding columns of the packed logits are never read: `in` may hold anything there)
+template <typename T>
+__global__ void scale_cols_loss_kernel(int M, int N, int n_valid, const float* __restrict__ in, long ld_in,
+                                       const float* __restrict__ g_losses, const float* __restrict__ g_total,
+                                       const int* __restrict__ col_to_loss, float mul, T* __restrict__ out, long ld_out) {
+  const long total = (long)M * N;
+  const float gt = g_total ? g_total[0] : 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / N; const int n = (int)(i - m * N);
+    float v = 0.f;
+    if (n < n_valid) v = in[m * ld_in + n] * (((g_losses ? g_losses[col_to_loss[n]] : 0.f) + gt) * mul);
+    Elem<T>::store(out + m * ld_out + n, v);
+  }
+}
+
+// the four views' proposal boxes / objectness of one image -> the packed tensors the heads work on (one launch instead of
+// five torch.cat / stack): boxes [4][R][4], obj [4][R], rois [2][2R][5] (scale s: rows [0,R) = view 2s with batch index 0,
+// rows [R,2R) = view 2s+1 with batch index 1; poolers.py:81-108 convert_boxes_to_pooler_format)
+struct PackViewsArgs { const float* box[4]; const float* obj[4]; };
+__global__ void pack_views_kernel(int R, PackViewsArgs a, float* __restrict__ boxes, float* __restrict__ obj,
+                                  float* __restrict__ rois) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * R) return;
+  const int v = i / R, r = i - v * R;
+  const float* b = a.box[v] + (long)r * 4;
+  const float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+  float* o = boxes + (long)i * 4;
+  o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
+  obj[i] = a.obj[v][r];
+  float* q = rois + (long)i * 5;                     // (scale v/2, row (v&1)*R + r) == flat row i
+  q[0] = (float)(v & 1); q[1] = x1; q[2] = y1; q[3] = x2; q[4] = y2;
+}
+
 __global__ void mean_views_kernel(int V, long n, const float* __restrict__ in, float* __restrict__ out) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = in[i];
@@ -625,12 +660,27 @@ __global__ void mean_views_kernel(int V, long n, const float* __restrict__ in, f
   }
 }
 
-__global__ void loss_finalize_kernel(int nl, int V, const float* __restrict__ lv, float* __restrict__ out) {
+// out[i] = mean over images b of (mean over views v of lv[b][i][v]); out[nl] = sum_i out[i] (fixed order)
+__global__ void loss_finalize_kernel(int nl, int V, int B, const float* __restrict__ lv, float* __restrict__ out,
+                                     float* __restrict__ total) {
+  __shared__ float s_l[64];
   const int i = threadIdx.x;
   if (i < nl) {
-    float s = lv[i * V];
-    for (int v = 1; v < V; ++v) s += lv[i * V + v];
-    out[i] = __fdiv_rn(s, (float)V);
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float* p = lv + ((long)b * nl + i) * V;
+      float s = p[0];
+      for (int v = 1; v < V; ++v) s += p[v];
+      acc += __fdiv_rn(s, (float)V);
+    }
+    s_l[i] = out[i] = B == 1 ? acc : __fdiv_rn(acc, (float)B);
+  }
+  __syncthreads();
+  if (i == 0 && total) {
+    float t = s_l[0];
+    for (int j = 1; j < nl; ++j) t += s_l[j];
+    total[0] = t;
+    total[1] = (t - t == 0.f) ? 1.f : 0.f;          // finite flag (NaN / inf of any loss reaches the sum)
   }
 }
 
@@ -819,6 +869,32 @@ extern "C" long sw_colsum_workspace_floats(int dtype, int M, int N) {
   return (long)chunks * N;
 }
 
+// the two halves of the workspace form on their own: several matrices (the views of a backbone pass running on different
+// streams) write their partial rows into ONE workspace back to back, a single fold then sums all of them in fixed order
+extern "C" int sw_colsum_partial(int dtype, int M, int N, const void* X, long ld, float* workspace, hipStream_t stream) {
+  SW_ENTER();
+  if (dtype != SW_BF16 && dtype != SW_F32) return -1;
+  const int vec = dtype == SW_BF16 ? 8 : 4;
+  if (!workspace || M <= 0 || N <= 0 || (N % vec) || (ld % vec) || (((uintptr_t)X) & 15)) return -5;
+  int slabs, chunks, rpc;
+  colsum_ws_geometry(dtype, M, N, &slabs, &chunks, &rpc);
+  dim3 grid(slabs, chunks);
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(colsum_ws_kernel<unsigned short>, grid, dim3(256), 0, stream, M, N, rpc, (const unsigned short*)X, ld,
+                       workspace),
+    hipLaunchKernelGGL(colsum_ws_kernel<float>, grid, dim3(256), 0, stream, M, N, rpc, (const float*)X, ld, workspace));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_colsum_fold(int N, int n_partial_rows, const float* workspace, float* out, hipStream_t stream) {
+  SW_ENTER();
+  if (N <= 0 || n_partial_rows < 1) return -5;
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, N, n_partial_rows, workspace, out);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, float* workspace, hipStream_t stream) {
   SW_ENTER();
   if (N <= 0) return 0;
@@ -826,17 +902,9 @@ extern "C" int sw_colsum(int dtype, int M, int N, const void* X, long ld, float*
   const int vec = dtype == SW_BF16 ? 8 : 4;
   const bool ws_form = workspace && M > 0 && (N % vec) == 0 && (ld % vec) == 0 && (((uintptr_t)X) & 15) == 0;
   if (ws_form) {
-    int slabs, chunks, rpc;
-    colsum_ws_geometry(dtype, M, N, &slabs, &chunks, &rpc);
-    dim3 grid(slabs, chunks);
-    DISPATCH_T(dtype,
-      hipLaunchKernelGGL(colsum_ws_kernel<unsigned short>, grid, dim3(256), 0, stream, M, N, rpc, (const unsigned short*)X, ld,
-                         workspace),
-      hipLaunchKernelGGL(colsum_ws_kernel<float>, grid, dim3(256), 0, stream, M, N, rpc, (const float*)X, ld, workspace));
-    SW_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, N, chunks, workspace, out);
-    SW_CHECK_LAUNCH();
-    return 0;
+    const int rc = sw_colsum_partial(dtype, M, N, X, ld, workspace, stream);
+    if (rc) return rc;
+    return sw_colsum_fold(N, (int)(sw_colsum_workspace_floats(dtype, M, N) / N), workspace, out, stream);
   }
   hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
@@ -947,10 +1015,38 @@ extern "C" int sw_mean_views(int V, long n, const float* in, float* out, hipStre
   return 0;
 }
 
-extern "C" int sw_loss_finalize(int n_losses, int V, const float* loss_view, float* out, hipStream_t stream) {
+extern "C" int sw_loss_finalize(int n_losses, int V, int n_images, const float* loss_view, float* out, float* total,
+                                hipStream_t stream) {
   SW_ENTER();
-  if (n_losses > 64) return -6;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, n_losses, V, loss_view, out);
+  if (n_losses > 64 || n_losses < 1 || V < 1 || n_images < 1) return -6;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, n_losses, V, n_images, loss_view, out, total);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_scale_cols_loss(int dtype, int M, int N, int n_valid, const float* in, long ld_in, const float* g_losses,
+                                  const float* g_total, const int32_t* col_to_loss, float mul, void* out, long ld_out,
+                                  hipStream_t stream) {
+  SW_ENTER();
+  const long n = (long)M * N;
+  if (n <= 0) return 0;
+  if (!col_to_loss && g_losses) return -5;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(scale_cols_loss_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, M, N, n_valid, in, ld_in,
+                       g_losses, g_total, col_to_loss, mul, (unsigned short*)out, ld_out),
+    hipLaunchKernelGGL(scale_cols_loss_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, M, N, n_valid, in, ld_in,
+                       g_losses, g_total, col_to_loss, mul, (float*)out, ld_out));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_pack_views(int R, const float* const* box_ptrs4, const float* const* obj_ptrs4, float* boxes, float* obj,
+                             float* rois, hipStream_t stream) {
+  SW_ENTER();
+  if (R <= 0) return 0;
+  PackViewsArgs a;
+  for (int v = 0; v < 4; ++v) { a.box[v] = box_ptrs4[v]; a.obj[v] = obj_ptrs4[v]; }
+  hipLaunchKernelGGL(pack_views_kernel, dim3((4 * R + 255) / 256), dim3(256), 0, stream, R, a, boxes, obj, rois);
   SW_CHECK_LAUNCH();
   return 0;
 }

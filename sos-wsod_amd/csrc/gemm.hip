@@ -847,8 +847,8 @@ extern "C" long sw_conv3x3_wgrad_workspace_floats(int dtype, int nimg, int H, in
 // Every K-split stores its partial [co][tap][ci] tile into its own slab of the workspace with plain coalesced stores;
 // a second kernel adds the slabs in fixed order and permutes to OIHW.  (f32 atomics were measured 3-5x slower here:
 // the splits of one tile finish together and collide on the same addresses; this form is also deterministic.)
-extern "C" int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
-                                const void* dy, float* dw_oihw, float* workspace, int splitk, hipStream_t stream) {
+extern "C" int sw_conv3x3_wgrad_slabs(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
+                                      const void* dy, float* workspace, int splitk, hipStream_t stream) {
   SW_ENTER();
   const int epc = dtype == SW_BF16 ? 8 : 4;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
@@ -867,14 +867,28 @@ extern "C" int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int 
     if (ab >= 0xFFFFFF00L || bb >= 0xFFFFFF00L) return -6;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
   }
-  const int rc = dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, OP_KSTRIDED, OP_CONV_B, nslab, stream)
-                                  : dispatch_modes<float>(g, OP_KSTRIDED, OP_CONV_B, nslab, stream);
-  if (rc) return rc;
-  if ((size_t)36 * Cin > 65536 || (((uintptr_t)dw_oihw) & 15)) return -5;
+  return dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, OP_KSTRIDED, OP_CONV_B, nslab, stream)
+                          : dispatch_modes<float>(g, OP_KSTRIDED, OP_CONV_B, nslab, stream);
+}
+
+extern "C" int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw,
+                                     hipStream_t stream) {
+  SW_ENTER();
+  if (nslab < 1 || (Cin % 4)) return -5;
+  if ((size_t)36 * Cin > 65536 || (((uintptr_t)dw_oihw) & 15) || (((uintptr_t)workspace) & 15)) return -5;
   int parts = 1;                                              // input-channel ranges per output channel: >= 1024 workgroups
   while (Cout * parts < 1024 && (Cin % (parts * 2 * 4)) == 0 && Cin / (parts * 2) >= 32) parts *= 2;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cout, (unsigned)parts), dim3(256), (size_t)36 * Cin / parts, stream, Cout, Cin,
                      nslab, workspace, dw_oihw);
   SW_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
+                                const void* dy, float* dw_oihw, float* workspace, int splitk, hipStream_t stream) {
+  const int rc = sw_conv3x3_wgrad_slabs(dtype, nimg, H, W, Cin, Cout, dilation, x, dy, workspace, splitk, stream);
+  if (rc) return rc;
+  const long nelem = (long)Cout * 9 * Cin;
+  const int nslab = (int)(sw_conv3x3_wgrad_workspace_floats(dtype, nimg, H, W, Cin, Cout, splitk) / nelem);
+  return sw_conv3x3_wgrad_fold(Cin, Cout, nslab, workspace, dw_oihw, stream);
 }

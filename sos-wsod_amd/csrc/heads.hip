@@ -133,6 +133,7 @@ __global__ void mean_scores_kernel(int V, int R, int K, const float* __restrict_
     for (int v = 1; v < V; ++v) a += scores[(long)v * n + i];
     const long r = i / K; const int k = (int)(i - r * K);
     out[r * ld_out + k] = __fdiv_rn(a, (float)V);
+    if (k == 0) for (long j = K; j < ld_out; ++j) out[r * ld_out + j] = 0.f;   // pad columns (the rounds share a K+1 pitch)
   }
 }
 

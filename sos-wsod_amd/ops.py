@@ -150,6 +150,42 @@ def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1, workspace=None, tag=None):
     return dw_oihw
 
 
+def conv3x3_wgrad_nslab(x, cout, splitk):
+    """slabs that conv3x3_wgrad_slabs(x, dy -> cout channels, splitk) writes"""
+    n, H, W, Cin = x.shape
+    return int(lib.sw_conv3x3_wgrad_workspace_floats(dt(x), n, H, W, Cin, cout, splitk)) // (cout * 9 * Cin)
+
+
+def conv3x3_wgrad_slabs(x, dy, workspace, dilation, splitk=1):
+    """split-K partial weight gradients of one (x, dy) pair into `workspace` (no fold): see sw_conv3x3_wgrad_slabs"""
+    _need_gpu(x, dy, workspace)
+    n, H, W, Cin = x.shape
+    check(lib.sw_conv3x3_wgrad_slabs(dt(x), n, H, W, Cin, dy.shape[3], dilation, _p(x), _p(dy), _p(workspace), splitk,
+                                     _stream()), "sw_conv3x3_wgrad_slabs")
+
+
+def conv3x3_wgrad_fold(workspace, nslab, dw_oihw):
+    """dw_oihw (Cout, Cin, 3, 3) f32 = ordered sum of `nslab` consecutive [co][tap][ci] slabs"""
+    Cout, Cin = dw_oihw.shape[:2]
+    check(lib.sw_conv3x3_wgrad_fold(Cin, Cout, nslab, _p(workspace), _p(dw_oihw), _stream()), "sw_conv3x3_wgrad_fold")
+    return dw_oihw
+
+
+def colsum_nrows(X_dtype, M, N):
+    """partial rows that colsum_partial writes for an M x N matrix"""
+    return int(lib.sw_colsum_workspace_floats(dt(X_dtype), M, N)) // N
+
+
+def colsum_partial(X, M, N, workspace, ld=None):
+    check(lib.sw_colsum_partial(dt(X), M, N, _p(X), X.stride(0) if ld is None else ld, _p(workspace), _stream()),
+          "sw_colsum_partial")
+
+
+def colsum_fold(workspace, n_rows, out):
+    check(lib.sw_colsum_fold(out.numel(), n_rows, _p(workspace), _p(out), _stream()), "sw_colsum_fold")
+    return out
+
+
 def conv_weight_prep(w_oihw, wk, mode, cin_pad=None):
     Cout, Cin = w_oihw.shape[:2]
     cin_pad = Cin if cin_pad is None else cin_pad
@@ -360,10 +396,28 @@ def sgd_momentum_step(param, grad, buf, lr, momentum, weight_decay, first_step, 
           "sw_sgd_momentum_step")
 
 
-def loss_finalize(loss_view, out):
-    n, V = loss_view.shape
-    check(lib.sw_loss_finalize(n, V, _p(loss_view), _p(out), _stream()), "sw_loss_finalize")
+def loss_finalize(loss_view, out, total=None):
+    """loss_view [n_losses][V] or [n_images][n_losses][V] -> out[n_losses] (mean over views and images), total[1] = sum"""
+    if loss_view.dim() == 2:
+        loss_view = loss_view[None]
+    B, n, V = loss_view.shape
+    check(lib.sw_loss_finalize(n, V, B, _p(loss_view), _p(out), _p(total), _stream()), "sw_loss_finalize")
     return out
+
+
+def scale_cols_loss(src_f32, g_losses, g_total, col_to_loss_i32, mul, dst, M, N, n_valid):
+    check(lib.sw_scale_cols_loss(dt(dst), M, N, n_valid, _p(src_f32), src_f32.stride(0), _p(g_losses), _p(g_total),
+                                 _p(col_to_loss_i32), float(mul), _p(dst), dst.stride(0), _stream()), "sw_scale_cols_loss")
+    return dst
+
+
+def pack_views(box_list, obj_list, boxes, obj, rois):
+    """4 x (R,4) f32 boxes + 4 x (R,) f32 objectness (contiguous device tensors) -> boxes (4,R,4), obj (4,R), rois (2,2R,5)"""
+    _need_gpu(*box_list, *obj_list, boxes, obj, rois)
+    R = box_list[0].shape[0]
+    bp = (ctypes.c_void_p * 4)(*[b.data_ptr() for b in box_list])
+    op = (ctypes.c_void_p * 4)(*[o.data_ptr() for o in obj_list])
+    check(lib.sw_pack_views(R, bp, op, _p(boxes), _p(obj), _p(rois), _stream()), "sw_pack_views")
 
 
 def nchw_to_nhwc(x_nchw_f32, out_nhwc):

@@ -2,7 +2,7 @@
 (uwsod/detectron2/modeling/meta_arch/rcnn_multi.py:23-291; build_model meta_arch/build.py:15-23).
 
 `model(batched_inputs) -> dict of 9 losses` in training, `list[{"instances": Instances}]` in eval; same
-input dict keys (image{1,2}{,_flip} u8 CHW BGR, proposals*, instances*), 1 image per GPU (:148).
+input dict keys (image{1,2}{,_flip} u8 CHW BGR, proposals*, instances*); the reference's 1-image-per-GPU assert (:148) is lifted.
 MI355X plan: the u8 -> normalised NHWC conversion is one fused kernel per view (sw_preprocess) instead of 4 H2D +
 8 elementwise kernels, the two backbone calls keep the reference's batch-of-2 shape (view + flipped view)."""
 import torch
@@ -48,13 +48,25 @@ class MultiInputRCNN(nn.Module):
         self.register_buffer("pixel_mean", torch.Tensor(pixel_mean).view(-1, 1, 1))
         self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1))
         self.dual_stream = True
-        self._side = None
         self._mean_host = [float(v) for v in pixel_mean]
         self._std_host = [float(v) for v in pixel_std]
 
     @property
     def device(self):
         return self.pixel_mean.device
+
+    def prepare_for_training(self):
+        """Everything that re-homes parameter storage or builds persistent compute-dtype weight copies, done ONCE and before a
+        DistributedDataParallel wrapper inspects the parameters: the 10 predictor weights become row slices of one flat
+        master (roi_heads._flatten_head_params), conv / fc weights get their kernel-layout copies."""
+        dev = self.device
+        if dev.type != "cuda":
+            return
+        hd = self.roi_heads
+        if hasattr(hd, "_flatten_head_params") and not hd._head_flat_ok(hd._flat_params(), dev):
+            hd._flatten_head_params(dev)
+        if hasattr(self.backbone, "stage_all_weights"):
+            self.backbone.stage_all_weights(with_dgrad=True)
 
     # ---- fused preprocess: u8 CHW -> normalised NHWC compute dtype (rcnn_multi.py:256-269)
     def _views_to_nhwc(self, imgs_u8):
@@ -77,48 +89,35 @@ class MultiInputRCNN(nn.Module):
         return tuple(outs)
 
     def forward(self, batched_inputs):
-        assert len(batched_inputs) == 1, "now, MultiInputRCNN only support the setting -> imgs_per_gpu=1"
+        """rcnn_multi.py:125-208.  The reference asserts ONE image per GPU (:148); here a batch of B images is B times the
+        same computation (every image keeps its own view sizes, proposal count, MIL softmax, mining and NMS) on stacked
+        rows, the losses averaged over the images — exactly what DDP forms over B ranks of one image each."""
         if not self.training:
+            assert len(batched_inputs) == 1, "inference runs one image per call (rcnn_multi.py:148)"
             return self.inference(batched_inputs)
-        x = batched_inputs[0]
-        for k in ("proposals1", "proposals1_flip", "proposals2", "proposals2_flip"):
-            assert k in x
-        # the two scales are independent until the ROI heads: run them on two HIP streams so that their ~250-workgroup
-        # conv4/conv5 launches (one workgroup per CU each) share the CUs (64 KiB LDS per workgroup -> two per CU)
-        proposals_list = [[x["proposals1"]], [x["proposals1_flip"]], [x["proposals2"]], [x["proposals2_flip"]]]
-        gts = [[x[k]] if k in x else None for k in ("instances1", "instances1_flip", "instances2", "instances2_flip")]
+        for x in batched_inputs:
+            for k in ("proposals1", "proposals1_flip", "proposals2", "proposals2_flip"):
+                assert k in x
+        proposals_list = [[x[k] for x in batched_inputs] for k in ("proposals1", "proposals1_flip", "proposals2", "proposals2_flip")]
+        gts = [[x[k] for x in batched_inputs] if all(k in x for x in batched_inputs) else None
+               for k in ("instances1", "instances1_flip", "instances2", "instances2_flip")]
         prepared = None
         if hasattr(self.roi_heads, "_prepare_inputs"):
             prepared = self.roi_heads._prepare_inputs(proposals_list, gts[0], self.device, need_grad=torch.is_grad_enabled())
-        x1 = self._views_to_nhwc([x["image1"], x["image1_flip"]])
-        x2 = self._views_to_nhwc([x["image2"], x["image2_flip"]])
-        if self.dual_stream:
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-                # the second scale's backward runs on the side stream while .grad lives on the main one: autograd orders
-                # the accumulation itself, the warning about it is noise here
-                warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-                if warn_off is not None:
-                    warn_off(False)
-            self.backbone.stage_all_weights(with_dgrad=torch.is_grad_enabled())
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                f2 = self.backbone.forward_nhwc(x2)
-            f1 = self.backbone.forward_nhwc(x1)
-            main.wait_stream(self._side)
-            x2.record_stream(self._side)
-            f2.record_stream(main)
-        else:
-            f1 = self.backbone.forward_nhwc(x1)
-            f2 = self.backbone.forward_nhwc(x2)
-        features1 = {"plain5": f1.permute(0, 3, 1, 2)}
-        features2 = {"plain5": f2.permute(0, 3, 1, 2)}
+        # one NHWC batch of 2 (view, flipped view) per scale and image; the backbone runs all of them as ONE autograd node
+        # whose batches alternate between two HIP streams (backbone_vgg._VGGFunction)
+        xs = []
+        for x in batched_inputs:
+            xs.append(self._views_to_nhwc([x["image1"], x["image1_flip"]]))
+            xs.append(self._views_to_nhwc([x["image2"], x["image2_flip"]]))
+        self.backbone.dual_stream = self.dual_stream
+        fs = self.backbone.forward_views(xs)
+        features = [{"plain5": f.permute(0, 3, 1, 2)} for f in fs]            # NCHW views, the reference's feature format
         images_list = [None, None, None, None]       # the heads never read pixel data (roi_heads_oicrplus.py:149-188)
         if prepared is not None:
-            _, detector_losses = self.roi_heads(images_list, [features1, features2], proposals_list, gts, prepared=prepared)
+            _, detector_losses = self.roi_heads(images_list, features, proposals_list, gts, prepared=prepared)
         else:
-            _, detector_losses = self.roi_heads(images_list, [features1, features2], proposals_list, gts)
+            _, detector_losses = self.roi_heads(images_list, features, proposals_list, gts)
         return detector_losses          # no proposal-generator losses to merge (PrecomputedProposals); keeps LossDict.total()
 
     @torch.no_grad()

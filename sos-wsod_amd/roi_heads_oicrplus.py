@@ -58,14 +58,21 @@ def _padded(rows, cols, device, dtype, pad=128):
 
 class LossDict(dict):
     """The reference's dict of named scalar losses; every value is a view of ONE device vector, kept as `.vector`.
-    `total()` = sum of all losses as a single reduction (what train_net_multi.py:129 computes with Python's sum())."""
+    `total()` = sum of all losses (what train_net_multi.py:129 computes with Python's sum()), produced by the same kernel
+    that finalises the vector — a second output of the heads' autograd node, so `total().backward(...)` runs no torch
+    arithmetic at all."""
 
-    def __init__(self, names, vector):
+    def __init__(self, names, vector, total=None, finite=None):
         super().__init__({n: vector[i] for i, n in enumerate(names)})
         self.vector = vector
+        self._total, self._finite = total, finite
 
     def total(self):
-        return self.vector.sum()
+        return self.vector.sum() if self._total is None else self._total.view(())      # a view: its backward is a reshape
+
+    def finite_flag(self):
+        """device scalar: 1.0 if the summed loss is finite (written by the kernel that finalises the losses)"""
+        return None if self._finite is None else self._finite.view(())
 
 
 def loss_names(refine_K):
@@ -75,21 +82,45 @@ def loss_names(refine_K):
     return names
 
 
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
+class _DropoutStream:
+    def __init__(self, heads):
+        self.heads = heads
+
+    def state_dict(self):
+        return {"dropout_seed": self.heads.dropout_seed, "drop_counter": int(self.heads._drop_counter)}
+
+    def load_state_dict(self, state):
+        self.heads.dropout_seed = state.get("dropout_seed", self.heads.dropout_seed)
+        self.heads._drop_counter = int(state.get("drop_counter", self.heads._drop_counter))
+
+
 class _HeadsTrainFunction(torch.autograd.Function):
-    """(feat1, feat2, *head params) -> vector of 1 + 2*refine_K losses."""
+    """(feat_0 .. feat_{n-1}, *head params) -> (vector of 1 + 2*refine_K losses, their sum)."""
 
     @staticmethod
-    def forward(ctx, heads, inp, feat1, feat2, *params):
-        st = heads._train_forward(inp, feat1, feat2, params)
+    def forward(ctx, heads, inp, n_feat, *args):
+        feats, params = args[:n_feat], args[n_feat:]
+        st = heads._train_forward(inp, feats, params)
         ctx.heads, ctx.st, ctx.params = heads, st, params
-        ctx.feat_req = (ctx.needs_input_grad[2], ctx.needs_input_grad[3])
-        return st["losses"]
+        ctx.feat_req = tuple(ctx.needs_input_grad[3:3 + n_feat])
+        ctx.set_materialize_grads(False)
+        return st["losses"], st["total"]
 
     @staticmethod
-    def backward(ctx, g_losses):
-        dfeats, dparams = ctx.heads._train_backward(ctx.st, ctx.params, g_losses.contiguous().float(), ctx.feat_req)
+    def backward(ctx, g_losses, g_total):
+        n_feat = len(ctx.feat_req)
+        if g_losses is None and g_total is None:
+            return (None, None, None) + (None,) * (n_feat + len(ctx.params))
+        dfeats, dparams = ctx.heads._train_backward(ctx.st, ctx.params, g_losses, g_total, ctx.feat_req)
         ctx.st = None
-        return (None, None, dfeats[0], dfeats[1]) + tuple(dparams)
+        return (None, None, None) + tuple(dfeats) + tuple(dparams)
 
 
 @ROI_HEADS_REGISTRY.register()
@@ -100,7 +131,7 @@ class OICRPlusHeads(nn.Module):
                  cls_agnostic_bbox_reg: bool = False, pooler_type: str = "ROIPool", cfg=None, num_classes: int = 20,
                  iou_thresholds=(0.5, 0.6), iou_labels=(0, -1, 1), bbox_reg_weights=(10.0, 10.0, 5.0, 5.0),
                  test_score_thresh=1e-6, test_nms_thresh=0.3, test_topk_per_image=100,
-                 compute_dtype=torch.bfloat16, **unused):
+                 compute_dtype=torch.bfloat16, seed=-1, **unused):
         super().__init__()
         assert refine_mist and mist_type == "nms", "WSL.REFINE_MIST True / MIST_TYPE nms is the configured path"
         assert list(iou_labels) == [0, -1, 1] and len(iou_thresholds) == 2
@@ -124,7 +155,10 @@ class OICRPlusHeads(nn.Module):
         self.compute_dtype = compute_dtype
         self.cfg = cfg
         self.iter = 0
-        self.dropout_seed = 0x5051
+        # dropout stream = hash(dropout_seed, element counter): the seed is drawn from SEED and the rank on first use (every
+        # rank its own stream, engine/defaults.py:147 seeds SEED + rank), both travel in the state dict (extra state)
+        self.seed = int(seed)
+        self.dropout_seed = None
         self._drop_counter = 0
         self._stage_cache = {}            # name -> (key list, persistent compute-dtype weight copy)
         self.debug_drop_masks = None      # tests: [[m1, m2] per view] uint8 keep masks (A.2 #9)
@@ -133,11 +167,32 @@ class OICRPlusHeads(nn.Module):
         self.n_head_cols = 2 * K + refine_K * (5 * K + 1)
         self.ld_head = (self.n_head_cols + 7) // 8 * 8
 
+    # ------------------------------------------------------------------ dropout stream state
+    def _dropout_stream_seed(self):
+        if self.dropout_seed is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            base = self.seed if self.seed >= 0 else torch.initial_seed()
+            self.dropout_seed = _splitmix64(_splitmix64(base & 0xFFFFFFFFFFFFFFFF) ^ (0x5051 + rank))
+        return self.dropout_seed
+
+    @property
+    def dropout_stream(self):
+        """checkpointable view of the dropout stream position (`state_dict()` / `load_state_dict()`): DetectionCheckpointer
+        stores it next to "model" / "optimizer" / "scheduler", so the model's own state dict keeps exactly the reference's keys"""
+        return _DropoutStream(self)
+
     # ------------------------------------------------------------------ construction from cfg
     @classmethod
     def from_config(cls, cfg, input_shape: Dict[str, ShapeSpec]):
         from .backbone_vgg import _dtype_from_cfg
         dtype = _dtype_from_cfg(cfg)
+        # keys the reference acts on that this path does not implement: refuse instead of training with other numerics
+        assert not cfg.get("OICRPLUS", {}).get("BBOX_UPDATE", False), "OICRPLUS.BBOX_UPDATE True is not implemented"
+        assert float(cfg.MODEL.ROI_BOX_HEAD.get("BBOX_REG_LOSS_WEIGHT", 1.0)) == 1.0, "BBOX_REG_LOSS_WEIGHT != 1 is not implemented"
+        assert cfg.MODEL.ROI_BOX_HEAD.get("BBOX_REG_LOSS_TYPE", "smooth_l1") == "smooth_l1" and \
+            float(cfg.MODEL.ROI_BOX_HEAD.get("SMOOTH_L1_BETA", 0.0)) == 0.0, "only smooth_l1 with beta 0 (= L1) is implemented"
+        assert all(cfg.WSL.REFINE_REG), "WSL.REFINE_REG must be all True (every refinement head regresses boxes)"
         in_features = cfg.MODEL.ROI_HEADS.IN_FEATURES
         res = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
         scales = tuple(1.0 / input_shape[k].stride for k in in_features)
@@ -158,7 +213,7 @@ class OICRPlusHeads(nn.Module):
                     bbox_reg_weights=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS,
                     test_score_thresh=cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
                     test_nms_thresh=cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST,
-                    test_topk_per_image=cfg.TEST.DETECTIONS_PER_IMAGE, compute_dtype=dtype)
+                    test_topk_per_image=cfg.TEST.DETECTIONS_PER_IMAGE, compute_dtype=dtype, seed=cfg.get("SEED", -1))
 
     # ------------------------------------------------------------------ parameter packing
     def _flat_params(self):
@@ -265,26 +320,29 @@ class OICRPlusHeads(nn.Module):
         return (buf, buf_t) if transposed else buf
 
     # ------------------------------------------------------------------ training forward (explicit)
-    def _train_forward(self, inp, feat1, feat2, params):
-        dt_, dev = self.compute_dtype, feat1.device
+    def _train_forward(self, inp, feats, params):
+        """feats: 2 NHWC maps per image (scale 1, scale 2), each a batch of 2 (view, flipped view).  Rows of every stacked
+        matrix are image-major: image b owns rows [off_b, off_b + 4 R_b), view v of it [off_b + v R_b, off_b + (v+1) R_b)."""
+        dt_ = self.compute_dtype
         K, V, RK = self.num_classes, 4, self.refine_K
-        R = inp["R"]
-        boxes = inp["boxes"]                      # (4, R, 4) f32
-        obj = inp["obj"]                          # (4, R) f32
-        feats = [feat1.permute(0, 2, 3, 1).contiguous(), feat2.permute(0, 2, 3, 1).contiguous()]  # NHWC (no copy if already)
+        B, Rs, offs, M = inp["B"], inp["R"], inp["off"], inp["M"]
         feats = [f if f.dtype == dt_ else f.to(dt_) for f in feats]
+        dev = feats[0].device
         C = feats[0].shape[3]
         P = self.box_pooler.output_size
         D0 = C * P * P
         # --- ROIPool (+ objectness prior fused) straight into the stacked fc6 operand
         # row pitch D0 + 64: with the natural 49 KiB pitch the rows of an fc6 operand tile start on 4 of the 16 L2 channels
-        pooled = _padded(V * R, D0, dev, dt_, pad=64)
-        argmax = _padded(V * R, D0, dev, ops.roi_argmax_dtype(max(f.shape[1] for f in feats), max(f.shape[2] for f in feats)),
+        pooled = _padded(M, D0, dev, dt_, pad=64)
+        argmax = _padded(M, D0, dev, ops.roi_argmax_dtype(max(f.shape[1] for f in feats), max(f.shape[2] for f in feats)),
                          pad=64)
-        rois = inp["rois"]                        # [2] x (2R, 5): batch index 0 = view, 1 = flipped view
-        for s in range(2):
-            ops.roi_pool_fwd(feats[s], rois[s], pooled[2 * s * R:(2 * s + 2) * R], argmax[2 * s * R:(2 * s + 2) * R],
-                             self.box_pooler.scale, P, P, row_scale=obj[2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0)
+        for b in range(B):
+            R, off = Rs[b], offs[b]
+            for s in range(2):
+                r0 = off + 2 * s * R
+                ops.roi_pool_fwd(feats[2 * b + s], inp["rois"][b][s], pooled[r0:r0 + 2 * R], argmax[r0:r0 + 2 * R],
+                                 self.box_pooler.scale, P, P, row_scale=inp["obj"][b][2 * s:2 * s + 2].reshape(-1),
+                                 row_scale_add=1.0)
         # --- fc6 / fc7 with bias + ReLU + dropout fused (box_head.py:82-91)
         fc1w, fc1b, fc2w, fc2b = params[0], params[1], params[2], params[3]
         D1, D2 = fc1w.shape[0], fc2w.shape[0]
@@ -293,70 +351,80 @@ class OICRPlusHeads(nn.Module):
         hashes = [None, None]
         if training_dropout:
             if self.debug_drop_masks is not None:
+                assert B == 1
                 masks = [torch.cat([self.debug_drop_masks[v][l].to(dev) for v in range(V)], 0).contiguous() for l in range(2)]
             else:                                     # decided inside the fc6 / fc7 epilogues: same stream, no mask tensors
+                seed = self._dropout_stream_seed()
                 for l, d in enumerate((D1, D2)):
-                    hashes[l] = (self.dropout_seed, self._drop_counter, 0.5)
-                    self._drop_counter += V * R * d
+                    hashes[l] = (seed, self._drop_counter, 0.5)
+                    self._drop_counter += M * d
         W1 = self._staged_matrix("fc1", fc1w, dev, transposed=inp["need_grad"])
         W1, W1T = W1 if isinstance(W1, tuple) else (W1, None)
         W2 = self._staged_matrix("fc2", fc2w, dev)
-        h1 = _padded(V * R, D1, dev, dt_)
-        ops.gemm(pooled, W1, h1, V * R, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], drop_hash=hashes[0], out_dtype=dt_),
+        h1 = _padded(M, D1, dev, dt_)
+        ops.gemm(pooled, W1, h1, M, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], drop_hash=hashes[0], out_dtype=dt_),
                  tag="fc6_fwd")
-        h2 = _padded(V * R, D2, dev, dt_)
-        ops.gemm(h1, W2, h2, V * R, D2, D1, ep=ops.make_epilogue(bias=fc2b, relu=True, drop_mask=masks[1], drop_hash=hashes[1],
-                                                               out_dtype=dt_))
+        h2 = _padded(M, D2, dev, dt_)
+        ops.gemm(h1, W2, h2, M, D2, D1, ep=ops.make_epilogue(bias=fc2b, relu=True, drop_mask=masks[1], drop_hash=hashes[1],
+                                                         out_dtype=dt_))
         # --- all 10 predictor matrices as one GEMM, f32 logits
         Wh, bh = self._pack_head_weights(params, dev)
         LD = self.ld_head
-        logits = torch.empty(V * R, LD, device=dev, dtype=torch.float32)
-        ops.gemm(h2, Wh, logits, V * R, LD, D2, ep=ops.make_epilogue(bias=bh, out_dtype=torch.float32))
+        logits = torch.empty(M, LD, device=dev, dtype=torch.float32)
+        ops.gemm(h2, Wh, logits, M, LD, D2, ep=ops.make_epilogue(bias=bh, out_dtype=torch.float32))
         cols = self._col_layout()
-        # --- WSDDN MIL scores + loss (+ unit gradient) and the view-averaged scores = round 0's mining input
         n_loss = 1 + 2 * RK
         K1 = K + 1
-        loss_view = torch.zeros(n_loss, V, device=dev, dtype=torch.float32)
-        dlogits = torch.zeros(V * R, LD, device=dev, dtype=torch.float32) if inp["need_grad"] else None
-        ones = inp["ones"]
-        scores = torch.empty(V, R, K, device=dev, dtype=torch.float32)
-        # mining scores of all rounds, one (R, K+1) matrix each: round 0 <- mean WSDDN scores (K columns used), round k+1
-        # <- mean softmax of refinement head k.  They depend on the logits only, so the rounds are mined side by side.
-        mine_scores = torch.zeros(RK, R, K1, device=dev, dtype=torch.float32)
-        ops.wsddn_mil(logits, V, R, K, cols["cls"], cols["det"], inp["gt_onehot"], scores, loss_view[0], dlogits, ones,
-                      mean_scores=mine_scores[0])
         col_stride = 5 * K + 1
-        if RK > 1:
-            ops.oicr_mean_probs(logits, V, R, K, RK - 1, cols["cls_score0"], col_stride, mine_scores[1:])
-        # --- K refinement rounds: mine pseudo-GT, label (one workgroup per round), then all rounds' losses at once
-        top_k = max(int(R * self.mist_p), 1)                      # roi_heads_oicrplus.py:659-660
-        G = inp["G"]
-        ws = torch.empty(ops.mine_workspace_bytes(R, top_k, G, RK), device=dev, dtype=torch.uint8)
-        lab_c = torch.empty(RK, R, device=dev, dtype=torch.int32); lab_w = torch.empty(RK, R, device=dev, dtype=torch.float32)
-        lab_i = torch.empty(RK, R, device=dev, dtype=torch.int32); cnt = torch.empty(RK, device=dev, dtype=torch.int32)
-        pi = torch.empty(RK, top_k * G, device=dev, dtype=torch.int32); pc = torch.empty_like(pi)
-        ps = torch.empty(RK, top_k * G, device=dev, dtype=torch.float32)
-        ops.oicr_mine_label(mine_scores, inp["gt_int32"], boxes[0], K, top_k, self.mist_thre, 0.01,
-                            self.iou_thresholds[0], self.iou_thresholds[1], lab_c, lab_w, lab_i, cnt, pi, pc, ps, ws)
-        ops.oicr_refine_loss(logits, V, R, K, cols["cls_score0"], cols["bbox_pred0"], boxes, lab_c, lab_w, lab_i,
-                             inp["pred_view"], self.bbox_reg_weights, loss_view[1:], dlogits, ones, n_rounds=RK,
-                             col_stride=col_stride)
-        aux = {"scores": scores, "rounds": [dict(lab_class=lab_c[k], lab_weight=lab_w[k], lab_index=lab_i[k],
-                                                 pgt_count=cnt[k:k + 1], pgt_index=pi[k], pgt_class=pc[k], pgt_score=ps[k])
-                                            for k in range(RK)]}
-        losses = torch.empty(n_loss, device=dev, dtype=torch.float32)
-        ops.loss_finalize(loss_view, losses)
+        loss_view = torch.empty(B, n_loss, V, device=dev, dtype=torch.float32)     # every entry is written below
+        # unit logit gradients: the loss kernels write every real column; the padding columns are never read (scale_cols_loss)
+        dlogits = torch.empty(M, LD, device=dev, dtype=torch.float32) if inp["need_grad"] else None
+        ones = inp["ones"]
+        images = []
+        for b in range(B):
+            R, off, G = Rs[b], offs[b], inp["G"][b]
+            lg = logits[off:off + V * R]
+            dl = None if dlogits is None else dlogits[off:off + V * R]
+            # --- WSDDN MIL scores + loss (+ unit gradient) and the view-averaged scores = round 0's mining input
+            scores = torch.empty(V, R, K, device=dev, dtype=torch.float32)
+            # mining scores of all rounds, one (R, K+1) matrix each: round 0 <- mean WSDDN scores (K columns used), round k+1
+            # <- mean softmax of refinement head k.  They depend on the logits only, so the rounds are mined side by side.
+            mine_scores = torch.empty(RK, R, K1, device=dev, dtype=torch.float32)
+            ops.wsddn_mil(lg, V, R, K, cols["cls"], cols["det"], inp["gt_onehot"][b], scores, loss_view[b, 0], dl, ones,
+                          mean_scores=mine_scores[0])
+            if RK > 1:
+                ops.oicr_mean_probs(lg, V, R, K, RK - 1, cols["cls_score0"], col_stride, mine_scores[1:])
+            # --- K refinement rounds: mine pseudo-GT, label (one workgroup per round), then all rounds' losses at once
+            top_k = max(int(R * self.mist_p), 1)                      # roi_heads_oicrplus.py:659-660
+            ws = torch.empty(ops.mine_workspace_bytes(R, top_k, G, RK), device=dev, dtype=torch.uint8)
+            lab_c = torch.empty(RK, R, device=dev, dtype=torch.int32); lab_w = torch.empty(RK, R, device=dev, dtype=torch.float32)
+            lab_i = torch.empty(RK, R, device=dev, dtype=torch.int32); cnt = torch.empty(RK, device=dev, dtype=torch.int32)
+            pi = torch.empty(RK, top_k * G, device=dev, dtype=torch.int32); pc = torch.empty_like(pi)
+            ps = torch.empty(RK, top_k * G, device=dev, dtype=torch.float32)
+            boxes = inp["boxes"][b]                                   # (4, R, 4) f32
+            ops.oicr_mine_label(mine_scores, inp["gt_int32"][b], boxes[0], K, top_k, self.mist_thre, 0.01,
+                                self.iou_thresholds[0], self.iou_thresholds[1], lab_c, lab_w, lab_i, cnt, pi, pc, ps, ws)
+            ops.oicr_refine_loss(lg, V, R, K, cols["cls_score0"], cols["bbox_pred0"], boxes, lab_c, lab_w, lab_i,
+                                 inp["pred_view"], self.bbox_reg_weights, loss_view[b, 1:], dl, ones, n_rounds=RK,
+                                 col_stride=col_stride)
+            images.append({"scores": scores, "mine_scores": mine_scores, "fc7": h2[off:off + V * R], "logits": lg,
+                           "rounds": [dict(lab_class=lab_c[k], lab_weight=lab_w[k], lab_index=lab_i[k],
+                                           pgt_count=cnt[k:k + 1], pgt_index=pi[k], pgt_class=pc[k], pgt_score=ps[k])
+                                      for k in range(RK)]})
+        out = torch.empty(n_loss + 2, device=dev, dtype=torch.float32)     # losses | their sum | finite flag
+        losses, total, finite = out[:n_loss], out[n_loss:n_loss + 1], out[n_loss + 1:]
+        ops.loss_finalize(loss_view, losses, out[n_loss:])
+        aux = dict(images[0])              # the reference's one-image-per-GPU view of the intermediates ...
+        aux["images"] = images             # ... and every image's when the batch holds more
         self.last_aux = aux
-        aux["fc7"] = h2
-        aux["logits"] = logits
-        aux["mine_scores"] = mine_scores
-        return dict(losses=losses, feats=feats, rois=rois, obj=obj, pooled=pooled, argmax=argmax, h1=h1, h2=h2, W1=W1, W1T=W1T, W2=W2,
-                    Wh=Wh, dlogits=dlogits, R=R, train_dropout=training_dropout)
+        self._last_finite = finite
+        return dict(losses=losses, total=total, feats=feats, pooled=pooled, argmax=argmax, h1=h1, h2=h2, W1=W1, W1T=W1T, W2=W2,
+                    Wh=Wh, dlogits=dlogits, inp=inp, train_dropout=training_dropout)
 
     def _col_to_loss(self, device):
         """loss index of every packed logit column (each column belongs to exactly one loss term)."""
         K = self.num_classes
-        idx = torch.zeros(self.ld_head, dtype=torch.int64)
+        idx = torch.zeros(self.ld_head, dtype=torch.int32)
         idx[: 2 * K] = 0
         for k in range(self.refine_K):
             base = 2 * K + k * (5 * K + 1)
@@ -365,20 +433,23 @@ class OICRPlusHeads(nn.Module):
         return idx.to(device)
 
     # ------------------------------------------------------------------ training backward (explicit)
-    def _train_backward(self, st, params, g_losses, feat_req):
+    def _train_backward(self, st, params, g_losses, g_total, feat_req):
         dt_ = self.compute_dtype
-        dev = g_losses.device
-        V, R = 4, st["R"]
-        M = V * R
+        inp = st["inp"]
+        B, Rs, offs, M = inp["B"], inp["R"], inp["off"], inp["M"]
         LD = self.ld_head
         pooled, h1, h2, W1, W2, Wh = st["pooled"], st["h1"], st["h2"], st["W1"], st["W2"], st["Wh"]
+        dev = pooled.device
         D0, D1, D2 = pooled.shape[1], h1.shape[1], h2.shape[1]
-        # cotangent of each loss -> its logit columns; unit gradients -> compute dtype
+        # cotangent of each loss (+ the total's) -> its logit columns, x 1/B (mean over the images); unit gradients -> compute dtype
         if not hasattr(self, "_c2l") or self._c2l.device != dev:
             self._c2l = self._col_to_loss(dev)
-        colscale = g_losses[self._c2l].contiguous()
+        if g_losses is not None:
+            g_losses = g_losses.contiguous().float()
+        if g_total is not None:
+            g_total = g_total.contiguous().float()
         dl = torch.empty(M, LD, device=dev, dtype=dt_)
-        ops.scale_cols(st["dlogits"], colscale, dl, M, LD)
+        ops.scale_cols_loss(st["dlogits"], g_losses, g_total, self._c2l, 1.0 / B, dl, M, LD, self.n_head_cols)
         rs = 2.0 if st["train_dropout"] else 1.0
         # predictor matrices
         dbh = torch.empty(LD, device=dev, dtype=torch.float32); ops.colsum(dl, M, LD, dbh)
@@ -396,10 +467,10 @@ class OICRPlusHeads(nn.Module):
         db1 = torch.empty(D1, device=dev, dtype=torch.float32); ops.colsum(dz1, M, D1, db1)
         dW1 = torch.empty(D1, D0, device=dev, dtype=torch.float32)
         ops.gemm(dz1, pooled, dW1, D1, D0, M, a_kstrided=True, b_kstrided=True, tag="fc6_wgrad")
-        dfeats = [None, None]
-        if feat_req[0] or feat_req[1]:
+        dfeats = [None] * len(feat_req)
+        if any(feat_req):
             dpooled = _padded(M, D0, dev, dt_, pad=64)          # same pitch as argmax (one pitch per ROIPool call)
-            amax = torch.zeros(1, device=dev, dtype=torch.float32)      # max|dpooled| -> fixed-point scale of the ROI scatter
+            amax = ops.fill_zero(torch.empty(1, device=dev, dtype=torch.float32))   # max|dpooled| -> fixed-point scale of the ROI scatter
             if st["W1T"] is not None:       # NT: B = W1^T (D0 x D1), K-contiguous
                 ops.gemm(dz1, st["W1T"], dpooled, M, D0, D1, ep=ops.make_epilogue(out_dtype=dt_, absmax_out=amax),
                          tag="fc6_dgrad")
@@ -407,15 +478,18 @@ class OICRPlusHeads(nn.Module):
                 ops.gemm(dz1, W1, dpooled, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt_, absmax_out=amax),
                          tag="fc6_dgrad")
             P = self.box_pooler.output_size
-            for s in range(2):
-                if not feat_req[s]:
-                    continue
-                f = st["feats"][s]
-                df = torch.empty_like(f)
-                ops.roi_pool_bwd(dpooled[2 * s * R:(2 * s + 2) * R], st["argmax"][2 * s * R:(2 * s + 2) * R], st["rois"][s], df,
-                                 P, P, row_scale=st["obj"][2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0, relu_ref=f,
-                                 dout_absmax=amax)
-                dfeats[s] = df.permute(0, 3, 1, 2)          # NCHW view, like the forward feature
+            for b in range(B):
+                R, off = Rs[b], offs[b]
+                for s in range(2):
+                    if not feat_req[2 * b + s]:
+                        continue
+                    f = st["feats"][2 * b + s]
+                    df = torch.empty_like(f)
+                    r0 = off + 2 * s * R
+                    ops.roi_pool_bwd(dpooled[r0:r0 + 2 * R], st["argmax"][r0:r0 + 2 * R], inp["rois"][b][s], df, P, P,
+                                     row_scale=inp["obj"][b][2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0, relu_ref=f,
+                                     dout_absmax=amax)
+                    dfeats[2 * b + s] = df
         # split the packed gradients back onto the 10 predictor tensors (row slices are contiguous views)
         dparams = [dW1, db1, dW2, db2]
         row = 0
@@ -428,50 +502,73 @@ class OICRPlusHeads(nn.Module):
 
     # ------------------------------------------------------------------ public forward
     def _prepare_inputs(self, proposals_list, targets1, device, need_grad):
+        """proposals_list: the 4 views' lists of per-image Instances (index aligned); targets1: per-image Instances of view 1.
+        The reference takes ONE image per GPU (roi_heads_oicrplus.py:193); more images are the same computation per image
+        (MIL softmax, mining and NMS are per image) on stacked rows, their losses averaged — what DDP forms over as many
+        ranks."""
         K = self.num_classes
-        assert all(len(p) == 1 for p in proposals_list), "the batchsize should be 1"     # roi_heads_oicrplus.py:193
-        props = [p[0] for p in proposals_list]
-        R = len(props[0])
-        assert all(len(p) == R for p in props), "the 4 proposal sets are index aligned (dataset_mapper.py:353-361)"
+        B = len(proposals_list[0])
+        assert B >= 1 and all(len(p) == B for p in proposals_list)
         _, gt_ints, gt_oh = get_image_level_gt(targets1, K)
-        gt_int = gt_ints[0]
-        boxes = torch.stack([p.proposal_boxes.tensor.to(device=device, dtype=torch.float32) for p in props], 0).contiguous()
-        obj = torch.stack([p.objectness_logits.to(device=device, dtype=torch.float32) for p in props], 0).contiguous()
-        idx = torch.cat([torch.zeros(R, 1, device=device), torch.ones(R, 1, device=device)], 0)
-        rois = [torch.cat([idx, boxes[2 * s:2 * s + 2].reshape(2 * R, 4)], 1).contiguous() for s in range(2)]
         if not hasattr(self, "_consts") or self._consts[0].device != device:
             self._consts = (torch.ones(max(2, 2 * self.refine_K), device=device),
                             torch.tensor([0, 1, 2, 2], dtype=torch.int32, device=device))
+        Rs, Gs, offs, boxes, obj, rois = [], [], [], [], [], []
+        off = 0
+        for b in range(B):
+            props = [p[b] for p in proposals_list]
+            R = len(props[0])
+            assert all(len(p) == R for p in props), "the 4 proposal sets are index aligned (dataset_mapper.py:353-361)"
+            bl = [p.proposal_boxes.tensor.to(device=device, dtype=torch.float32).contiguous() for p in props]
+            ol = [p.objectness_logits.to(device=device, dtype=torch.float32).contiguous() for p in props]
+            bx = torch.empty(4, R, 4, device=device, dtype=torch.float32)
+            ob = torch.empty(4, R, device=device, dtype=torch.float32)
+            ro = torch.empty(2, 2 * R, 5, device=device, dtype=torch.float32)
+            if device.type == "cuda":
+                ops.pack_views(bl, ol, bx, ob, ro)
+            else:                                      # host-side plumbing tests only
+                bx.copy_(torch.stack(bl)); ob.copy_(torch.stack(ol))
+                ro[..., 1:] = bx.view(2, 2 * R, 4); ro[:, :R, 0] = 0; ro[:, R:, 0] = 1
+            Rs.append(R); Gs.append(int(gt_ints[b].numel())); offs.append(off); boxes.append(bx); obj.append(ob); rois.append(ro)
+            off += 4 * R
         # the image-level labels are the only host data of the step: stage them through pinned memory so that the copy is
         # asynchronous (a pageable H2D copy blocks the host until the stream drains = one full pipeline bubble per step)
-        G = int(gt_int.numel())
+        nG = sum(Gs)
         if device.type == "cuda":
-            host = torch.empty(G + K, dtype=torch.float32, pin_memory=True)
-            host[:G].view(torch.int32).copy_(gt_int.to(torch.int32))
-            host[G:].copy_(gt_oh.view(-1))
+            host = torch.empty(nG + B * K, dtype=torch.float32, pin_memory=True)
+            host[:nG].view(torch.int32).copy_(torch.cat(gt_ints).to(torch.int32))
+            host[nG:].copy_(gt_oh.reshape(-1))
             devbuf = host.to(device, non_blocking=True)
-            gt_i32, gt_onehot = devbuf[:G].view(torch.int32), devbuf[G:]
         else:
-            gt_i32, gt_onehot = gt_int.to(torch.int32), gt_oh.view(-1).clone()
-        return dict(R=R, G=G, boxes=boxes, obj=obj, rois=rois, gt_int32=gt_i32, gt_onehot=gt_onehot,
+            devbuf = torch.cat([torch.cat(gt_ints).to(torch.int32).view(torch.float32), gt_oh.reshape(-1)])
+        gt_i32, gt_onehot, g0 = [], [], 0
+        for b in range(B):
+            gt_i32.append(devbuf[g0:g0 + Gs[b]].view(torch.int32)); g0 += Gs[b]
+            gt_onehot.append(devbuf[nG + b * K: nG + (b + 1) * K])
+        return dict(B=B, R=Rs, G=Gs, off=offs, M=off, boxes=boxes, obj=obj, rois=rois, gt_int32=gt_i32, gt_onehot=gt_onehot,
                     ones=self._consts[0], pred_view=self._consts[1], need_grad=need_grad)
 
     def forward(self, images_list, features_list, proposals_list, targets_list=(None, None, None, None), prepared=None):
+        """training: features_list = [features1, features2] ({"plain5": NCHW view} of scale 1 / scale 2, as the reference
+        passes them, roi_heads_oicrplus.py:149-188) or, for several images per GPU, one such pair per image
+        ([f1_img0, f2_img0, f1_img1, ...]); each holds the view and its flipped copy as a batch of 2."""
         if not self.training:
             pred_instances, all_scores, all_boxes = self._forward_box_test(features_list, proposals_list, targets_list)
             return pred_instances, {}, all_scores, all_boxes
-        features1, features2 = features_list
-        f1 = features1[self.box_in_features[0]]
-        f2 = features2[self.box_in_features[0]]
+        key = self.box_in_features[0]
+        feats = [(f[key] if isinstance(f, dict) else f) for f in features_list]
+        # NCHW views of NHWC storage (what the backbone hands out) go back to NHWC without a copy
+        feats = [f.permute(0, 2, 3, 1).contiguous() for f in feats]
         targets1 = targets_list[0]
         # `prepared`: the meta-architecture may build the (feature independent) ROI / label tensors before it queues the
-        # backbone, so that those ~10 tiny kernels do not sit between the backbone and ROIPool on the critical path
-        inp = prepared if prepared is not None else self._prepare_inputs(proposals_list, targets1, f1.device,
+        # backbone, so that those tiny kernels do not sit between the backbone and ROIPool on the critical path
+        inp = prepared if prepared is not None else self._prepare_inputs(proposals_list, targets1, feats[0].device,
                                                                          need_grad=torch.is_grad_enabled())
-        self.gt_classes_img_int = [inp["gt_int32"].to(torch.int64)]
-        vec = _HeadsTrainFunction.apply(self, inp, f1, f2, *self._flat_params())
+        assert len(feats) == 2 * inp["B"]
+        self.gt_classes_img_int = [g.to(torch.int64) for g in inp["gt_int32"]]
+        vec, total = _HeadsTrainFunction.apply(self, inp, len(feats), *feats, *self._flat_params())
         names = loss_names(self.refine_K)
-        losses = LossDict(names, vec)
+        losses = LossDict(names, vec, total, self._last_finite)
         self.iter = self.iter + 1
         if has_event_storage():
             st = get_event_storage()

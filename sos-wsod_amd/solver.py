@@ -58,15 +58,24 @@ class HipSGD(torch.optim.Optimizer):
 
 
 def build_optimizer(cfg, model) -> torch.optim.Optimizer:
-    """solver/build.py:191-215: one group per parameter; biases get BASE_LR*BIAS_LR_FACTOR and WEIGHT_DECAY_BIAS."""
+    """solver/build.py:143-218: one group per parameter; biases get BASE_LR*BIAS_LR_FACTOR and WEIGHT_DECAY_BIAS; with
+    SOLVER.REFINE_SCALE_ON every parameter whose name contains "refine" (the box_refinery_k heads) additionally gets
+    lr x REFINE_LR_SCALE (:162-188).  VGG16 + fc heads hold no norm layers, so WEIGHT_DECAY_NORM never applies;
+    NESTEROV must be False (the fused update is plain momentum SGD)."""
+    assert not cfg.SOLVER.get("NESTEROV", False), "SOLVER.NESTEROV True is not implemented by HipSGD"
+    refine_on = bool(cfg.SOLVER.get("REFINE_SCALE_ON", False))
+    refine_scale = float(cfg.SOLVER.get("REFINE_LR_SCALE", 1.0))
     groups = []
     for name, p in model.named_parameters():
         if not p.requires_grad:
             continue
         lr, wd = cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY
-        if name.endswith(".bias"):
+        is_bias = ("bias" in name) if refine_on else name.endswith(".bias")     # :176-185 substring test / :204 key == "bias"
+        if is_bias:
             lr = cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR
             wd = cfg.SOLVER.WEIGHT_DECAY_BIAS
+        if refine_on and "refine" in name:
+            lr = lr * refine_scale
         groups.append({"params": [p], "lr": lr, "weight_decay": wd})
     return HipSGD(groups, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
 

@@ -4,7 +4,10 @@ per-iteration host round trips: no .item() on the 9 losses, no gloo gather, no e
 
 Data parallelism = the reference's: one process per GPU, torch DistributedDataParallel; on ROCm the "nccl" backend IS
 RCCL (xGMI).  Gradients leave the two autograd nodes of this model in two bursts (heads: 92 % of the bytes, first;
-backbone afterwards), so DDP's bucketed all-reduce of the fc6/fc7 gradients overlaps the conv backward."""
+backbone afterwards), so DDP's bucketed all-reduce of the fc6/fc7 gradients overlaps the conv backward.
+
+Step rule as the reference wrote it: optimizer.step() when `iter % ITER_SIZE == 0` (:149), the LR scheduler advances every
+iteration (its hook), gradients are zeroed at the start iteration and after every step."""
 import os
 
 import torch
@@ -27,25 +30,59 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
+def auto_scale_workers(cfg, num_workers: int):
+    """train_net_multi.py:306-324, restated as written there: when fewer workers than SOLVER.REFERENCE_WORLD_SIZE run the
+    recipe, the gradient is accumulated over ceil(ITER_SIZE / scale) iterations and BASE_LR is DIVIDED by scale =
+    num_workers / REFERENCE_WORLD_SIZE (< 1, so the learning rate grows); more workers than the reference leave the
+    config untouched."""
+    import math
+    old = cfg.SOLVER.REFERENCE_WORLD_SIZE
+    if old == 0 or old == num_workers or old < num_workers:
+        return cfg
+    cfg = cfg.clone()
+    scale = num_workers / old
+    cfg.SOLVER.BASE_LR = cfg.SOLVER.BASE_LR / scale
+    cfg.WSL.ITER_SIZE = math.ceil(cfg.WSL.ITER_SIZE / scale)
+    return cfg
+
+
 class Trainer:
+    """`metrics_period`: every that many iterations the 9 losses are averaged over the ranks by ONE device-side all-reduce
+    of the loss vector and stored (as device scalars) in the EventStorage — the reference gathers python floats over gloo
+    every iteration (train_loop.py:274 -> comm.gather), i.e. one host sync per step."""
+
     def __init__(self, model, optimizer, data_iter=None, iter_size=1, scheduler=None, ddp=None, find_unused=False,
-                 check_finite_every=0, grad_compress=None):
+                 check_finite_every=20, grad_compress=None, metrics_period=20, bucket_cap_mb=None, start_iter=0):
         self.raw_model = model
         self.optimizer, self.scheduler = optimizer, scheduler
         self.iter_size = max(int(iter_size), 1)
         self.data_iter = data_iter
-        self.iter = 0
+        self.iter = self.start_iter = int(start_iter)
         self.check_finite_every = check_finite_every
-        self.storage = EventStorage(0)
-        use_ddp = ddp if ddp is not None else (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.metrics_period = metrics_period
+        self.storage = EventStorage(self.iter)
+        self._finite_flag = None            # (iteration, device bool) of the last queued check
+        self._grad_seed = None
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        prepare = getattr(model, "prepare_for_training", None)
+        if callable(prepare):
+            prepare()                       # flat predictor master, compute-dtype weight copies: BEFORE DDP looks at the parameters
+        use_ddp = ddp if ddp is not None else self.world > 1
         if use_ddp:
             dev = next(model.parameters()).device
             ids = [dev.index] if dev.type == "cuda" else None
             # broadcast_buffers=False as the reference (train_net_multi.py:76-78); every trainable parameter is used
-            # each step (REFINE_REG all True), so the unused-parameter scan is off
+            # each step (REFINE_REG all True), so the unused-parameter scan is off (SURVEY A.2 #12).
+            # Buckets: DDP fills them in REVERSE registration order = the order the gradients become ready here — the heads
+            # node (predictors, fc7, fc6: 92 % of the bytes) finishes first, the backbone node last.  A parameter is never
+            # split, so fc1.weight (411 MB) is a bucket of its own whatever the cap and its all-reduce overlaps the whole conv
+            # backward that follows; bucket_cap_mb (default SW_DDP_BUCKET_MB or 128) only groups the small tensors
+            # (predictors + fc7 68 MB, the convs 59 MB) into few launches.
+            if bucket_cap_mb is None:
+                bucket_cap_mb = float(os.environ.get("SW_DDP_BUCKET_MB", "128"))
             self.model = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, broadcast_buffers=False,
                                                                    find_unused_parameters=find_unused,
-                                                                   gradient_as_bucket_view=True)
+                                                                   gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
             # opt-in (NOT the reference's numerics): all-reduce the gradient buckets as bf16 — half the bytes on the xGMI
             # ring (the fc6 weight gradient alone is 411 MB per step); the sum is formed in bf16, the result returns as f32
             grad_compress = grad_compress or os.environ.get("SW_DDP_GRAD_COMPRESS")
@@ -56,6 +93,20 @@ class Trainer:
         else:
             self.model = model
 
+    def _seed_grad(self, total):
+        """cotangent of the summed loss: 1 / ITER_SIZE as a cached device scalar (train_net_multi.py:146 `losses / iter_size`
+        without the division kernel and without autograd's ones_like fill)"""
+        if self._grad_seed is None or self._grad_seed.device != total.device or self._grad_seed.dtype != total.dtype:
+            self._grad_seed = torch.full_like(total, 1.0 / self.iter_size)
+        return self._grad_seed
+
+    def _raise_if_nonfinite(self):
+        if self._finite_flag is not None:
+            it, flag = self._finite_flag
+            self._finite_flag = None
+            if not bool(flag.item()):                                          # train_loop.py:253-259 `_detect_anomaly`
+                raise FloatingPointError("Loss became infinite or NaN at iteration={}!".format(it))
+
     def run_step(self, data=None):
         """train_net_multi.py:112-168"""
         assert self.model.training, "[Trainer] model was changed to eval mode!"
@@ -63,23 +114,51 @@ class Trainer:
             data = next(self.data_iter)
             while any(len(x["instances1"]) == 0 for x in data):           # :121-127 skip images without labels
                 data = next(self.data_iter)
+        if self.iter == self.start_iter:
+            self.optimizer.zero_grad()                                     # :143-144
         with self.storage:
             loss_dict = self.model(data)
-            # the 9 losses are views of one device vector (LossDict): one sum kernel forward, one expand backward instead
-            # of 8 adds + 9 select-backward (zeros + copy + add each); a plain dict falls back to the reference's sum()
+            # the 9 losses are views of one device vector (LossDict) whose sum is a second output of the heads node: no
+            # torch arithmetic between the model and .backward(); a plain dict falls back to the reference's sum()
             total = getattr(loss_dict, "total", None)
             losses = total() if callable(total) else sum(loss_dict.values())
-            if self.iter_size != 1:
-                losses = losses / self.iter_size
-            losses.backward()
-        if (self.iter + 1) % self.iter_size == 0:
+            losses.backward(gradient=self._seed_grad(losses))             # :146-147  (losses / iter_size).backward()
+        if self.iter % self.iter_size == 0:                                # :149 — the reference's rule, first step at iter 0
             self.optimizer.step()
             self.optimizer.zero_grad()
-            if self.scheduler is not None:
-                self.scheduler.step()
+        if self.scheduler is not None:
+            self.scheduler.step()                                          # hooks.LRScheduler.after_step: every iteration
+        # non-finite losses (train_loop.py:253-259): the reference syncs every iteration; here a device flag is queued every
+        # `check_finite_every` iterations and read one check later, when it has long been computed (no pipeline bubble)
         if self.check_finite_every and (self.iter + 1) % self.check_finite_every == 0:
-            if not torch.isfinite(losses).item():                          # train_loop.py:253-259, made periodic
-                raise FloatingPointError("Loss became infinite or NaN at iteration={}!".format(self.iter))
+            self._raise_if_nonfinite()
+            ff = getattr(loss_dict, "finite_flag", None)
+            flag = ff() if callable(ff) else None
+            self._finite_flag = (self.iter, torch.isfinite(losses.detach()).all() if flag is None else flag)
+        if self.metrics_period and (self.iter + 1) % self.metrics_period == 0:
+            self._write_metrics(loss_dict)
         self.storage.step()
         self.iter += 1
         return loss_dict
+
+    def _write_metrics(self, loss_dict):
+        """train_loop.py:261-297: rank-mean of every loss, on the device (one all-reduce of the 9-float vector)"""
+        vec = getattr(loss_dict, "vector", None)
+        if vec is None:
+            vec = torch.stack([v.detach() for v in loss_dict.values()])
+        vec = vec.detach()
+        total = getattr(loss_dict, "total", None)
+        tot = total().detach() if callable(total) else None
+        if self.world > 1:
+            vec = vec.clone()
+            dist.all_reduce(vec)
+            vec /= self.world
+            tot = None
+        with self.storage:
+            for i, k in enumerate(loss_dict.keys()):
+                self.storage.put_scalar(k, vec[i])
+            self.storage.put_scalar("total_loss", vec.sum() if tot is None else tot)
+
+    def finish(self):
+        """call after the last step: surfaces a pending non-finite flag"""
+        self._raise_if_nonfinite()

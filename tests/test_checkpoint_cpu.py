@@ -34,7 +34,7 @@ def test_pth_roundtrip_with_optimizer_scheduler_and_iteration(tmp_path):
     path = ck.save("model_0000003", iteration=3)
     assert path.endswith("model_0000003.pth") and ck.has_checkpoint() and ck.get_checkpoint_file() == path
     raw = torch.load(path, weights_only=False)
-    assert set(raw) == {"model", "optimizer", "scheduler", "iteration"}
+    assert set(raw) == {"model", "optimizer", "scheduler", "iteration", "dropout_stream"}
     assert "backbone.plain3.0.conv2.weight" in raw["model"] and "roi_heads.box_refinery_2.bbox_pred.bias" in raw["model"]
     torch.manual_seed(1)
     m2 = _model()

@@ -82,8 +82,9 @@ def test_ddp_step_loop_world2_gloo(tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     res = torch.load(out)
     assert res["same"] and res["tmax"] == 2.0 and res["iters"] == 4
-    # single-process reference: mean of the two ranks' gradients each micro-step, step every 2 (ITER_SIZE 2; DDP averages
-    # every micro-step like the reference, which never uses no_sync — SURVEY §2.3)
+    # single-process reference: mean of the two ranks' gradients each micro-step, step when iter % ITER_SIZE == 0 — the
+    # reference's rule (train_net_multi.py:149: iterations 0 and 2 here) — DDP averages every micro-step like the reference,
+    # which never uses no_sync
     model = _Toy()
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
     gens = [torch.Generator().manual_seed(100 + r) for r in range(2)]
@@ -92,7 +93,7 @@ def test_ddp_step_loop_world2_gloo(tmp_path):
             x = torch.randn(6, 8, generator=gens[r])
             losses = model([{"x": x}])
             (sum(losses.values()) / 2 / 2).backward()        # /ITER_SIZE and /world (DDP mean)
-        if (it + 1) % 2 == 0:
+        if it % 2 == 0:
             opt.step(); opt.zero_grad()
     ref = torch.cat([p.detach().flatten() for p in model.parameters()])
     assert torch.allclose(res["params"], ref, rtol=1e-5, atol=1e-6)

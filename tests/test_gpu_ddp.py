@@ -1,0 +1,56 @@
+"""The REAL model under data parallelism before anyone hands it 8 GPUs: two ranks share cuda:0 (gloo backend, so no second
+GPU is needed) and run tests/ddp_real_worker.py; plus bench.py's own multi-rank launch (train_net_multi.py:76-78,
+engine/launch.py:55-73)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    return dict(os.environ, SW_DIST_BACKEND="gloo", SW_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_real_model_two_ranks_gradients_and_parameters(tmp_path, dtype):
+    out = str(tmp_path / "ddp")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_real_worker.py"), out, dtype]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    for rank in range(2):
+        res = torch.load(f"{out}.rank{rank}")
+        # DDP divides by the world size before the all-reduce, the replica after the sum: equal up to the f32 rounding of /2,
+        # i.e. exactly, except for denormals; bf16 activations do not enter (both sides run the same kernels)
+        assert max(res["grad_err"]) <= 1e-6, max(res["grad_err"])
+        assert res["same_across_ranks"]
+        assert res["replica_err"] <= 1e-6, res["replica_err"]
+        assert res["moved"] > 0
+        assert res["dropout_seeds_differ"]
+        assert len(res["metrics"]) == 9 and all(v == v for v in res["metrics"].values())
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it prints one line with n_gpus 2 (both ranks on cuda:0 over gloo here)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = _env()
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp2"

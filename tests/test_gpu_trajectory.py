@@ -1,0 +1,136 @@
+"""Several SGD steps, not one iteration: the fp32 HIP path stepped by Trainer + HipSGD against the oracle stepped by a numpy
+SGD with the reference's parameter groups (solver/build.py:191-215; torch.optim.SGD semantics: g += wd * w; buf = g on the
+first step, else buf = mu * buf + g; w -= lr * buf), on the reference-generated fixture s0.
+
+The iteration contains discrete decisions (ROIPool / maxpool argmax, top-p% mining, NMS, IoU thresholds) and the fixture's
+peaky heads (|logit| ~ 50) amplify f32 summation-order noise, so two free-running f32 implementations separate after a few
+steps whatever their quality (measured: 8e-4 in loss_cls at step 1).  The comparison is therefore TEACHER FORCED: at every
+step the oracle starts from the HIP run's current master weights (and its own momentum buffers, fed with its own
+gradients), and the HIP loss of that step and the HIP weights after it are compared with the oracle's.  That is what can go
+wrong over steps and not in one iteration — stale compute-dtype weight copies after an update, momentum / first-step
+handling, learning-rate groups, gradient accumulation leftovers — without the chaos.  The free-running oracle's distance is
+reported.  A second test reports how far the bf16 mode (the benchmarked one) drifts from fp32 over the same steps."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oicr_oracle as O  # noqa: E402  (checker only)
+from helpers import build_model, load_params, to_batched_inputs  # noqa: E402
+
+N_STEPS = 5
+LR, MOM, WD = 1e-3, 0.9, 5e-4
+
+
+def _groups(model):
+    return [{"params": [p], "lr": 2 * LR if n.endswith(".bias") else LR, "weight_decay": 0.0 if n.endswith(".bias") else WD}
+            for n, p in model.named_parameters() if p.requires_grad]
+
+
+def _setup(case, golden_dir, dtype):
+    from sos_wsod_amd.solver import HipSGD
+    from sos_wsod_amd.trainer import Trainer
+    g = np.load(os.path.join(golden_dir, f"e2e_{case}.npz"), allow_pickle=False)
+    K, R, H, W = int(g["K"]), int(g["R"]), int(g["H"]), int(g["W"])
+    dan = tuple(int(x) for x in g["dan"])
+    P = O.make_params(K, dan, tag="p" + case, head_scale=float(g["head_scale"]))
+    views, gt = O.make_views(H, W, R, n_gt=int(g["n_gt"]), K=K, tag="v" + case)
+    masks = O.make_masks(R, dan, tag="m" + case)
+    model = build_model(K, dan, dtype)
+    load_params(model, P)
+    model.train()
+    model.roi_heads.debug_drop_masks = [[torch.from_numpy(m) for m in v] for v in masks]
+    tr = Trainer(model, HipSGD(_groups(model), LR, momentum=MOM), check_finite_every=1)
+    return (P, views, gt, masks, K), model, tr, to_batched_inputs(views, gt)
+
+
+def _weights(model):
+    return {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+
+
+def _hip_run(case, golden_dir, dtype, n_steps):
+    ctx, model, tr, data = _setup(case, golden_dir, dtype)
+    losses = []
+    for _ in range(n_steps):
+        ld = tr.run_step(data)
+        losses.append({k: float(v) for k, v in ld.items()})
+    tr.finish()
+    torch.cuda.synchronize()
+    frozen = {n for n, p in model.named_parameters() if not p.requires_grad}
+    return ctx, losses, _weights(model), frozen
+
+
+def _sgd_update(W, grads, buf, frozen):
+    out = {}
+    for n in W:
+        if n in frozen or grads.get(n) is None:
+            out[n] = W[n]
+            continue
+        bias = n.endswith(".bias")
+        g = grads[n].astype(np.float32) + np.float32(0.0 if bias else WD) * W[n]
+        buf[n] = g.copy() if n not in buf else np.float32(MOM) * buf[n] + g
+        out[n] = (W[n] - np.float32(2 * LR if bias else LR) * buf[n]).astype(np.float32)
+    return out
+
+
+def test_fp32_five_sgd_steps_track_the_oracle(golden_dir):
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(nthreads, 16))           # the oracle's small CPU convs crawl on a 128-thread pool
+    try:
+        (P, views, gt, masks, K), model, tr, data = _setup("s0", golden_dir, torch.float32)
+        frozen = {n for n, p in model.named_parameters() if not p.requires_grad}
+        buf, free_buf = {}, {}
+        free_W = {k: np.array(v, np.float32) for k, v in P.items()}
+        worst, free_gap = ("", 0.0), []
+        for step in range(N_STEPS):
+            W = _weights(model)                                               # the HIP run's masters before this step
+            ld = tr.run_step(data)
+            hip_losses = {k: float(v) for k, v in ld.items()}
+            ol, _, grads = O.oicr_plus_iteration(W, views, gt, masks, K=K, want_grads=True)
+            for k in ol:                                                      # this step's losses from the same weights
+                assert abs(hip_losses[k] - ol[k]) <= 1e-4 * abs(ol[k]) + 1e-7, (step, k, hip_losses[k], ol[k])
+            want = _sgd_update(W, grads, buf, frozen)
+            got = _weights(model)
+            for n in want:
+                if n in frozen:
+                    assert np.array_equal(got[n], P[n]), n                    # FREEZE_AT 2: plain1 / plain2 never move
+                    continue
+                err = float(np.abs(got[n] - want[n]).max() / (np.abs(want[n]).max() + 1e-30))
+                assert float(np.abs(want[n] - W[n]).max()) > 0, n
+                worst = max(worst, (f"{n}@{step}", err), key=lambda t: t[1])
+                # backbone: ONE ROIPool argmax that flips between two features equal to ~1e-6 relative re-routes that bin's
+                # gradient to the neighbouring pixel (test_gpu_e2e.py: 2e-2 of max|grad| on this fixture) -> lr * that
+                assert err <= (2e-4 if n.startswith("backbone.") else 1e-5), (step, n, err)
+            # the momentum buffers the oracle side carries are fed by ITS gradients: from step 1 on the check above covers
+            # buf = mu * buf + g with a buffer that differs from the HIP one by the accumulated gradient differences only
+            fl, _, fg = O.oicr_plus_iteration(free_W, views, gt, masks, K=K, want_grads=True)
+            free_gap.append(max(abs(fl[k] - hip_losses[k]) / (abs(fl[k]) + 1e-12) for k in fl))
+            free_W = _sgd_update(free_W, fg, free_buf, frozen)
+        tr.finish()
+        print(f"\n5 teacher-forced fp32 steps: worst relative weight error {worst[1]:.2e} ({worst[0]}); "
+              f"free-running oracle, worst relative loss gap per step: {['%.1e' % v for v in free_gap]}")
+    finally:
+        torch.set_num_threads(nthreads)
+
+
+def test_bf16_loss_drift_from_fp32_over_five_steps(golden_dir):
+    """bf16 storage with f32 accumulation against the fp32 mode over the same 5 steps: the per-step relative loss difference is
+    REPORTED and bounded loosely (bf16 has 8 significant bits; the bound catches a diverging mode, not rounding)"""
+    (P, *_), l32, w32, frozen = _hip_run("s0", golden_dir, torch.float32, N_STEPS)
+    _, l16, w16, _ = _hip_run("s0", golden_dir, torch.bfloat16, N_STEPS)
+    drift = []
+    for step in range(N_STEPS):
+        t32, t16 = sum(l32[step].values()), sum(l16[step].values())
+        drift.append(abs(t16 - t32) / abs(t32))
+        for k in l32[step]:
+            assert abs(l16[step][k] - l32[step][k]) <= 5e-2 * abs(l32[step][k]) + 1e-3, (step, k, l16[step][k], l32[step][k])
+    assert drift[-1] <= 3 * max(drift[0], 5e-3), drift                       # the gap does not compound over the steps
+    # the masters are f32 in both modes: after 5 steps the update directions still agree
+    for n in ("roi_heads.box_head.fc2.bias", "roi_heads.box_head.fc1.weight", "backbone.plain5.0.conv3.weight"):
+        d32, d16 = (w32[n] - P[n]).ravel(), (w16[n] - P[n]).ravel()            # the accumulated updates
+        cos = float((d32 * d16).sum() / (np.linalg.norm(d32) * np.linalg.norm(d16) + 1e-30))
+        assert cos > 0.98, (n, cos)
+    print("\\nbf16 vs fp32 total-loss drift per step:", ["%.2e" % d for d in drift])
