@@ -273,6 +273,14 @@ int sw_loss_finalize(int n_losses, int V, int n_images, const float* loss_view, 
 int sw_scale_cols_loss(int dtype, int M, int N, int n_valid, const float* in, long ld_in, const float* g_losses,
                        const float* g_total, const int32_t* col_to_loss, float mul, void* out, long ld_out,
                        sw_stream_t stream);
+/* One pass of Pillow's 8-bit separable resize over a planar (C, H, W) u8 image — the arithmetic of the reference's
+ * ResizeTransform.apply_image (PIL Image.resize(..., BILINEAR), used by DatasetMapperMultiInput dataset_mapper.py:303-352 and
+ * DatasetMapperTTAAVG test_time_augmentation_avg.py:199-310): out = clip8((2^21 + sum_t in[first + t] * kk[o][t]) >> 22) along
+ * x (horizontal != 0: out (C, H, out_size)) or y (out (C, out_size, W)).  bounds int32 [out_size][2] = (first input index, tap
+ * count), kk int32 [out_size][ksize] = 22-bit fixed-point weights, both DEVICE arrays computed by the caller as Pillow's
+ * precompute_coeffs does.  out_flip (optional): the same rows mirrored in x.  Bit exact with Pillow (tests/golden/resize_*.npz). */
+int sw_resize_pass_u8(int C, int H, int W, int out_size, int horizontal, const uint8_t* in, const int32_t* bounds,
+                      const int32_t* kk, int ksize, uint8_t* out, uint8_t* out_flip, sw_stream_t stream);
 /* The four views' (R,4) proposal boxes and (R,) objectness logits of one image (box_ptrs4 / obj_ptrs4: HOST arrays of 4
  * device pointers) -> boxes [4][R][4], obj [4][R], rois [2][2R][5] = (batch index 0 | 1, box) per scale
  * (poolers.py:81-108 convert_boxes_to_pooler_format for the view / flipped-view pair of a scale). */

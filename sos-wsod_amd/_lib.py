@@ -100,6 +100,8 @@ SIGNATURES = {
     "sw_loss_finalize": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_scale_cols_loss": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_float,
                                    c_void_p, c_long, c_void_p]),
+    "sw_resize_pass_u8": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                  c_void_p]),
     "sw_pack_views": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
                               c_void_p]),
     "sw_version": (ctypes.c_char_p, []),

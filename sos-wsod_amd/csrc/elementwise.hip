@@ -652,6 +652,36 @@ __global__ void pack_views_kernel(int R, PackViewsArgs a, float* __restrict__ bo
   q[0] = (float)(v & 1); q[1] = x1; q[2] = y1; q[3] = x2; q[4] = y2;
 }
 
+// One pass of Pillow's 8-bit separable resize (libImaging/Resample.c ImagingResampleHorizontal_8bpc / Vertical_8bpc):
+//   out[o] = clip8((2^21 + sum_t in[first[o] + t] * kk[o][t]) >> 22)   along x (horizontal = 1) or y, per band.
+// `bounds` (first input index, tap count) and the 22-bit fixed-point coefficients `kk` come from the host, computed in double
+// precision exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do (sos_wsod_amd.resize).  out_flip (optional) also
+// receives the row mirrored in x: the h-flipped view of the multi-view mapper in the same launch.
+__global__ void resize_pass_u8_kernel(int C, int H, int W, int OH, int OW, int horizontal, const uint8_t* __restrict__ in,
+                                      const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                      uint8_t* __restrict__ out, uint8_t* __restrict__ out_flip) {
+  const long total = (long)C * OH * OW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % OW); const long t = i / OW;
+    const int y = (int)(t % OH), c = (int)(t / OH);
+    const int o = horizontal ? x : y;
+    const int first = bounds[2 * o], n = bounds[2 * o + 1];
+    const int* k = kk + (long)o * ksize;
+    int ss = 1 << 21;
+    if (horizontal) {
+      const uint8_t* p = in + ((long)c * H + y) * W + first;
+      for (int j = 0; j < n; ++j) ss += (int)p[j] * k[j];
+    } else {
+      const uint8_t* p = in + ((long)c * H + first) * W + x;
+      for (int j = 0; j < n; ++j) ss += (int)p[(long)j * W] * k[j];
+    }
+    int v = ss >> 22;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    out[i] = (uint8_t)v;
+    if (out_flip) out_flip[((long)c * OH + y) * OW + (OW - 1 - x)] = (uint8_t)v;
+  }
+}
+
 __global__ void mean_views_kernel(int V, long n, const float* __restrict__ in, float* __restrict__ out) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = in[i];
@@ -1036,6 +1066,18 @@ extern "C" int sw_scale_cols_loss(int dtype, int M, int N, int n_valid, const fl
                        g_losses, g_total, col_to_loss, mul, (unsigned short*)out, ld_out),
     hipLaunchKernelGGL(scale_cols_loss_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, M, N, n_valid, in, ld_in,
                        g_losses, g_total, col_to_loss, mul, (float*)out, ld_out));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_resize_pass_u8(int C, int H, int W, int out_size, int horizontal, const uint8_t* in, const int32_t* bounds,
+                                 const int32_t* kk, int ksize, uint8_t* out, uint8_t* out_flip, hipStream_t stream) {
+  SW_ENTER();
+  if (C < 1 || H < 1 || W < 1 || out_size < 1 || ksize < 1) return -5;
+  const int OH = horizontal ? H : out_size, OW = horizontal ? out_size : W;
+  const long n = (long)C * OH * OW;
+  hipLaunchKernelGGL(resize_pass_u8_kernel, dim3(grid_for(n)), dim3(256), 0, stream, C, H, W, OH, OW, horizontal, in, bounds, kk,
+                     ksize, out, out_flip);
   SW_CHECK_LAUNCH();
   return 0;
 }

@@ -11,9 +11,10 @@ SAME proposal list through resize (+ flip), clips it, and computes a keep mask (
 all four sets, so row i is the same proposal in every view (the consistency losses need that).  All of it runs as tensor ops
 on the image's device, no host round trip.
 
-The pixel side is a stand-in: the reference resizes with PIL bilinear on the CPU; here it is
-`torch.nn.functional.interpolate(..., antialias=True)` on the device — same output shape rule
-(`ResizeShortestEdge.get_transform`), not bit-identical pixels (documented, not claimed as parity).  Decoding the image
+The pixel side: the reference resizes with PIL bilinear on the CPU (`ResizeTransform.apply_image`); here the same 8-bit
+two-pass arithmetic runs as a HIP kernel (`resize.resize_bilinear_u8`, `sw_resize_pass_u8`), bit-identical to Pillow
+(tests/golden/resize_*.npz), the flipped view written by the same launch.  There is no CPU pixel path: a host-resident image
+raises unless the mapper was built with `resize_pixels=False` (box / label side only: host logic tests).  Decoding the image
 file and reading the proposal pickle stay with the caller.
 """
 import sys
@@ -21,8 +22,8 @@ from typing import Optional, Sequence
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
+from .resize import resize_bilinear_u8
 from .structures import Boxes, Instances
 from .tta import DeviceTTAMapper, ViewTransform
 
@@ -61,11 +62,13 @@ class DeviceMultiInputMapper:
     """
 
     def __init__(self, min_sizes: Sequence[int] = (480, 576, 688, 864, 1000, 1200), max_size: int = 2000,
-                 proposal_topk: Optional[int] = 2000, min_box_size: float = 0.0, seed: Optional[int] = None):
+                 proposal_topk: Optional[int] = 2000, min_box_size: float = 0.0, seed: Optional[int] = None,
+                 resize_pixels: bool = True):
         assert len(min_sizes) >= 2, "two different scales are drawn per image (dataset_mapper.py:305-321)"
         self.min_sizes, self.max_size = tuple(min_sizes), max_size
         self.proposal_topk, self.min_box_size = proposal_topk, min_box_size
         self.rng = np.random.RandomState(seed)
+        self.resize_pixels = resize_pixels
 
     def _draw_shapes(self, h, w):
         s1 = int(self.rng.choice(self.min_sizes))
@@ -79,10 +82,12 @@ class DeviceMultiInputMapper:
         raise RuntimeError(f"no second scale of {self.min_sizes} gives a shape different from {hw1} "
                            f"(the reference would loop forever here)")
 
-    @staticmethod
-    def _resize(img, hw):
-        r = F.interpolate(img[None].float(), size=hw, mode="bilinear", align_corners=False, antialias=True)[0]
-        return r.round().clamp(0, 255).to(torch.uint8)
+    def _resize_with_flip(self, img, hw):
+        """-> (resized view, its horizontal flip); PIL-bilinear pixels from the HIP kernel"""
+        if not self.resize_pixels:                       # box / label side only: shapes are right, pixels are not produced
+            z = torch.zeros(img.shape[0], hw[0], hw[1], dtype=torch.uint8, device=img.device)
+            return z, z.clone()
+        return resize_bilinear_u8(img, hw, with_flip=True)
 
     def __call__(self, d, shapes=None):
         img = d["image"]
@@ -93,9 +98,8 @@ class DeviceMultiInputMapper:
                                                        "proposal_bbox_mode", "annotations")}
         out.setdefault("height", h)
         out.setdefault("width", w)
-        image1, image2 = self._resize(img, hw1), self._resize(img, hw2)
-        out["image1"], out["image2"] = image1, image2
-        out["image1_flip"], out["image2_flip"] = image1.flip(-1).contiguous(), image2.flip(-1).contiguous()
+        out["image1"], out["image1_flip"] = self._resize_with_flip(img, hw1)
+        out["image2"], out["image2_flip"] = self._resize_with_flip(img, hw2)
         views = (("1", hw1, False), ("2", hw2, False), ("1_flip", hw1, True), ("2_flip", hw2, True))
         tfms = {name: ViewTransform((h, w), hw, flip) for name, hw, flip in views}
 

@@ -411,6 +411,16 @@ def scale_cols_loss(src_f32, g_losses, g_total, col_to_loss_i32, mul, dst, M, N,
     return dst
 
 
+def resize_pass_u8(src, dst, bounds_i32, kk_i32, ksize, horizontal, dst_flip=None):
+    """one pass of Pillow's 8-bit resize (sw_resize_pass_u8): src (C,H,W) u8 -> dst (C,H,out) / (C,out,W)"""
+    _need_gpu(src, dst, bounds_i32, kk_i32)
+    C, H, W = src.shape
+    out_size = dst.shape[2] if horizontal else dst.shape[1]
+    check(lib.sw_resize_pass_u8(C, H, W, out_size, int(horizontal), _p(src), _p(bounds_i32), _p(kk_i32), int(ksize), _p(dst),
+                                _p(dst_flip), _stream()), "sw_resize_pass_u8")
+    return dst
+
+
 def pack_views(box_list, obj_list, boxes, obj, rois):
     """4 x (R,4) f32 boxes + 4 x (R,) f32 objectness (contiguous device tensors) -> boxes (4,R,4), obj (4,R), rois (2,2R,5)"""
     _need_gpu(*box_list, *obj_list, boxes, obj, rois)

@@ -7,16 +7,16 @@ coordinates; the boxes are mapped back through the inverse transforms (un-flip i
 are averaged over the views (the proposals are index aligned across views), and the averaged set goes through the usual
 threshold / per-class NMS / top-k (`sw_detect_postprocess`).
 
-The reference builds the views on the CPU (`DatasetMapperTTAAVG`: PIL resize, numpy flip, `transform_proposals`); that
-input side is SURVEY §8f row 3 and out of scope.  `DeviceTTAMapper` is the device-side stand-in: bilinear resize of the
-CHW tensor with `torch.nn.functional.interpolate` (not bit-identical to PIL's resampling — documented, not claimed as
-parity) and the same affine maps on the proposal boxes.
+The reference builds the views on the CPU (`DatasetMapperTTAAVG`: PIL resize, numpy flip, `transform_proposals`).
+`DeviceTTAMapper` builds them on the device: the resize is the HIP restatement of Pillow's 8-bit bilinear resampling
+(`resize.resize_bilinear_u8`, bit-identical pixels, the flipped view from the same launch) and the proposal boxes go through
+the same affine maps (fvcore's ResizeTransform / HFlipTransform `apply_box`, third-party, restated in `ViewTransform`).
 """
 from typing import List, Tuple
 
 import torch
-import torch.nn.functional as F
 
+from .resize import resize_bilinear_u8
 from .structures import Boxes, Instances
 
 
@@ -65,14 +65,13 @@ class DeviceTTAMapper:
         out = []
         for size in self.min_sizes:
             nh, nw = self._shortest_edge(h, w, size, self.max_size)
-            r = F.interpolate(img[None].float(), size=(nh, nw), mode="bilinear", align_corners=False)[0]
-            r = r.round().clamp(0, 255).to(torch.uint8)
+            r, r_flip = resize_bilinear_u8(img, (nh, nw), with_flip=True)
             for flip in ((False, True) if self.flip else (False,)):
                 t = ViewTransform((h, w), (nh, nw), flip)
                 p = Instances((nh, nw))
                 p.proposal_boxes = Boxes(t.apply_box(prop.proposal_boxes.tensor.float()))
                 p.objectness_logits = prop.objectness_logits
-                view = {"image": r.flip(-1).contiguous() if flip else r, "proposals": p, "height": d.get("height", h),
+                view = {"image": r_flip if flip else r, "proposals": p, "height": d.get("height", h),
                         "width": d.get("width", w)}
                 out.append((view, t))
         return out

@@ -35,7 +35,7 @@ def check_mapper_against_golden(device):
          "annotations": [{"bbox": [10.5, 20.0, 200.25, 300.0], "category_id": 3},
                          {"bbox": [0.0, 0.0, 499.0, 374.0], "category_id": 11, "iscrowd": 0},
                          {"bbox": [5.0, 5.0, 50.0, 50.0], "category_id": 1, "iscrowd": 1}]}
-    m = DeviceMultiInputMapper(proposal_topk=2000)
+    m = DeviceMultiInputMapper(proposal_topk=2000, resize_pixels=device != "cpu")
     out = m(d, shapes=(tuple(int(v) for v in g["hw1"]), tuple(int(v) for v in g["hw2"])))
     keep = g["keep"]
     for name, hwk, flip in VIEWS:
@@ -98,7 +98,7 @@ def test_topk_slice_keeps_alignment():
     h, w = (int(v) for v in g["orig_hw"])
     d = {"image": torch.zeros(3, h, w, dtype=torch.uint8), "proposal_boxes": g["boxes"],
          "proposal_objectness_logits": g["logits"]}
-    out = DeviceMultiInputMapper(proposal_topk=100)(d, shapes=((480, 640), (1200, 1600)))
+    out = DeviceMultiInputMapper(proposal_topk=100, resize_pixels=False)(d, shapes=((480, 640), (1200, 1600)))
     n = int(g["keep"][:100].sum())
     for name, _, _ in VIEWS:
         assert len(out["proposals" + name].proposal_boxes) == n
@@ -129,7 +129,7 @@ def test_proposal_file_reader(tmp_path):
         load_proposals_into_dataset([{"image_id": 1234}], f1)
     # XYWH proposals reach the views as XYXY
     rec = dict(ds[0], image=torch.zeros(3, 200, 300, dtype=torch.uint8))
-    out = DeviceMultiInputMapper(proposal_topk=100)(rec, shapes=((200, 300), (400, 600)))
+    out = DeviceMultiInputMapper(proposal_topk=100, resize_pixels=False)(rec, shapes=((200, 300), (400, 600)))
     b = rec["proposal_boxes"]
     want = np.concatenate([b[:, :2], b[:, :2] + b[:, 2:]], 1)
     want[:, 0::2] = want[:, 0::2].clip(0, 300); want[:, 1::2] = want[:, 1::2].clip(0, 200)
