@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--images-per-gpu", type=int, default=1,
                     help="images (4-view sets) per GPU per step; BASELINE config #3 = --gpus 8 --images-per-gpu 2")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the short fp32 timing (extra key fp32_ms_per_step)")
+    ap.add_argument("--graph", type=int, default=None,
+                    help="1: replay the step as a captured hipGraph (default for --gpus 1), 0: eager launches (default under DDP)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -166,7 +168,8 @@ def main():
             groups.append({"params": [p], "lr": 2e-3 if name.endswith(".bias") else 1e-3,
                            "weight_decay": 0.0 if name.endswith(".bias") else 5e-4})
     opt = HipSGD(groups, 1e-3, momentum=0.9)
-    trainer = Trainer(model, opt)
+    use_graph = (world == 1) if args.graph is None else bool(args.graph)
+    trainer = Trainer(model, opt, use_graph=use_graph)
     B = args.images_per_gpu
     batches = [sum((make_inputs(device, 100 + rank * 17 + 2 * i + 1000 * b) for b in range(B)), []) for i in range(2)]
 
@@ -175,16 +178,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graphs = trainer._graphs
+    if graphs is not None:                       # "compile" phase: every distinct input signature is captured before any timing
+        for i in range(6):
+            trainer.run_step(batches[i % 2])
     for i in range(args.warmup):
         trainer.run_step(batches[i % 2])
     tags = ["fc6_fwd", "fc6_dgrad", "fc6_wgrad", "plain5.conv3_fwd"]
-    ops.TIMER = ops.KernelTimer(tags)
+    if graphs is None:
+        ops.TIMER = ops.KernelTimer(tags)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         trainer.run_step(batches[i % 2])
     sync()
     dt = time.perf_counter() - t0
+    eager_ms = None
+    n_timer_steps = args.steps
+    if graphs is not None:
+        # per-kernel durations need HIP events between launches, which a graph replay has no place for: the same kernels are
+        # timed in a few eager steps after the measured region (same shapes, same data)
+        replays, captures = graphs.replays, graphs.captures
+        trainer._graphs = None
+        trainer.run_step(batches[0])
+        ops.TIMER = ops.KernelTimer(tags)
+        n_timer_steps = 8
+        sync(); t1 = time.perf_counter()
+        for i in range(n_timer_steps):
+            trainer.run_step(batches[i % 2])
+        sync()
+        eager_ms = (time.perf_counter() - t1) / n_timer_steps * 1e3
     times = ops.TIMER.summary_ms()
     ops.TIMER = None
     if world > 1:
@@ -197,7 +220,7 @@ def main():
         flops = {"fc6_fwd": 2.0 * M * 25088 * DAN[0], "fc6_dgrad": 2.0 * M * 25088 * DAN[0], "fc6_wgrad": 2.0 * M * 25088 * DAN[0],
                  "plain5.conv3_fwd": 2.0 * (2 * 63 * 63) * 512 * 4608}
         avg_ms = {t: (sum(v) / len(v) if v else None) for t, v in times.items()}
-        tot_ms = {t: sum(v) / args.steps for t, v in times.items()}
+        tot_ms = {t: sum(v) / n_timer_steps for t, v in times.items()}
         dom = max((t for t in ("fc6_fwd", "fc6_dgrad", "fc6_wgrad")), key=lambda t: tot_ms[t])
         peak = MFMA_BF16_DENSE_PEAK_TFLOPS if dtype == torch.bfloat16 else 157.3
 
@@ -261,6 +284,10 @@ def main():
                                        "frac": round(flops["plain5.conv3_fwd"] / (conv_alone_ms * 1e-3) / 1e12 / peak, 4),
                                        "avg_ms": round(conv_alone_ms, 4), "mfma_busy_counter": busy_of("conv5_3")},
             "kernel_ms_per_step": {t: round(v, 3) for t, v in tot_ms.items()},
+            # whole step as ONE captured hipGraph (forward + backward + SGD; ms_per_step above) vs the same step issued launch by
+            # launch from Python (what DDP runs use); per-kernel figures come from the eager steps
+            "step_launch": ({"mode": "hipGraph replay", "graph_replays": replays, "graph_captures": captures,
+                             "eager_ms_per_step": round(eager_ms, 3)} if graphs is not None else {"mode": "eager launches"}),
         }
         if world == 1 and dtype == torch.bfloat16 and not args.no_fp32_line:
             # the reference's own precision (fp32 storage, exact-f32 MFMA: 1/16 of the bf16 rate), a short run for the record

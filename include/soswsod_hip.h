@@ -49,6 +49,9 @@ typedef struct sw_epilogue {
    * sw_dropout_mask(seed, offset, p) writes at index m*N + n is 1 — the same Bernoulli stream without the mask tensor */
   uint64_t drop_seed, drop_offset;
   float drop_hash_p;
+  /* optional DEVICE counter added to drop_offset when the kernel runs: the stream position then lives on the device
+   * (sw_counter_add advances it in-stream), so a captured hipGraph replays with a fresh dropout mask every time */
+  const uint64_t* drop_offset_dev;
   /* deterministic split-K (sw_gemm, f32 C, no other epilogue option): every K-split stores its partial tile into its own
    * slab of this workspace (sw_gemm_splitk_workspace_floats floats), a second kernel adds the slabs in fixed order into C
    * (overwritten) — no atomics.  Also used, when given, for the tail peel of the large f32-output GEMMs (see sw_gemm). */
@@ -82,6 +85,17 @@ int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int d
 int sw_conv3x3_wgrad_slabs(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                            const void* dy, float* workspace, int splitk, sw_stream_t stream);
 int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, sw_stream_t stream);
+/* ALL weight gradients of a backward pass in ONE launch: problem i writes the slabs sw_conv3x3_wgrad_slabs(..., splitk =
+ * nsplit) would write (sw_conv3x3_wgrad_workspace_floats(...) floats at `slabs`), computed on 256x256 tiles by one resident
+ * workgroup per CU walking the (problem, K-split, tile) list — instead of one launch of 128x128 tiles per layer and view,
+ * each cut into many K-splits to fill the chip.  `problems` is a HOST array.  Fold with sw_conv3x3_wgrad_fold. */
+typedef struct {
+  int nimg, H, W, Cin, Cout, dilation, nsplit;
+  const void* x;      /* [nimg][H][W][Cin] */
+  const void* dy;     /* [nimg][H][W][Cout] */
+  float* slabs;
+} sw_wgrad_problem;
+int sw_conv3x3_wgrad_grouped(int dtype, int n_problems, const sw_wgrad_problem* problems, sw_stream_t stream);
 /* OIHW f32 master weights -> kernel layout.  mode 0: wk[co][tap][ci_pad] (forward, ci zero padded to cin_pad);
  * mode 1: wk[ci][8-tap][co] (data gradient: taps flipped, in/out swapped). */
 int sw_conv_weight_prep(int dtype, int mode, int Cout, int Cin, int cin_pad, const float* w_oihw, void* wk,
@@ -204,6 +218,8 @@ int sw_detect_postprocess(int R, int K, const float* all_scores, const float* al
                           sw_stream_t stream);
 
 /* ---- small utilities ------------------------------------------------------------------------------------ */
+/* *counter += increment, in stream order (one thread): the dropout stream position of sw_epilogue.drop_offset_dev */
+int sw_counter_add(uint64_t* counter, uint64_t increment, sw_stream_t stream);
 /* out[n] = sum_m X[m][ld..] (column sums; the bias gradients of the reference's conv / Linear backward).  out f32,
  * overwritten.  With `workspace` (sw_colsum_workspace_floats floats) the sum is deterministic: partial rows per row chunk,
  * then an ordered fold.  workspace NULL (or N / ld not a multiple of 16 bytes): zero fill + one f32 atomic per column and

@@ -25,8 +25,16 @@ class Epilogue(ctypes.Structure):
         ("bias", c_void_p), ("relu", c_int), ("drop_mask", c_void_p), ("ld_drop", c_long), ("drop_scale", c_float),
         ("relu_ref", c_void_p), ("ld_ref", c_long), ("ref_scale", c_float), ("ref_dtype", c_int),
         ("out_dtype", c_int), ("accumulate_atomic", c_int), ("absmax_out", c_void_p),
-        ("drop_seed", c_u64), ("drop_offset", c_u64), ("drop_hash_p", c_float), ("splitk_workspace", c_void_p),
+        ("drop_seed", c_u64), ("drop_offset", c_u64), ("drop_hash_p", c_float), ("drop_offset_dev", c_void_p),
+        ("splitk_workspace", c_void_p),
     ]
+
+
+class WgradProblem(ctypes.Structure):
+    """sw_wgrad_problem"""
+    _fields_ = [("nimg", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int),
+                ("dilation", ctypes.c_int), ("nsplit", ctypes.c_int), ("x", ctypes.c_void_p), ("dy", ctypes.c_void_p),
+                ("slabs", ctypes.c_void_p)]
 
 
 class SgdTensor(ctypes.Structure):
@@ -86,6 +94,7 @@ SIGNATURES = {
     "sw_conv3x3_wgrad_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p]),
     "sw_conv3x3_wgrad_fold": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_conv3x3_wgrad_grouped": (c_int, [c_int, c_int, ctypes.POINTER(WgradProblem), c_void_p]),
     "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_relu_bwd": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
@@ -102,6 +111,7 @@ SIGNATURES = {
                                    c_void_p, c_long, c_void_p]),
     "sw_resize_pass_u8": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_void_p]),
+    "sw_counter_add": (c_int, [c_void_p, c_u64, c_void_p]),
     "sw_pack_views": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
                               c_void_p]),
     "sw_version": (ctypes.c_char_p, []),

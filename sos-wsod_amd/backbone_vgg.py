@@ -6,6 +6,8 @@ freeze_at semantics, `forward(x) -> {"plain5": (N,512,h,w)}`.  Every conv is the
 (sw_conv3x3_igemm) on NHWC bf16/f32 activations with bias+ReLU fused; backward is explicit
 (sw_conv3x3_wgrad, sw_conv3x3_igemm with flipped weights + fused ReLU mask, sw_maxpool2x2_bwd) inside ONE
 torch.autograd.Function, so autograd sees a single node.  The returned feature is an NCHW *view* of NHWC storage."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -56,6 +58,48 @@ def _wgrad_splitk(cout, cin, npix):
     more split starts a second, mostly empty wave (+30 %)"""
     tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
     return max(1, min(32, 512 // tiles, max(1, npix // 1024)))
+
+
+_WGRAD_PLAN_CACHE = {}
+
+
+def _wgrad_grouped_target(shapes, bk, n_cu=256):
+    """K-tiles per work item of the grouped weight-gradient launch for this set of problems.  shapes: [(npix, cout, n_cols)].
+    The launch deals the item list round-robin to n_cu resident workgroups, so its length is the busiest workgroup's sum of
+    K-tiles: simulated here for a few targets (plus the extra slab traffic of more K-splits, priced at ~25 K-tile-times per
+    extra slab of a 512 x 4608 gradient) and the cheapest kept.  Cached per shape set: the schedule of a training run's view
+    sizes is computed once."""
+    key = (tuple(shapes), bk, n_cu)
+    hit = _WGRAD_PLAN_CACHE.get(key)
+    if hit is not None:
+        return hit
+    best = None
+    for T in (40, 48, 56, 64, 72, 80, 96, 112, 128, 160):
+        load = [0.0] * n_cu
+        t, slabs = 0, 0.0
+        for npix, cout, ncols in shapes:
+            ktiles = (npix + bk - 1) // bk
+            ns = max(1, (ktiles + T // 2) // T)
+            per = (ktiles + ns - 1) // ns
+            ntile = ((cout + 255) // 256) * ((ncols + 255) // 256)
+            for _ in range(ns * ntile):
+                load[t % n_cu] += per
+                t += 1
+            slabs += (ns - 1) * cout * ncols / (512.0 * 4608.0)
+        cost = max(load) + 25.0 * slabs / max(1, n_cu // 32)
+        if best is None or cost < best[0]:
+            best = (cost, T)
+    if len(_WGRAD_PLAN_CACHE) > 512:
+        _WGRAD_PLAN_CACHE.clear()
+    _WGRAD_PLAN_CACHE[key] = best[1]
+    return best[1]
+
+
+def _wgrad_grouped_splits(npix, bk, target_ktiles):
+    """K-splits of one (layer, view batch) problem of the grouped weight-gradient launch: work items of ~target_ktiles K-tiles
+    each, so that the 256x256 items of all layers are of similar length (conv3 maps hold 4x the pixels of conv4 / conv5)"""
+    ktiles = (npix + bk - 1) // bk
+    return max(1, (ktiles + target_ktiles // 2) // target_ktiles)
 
 
 class _VGGFunction(torch.autograd.Function):
@@ -135,7 +179,25 @@ class _VGGFunction(torch.autograd.Function):
         dtype = infos[0][0][0][0][0].dtype
         main = torch.cuda.current_stream()
         side = module.side_stream() if len(live) > 1 else None
-        # ---- plan: per trainable conv one slab workspace / one partial-row workspace shared by all view batches
+        # ---- plan: per trainable conv one slab workspace / one partial-row workspace shared by all view batches.
+        # grouped: the weight gradients of ALL layers and view batches run as ONE launch after the data-gradient chains
+        # (sw_conv3x3_wgrad_grouped: 256x256 tiles, every CU busy); else one 128x128-tile launch per layer and view inside the chains
+        grouped = module.grouped_wgrad
+        bk = 64 if dtype == torch.bfloat16 else 32
+        deferred = []
+        target = module.wgrad_target_ktiles
+        if grouped and target <= 0:             # pick the K-tiles per item for THIS set of (layer, view batch) problems
+            shapes = []
+            pj = len(params)
+            for sj in range(len(module.blocks) - 1, -1, -1):
+                bj = module.blocks[sj]
+                for cj in range(bj.num_conv - 1, -1, -1):
+                    pj -= 2
+                    if params[pj].requires_grad:
+                        for i in live:
+                            xin = infos[i][sj][0][cj][0]
+                            shapes.append((xin.shape[0] * xin.shape[1] * xin.shape[2], bj.out_channels, 9 * xin.shape[3]))
+            target = _wgrad_grouped_target(shapes, bk)
         plan = {}            # pidx -> dict(ws, rows, per-batch offsets, totals, dw, db)
         pidx = len(params)
         for si in range(len(module.blocks) - 1, -1, -1):
@@ -149,7 +211,8 @@ class _VGGFunction(torch.autograd.Function):
                     for i in live:
                         x_in = infos[i][si][0][ci][0]
                         n, H, W, cin = x_in.shape
-                        splits[i] = _wgrad_splitk(cout, cin, n * H * W)
+                        splits[i] = (_wgrad_grouped_splits(n * H * W, bk, target) if grouped
+                                     else _wgrad_splitk(cout, cin, n * H * W))
                         slab_off[i], row_off[i] = nslab, nrow
                         nslab += ops.conv3x3_wgrad_nslab(x_in, cout, splits[i])
                         nrow += ops.colsum_nrows(dtype, n * H * W, cout)
@@ -171,10 +234,14 @@ class _VGGFunction(torch.autograd.Function):
                 g = gs[i]
                 if st is not main:
                     g.record_stream(st)
-                _VGGFunction._backward_one(module, infos[i], params, g, dtype, plan, i, first_trainable)
+                _VGGFunction._backward_one(module, infos[i], params, g, dtype, plan, i, first_trainable,
+                                           deferred if grouped else None, None if st is main else main)
             infos[i] = None
         if side is not None:
             main.wait_stream(side)
+        if deferred:
+            ops.conv3x3_wgrad_grouped(deferred)
+            deferred.clear()
         # ---- one ordered fold per parameter over the slabs / partial rows of every view batch
         for pidx, pl in plan.items():
             w = params[pidx]
@@ -185,7 +252,7 @@ class _VGGFunction(torch.autograd.Function):
         return (None, None) + (None,) * n_in + tuple(grads)
 
     @staticmethod
-    def _backward_one(module, stage_info, params, g, dtype, plan, i, first_trainable):
+    def _backward_one(module, stage_info, params, g, dtype, plan, i, first_trainable, deferred, consumer_stream):
         g = g.contiguous()
         if g.dtype != dtype:
             g = g.to(dtype)
@@ -205,7 +272,12 @@ class _VGGFunction(torch.autograd.Function):
                 pl = plan.get(pidx)
                 if pl is not None:
                     npix = n * H * W
-                    ops.conv3x3_wgrad_slabs(x_in, dz, pl["ws"][pl["slab_off"][i]:], blk.dilation, splitk=pl["splits"][i])
+                    if deferred is None:
+                        ops.conv3x3_wgrad_slabs(x_in, dz, pl["ws"][pl["slab_off"][i]:], blk.dilation, splitk=pl["splits"][i])
+                    else:                       # the grouped launch reads (x_in, dz) later, on the main stream
+                        if consumer_stream is not None:
+                            x_in.record_stream(consumer_stream); dz.record_stream(consumer_stream)
+                        deferred.append((x_in, dz, pl["ws"][pl["slab_off"][i]:], blk.dilation, pl["splits"][i]))
                     ops.colsum_partial(dz.view(npix, blk.out_channels), npix, blk.out_channels, pl["rows"][pl["row_off"][i]:])
                 if (si, ci) == first_trainable:
                     return
@@ -232,6 +304,8 @@ class VGG16(nn.Module):
         self.num_classes = num_classes
         self.compute_dtype = compute_dtype
         self.dual_stream = True           # alternate the view batches of forward_views between two HIP streams
+        self.grouped_wgrad = os.environ.get("SW_WGRAD_GROUPED", "1") != "0"      # development switch: per-layer launches
+        self.wgrad_target_ktiles = int(os.environ.get("SW_WGRAD_KTILES", "0"))   # 0: chosen per shape set (_wgrad_grouped_target)
         self._side = None
         self._wk_cache = {}
         self._out_feature_strides, self._out_feature_channels = {}, {}

@@ -1082,6 +1082,15 @@ extern "C" int sw_resize_pass_u8(int C, int H, int W, int out_size, int horizont
   return 0;
 }
 
+namespace { __global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) { *c += inc; } }
+
+extern "C" int sw_counter_add(uint64_t* counter, uint64_t increment, hipStream_t stream) {
+  SW_ENTER();
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, stream, (unsigned long long*)counter, (unsigned long long)increment);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sw_pack_views(int R, const float* const* box_ptrs4, const float* const* obj_ptrs4, float* boxes, float* obj,
                              float* rois, hipStream_t stream) {
   SW_ENTER();

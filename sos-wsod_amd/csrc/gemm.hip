@@ -33,6 +33,7 @@ struct GemmArgs {
   const float* bias;               // per column n (or per row m when bias_on_m)
   const uint8_t* drop; long ldd; float drop_scale;
   unsigned long long drop_seed_mixed, drop_offset; float drop_p;   // hash dropout: splitmix64(seed) pre-mixed on the host side
+  const unsigned long long* drop_offset_dev;                       // optional device-resident part of the stream position
   const void* ref; long ldr; float ref_scale; int ref_bf16;
   int relu, out_bf16, atomic, oihw_cin, staged_out;
   unsigned a_bytes, b_bytes;       // extents of the A / B operands (buffer descriptors' num_records)
@@ -151,8 +152,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// One output tile (bm, bn) of K-split `zsplit`: the whole main loop and epilogue.  Called by gemm2_kernel (one problem, the
+// workgroup -> tile map of the plain / split-K / persistent launches) and by gemm2_grouped_kernel (a list of problems).
 template <typename T, int AMODE, int BMODE, int BM, int BN, int STAGES, int WTM, int WTN>
-__global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, const int bn, const int zsplit, char* const smem) {
   using GA = Geom2<T, AMODE, BM>;
   using GB = Geom2<T, BMODE, BN>;
   constexpr int BK = GT<T>::BK, EPC = GT<T>::EPC;
@@ -166,37 +169,10 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
   constexpr int A_SLOTS = GA::BYTES / 16 / NT, B_SLOTS = GB::BYTES / 16 / NT;     // 16-byte chunks per thread per K-tile
   constexpr int STAGE_BYTES = GA::BYTES + GB::BYTES;
   constexpr int GROUP = A_SLOTS + B_SLOTS;                                        // LDS-DMA instructions per wave per K-tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];                     // [STAGES][A | B]
 
-  // Workgroup -> (tile, K-split).  The dispatcher deals workgroups round-robin to the 8 XCDs in flat launch order and
-  // every XCD has a private 4 MiB L2:
-  //  * no split-K: XCD x takes a contiguous run of 8x8-tile patches, so its 32 CUs share A rows / B columns in L2;
-  //  * split-K (few tiles, long K: the weight gradients): the grid holds valid tiles only and XCD x takes a contiguous
-  //    run of the split-major work list, i.e. ONE or two K-ranges for all tiles — its L2 then holds just that K-range
-  //    of both operands.  (With every XCD walking all of K the conv3 wgrad fetched 6x its operands from HBM; profiles/.)
-  const int vgrid = (g.vgrid > 0 && gridDim.z == 1) ? g.vgrid : (int)gridDim.x;
-  for (int vbid = blockIdx.x; vbid < vgrid; vbid += gridDim.x) {
-  int bm, bn, zsplit = 0;
-  if (gridDim.z > 1) {
-    const int ntv = gridDim.x, tot = ntv * (int)gridDim.z;
-    const int f = blockIdx.z * ntv + blockIdx.x;
-    const int x = f & 7, j = f >> 3;
-    const int w = x * (tot >> 3) + min(x, tot & 7) + j;
-    zsplit = w / ntv;
-    const int t = w - zsplit * ntv;
-    bm = t % g.tiles_m; bn = t / g.tiles_m;
-  } else {
-    const int nwg = vgrid;
-    const int bid = vbid;
-    const int swz = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    const int patch = swz >> 6, within = swz & 63;
-    bm = (patch % g.patches_m) * 8 + (within & 7);
-    bn = (patch / g.patches_m) * 8 + (within >> 3);
-    if (bm >= g.tiles_m || bn >= g.tiles_n) continue;
-  }
   const int kbeg = zsplit * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
-  if (kbeg >= kend) continue;
+  if (kbeg >= kend) return;
   const int nt = (kend - kbeg + BK - 1) / BK;
   const int m0 = bm * BM, n0t = bn * BN;
 
@@ -457,6 +433,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
   // ---- epilogue (C/D element map: Mma<T>::row / col)
   const int r = MM::col(lane);
   float vmax = 0.f;
+  const unsigned long long drop_base = g.drop_seed_mixed + g.drop_offset + ((g.drop_p > 0.f && g.drop_offset_dev) ? *g.drop_offset_dev : 0ull);
   // bf16 outputs go through LDS (the ring is free now): the accumulator layout gives a lane one 2-byte element per
   // store (64-byte segments); staged, every lane stores 16 contiguous bytes of one output row (8x fewer, full-line stores)
   const bool staged = g.staged_out;                          // host: bf16 out, plain store, N % 8 == 0, ldc % 8 == 0
@@ -478,7 +455,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
         if (g.relu) v = fmaxf(v, 0.f);
         if (g.drop && ok) v = g.drop[(long)m * g.ldd + n] ? v * g.drop_scale : 0.f;
         if (g.drop_p > 0.f && ok) {                        // identical Bernoulli stream to dropout_mask_kernel (elementwise.hip)
-          unsigned long long z = g.drop_seed_mixed + g.drop_offset + (unsigned long long)((long)m * g.N + n);
+          unsigned long long z = drop_base + (unsigned long long)((long)m * g.N + n);
           z += 0x9E3779B97F4A7C15ull;
           z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
           z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -516,9 +493,91 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
     vmax = wave_reduce_max(vmax);
     if (lane == 0) atomicMax((unsigned int*)g.absmax, __float_as_uint(vmax));
   }
+}
+
+template <typename T, int AMODE, int BMODE, int BM, int BN, int STAGES, int WTM, int WTN>
+__global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];                     // [STAGES][A | B]
+  // Workgroup -> (tile, K-split).  The dispatcher deals workgroups round-robin to the 8 XCDs in flat launch order and
+  // every XCD has a private 4 MiB L2:
+  //  * no split-K: XCD x takes a contiguous run of 8x8-tile patches, so its 32 CUs share A rows / B columns in L2;
+  //  * split-K (few tiles, long K: the weight gradients): the grid holds valid tiles only and XCD x takes a contiguous
+  //    run of the split-major work list, i.e. ONE or two K-ranges for all tiles — its L2 then holds just that K-range
+  //    of both operands.  (With every XCD walking all of K the conv3 wgrad fetched 6x its operands from HBM; profiles/.)
+  const int vgrid = (g.vgrid > 0 && gridDim.z == 1) ? g.vgrid : (int)gridDim.x;
+  for (int vbid = blockIdx.x; vbid < vgrid; vbid += gridDim.x) {
+  int bm, bn, zsplit = 0;
+  if (gridDim.z > 1) {
+    const int ntv = gridDim.x, tot = ntv * (int)gridDim.z;
+    const int f = blockIdx.z * ntv + blockIdx.x;
+    const int x = f & 7, j = f >> 3;
+    const int w = x * (tot >> 3) + min(x, tot & 7) + j;
+    zsplit = w / ntv;
+    const int t = w - zsplit * ntv;
+    bm = t % g.tiles_m; bn = t / g.tiles_m;
+  } else {
+    const int nwg = vgrid;
+    const int bid = vbid;
+    const int swz = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int patch = swz >> 6, within = swz & 63;
+    bm = (patch % g.patches_m) * 8 + (within & 7);
+    bn = (patch / g.patches_m) * 8 + (within >> 3);
+    if (bm >= g.tiles_m || bn >= g.tiles_n) continue;
+  }
+  gemm2_tile<T, AMODE, BMODE, BM, BN, STAGES, WTM, WTN>(g, bm, bn, zsplit, smem);
   if (vbid + (int)gridDim.x < vgrid) __syncthreads();       // persistent form: the staged epilogue is done with the LDS ring
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Grouped conv weight gradients: ALL trainable conv layers x ALL view batches of a backward pass as ONE launch of resident
+// workgroups (one per CU) walking a list of (problem, K-split, 256x256 tile) items.
+// Why: launched one by one, a conv4 / conv5 weight gradient has 36 tiles of 256x256 (or 144 of 128x128): to fill 256 CUs it
+// was cut into 3-28 K-splits of 128x128 tiles, whose 64 FLOP per staged byte keep the XCD L2s, not the MFMA pipe, busy
+// (0.17 of the MFMA peak, 18 launches + 9 slab folds per step).  All layers together are ~600-1200 items of 256x256 x ~64
+// K-tiles: 128 FLOP per staged byte, every CU busy for the whole launch, few slabs.
+struct GroupedProblem {
+  const void* A; const void* B; float* C;        // dy [pixels][Cout], x NHWC, slabs [nsplit][Cout][9*Cin]
+  int M, N, K, cH, cW, cC, cDil, k_per_split, nsplit, tiles_m, tiles_n;
+  unsigned a_bytes, b_bytes;
+};
+constexpr int GROUPED_MAX = 40;
+struct GroupedArgs {
+  int n_problems, n_items;
+  int first_item[GROUPED_MAX + 1];               // prefix sums of the problems' item counts (items = nsplit * tiles)
+  GroupedProblem p[GROUPED_MAX];
+};
+
+template <typename T>
+__global__ __launch_bounds__(1024, 1) void gemm2_grouped_kernel(GroupedArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // resident workgroup b serves the virtual ids b, b + G, b + 2G, ... (G = gridDim.x, a multiple of 8: all on one XCD).  Inside a
+  // round of G ids, XCD x (= id & 7) takes the contiguous run [x * G/8, (x+1) * G/8) of the locality-ordered item list
+  // (problem-major, K-split-major, tile rows fastest): its CUs share one problem's K-range — A rows / B columns — in L2.
+  const int G = gridDim.x;
+  for (int vbid = blockIdx.x; vbid < ga.n_items; vbid += G) {
+    const int round = vbid / G, within = vbid - round * G;
+    const int in_round = min(G, ga.n_items - round * G);          // the last round may be short: keep the map a bijection
+    const int x = within & 7, j = within >> 3;
+    const int per = in_round >> 3, extra = in_round & 7;
+    if (j >= per + (x < extra ? 1 : 0)) continue;
+    const int t = round * G + x * per + min(x, extra) + j;
+    int pi = 0;
+    while (pi + 1 < ga.n_problems && t >= ga.first_item[pi + 1]) ++pi;
+    const GroupedProblem& P = ga.p[pi];
+    const int local = t - ga.first_item[pi];
+    const int ntile = P.tiles_m * P.tiles_n;
+    const int zsplit = local / ntile, tl = local - zsplit * ntile;
+    GemmArgs g = {};
+    g.A = P.A; g.B = P.B; g.C = P.C; g.M = P.M; g.N = P.N; g.K = P.K; g.lda = P.M; g.ldb = 0; g.ldc = P.N;
+    g.cH = P.cH; g.cW = P.cW; g.cC = P.cC; g.cDil = P.cDil; g.k_per_split = P.k_per_split;
+    g.tiles_m = P.tiles_m; g.tiles_n = P.tiles_n; g.a_bytes = P.a_bytes; g.b_bytes = P.b_bytes;
+    g.slab_stride = (long)P.M * P.N; g.drop_scale = 1.f; g.ref_scale = 1.f;
+    gemm2_tile<T, OP_KSTRIDED, OP_CONV_B, 256, 256, 2, 64, 64>(g, tl % P.tiles_m, tl / P.tiles_m, zsplit, smem);
+    __syncthreads();                                              // the next item restarts the LDS ring
+  }
+}
+
 
 template <typename T, int AMODE, int BMODE, int BM, int BN, int STAGES, int WTM = 64, int WTN = 64>
 int launch2(GemmArgs& g, int splitk, hipStream_t stream) {
@@ -714,6 +773,7 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
       x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
       x ^= x >> 31;
       g.drop_seed_mixed = x; g.drop_offset = ep->drop_offset; g.drop_p = ep->drop_hash_p;
+      g.drop_offset_dev = (const unsigned long long*)ep->drop_offset_dev;
     }
   }
   {
@@ -881,6 +941,63 @@ extern "C" int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cout, (unsigned)parts), dim3(256), (size_t)36 * Cin / parts, stream, Cout, Cin,
                      nslab, workspace, dw_oihw);
   SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_conv3x3_wgrad_grouped(int dtype, int n_problems, const sw_wgrad_problem* problems, hipStream_t stream) {
+  SW_ENTER();
+  if (dtype != SW_BF16 && dtype != SW_F32) return -1;
+  if (n_problems <= 0) return 0;
+  const int epc = dtype == SW_BF16 ? 8 : 4, bk = dtype == SW_BF16 ? 64 : 32;
+  const long es = dtype == SW_BF16 ? 2 : 4;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
+    else ncu = 256;
+  }
+  constexpr int LDS = 2 * (Geom2<unsigned short, OP_KSTRIDED, 256>::BYTES + Geom2<unsigned short, OP_CONV_B, 256>::BYTES);
+  static_assert(LDS == 2 * (Geom2<float, OP_KSTRIDED, 256>::BYTES + Geom2<float, OP_CONV_B, 256>::BYTES), "one LDS size for both types");
+  for (int base = 0; base < n_problems; base += GROUPED_MAX) {
+    GroupedArgs ga = {};
+    ga.n_problems = n_problems - base < GROUPED_MAX ? n_problems - base : GROUPED_MAX;
+    int items = 0;
+    for (int i = 0; i < ga.n_problems; ++i) {
+      const sw_wgrad_problem& q = problems[base + i];
+      if ((q.Cin % epc) || (q.Cout % epc)) return -5;
+      if (check_align(q.x) || check_align(q.dy) || check_align(q.slabs)) return -4;
+      if ((64 / q.W) + 1 > 2 * q.H) return -6;          // pixel-advance carry logic of the gather (tiny maps only)
+      GroupedProblem& P = ga.p[i];
+      P.A = q.dy; P.B = q.x; P.C = q.slabs;
+      P.M = q.Cout; P.N = 9 * q.Cin; P.K = q.nimg * q.H * q.W; P.cH = q.H; P.cW = q.W; P.cC = q.Cin; P.cDil = q.dilation;
+      int ns = q.nsplit < 1 ? 1 : q.nsplit;
+      long kps = (P.K + ns - 1) / ns;
+      kps = ((kps + bk - 1) / bk) * bk;
+      P.k_per_split = (int)kps;
+      P.nsplit = (int)((P.K + kps - 1) / kps);
+      P.tiles_m = (P.M + 255) / 256; P.tiles_n = (P.N + 255) / 256;
+      const long ab = (long)P.K * q.Cout * es, bb = (long)P.K * q.Cin * es;
+      if (ab >= 0xFFFFFF00L || bb >= 0xFFFFFF00L) return -6;
+      P.a_bytes = (unsigned)ab; P.b_bytes = (unsigned)bb;
+      ga.first_item[i] = items;
+      items += P.nsplit * P.tiles_m * P.tiles_n;
+    }
+    ga.first_item[ga.n_problems] = items;
+    ga.n_items = items;
+    int G = ncu - (ncu % 8);
+    if (G < 8) G = 8;
+    hipError_t e;
+    if (dtype == SW_BF16) {
+      e = hipFuncSetAttribute((const void*)gemm2_grouped_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(gemm2_grouped_kernel<unsigned short>, dim3(G), dim3(1024), LDS, stream, ga);
+    } else {
+      e = hipFuncSetAttribute((const void*)gemm2_grouped_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(gemm2_grouped_kernel<float>, dim3(G), dim3(1024), LDS, stream, ga);
+    }
+    SW_CHECK_LAUNCH();
+  }
   return 0;
 }
 

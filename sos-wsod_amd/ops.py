@@ -85,7 +85,8 @@ def _need_gpu(*ts):
 
 def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_ref=None, ref_scale=1.0,
                   out_dtype=torch.float32, atomic=False, absmax_out=None, drop_hash=None, splitk_workspace=None):
-    """drop_hash=(seed, offset, p): dropout decided in the epilogue by the hash that sw_dropout_mask uses (no mask tensor)"""
+    """drop_hash=(seed, offset, p[, device counter]): dropout decided in the epilogue by the hash that sw_dropout_mask uses (no
+    mask tensor); with a device counter (uint64 scalar tensor) the stream position is offset + *counter at run time"""
     ep = Epilogue()
     ep.bias = None if bias is None else bias.data_ptr()
     ep.relu = int(relu)
@@ -102,7 +103,9 @@ def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_re
     ep.splitk_workspace = None if splitk_workspace is None else splitk_workspace.data_ptr()
     if drop_hash is not None and drop_mask is None:
         ep.drop_seed, ep.drop_offset, ep.drop_hash_p = int(drop_hash[0]) & (2 ** 64 - 1), int(drop_hash[1]), float(drop_hash[2])
-    ep._keepalive = (bias, drop_mask, relu_ref, absmax_out, splitk_workspace)     # the struct holds raw pointers only
+        if len(drop_hash) > 3 and drop_hash[3] is not None:
+            ep.drop_offset_dev = drop_hash[3].data_ptr()
+    ep._keepalive = (bias, drop_mask, relu_ref, absmax_out, splitk_workspace, drop_hash)     # the struct holds raw pointers only
     return ep
 
 
@@ -162,6 +165,23 @@ def conv3x3_wgrad_slabs(x, dy, workspace, dilation, splitk=1):
     n, H, W, Cin = x.shape
     check(lib.sw_conv3x3_wgrad_slabs(dt(x), n, H, W, Cin, dy.shape[3], dilation, _p(x), _p(dy), _p(workspace), splitk,
                                      _stream()), "sw_conv3x3_wgrad_slabs")
+
+
+def conv3x3_wgrad_grouped(problems):
+    """problems: list of (x NHWC, dy NHWC, slabs f32 tensor, dilation, nsplit) — every weight gradient of a backward pass in one
+    launch (sw_conv3x3_wgrad_grouped); each writes conv3x3_wgrad_nslab(x, cout, nsplit) slabs at `slabs`"""
+    from ._lib import WgradProblem
+    n = len(problems)
+    if n == 0:
+        return
+    arr = (WgradProblem * n)()
+    for i, (x, dy, slabs, dil, nsplit) in enumerate(problems):
+        _need_gpu(x, dy, slabs)
+        q = arr[i]
+        q.nimg, q.H, q.W, q.Cin = x.shape
+        q.Cout, q.dilation, q.nsplit = dy.shape[3], int(dil), int(nsplit)
+        q.x, q.dy, q.slabs = x.data_ptr(), dy.data_ptr(), slabs.data_ptr()
+    check(lib.sw_conv3x3_wgrad_grouped(dt(problems[0][0]), n, arr, _stream()), "sw_conv3x3_wgrad_grouped")
 
 
 def conv3x3_wgrad_fold(workspace, nslab, dw_oihw):
@@ -419,6 +439,11 @@ def resize_pass_u8(src, dst, bounds_i32, kk_i32, ksize, horizontal, dst_flip=Non
     check(lib.sw_resize_pass_u8(C, H, W, out_size, int(horizontal), _p(src), _p(bounds_i32), _p(kk_i32), int(ksize), _p(dst),
                                 _p(dst_flip), _stream()), "sw_resize_pass_u8")
     return dst
+
+
+def counter_add(counter_u64, increment):
+    """*counter += increment in stream order (the device-resident dropout stream position)"""
+    check(lib.sw_counter_add(_p(counter_u64), int(increment), _stream()), "sw_counter_add")
 
 
 def pack_views(box_list, obj_list, boxes, obj, rois):

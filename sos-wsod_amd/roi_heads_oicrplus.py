@@ -159,7 +159,9 @@ class OICRPlusHeads(nn.Module):
         # rank its own stream, engine/defaults.py:147 seeds SEED + rank), both travel in the state dict (extra state)
         self.seed = int(seed)
         self.dropout_seed = None
-        self._drop_counter = 0
+        self._drop_counter_host = 0       # stream position; lives in a device scalar once the first training forward ran, so that
+        self._drop_ctr_dev = None         # a captured hipGraph of the step draws a fresh mask on every replay
+        self._prestaged_labels = None     # graph capture / replay: (static device buffer, per-image class counts), see stage_labels
         self._stage_cache = {}            # name -> (key list, persistent compute-dtype weight copy)
         self.debug_drop_masks = None      # tests: [[m1, m2] per view] uint8 keep masks (A.2 #9)
         self.last_aux = None              # tests / metrics: device tensors of the last iteration
@@ -175,6 +177,23 @@ class OICRPlusHeads(nn.Module):
             base = self.seed if self.seed >= 0 else torch.initial_seed()
             self.dropout_seed = _splitmix64(_splitmix64(base & 0xFFFFFFFFFFFFFFFF) ^ (0x5051 + rank))
         return self.dropout_seed
+
+    @property
+    def _drop_counter(self):
+        if self._drop_ctr_dev is not None:
+            return int(self._drop_ctr_dev.item())
+        return self._drop_counter_host
+
+    @_drop_counter.setter
+    def _drop_counter(self, value):
+        self._drop_counter_host = int(value)
+        if self._drop_ctr_dev is not None:
+            self._drop_ctr_dev.fill_(int(value))
+
+    def _drop_counter_device(self, device):
+        if self._drop_ctr_dev is None or self._drop_ctr_dev.device != device:
+            self._drop_ctr_dev = torch.full((1,), int(self._drop_counter_host), dtype=torch.int64, device=device)
+        return self._drop_ctr_dev
 
     @property
     def dropout_stream(self):
@@ -355,9 +374,8 @@ class OICRPlusHeads(nn.Module):
                 masks = [torch.cat([self.debug_drop_masks[v][l].to(dev) for v in range(V)], 0).contiguous() for l in range(2)]
             else:                                     # decided inside the fc6 / fc7 epilogues: same stream, no mask tensors
                 seed = self._dropout_stream_seed()
-                for l, d in enumerate((D1, D2)):
-                    hashes[l] = (seed, self._drop_counter, 0.5)
-                    self._drop_counter += M * d
+                ctr = self._drop_counter_device(dev)
+                hashes = [(seed, 0, 0.5, ctr), (seed, M * D1, 0.5, ctr)]       # position = device counter + offset inside the step
         W1 = self._staged_matrix("fc1", fc1w, dev, transposed=inp["need_grad"])
         W1, W1T = W1 if isinstance(W1, tuple) else (W1, None)
         W2 = self._staged_matrix("fc2", fc2w, dev)
@@ -367,6 +385,8 @@ class OICRPlusHeads(nn.Module):
         h2 = _padded(M, D2, dev, dt_)
         ops.gemm(h1, W2, h2, M, D2, D1, ep=ops.make_epilogue(bias=fc2b, relu=True, drop_mask=masks[1], drop_hash=hashes[1],
                                                          out_dtype=dt_))
+        if hashes[0] is not None:
+            ops.counter_add(hashes[0][3], M * (D1 + D2))                       # in stream order, after both readers
         # --- all 10 predictor matrices as one GEMM, f32 logits
         Wh, bh = self._pack_head_weights(params, dev)
         LD = self.ld_head
@@ -534,10 +554,12 @@ class OICRPlusHeads(nn.Module):
         # the image-level labels are the only host data of the step: stage them through pinned memory so that the copy is
         # asynchronous (a pageable H2D copy blocks the host until the stream drains = one full pipeline bubble per step)
         nG = sum(Gs)
-        if device.type == "cuda":
+        if self._prestaged_labels is not None:           # a captured step reads the labels from a static device buffer that
+            devbuf, staged_G = self._prestaged_labels    # stage_labels filled in stream order BEFORE the capture / replay
+            assert tuple(staged_G) == tuple(Gs), "the class counts are kernel arguments of the captured step"
+        elif device.type == "cuda":
             host = torch.empty(nG + B * K, dtype=torch.float32, pin_memory=True)
-            host[:nG].view(torch.int32).copy_(torch.cat(gt_ints).to(torch.int32))
-            host[nG:].copy_(gt_oh.reshape(-1))
+            self._fill_label_host(host, gt_ints, gt_oh, nG)
             devbuf = host.to(device, non_blocking=True)
         else:
             devbuf = torch.cat([torch.cat(gt_ints).to(torch.int32).view(torch.float32), gt_oh.reshape(-1)])
@@ -547,6 +569,25 @@ class OICRPlusHeads(nn.Module):
             gt_onehot.append(devbuf[nG + b * K: nG + (b + 1) * K])
         return dict(B=B, R=Rs, G=Gs, off=offs, M=off, boxes=boxes, obj=obj, rois=rois, gt_int32=gt_i32, gt_onehot=gt_onehot,
                     ones=self._consts[0], pred_view=self._consts[1], need_grad=need_grad)
+
+    @staticmethod
+    def _fill_label_host(host, gt_ints, gt_oh, nG):
+        host[:nG].view(torch.int32).copy_(torch.cat(gt_ints).to(torch.int32))
+        host[nG:].copy_(gt_oh.reshape(-1))
+
+    def stage_labels(self, targets1, static_dev):
+        """Upload the image-level labels of `targets1` into the static device buffer a captured step reads them from (layout of
+        _prepare_inputs: all class lists, then one K-wide one-hot per image), asynchronously and in stream order — call it on
+        the stream that will replay the graph, before the replay.  Returns the per-image class counts (graph key)."""
+        K = self.num_classes
+        _, gt_ints, gt_oh = get_image_level_gt(targets1, K)
+        Gs = tuple(int(g.numel()) for g in gt_ints)
+        nG = sum(Gs)
+        host = torch.empty(nG + len(Gs) * K, dtype=torch.float32, pin_memory=True)
+        self._fill_label_host(host, gt_ints, gt_oh, nG)
+        static_dev[:host.numel()].copy_(host, non_blocking=True)
+        self._prestaged_labels = (static_dev[:host.numel()], Gs)
+        return Gs
 
     def forward(self, images_list, features_list, proposals_list, targets_list=(None, None, None, None), prepared=None):
         """training: features_list = [features1, features2] ({"plain5": NCHW view} of scale 1 / scale 2, as the reference

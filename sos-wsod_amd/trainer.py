@@ -52,7 +52,8 @@ class Trainer:
     every iteration (train_loop.py:274 -> comm.gather), i.e. one host sync per step."""
 
     def __init__(self, model, optimizer, data_iter=None, iter_size=1, scheduler=None, ddp=None, find_unused=False,
-                 check_finite_every=20, grad_compress=None, metrics_period=20, bucket_cap_mb=None, start_iter=0):
+                 check_finite_every=20, grad_compress=None, metrics_period=20, bucket_cap_mb=None, start_iter=0,
+                 use_graph=None):
         self.raw_model = model
         self.optimizer, self.scheduler = optimizer, scheduler
         self.iter_size = max(int(iter_size), 1)
@@ -63,6 +64,11 @@ class Trainer:
         self.storage = EventStorage(self.iter)
         self._finite_flag = None            # (iteration, device bool) of the last queued check
         self._grad_seed = None
+        # hipGraph replay of the whole step (forward + backward + optimizer) for recurring input signatures: see _StepGraphs
+        if use_graph is None:
+            use_graph = os.environ.get("SW_STEP_GRAPH", "0") == "1"
+        self._graphs = None
+        self._want_graph = bool(use_graph)
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         prepare = getattr(model, "prepare_for_training", None)
         if callable(prepare):
@@ -92,6 +98,9 @@ class Trainer:
                 self.model.register_comm_hook(None, default_hooks.bf16_compress_hook)
         else:
             self.model = model
+        if self._want_graph and not use_ddp and self.iter_size == 1 and hasattr(model, "roi_heads") and \
+                next(model.parameters()).is_cuda:
+            self._graphs = _StepGraphs(self)
 
     def _seed_grad(self, total):
         """cotangent of the summed loss: 1 / ITER_SIZE as a cached device scalar (train_net_multi.py:146 `losses / iter_size`
@@ -116,16 +125,19 @@ class Trainer:
                 data = next(self.data_iter)
         if self.iter == self.start_iter:
             self.optimizer.zero_grad()                                     # :143-144
-        with self.storage:
-            loss_dict = self.model(data)
-            # the 9 losses are views of one device vector (LossDict) whose sum is a second output of the heads node: no
-            # torch arithmetic between the model and .backward(); a plain dict falls back to the reference's sum()
-            total = getattr(loss_dict, "total", None)
-            losses = total() if callable(total) else sum(loss_dict.values())
-            losses.backward(gradient=self._seed_grad(losses))             # :146-147  (losses / iter_size).backward()
-        if self.iter % self.iter_size == 0:                                # :149 — the reference's rule, first step at iter 0
-            self.optimizer.step()
-            self.optimizer.zero_grad()
+        if self._graphs is not None:
+            # every step of a graph-enabled trainer — eager, capture or replay — runs on ONE side stream: a capture cannot use
+            # the default stream, and autograd pins each parameter's gradient accumulation to the stream its first forward ran
+            # on; an eager warm-up on the default stream followed by a capture elsewhere makes autograd synchronise the two
+            # inside the capture (the default stream joins it and never leaves: an unjoined capture, a crash on ROCm)
+            caller = torch.cuda.current_stream()
+            self._graphs.stream.wait_stream(caller)
+            with torch.cuda.stream(self._graphs.stream):
+                replayed = self._graphs.step(data) if self.iter > self.start_iter else None
+                loss_dict, losses = replayed if replayed is not None else self._forward_backward_update(data)
+            caller.wait_stream(self._graphs.stream)
+        else:
+            loss_dict, losses = self._forward_backward_update(data)
         if self.scheduler is not None:
             self.scheduler.step()                                          # hooks.LRScheduler.after_step: every iteration
         # non-finite losses (train_loop.py:253-259): the reference syncs every iteration; here a device flag is queued every
@@ -140,6 +152,19 @@ class Trainer:
         self.storage.step()
         self.iter += 1
         return loss_dict
+
+    def _forward_backward_update(self, data):
+        with self.storage:
+            loss_dict = self.model(data)
+            # the 9 losses are views of one device vector (LossDict) whose sum is a second output of the heads node: no
+            # torch arithmetic between the model and .backward(); a plain dict falls back to the reference's sum()
+            total = getattr(loss_dict, "total", None)
+            losses = total() if callable(total) else sum(loss_dict.values())
+            losses.backward(gradient=self._seed_grad(losses))             # :146-147  (losses / iter_size).backward()
+        if self.iter % self.iter_size == 0:                                # :149 — the reference's rule, first step at iter 0
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+        return loss_dict, losses
 
     def _write_metrics(self, loss_dict):
         """train_loop.py:261-297: rank-mean of every loss, on the device (one all-reduce of the 9-float vector)"""
@@ -162,3 +187,120 @@ class Trainer:
     def finish(self):
         """call after the last step: surfaces a pending non-finite flag"""
         self._raise_if_nonfinite()
+
+
+class _StepGraphs:
+    """hipGraph capture / replay of one whole training step (model forward, backward, HipSGD update of the masters and their
+    compute-dtype copies): ~250 kernel launches on two streams become ONE graph launch, so the step no longer waits for the
+    host (eager: 4-6 ms of Python / ctypes per step against 9-10 ms of GPU work, and the first ~1.5 ms of every step — the
+    backbone forward's 40 short kernels — is issue bound).
+
+    A graph is valid for one input SIGNATURE: the four view sizes and the proposal count of every image (buffer shapes), the
+    number of image-level classes per image (a kernel argument of the mining kernel), the learning rates / weight decays of the
+    optimizer groups (kernel arguments of the update).  A signature is captured the second time it is seen; other steps run
+    eagerly.  What varies from step to step travels through device memory the graph reads: the images and proposals are copied
+    into the graph's static input tensors, the image-level labels into a static label buffer (OICRPlusHeads.stage_labels), and
+    the dropout stream position is a device counter the graph itself advances (sw_counter_add).  One image-size bucket of a
+    real training run = one graph; a run whose every image has its own size simply never replays."""
+
+    MAX_GRAPHS = 16
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        self.model = trainer.raw_model
+        self.heads = self.model.roi_heads
+        self.dev = next(self.model.parameters()).device
+        self.seen = {}
+        self.graphs = {}
+        self.pool = None
+        self.labels = torch.zeros(4096, dtype=torch.float32, device=self.dev)
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.replays = self.captures = 0
+
+    VIEW_KEYS = ("1", "1_flip", "2", "2_flip")
+
+    def _signature(self, data):
+        sig = []
+        for x in data:
+            for k in self.VIEW_KEYS:
+                im, p = x["image" + k], x["proposals" + k]
+                if not (im.is_cuda and p.proposal_boxes.tensor.is_cuda and p.objectness_logits.is_cuda):
+                    return None
+                sig.append((tuple(im.shape), len(p)))
+            g = x["instances1"].gt_classes
+            sig.append(int(torch.unique(g.detach().cpu()).numel()))
+        opt = tuple((float(g["lr"]), float(g["weight_decay"]), float(g.get("momentum", 0.0))) for g in self.tr.optimizer.param_groups)
+        return (tuple(sig), opt, self.model.training)
+
+    @staticmethod
+    def _clone_inputs(data):
+        from .structures import Boxes, Instances
+        out = []
+        for x in data:
+            d = {}
+            for k, v in x.items():
+                if k.startswith("image") and isinstance(v, torch.Tensor):
+                    d[k] = v.clone()
+                elif k.startswith("proposals"):
+                    p = Instances(v.image_size)
+                    p.proposal_boxes = Boxes(v.proposal_boxes.tensor.clone())
+                    p.objectness_logits = v.objectness_logits.clone()
+                    d[k] = p
+                else:
+                    d[k] = v                        # instances*: host-side labels, restaged per step (stage_labels)
+            out.append(d)
+        return out
+
+    def _stage(self, static, data):
+        for s, x in zip(static, data):
+            for k in self.VIEW_KEYS:
+                s["image" + k].copy_(x["image" + k], non_blocking=True)
+                s["proposals" + k].proposal_boxes.tensor.copy_(x["proposals" + k].proposal_boxes.tensor, non_blocking=True)
+                s["proposals" + k].objectness_logits.copy_(x["proposals" + k].objectness_logits, non_blocking=True)
+        self.heads.stage_labels([x["instances1"] for x in data], self.labels)
+
+    def step(self, data):
+        """-> (loss_dict, total) after replaying (or capturing + replaying) this step's graph, or None: run eagerly"""
+        sig = self._signature(data)
+        if sig is None:
+            return None
+        hit = self.graphs.get(sig)
+        if hit is None:
+            n = self.seen.get(sig, 0) + 1
+            self.seen[sig] = n
+            if n < 2 or len(self.graphs) >= self.MAX_GRAPHS:
+                if len(self.seen) > 4096:
+                    self.seen.clear()
+                return None
+            hit = self._capture(sig, data)
+            if hit is None:
+                return None
+        graph, static, loss_dict, losses = hit
+        try:
+            self._stage(static, data)
+            graph.replay()
+        finally:
+            self.heads._prestaged_labels = None
+        self.replays += 1
+        return loss_dict, losses
+
+    def _capture(self, sig, data):
+        tr = self.tr
+        for p in self.model.parameters():                      # the captured optimizer must not create state
+            if p.requires_grad and "momentum_buffer" not in tr.optimizer.state.get(p, {}):
+                return None
+        static = self._clone_inputs(data)
+        self.heads.stage_labels([x["instances1"] for x in data], self.labels)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
+                loss_dict, losses = tr._forward_backward_update(static)
+        finally:
+            self.heads._prestaged_labels = None
+        if self.pool is None:
+            self.pool = graph.pool()
+        self.captures += 1
+        hit = (graph, static, loss_dict, losses)
+        self.graphs[sig] = hit
+        return hit

@@ -572,3 +572,49 @@ def test_baseline_config1_fp32_parity_against_the_oracle():
         assert np.array_equal(r["pgt_class"][:n].cpu().numpy(), o["pgt"]["classes"])
         assert np.array_equal(r["lab_class"].cpu().numpy(), o["labels"]["gt_classes"])
         assert np.array_equal(r["lab_index"].cpu().numpy(), o["labels"]["gt_index"])
+
+
+def test_step_graph_replay_equals_eager_steps(golden_dir):
+    """Trainer(use_graph=True): after the second sight of an input signature the whole step (forward, backward, HipSGD) replays
+    as one hipGraph.  Same start, same data sequence, same dropout stream => losses and weights of every step are bitwise those
+    of the eager run, for new images / proposals / labels copied into the graph's static inputs each step."""
+    from sos_wsod_amd.solver import HipSGD
+    from sos_wsod_amd.trainer import Trainer
+    K, dan, R, H, W = 20, (256, 256), 80, 96, 128
+    P = O.make_params(K, dan, tag="pgraph", head_scale=3.0)
+
+    def batches():
+        out = []
+        for i in range(6):
+            views, _ = O.make_views(H, W, R, n_gt=2, K=K, tag=f"vgraph{i}")
+            out.append(to_batched_inputs(views, np.array([(3 + i) % K, (11 + 2 * i) % K])))      # two classes each: one signature
+            for k, v in out[-1][0].items():                                                       # device-resident inputs
+                if k.startswith("image"):
+                    out[-1][0][k] = v.cuda()
+                elif k.startswith("proposals"):
+                    v.proposal_boxes.tensor = v.proposal_boxes.tensor.cuda(); v.objectness_logits = v.objectness_logits.cuda()
+        return out
+
+    def run(use_graph):
+        model = build_model(K, dan, torch.bfloat16)
+        load_params(model, P)
+        model.train()
+        model.roi_heads.seed = 77
+        groups = [{"params": [p], "lr": 1e-3, "weight_decay": 5e-4} for p in model.parameters() if p.requires_grad]
+        tr = Trainer(model, HipSGD(groups, 1e-3, momentum=0.9), use_graph=use_graph, check_finite_every=2, metrics_period=2)
+        losses = []
+        for b in batches():
+            ld = tr.run_step(b)
+            losses.append(ld.vector.detach().clone())
+        tr.finish()
+        torch.cuda.synchronize()
+        return tr, losses, {n: p.detach().clone() for n, p in model.named_parameters()}
+    tr_e, le, we = run(False)
+    tr_g, lg, wg = run(True)
+    assert tr_e._graphs is None and tr_g._graphs is not None
+    assert tr_g._graphs.captures == 1 and tr_g._graphs.replays == 4          # steps 0, 1 eager (step 1 = first sight), 2..5 replayed
+    for i, (a, b) in enumerate(zip(le, lg)):
+        assert torch.equal(a, b), (i, a, b)
+    bad = [n for n in we if not torch.equal(we[n], wg[n])]
+    assert not bad, bad
+    assert tr_g.raw_model.roi_heads._drop_counter == tr_e.raw_model.roi_heads._drop_counter > 0

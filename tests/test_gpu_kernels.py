@@ -130,6 +130,51 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cin, cout, dil):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_conv3x3_wgrad_grouped_launch(ops, dtype):
+    """all weight gradients of a backward pass in ONE launch (sw_conv3x3_wgrad_grouped): problems of different map sizes,
+    channel counts, dilations and K-splits (two view batches share a parameter = consecutive slabs, one fold) against an fp64
+    convolution gradient; more problems than one kernel-argument block holds (40) exercise the chunked launch"""
+    specs = [(2, 19, 23, 64, 128, 1, 2), (2, 25, 17, 64, 128, 1, 3),          # one parameter, two view batches
+             (2, 31, 33, 128, 64, 2, 1), (1, 40, 37, 32, 264, 1, 4), (2, 16, 16, 8, 8, 1, 1)]
+    specs = specs + [(1, 9, 11, 16, 16, 1, 1)] * 38                             # 43 problems > GROUPED_MAX
+    probs, checks = [], []
+    seed = 100
+    for (n, H, W, cin, cout, dil, ns) in specs:
+        x = _rand((n, H, W, cin), seed, dtype); dz = _rand((n, H, W, cout), seed + 1, dtype); seed += 2
+        nslab = ops.conv3x3_wgrad_nslab(x.cuda(), cout, ns)
+        slabs = torch.full((nslab, cout * 9 * cin), float("nan"), device="cuda")
+        probs.append((x.cuda(), dz.cuda(), slabs, dil, ns))
+        checks.append((x, dz, slabs, nslab, cin, cout, dil))
+    ops.conv3x3_wgrad_grouped(probs)
+    torch.cuda.synchronize()
+
+    def ref_grad(x, dz, cin, cout, dil):
+        wd = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x.double().permute(0, 3, 1, 2), wd, None, padding=dil, dilation=dil)
+        return torch.autograd.grad(y, wd, dz.double().permute(0, 3, 1, 2))[0]
+    for k, (x, dz, slabs, nslab, cin, cout, dil) in enumerate(checks[:6]):
+        dw = torch.empty(cout, cin, 3, 3, device="cuda")
+        ops.conv3x3_wgrad_fold(slabs, nslab, dw)
+        want = ref_grad(x, dz, cin, cout, dil)
+        assert ((dw.cpu().double() - want).abs().max() / want.abs().max()) < 3e-5, k
+        one = torch.empty(cout, cin, 3, 3, device="cuda")                        # the per-launch path on the same problem
+        ops.conv3x3_wgrad(x.cuda(), dz.cuda(), one, dil, splitk=1)
+        assert ((dw - one).abs().max() / one.abs().max()) < 1e-5, k
+    # two view batches of one parameter: their slabs back to back, ONE fold = the sum of both gradients
+    (x0, dz0, s0, n0, cin, cout, dil), (x1, dz1, s1, n1, _, _, _) = checks[0], checks[1]
+    both = torch.cat([s0, s1], 0).contiguous()
+    dw = torch.empty(cout, cin, 3, 3, device="cuda")
+    ops.conv3x3_wgrad_fold(both, n0 + n1, dw)
+    want = ref_grad(x0, dz0, cin, cout, dil) + ref_grad(x1, dz1, cin, cout, dil)
+    assert ((dw.cpu().double() - want).abs().max() / want.abs().max()) < 3e-5
+    last = checks[-1]
+    dw = torch.empty(last[5], last[4], 3, 3, device="cuda")
+    ops.conv3x3_wgrad_fold(last[2], last[3], dw)
+    want = ref_grad(last[0], last[1], last[4], last[5], last[6])
+    assert ((dw.cpu().double() - want).abs().max() / want.abs().max()) < 3e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("C", [24, 6])
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("H,W", [(11, 14), (9, 13), (8, 8)])       # odd sizes: the last row / column belongs to no stride-2 window
