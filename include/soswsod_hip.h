@@ -96,6 +96,9 @@ typedef struct {
   float* slabs;
 } sw_wgrad_problem;
 int sw_conv3x3_wgrad_grouped(int dtype, int n_problems, const sw_wgrad_problem* problems, sw_stream_t stream);
+/* n folds (sw_conv3x3_wgrad_fold) in ONE launch; `folds` is a HOST array */
+typedef struct { int Cin, Cout, nslab; const float* workspace; float* dw_oihw; } sw_wgrad_fold;
+int sw_conv3x3_wgrad_fold_multi(int n, const sw_wgrad_fold* folds, sw_stream_t stream);
 /* OIHW f32 master weights -> kernel layout.  mode 0: wk[co][tap][ci_pad] (forward, ci zero padded to cin_pad);
  * mode 1: wk[ci][8-tap][co] (data gradient: taps flipped, in/out swapped). */
 int sw_conv_weight_prep(int dtype, int mode, int Cout, int Cin, int cin_pad, const float* w_oihw, void* wk,
@@ -230,6 +233,9 @@ int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, float
  * `_fold` adds n_partial_rows consecutive rows (of one or several matrices) in fixed order */
 int sw_colsum_partial(int dtype, int M, int N, const void* X, long ld, float* workspace, sw_stream_t stream);
 int sw_colsum_fold(int N, int n_partial_rows, const float* workspace, float* out, sw_stream_t stream);
+/* n folds in ONE launch; `folds` is a HOST array */
+typedef struct { int N, n_partial_rows; const float* workspace; float* out; } sw_colsum_fold_desc;
+int sw_colsum_fold_multi(int n, const sw_colsum_fold_desc* folds, sw_stream_t stream);
 /* rows x cols copy/convert f32 -> dtype with independent leading dimensions (weight staging). */
 int sw_convert_2d(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
                   sw_stream_t stream);

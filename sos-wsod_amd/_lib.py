@@ -12,7 +12,7 @@ import torch  # noqa: F401  — FIRST: torch bundles its own HIP runtime (torch/
 #                has an initialised device (every launch from this library then fails with hipErrorNoDevice = 100)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsoswsod_hip.so")
+LIB_PATH = os.environ.get("SW_LIB_PATH") or os.path.join(_HERE, "libsoswsod_hip.so")     # SW_LIB_PATH: development builds (kernel A/B runs)
 
 SW_F32, SW_BF16 = 0, 1
 
@@ -35,6 +35,17 @@ class WgradProblem(ctypes.Structure):
     _fields_ = [("nimg", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int),
                 ("dilation", ctypes.c_int), ("nsplit", ctypes.c_int), ("x", ctypes.c_void_p), ("dy", ctypes.c_void_p),
                 ("slabs", ctypes.c_void_p)]
+
+
+class WgradFold(ctypes.Structure):
+    """sw_wgrad_fold"""
+    _fields_ = [("Cin", ctypes.c_int), ("Cout", ctypes.c_int), ("nslab", ctypes.c_int), ("workspace", ctypes.c_void_p),
+                ("dw_oihw", ctypes.c_void_p)]
+
+
+class ColsumFold(ctypes.Structure):
+    """sw_colsum_fold_desc"""
+    _fields_ = [("N", ctypes.c_int), ("n_partial_rows", ctypes.c_int), ("workspace", ctypes.c_void_p), ("out", ctypes.c_void_p)]
 
 
 class SgdTensor(ctypes.Structure):
@@ -94,6 +105,8 @@ SIGNATURES = {
     "sw_conv3x3_wgrad_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p]),
     "sw_conv3x3_wgrad_fold": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_conv3x3_wgrad_fold_multi": (c_int, [c_int, ctypes.POINTER(WgradFold), c_void_p]),
+    "sw_colsum_fold_multi": (c_int, [c_int, ctypes.POINTER(ColsumFold), c_void_p]),
     "sw_conv3x3_wgrad_grouped": (c_int, [c_int, c_int, ctypes.POINTER(WgradProblem), c_void_p]),
     "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

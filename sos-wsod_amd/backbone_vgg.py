@@ -242,12 +242,12 @@ class _VGGFunction(torch.autograd.Function):
         if deferred:
             ops.conv3x3_wgrad_grouped(deferred)
             deferred.clear()
-        # ---- one ordered fold per parameter over the slabs / partial rows of every view batch
+        # ---- one ordered fold per parameter over the slabs / partial rows of every view batch: all of them in two launches
+        ops.conv3x3_wgrad_fold_multi([(pl["ws"], pl["nslab"], pl["dw"]) for pl in plan.values()])
+        ops.colsum_fold_multi([(pl["rows"], pl["nrow"], pl["db"]) for pl in plan.values()])
         for pidx, pl in plan.items():
             w = params[pidx]
-            ops.conv3x3_wgrad_fold(pl["ws"], pl["nslab"], pl["dw"])
             grads[pidx] = pl["dw"][:, : w.shape[1]].contiguous() if pl["cin"] != w.shape[1] else pl["dw"]
-            ops.colsum_fold(pl["rows"], pl["nrow"], pl["db"])
             grads[pidx + 1] = pl["db"]
         return (None, None) + (None,) * n_in + tuple(grads)
 

@@ -355,9 +355,9 @@ __global__ __launch_bounds__(256) void colsum_ws_kernel(int M, int N, int rows_p
 // out[n] = sum_c ws[c][n]: a workgroup owns 16 columns x 16 chunk-lanes (the <= 128 partial rows are 8 loads deep per
 // thread; 64 columns x 4 lanes was 32 deep on 4-8 workgroups: 11 us); chunks in fixed order per lane, lanes folded in fixed
 // order through LDS
-__global__ __launch_bounds__(256) void colsum_fold_kernel(int N, int nchunk, const float* __restrict__ ws, float* __restrict__ out) {
+__device__ __forceinline__ void colsum_fold_body(int N, int nchunk, const float* __restrict__ ws, float* __restrict__ out, int wg) {
   __shared__ float fold[16][17];
-  const int tid = threadIdx.x, cl = tid >> 4, c16 = tid & 15, col = blockIdx.x * 16 + c16;
+  const int tid = threadIdx.x, cl = tid >> 4, c16 = tid & 15, col = wg * 16 + c16;
   float f = 0.f;
   if (col < N)
     for (int c = cl; c < nchunk; c += 16) f += ws[(long)c * N + col];
@@ -369,6 +369,24 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(int N, int nchunk, con
     for (int r = 0; r < 16; ++r) s += fold[r][c16];
     out[col] = s;
   }
+}
+
+__global__ __launch_bounds__(256) void colsum_fold_kernel(int N, int nchunk, const float* __restrict__ ws, float* __restrict__ out) {
+  colsum_fold_body(N, nchunk, ws, out, blockIdx.x);
+}
+
+constexpr int CFOLD_MAX = 32;
+struct ColsumFoldMulti {
+  int n;
+  int first_wg[CFOLD_MAX + 1];
+  int N[CFOLD_MAX], rows[CFOLD_MAX];
+  const float* ws[CFOLD_MAX];
+  float* out[CFOLD_MAX];
+};
+__global__ __launch_bounds__(256) void colsum_fold_multi_kernel(ColsumFoldMulti f) {
+  int i = 0;
+  while (i + 1 < f.n && (int)blockIdx.x >= f.first_wg[i + 1]) ++i;
+  colsum_fold_body(f.N[i], f.rows[i], f.ws[i], f.out[i], blockIdx.x - f.first_wg[i]);
 }
 
 // ---------------------------------------------------------------- dropout keep mask
@@ -922,6 +940,26 @@ extern "C" int sw_colsum_fold(int N, int n_partial_rows, const float* workspace,
   if (N <= 0 || n_partial_rows < 1) return -5;
   hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, N, n_partial_rows, workspace, out);
   SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_colsum_fold_multi(int n, const sw_colsum_fold_desc* folds, hipStream_t stream) {
+  SW_ENTER();
+  for (int base = 0; base < n; base += CFOLD_MAX) {
+    ColsumFoldMulti f = {};
+    f.n = n - base < CFOLD_MAX ? n - base : CFOLD_MAX;
+    int wgs = 0;
+    for (int i = 0; i < f.n; ++i) {
+      const sw_colsum_fold_desc& q = folds[base + i];
+      if (q.N <= 0 || q.n_partial_rows < 1) return -5;
+      f.N[i] = q.N; f.rows[i] = q.n_partial_rows; f.ws[i] = q.workspace; f.out[i] = q.out;
+      f.first_wg[i] = wgs;
+      wgs += (q.N + 15) / 16;
+    }
+    f.first_wg[f.n] = wgs;
+    hipLaunchKernelGGL(colsum_fold_multi_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, f);
+    SW_CHECK_LAUNCH();
+  }
   return 0;
 }
 

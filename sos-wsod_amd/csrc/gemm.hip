@@ -147,6 +147,8 @@ __device__ __forceinline__ u32x4 load_frag2(const char* tile, int sub_base, int 
   }
 }
 
+template <int V> struct IntC { static constexpr int value = V; };
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -296,6 +298,7 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
     is_kb = kbeg + kt * BK;
     is_base = smem + (kt % STAGES) * STAGE_BYTES;
     is_tail = is_kb + BK > kend;            // only the last K-tile of a split can be partial (wave-uniform)
+    if constexpr (BM == 256 && BN == 256 && WTM == 128 && WTN == 64) is_tail = false;   // ping-pong form: K % BK == 0 (launch_auto)
   };
   auto issue_a = [&](int i) {
     unsigned voff = a_v[i], soff;
@@ -409,6 +412,87 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
     }
   };
 
+  // ---------------------------------------------------------------------------------------------------------------------
+  // Ping-pong main loop (256x256 tile, EIGHT waves of 128x64, two per SIMD, up to 256 VGPRs each).
+  // The 16-wave loop below runs four waves per SIMD under a 128-VGPR cap: no room to prefetch fragments, every wave alternates
+  // a ds_read burst and an MFMA burst and all sixteen do so in step after each K-tile barrier (MFMA pipe 55-69 % busy).  Here
+  // the waves form two groups (wave < 4 / wave >= 4 = one wave of each group on every SIMD) that run the SAME program shifted
+  // by one barrier: a K-tile is 4 phases (one 64x32 quadrant of the wave tile x K = 64 = 16 MFMAs), every phase is a LOAD
+  // segment (the quadrant's new fragments: 12 / 4 / 8 / 0 ds_read_b128, plus 2 of the wave's 8 LDS-DMA pieces of a later
+  // K-tile) and an MFMA segment, separated by barriers — while one group issues its 16 MFMAs, the other loads.  Fragment reads
+  // per K-tile drop from 256 to 192 KiB as well (128x64 wave tiles; the B fragments of both column halves stay in registers).
+  // LDS-DMA schedule (2 buffers): the pieces of tile t+2 go out in phase 3 of tile t (its buffer was last read in phase 2: the
+  // second group drains those reads before the barrier) and phases 0-2 of tile t+1; each wave waits for them with a counted
+  // vmcnt at the end of tile t+1, one barrier before the first read.
+  constexpr bool PP = (BM == 256 && BN == 256 && WTM == 128 && WTN == 64 && STAGES == 2 && sizeof(T) == 2 && TS == 16 &&
+                       AMODE <= OP_KSTRIDED && BMODE <= OP_KSTRIDED);
+  if constexpr (PP) {
+    const int grp = wm;                                   // 0: waves 0-3, 1: waves 4-7
+    auto dma_pair = [&](int tile, int j) {
+      if (tile < nt) { issue_begin(tile); issue_range(2 * j, 2 * j + 2); }
+    };
+    auto tile_wait = [&](int kt) {                        // everything of tile kt+1 landed; the first pair of kt+2 may fly on
+      if (kt + 2 < nt) wait_vmcnt<2>(); else wait_vmcnt<0>();
+    };
+    if (nt > 0) { issue_begin(0); issue_range(0, GROUP); }
+    dma_pair(1, 0);
+    tile_wait(-1);
+    __builtin_amdgcn_s_barrier();
+#ifndef SW_PP_NOSTAGGER
+    if (grp == 1) __builtin_amdgcn_s_barrier();           // the stagger: group 1 runs one segment behind
+#endif
+    u32x4 fa[4][2], fb[2][2][2];
+    for (int kt = 0; kt < nt; ++kt) {
+      const char* sa = smem + (kt & 1) * STAGE_BYTES;
+      const char* sb = sa + GA::BYTES;
+      auto phase = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int mq = p >> 1, nq = (p == 1 || p == 2) ? 1 : 0;       // quadrant order (0,0) (0,1) (1,1) (1,0)
+        // ---- LOAD segment
+        __builtin_amdgcn_sched_barrier(0);
+        if (p == 0 || p == 2) {
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) fa[ii][st] = load_frag2<T, GA::KS, GA::ROW_BYTES>(sa, wm * WTM + (mq * 4 + ii) * TS, st, lane);
+        }
+        if (p == 0 || p == 1) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) fb[nq][jj][st] = load_frag2<T, GB::KS, GB::ROW_BYTES>(sb, wn * WTN + (nq * 2 + jj) * TS, st, lane);
+        }
+        if (p == 3) dma_pair(kt + 2, 0); else dma_pair(kt + 1, p + 1);
+        if (grp == 1 && p == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // tile kt's last reads done before its buffer is refilled
+        if (grp == 1 && p == 3) tile_wait(kt);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA segment
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef SW_PP_NOPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) MM::mma(acc[mq * 4 + ii][nq * 2 + jj], fa[ii][st], fb[nq][jj][st]);
+#ifndef SW_PP_NOPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if (grp == 0 && p == 3) tile_wait(kt);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      phase(IntC<0>{}); phase(IntC<1>{}); phase(IntC<2>{}); phase(IntC<3>{});
+    }
+#ifndef SW_PP_NOSTAGGER
+    if (grp == 0) __builtin_amdgcn_s_barrier();           // both groups executed the same number of barriers
+#endif
+  } else {
   // prologue: STAGES-1 K-tiles in flight
 #pragma unroll
   for (int t = 0; t < STAGES - 1; ++t)
@@ -429,11 +513,109 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
       compute(kt, false);
     }
   }
+  }
 
   // ---- epilogue (C/D element map: Mma<T>::row / col)
   const int r = MM::col(lane);
   float vmax = 0.f;
   const unsigned long long drop_base = g.drop_seed_mixed + g.drop_offset + ((g.drop_p > 0.f && g.drop_offset_dev) ? *g.drop_offset_dev : 0ull);
+  if constexpr (PP) {
+    // Row-wise epilogue through LDS (the ring is free now).  128 accumulator registers plus a fully unrolled 128-element
+    // epilogue do not fit 256 VGPRs (the compiler parked every accumulator in scratch: ~55 us per tile); here a wave moves its
+    // tile 32 rows at a time into a private 32 x 68 f32 LDS image and walks it in row pieces: a lane owns 4 (f32 output) or 8
+    // (bf16 output) consecutive columns of one row, applies bias / ReLU / dropout / mask to them and stores 16 bytes.
+    constexpr int LDW = WTN + 4;                                   // padded pitch: the 4 row groups of a store hit different banks
+    float* wt = (float*)smem + wave * (32 * LDW);
+    __syncthreads();                                               // every wave is done reading the last K-tile
+    const bool vec_ok = g.staged_out;                              // host: 16-byte row pieces are aligned and inside the row pitch
+    auto quarter = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < NACC; ++e) wt[(ii * TS + MM::row(lane, e)) * LDW + j * TS + r] = acc[2 * q + ii][j][e];
+      __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): own LDS writes before own reads (same wave)
+      // a lane owns CP consecutive columns of one row: 8 for bf16 rows (16-byte stores), 4 for f32 rows.  CP and "no
+      // per-element work" are compile-time cases: left as run-time tests inside the element loop, hipcc keeps that loop rolled
+      // and selects v[t] through compare chains (~60 instructions per element: 50 us per tile)
+      auto pieces = [&](auto cpc, auto plainc) {
+        constexpr int CP = decltype(cpc)::value;
+        constexpr bool PLAIN = decltype(plainc)::value != 0;
+        constexpr int PPR = WTN / CP;
+#pragma unroll
+        for (int it = 0; it < (32 * PPR) / 64; ++it) {
+          const int pc = it * 64 + lane;
+          const int row = pc / PPR, c0 = (pc % PPR) * CP;
+          const int m = m0 + wm * WTM + q * 32 + row;
+          const int nb = n0t + wn * WTN + c0;
+          if (m >= g.M || nb >= g.N) continue;
+          float v[CP];
+          *(f32x4*)&v[0] = *(const f32x4*)&wt[row * LDW + c0];
+          if (CP == 8) *(f32x4*)&v[CP - 4] = *(const f32x4*)&wt[row * LDW + c0 + 4];
+          const bool full = nb + CP <= g.N;
+#pragma unroll
+          for (int t = 0; t < CP; ++t) {
+            const int n = nb + t;
+            const bool ok = n < g.N;
+            float x = v[t];
+            if (!PLAIN) {
+              x += (g.bias && ok) ? g.bias[n] : 0.f;
+              if (g.relu) x = fmaxf(x, 0.f);
+              if (g.drop && ok) x = g.drop[(long)m * g.ldd + n] ? x * g.drop_scale : 0.f;
+              if (g.drop_p > 0.f && ok) {                          // identical Bernoulli stream to dropout_mask_kernel (elementwise.hip)
+                unsigned long long z = drop_base + (unsigned long long)((long)m * g.N + n);
+                z += 0x9E3779B97F4A7C15ull;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                z ^= z >> 31;
+                const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+                x = u >= g.drop_p ? x * g.drop_scale : 0.f;
+              }
+              if (g.ref && ok) {
+                const float rv = g.ref_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.ref)[(long)m * g.ldr + n])
+                                            : ((const float*)g.ref)[(long)m * g.ldr + n];
+                x = rv > 0.f ? x * g.ref_scale : 0.f;
+              }
+            }
+            if (ok) vmax = fmaxf(vmax, fabsf(x));
+            v[t] = x;
+          }
+          const long o = (long)m * g.ldc + nb;
+          if (CP == 4) {
+            if (g.atomic && g.slab_stride <= 0) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) if (nb + t < g.N) atomicAdd((float*)g.C + o + t, v[t]);
+            } else {                                               // f32 rows (plain or K-split slab)
+              float* dst = (float*)g.C + o + (g.slab_stride > 0 ? (long)zsplit * g.slab_stride : 0);
+              if (full && vec_ok) *(f32x4*)dst = *(const f32x4*)&v[0];
+              else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (nb + t < g.N) dst[t] = v[t];
+              }
+            }
+          } else {                                                 // bf16 rows
+            unsigned short* dst = (unsigned short*)g.C + o;
+            if (full && vec_ok) {
+              u32x4 w;
+#pragma unroll
+              for (int t = 0; t < 4; ++t) w[t] = (unsigned)f32_to_bf16_bits(v[2 * t]) | ((unsigned)f32_to_bf16_bits(v[2 * t + 1]) << 16);
+              *(u32x4*)dst = w;
+            } else {
+#pragma unroll
+              for (int t = 0; t < CP; ++t) if (nb + t < g.N) dst[t] = f32_to_bf16_bits(v[t]);
+            }
+          }
+        }
+      };
+      const bool plain_ep = !g.bias && !g.relu && !g.drop && !(g.drop_p > 0.f) && !g.ref;
+      const bool bf16_rows = g.out_bf16 && g.slab_stride <= 0 && !g.atomic;
+      if (bf16_rows) { if (plain_ep) pieces(IntC<8>{}, IntC<1>{}); else pieces(IntC<8>{}, IntC<0>{}); }
+      else { if (plain_ep) pieces(IntC<4>{}, IntC<1>{}); else pieces(IntC<4>{}, IntC<0>{}); }
+    };
+    quarter(IntC<0>{}); quarter(IntC<1>{}); quarter(IntC<2>{}); quarter(IntC<3>{});
+  } else {
   // bf16 outputs go through LDS (the ring is free now): the accumulator layout gives a lane one 2-byte element per
   // store (64-byte segments); staged, every lane stores 16 contiguous bytes of one output row (8x fewer, full-line stores)
   const bool staged = g.staged_out;                          // host: bf16 out, plain store, N % 8 == 0, ldc % 8 == 0
@@ -488,6 +670,7 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
       if (m < g.M && n < g.N)
         *(u32x4*)((unsigned short*)g.C + (long)m * g.ldc + n) = *(const u32x4*)(stile + lrow * WTN + ch * 8);
     }
+  }
   }
   if (g.absmax) {
     vmax = wave_reduce_max(vmax);
@@ -598,6 +781,9 @@ int launch2(GemmArgs& g, int splitk, hipStream_t stream) {
   if (splitk > 1 && !g.atomic && g.slab_stride <= 0) return -2;
   g.staged_out = (g.out_bf16 && !g.atomic && g.slab_stride <= 0 && (g.N % 8) == 0 && (g.ldc % 8) == 0 &&
                   (((uintptr_t)g.C) & 15) == 0 && (long)NT / 64 * WTM * WTN * 2 <= (long)LDS) ? 1 : 0;
+  if (BM == 256 && BN == 256 && WTM == 128 && WTN == 64 && sizeof(T) == 2)      // ping-pong form: "16-byte row pieces are legal"
+    g.staged_out = ((((uintptr_t)g.C) & 15) == 0 && (g.ldc % (g.out_bf16 && g.slab_stride <= 0 ? 8 : 4)) == 0 &&
+                    (g.slab_stride % 4) == 0) ? 1 : 0;
   dim3 grid(splitk > 1 ? g.tiles_m * g.tiles_n : g.patches_m * patches_n * 64, 1, splitk), block(NT);
   // Persistent form for the one-workgroup-per-CU tile (256x256, 128 KiB LDS) when there is more than one round of tiles: one
   // workgroup per CU walks the tile list (same XCD: virtual id = resident id + k * CUs keeps id & 7) instead of being
@@ -635,7 +821,17 @@ int launch_auto(GemmArgs& g, int splitk, hipStream_t s) {
   const long sk = splitk < 1 ? 1 : splitk;
   auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * sk; };
   const bool big = (v && v[0] == '4') ? true : (v && v[0] == '8') ? false : (g.N > 128 && tiles(256, 256) >= 200);
-  if (big) return launch2<T, AMODE, BMODE, 256, 256, 2>(g, splitk, s);
+  if (big) {
+    static const char* pp = getenv("SW_GEMM_PP");             // development switch: "0" = the 16-wave loop
+    // ping-pong form (8 waves of 128x64, two staggered groups): forward / data-gradient shapes (A K-contiguous) run 4-6 % faster
+    // on it; the weight gradients (both operands transposed on the fly: twice the LDS instructions per fragment in the load
+    // segments) stay on the 16-wave loop, +1 % there.  SW_GEMM_PP=0 / =2: never / also for the weight gradients.
+    if constexpr (sizeof(T) == 2 && AMODE <= OP_KSTRIDED && BMODE <= OP_KSTRIDED) {
+      const bool want = pp ? (pp[0] == '2' || (pp[0] != '0' && AMODE == OP_KCONTIG)) : AMODE == OP_KCONTIG;
+      if (want && (g.K % 64) == 0 && sk == 1) return launch2<T, AMODE, BMODE, 256, 256, 2, 128, 64>(g, splitk, s);
+    }
+    return launch2<T, AMODE, BMODE, 256, 256, 2>(g, splitk, s);
+  }
   const bool narrow = (v && v[0] == '6') || (!v && g.N <= 64 && sk == 1);     // 64-wide outputs (conv1_x): no half-empty N tile
   if (narrow) return launch2<T, AMODE, BMODE, 256, 64, 2, 32, 64>(g, splitk, s);
   return launch2<T, AMODE, BMODE, 128, 128, 2, 32, 64>(g, splitk, s);
@@ -855,10 +1051,9 @@ namespace {
 // pieces (eight slabs in flight per iteration; a scalar one-slab-at-a-time loop was latency bound once the launches grew to
 // 14-28 slabs), folded, transposed through LDS and written as ONE contiguous run of 16-byte stores (the direct form
 // scattered 4-byte stores 36 bytes apart: 2.4 M write transactions per conv4 layer).  Requires (Cin / gridDim.y) % 4 == 0.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int Cout, int Cin, int nslab, const float* __restrict__ slabs,
-                                                           float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float s_t[];       // [9][CI]
-  const int co = blockIdx.x, CI = Cin / (int)gridDim.y, ci0 = blockIdx.y * CI;
+__device__ __forceinline__ void wgrad_reduce_body(int Cout, int Cin, int nslab, const float* __restrict__ slabs,
+                                                  float* __restrict__ out, int co, int parts, int part, float* s_t) {
+  const int CI = Cin / parts, ci0 = part * CI;
   const int cv = CI >> 2, nv = 9 * cv;                              // 16-byte pieces per tap / per workgroup
   const long slab_f = (long)Cout * 9 * Cin;
   const float* src = slabs + (long)co * 9 * Cin + ci0;
@@ -888,6 +1083,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int Cout, int Cin, in
     }
     dst[q] = o;
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int Cout, int Cin, int nslab, const float* __restrict__ slabs,
+                                                           float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_t[];       // [9][CI]
+  wgrad_reduce_body(Cout, Cin, nslab, slabs, out, blockIdx.x, (int)gridDim.y, blockIdx.y, s_t);
+}
+
+// every fold of a backward pass in ONE launch: workgroup -> (parameter, output channel, input-channel range)
+constexpr int FOLD_MAX = 32;
+struct FoldMulti {
+  int n;
+  int first_wg[FOLD_MAX + 1];
+  int Cin[FOLD_MAX], Cout[FOLD_MAX], nslab[FOLD_MAX], parts[FOLD_MAX];
+  const float* ws[FOLD_MAX];
+  float* out[FOLD_MAX];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(FoldMulti f) {
+  extern __shared__ __attribute__((aligned(16))) float s_t[];
+  int i = 0;
+  while (i + 1 < f.n && (int)blockIdx.x >= f.first_wg[i + 1]) ++i;
+  const int local = blockIdx.x - f.first_wg[i];
+  wgrad_reduce_body(f.Cout[i], f.Cin[i], f.nslab[i], f.ws[i], f.out[i], local / f.parts[i], f.parts[i], local % f.parts[i], s_t);
 }
 
 }  // namespace
@@ -996,6 +1214,31 @@ extern "C" int sw_conv3x3_wgrad_grouped(int dtype, int n_problems, const sw_wgra
       if (e != hipSuccess) return (int)e;
       hipLaunchKernelGGL(gemm2_grouped_kernel<float>, dim3(G), dim3(1024), LDS, stream, ga);
     }
+    SW_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int sw_conv3x3_wgrad_fold_multi(int n, const sw_wgrad_fold* folds, hipStream_t stream) {
+  SW_ENTER();
+  for (int base = 0; base < n; base += FOLD_MAX) {
+    FoldMulti f = {};
+    f.n = n - base < FOLD_MAX ? n - base : FOLD_MAX;
+    int wgs = 0;
+    size_t lds = 0;
+    for (int i = 0; i < f.n; ++i) {
+      const sw_wgrad_fold& q = folds[base + i];
+      if (q.nslab < 1 || (q.Cin % 4) || (size_t)36 * q.Cin > 65536 || (((uintptr_t)q.dw_oihw) & 15) || (((uintptr_t)q.workspace) & 15)) return -5;
+      int parts = 1;
+      while (q.Cout * parts < 1024 && (q.Cin % (parts * 2 * 4)) == 0 && q.Cin / (parts * 2) >= 32) parts *= 2;
+      f.Cin[i] = q.Cin; f.Cout[i] = q.Cout; f.nslab[i] = q.nslab; f.parts[i] = parts; f.ws[i] = q.workspace; f.out[i] = q.dw_oihw;
+      f.first_wg[i] = wgs;
+      wgs += q.Cout * parts;
+      const size_t need = (size_t)36 * q.Cin / parts;
+      lds = need > lds ? need : lds;
+    }
+    f.first_wg[f.n] = wgs;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)wgs), dim3(256), lds, stream, f);
     SW_CHECK_LAUNCH();
   }
   return 0;

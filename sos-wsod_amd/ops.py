@@ -191,6 +191,31 @@ def conv3x3_wgrad_fold(workspace, nslab, dw_oihw):
     return dw_oihw
 
 
+def conv3x3_wgrad_fold_multi(folds):
+    """folds: list of (workspace, nslab, dw_oihw): every weight-gradient fold of a backward pass in one launch"""
+    from ._lib import WgradFold
+    n = len(folds)
+    if n == 0:
+        return
+    arr = (WgradFold * n)()
+    for i, (ws, nslab, dw) in enumerate(folds):
+        arr[i].Cout, arr[i].Cin, arr[i].nslab = dw.shape[0], dw.shape[1], int(nslab)
+        arr[i].workspace, arr[i].dw_oihw = ws.data_ptr(), dw.data_ptr()
+    check(lib.sw_conv3x3_wgrad_fold_multi(n, arr, _stream()), "sw_conv3x3_wgrad_fold_multi")
+
+
+def colsum_fold_multi(folds):
+    """folds: list of (workspace, n_rows, out): every bias-gradient fold of a backward pass in one launch"""
+    from ._lib import ColsumFold
+    n = len(folds)
+    if n == 0:
+        return
+    arr = (ColsumFold * n)()
+    for i, (ws, rows, out) in enumerate(folds):
+        arr[i].N, arr[i].n_partial_rows, arr[i].workspace, arr[i].out = out.numel(), int(rows), ws.data_ptr(), out.data_ptr()
+    check(lib.sw_colsum_fold_multi(n, arr, _stream()), "sw_colsum_fold_multi")
+
+
 def colsum_nrows(X_dtype, M, N):
     """partial rows that colsum_partial writes for an M x N matrix"""
     return int(lib.sw_colsum_workspace_floats(dt(X_dtype), M, N)) // N
