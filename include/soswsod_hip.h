@@ -221,6 +221,10 @@ int sw_detect_postprocess(int R, int K, const float* all_scores, const float* al
                           sw_stream_t stream);
 
 /* ---- small utilities ------------------------------------------------------------------------------------ */
+/* dst[c][r] = src[r][c] (rows x cols elements of `dtype`, row pitches in elements, multiples of 16 bytes).  The weight-gradient
+ * GEMMs of the box head read dZ^T through it: with A K-contiguous they run the forward-style kernel (1.2-1.3 PFLOP/s) instead of
+ * transposing both operands on the fly inside LDS (1.0). */
+int sw_transpose_2d(int dtype, int rows, int cols, const void* src, long ld_src, void* dst, long ld_dst, sw_stream_t stream);
 /* *counter += increment, in stream order (one thread): the dropout stream position of sw_epilogue.drop_offset_dev */
 int sw_counter_add(uint64_t* counter, uint64_t increment, sw_stream_t stream);
 /* out[n] = sum_m X[m][ld..] (column sums; the bias gradients of the reference's conv / Linear backward).  out f32,

@@ -124,6 +124,7 @@ SIGNATURES = {
                                    c_void_p, c_long, c_void_p]),
     "sw_resize_pass_u8": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_void_p]),
+    "sw_transpose_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_counter_add": (c_int, [c_void_p, c_u64, c_void_p]),
     "sw_pack_views": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
                               c_void_p]),

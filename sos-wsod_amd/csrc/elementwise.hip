@@ -1120,6 +1120,50 @@ extern "C" int sw_resize_pass_u8(int C, int H, int W, int out_size, int horizont
   return 0;
 }
 
+namespace {
+// dst[c][r] = src[r][c] through a 64 x 64 LDS tile: both sides move 16-byte row pieces (>= 128-byte runs per row)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_2d_kernel(int rows, int cols, const T* __restrict__ src, long ld_src,
+                                                           T* __restrict__ dst, long ld_dst) {
+  constexpr int V = 16 / (int)sizeof(T);                 // elements per 16-byte piece
+  __shared__ T tile[64][64 + V];                         // [source column][source row], padded rows
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * (64 / V); i += 256) {
+    const int r = i / (64 / V), cv = (i % (64 / V)) * V;
+    T v[V];
+    if (r0 + r < rows && c0 + cv + V <= cols) *(u32x4*)v = *(const u32x4*)(src + (long)(r0 + r) * ld_src + c0 + cv);
+    else
+      for (int t = 0; t < V; ++t) v[t] = (r0 + r < rows && c0 + cv + t < cols) ? src[(long)(r0 + r) * ld_src + c0 + cv + t] : (T)0;
+#pragma unroll
+    for (int t = 0; t < V; ++t) tile[cv + t][r] = v[t];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * (64 / V); i += 256) {
+    const int c = i / (64 / V), rv = (i % (64 / V)) * V;
+    if (c0 + c >= cols) continue;
+    T* d = dst + (long)(c0 + c) * ld_dst + r0 + rv;
+    if (r0 + rv + V <= rows) *(u32x4*)d = *(const u32x4*)&tile[c][rv];
+    else
+      for (int t = 0; t < V; ++t) if (r0 + rv + t < rows) d[t] = tile[c][rv + t];
+  }
+}
+}  // namespace
+
+extern "C" int sw_transpose_2d(int dtype, int rows, int cols, const void* src, long ld_src, void* dst, long ld_dst,
+                               hipStream_t stream) {
+  SW_ENTER();
+  if (rows <= 0 || cols <= 0) return 0;
+  const int vec = dtype == SW_BF16 ? 8 : 4;
+  if ((ld_src % vec) || (ld_dst % vec) || (((uintptr_t)src) & 15) || (((uintptr_t)dst) & 15)) return -5;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(transpose_2d_kernel<unsigned short>, grid, dim3(256), 0, stream, rows, cols, (const unsigned short*)src, ld_src,
+                       (unsigned short*)dst, ld_dst),
+    hipLaunchKernelGGL(transpose_2d_kernel<float>, grid, dim3(256), 0, stream, rows, cols, (const float*)src, ld_src, (float*)dst, ld_dst));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
 namespace { __global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) { *c += inc; } }
 
 extern "C" int sw_counter_add(uint64_t* counter, uint64_t increment, hipStream_t stream) {

@@ -466,6 +466,13 @@ def resize_pass_u8(src, dst, bounds_i32, kk_i32, ksize, horizontal, dst_flip=Non
     return dst
 
 
+def transpose_2d(src, dst, rows, cols):
+    """dst[c][r] = src[r][c]; src (rows, cols), dst (cols, rows), same dtype, unit inner stride"""
+    _need_gpu(src, dst)
+    check(lib.sw_transpose_2d(dt(src), rows, cols, _p(src), src.stride(0), _p(dst), dst.stride(0), _stream()), "sw_transpose_2d")
+    return dst
+
+
 def counter_add(counter_u64, increment):
     """*counter += increment in stream order (the device-resident dropout stream position)"""
     check(lib.sw_counter_add(_p(counter_u64), int(increment), _stream()), "sw_counter_add")

@@ -479,14 +479,28 @@ class OICRPlusHeads(nn.Module):
         ops.gemm(dl, Wh, dz2, M, D2, LD, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h2, ref_scale=rs, out_dtype=dt_))
         # fc7
         db2 = torch.empty(D2, device=dev, dtype=torch.float32); ops.colsum(dz2, M, D2, db2)
+        # weight gradients read dZ^T (one 64x64-tiled transpose, 65 MB) so that the GEMM's A operand is K-contiguous: the
+        # forward-style kernel instead of transposing both operands on the fly inside LDS (fc6: 1.63 -> ~1.3 ms)
+        # (needs 16-byte K pieces: M a multiple of 8 bf16 / 4 f32 rows — else both operands stay K-strided)
+        epc = 8 if dt_ == torch.bfloat16 else 4
+        wgrad_nn = M % epc == 0
+
+        def dz_t(dz, D):
+            return ops.transpose_2d(dz, torch.empty(D, M + 8 * epc, device=dev, dtype=dt_)[:, :M], M, D)
         dW2 = torch.empty(D2, D1, device=dev, dtype=torch.float32)
-        ops.gemm(dz2, h1, dW2, D2, D1, M, a_kstrided=True, b_kstrided=True)
+        if wgrad_nn:
+            ops.gemm(dz_t(dz2, D2), h1, dW2, D2, D1, M, b_kstrided=True)
+        else:
+            ops.gemm(dz2, h1, dW2, D2, D1, M, a_kstrided=True, b_kstrided=True)
         dz1 = _padded(M, D1, dev, dt_)
         ops.gemm(dz2, W2, dz1, M, D1, D2, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h1, ref_scale=rs, out_dtype=dt_))
         # fc6
         db1 = torch.empty(D1, device=dev, dtype=torch.float32); ops.colsum(dz1, M, D1, db1)
         dW1 = torch.empty(D1, D0, device=dev, dtype=torch.float32)
-        ops.gemm(dz1, pooled, dW1, D1, D0, M, a_kstrided=True, b_kstrided=True, tag="fc6_wgrad")
+        if wgrad_nn:
+            ops.gemm(dz_t(dz1, D1), pooled, dW1, D1, D0, M, b_kstrided=True, tag="fc6_wgrad")
+        else:
+            ops.gemm(dz1, pooled, dW1, D1, D0, M, a_kstrided=True, b_kstrided=True, tag="fc6_wgrad")
         dfeats = [None] * len(feat_req)
         if any(feat_req):
             dpooled = _padded(M, D0, dev, dt_, pad=64)          # same pitch as argmax (one pitch per ROIPool call)

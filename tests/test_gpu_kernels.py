@@ -130,6 +130,19 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cin, cout, dil):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,cols", [(8000, 4096), (130, 72), (64, 64), (37, 200)])
+def test_transpose_2d(ops, dtype, rows, cols):
+    vec = 8 if dtype == torch.bfloat16 else 4
+    pr, pc = (rows + vec - 1) // vec * vec + vec, (cols + vec - 1) // vec * vec + vec          # padded pitches
+    src = torch.empty(rows, pc, dtype=dtype, device="cuda")[:, :cols]
+    src.copy_(_rand((rows, cols), 5, dtype))
+    dst = torch.full((cols, pr), 7.0, dtype=dtype, device="cuda")
+    ops.transpose_2d(src, dst[:, :rows], rows, cols)
+    assert torch.equal(dst[:, :rows], src.t())
+    assert (dst[:, rows:] == 7.0).all()                                     # nothing written past the row
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_conv3x3_wgrad_grouped_launch(ops, dtype):
     """all weight gradients of a backward pass in ONE launch (sw_conv3x3_wgrad_grouped): problems of different map sizes,
     channel counts, dilations and K-splits (two view batches share a parameter = consecutive slabs, one fold) against an fp64
