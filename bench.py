@@ -184,7 +184,7 @@ def main():
             trainer.run_step(batches[i % 2])
     for i in range(args.warmup):
         trainer.run_step(batches[i % 2])
-    tags = ["fc6_fwd", "fc6_dgrad", "fc6_wgrad", "plain5.conv3_fwd"]
+    tags = ["fc6_fwd", "fc6_dgrad", "fc6_wgrad", "plain5.conv3_fwd", "roi_fwd", "roi_bwd"]
     if graphs is None:
         ops.TIMER = ops.KernelTimer(tags)
     sync()
@@ -243,17 +243,30 @@ def main():
             ops.conv3x3(x5, wk5, o5, 2, ep5)
         e1.record(); torch.cuda.synchronize()
         conv_alone_ms = e0.elapsed_time(e1) / 20
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # filled from the committed rocprofv3 --pmc passes
+        # HBM bytes per call from the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh): (2*FETCH_SIZE + WRITE_SIZE)*1024
+        pmc = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_traffic.json", "pmc_traffic.json"))
+                    if os.path.exists(p)), None)
+        traffic = json.load(open(pmc)) if pmc else {}
         roofline = roof(dom)
-        if os.path.exists(pmc):
-            entry = json.load(open(pmc)).get(dom)                     # HBM bytes per launch: (2*FETCH_SIZE + WRITE_SIZE)*1024
-            roofline["traffic"] = entry["hbm_bytes_per_launch"] if entry else None
-            roofline["algorithmic_bytes"] = entry["algorithmic_bytes"] if entry else None
+        entry = traffic.get(dom)
+        roofline["traffic"] = entry["hbm_bytes_per_launch"] if entry else None
+        roofline["algorithmic_bytes"] = entry["algorithmic_bytes"] if entry else None
+        roofline["traffic_source"] = os.path.basename(pmc) if pmc else None
+
+        def roof_hbm(tag, alg_bytes, what):
+            a = alg_bytes / (avg_ms[tag] * 1e-3) / 1e9
+            ent = traffic.get(tag) or {}
+            return {"kernel": what, "bound": "hbm", "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(a / 8000.0, 4),
+                    "traffic": ent.get("hbm_bytes_per_launch"), "algorithmic_bytes": alg_bytes, "avg_ms": round(avg_ms[tag], 4)}
+        es = 2 if dtype == torch.bfloat16 else 4
+        fmap = 2 * 63 * 63 * 512 * es                                  # the 2-image feature map of one scale
+        roi_rows = 2 * R                                               # one call = view + flipped view of one scale
         # counter-based MFMA utilisation of the same kernels run alone (tools/pmc_mfma.sh, committed under profiles/):
         # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32).  The FLOP-based `frac` prices against the 2.4 GHz peak;
         # under MFMA load the chip runs 1.6-2.0 GHz (DVFS), so the pipe is busier than `frac` says.
-        busy_path = os.path.join(ROOT, "profiles", "r01_mfma_busy.json")
-        busy = json.load(open(busy_path)) if os.path.exists(busy_path) else {}
+        busy_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_mfma_busy.json", "r01_mfma_busy.json"))
+                          if os.path.exists(p)), None)
+        busy = json.load(open(busy_path)) if busy_path else {}
 
         def busy_of(shape):
             ent = busy.get(shape) or {}
@@ -261,7 +274,7 @@ def main():
                 return None
             k = max(ent, key=lambda n: ent[n]["SQ_VALU_MFMA_BUSY_CYCLES"])       # the main launch (not a split-K tail)
             return {"mfma_busy_frac": ent[k]["mfma_busy_frac"], "effective_clock_GHz": ent[k]["effective_clock_GHz"],
-                    "source": "profiles/r01_mfma_busy.json (rocprofv3 --pmc, kernel alone)"}
+                    "source": f"profiles/{os.path.basename(busy_path)} (rocprofv3 --pmc, kernel alone)"}
         roofline["mfma_busy_counter"] = busy_of(dom)
         out = {
             "metric": "images/s (1/2/4/8 MI355X) VGG16+OICR 2000-prop; conv5_3 MFMA-util %",
@@ -283,6 +296,10 @@ def main():
                                        "peak": peak, "unit": "TFLOP/s",
                                        "frac": round(flops["plain5.conv3_fwd"] / (conv_alone_ms * 1e-3) / 1e12 / peak, 4),
                                        "avg_ms": round(conv_alone_ms, 4), "mfma_busy_counter": busy_of("conv5_3")},
+            # ROIPool (HBM-bound: the pooled rows + argmax dominate the bytes): one call = 2 x R ROIs on one scale's 2-image map
+            "roofline_roipool": {
+                "fwd": roof_hbm("roi_fwd", roi_rows * 25088 * (es + 2) + fmap, f"roi_pool_fwd: {roi_rows} ROIs x 512 x 7 x 7, values + u16 argmax written"),
+                "bwd": roof_hbm("roi_bwd", roi_rows * 25088 * (es + 2) + 2 * fmap, f"roi_pool_bwd: {roi_rows} ROIs, gradients + argmax read, map written")},
             "kernel_ms_per_step": {t: round(v, 3) for t, v in tot_ms.items()},
             # whole step as ONE captured hipGraph (forward + backward + SGD; ms_per_step above) vs the same step issued launch by
             # launch from Python (what DDP runs use); per-kernel figures come from the eager steps

@@ -225,6 +225,19 @@ int sw_detect_postprocess(int R, int K, const float* all_scores, const float* al
  * GEMMs of the box head read dZ^T through it: with A K-contiguous they run the forward-style kernel (1.2-1.3 PFLOP/s) instead of
  * transposing both operands on the fly inside LDS (1.0). */
 int sw_transpose_2d(int dtype, int rows, int cols, const void* src, long ld_src, void* dst, long ld_dst, sw_stream_t stream);
+/* ---- Stage-3 (Unbiased-Teacher semi-supervised step, unbias/ubteacher/engine/trainer.py:436-604) building blocks ------------
+ * sw_ema_multi: teacher[i] = student[i] * (1 - keep_rate) + teacher[i] * keep_rate for n_tensors f32 tensors in as few
+ * launches as 48-tensor batches allow (_update_teacher_model :588-604; keep_rate 0 = the copy at the end of burn-in).
+ * teacher / student / numel are HOST arrays (of device pointers / element counts). */
+int sw_ema_multi(int n_tensors, float* const* teacher, const float* const* student, const long* numel, float keep_rate,
+                 sw_stream_t stream);
+/* sw_threshold_select: pseudo-label thresholding (threshold_bbox :361-400): keeps detection i iff scores[i] > thres (and, when
+ * allowed_classes != NULL, classes[i] is one of the n_allowed image-level labels: the "multi_label" filter), compacted in input
+ * order.  out_count[1]; out_boxes [n][4], out_classes [n] (optional: the "rpn" branch has none), out_scores [n], out_index [n]
+ * (optional: source positions).  One workgroup; n is a few hundred teacher detections per image. */
+int sw_threshold_select(int n, const float* scores, const int32_t* classes, const float* boxes, float thres,
+                        const int32_t* allowed_classes, int n_allowed, int32_t* out_count, float* out_boxes,
+                        int32_t* out_classes, float* out_scores, int32_t* out_index, sw_stream_t stream);
 /* *counter += increment, in stream order (one thread): the dropout stream position of sw_epilogue.drop_offset_dev */
 int sw_counter_add(uint64_t* counter, uint64_t increment, sw_stream_t stream);
 /* out[n] = sum_m X[m][ld..] (column sums; the bias gradients of the reference's conv / Linear backward).  out f32,

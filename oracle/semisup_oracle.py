@@ -1,0 +1,60 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+CPU restatement of the model-independent parts of the Stage-3 Unbiased-Teacher step (BASELINE config #5):
+  /root/reference/unbias/ubteacher/engine/trainer.py
+    :361-400  threshold_bbox            (score / objectness > threshold, optional multi-label class filter)
+    :436-549  run_step_full_semisup     (burn-in, teacher refresh schedule, loss weighting: *_pseudo box losses x 0, other
+                                         *_pseudo losses x UNSUP_LOSS_WEIGHT, supervised x 1)
+    :588-604  _update_teacher_model     (teacher = student * (1 - keep) + teacher * keep, float32)
+
+PARITY PINNING: parity unpinned — the reference file imports the whole detectron2 engine / data stack (absent here: fvcore,
+yacs, …), so no fixture could be generated from it; these few lines are restated from the source text cited above and the
+reference's tests hold no vectors for them.
+"""
+import numpy as np
+
+
+def threshold_bbox(scores, classes, boxes, thres=0.7, multi_label=None):
+    """:361-400 ('roih' branch; 'rpn' = classes None).  Returns (boxes, classes, scores, kept index) in input order."""
+    scores = np.asarray(scores, np.float32)
+    valid = scores > np.float32(thres)
+    if multi_label is not None and classes is not None:
+        ml = set(int(c) for c in multi_label)
+        valid &= np.array([int(c) in ml for c in classes], bool)
+    idx = np.nonzero(valid)[0]
+    return np.asarray(boxes, np.float32)[idx], (None if classes is None else np.asarray(classes)[idx]), scores[idx], idx
+
+
+def update_teacher(teacher: dict, student: dict, keep_rate: float) -> dict:
+    """:588-604 in float32: value = student * (1 - keep) + teacher * keep (python-float scalars times f32 tensors, as torch does)"""
+    out = {}
+    for k, v in teacher.items():
+        if k not in student:
+            raise Exception("{} is not found in student model".format(k))
+        out[k] = (student[k].astype(np.float32) * np.float32(1 - keep_rate) + v.astype(np.float32) * np.float32(keep_rate)).astype(np.float32)
+    return out
+
+
+def weight_losses(record: dict, unsup_weight: float) -> dict:
+    """:520-534"""
+    out = {}
+    for key, v in record.items():
+        if key[:4] == "loss":
+            if key == "loss_rpn_loc_pseudo" or key == "loss_box_reg_pseudo":
+                out[key] = v * 0
+            elif key[-6:] == "pseudo":
+                out[key] = v * unsup_weight
+            else:
+                out[key] = v * 1
+    return out
+
+
+def teacher_action(it: int, burn_up_step: int, update_iter: int):
+    """:455-466 -> 'burn_in' (supervised only), 'copy' (keep_rate 0), 'ema', or 'none'"""
+    if it < burn_up_step:
+        return "burn_in"
+    if it == burn_up_step and burn_up_step > 0:
+        return "copy"
+    if (it - burn_up_step) % update_iter == 0:
+        return "ema"
+    return "none"

@@ -1164,6 +1164,105 @@ extern "C" int sw_transpose_2d(int dtype, int rows, int cols, const void* src, l
   return 0;
 }
 
+// ---------------------------------------------------------------- Stage-3 (Unbiased Teacher) step pieces
+namespace {
+constexpr int EMA_MAX = 48;
+struct EmaBatch {
+  float* teacher[EMA_MAX];
+  const float* student[EMA_MAX];
+  long n[EMA_MAX];
+  int block_start[EMA_MAX + 1];
+  int count;
+};
+// teacher = student * (1 - keep) + teacher * keep  (ubteacher/engine/trainer.py:588-604 _update_teacher_model), the products and
+// the sum rounded as torch rounds them (two multiplies, one add: no fused multiply-add)
+__global__ __launch_bounds__(256) void ema_multi_kernel(EmaBatch b, float keep, float one_minus_keep) {
+  int t = 0;
+  while (t + 1 < b.count && (int)blockIdx.x >= b.block_start[t + 1]) ++t;
+  const long base = (long)(blockIdx.x - b.block_start[t]) * 4096;
+  float* te = b.teacher[t];
+  const float* st = b.student[t];
+  const long n = b.n[t];
+  for (long i = base + threadIdx.x; i < base + 4096 && i < n; i += 256)
+    te[i] = __fadd_rn(__fmul_rn(st[i], one_minus_keep), __fmul_rn(te[i], keep));
+}
+
+// keep[i] = score[i] > thres (and class[i] in the image's label set when given); stable compaction in input order by one
+// workgroup (the teacher emits <= a few hundred detections per image)  (trainer.py:361-400 threshold_bbox)
+__global__ __launch_bounds__(1024) void threshold_select_kernel(int n, const float* __restrict__ scores, const int* __restrict__ classes,
+                                                                const float* __restrict__ boxes, float thres,
+                                                                const int* __restrict__ allowed, int n_allowed,
+                                                                int* __restrict__ out_count, float* __restrict__ out_boxes,
+                                                                int* __restrict__ out_classes, float* __restrict__ out_scores,
+                                                                int* __restrict__ out_index) {
+  __shared__ int s_scan[1024];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    bool ok = i < n && scores[i] > thres;
+    if (ok && allowed) {
+      bool in = false;
+      for (int a = 0; a < n_allowed; ++a) in = in || (allowed[a] == classes[i]);
+      ok = in;
+    }
+    s_scan[threadIdx.x] = ok ? 1 : 0;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int add = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_scan[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (ok) {
+      const int o = s_base + s_scan[threadIdx.x] - 1;
+      out_boxes[4 * o + 0] = boxes[4 * i + 0]; out_boxes[4 * o + 1] = boxes[4 * i + 1];
+      out_boxes[4 * o + 2] = boxes[4 * i + 2]; out_boxes[4 * o + 3] = boxes[4 * i + 3];
+      if (out_classes && classes) out_classes[o] = classes[i];
+      out_scores[o] = scores[i];
+      if (out_index) out_index[o] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += s_scan[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_count[0] = s_base;
+}
+}  // namespace
+
+extern "C" int sw_ema_multi(int n_tensors, float* const* teacher, const float* const* student, const long* numel, float keep_rate,
+                            hipStream_t stream) {
+  SW_ENTER();
+  for (int t0 = 0; t0 < n_tensors; t0 += EMA_MAX) {
+    EmaBatch b = {};
+    int blocks = 0;
+    for (int i = t0; i < n_tensors && i < t0 + EMA_MAX; ++i) {
+      if (numel[i] <= 0) continue;
+      b.teacher[b.count] = teacher[i]; b.student[b.count] = student[i]; b.n[b.count] = numel[i];
+      b.block_start[b.count] = blocks;
+      blocks += (int)((numel[i] + 4095) / 4096);
+      ++b.count;
+    }
+    b.block_start[b.count] = blocks;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(ema_multi_kernel, dim3(blocks), dim3(256), 0, stream, b, keep_rate, 1.0f - keep_rate);
+    SW_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int sw_threshold_select(int n, const float* scores, const int32_t* classes, const float* boxes, float thres,
+                                   const int32_t* allowed_classes, int n_allowed, int32_t* out_count, float* out_boxes,
+                                   int32_t* out_classes, float* out_scores, int32_t* out_index, hipStream_t stream) {
+  SW_ENTER();
+  if (n < 0) return -5;
+  hipLaunchKernelGGL(threshold_select_kernel, dim3(1), dim3(1024), 0, stream, n, scores, classes, boxes, thres, allowed_classes,
+                     n_allowed, out_count, out_boxes, out_classes, out_scores, out_index);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
 namespace { __global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) { *c += inc; } }
 
 extern "C" int sw_counter_add(uint64_t* counter, uint64_t increment, hipStream_t stream) {

@@ -2,6 +2,7 @@
 (uwsod/projects/WSL/wsl/modeling/roi_heads/fast_rcnn_oicr.py:408-528: `cls_score` Linear(4096->K+1) N(0,0.01),
 `bbox_pred` Linear(4096->4K) N(0,0.001), zero bias).  Losses (:157-352) are the fused kernel
 sw_oicr_refine_loss; inference utilities (:46-148, :674-735) live in OICRPlusHeads._forward_box_test."""
+import torch
 import torch.nn as nn
 
 from .box_head import _Linear
@@ -18,6 +19,7 @@ class OICROutputLayers(nn.Module):
         refine_reg = refine_reg if refine_reg is not None else [True] * (refine_k + 1)
         assert refine_reg[refine_k], "WSL.REFINE_REG all True on this path"
         self.num_classes, self.refine_k = num_classes, refine_k
+        self.bbox_reg_weights = tuple(getattr(box2box_transform, "weights", (10.0, 10.0, 5.0, 5.0)))     # defaults.py:296
         self.cls_score = _Linear(d, num_classes + 1)
         self.bbox_pred = _Linear(d, 4 * num_classes)
         nn.init.normal_(self.cls_score.weight, std=0.01)      # fast_rcnn_oicr.py:474-478
@@ -28,6 +30,29 @@ class OICROutputLayers(nn.Module):
         if isinstance(loss_weight, float):
             loss_weight = {"loss_cls": loss_weight, "loss_box_reg": loss_weight}
         self.loss_weight = loss_weight
+
+    # ---- stand-alone call API (predictor_api.py); OICRPlusHeads' training path runs the same kernels fused over all views
+    compute_dtype = torch.float32
+
+    def forward(self, x):
+        """fast_rcnn_oicr.py:504-528 -> (scores (N, K+1), proposal_deltas (N, 4K))"""
+        from .predictor_api import oicr_forward
+        return oicr_forward(self, x, self.compute_dtype)
+
+    def losses(self, predictions, proposals):
+        """fast_rcnn_oicr.py:530-554 -> {"loss_cls", "loss_box_reg"}; proposals: proposal_boxes, gt_boxes, gt_classes, gt_weights"""
+        from .predictor_api import oicr_losses
+        return oicr_losses(self, predictions, proposals)
+
+    def predict_probs(self, predictions, proposals):
+        """fast_rcnn_oicr.py:702-716"""
+        from .predictor_api import oicr_predict_probs
+        return oicr_predict_probs(self, predictions, proposals)
+
+    def inference(self, predictions, proposals):
+        """fast_rcnn_oicr.py:584-614"""
+        from .predictor_api import oicr_inference
+        return oicr_inference(self, predictions, proposals)
 
     @classmethod
     def from_config(cls, cfg, input_shape, k):

@@ -26,6 +26,25 @@ class WSDDNOutputLayers(nn.Module):
             loss_weight = {"loss_cls": loss_weight, "loss_box_reg": loss_weight}
         self.loss_weight = loss_weight
 
+    # ---- stand-alone call API (predictor_api.py); OICRPlusHeads' training path runs the same kernels fused over all views
+    compute_dtype = torch.float32
+
+    def forward(self, x, proposals=None, context=False):
+        """fast_rcnn_wsddn.py:542-589 -> (scores (N, K), zero proposal_deltas (N, 4K))"""
+        assert not context, "contextlocnet is not on the OICR+ path"
+        from .predictor_api import wsddn_forward
+        return wsddn_forward(self, x, proposals, self.compute_dtype)
+
+    def losses(self, predictions, proposals, gt_classes_img_oh):
+        """fast_rcnn_wsddn.py:658-681 -> {"loss_cls": ...}"""
+        from .predictor_api import wsddn_losses
+        return wsddn_losses(self, predictions, proposals, gt_classes_img_oh)
+
+    def predict_probs(self, predictions, proposals):
+        """fast_rcnn_wsddn.py:683-697: the scores, split per image"""
+        scores, _ = predictions
+        return scores.split([len(p) for p in proposals], dim=0)
+
     @classmethod
     def from_config(cls, cfg, input_shape):
         return dict(input_shape=input_shape, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES,

@@ -260,15 +260,15 @@ def preprocess(img_u8_chw, out_hwc, mean, std):
     return out_hwc
 
 
-def roi_pool_fwd(feat, rois, out, argmax, spatial_scale, PH, PW, row_scale=None, row_scale_add=0.0):
+def roi_pool_fwd(feat, rois, out, argmax, spatial_scale, PH, PW, row_scale=None, row_scale_add=0.0, tag=None):
     """feat [n][H][W][C], rois [R][5] f32, out [R][C*PH*PW]; argmax same shape, int32 (h*W+w or -1) or int16/uint16
     storage holding uint16 (h*W+w or 0xFFFF; see argmax_to_int32)"""
     _need_gpu(feat, rois, out, argmax)
     n, H, W, C = feat.shape
     R = rois.shape[0]
-    check(lib.sw_roi_pool_fwd(dt(feat), n, H, W, C, PH, PW, float(spatial_scale), _p(feat), _p(rois), R, _p(row_scale),
-                              float(row_scale_add), _p(out), _p(argmax), _argmax_bits(argmax), _roi_pitch(out, argmax),
-                              _stream()), "sw_roi_pool_fwd")
+    check(_launch(tag, lambda: lib.sw_roi_pool_fwd(dt(feat), n, H, W, C, PH, PW, float(spatial_scale), _p(feat), _p(rois), R,
+                                                   _p(row_scale), float(row_scale_add), _p(out), _p(argmax), _argmax_bits(argmax),
+                                                   _roi_pitch(out, argmax), _stream())), "sw_roi_pool_fwd")
     return out, argmax
 
 
@@ -306,7 +306,8 @@ def absmax(x, out=None):
     return out
 
 
-def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_add=0.0, relu_ref=None, dout_absmax="auto"):
+def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_add=0.0, relu_ref=None, dout_absmax="auto",
+                 tag=None):
     """dout_absmax: device scalar >= max|dout| (selects the fixed-point accumulation), "auto" = compute it here,
     None = LDS float atomics."""
     _need_gpu(dout, argmax, rois, dfeat)
@@ -314,9 +315,9 @@ def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_ad
     R = rois.shape[0]
     if isinstance(dout_absmax, str):
         dout_absmax = absmax(dout)
-    check(lib.sw_roi_pool_bwd(dt(dfeat), n, H, W, C, PH, PW, _p(dout), _p(argmax), _argmax_bits(argmax), _roi_pitch(dout, argmax),
-                              _p(rois), R, _p(row_scale),
-                              float(row_scale_add), _p(relu_ref), _p(dout_absmax), _p(dfeat), _stream()), "sw_roi_pool_bwd")
+    check(_launch(tag, lambda: lib.sw_roi_pool_bwd(dt(dfeat), n, H, W, C, PH, PW, _p(dout), _p(argmax), _argmax_bits(argmax),
+                                                   _roi_pitch(dout, argmax), _p(rois), R, _p(row_scale), float(row_scale_add),
+                                                   _p(relu_ref), _p(dout_absmax), _p(dfeat), _stream())), "sw_roi_pool_bwd")
     return dfeat
 
 
@@ -471,6 +472,38 @@ def transpose_2d(src, dst, rows, cols):
     _need_gpu(src, dst)
     check(lib.sw_transpose_2d(dt(src), rows, cols, _p(src), src.stride(0), _p(dst), dst.stride(0), _stream()), "sw_transpose_2d")
     return dst
+
+
+def ema_multi(teacher, student, keep_rate):
+    """teacher[i] <- student[i] * (1 - keep_rate) + teacher[i] * keep_rate over lists of contiguous f32 tensors (sw_ema_multi)"""
+    n = len(teacher)
+    assert n == len(student)
+    if n == 0:
+        return
+    for t, s_ in zip(teacher, student):
+        _need_gpu(t, s_)
+        if t.dtype != torch.float32 or s_.dtype != torch.float32 or not t.is_contiguous() or not s_.is_contiguous() or t.numel() != s_.numel():
+            raise TypeError("ema_multi takes matching contiguous float32 tensors")
+    tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in teacher])
+    sp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in student])
+    ne = (ctypes.c_long * n)(*[t.numel() for t in teacher])
+    check(lib.sw_ema_multi(n, tp, sp, ne, float(keep_rate), _stream()), "sw_ema_multi")
+
+
+def threshold_select(scores, classes, boxes, thres, allowed=None):
+    """-> (count[1] i32, boxes [n,4], classes [n] i32 or None, scores [n], index [n] i32): entries with score > thres (and class in
+    `allowed`, an int32 device tensor, when given), compacted in input order; the first count rows are valid"""
+    _need_gpu(scores, boxes)
+    n = scores.shape[0]
+    dev = scores.device
+    cnt = torch.empty(1, device=dev, dtype=torch.int32)
+    ob = torch.empty(max(n, 1), 4, device=dev); osc = torch.empty(max(n, 1), device=dev)
+    oc = torch.empty(max(n, 1), device=dev, dtype=torch.int32) if classes is not None else None
+    oi = torch.empty(max(n, 1), device=dev, dtype=torch.int32)
+    check(lib.sw_threshold_select(n, _p(scores), _p(classes), _p(boxes), float(thres), _p(allowed),
+                                  0 if allowed is None else allowed.numel(), _p(cnt), _p(ob), _p(oc), _p(osc), _p(oi), _stream()),
+          "sw_threshold_select")
+    return cnt, ob, oc, osc, oi
 
 
 def counter_add(counter_u64, increment):

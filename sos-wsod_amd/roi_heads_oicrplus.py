@@ -361,7 +361,7 @@ class OICRPlusHeads(nn.Module):
                 r0 = off + 2 * s * R
                 ops.roi_pool_fwd(feats[2 * b + s], inp["rois"][b][s], pooled[r0:r0 + 2 * R], argmax[r0:r0 + 2 * R],
                                  self.box_pooler.scale, P, P, row_scale=inp["obj"][b][2 * s:2 * s + 2].reshape(-1),
-                                 row_scale_add=1.0)
+                                 row_scale_add=1.0, tag="roi_fwd")
         # --- fc6 / fc7 with bias + ReLU + dropout fused (box_head.py:82-91)
         fc1w, fc1b, fc2w, fc2b = params[0], params[1], params[2], params[3]
         D1, D2 = fc1w.shape[0], fc2w.shape[0]
@@ -522,7 +522,7 @@ class OICRPlusHeads(nn.Module):
                     r0 = off + 2 * s * R
                     ops.roi_pool_bwd(dpooled[r0:r0 + 2 * R], st["argmax"][r0:r0 + 2 * R], inp["rois"][b][s], df, P, P,
                                      row_scale=inp["obj"][b][2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0, relu_ref=f,
-                                     dout_absmax=amax)
+                                     dout_absmax=amax, tag="roi_bwd")
                     dfeats[2 * b + s] = df
         # split the packed gradients back onto the 10 predictor tensors (row slices are contiguous views)
         dparams = [dW1, db1, dW2, db2]

@@ -1,0 +1,129 @@
+"""Stage-3 (Unbiased-Teacher semi-supervised) training step — the model-independent half (BASELINE config #5;
+reference unbias/ubteacher/engine/trainer.py:436-549 `run_step_full_semisup`, :361-434 pseudo-labelling, :588-604 teacher EMA).
+
+What is here: the step's control flow behind the reference's interface (`model(data, branch=...) -> (record_dict, proposals_rpn,
+proposals_roih, _)` for student and teacher), the teacher refresh as ONE multi-tensor HIP launch per 48 parameters
+(`sw_ema_multi`), pseudo-label thresholding as a device-side stable compaction (`sw_threshold_select`: no `.nonzero()` host
+sync per image), and the loss weighting.  What is NOT here yet: the ResNet-50-FPN Faster-RCNN the reference plugs in as
+student / teacher — the step takes any module with that call signature.  Parity of this half is restatement-only
+(oracle/semisup_oracle.py explains why no fixture could be generated)."""
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .structures import Boxes, Instances
+
+
+@torch.no_grad()
+def update_teacher_model(student: torch.nn.Module, teacher: torch.nn.Module, keep_rate: float = 0.996):
+    """trainer.py:588-604.  Every float32 entry of the state dicts in one fused pass; other dtypes (integer buffers such as
+    BatchNorm's num_batches_tracked, which the reference blends in floating point and load_state_dict casts back) are blended
+    the reference's way with torch ops."""
+    if isinstance(student, torch.nn.parallel.DistributedDataParallel):
+        student = student.module
+    sd_s, sd_t = student.state_dict(), teacher.state_dict()
+    fused_t, fused_s = [], []
+    for k, v in sd_t.items():
+        if k not in sd_s:
+            raise Exception("{} is not found in student model".format(k))
+        s = sd_s[k]
+        if v.is_cuda and v.dtype == torch.float32 and s.dtype == torch.float32 and v.is_contiguous() and s.is_contiguous():
+            fused_t.append(v); fused_s.append(s)
+        else:
+            v.copy_(s * (1 - keep_rate) + v * keep_rate)
+    ops.ema_multi(fused_t, fused_s, keep_rate)
+
+
+def threshold_bbox(data_inst: Optional[dict], proposals: Instances, thres: float = 0.7, proposal_type: str = "roih",
+                   has_multi_label: bool = False) -> Instances:
+    """trainer.py:361-400.  Returns Instances with `gt_boxes` (+ `gt_classes`, `scores` | `objectness_logits`); the kept count is
+    read back once per image (the reference's boolean indexing syncs too) to size the result."""
+    out = Instances(proposals.image_size)
+    if proposal_type == "rpn":
+        cnt, b, _, sc, _ = ops.threshold_select(proposals.objectness_logits.float().contiguous(), None,
+                                                proposals.proposal_boxes.tensor.float().contiguous(), thres)
+        n = int(cnt.item())
+        out.gt_boxes = Boxes(b[:n]); out.objectness_logits = sc[:n]
+    elif proposal_type == "roih":
+        allowed = None
+        if has_multi_label:
+            allowed = torch.as_tensor(data_inst["multi_label"], dtype=torch.int32).to(proposals.scores.device)
+        cnt, b, c, sc, _ = ops.threshold_select(proposals.scores.float().contiguous(), proposals.pred_classes.to(torch.int32).contiguous(),
+                                                proposals.pred_boxes.tensor.float().contiguous(), thres, allowed)
+        n = int(cnt.item())
+        out.gt_boxes = Boxes(b[:n]); out.gt_classes = c[:n].to(torch.int64); out.scores = sc[:n]
+    else:
+        raise ValueError("Unkown pseudo label boxes methods")
+    return out
+
+
+def process_pseudo_label(unlabel_data, proposals, cur_threshold, proposal_type, method="thresholding", has_multi_label=False):
+    """trainer.py:402-420"""
+    if method != "thresholding":
+        raise ValueError("Unkown pseudo label boxes methods")
+    insts, total = [], 0.0
+    for d, p in zip(unlabel_data, proposals):
+        inst = threshold_bbox(d, p, cur_threshold, proposal_type, has_multi_label)
+        total += len(inst)
+        insts.append(inst)
+    return insts, total / max(len(proposals), 1)
+
+
+def weight_losses(record: Dict[str, torch.Tensor], unsup_loss_weight: float) -> Dict[str, torch.Tensor]:
+    """trainer.py:520-534: pseudo box-regression losses x 0, other *_pseudo losses x UNSUP_LOSS_WEIGHT, supervised x 1"""
+    out = {}
+    for key, v in record.items():
+        if key[:4] == "loss":
+            if key in ("loss_rpn_loc_pseudo", "loss_box_reg_pseudo"):
+                out[key] = v * 0
+            elif key[-6:] == "pseudo":
+                out[key] = v * unsup_loss_weight
+            else:
+                out[key] = v * 1
+    return out
+
+
+class SemiSupStep:
+    """`run_step_full_semisup` (trainer.py:436-549) over any student / teacher pair with the reference's branch interface."""
+
+    def __init__(self, model, model_teacher, optimizer, *, burn_up_step, teacher_update_iter=1, ema_keep_rate=0.9996,
+                 bbox_threshold=0.7, unsup_loss_weight=4.0, burn_up_with_strong_aug=True, has_multi_label=False):
+        self.model, self.model_teacher, self.optimizer = model, model_teacher, optimizer
+        self.burn_up_step, self.teacher_update_iter, self.ema_keep_rate = burn_up_step, teacher_update_iter, ema_keep_rate
+        self.bbox_threshold, self.unsup_loss_weight = bbox_threshold, unsup_loss_weight
+        self.burn_up_with_strong_aug, self.has_multi_label = burn_up_with_strong_aug, has_multi_label
+        self.iter = 0
+
+    def run_step(self, data):
+        label_q, label_k, unlabel_q, unlabel_k = data
+        if self.iter < self.burn_up_step:
+            batch = list(label_q) + list(label_k) if self.burn_up_with_strong_aug else label_k
+            record, _, _, _ = self.model(batch, branch="supervised")
+            loss_dict = {k: v * 1 for k, v in record.items() if k[:4] == "loss"}
+        else:
+            if self.iter == self.burn_up_step and self.burn_up_step > 0:
+                update_teacher_model(self.model, self.model_teacher, keep_rate=0.00)
+            elif (self.iter - self.burn_up_step) % self.teacher_update_iter == 0:
+                update_teacher_model(self.model, self.model_teacher, keep_rate=self.ema_keep_rate)
+            record = {}
+            with torch.no_grad():
+                _, props_rpn, props_roih, _ = self.model_teacher(unlabel_k, branch="unsup_data_weak")
+            process_pseudo_label(unlabel_k, props_rpn, self.bbox_threshold, "rpn")                 # :490-494 (joint dict, unused after)
+            pseudo_roih, _ = process_pseudo_label(unlabel_k, props_roih, self.bbox_threshold, "roih",
+                                                  has_multi_label=self.has_multi_label)
+            for d in list(unlabel_q) + list(unlabel_k):                                               # remove_label
+                d.pop("instances", None)
+            for dq, dk, lab in zip(unlabel_q, unlabel_k, pseudo_roih):                                # add_label
+                dq["instances"] = lab; dk["instances"] = lab
+            rec_label, _, _, _ = self.model(list(label_q) + list(label_k), branch="supervised")
+            record.update(rec_label)
+            rec_unlabel, _, _, _ = self.model(unlabel_q, branch="supervised")
+            record.update({k + "_pseudo": v for k, v in rec_unlabel.items()})
+            loss_dict = weight_losses(record, self.unsup_loss_weight)
+        losses = sum(loss_dict.values())
+        self.optimizer.zero_grad()
+        losses.backward()
+        self.optimizer.step()
+        self.iter += 1
+        return record, loss_dict

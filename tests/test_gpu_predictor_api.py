@@ -1,0 +1,104 @@
+"""GPU: the predictor modules' own call API (forward / losses / predict_probs / inference of WSDDNOutputLayers and
+OICROutputLayers, fast_rcnn_wsddn.py:542-589,658-681; fast_rcnn_oicr.py:504-614,702-716) against the oracle's torch-CPU
+restatement of the same functions: outputs, losses and the gradients that reach the weights and the input features."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oicr_oracle as O  # noqa: E402  (checker only)
+
+
+def _rel(a, b):
+    """max error relative to the reference's largest element; + 1e-7 absolute: d/d(det.bias) is analytically 0 (the softmax over
+    proposals is shift invariant), both sides hold rounding noise there"""
+    return float(((a - b).abs().max() - 1e-7).clamp(min=0) / (b.abs().max() + 1e-30))
+
+
+def test_wsddn_layer_forward_losses_and_gradients():
+    from sos_wsod_amd.fast_rcnn_wsddn import WSDDNOutputLayers
+    from sos_wsod_amd.structures import Boxes, Instances
+    torch.manual_seed(0)
+    K, D, sizes = 20, 256, [70, 45]
+    layer = WSDDNOutputLayers(D, num_classes=K).cuda()
+    with torch.no_grad():
+        layer.cls.weight.mul_(8); layer.det.weight.mul_(8); layer.cls.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(sum(sizes), D, device="cuda", requires_grad=True)
+    props = []
+    for n in sizes:
+        p = Instances((100, 100)); p.proposal_boxes = Boxes(torch.rand(n, 4).cuda()); props.append(p)
+    oh = torch.zeros(2, K, device="cuda"); oh[0, [2, 7]] = 1; oh[1, 11] = 1
+    scores, deltas = layer(x, props)
+    assert tuple(scores.shape) == (115, K) and tuple(deltas.shape) == (115, 4 * K) and float(deltas.abs().max()) == 0
+    losses = layer.losses((scores, deltas), props, oh)
+    losses["loss_cls"].backward()
+    # oracle: the same arithmetic on the CPU (fast_rcnn_wsddn.py:556-567, 340-375)
+    xc = x.detach().cpu().requires_grad_(True)
+    Wc = {n: p.detach().cpu().requires_grad_(True) for n, p in layer.named_parameters()}
+    C = F.linear(xc, Wc["cls.weight"], Wc["cls.bias"]); Dd = F.linear(xc, Wc["det.weight"], Wc["det.bias"])
+    ref_scores, loss = [], 0.0
+    off = 0
+    for i, n in enumerate(sizes):
+        s = F.softmax(C[off:off + n], dim=1) * F.softmax(Dd[off:off + n], dim=0)
+        ref_scores.append(s)
+        loss = loss + O.wsddn_loss(s, oh[i:i + 1].cpu())
+        off += n
+    loss = loss / len(sizes)
+    loss.backward()
+    assert _rel(scores.detach().cpu(), torch.cat(ref_scores).detach()) < 2e-5
+    assert abs(float(losses["loss_cls"]) - float(loss)) <= 2e-5 * abs(float(loss))
+    for n, p in layer.named_parameters():
+        assert _rel(p.grad.cpu(), Wc[n].grad) < 2e-4, n
+    assert _rel(x.grad.cpu(), xc.grad) < 2e-4
+    parts = layer.predict_probs((scores, deltas), props)
+    assert [len(t) for t in parts] == sizes
+
+
+def test_oicr_layer_forward_losses_probs_inference():
+    from sos_wsod_amd.fast_rcnn_oicr import OICROutputLayers
+    from sos_wsod_amd.structures import Boxes, Instances
+    torch.manual_seed(1)
+    K, D, sizes = 20, 128, [60, 33]
+    layer = OICROutputLayers(D, num_classes=K, refine_k=0, refine_reg=[True], test_score_thresh=0.05, test_nms_thresh=0.3).cuda()
+    with torch.no_grad():
+        layer.cls_score.weight.mul_(30); layer.bbox_pred.weight.mul_(30)
+    N = sum(sizes)
+    x = torch.randn(N, D, device="cuda", requires_grad=True)
+    views, _ = O.make_views(120, 160, N, n_gt=2, K=K, tag="papi")
+    pb = torch.from_numpy(views[0]["boxes"])
+    gen = torch.Generator().manual_seed(2)
+    gtb = pb[torch.randint(0, N, (N,), generator=gen)] + torch.rand(N, 4, generator=gen)
+    gtc = torch.randint(-1, K + 1, (N,), generator=gen)
+    gtw = torch.rand(N, generator=gen)
+    props, off = [], 0
+    for n in sizes:
+        p = Instances((120, 160))
+        p.proposal_boxes = Boxes(pb[off:off + n].cuda()); p.gt_boxes = Boxes(gtb[off:off + n].cuda())
+        p.gt_classes = gtc[off:off + n].cuda(); p.gt_weights = gtw[off:off + n].cuda()
+        props.append(p); off += n
+    scores, deltas = layer(x)
+    assert tuple(scores.shape) == (N, K + 1) and tuple(deltas.shape) == (N, 4 * K)
+    losses = layer.losses((scores, deltas), props)
+    (losses["loss_cls"] + 2.0 * losses["loss_box_reg"]).backward()
+    xc = x.detach().cpu().requires_grad_(True)
+    Wc = {n: p.detach().cpu().requires_grad_(True) for n, p in layer.named_parameters()}
+    lg = F.linear(xc, Wc["cls_score.weight"], Wc["cls_score.bias"]); dl = F.linear(xc, Wc["bbox_pred.weight"], Wc["bbox_pred.bias"])
+    a, b = O.oicr_losses(lg, dl, pb.numpy(), gtb.numpy(), gtc.numpy(), gtw.numpy(), K)      # fast_rcnn_oicr.py:157-352 (mean over all N)
+    (a + 2.0 * b).backward()
+    assert _rel(scores.detach().cpu(), lg.detach()) < 2e-5 and _rel(deltas.detach().cpu(), dl.detach()) < 2e-5
+    assert abs(float(losses["loss_cls"]) - float(a)) <= 2e-5 * abs(float(a))
+    assert abs(float(losses["loss_box_reg"]) - float(b)) <= 2e-5 * abs(float(b))
+    for n, p in layer.named_parameters():
+        assert _rel(p.grad.cpu(), Wc[n].grad) < 3e-4, n
+    assert _rel(x.grad.cpu(), xc.grad) < 3e-4
+    probs = layer.predict_probs((scores, deltas), props)
+    ref = F.softmax(lg.detach(), dim=-1)
+    assert [len(t) for t in probs] == sizes and _rel(torch.cat(probs).cpu(), ref) < 2e-5
+    dets, kept = layer.inference((scores, deltas), props)
+    assert len(dets) == 2
+    for d, k_, p in zip(dets, kept, props):
+        assert len(d) == len(k_) <= 100 and (d.scores[:-1] >= d.scores[1:]).all()
+        bx = d.pred_boxes.tensor
+        assert (bx[:, 0] >= 0).all() and (bx[:, 2] <= 160).all() and (bx[:, 3] <= 120).all()
