@@ -229,7 +229,7 @@ int sw_transpose_2d(int dtype, int rows, int cols, const void* src, long ld_src,
  * sw_ema_multi: teacher[i] = student[i] * (1 - keep_rate) + teacher[i] * keep_rate for n_tensors f32 tensors in as few
  * launches as 48-tensor batches allow (_update_teacher_model :588-604; keep_rate 0 = the copy at the end of burn-in).
  * teacher / student / numel are HOST arrays (of device pointers / element counts). */
-int sw_ema_multi(int n_tensors, float* const* teacher, const float* const* student, const long* numel, float keep_rate,
+int sw_ema_multi(int n_tensors, float* const* teacher, const float* const* student, const long* numel, double keep_rate,
                  sw_stream_t stream);
 /* sw_threshold_select: pseudo-label thresholding (threshold_bbox :361-400): keeps detection i iff scores[i] > thres (and, when
  * allowed_classes != NULL, classes[i] is one of the n_allowed image-level labels: the "multi_label" filter), compacted in input

@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(1024) void threshold_select_kernel(int n, const flo
 }
 }  // namespace
 
-extern "C" int sw_ema_multi(int n_tensors, float* const* teacher, const float* const* student, const long* numel, float keep_rate,
+extern "C" int sw_ema_multi(int n_tensors, float* const* teacher, const float* const* student, const long* numel, double keep_rate,
                             hipStream_t stream) {
   SW_ENTER();
   for (int t0 = 0; t0 < n_tensors; t0 += EMA_MAX) {
@@ -1246,7 +1246,8 @@ extern "C" int sw_ema_multi(int n_tensors, float* const* teacher, const float* c
     }
     b.block_start[b.count] = blocks;
     if (blocks == 0) continue;
-    hipLaunchKernelGGL(ema_multi_kernel, dim3(blocks), dim3(256), 0, stream, b, keep_rate, 1.0f - keep_rate);
+    // the two python-float scalars of `student * (1 - keep) + teacher * keep`, each rounded to f32 as torch rounds a scalar operand
+    hipLaunchKernelGGL(ema_multi_kernel, dim3(blocks), dim3(256), 0, stream, b, (float)keep_rate, (float)(1.0 - keep_rate));
     SW_CHECK_LAUNCH();
   }
   return 0;

@@ -24,9 +24,9 @@ class _HipLinear(torch.autograd.Function):
         xs = x.detach().contiguous()
         if xs.dtype != compute_dtype:
             xs = xs.to(compute_dtype)
-        ws = torch.empty(out_f, D, device=x.device, dtype=compute_dtype)
+        ld = (out_f + 7) // 8 * 8                                            # 16-byte K pieces for the data-gradient GEMM
+        ws = torch.zeros(ld, D, device=x.device, dtype=compute_dtype)        # rows beyond out_f stay zero
         ops.convert_2d(w.detach().float().contiguous(), ws, out_f, D)
-        ld = (out_f + 7) // 8 * 8
         y = torch.empty(N, ld, device=x.device, dtype=torch.float32)[:, :out_f]
         ops.gemm(xs, ws, y, N, out_f, D, ep=ops.make_epilogue(bias=None if b is None else b.detach().float().contiguous(),
                                                               out_dtype=torch.float32))
@@ -38,15 +38,15 @@ class _HipLinear(torch.autograd.Function):
     def backward(ctx, g):
         xs, ws = ctx.saved_tensors
         N, D = xs.shape
-        out_f = ws.shape[0]
+        out_f = g.shape[1]
         cd = xs.dtype
-        ld = (out_f + 7) // 8 * 8
+        ld = ws.shape[0]
         gs = torch.zeros(N, ld, device=g.device, dtype=cd)                   # 16-byte row pitch for the K-strided operand
         gs[:, :out_f] = g
         dx = dw = db = None
         if ctx.needs[0]:
             dx = torch.empty(N, D, device=g.device, dtype=torch.float32)
-            ops.gemm(gs, ws, dx, N, D, out_f, b_kstrided=True, lda=gs.stride(0))
+            ops.gemm(gs, ws, dx, N, D, ld, b_kstrided=True)
             if ctx.x_dtype != torch.float32:
                 dx = dx.to(ctx.x_dtype)
         if ctx.needs[1]:
