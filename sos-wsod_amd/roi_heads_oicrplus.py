@@ -158,6 +158,7 @@ class OICRPlusHeads(nn.Module):
         # dropout stream = hash(dropout_seed, element counter): the seed is drawn from SEED and the rank on first use (every
         # rank its own stream, engine/defaults.py:147 seeds SEED + rank), both travel in the state dict (extra state)
         self.seed = int(seed)
+        self.train_dropout = True         # tests: switch the fc6 / fc7 dropout off (box_head.py:90 always drops 0.5 in training)
         self.dropout_seed = None
         self._drop_counter_host = 0       # stream position; lives in a device scalar once the first training forward ran, so that
         self._drop_ctr_dev = None         # a captured hipGraph of the step draws a fresh mask on every replay
@@ -365,7 +366,7 @@ class OICRPlusHeads(nn.Module):
         # --- fc6 / fc7 with bias + ReLU + dropout fused (box_head.py:82-91)
         fc1w, fc1b, fc2w, fc2b = params[0], params[1], params[2], params[3]
         D1, D2 = fc1w.shape[0], fc2w.shape[0]
-        training_dropout = self.training
+        training_dropout = self.training and self.train_dropout
         masks = [None, None]
         hashes = [None, None]
         if training_dropout:
@@ -497,8 +498,8 @@ class OICRPlusHeads(nn.Module):
         # fc6
         db1 = torch.empty(D1, device=dev, dtype=torch.float32); ops.colsum(dz1, M, D1, db1)
         dW1 = torch.empty(D1, D0, device=dev, dtype=torch.float32)
-        if wgrad_nn:
-            ops.gemm(dz_t(dz1, D1), pooled, dW1, D1, D0, M, b_kstrided=True, tag="fc6_wgrad")
+        if wgrad_nn:                                     # the tagged region holds the transpose too: one "fc6_wgrad" measurement
+            ops._launch("fc6_wgrad", lambda: ops.gemm(dz_t(dz1, D1), pooled, dW1, D1, D0, M, b_kstrided=True))
         else:
             ops.gemm(dz1, pooled, dW1, D1, D0, M, a_kstrided=True, b_kstrided=True, tag="fc6_wgrad")
         dfeats = [None] * len(feat_req)

@@ -46,8 +46,9 @@ class ViewTransform:
 class DeviceTTAMapper:
     """dataset dict -> list of (augmented dict, ViewTransform) for TEST.AUG.{MIN_SIZES, MAX_SIZE, FLIP}"""
 
-    def __init__(self, min_sizes=(480, 576, 688, 864, 1000, 1200), max_size=4000, flip=True):
+    def __init__(self, min_sizes=(480, 576, 688, 864, 1000, 1200), max_size=4000, flip=True, proposal_topk=None, min_box_size=0):
         self.min_sizes, self.max_size, self.flip = tuple(min_sizes), max_size, flip
+        self.proposal_topk, self.min_box_size = proposal_topk, min_box_size
 
     @staticmethod
     def _shortest_edge(h, w, size, max_size):                # ResizeShortestEdge.get_output_shape
@@ -68,9 +69,18 @@ class DeviceTTAMapper:
             r, r_flip = resize_bilinear_u8(img, (nh, nw), with_flip=True)
             for flip in ((False, True) if self.flip else (False,)):
                 t = ViewTransform((h, w), (nh, nw), flip)
+                # transform_proposals (test_time_augmentation_avg.py:29-71): map, clip to the view, drop empty boxes, top-k.
+                # (The reference filters per view and later stacks the views' (R, 4K) outputs: views that drop different
+                # proposals fail there; here too the merge requires equal counts.)
+                b = t.apply_box(prop.proposal_boxes.tensor.float())
+                b = torch.stack([b[:, 0].clamp(0, nw), b[:, 1].clamp(0, nh), b[:, 2].clamp(0, nw), b[:, 3].clamp(0, nh)], 1)
+                keep = ((b[:, 2] - b[:, 0]) > self.min_box_size) & ((b[:, 3] - b[:, 1]) > self.min_box_size)
+                logits = prop.objectness_logits
+                if not bool(keep.all()):
+                    b, logits = b[keep], logits[keep]
                 p = Instances((nh, nw))
-                p.proposal_boxes = Boxes(t.apply_box(prop.proposal_boxes.tensor.float()))
-                p.objectness_logits = prop.objectness_logits
+                p.proposal_boxes = Boxes(b[:self.proposal_topk])
+                p.objectness_logits = logits[:self.proposal_topk]
                 view = {"image": r_flip if flip else r, "proposals": p, "height": d.get("height", h),
                         "width": d.get("width", w)}
                 out.append((view, t))

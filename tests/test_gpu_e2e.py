@@ -618,3 +618,40 @@ def test_step_graph_replay_equals_eager_steps(golden_dir):
     bad = [n for n in we if not torch.equal(we[n], wg[n])]
     assert not bad, bad
     assert tr_g.raw_model.roi_heads._drop_counter == tr_e.raw_model.roi_heads._drop_counter > 0
+
+
+def test_two_images_per_gpu_equal_the_mean_of_two_single_image_iterations():
+    """The reference asserts one image per GPU (rcnn_multi.py:148); B images here are B times the same computation on stacked
+    rows with the losses averaged — what DDP forms over B ranks.  Two images of DIFFERENT view sizes, proposal counts and label
+    sets: losses and every gradient of the B = 2 iteration equal the mean of the two B = 1 iterations (fp32, dropout off: the
+    hash stream indexes rows of the stacked matrix, so the second image would draw another mask)."""
+    from sos_wsod_amd.events import EventStorage
+    K, dan = 20, (256, 256)
+    P = O.make_params(K, dan, tag="pb2", head_scale=6.0)
+    va, ga = O.make_views(96, 128, 70, n_gt=2, K=K, tag="vb2a")
+    vb, gb = O.make_views(112, 96, 53, n_gt=3, K=K, tag="vb2b")
+    da, db = to_batched_inputs(va, ga)[0], to_batched_inputs(vb, gb)[0]
+    model = build_model(K, dan, torch.float32)
+    load_params(model, P)
+    model.train()
+    model.roi_heads.train_dropout = False
+
+    def run(batch):
+        for p in model.parameters():
+            p.grad = None
+        with EventStorage(0):
+            ld = model(batch)
+            ld.total().backward()
+        torch.cuda.synchronize()
+        return ld.vector.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    la, gra = run([da])
+    lb, grb = run([db])
+    l2, gr2 = run([da, db])
+    want = (la + lb) / 2
+    assert ((l2 - want).abs() <= 1e-5 * want.abs() + 1e-7).all(), (l2, want)
+    assert set(gr2) == set(gra)
+    for n in gr2:
+        ref = (gra[n] + grb[n]) / 2
+        assert float((gr2[n] - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-8, n
+    aux = model.roi_heads.last_aux
+    assert len(aux["images"]) == 2 and aux["images"][1]["scores"].shape == (4, 53, K)
