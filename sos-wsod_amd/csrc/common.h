@@ -47,6 +47,15 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
   return v;
 }
 
+// max of |x| carried as IEEE bits: for non-negative floats the unsigned order is the numeric order, Inf sits above every finite
+// value and NaN above Inf — a NaN / Inf anywhere survives the reduction (fmaxf drops NaN)
+__device__ __forceinline__ unsigned int absbits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
+__device__ __forceinline__ unsigned int wave_reduce_max_u32(unsigned int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned int)__shfl_xor((int)v, o, 64));
+  return v;
+}
+
 // block-wide reductions for blockDim.x a multiple of 64 and <= 1024; red must hold >= 16 floats.
 __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
   v = wave_reduce_sum(v);

@@ -9,13 +9,14 @@
 //   OP_CONV_A    : A(m,k) gathered from an NHWC tensor: m=(img,y,x), k=(tap,c)   (conv fwd / dgrad)
 //   OP_CONV_B    : B(k,n) gathered from an NHWC tensor: k=(img,y,x), n=(tap,c)   (conv wgrad)
 //
-// Kernel structure, tile choice and the staging path are described at gemm2_kernel below.
-// K-step of 128 bytes per row (64 bf16 / 32 f32), LDS double buffered, register-staged global
-// loads issued before the MFMA block and written to the other LDS buffer after it (one barrier
-// per K-step).  bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32 (exact f32).
-// K-contiguous operands are read from LDS with ds_read_b128 through an XOR swizzle; K-strided
-// operands keep their natural [k][m] image and are transposed on the fly by ds_read_b64_tr_b16
-// (bf16) or read element-wise (f32).
+// Kernel structure, tile choice and the staging path are described at gemm2_tile below: operands are staged by LDS-DMA buffer
+// loads (no register staging), K-step of 128 bytes per row (64 bf16 / 32 f32), a 2-stage LDS ring with counted vmcnt waits and raw
+// barriers.  bf16: v_mfma_f32_16x16x32_bf16; f32: v_mfma_f32_32x32x2_f32 (exact f32).  K-contiguous operands are read from LDS
+// with ds_read_b128 through an XOR swizzle applied on the DMA source side; K-strided operands keep their natural [k][m] image
+// and are transposed on the fly by ds_read_b64_tr_b16 (bf16) or read element-wise (f32).  Two main loops: 16 waves of 64x64
+// (one barrier per K-tile) and, for 256x256 tiles with a K-contiguous A operand, 8 waves of 128x64 in two staggered groups
+// (ping-pong: one group issues MFMAs while the other loads).  gemm2_grouped_kernel walks a list of conv weight-gradient
+// problems with the same tile code.
 #include <stdlib.h>
 #include "common.h"
 #include "soswsod_hip.h"
@@ -517,7 +518,7 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
 
   // ---- epilogue (C/D element map: Mma<T>::row / col)
   const int r = MM::col(lane);
-  float vmax = 0.f;
+  unsigned int vmax = 0u;                                    // max |stored value| as IEEE bits (NaN / Inf survive)
   const unsigned long long drop_base = g.drop_seed_mixed + g.drop_offset + ((g.drop_p > 0.f && g.drop_offset_dev) ? *g.drop_offset_dev : 0ull);
   if constexpr (PP) {
     // Row-wise epilogue through LDS (the ring is free now).  128 accumulator registers plus a fully unrolled 128-element
@@ -579,7 +580,7 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
                 x = rv > 0.f ? x * g.ref_scale : 0.f;
               }
             }
-            if (ok) vmax = fmaxf(vmax, fabsf(x));
+            if (ok) vmax = max(vmax, absbits(x));
             v[t] = x;
           }
           const long o = (long)m * g.ldc + nb;
@@ -650,7 +651,7 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
                                       : ((const float*)g.ref)[(long)m * g.ldr + n];
           v = rv > 0.f ? v * g.ref_scale : 0.f;
         }
-        if (ok) vmax = fmaxf(vmax, fabsf(v));
+        if (ok) vmax = max(vmax, absbits(v));
         if (staged) { stile[lrow * WTN + j * TS + r] = f32_to_bf16_bits(v); continue; }
         if (!ok) continue;
         const long o = (long)m * g.ldc + n;
@@ -673,8 +674,8 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
   }
   }
   if (g.absmax) {
-    vmax = wave_reduce_max(vmax);
-    if (lane == 0) atomicMax((unsigned int*)g.absmax, __float_as_uint(vmax));
+    vmax = wave_reduce_max_u32(vmax);
+    if (lane == 0) atomicMax((unsigned int*)g.absmax, vmax);
   }
 }
 

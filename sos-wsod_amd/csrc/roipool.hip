@@ -194,16 +194,17 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
 // Backward, fixed-point path.  Measured on MI355X (tools/roi_bench.py): LDS float atomics (ds_add_f32) run ~3.4x
 // slower than LDS integer atomics (ds_add_u32 / ds_add_u64 ~ plain ds_write rate) and set the kernel's time.  So the slab
 // accumulates in 64-bit fixed point: every product grad*scale (rounded to f32 exactly as the float path does) is
-// converted with 2^FRAC, FRAC chosen from max|grad|*max|scale| so that 2^40 bounds one term and 4*R terms (a pixel is
-// the argmax of at most 4 bins per ROI) cannot overflow 63 bits.  Integer adds are associative => the result is
+// converted with 2^FRAC, FRAC chosen from max|grad|*max|scale| so that 2^40 bounds one term and PH*PW*R_image terms (a pixel
+// can be the argmax of every bin of a ROI whose bins are smaller than a pixel) cannot overflow 63 bits.  Integer adds are associative => the result is
 // BITWISE REPRODUCIBLE and at least as accurate as f32 accumulation.
 // Workgroup = (image, slab of CB channels, CB % 4 == 0) owning H*W*CB int64 in LDS; a lane loads 4 gradients and 4
 // argmax words of 4 ROIs (16-byte aligned, 8 loads in flight) before scattering.
 constexpr int FX_CHUNK = 1024;          // ROIs per compaction round of the fixed-point backward
 
 // ACC = unsigned long long: 40 fractional-range bits per term (fp32 mode).  ACC = unsigned int (bf16 mode): a pixel-channel
-// receives at most 4 bins of every ROI, so with bits = ceil(log2(4R)) a term may use 30 - bits bits (16 for R = 4000: 2^-16 of
-// the largest term, against bf16's 2^-8 outputs) and the sum cannot overflow; the conversion is then ONE v_cvt_i32_f32 instead
+// receives at most PH*PW bins of every ROI of its image, so with bits = ceil(log2(PH*PW*R_image)) a term may use 30 - bits bits
+// (13 for R_image = 2000: 2^-13 of the largest term, against bf16's 2^-8 outputs) and the sum cannot overflow whatever the ROI
+// sizes; the conversion is then ONE v_cvt_i32_f32 instead
 // of an emulated f32 -> i64 (the kernel is VALU-issue bound: 88 M wave instructions per 4000 ROIs).
 template <typename T, typename IT, typename ACC>
 __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int C, long ld, int nb, int CB,
@@ -232,9 +233,21 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   smax = block_reduce_max(smax, red);
   smax = __shfl(smax, 0, 64);
   const float bound = dout_absmax[0] * smax;
+  // A diverged gradient (NaN / Inf anywhere in dout: its |max| is then NaN or Inf) must stay visible: the integer conversion
+  // would turn NaN into 0 and saturate Inf, so the whole slab is written as NaN instead.
+  const bool poisoned = !(bound < 3.0e38f);
+  // Terms per accumulator: a pixel-channel can be the argmax of EVERY bin of a ROI whose bins are smaller than a pixel (ROIs
+  // narrower than PW feature pixels: MIN_SIZE 20 at stride 8), so the bound is nb per ROI of this image — not the 4 of
+  // well-formed ROIs.  32-bit accumulators: 30 - ceil(log2(nb * R_image)) bits per term (R = 2000: 13 bits, still 32x finer
+  // than the bf16 result); 64-bit: 40 bits per term leave room for 2^23 terms.
+  int n_img = 0;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) n_img += ((int)rois[(long)r * 5] == img) ? 1 : 0;
+  n_img = (int)(block_reduce_sum((float)n_img, red) + 0.5f);        // exact: counts < 2^24
+  n_img = __shfl(n_img, 0, 64);
+  const unsigned terms = (unsigned)max(nb * max(n_img, 1), 1);
   int frac = 0;
-  const int term_bits = sizeof(ACC) == 8 ? 40 : 30 - (32 - __clz(4 * R));
-  if (bound > 0.f && bound < 3.0e38f) frac = term_bits - (ilogbf(bound) + 1);
+  const int term_bits = sizeof(ACC) == 8 ? 40 : max(30 - (32 - __clz(terms)), 1);
+  if (bound > 0.f && !poisoned) frac = term_bits - (ilogbf(bound) + 1);
   __syncthreads();
   // ROIs are taken in chunks of FX_CHUNK: the workgroup first compacts (roi, scale) of the ROIs of ITS image into LDS,
   // then every wave streams 8 listed ROIs per step with all 16 loads issued before the first use — the only global
@@ -303,6 +316,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
     float v = sizeof(ACC) == 8 ? scalbnf((float)(long long)acc[cc * npix + p], -frac)
                                : scalbnf((float)(int)acc[cc * npix + p], -frac);
     if (rimg && !(Elem<T>::load(rimg + (long)p * C + c0 + cc) > 0.f)) v = 0.f;
+    if (poisoned) v = __uint_as_float(0x7FC00000u);
     Elem<T>::store(dimg + (long)p * C + c0 + cc, v);
   }
 }
@@ -492,14 +506,15 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
 }
 
 
-// max |x| over n elements -> out[0] (f32; caller zero-fills).  |x| as IEEE bits is monotone => integer atomicMax.
+// max |x| over n elements -> out[0] (f32; caller zero-fills).  |x| as IEEE bits is monotone => integer atomicMax; a NaN in x
+// yields NaN, an Inf yields Inf.
 template <typename T>
 __global__ void absmax_kernel(long n, const T* __restrict__ x, float* __restrict__ out) {
-  float m = 0.f;
+  unsigned int m = 0u;                       // IEEE bits of |x|: NaN > Inf > finite, so a poisoned tensor reports it
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(Elem<T>::load(x + i)));
-  m = wave_reduce_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(m));
+    m = max(m, absbits(Elem<T>::load(x + i)));
+  m = wave_reduce_max_u32(m);
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, m);
 }
 
 }  // namespace
@@ -577,8 +592,10 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, con
                      void* dfeat, hipStream_t stream) {
   // fixed-point path: CB in {8, 4} with H*W*CB*8 bytes of LDS; needs max|dout| (device scalar)
   static const bool float_atomics = getenv("SW_ROI_FLOAT_ATOMICS") != nullptr;    // development switch
-  // bf16: 32-bit accumulators (see the kernel) when 4R terms leave >= 12 bits per term; fp32: 64-bit
-  const bool acc32 = sizeof(T) == 2 && R > 0 && (30 - (32 - __builtin_clz((unsigned)(4 * R)))) >= 12;
+  // bf16: 32-bit accumulators (see the kernel) when PH*PW*R terms (every bin of every ROI on one pixel: the worst case) leave
+  // >= 10 bits per term; fp32: 64-bit
+  const bool acc32 = sizeof(T) == 2 && R > 0 && (long)PH * PW * R < (1L << 30) &&
+                     (30 - (32 - __builtin_clz((unsigned)(PH * PW * R)))) >= 10;
   const size_t ab = acc32 ? 4 : 8;
   int cbx = 8;
   while (cbx > 4 && ((size_t)H * W * cbx * ab > 128 * 1024 || (C % cbx) || (C / cbx) * nimg < 256)) cbx >>= 1;

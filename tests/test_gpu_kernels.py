@@ -247,6 +247,32 @@ def test_roi_pool_bit_exact_and_backward(ops, dtype, adt):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_roi_pool_backward_tiny_rois_and_poisoned_gradients(ops, dtype):
+    """(1) 2000 ROIs no wider than one feature pixel, all on the SAME pixel with gradients of one sign: every one of the 49 bins
+    of every ROI scatters onto one accumulator — the fixed-point sizing must count PH*PW bins per ROI, not 4 (a 4-per-ROI
+    bound wraps the 32-bit accumulator here).  (2) a NaN / Inf anywhere in the incoming gradient reaches the feature gradient
+    (the integer conversion would turn NaN into 0)."""
+    n, C, H, W, R = 2, 16, 20, 24, 2000
+    feat = torch.rand(n, C, H, W, generator=torch.Generator().manual_seed(4)).add_(0.5).to(dtype).float()   # the values both sides see
+    boxes = np.tile(np.array([[40.0, 48.0, 44.0, 52.0]], np.float32), (R, 1))           # round(x / 8) = 5 .. 6: a 1-2 pixel ROI
+    rois = np.concatenate([np.zeros((R, 1), np.float32), boxes], 1)
+    ref_out, ref_arg = O.roi_pool_fwd(feat.numpy(), rois, 1.0 / 8)
+    f = _nhwc(feat).to(dtype).cuda()
+    out = torch.empty(R, C * 49, device="cuda", dtype=dtype); arg = torch.empty(R, C * 49, device="cuda", dtype=torch.int16)
+    ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7)
+    g = torch.full((R, C, 7, 7), 0.75)                                                   # same sign, near the absmax: worst case
+    ref_g = _nhwc(torch.from_numpy(O.roi_pool_bwd(g.numpy(), ref_arg, rois, feat.shape)))
+    assert ref_g.max() > 4 * R * 0.75                                                    # more than 4 bins per ROI did hit one pixel
+    dfeat = torch.empty(n, H, W, C, device="cuda", dtype=dtype)
+    ops.roi_pool_bwd(g.to(dtype).view(R, -1).cuda().contiguous(), arg, torch.from_numpy(rois).cuda(), dfeat, 7, 7)
+    assert (dfeat.cpu().float() - ref_g).abs().max() <= (1e-2 if dtype == torch.bfloat16 else 1e-5) * ref_g.abs().max()
+    for bad in (float("nan"), float("inf")):
+        gb = g.clone(); gb[17, 3, 2, 2] = bad
+        ops.roi_pool_bwd(gb.to(dtype).view(R, -1).cuda().contiguous(), arg, torch.from_numpy(rois).cuda(), dfeat, 7, 7)
+        assert torch.isnan(dfeat[0]).all()                                               # image 0 received the poisoned ROI
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_roi_pool_ties_and_special_values(ops, dtype):
     """first maximum in row-major order on plateaus; -0.0/+0.0, -inf, +-NaN and the most negative finite value follow
     the reference's strict '>' from -FLT_MAX (ROILoopPool_cpu.cpp:60-72)"""
