@@ -49,7 +49,7 @@ template <> struct ArgIdx<int> {
   __device__ static __forceinline__ int dec(int v) { return v; }
 };
 template <> struct ArgIdx<unsigned short> {
-  __device__ static __forceinline__ unsigned short enc(int i) { return (unsigned short)(i < 0 ? 0xFFFF : i); }
+  __device__ static __forceinline__ unsigned short enc(int i) { return (unsigned short)i; }     // i is a pixel index or -1 (-> 0xFFFF)
   __device__ static __forceinline__ int dec(unsigned short v) { return v == 0xFFFF ? -1 : (int)v; }
 };
 
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
   int* s_list = (int*)(smem + (((size_t)H * W * PXB + 15) & ~(size_t)15));   // [chunk] ROIs of this image
   unsigned short* s_hb = (unsigned short*)(s_list + chunk);        // [chunk][PH] bin row range  start | end << 8  (H, W <= 255)
   unsigned short* s_wb = s_hb + chunk * PH;                        // [chunk][PW] bin column range
+  float* s_mul = (float*)(s_wb + chunk * PW + ((chunk * (PH + PW)) & 1));   // [chunk] output scale of the ROI (4-byte aligned)
   const int c0 = blockIdx.x * CB, img = blockIdx.y;
   const int r0 = blockIdx.z * chunk, r1 = min(R, r0 + chunk);
   const int tid = threadIdx.x;
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
   for (int i = tid; i < cnt * (PH + PW); i += NT) {
     const int li = i / (PH + PW), k = i - li * (PH + PW);
     const RoiGeom g = roi_geom(rois + (long)s_list[li] * 5, scale, PH, PW);
+    if (k == 0) s_mul[li] = row_scale ? (row_scale[s_list[li]] + row_scale_add) : 1.0f;
     if (k < PH) {
       int hs = (int)floorf(__fmul_rn((float)k, g.bin_h)), he = (int)ceilf(__fmul_rn((float)(k + 1), g.bin_h));
       hs = min(max(hs + g.start_h, 0), H); he = min(max(he + g.start_h, 0), H);
@@ -440,10 +442,13 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
   const int nb = PH * PW;
   const int total = cnt * nb;
   constexpr unsigned KEY_INIT = 0x007FFFFFu;                       // key(-inf) << 16 | 0xFFFF
+  // task t = (ROI li of the list, bin row ph, bin column pw), t advancing by NT per iteration: carried as three counters
+  // (two integer divisions per task were a fifth of the ~230 VALU instructions a task spends outside its window scan)
+  const int dli = NT / nb, dph = (NT - dli * nb) / PW, dpw = NT - dli * nb - dph * PW;
+  int li = tid / nb, ph = (tid - li * nb) / PW, pw = tid - li * nb - ph * PW;
   for (int t = tid; t < total; t += NT) {
-    const int li = t / nb, b = t - li * nb;
+    const int b = ph * PW + pw;
     const int r = s_list[li];
-    const int ph = b / PW, pw = b - ph * PW;
     const int hb = s_hb[li * PH + ph], wb = s_wb[li * PW + pw];
     const int hs = hb & 0xFF, he = hb >> 8, ws = wb & 0xFF, we = wb >> 8;
     const bool empty = (he <= hs) || (we <= ws);
@@ -453,29 +458,43 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
 #pragma unroll
       for (int q = 0; q < CB; ++q) best[q] = KEY_INIT;
       if (!empty) {
+        // two window pixels per step (the second clamped to the row's last pixel: re-reading a pixel cannot change a
+        // maximum): v_max3_u32 folds both keys into the running best — 3 VALU per channel and pixel PAIR instead of 4 — and the
+        // loop / address overhead (a third of the 27 VALU per visit this scan spent; rocprof: 126 M wave instructions per
+        // 4000 ROIs, VALU 86 % busy) is paid once per pair; windows 3 and 4 pixels wide both take two steps
         const int bw = we - ws;
         for (int hh = hs; hh < he; ++hh) {
           const int rowi = hh * W + ws;
-          for (int x = 0; x < bw; ++x) {
-            const int idx = rowi + x;
-            const word_t w = plane[idx];
-            const unsigned int* u = (const unsigned int*)&w;
-            const unsigned int inv = 0xFFFEu - (unsigned)idx;
+          for (int x = 0; x < bw; x += 2) {
+            const int i0 = rowi + x, i1 = rowi + min(x + 1, bw - 1);
+            const word_t w0 = plane[i0], w1 = plane[i1];
+            const unsigned int* u0 = (const unsigned int*)&w0;
+            const unsigned int* u1 = (const unsigned int*)&w1;
+            const unsigned int inv0 = 0xFFFEu - (unsigned)i0, inv1 = 0xFFFEu - (unsigned)i1;
 #pragma unroll
             for (int i = 0; i < NWORD; ++i) {
-              best[2 * i] = max(best[2 * i], (u[i] << 16) | inv);
-              best[2 * i + 1] = max(best[2 * i + 1], (u[i] & 0xFFFF0000u) | inv);
+              best[2 * i] = max(max(best[2 * i], (u0[i] << 16) | inv0), (u1[i] << 16) | inv1);
+              best[2 * i + 1] = max(max(best[2 * i + 1], (u0[i] & 0xFFFF0000u) | inv0), (u1[i] & 0xFFFF0000u) | inv1);
             }
           }
         }
       }
+      // key -> bf16 bits: positive values (key bit 15 set) flip that bit back, negative ones were stored complemented; the pixel
+      // index 0xFFFE - low half is -1 by itself when nothing won (low half still 0xFFFF).  best never drops below KEY_INIT, and a
+      // channel still AT it (empty bin, or a window of -inf / NaN only) is the one case the reference answers differently
+      // (0 resp. -FLT_MAX): one min over the channels finds it, so the common path pays no per-channel selects
+      unsigned int lowest = best[0];
 #pragma unroll
       for (int q = 0; q < CB; ++q) {
-        const unsigned int hi = best[q] >> 16, lo = best[q] & 0xFFFFu;
-        const unsigned int bts = (hi & 0x8000u) ? (hi ^ 0x8000u) : (hi ^ 0xFFFFu);
-        const bool none = lo == 0xFFFFu;
-        mv[q] = empty ? 0.f : none ? -FLT_MAX : __uint_as_float(bts << 16);
-        mi[q] = (empty || none) ? -1 : (int)(0xFFFEu - lo);
+        const unsigned int m = (unsigned int)((int)best[q] >> 31);
+        mv[q] = __uint_as_float((best[q] & 0xFFFF0000u) ^ (0x80000000u | (~m & 0x7FFF0000u)));
+        mi[q] = (int)(0xFFFEu - (best[q] & 0xFFFFu));
+        lowest = min(lowest, best[q]);
+      }
+      if (lowest == KEY_INIT) {
+#pragma unroll
+        for (int q = 0; q < CB; ++q)
+          if (best[q] == KEY_INIT) mv[q] = empty ? 0.f : -FLT_MAX;
       }
     } else {
 #pragma unroll
@@ -495,13 +514,19 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
         }
       }
     }
-    const float mul = row_scale ? (row_scale[r] + row_scale_add) : 1.0f;
+    // 2 x CB two-byte stores per task (a 64-lane wave writes one contiguous 98-byte run per channel and ROI): measured 45 us of the
+    // 260 us a 4000-ROI call takes (stores compiled out: 215 us), the rest is the scan's VALU issue — staging the rows through LDS
+    // for 16-byte stores would need 31 KiB more LDS and drop 63x63 maps to one workgroup per CU, so the stores stay direct
+    const float mul = s_mul[li];
     const long o = (long)r * ld + (long)c0 * nb + b;
 #pragma unroll
     for (int q = 0; q < CB; ++q) {
       Elem<T>::store(out + o + (long)q * nb, __fmul_rn(mv[q], mul));
       argmax[o + (long)q * nb] = ArgIdx<IT>::enc(mi[q]);
     }
+    pw += dpw; ph += dph; li += dli;
+    if (pw >= PW) { pw -= PW; ++ph; }
+    if (ph >= PH) { ph -= PH; ++li; }
   }
 }
 
@@ -524,7 +549,7 @@ template <typename T, int CB, typename IT>
 int launch_fwd_plane(int nimg, int H, int W, int C, long ld, int PH, int PW, float scale, const void* feat, const float* rois, int R,
                      const float* row_scale, float row_scale_add, void* out, void* argmax, hipStream_t stream) {
   constexpr int NT = 1024, CHUNK = 256;
-  const size_t lds = (((size_t)H * W * CB * sizeof(T) + 15) & ~(size_t)15) + (size_t)CHUNK * (4 + 2 * (PH + PW));
+  const size_t lds = (((size_t)H * W * CB * sizeof(T) + 15) & ~(size_t)15) + (size_t)CHUNK * (4 + 2 * (PH + PW)) + 4 + (size_t)CHUNK * 4;
   const bool key = sizeof(T) == 2 && (long)H * W < 65535;
   auto kern = key ? roi_pool_fwd_plane_kernel<T, CB, NT, IT, (sizeof(T) == 2)> : roi_pool_fwd_plane_kernel<T, CB, NT, IT, false>;
   if (lds > 64 * 1024) {
@@ -549,7 +574,7 @@ int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, long ld, int PH, 
   if (!force_gather && nimg > 0 && (((uintptr_t)feat) & 15) == 0 && H <= 255 && W <= 255) {      // 8-bit bin tables
     int pxb = 0;
     for (int cand = 16; cand >= 4 && !pxb; cand >>= 1)
-      if ((C % (cand / (int)es)) == 0 && (size_t)H * W * cand <= 71 * 1024) pxb = cand;   // + 8 KiB of ROI tables: two workgroups per CU
+      if ((C % (cand / (int)es)) == 0 && (size_t)H * W * cand <= 70 * 1024) pxb = cand;   // + 9 KiB of ROI tables: two workgroups per CU
     // one workgroup per CU: only slabs of >= 8 bytes per pixel — with 4-byte slabs (2 bf16 channels per lane) the per-pixel
     // loop overhead is amortised over too little: on 125x167 / 150x200 maps (1000 / 1200-pixel views) the ROI-stationary
     // gather kernel below was 0.9 ms per iteration faster, on 86x115 / 108x144 maps (8-byte slabs) the two are equal
