@@ -312,14 +312,42 @@ __device__ __forceinline__ unsigned long long make_key(float score, unsigned int
   return ((unsigned long long)(~orderable(score)) << 32) | idx;
 }
 
-__device__ void bitonic_sort(unsigned long long* keys, int N) {
+// WAVE_LOCAL (keys in LDS): a pass whose partner distance j is < 128 stays inside one aligned block of 128 keys.  A wave owns
+// such a block (lane = the pair whose lower index has bit j clear) and runs all the remaining passes of the stage on it back to
+// back: the LDS serves one wave's requests in issue order, so those passes need no workgroup barrier — 2048 keys take 14
+// barriers instead of 66 (the mining kernel sorts one score column per image-level class on the step's critical path).
+// (Holding the block in registers and exchanging by __shfl_xor was slower — four ds_bpermute per pass — and so was giving a thread
+// four independent pairs per pass: a pass costs ~0.2 us of issue + LDS round trip either way; in-kernel stamps at R = 2000, G = 2:
+// column sorts 27 us, threshold + keys 2, NMS sort 7, NMS 12, labels 6.)
+// nseg > 1: nseg independent arrays of N keys back to back, all sorted ascending by the same passes (the passes are latency bound,
+// so several score columns sort in the time of one).
+template <bool WAVE_LOCAL>
+__device__ void bitonic_sort(unsigned long long* keys, int N, int nseg = 1) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int T = N * nseg;
   for (int k = 2; k <= N; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      if (WAVE_LOCAL && j < 128) {
+        for (int base = wave * 128; base < T; base += nwaves * 128) {
+          for (int jj = j; jj > 0; jj >>= 1) {
+            const int i = base + (((lane & ~(jj - 1)) << 1) | (lane & (jj - 1))), p = i | jj;
+            if (p < T) {
+              const unsigned long long a = keys[i], b = keys[p];
+              const bool asc = ((i & (N - 1)) & k) == 0;
+              if ((a > b) == asc) { keys[i] = b; keys[p] = a; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        __syncthreads();
+        break;
+      }
+      for (int i = threadIdx.x; i < T; i += blockDim.x) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const unsigned long long a = keys[i], b = keys[ixj];
-          const bool asc = (i & k) == 0;
+          const bool asc = ((i & (N - 1)) & k) == 0;
           if ((a > b) == asc) { keys[i] = b; keys[ixj] = a; }
         }
       }
@@ -347,6 +375,17 @@ __device__ __forceinline__ float iou_pair(const float* gtb, const float* pb) {
   return inter > 0.f ? __fdiv_rn(inter, __fadd_rn(box_area(gtb), box_area(pb)) - inter) : 0.f;
 }
 
+__device__ __forceinline__ float from_orderable(unsigned int o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+// STAGED (the usual case: the sort keys + 25 bytes per (rank, class) slot fit LDS): the slot lists live in LDS, the NMS sort keys
+// are built straight from the thresholded slots (slot order = masked_select order, so the slot number is the tie-break), and the
+// greedy NMS walks the candidates in SORTED order with their boxes gathered once into that order — the serial part of the kernel
+// (one step per kept box, ~25 at NMS 0.01) reads LDS only.  With the lists in the global workspace each kept box cost two
+// dependent L2 round trips per thread plus tid 0's three, and the label pass paid the same per pseudo box (116 us for R = 2000,
+// G = 2 — and the step waits on this kernel).  The workspace form stays for slot counts beyond LDS.
+template <bool STAGED>
 __global__ __launch_bounds__(1024) void mine_label_kernel(int R, int ncol, int K, const float* __restrict__ scores,
                                                           const int* __restrict__ gt_classes, int G,
                                                           const float* __restrict__ boxes, int top_k, float score_thresh,
@@ -355,7 +394,7 @@ __global__ __launch_bounds__(1024) void mine_label_kernel(int R, int ncol, int K
                                                           int* __restrict__ lab_index, int* __restrict__ pgt_count,
                                                           int* __restrict__ pgt_index, int* __restrict__ pgt_class,
                                                           float* __restrict__ pgt_score, char* __restrict__ ws,
-                                                          long ws_stride, int keys_in_ws) {
+                                                          long ws_stride, int keys_in_ws, int class_batch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n_slots = top_k * G;
   {                                             // one workgroup per refinement round, rounds laid out back to back
@@ -369,33 +408,38 @@ __global__ __launch_bounds__(1024) void mine_label_kernel(int R, int ncol, int K
   // sort keys: LDS while NP * 8 B + the suppression bytes fit (R, top_k*G <= 16384: every VOC / COCO recipe with up to 16
   // image-level classes), else a key array at the end of this round's workspace (COCO's 10000 proposals with >= 17 classes:
   // one workgroup sorts through its CU's write-through L1, __syncthreads() orders the passes)
-  unsigned long long* keys = keys_in_ws ? (unsigned long long*)(ws + ws_stride - (long)NP * 8) : (unsigned long long*)smem;
-  unsigned char* sup = (unsigned char*)(smem + (keys_in_ws ? 0 : (size_t)NP * 8));   // [n_slots]
-  __shared__ int s_scan[1024];
-  __shared__ int s_nk;
-  float* slot_score = (float*)ws;                                        // [n_slots]  rank-major, class-minor
+  unsigned long long* keys = (!STAGED && keys_in_ws) ? (unsigned long long*)(ws + ws_stride - (long)NP * 8) : (unsigned long long*)smem;
+  char* const lists = STAGED ? smem + (size_t)max(NP, class_batch * next_pow2(R)) * 8 : ws;   // STAGED: [n_slots] float4 first (16-byte aligned)
+  float4* const sbox = (float4*)lists;                                     // STAGED only: candidate boxes in sorted order
+  float* slot_score = (float*)(lists + (STAGED ? (size_t)n_slots * 16 : 0));   // [n_slots]  rank-major, class-minor
   int* slot_idx = (int*)(slot_score + n_slots);
-  float* c_score = (float*)(slot_idx + n_slots);                         // compacted candidates
+  float* c_score = (float*)(slot_idx + n_slots);                         // workspace form only: compacted candidates
   int* c_idx = (int*)(c_score + n_slots);
   int* c_cls = c_idx + n_slots;
+  unsigned char* sup = STAGED ? (unsigned char*)(slot_idx + n_slots) : (unsigned char*)(smem + (keys_in_ws ? 0 : (size_t)NP * 8));   // [n_slots]
+  __shared__ int s_scan[1024];
+  __shared__ int s_nk;
   const int tid = threadIdx.x;
 
   // ---- 1. per gt class: full sort of the score column, take the first top_k (get_pgt_top_k :646-666)
   const int NPR = next_pow2(R);
-  for (int g = 0; g < G; ++g) {
-    const int col = gt_classes[g];
-    for (int i = tid; i < NPR; i += blockDim.x)
-      keys[i] = i < R ? make_key(scores[(long)i * ncol + col], (unsigned)i) : ~0ull;
+  for (int g0 = 0; g0 < G; g0 += class_batch) {              // class_batch score columns sort side by side (STAGED: as LDS allows)
+    const int nb = min(class_batch, G - g0);
+    for (int i = tid; i < NPR * nb; i += blockDim.x) {
+      const int b = i / NPR, r = i - b * NPR;
+      keys[i] = r < R ? make_key(scores[(long)r * ncol + gt_classes[g0 + b]], (unsigned)r) : ~0ull;
+    }
     __syncthreads();
-    bitonic_sort(keys, NPR);
-    for (int rank = tid; rank < top_k; rank += blockDim.x) {
-      const unsigned int idx = (unsigned int)(keys[rank] & 0xFFFFFFFFu);
-      slot_idx[rank * G + g] = (int)idx;
-      slot_score[rank * G + g] = scores[(long)idx * ncol + col];
+    if (!STAGED && keys_in_ws) bitonic_sort<false>(keys, NPR, nb); else bitonic_sort<true>((unsigned long long*)smem, NPR, nb);
+    for (int i = tid; i < top_k * nb; i += blockDim.x) {
+      const int b = i / top_k, rank = i - b * top_k;
+      const unsigned long long key = keys[b * NPR + rank];
+      slot_idx[rank * G + g0 + b] = (int)(unsigned int)(key & 0xFFFFFFFFu);
+      slot_score[rank * G + g0 + b] = from_orderable(~(unsigned int)(key >> 32));     // the key holds the score bit for bit
     }
     __syncthreads();
   }
-  __threadfence_block();
+  if (!STAGED) __threadfence_block();
   // ---- 2. threshold mask with rank 0 always kept (:698-704), masked_select order = slot order
   const int per = (n_slots + 1023) / 1024;
   int cnt = 0;
@@ -410,42 +454,86 @@ __global__ __launch_bounds__(1024) void mine_label_kernel(int R, int ncol, int K
     __syncthreads();
   }
   const int n = s_scan[1023];
-  int pos = s_scan[tid] - cnt;
-  for (int s = tid * per; s < min(n_slots, (tid + 1) * per); ++s) {
-    if (s < G || slot_score[s] >= score_thresh) {
-      c_score[pos] = slot_score[s]; c_idx[pos] = slot_idx[s]; c_cls[pos] = gt_classes[s % G];
-      ++pos;
-    }
-  }
-  __syncthreads();
-  // ---- 3. class-agnostic greedy NMS (get_pgt_mist :576-581; torchvision nms): sort by score desc, position asc
   const int NPN = next_pow2(n);
-  for (int i = tid; i < NPN; i += blockDim.x) keys[i] = i < n ? make_key(c_score[i], (unsigned)i) : ~0ull;
-  for (int i = tid; i < n; i += blockDim.x) sup[i] = 0;
-  if (tid == 0) s_nk = 0;
-  __syncthreads();
-  bitonic_sort(keys, NPN);
-  int nk = 0;
-  for (int t = 0; t < n; ++t) {
-    const int p = (int)(keys[t] & 0xFFFFFFFFu);
-    if (sup[p]) continue;                                               // uniform across the workgroup
-    if (tid == 0) { pgt_index[nk] = c_idx[p]; pgt_class[nk] = c_cls[p]; pgt_score[nk] = c_score[p]; }
-    ++nk;
-    const float* bp = boxes + (long)c_idx[p] * 4;
-    for (int u = t + 1 + tid; u < n; u += blockDim.x) {
-      const int q = (int)(keys[u] & 0xFFFFFFFFu);
-      if (!sup[q] && iou_nms(bp, boxes + (long)c_idx[q] * 4) > nms_thresh) sup[q] = 1;
+  int pos = s_scan[tid] - cnt;
+  // ---- 3. class-agnostic greedy NMS (get_pgt_mist :576-581; torchvision nms): sort by score desc, position asc
+  if (STAGED) {
+    for (int s = tid * per; s < min(n_slots, (tid + 1) * per); ++s)
+      if (s < G || slot_score[s] >= score_thresh) keys[pos++] = make_key(slot_score[s], (unsigned)s);
+    for (int i = n + tid; i < NPN; i += blockDim.x) keys[i] = ~0ull;
+  } else {
+    for (int s = tid * per; s < min(n_slots, (tid + 1) * per); ++s) {
+      if (s < G || slot_score[s] >= score_thresh) {
+        c_score[pos] = slot_score[s]; c_idx[pos] = slot_idx[s]; c_cls[pos] = gt_classes[s % G];
+        ++pos;
+      }
     }
     __syncthreads();
+    for (int i = tid; i < NPN; i += blockDim.x) keys[i] = i < n ? make_key(c_score[i], (unsigned)i) : ~0ull;
+    for (int i = tid; i < n; i += blockDim.x) sup[i] = 0;
+  }
+  if (tid == 0) s_nk = 0;
+  __syncthreads();
+  if (!STAGED && keys_in_ws) bitonic_sort<false>(keys, NPN); else bitonic_sort<true>((unsigned long long*)smem, NPN);
+  int nk = 0;
+  if (STAGED) {
+    for (int t = tid; t < n; t += blockDim.x) {
+      const int row = slot_idx[(int)(keys[t] & 0xFFFFFFFFu)];
+      sbox[t] = *(const float4*)(boxes + (long)row * 4);
+      sup[t] = 0;
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    int t = 0;
+    while (true) {
+      // next candidate not yet suppressed: every wave scans the same flags 64 at a time (uniform result, no barrier)
+      while (t < n) {
+        const int tt = t + lane;
+        const unsigned long long alive = __ballot(tt < n && !sup[tt]);
+        if (alive) { t += __ffsll((long long)alive) - 1; break; }
+        t += 64;
+      }
+      if (t >= n) break;
+      const float4 bp = sbox[t];
+      for (int u = t + 1 + tid; u < n; u += blockDim.x) {
+        const float4 bq = sbox[u];
+        if (!sup[u] && iou_nms((const float*)&bp, (const float*)&bq) > nms_thresh) sup[u] = 1;
+      }
+      __syncthreads();                         // flags final; everybody holds box t in registers
+      if (tid == 0) {                          // the kept boxes are the prefix of the sorted list (nk <= t: slots already consumed)
+        const unsigned long long key = keys[t];
+        const int slot = (int)(key & 0xFFFFFFFFu);
+        sbox[nk] = bp;
+        pgt_index[nk] = slot_idx[slot]; pgt_class[nk] = gt_classes[slot % G];
+        pgt_score[nk] = from_orderable(~(unsigned int)(key >> 32));
+      }
+      ++nk; ++t;
+    }
+  } else {
+    for (int t = 0; t < n; ++t) {
+      const int p = (int)(keys[t] & 0xFFFFFFFFu);
+      if (sup[p]) continue;                                               // uniform across the workgroup
+      if (tid == 0) { pgt_index[nk] = c_idx[p]; pgt_class[nk] = c_cls[p]; pgt_score[nk] = c_score[p]; }
+      ++nk;
+      const float* bp = boxes + (long)c_idx[p] * 4;
+      for (int u = t + 1 + tid; u < n; u += blockDim.x) {
+        const int q = (int)(keys[u] & 0xFFFFFFFFu);
+        if (!sup[q] && iou_nms(bp, boxes + (long)c_idx[q] * 4) > nms_thresh) sup[q] = 1;
+      }
+      __syncthreads();
+    }
   }
   if (tid == 0) { pgt_count[0] = nk; __threadfence(); }
   __syncthreads();
   // ---- 4. IoU matching + labels (pairwise_iou, Matcher [iou_bg, iou_fg] -> {0,-1,1}, roi_heads.py:225-257,266-375)
   for (int r = tid; r < R; r += blockDim.x) {
-    const float* pb = boxes + (long)r * 4;
+    const float4 pbv = *(const float4*)(boxes + (long)r * 4);
+    const float* pb = (const float*)&pbv;
     float best = -1.f; int bj = 0;
     for (int j = 0; j < nk; ++j) {
-      const float v = iou_pair(boxes + (long)pgt_index[j] * 4, pb);
+      float v;
+      if (STAGED) { const float4 gb = sbox[j]; v = iou_pair((const float*)&gb, pb); }
+      else v = iou_pair(boxes + (long)pgt_index[j] * 4, pb);
       if (v > best) { best = v; bj = j; }                               // first max = lowest pgt index
     }
     int cls; float w = 0.f; int gi = 0;
@@ -539,7 +627,7 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
     if (i < R) sup[i] = 0;
   }
   __syncthreads();
-  bitonic_sort(keys, NP);
+  bitonic_sort<true>(keys, NP);
   int nk = 0;
   for (int t = 0; t < R && nk < topk; ++t) {
     const unsigned long long key = keys[t];
@@ -586,7 +674,7 @@ __global__ __launch_bounds__(1024) void det_merge_kernel(int K, int topk, float 
     keys[i] = key;
   }
   __syncthreads();
-  bitonic_sort(keys, NP);
+  bitonic_sort<true>(keys, NP);
   const int n = min(s_n, topk);
   for (int t = tid; t < n; t += blockDim.x) {
     const unsigned int pos = (unsigned int)(keys[t] & 0xFFFFFFFFu);
@@ -682,8 +770,19 @@ static int mine_np(int R, int top_k, int G) {
   while (np < need) np <<= 1;
   return np;
 }
+static int mine_npr(int R) { int np = 64; while (np < R) np <<= 1; return np; }
+static size_t mine_staged_lds(int R, int top_k, int G, int batch = 1) {        // keys + 25 bytes per slot (mine_label_kernel<true>)
+  const size_t nkeys = std::max((size_t)mine_np(R, top_k, G), (size_t)batch * mine_npr(R));
+  return nkeys * 8 + (size_t)top_k * G * 25 + 16;
+}
+static bool mine_staged(int R, int top_k, int G) { return mine_staged_lds(R, top_k, G) <= 144 * 1024; }
+static int mine_class_batch(int R, int top_k, int G) {          // score columns sorted side by side: as many as LDS holds, <= 8
+  int b = 1;
+  while (b < G && b < 8 && mine_staged_lds(R, top_k, G, b + 1) <= 144 * 1024) ++b;
+  return b;
+}
 static bool mine_keys_in_ws(int R, int top_k, int G) {
-  return (size_t)mine_np(R, top_k, G) * 8 + (size_t)top_k * G > 144 * 1024;
+  return !mine_staged(R, top_k, G) && (size_t)mine_np(R, top_k, G) * 8 + (size_t)top_k * G > 144 * 1024;
 }
 extern "C" long sw_mine_workspace_bytes(int R, int top_k, int G) {
   long b = (((long)top_k * G * 20 + 64) + 15) / 16 * 16;
@@ -698,15 +797,21 @@ extern "C" int sw_oicr_mine_label(int R, int ncol, int K, int n_rounds, const fl
                                   float* pgt_score, void* workspace, hipStream_t stream) {
   SW_ENTER();
   if (R > (1 << 22) || (long)top_k * G > (1 << 22) || top_k > R || G < 1 || n_rounds < 1) return -6;
+  if (((uintptr_t)boxes) & 15) return -4;                    // proposal boxes are read as float4
   const int np = mine_np(R, top_k, G);
-  const int in_ws = mine_keys_in_ws(R, top_k, G) ? 1 : 0;
-  const size_t lds = (in_ws ? 0 : (size_t)np * 8) + (size_t)top_k * G;
+  static const bool no_stage = getenv("SW_MINE_NO_STAGE") != nullptr;      // development switch
+  const bool staged = !no_stage && mine_staged(R, top_k, G);
+  const int in_ws = (!staged && (size_t)np * 8 + (size_t)top_k * G > 144 * 1024) ? 1 : 0;
+  if (in_ws && !mine_keys_in_ws(R, top_k, G)) return -6;    // (only with the development switch: the workspace has no key array)
+  const int batch = staged ? mine_class_batch(R, top_k, G) : 1;
+  const size_t lds = staged ? mine_staged_lds(R, top_k, G, batch) : (in_ws ? 0 : (size_t)np * 8) + (size_t)top_k * G;
   if (lds > 144 * 1024) return -6;
-  hipError_t e = hipFuncSetAttribute((const void*)mine_label_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto kern = staged ? mine_label_kernel<true> : mine_label_kernel<false>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(mine_label_kernel, dim3(n_rounds), dim3(1024), lds, stream, R, ncol, K, scores, gt_classes, G, boxes,
+  hipLaunchKernelGGL(kern, dim3(n_rounds), dim3(1024), lds, stream, R, ncol, K, scores, gt_classes, G, boxes,
                      top_k, score_thresh, nms_thresh, iou_bg, iou_fg, lab_class, lab_weight, lab_index, pgt_count,
-                     pgt_index, pgt_class, pgt_score, (char*)workspace, sw_mine_workspace_bytes(R, top_k, G), in_ws);
+                     pgt_index, pgt_class, pgt_score, (char*)workspace, sw_mine_workspace_bytes(R, top_k, G), in_ws, batch);
   SW_CHECK_LAUNCH();
   return 0;
 }

@@ -84,6 +84,33 @@ def test_gemm_splitk_deterministic_slabs(ops, dtype, M, N, K, pad, sk):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
+@pytest.mark.parametrize("plain", [True, False])
+def test_gemm_tail_peel_with_column_local_epilogue(ops, plain):
+    """32 x 18 tiles of 256 x 256 = 2.25 rounds of 256 CUs: sw_gemm peels the last two tile columns into a second launch.  The
+    plain f32 form (fc weight gradients) and the bias / ReLU-mask / bf16-output / absmax form (fc6's data gradient: 32 x 98
+    tiles) both have to equal the unpeeled contraction, column for column."""
+    M, N, K = 8000, 4600, 128
+    dt = torch.bfloat16
+    a = _rand((M, K), 41, dt).cuda(); w = _rand((N, K), 42, dt).cuda()
+    want = a.double() @ w.double().t()
+    if plain:
+        C = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm(a, w, C, M, N, K)
+        assert ((C.double() - want).abs().max() / want.abs().max()) < 2e-5
+        return
+    bias = _rand((N,), 43).cuda(); refm = _rand((M, N), 44, dt).cuda()
+    amax = torch.zeros(1, device="cuda")
+    C = torch.full((M, N + 8), float("nan"), device="cuda", dtype=dt)[:, :N]
+    ep = ops.make_epilogue(bias=bias, relu_ref=refm, ref_scale=1.0, out_dtype=dt, absmax_out=amax)
+    ops.gemm(a, w, C, M, N, K, ep=ep)
+    ref = (want + bias.double()) * (refm.double() > 0)
+    assert torch.isfinite(C.float()).all()
+    assert ((C.double() - ref).abs().max() / ref.abs().max()) < 1e-2          # bf16 output rounding
+    assert abs(amax.item() - C.float().abs().max().item()) <= 1e-2 * amax.item()
+    for c in (0, 4095, 4096, 4599):                                          # either side of the peel boundary
+        assert ((C[:, c].double() - ref[:, c]).abs().max() / ref.abs().max()) < 1e-2
+
+
 # ------------------------------------------------------------------------------------------ conv
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
