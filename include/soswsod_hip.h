@@ -240,6 +240,10 @@ int sw_threshold_select(int n, const float* scores, const int32_t* classes, cons
                         int32_t* out_classes, float* out_scores, int32_t* out_index, sw_stream_t stream);
 /* *counter += increment, in stream order (one thread): the dropout stream position of sw_epilogue.drop_offset_dev */
 int sw_counter_add(uint64_t* counter, uint64_t increment, sw_stream_t stream);
+/* n device-to-device byte copies in one launch (input staging into a captured step's static buffers; replaces n
+ * `Tensor.copy_` calls of DatasetMapperMultiInput-shaped batches, dataset_mapper.py:272-439).  Regions must not overlap. */
+typedef struct sw_copy_desc { const void* src; void* dst; long bytes; } sw_copy_desc;
+int sw_copy_multi(int n, const sw_copy_desc* copies, sw_stream_t stream);
 /* out[n] = sum_m X[m][ld..] (column sums; the bias gradients of the reference's conv / Linear backward).  out f32,
  * overwritten.  With `workspace` (sw_colsum_workspace_floats floats) the sum is deterministic: partial rows per row chunk,
  * then an ordered fold.  workspace NULL (or N / ld not a multiple of 16 bytes): zero fill + one f32 atomic per column and
@@ -265,6 +269,9 @@ int sw_nchw_to_nhwc(int dtype, int N, int C, int H, int W, int cpad, const float
                     sw_stream_t stream);
 /* ReLU backward in place: grad = ref > 0 ? grad : 0  (F.relu_ backward, vgg.py:105-116). */
 int sw_relu_bwd(int dtype, long n, const void* ref, void* grad, sw_stream_t stream);
+/* The same into a separate buffer: out = ref > 0 ? grad : 0 (the backbone's entry gradient belongs to autograd and is not
+ * modified; out == grad is allowed). */
+int sw_relu_bwd_out(int dtype, long n, const void* ref, const void* grad, void* out, sw_stream_t stream);
 /* out[m][n] = in[m][n] * colscale[n] (f32 -> dtype): applies each loss term's cotangent to its logit columns. */
 int sw_scale_cols(int dtype, int M, int N, const float* in, long ld_in, const float* colscale, void* out,
                   long ld_out, sw_stream_t stream);

@@ -43,6 +43,11 @@ class WgradFold(ctypes.Structure):
                 ("dw_oihw", ctypes.c_void_p)]
 
 
+class CopyDesc(ctypes.Structure):
+    """sw_copy_desc"""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_long)]
+
+
 class ColsumFold(ctypes.Structure):
     """sw_colsum_fold_desc"""
     _fields_ = [("N", ctypes.c_int), ("n_partial_rows", ctypes.c_int), ("workspace", ctypes.c_void_p), ("out", ctypes.c_void_p)]
@@ -111,6 +116,7 @@ SIGNATURES = {
     "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_relu_bwd": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    "sw_relu_bwd_out": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_scale_cols": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
     "sw_to_f32": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "sw_fill_zero": (c_int, [c_void_p, c_long, c_void_p]),
@@ -129,6 +135,7 @@ SIGNATURES = {
     "sw_threshold_select": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
     "sw_counter_add": (c_int, [c_void_p, c_u64, c_void_p]),
+    "sw_copy_multi": (c_int, [c_int, ctypes.POINTER(CopyDesc), c_void_p]),
     "sw_pack_views": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
                               c_void_p]),
     "sw_version": (ctypes.c_char_p, []),

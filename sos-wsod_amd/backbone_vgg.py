@@ -259,7 +259,7 @@ class _VGGFunction(torch.autograd.Function):
         # dz of the last conv: ReLU backward of the output feature (idempotent if the producer already masked)
         last_out = stage_info[-1][0][-1][1]
         assert stage_info[-1][1] is None, "backward expects the last stage to have no pool (vgg.py:197)"
-        dz = ops.relu_bwd(last_out, g.clone())
+        dz = ops.relu_bwd(last_out, g, out=torch.empty_like(g))      # autograd owns g: masked copy, not in place
         pidx = len(params)
         for si in range(len(stage_info) - 1, -1, -1):
             blk = module.blocks[si]

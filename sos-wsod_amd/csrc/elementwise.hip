@@ -617,11 +617,11 @@ __global__ void nchw_to_nhwc_kernel(int N, int C, int H, int W, int cpad, const 
   }
 }
 
-// ReLU backward: g = ref > 0 ? g : 0 (in place)
+// ReLU backward: out = ref > 0 ? g : 0 (out may be g)
 template <typename T>
-__global__ void relu_bwd_kernel(long n, const T* __restrict__ ref, T* __restrict__ g) {
+__global__ void relu_bwd_kernel(long n, const T* __restrict__ ref, const T* g, T* out) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    if (!(Elem<T>::load(ref + i) > 0.f)) Elem<T>::store(g + i, 0.f);
+    out[i] = Elem<T>::load(ref + i) > 0.f ? g[i] : (T)0;
 }
 
 // out[m][n] = in[m][n] * colscale[n]  (f32 -> dtype): applies the per-loss cotangents to the unit logit gradients
@@ -874,14 +874,18 @@ extern "C" int sw_nchw_to_nhwc(int dtype, int N, int C, int H, int W, int cpad, 
   return 0;
 }
 
-extern "C" int sw_relu_bwd(int dtype, long n, const void* ref, void* grad, hipStream_t stream) {
+extern "C" int sw_relu_bwd_out(int dtype, long n, const void* ref, const void* grad, void* out, hipStream_t stream) {
   SW_ENTER();
   if (n <= 0) return 0;
   DISPATCH_T(dtype,
-    hipLaunchKernelGGL(relu_bwd_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const unsigned short*)ref, (unsigned short*)grad),
-    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const float*)ref, (float*)grad));
+    hipLaunchKernelGGL(relu_bwd_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const unsigned short*)ref, (const unsigned short*)grad, (unsigned short*)out),
+    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const float*)ref, (const float*)grad, (float*)out));
   SW_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int sw_relu_bwd(int dtype, long n, const void* ref, void* grad, hipStream_t stream) {
+  return sw_relu_bwd_out(dtype, n, ref, grad, grad, stream);
 }
 
 extern "C" int sw_scale_cols(int dtype, int M, int N, const float* in, long ld_in, const float* colscale, void* out,
@@ -1281,6 +1285,46 @@ extern "C" int sw_pack_views(int R, const float* const* box_ptrs4, const float* 
   for (int v = 0; v < 4; ++v) { a.box[v] = box_ptrs4[v]; a.obj[v] = obj_ptrs4[v]; }
   hipLaunchKernelGGL(pack_views_kernel, dim3((4 * R + 255) / 256), dim3(256), 0, stream, R, a, boxes, obj, rois);
   SW_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- several device-to-device copies in one launch (the step's input staging: 4 images + 4 x (boxes, objectness) into the
+// captured graph's static buffers was 12 copy-engine launches, ~75 us of stream time for 3 MB)
+namespace {
+constexpr int COPY_MAX = 16;
+struct CopyArgs { const char* src[COPY_MAX]; char* dst[COPY_MAX]; long bytes[COPY_MAX]; };
+__global__ __launch_bounds__(256) void copy_multi_kernel(CopyArgs a) {
+  const int t = blockIdx.y;
+  const char* __restrict__ src = a.src[t]; char* __restrict__ dst = a.dst[t];
+  const long n = a.bytes[t];
+  const long stride = (long)gridDim.x * blockDim.x, first = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+    const long nv = n >> 4;
+    for (long i = first; i < nv; i += stride) ((u32x4*)dst)[i] = ((const u32x4*)src)[i];
+    for (long i = (nv << 4) + first; i < n; i += stride) dst[i] = src[i];
+  } else {
+    for (long i = first; i < n; i += stride) dst[i] = src[i];
+  }
+}
+}  // namespace
+
+extern "C" int sw_copy_multi(int n, const sw_copy_desc* copies, hipStream_t stream) {
+  SW_ENTER();
+  for (int base = 0; base < n; base += COPY_MAX) {
+    CopyArgs a = {};
+    const int m = n - base < COPY_MAX ? n - base : COPY_MAX;
+    long longest = 0;
+    for (int i = 0; i < m; ++i) {
+      a.src[i] = (const char*)copies[base + i].src; a.dst[i] = (char*)copies[base + i].dst; a.bytes[i] = copies[base + i].bytes;
+      if (a.bytes[i] < 0 || (a.bytes[i] > 0 && (!a.src[i] || !a.dst[i]))) return -1;
+      longest = a.bytes[i] > longest ? a.bytes[i] : longest;
+    }
+    if (longest == 0) continue;
+    long blocks = (longest / 16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+    hipLaunchKernelGGL(copy_multi_kernel, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, stream, a);
+    SW_CHECK_LAUNCH();
+  }
   return 0;
 }
 

@@ -506,6 +506,19 @@ def threshold_select(scores, classes, boxes, thres, allowed=None):
     return cnt, ob, oc, osc, oi
 
 
+def copy_multi(pairs):
+    """[(src, dst)] contiguous device tensors of equal dtype and shape: all copied by one launch"""
+    from ._lib import CopyDesc
+    pairs = [(s, d) for s, d in pairs if d.numel()]
+    if not pairs:
+        return
+    arr = (CopyDesc * len(pairs))()
+    for i, (s, d) in enumerate(pairs):
+        assert s.is_cuda and d.is_cuda and s.dtype == d.dtype and s.shape == d.shape and s.is_contiguous() and d.is_contiguous()
+        arr[i].src, arr[i].dst, arr[i].bytes = s.data_ptr(), d.data_ptr(), d.numel() * d.element_size()
+    check(lib.sw_copy_multi(len(pairs), arr, _stream()), "sw_copy_multi")
+
+
 def counter_add(counter_u64, increment):
     """*counter += increment in stream order (the device-resident dropout stream position)"""
     check(lib.sw_counter_add(_p(counter_u64), int(increment), _stream()), "sw_counter_add")
@@ -527,9 +540,11 @@ def nchw_to_nhwc(x_nchw_f32, out_nhwc):
     return out_nhwc
 
 
-def relu_bwd(ref, grad):
-    check(lib.sw_relu_bwd(dt(grad), grad.numel(), _p(ref), _p(grad), _stream()), "sw_relu_bwd")
-    return grad
+def relu_bwd(ref, grad, out=None):
+    """out = ref > 0 ? grad : 0; in place on `grad` when no `out` is given"""
+    out = grad if out is None else out
+    check(lib.sw_relu_bwd_out(dt(grad), grad.numel(), _p(ref), _p(grad), _p(out), _stream()), "sw_relu_bwd_out")
+    return out
 
 
 def scale_cols(src_f32, colscale, dst, M, N):

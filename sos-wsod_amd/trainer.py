@@ -252,11 +252,17 @@ class _StepGraphs:
         return out
 
     def _stage(self, static, data):
+        pairs, slow = [], []
         for s, x in zip(static, data):
             for k in self.VIEW_KEYS:
-                s["image" + k].copy_(x["image" + k], non_blocking=True)
-                s["proposals" + k].proposal_boxes.tensor.copy_(x["proposals" + k].proposal_boxes.tensor, non_blocking=True)
-                s["proposals" + k].objectness_logits.copy_(x["proposals" + k].objectness_logits, non_blocking=True)
+                for src, dst in ((x["image" + k], s["image" + k]),
+                                 (x["proposals" + k].proposal_boxes.tensor, s["proposals" + k].proposal_boxes.tensor),
+                                 (x["proposals" + k].objectness_logits, s["proposals" + k].objectness_logits)):
+                    (pairs if src.dtype == dst.dtype and src.is_contiguous() else slow).append((src, dst))
+        from . import ops
+        ops.copy_multi(pairs)                       # one launch for the whole batch (12 tensors per image)
+        for src, dst in slow:
+            dst.copy_(src, non_blocking=True)
         self.heads.stage_labels([x["instances1"] for x in data], self.labels)
 
     def step(self, data):

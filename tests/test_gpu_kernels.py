@@ -661,3 +661,23 @@ def test_colsum_workspace_form(ops, dtype, M, N, pad):
     torch.cuda.synchronize()
     np.testing.assert_allclose(cs_a.cpu().numpy(), want, **tol)
     np.testing.assert_allclose(cs_b.cpu().numpy(), want, **tol)
+
+
+def test_copy_multi_and_relu_bwd_out(ops):
+    """sw_copy_multi: aligned / unaligned / odd-sized / empty tensors in one launch; sw_relu_bwd_out leaves its gradient input alone"""
+    g = torch.Generator().manual_seed(3)
+    srcs = [torch.randint(0, 256, (3, 512, 512), generator=g, dtype=torch.uint8), torch.randn(2000, 4, generator=g),
+            torch.randn(2000, generator=g), torch.randn(1037, generator=g), torch.randint(0, 256, (77,), generator=g, dtype=torch.uint8),
+            torch.empty(0)] + [torch.randn(33 + i, generator=g) for i in range(14)]           # 20 tensors: two launches
+    srcs = [s.cuda() for s in srcs]
+    srcs[3] = srcs[3][1:]                                       # 4-byte aligned source: the byte-wise branch
+    dsts = [torch.zeros_like(s) for s in srcs]
+    assert (srcs[3].data_ptr() & 15) != 0
+    ops.copy_multi(list(zip(srcs, dsts)))
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(s, d)
+    for dt_ in DT:
+        ref = _rand((1000, 64), 5, dt_).cuda(); gr = _rand((1000, 64), 6, dt_).cuda(); keep = gr.clone()
+        out = ops.relu_bwd(ref, gr, out=torch.full_like(gr, float("nan")))
+        assert torch.equal(gr, keep) and torch.equal(out, torch.where(ref > 0, gr, torch.zeros_like(gr)))
+        assert ops.relu_bwd(ref, gr) is gr and torch.equal(gr, out)
