@@ -11,7 +11,8 @@ What differs is the execution plan (MI355X-first, not a translation):
   * ROIPool writes the fc6 input directly ((R,C,7,7) order, objectness prior fused);
   * MIL scoring, pseudo-GT mining (top-p%, threshold, NMS), IoU labelling and the refinement losses are one
     kernel each, entirely device side: no .item()/nonzero host syncs inside the iteration;
-  * forward and backward are ONE autograd node with an explicit backward (no autograd tape over ~200 ops);
+  * the forward is ONE block with an explicit backward (no autograd tape over ~200 ops), cut into three autograd
+    nodes only so that the gradients are released in the order they are produced (see _HeadsPoolFunction);
     the loss kernels emit unit logit-gradients in the forward sweep, the backward only scales them by the
     incoming cotangents.
 Reference quirks kept on purpose: losses_k2_flip pairs predictions_k2 with the flipped targets
@@ -101,26 +102,73 @@ class _DropoutStream:
         self.heads._drop_counter = int(state.get("drop_counter", self.heads._drop_counter))
 
 
-class _HeadsTrainFunction(torch.autograd.Function):
-    """(feat_0 .. feat_{n-1}, *head params) -> (vector of 1 + 2*refine_K losses, their sum)."""
+# The heads are ONE forward computation and a backward in three stages, each its own autograd node, so that the gradients leave
+# in the order they are produced and a data-parallel reducer (DDP hooks fire when a node returns) can start on them while the
+# rest of the backward still runs:
+#   _HeadsLossFunction  (handle, fc7 + predictor params) -> (loss vector, total)   backward: logits -> ... -> dZ1; releases the
+#                                                                                  predictor / fc7 gradients (68 MB)
+#   _HeadsFc6Function   (handle, fc6 weight, bias)       -> handle                 backward: fc6 weight gradient; releases the 411 MB
+#                                                                                  that dominate the all-reduce
+#   _HeadsPoolFunction  (feat_0 .. feat_{n-1})           -> handle                 backward: fc6 data gradient + ROIPool backward
+# The 1.6 ms of the last stage and the whole conv backward then overlap fc6's all-reduce; as one node every gradient of the
+# heads became ready at the same instant, after the ROIPool backward.  The forward runs entirely inside the first node (the
+# parameters reach it in a plain list); the handles are 1-element tensors that only carry the graph edges, the activations
+# travel in the shared state `box[0]`.
+class _HeadsPoolFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, heads, inp, params, box, *feats):
+        st = heads._train_forward(inp, feats, params)
+        box[0] = st
+        ctx.heads, ctx.box = heads, box
+        ctx.feat_req = tuple(ctx.needs_input_grad[4:])
+        ctx.set_materialize_grads(False)
+        return heads._handle(feats[0].device, fresh=True)
 
     @staticmethod
-    def forward(ctx, heads, inp, n_feat, *args):
-        feats, params = args[:n_feat], args[n_feat:]
-        st = heads._train_forward(inp, feats, params)
-        ctx.heads, ctx.st, ctx.params = heads, st, params
-        ctx.feat_req = tuple(ctx.needs_input_grad[3:3 + n_feat])
+    def backward(ctx, g_handle):
+        st, ctx.box[0] = ctx.box[0], None
+        if g_handle is None or st is None or "dz1" not in st:
+            return (None,) * (4 + len(ctx.feat_req))
+        return (None, None, None, None) + tuple(ctx.heads._train_backward_pool(st, ctx.feat_req))
+
+
+class _HeadsFc6Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, heads, box, handle, W1, b1):
+        ctx.heads, ctx.box = heads, box
+        ctx.req = tuple(ctx.needs_input_grad[2:5])
+        ctx.set_materialize_grads(False)
+        return heads._handle(W1.device, fresh=True)
+
+    @staticmethod
+    def backward(ctx, g_handle):
+        st = ctx.box[0]
+        if g_handle is None or st is None or "dz1" not in st:
+            return (None,) * 5
+        dW1, db1 = ctx.heads._train_backward_fc6(st)
+        if not ctx.req[0]:
+            ctx.box[0] = None                      # no feature gradient wanted: this is the last stage
+        return (None, None, ctx.heads._handle(dW1.device) if ctx.req[0] else None,
+                dW1 if ctx.req[1] else None, db1 if ctx.req[2] else None)
+
+
+class _HeadsLossFunction(torch.autograd.Function):
+    """(handle, *fc7 and predictor params) -> (vector of 1 + 2*refine_K losses, their sum)."""
+
+    @staticmethod
+    def forward(ctx, heads, box, handle, *params):
+        st = box[0]
+        ctx.heads, ctx.box, ctx.params = heads, box, params
         ctx.set_materialize_grads(False)
         return st["losses"], st["total"]
 
     @staticmethod
     def backward(ctx, g_losses, g_total):
-        n_feat = len(ctx.feat_req)
-        if g_losses is None and g_total is None:
-            return (None, None, None) + (None,) * (n_feat + len(ctx.params))
-        dfeats, dparams = ctx.heads._train_backward(ctx.st, ctx.params, g_losses, g_total, ctx.feat_req)
-        ctx.st = None
-        return (None, None, None) + tuple(dfeats) + tuple(dparams)
+        st = ctx.box[0]
+        if (g_losses is None and g_total is None) or st is None:
+            return (None,) * (3 + len(ctx.params))
+        dparams = ctx.heads._train_backward_top(st, ctx.params, g_losses, g_total)
+        return (None, None, ctx.heads._handle(st["pooled"].device)) + tuple(dparams)
 
 
 @ROI_HEADS_REGISTRY.register()
@@ -454,14 +502,25 @@ class OICRPlusHeads(nn.Module):
         return idx.to(device)
 
     # ------------------------------------------------------------------ training backward (explicit)
-    def _train_backward(self, st, params, g_losses, g_total, feat_req):
+    def _handle(self, device, fresh=False):
+        """1-element tensor that carries an autograd edge between the heads' nodes (never read).  Forward outputs must be
+        fresh tensors; the backward side reuses one zero per device."""
+        if fresh:
+            return torch.empty(1, device=device, dtype=torch.float32)
+        z = getattr(self, "_zero_handle", None)
+        if z is None or z.device != device:
+            z = self._zero_handle = torch.zeros(1, device=device, dtype=torch.float32)
+        return z
+
+    def _train_backward_top(self, st, params_top, g_losses, g_total):
+        """stage 1: loss cotangents -> predictor and fc7 gradients, dZ1 (kept in `st`) — params_top = fc7 W, b, predictor pairs"""
         dt_ = self.compute_dtype
         inp = st["inp"]
-        B, Rs, offs, M = inp["B"], inp["R"], inp["off"], inp["M"]
+        B, M = inp["B"], inp["M"]
         LD = self.ld_head
-        pooled, h1, h2, W1, W2, Wh = st["pooled"], st["h1"], st["h2"], st["W1"], st["W2"], st["Wh"]
+        pooled, h1, h2, W2, Wh = st["pooled"], st["h1"], st["h2"], st["W2"], st["Wh"]
         dev = pooled.device
-        D0, D1, D2 = pooled.shape[1], h1.shape[1], h2.shape[1]
+        D1, D2 = h1.shape[1], h2.shape[1]
         # cotangent of each loss (+ the total's) -> its logit columns, x 1/B (mean over the images); unit gradients -> compute dtype
         if not hasattr(self, "_c2l") or self._c2l.device != dev:
             self._c2l = self._col_to_loss(dev)
@@ -495,13 +554,42 @@ class OICRPlusHeads(nn.Module):
             ops.gemm(dz2, h1, dW2, D2, D1, M, a_kstrided=True, b_kstrided=True)
         dz1 = _padded(M, D1, dev, dt_)
         ops.gemm(dz2, W2, dz1, M, D1, D2, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h1, ref_scale=rs, out_dtype=dt_))
-        # fc6
+        st["dz1"] = dz1
+        # split the packed gradients back onto the 10 predictor tensors (row slices are contiguous views)
+        dparams = [dW2, db2]
+        row = 0
+        for i in range(2, len(params_top), 2):
+            n = params_top[i].shape[0]
+            dparams += [dWh[row:row + n], dbh[row:row + n]]
+            row += n
+        return [g if p.requires_grad else None for g, p in zip(dparams, params_top)]
+
+    def _train_backward_fc6(self, st):
+        """stage 2: the fc6 weight and bias gradients (411 MB of the step's 544 MB of gradients)"""
+        dt_ = self.compute_dtype
+        pooled, dz1 = st["pooled"], st["dz1"]
+        dev, M = pooled.device, st["inp"]["M"]
+        D0, D1 = pooled.shape[1], dz1.shape[1]
+        epc = 8 if dt_ == torch.bfloat16 else 4
         db1 = torch.empty(D1, device=dev, dtype=torch.float32); ops.colsum(dz1, M, D1, db1)
         dW1 = torch.empty(D1, D0, device=dev, dtype=torch.float32)
-        if wgrad_nn:                                     # the tagged region holds the transpose too: one "fc6_wgrad" measurement
-            ops._launch("fc6_wgrad", lambda: ops.gemm(dz_t(dz1, D1), pooled, dW1, D1, D0, M, b_kstrided=True))
+        if M % epc == 0:                                 # dZ^T as in stage 1; the tagged region holds the transpose too: one "fc6_wgrad" measurement
+            def nn():
+                dzt = ops.transpose_2d(dz1, torch.empty(D1, M + 8 * epc, device=dev, dtype=dt_)[:, :M], M, D1)
+                ops.gemm(dzt, pooled, dW1, D1, D0, M, b_kstrided=True)
+            ops._launch("fc6_wgrad", nn)
         else:
             ops.gemm(dz1, pooled, dW1, D1, D0, M, a_kstrided=True, b_kstrided=True, tag="fc6_wgrad")
+        return dW1, db1
+
+    def _train_backward_pool(self, st, feat_req):
+        """stage 3: fc6 data gradient and the ROIPool backward of every view batch that wants a feature gradient"""
+        dt_ = self.compute_dtype
+        inp = st["inp"]
+        B, Rs, offs, M = inp["B"], inp["R"], inp["off"], inp["M"]
+        pooled, dz1, W1 = st["pooled"], st["dz1"], st["W1"]
+        dev = pooled.device
+        D0, D1 = pooled.shape[1], dz1.shape[1]
         dfeats = [None] * len(feat_req)
         if any(feat_req):
             dpooled = _padded(M, D0, dev, dt_, pad=64)          # same pitch as argmax (one pitch per ROIPool call)
@@ -525,15 +613,7 @@ class OICRPlusHeads(nn.Module):
                                      row_scale=inp["obj"][b][2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0, relu_ref=f,
                                      dout_absmax=amax, tag="roi_bwd")
                     dfeats[2 * b + s] = df
-        # split the packed gradients back onto the 10 predictor tensors (row slices are contiguous views)
-        dparams = [dW1, db1, dW2, db2]
-        row = 0
-        for i in range(4, len(params), 2):
-            n = params[i].shape[0]
-            dparams += [dWh[row:row + n], dbh[row:row + n]]
-            row += n
-        dparams = [g if p.requires_grad else None for g, p in zip(dparams, params)]
-        return dfeats, dparams
+        return dfeats
 
     # ------------------------------------------------------------------ public forward
     def _prepare_inputs(self, proposals_list, targets1, device, need_grad):
@@ -622,7 +702,11 @@ class OICRPlusHeads(nn.Module):
                                                                          need_grad=torch.is_grad_enabled())
         assert len(feats) == 2 * inp["B"]
         self.gt_classes_img_int = [g.to(torch.int64) for g in inp["gt_int32"]]
-        vec, total = _HeadsTrainFunction.apply(self, inp, len(feats), *feats, *self._flat_params())
+        params = self._flat_params()              # fc6 W, b, fc7 W, b, then the predictors' (W, b) pairs
+        box = [None]
+        h0 = _HeadsPoolFunction.apply(self, inp, params, box, *feats)
+        h1 = _HeadsFc6Function.apply(self, box, h0, params[0], params[1])
+        vec, total = _HeadsLossFunction.apply(self, box, h1, *params[2:])
         names = loss_names(self.refine_K)
         losses = LossDict(names, vec, total, self._last_finite)
         self.iter = self.iter + 1

@@ -3,8 +3,9 @@ control flow — skip empty images, forward, sum(losses)/ITER_SIZE, backward, st
 per-iteration host round trips: no .item() on the 9 losses, no gloo gather, no empty_cache().
 
 Data parallelism = the reference's: one process per GPU, torch DistributedDataParallel; on ROCm the "nccl" backend IS
-RCCL (xGMI).  Gradients leave the two autograd nodes of this model in two bursts (heads: 92 % of the bytes, first;
-backbone afterwards), so DDP's bucketed all-reduce of the fc6/fc7 gradients overlaps the conv backward.
+RCCL (xGMI).  Gradients leave the model's autograd nodes in the order they are produced: predictors + fc7 (68 MB), then fc6
+(411 MB) right after its weight-gradient GEMM, then — after fc6's data gradient, the ROIPool backward and the conv backward
+(~3.3 ms of compute the fc6 all-reduce hides behind) — the backbone's 59 MB (roi_heads_oicrplus._HeadsPoolFunction).
 
 Step rule as the reference wrote it: optimizer.step() when `iter % ITER_SIZE == 0` (:149), the LR scheduler advances every
 iteration (its hook), gradients are zeroed at the start iteration and after every step."""
@@ -79,11 +80,12 @@ class Trainer:
             ids = [dev.index] if dev.type == "cuda" else None
             # broadcast_buffers=False as the reference (train_net_multi.py:76-78); every trainable parameter is used
             # each step (REFINE_REG all True), so the unused-parameter scan is off.
-            # Buckets: DDP fills them in REVERSE registration order = the order the gradients become ready here — the heads
-            # node (predictors, fc7, fc6: 92 % of the bytes) finishes first, the backbone node last.  A parameter is never
-            # split, so fc1.weight (411 MB) is a bucket of its own whatever the cap and its all-reduce overlaps the whole conv
-            # backward that follows; bucket_cap_mb (default SW_DDP_BUCKET_MB or 128) only groups the small tensors
-            # (predictors + fc7 68 MB, the convs 59 MB) into few launches.
+            # Buckets: DDP fills them in REVERSE registration order = the order the gradients become ready here — the heads'
+            # three backward nodes release predictors + fc7, then fc6, and the backbone node comes last.  A parameter is never
+            # split, so fc1.weight (411 MB) is a bucket of its own whatever the cap; its all-reduce starts when the fc6
+            # weight-gradient GEMM has finished and overlaps fc6's data gradient, the ROIPool backward and the whole conv
+            # backward; bucket_cap_mb (default SW_DDP_BUCKET_MB or 128) only groups the small tensors (predictors + fc7
+            # 68 MB, the convs 59 MB) into few launches.
             if bucket_cap_mb is None:
                 bucket_cap_mb = float(os.environ.get("SW_DDP_BUCKET_MB", "128"))
             self.model = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, broadcast_buffers=False,

@@ -86,9 +86,9 @@ def test_gemm_splitk_deterministic_slabs(ops, dtype, M, N, K, pad, sk):
 
 @pytest.mark.parametrize("plain", [True, False])
 def test_gemm_tail_peel_with_column_local_epilogue(ops, plain):
-    """32 x 18 tiles of 256 x 256 = 2.25 rounds of 256 CUs: sw_gemm peels the last two tile columns into a second launch.  The
-    plain f32 form (fc weight gradients) and the bias / ReLU-mask / bf16-output / absmax form (fc6's data gradient: 32 x 98
-    tiles) both have to equal the unpeeled contraction, column for column."""
+    """32 x 18 tiles of 256 x 256 = 2.25 rounds of 256 CUs: sw_gemm peels the last two tile columns of the plain f32 form (fc
+    weight gradients) into a second launch; the bias / ReLU-mask / bf16-output / absmax form of the same shape runs whole.  Both
+    have to equal the contraction, column for column."""
     M, N, K = 8000, 4600, 128
     dt = torch.bfloat16
     a = _rand((M, K), 41, dt).cuda(); w = _rand((N, K), 42, dt).cuda()
