@@ -567,19 +567,22 @@ template <typename IT>
 int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, long ld, int PH, int PW, float spatial_scale, const void* feat,
                      const float* rois, int R, const float* row_scale, float row_scale_add, void* out, void* argmax,
                      hipStream_t stream) {
-  // feature-stationary form: the widest channel slab (16 / 8 / 4 bytes per pixel) whose H*W plane fits LDS, two
-  // workgroups per CU when it can (<= 76 KiB each)
+  // feature-stationary form with the widest channel slab (16 / 8 / 4 bytes per pixel) whose H*W plane fits LDS next to the 9 KiB
+  // of ROI tables — ONE workgroup per CU if need be: the per-task work outside the window scan is paid per slab, so 8 channels
+  // per lane at 16 waves per CU beat 4 channels at 32 (76x114 map, 4000 ROIs: 393 vs 439 us; 86x115: 560 vs 657 with 8- vs
+  // 4-byte slabs), and on maps too large for any two-workgroup slab (125x167, 150x200) the 4-byte slab still beats the
+  // ROI-stationary gather kernel below (1368 vs 1479, 1762 vs 2072 us) since the per-task overhead was cut (tools/roi_bench_voc.py)
   static const bool force_gather = getenv("SW_ROI_FWD_GATHER") != nullptr;    // development switch
   const size_t es = dtype == SW_BF16 ? 2 : 4;
   if (!force_gather && nimg > 0 && (((uintptr_t)feat) & 15) == 0 && H <= 255 && W <= 255) {      // 8-bit bin tables
     int pxb = 0;
     for (int cand = 16; cand >= 4 && !pxb; cand >>= 1)
-      if ((C % (cand / (int)es)) == 0 && (size_t)H * W * cand <= 70 * 1024) pxb = cand;   // + 9 KiB of ROI tables: two workgroups per CU
-    // one workgroup per CU: only slabs of >= 8 bytes per pixel — with 4-byte slabs (2 bf16 channels per lane) the per-pixel
-    // loop overhead is amortised over too little: on 125x167 / 150x200 maps (1000 / 1200-pixel views) the ROI-stationary
-    // gather kernel below was 0.9 ms per iteration faster, on 86x115 / 108x144 maps (8-byte slabs) the two are equal
-    for (int cand = 16; cand >= 8 && !pxb; cand >>= 1)
       if ((C % (cand / (int)es)) == 0 && (size_t)H * W * cand <= 150 * 1024) pxb = cand;
+    static const char* force_pxb = getenv("SW_ROI_FWD_PXB");                      // development switch: 16 / 8 / 4, 0 = gather form
+    if (force_pxb) {
+      const int want = atoi(force_pxb);
+      pxb = (want && (C % (want / (int)es)) == 0 && (size_t)H * W * want <= 150 * 1024) ? want : 0;
+    }
     if (pxb) {
 #define SW_FWD_PLANE(T, CB) return launch_fwd_plane<T, CB, IT>(nimg, H, W, C, ld, PH, PW, spatial_scale, feat, rois, R, row_scale, \
                                                                row_scale_add, out, argmax, stream)

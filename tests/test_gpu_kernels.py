@@ -327,6 +327,24 @@ def test_roi_pool_ties_and_special_values(ops, dtype):
         assert np.array_equal(got, want, equal_nan=True)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("H,W", [(100, 120), (125, 167)])
+def test_roi_pool_forward_slab_widths_of_large_maps(ops, dtype, H, W):
+    """maps whose plane only fits LDS with a narrower channel slab: 8 bytes per pixel (100x120) and 4 bytes (125x167) — bins,
+    argmax and values still bit-exact vs the C oracle"""
+    n, C, R = 2, 16, 120
+    feat = _rand((n, C, H, W), 61, dtype).float()
+    views, _ = O.make_views(H * 8, W * 8, R, tag="slab")
+    rois = np.concatenate([(np.arange(R) % n)[:, None].astype(np.float32), views[0]["boxes"]], 1).astype(np.float32)
+    ref_out, ref_arg = O.roi_pool_fwd(feat.numpy(), rois, 1.0 / 8)
+    f = _nhwc(feat).to(dtype).cuda()
+    out = torch.empty(R, C * 49, device="cuda", dtype=dtype)
+    arg = torch.empty(R, C * 49, device="cuda", dtype=ops.roi_argmax_dtype(H, W))
+    ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7)
+    assert np.array_equal(ops.argmax_to_int32(arg).cpu().numpy().reshape(ref_arg.shape), ref_arg)
+    assert torch.equal(out.cpu().float().reshape(ref_out.shape), torch.from_numpy(ref_out).to(dtype).float())
+
+
 def test_roi_pool_large_map_uses_gather_form(ops):
     """a map whose H*W plane does not fit LDS falls back to the gather kernel; > 65534 pixels needs int32 indices"""
     n, C, H, W, R = 1, 8, 260, 256, 64

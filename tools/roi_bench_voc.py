@@ -1,10 +1,11 @@
 #!/usr/bin/env python
-"""ROIPool forward / backward at a VOC-sized map (76 x 114): which slab width is faster when the plane exceeds 76 KiB?"""
+"""ROIPool forward / backward at a given map size (env RH, RW, RR; default the VOC-sized 76 x 114 map, 4000 ROIs on 2 images): which
+slab width is faster when the plane exceeds 76 KiB?  SW_ROI_FWD_PXB=16|8|4|0 forces the forward's slab bytes per pixel (0 = gather)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
-R, C, H, W = 4000, 512, 76, 114
+R, C, H, W = int(os.environ.get('RR', 4000)), 512, int(os.environ.get('RH', 76)), int(os.environ.get('RW', 114))
 g = torch.Generator().manual_seed(0)
 x1 = torch.rand(R, generator=g) * (W * 8 - 32); y1 = torch.rand(R, generator=g) * (H * 8 - 32)
 bw = 24 + torch.rand(R, generator=g) * (W * 8 - x1 - 24); bh = 24 + torch.rand(R, generator=g) * (H * 8 - y1 - 24)
@@ -19,4 +20,4 @@ def t(fn, n=10):
 tf = t(lambda: ops.roi_pool_fwd(feat, rois, out, arg, 0.125, 7, 7, row_scale=obj, row_scale_add=1.0))
 amax = ops.absmax(dout)
 tb = t(lambda: ops.roi_pool_bwd(dout, arg, rois, dfeat, 7, 7, row_scale=obj, row_scale_add=1.0, relu_ref=feat, dout_absmax=amax))
-print(f"76x114 map: roi_pool fwd {tf*1e3:.0f} us   bwd {tb*1e3:.0f} us")
+print(f"{H}x{W} map, {R} ROIs, pxb={os.environ.get('SW_ROI_FWD_PXB', 'auto')}: roi_pool fwd {tf*1e3:.0f} us   bwd {tb*1e3:.0f} us")
