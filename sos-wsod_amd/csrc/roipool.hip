@@ -354,33 +354,73 @@ __device__ __forceinline__ void pix_decode(const typename PixWord<CB * (int)size
 // earlier pixel" — 2 VALU instructions per channel and pixel instead of convert + compare + two selects.  The start
 // value key(-inf) << 16 | 0xFFFF can only be beaten by values > -inf, i.e. exactly those that beat -FLT_MAX.
 // (-0.0 shares +0.0's key, as they compare equal; a bin won by a -0.0 pixel then outputs +0.0.)
-template <typename T, int CB, int NT, typename IT, bool KEY>
+//
+// BAND = true (maps whose whole plane does not fit LDS with 16-byte pixels; KEY form only): a workgroup holds `band_rows`
+// consecutive map ROWS of all W columns instead of the whole plane, and the (ROI, bin row) pairs of its ROI chunk are dealt to the
+// band whose first `band_S` rows hold the bin's first window row; band_rows - band_S >= ceil(H / PH) + 1 rows of overlap hold the
+// rest of any window of a ROI that lies inside the image.  So large maps keep 8 channels per lane (the per-task cost outside the
+// scan and the scan's loop overhead are paid per slab: 150x200 map, 4000 ROIs: 4-byte slabs 1.76 ms) at the price of loading
+// each map row ~2x.  Window rows past the band (ROIs reaching far outside the image: their clipped bins can be as tall as the
+// map) are read from global memory by a cold loop.  The pairs owned by a band are compacted into an LDS list first.
+template <typename T, int CB>
+__device__ __forceinline__ typename PixWord<CB * (int)sizeof(T)>::type pix_to_keys(typename PixWord<CB * (int)sizeof(T)>::type w) {
+  unsigned int* u = (unsigned int*)&w;
+#pragma unroll
+  for (int i = 0; i < CB * (int)sizeof(T) / 4; ++i) {
+    unsigned int k = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned int bts = (u[i] >> (16 * h)) & 0xFFFFu;
+      unsigned int key = (bts & 0x8000u) ? (bts ^ 0xFFFFu) : (bts | 0x8000u);
+      if (bts > 0x7F80u && bts < 0x8000u) key = 0;              // +NaN never wins
+      if (bts == 0x8000u) key = 0x8000u;                        // -0.0 == +0.0 under '>': the earlier pixel wins
+      k |= key << (16 * h);
+    }
+    u[i] = k;
+  }
+  return w;
+}
+
+template <typename T, int CB, int NT, typename IT, bool KEY, bool BAND = false>
 __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, int C, long ld, int PH, int PW, float scale,
                                                                 const T* __restrict__ feat, const float* __restrict__ rois,
                                                                 int R, int chunk, const float* __restrict__ row_scale,
                                                                 float row_scale_add, T* __restrict__ out,
-                                                                IT* __restrict__ argmax) {
+                                                                IT* __restrict__ argmax, int band_S, int band_rows, int n_bands, int n_zsplit) {
+  static_assert(!BAND || KEY, "the band form exists for the packed-key scan only");
   constexpr int PXB = CB * (int)sizeof(T);
   constexpr int NWORD = PXB / 4;
   typedef typename PixWord<PXB>::type word_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_cnt;
-  word_t* plane = (word_t*)smem;                                   // [H*W] pixels x CB channels
-  int* s_list = (int*)(smem + (((size_t)H * W * PXB + 15) & ~(size_t)15));   // [chunk] ROIs of this image
+  __shared__ int s_cnt, s_ntask;
+  const int band = BAND ? (int)(blockIdx.z % n_bands) : 0, zfirst = BAND ? (int)(blockIdx.z / n_bands) : (int)blockIdx.z;
+  const int y0 = BAND ? band * band_S : 0, y1 = BAND ? min(H, y0 + band_rows) : H;      // map rows [y0, y1) live in LDS
+  const int lds_rows = BAND ? band_rows : H;
+  word_t* plane = (word_t*)smem;                                   // [rows*W] pixels x CB channels
+  int* s_list = (int*)(smem + (((size_t)lds_rows * W * PXB + 15) & ~(size_t)15));   // [chunk] ROIs of this image
   unsigned short* s_hb = (unsigned short*)(s_list + chunk);        // [chunk][PH] bin row range  start | end << 8  (H, W <= 255)
   unsigned short* s_wb = s_hb + chunk * PH;                        // [chunk][PW] bin column range
   float* s_mul = (float*)(s_wb + chunk * PW + ((chunk * (PH + PW)) & 1));   // [chunk] output scale of the ROI (4-byte aligned)
+  unsigned int* s_task = (unsigned int*)(s_mul + chunk);           // BAND: [chunk * PH] owned (ROI << 8 | bin row)
   const int c0 = blockIdx.x * CB, img = blockIdx.y;
-  const int r0 = blockIdx.z * chunk, r1 = min(R, r0 + chunk);
   const int tid = threadIdx.x;
+  const int npx = H * W;
+  const T* fimg = feat + (long)img * npx * C + c0;
+  constexpr int NC1 = 7, NCLS = NC1 * NC1;
+  __shared__ int s_hist[NCLS + 1];
+  bool plane_loaded = false;
+  // The workgroup keeps its slab (band) of the map and walks ROI chunks zfirst, zfirst + n_zsplit, ...: the slab is fetched once
+  // per workgroup, not once per chunk — every pixel's 16 bytes are their own 64-byte L2 sector at a 1 KiB NHWC pixel pitch, so the
+  // plane loads of one workgroup per chunk cost as much as the scan on large maps.  n_zsplit is sized by the host to fill the chip.
+  for (int zchunk = zfirst; zchunk * chunk < R; zchunk += n_zsplit) {
+  const int r0 = zchunk * chunk, r1 = min(R, r0 + chunk);
+  __syncthreads();                                            // the previous chunk's tables are no longer read
   // ROIs of this image, grouped by bin-window size class (counting sort): a wave holds the 49 bins of one
   // ROI plus 15 of the next, and walks every lane's window to the longest one — neighbours of similar size waste less
   // The scan below runs every lane of a wave max(window rows) x max(window columns) times, so the classes are 2-D: 7 classes
   // of the window height x 7 of its width (an area class put 2x8 and 8x2 windows side by side: 64 iterations for 16 pixels).
-  constexpr int NC1 = 7, NCLS = NC1 * NC1;
-  __shared__ int s_hist[NCLS + 1];
   if (tid <= NCLS) s_hist[tid] = 0;
-  if (tid == 0) s_cnt = 0;
+  if (tid == 0) { s_cnt = 0; s_ntask = 0; }
   __syncthreads();
   int my_cls = -1;                                            // chunk <= NT: at most one ROI per thread
   for (int r = r0 + tid; r < r1; r += NT)
@@ -397,30 +437,16 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
   if (my_cls >= 0) s_list[atomicAdd(&s_hist[my_cls], 1)] = r0 + tid;
   __syncthreads();
   const int cnt = s_cnt;
-  if (cnt == 0) return;
-  const int npx = H * W;
-  const T* fimg = feat + (long)img * npx * C + c0;
-  for (int px = tid; px < npx; px += NT) {
-    word_t w = *(const word_t*)(fimg + (long)px * C);
-    if (KEY) {
-      unsigned int* u = (unsigned int*)&w;
-#pragma unroll
-      for (int i = 0; i < NWORD; ++i) {
-        unsigned int k = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const unsigned int bts = (u[i] >> (16 * h)) & 0xFFFFu;
-          unsigned int key = (bts & 0x8000u) ? (bts ^ 0xFFFFu) : (bts | 0x8000u);
-          if (bts > 0x7F80u && bts < 0x8000u) key = 0;              // +NaN never wins
-          if (bts == 0x8000u) key = 0x8000u;                        // -0.0 == +0.0 under '>': the earlier pixel wins
-          k |= key << (16 * h);
-        }
-        u[i] = k;
-      }
+  if (cnt == 0) continue;
+  if (!plane_loaded) {
+    plane_loaded = true;
+    for (int px = tid; px < (y1 - y0) * W; px += NT) {
+      word_t w = *(const word_t*)(fimg + (long)(y0 * W + px) * C);
+      if (KEY) w = pix_to_keys<T, CB>(w);
+      plane[px] = w;
     }
-    plane[px] = w;
+    __syncthreads();
   }
-  __syncthreads();
   // bin ranges once per (ROI, bin row / column) instead of once per (ROI, bin, channel slab lane): the scan below is
   // VALU-issue bound (rocprof: 31 VALU instructions per window pixel, a third of them this per-task geometry)
   for (int i = tid; i < cnt * (PH + PW); i += NT) {
@@ -440,13 +466,36 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
   }
   __syncthreads();
   const int nb = PH * PW;
-  const int total = cnt * nb;
   constexpr unsigned KEY_INIT = 0x007FFFFFu;                       // key(-inf) << 16 | 0xFFFF
+  int ntask = cnt * PH;                                            // (ROI, bin row) pairs this workgroup works on
+  if (BAND) {
+    // the pairs whose first window row falls into this band's first band_S rows, compacted (order inside a wave kept: the size
+    // classes stay together; across waves it is whatever order the counter was reached in — the results do not depend on it)
+    const int lane = tid & 63;
+    for (int e0 = 0; e0 < cnt * PH; e0 += NT) {
+      const int e = e0 + tid;
+      bool mine = false;
+      if (e < cnt * PH) mine = min((int)(s_hb[e] & 0xFF) / band_S, n_bands - 1) == band;
+      const unsigned long long m = __ballot(mine);
+      int base = 0;
+      if (lane == 0 && m) base = atomicAdd(&s_ntask, __popcll(m));
+      base = __shfl(base, 0);
+      if (mine) { const int li_ = e / PH; s_task[base + __popcll(m & ((1ull << lane) - 1))] = (unsigned)(li_ << 8) | (unsigned)(e - li_ * PH); }
+    }
+    __syncthreads();
+    ntask = s_ntask;
+  }
+  const int total = ntask * PW;
   // task t = (ROI li of the list, bin row ph, bin column pw), t advancing by NT per iteration: carried as three counters
   // (two integer divisions per task were a fifth of the ~230 VALU instructions a task spends outside its window scan)
   const int dli = NT / nb, dph = (NT - dli * nb) / PW, dpw = NT - dli * nb - dph * PW;
   int li = tid / nb, ph = (tid - li * nb) / PW, pw = tid - li * nb - ph * PW;
+  const int dte = NT / PW, dtw = NT - dte * PW;                    // BAND: (entry of the owned list, bin column)
+  int te = tid / PW;
+  if (BAND) pw = tid - te * PW;
+  const unsigned int inv_base = 0xFFFEu - (unsigned)(y0 * W);      // plane index i holds map pixel y0 * W + i
   for (int t = tid; t < total; t += NT) {
+    if (BAND) { const unsigned int pk = s_task[te]; li = (int)(pk >> 8); ph = (int)(pk & 0xFF); }
     const int b = ph * PW + pw;
     const int r = s_list[li];
     const int hb = s_hb[li * PH + ph], wb = s_wb[li * PW + pw];
@@ -463,20 +512,35 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
         // loop / address overhead (a third of the 27 VALU per visit this scan spent; rocprof: 126 M wave instructions per
         // 4000 ROIs, VALU 86 % busy) is paid once per pair; windows 3 and 4 pixels wide both take two steps
         const int bw = we - ws;
-        for (int hh = hs; hh < he; ++hh) {
-          const int rowi = hh * W + ws;
+        const int he_lds = BAND ? min(he, y1) : he;
+        for (int hh = hs; hh < he_lds; ++hh) {
+          const int rowi = (hh - y0) * W + ws;
           for (int x = 0; x < bw; x += 2) {
             const int i0 = rowi + x, i1 = rowi + min(x + 1, bw - 1);
             const word_t w0 = plane[i0], w1 = plane[i1];
             const unsigned int* u0 = (const unsigned int*)&w0;
             const unsigned int* u1 = (const unsigned int*)&w1;
-            const unsigned int inv0 = 0xFFFEu - (unsigned)i0, inv1 = 0xFFFEu - (unsigned)i1;
+            const unsigned int inv0 = inv_base - (unsigned)i0, inv1 = inv_base - (unsigned)i1;
 #pragma unroll
             for (int i = 0; i < NWORD; ++i) {
               best[2 * i] = max(max(best[2 * i], (u0[i] << 16) | inv0), (u1[i] << 16) | inv1);
               best[2 * i + 1] = max(max(best[2 * i + 1], (u0[i] & 0xFFFF0000u) | inv0), (u1[i] & 0xFFFF0000u) | inv1);
             }
           }
+        }
+        if (BAND) {                            // window rows below the band (a ROI reaching far outside the image): from global memory
+          for (int hh = max(hs, y1); hh < he; ++hh)
+            for (int x = ws; x < we; ++x) {
+              const int gi = hh * W + x;
+              const word_t w0 = pix_to_keys<T, CB>(*(const word_t*)(fimg + (long)gi * C));
+              const unsigned int* u0 = (const unsigned int*)&w0;
+              const unsigned int inv0 = 0xFFFEu - (unsigned)gi;
+#pragma unroll
+              for (int i = 0; i < NWORD; ++i) {
+                best[2 * i] = max(best[2 * i], (u0[i] << 16) | inv0);
+                best[2 * i + 1] = max(best[2 * i + 1], (u0[i] & 0xFFFF0000u) | inv0);
+              }
+            }
         }
       }
       // key -> bf16 bits: positive values (key bit 15 set) flip that bit back, negative ones were stored complemented; the pixel
@@ -524,10 +588,16 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
       Elem<T>::store(out + o + (long)q * nb, __fmul_rn(mv[q], mul));
       argmax[o + (long)q * nb] = ArgIdx<IT>::enc(mi[q]);
     }
-    pw += dpw; ph += dph; li += dli;
-    if (pw >= PW) { pw -= PW; ++ph; }
-    if (ph >= PH) { ph -= PH; ++li; }
+    if (BAND) {
+      pw += dtw; te += dte;
+      if (pw >= PW) { pw -= PW; ++te; }
+    } else {
+      pw += dpw; ph += dph; li += dli;
+      if (pw >= PW) { pw -= PW; ++ph; }
+      if (ph >= PH) { ph -= PH; ++li; }
+    }
   }
+  }   // ROI chunks
 }
 
 
@@ -545,6 +615,18 @@ __global__ void absmax_kernel(long n, const T* __restrict__ x, float* __restrict
 }  // namespace
 
 namespace {
+// workgroups per (slab, image, band) = how many ways the ROI chunks are dealt out: enough workgroups to fill the chip a few times
+// over (the chunks differ in work), no more (each one fetches its slab of the map)
+inline int fwd_zsplit(int wg_per_z, int n_chunks, size_t lds) {
+  // measured (tools/roi_bench_voc.py, SW_ROI_FWD_WGS sweep): one-workgroup-per-CU slabs 512-1024 workgroups (150x200 map: 1.36 ms
+  // at 1024, 1.52 at 4096), two-per-CU slabs flat from 512 to 4096
+  static const int forced = getenv("SW_ROI_FWD_WGS") ? atoi(getenv("SW_ROI_FWD_WGS")) : 0;      // development switch
+  const int target = forced ? forced : (lds > 80 * 1024 ? 768 : 2048);
+  int nz = (target + wg_per_z - 1) / wg_per_z;
+  nz = nz < 1 ? 1 : nz;
+  return nz > n_chunks ? n_chunks : nz;
+}
+
 template <typename T, int CB, typename IT>
 int launch_fwd_plane(int nimg, int H, int W, int C, long ld, int PH, int PW, float scale, const void* feat, const float* rois, int R,
                      const float* row_scale, float row_scale_add, void* out, void* argmax, hipStream_t stream) {
@@ -556,9 +638,42 @@ int launch_fwd_plane(int nimg, int H, int W, int C, long ld, int PH, int PW, flo
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  dim3 grid(C / CB, nimg, (R + CHUNK - 1) / CHUNK), block(NT);
+  const int nz = fwd_zsplit((C / CB) * nimg, (R + CHUNK - 1) / CHUNK, lds);
+  dim3 grid(C / CB, nimg, nz), block(NT);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, H, W, C, ld, PH, PW, scale, (const T*)feat, rois, R, CHUNK, row_scale,
-                     row_scale_add, (T*)out, (IT*)argmax);
+                     row_scale_add, (T*)out, (IT*)argmax, H, H, 1, nz);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+// band form (bf16, 8 channels per lane): rows per band from the LDS left beside the ROI tables and the owned-pair list
+constexpr int BAND_CHUNK = 256;
+inline size_t band_tables_bytes(int PH, int PW) {
+  return (size_t)BAND_CHUNK * (4 + 2 * (PH + PW)) + 4 + (size_t)BAND_CHUNK * 4 + (size_t)BAND_CHUNK * PH * 4;
+}
+inline bool band_geometry(int H, int W, int PH, int PW, int* S, int* rows) {
+  const size_t budget = 160 * 1024 - 1024 - band_tables_bytes(PH, PW);     // 1 KiB: the kernel's static LDS + alignment
+  const int fit = (int)(budget / ((size_t)W * 16));
+  const int halo = (H + PH - 1) / PH + 1;          // a bin window of a ROI inside the image: <= ceil(H / PH) + 1 rows
+  if (fit - halo < 8 || PH > 255) return false;
+  *S = fit - halo; *rows = fit;
+  return true;
+}
+template <typename IT>
+int launch_fwd_band(int nimg, int H, int W, int C, long ld, int PH, int PW, float scale, const void* feat, const float* rois, int R,
+                    const float* row_scale, float row_scale_add, void* out, void* argmax, int S, int rows, hipStream_t stream) {
+  constexpr int NT = 1024, CB = 8;
+  typedef unsigned short T;
+  const size_t lds = (((size_t)rows * W * 16 + 15) & ~(size_t)15) + band_tables_bytes(PH, PW);
+  auto kern = roi_pool_fwd_plane_kernel<T, CB, NT, IT, true, true>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  const int n_bands = (H + S - 1) / S, n_chunks = (R + BAND_CHUNK - 1) / BAND_CHUNK;
+  const int nz = fwd_zsplit((C / CB) * nimg * n_bands, n_chunks, lds);
+  if ((long)n_bands * nz > 65535) return -6;
+  dim3 grid(C / CB, nimg, n_bands * nz), block(NT);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, H, W, C, ld, PH, PW, scale, (const T*)feat, rois, R, BAND_CHUNK, row_scale,
+                     row_scale_add, (T*)out, (IT*)argmax, S, rows, n_bands, nz);
   SW_CHECK_LAUNCH();
   return 0;
 }
@@ -583,6 +698,12 @@ int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, long ld, int PH, 
       const int want = atoi(force_pxb);
       pxb = (want && (C % (want / (int)es)) == 0 && (size_t)H * W * want <= 150 * 1024) ? want : 0;
     }
+    static const bool no_band = getenv("SW_ROI_FWD_NO_BAND") != nullptr;            // development switch
+    int bS = 0, brows = 0;
+    if (!no_band && !force_pxb && dtype == SW_BF16 && pxb < 16 && (C % 8) == 0 && (long)H * W < 65535 &&
+        band_geometry(H, W, PH, PW, &bS, &brows))
+      return launch_fwd_band<IT>(nimg, H, W, C, ld, PH, PW, spatial_scale, feat, rois, R, row_scale, row_scale_add, out, argmax,
+                                 bS, brows, stream);
     if (pxb) {
 #define SW_FWD_PLANE(T, CB) return launch_fwd_plane<T, CB, IT>(nimg, H, W, C, ld, PH, PW, spatial_scale, feat, rois, R, row_scale, \
                                                                row_scale_add, out, argmax, stream)

@@ -330,12 +330,16 @@ def test_roi_pool_ties_and_special_values(ops, dtype):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("H,W", [(100, 120), (125, 167)])
 def test_roi_pool_forward_slab_widths_of_large_maps(ops, dtype, H, W):
-    """maps whose plane only fits LDS with a narrower channel slab: 8 bytes per pixel (100x120) and 4 bytes (125x167) — bins,
-    argmax and values still bit-exact vs the C oracle"""
+    """maps whose whole plane does not fit LDS with 16-byte pixels: bf16 runs the band form (row bands of 8-channel slabs; ROIs
+    reaching far outside the image exercise its beyond-the-band rows), f32 the narrower slabs — bins, argmax and values still
+    bit-exact vs the C oracle"""
     n, C, R = 2, 16, 120
     feat = _rand((n, C, H, W), 61, dtype).float()
     views, _ = O.make_views(H * 8, W * 8, R, tag="slab")
-    rois = np.concatenate([(np.arange(R) % n)[:, None].astype(np.float32), views[0]["boxes"]], 1).astype(np.float32)
+    boxes = views[0]["boxes"].copy()
+    boxes[:6] = [[0, 0, 1e4, 1e4], [-900, -700, 8 * W + 500, 8 * H + 900], [40, -3000, 300, 5000], [-50, -50, -10, -10],
+                 [8 * W - 9, 8 * H - 9, 8 * W + 40, 8 * H + 40], [0, 8 * H - 200, 8 * W, 8 * H - 1]]   # bins taller than a band's overlap
+    rois = np.concatenate([(np.arange(R) % n)[:, None].astype(np.float32), boxes], 1).astype(np.float32)
     ref_out, ref_arg = O.roi_pool_fwd(feat.numpy(), rois, 1.0 / 8)
     f = _nhwc(feat).to(dtype).cuda()
     out = torch.empty(R, C * 49, device="cuda", dtype=dtype)
