@@ -272,6 +272,14 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
     const int cnt = s_cnt;
     for (int l0 = wave * 8; l0 < cnt; l0 += nwave * 8) {
       for (int j = lane; j < nvec; j += 64) {
+        // channel row of each of the lane's 4 elements, formed ONCE per step and outside the range test below: left inside it, the
+        // compiler sank the division by nb into every element's guarded block (16 of its 27 VALU instructions)
+        int crow[4];
+        {
+          const int q0 = (j * 4) / nb, rem0 = j * 4 - q0 * nb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) crow[e] = (q0 + (rem0 + e >= nb ? 1 : 0)) * npix;
+        }
         u32x4 av[8]; u32x4 dv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -288,19 +296,20 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
           const float mul = s_m[l0 + u];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            int a; float d;
-            if (sizeof(IT) == 4) a = (int)av[u][e];
-            else a = ArgIdx<unsigned short>::dec((unsigned short)((av[u][e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
+            // "no pixel" (-1, or 0xFFFF in the 16-bit form: maps hold < 65535 pixels) and pixels of other ranges fail ONE
+            // unsigned compare of the index relative to this workgroup's range
+            unsigned int rel; float d;
+            if (sizeof(IT) == 4) rel = av[u][e] - (unsigned)p0;
+            else rel = ((av[u][e >> 1] >> (16 * (e & 1))) & 0xFFFFu) - (unsigned)p0;
             if (sizeof(T) == 2) d = __uint_as_float((e & 1) ? (dv[u][e >> 1] & 0xFFFF0000u) : (dv[u][e >> 1] << 16));
             else d = __uint_as_float(dv[u][e]);
-            const int cc = (j * 4 + e) / nb;
-            if (a >= p0 && a < p1) {
+            if (rel < (unsigned)npix) {
               if (sizeof(ACC) == 8) {
                 const long long q = __float2ll_rn(scalbnf(__fmul_rn(d, mul), frac));
-                atomicAdd((unsigned long long*)&acc[cc * npix + (a - p0)], (unsigned long long)q);
+                atomicAdd((unsigned long long*)&acc[crow[e] + (int)rel], (unsigned long long)q);
               } else {
                 const int q = __float2int_rn(scalbnf(__fmul_rn(d, mul), frac));
-                atomicAdd((unsigned int*)&acc[cc * npix + (a - p0)], (unsigned int)q);
+                atomicAdd((unsigned int*)&acc[crow[e] + (int)rel], (unsigned int)q);
               }
             }
           }
