@@ -201,6 +201,12 @@ int sw_oicr_refine_loss(int V, int R, int K, int n_rounds, const float* logits, 
                         float* loss_view, float* dlogits, long ld_d, const float* grad_scale, float* workspace,
                         sw_stream_t stream);
 
+/* Stage-3 (Unbiased-Teacher) focal classification loss of the ROI heads, replaces FastRCNNFocalLoss.comput_focal_loss +
+ * FocalLoss.forward (unbias/ubteacher/modeling/roi_heads/fast_rcnn.py:73-105):
+ *   loss[0] = sum_r (1 - p_r)^gamma * CE_r / N,  CE_r = cross_entropy(logits[r], targets[r]),  p_r = exp(-CE_r);
+ * dlogits (nullable, N x C, pitch ld_d) receives dloss/dlogits.  workspace: N floats.  Rows are summed in a fixed order. */
+int sw_focal_loss(int N, int C, const float* logits, long ld, const int32_t* targets, float gamma, float* loss,
+                  float* dlogits, long ld_d, float* workspace, sw_stream_t stream);
 /* ---- inference (reference: OICRPlusHeads._forward_box_test roi_heads_oicrplus.py:432-475, predict_probs_K /
  *      predict_boxes_K fast_rcnn_oicr.py:674-735, Box2BoxTransform.apply_deltas box_regression.py:73-110,
  *      fast_rcnn_inference_single_image fast_rcnn_oicr.py:86-148 incl. torchvision batched_nms) ----------------

@@ -6,6 +6,8 @@ CPU restatement of the model-independent parts of the Stage-3 Unbiased-Teacher s
     :436-549  run_step_full_semisup     (burn-in, teacher refresh schedule, loss weighting: *_pseudo box losses x 0, other
                                          *_pseudo losses x UNSUP_LOSS_WEIGHT, supervised x 1)
     :588-604  _update_teacher_model     (teacher = student * (1 - keep) + teacher * keep, float32)
+  /root/reference/unbias/ubteacher/modeling/roi_heads/fast_rcnn.py
+    :73-105   comput_focal_loss / FocalLoss.forward   (CE = cross_entropy(x, t); p = exp(-CE); sum (1 - p)^gamma CE / N)
 
 PARITY PINNING: parity unpinned — the reference file imports the whole detectron2 engine / data stack (absent here: fvcore,
 yacs, …), so no fixture could be generated from it; these few lines are restated from the source text cited above and the
@@ -58,3 +60,23 @@ def teacher_action(it: int, burn_up_step: int, update_iter: int):
     if (it - burn_up_step) % update_iter == 0:
         return "ema"
     return "none"
+
+
+def focal_loss(logits, targets, gamma=1.5):
+    """fast_rcnn.py:73-105 in float64 (value and d loss / d logits): F.cross_entropy(reduction="none"), p = exp(-CE),
+    sum((1 - p)^gamma * CE) / N"""
+    x = np.asarray(logits, np.float64)
+    t = np.asarray(targets, np.int64)
+    n = x.shape[0]
+    m = x.max(1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(x - m).sum(1))
+    ce = lse - x[np.arange(n), t]
+    p = np.exp(-ce)
+    om = 1.0 - p
+    loss = (om ** gamma * ce).sum() / n
+    sm = np.exp(x - lse[:, None])
+    onehot = np.zeros_like(x); onehot[np.arange(n), t] = 1.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dw = np.where(om > 0, gamma * om ** (gamma - 1.0) * p * ce, 0.0)
+    g = (om ** gamma + dw)[:, None] * (sm - onehot) / n
+    return loss, g

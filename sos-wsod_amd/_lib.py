@@ -135,6 +135,7 @@ SIGNATURES = {
     "sw_threshold_select": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
     "sw_counter_add": (c_int, [c_void_p, c_u64, c_void_p]),
+    "sw_focal_loss": (c_int, [c_int, c_int, c_void_p, c_long, c_void_p, c_float, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_copy_multi": (c_int, [c_int, ctypes.POINTER(CopyDesc), c_void_p]),
     "sw_pack_views": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
                               c_void_p]),

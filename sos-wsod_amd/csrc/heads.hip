@@ -302,6 +302,49 @@ __global__ __launch_bounds__(256) void refine_reduce_kernel(int R, const float* 
   if (threadIdx.x == 0) loss_view[blockIdx.x] = s / (float)R;           // mean over ALL R (:269-273) / sum over R (:351)
 }
 
+// ------------------------------------------------------------------------------------------- Stage-3 focal classification loss
+// unbias/ubteacher/modeling/roi_heads/fast_rcnn.py:73-105 (FastRCNNFocalLoss.comput_focal_loss + FocalLoss.forward):
+//   CE_r = logsumexp(x_r) - x_r[t_r];  p_r = exp(-CE_r);  loss = sum_r (1 - p_r)^gamma * CE_r / N
+// One wave per proposal row (C = K + 1 <= a few hundred logits): max / sum-exp by wave shuffles, the per-row term to a scratch
+// array (ordered sum by focal_reduce_kernel: deterministic), and the unit gradient
+//   dloss/dx_j = scale * ((1 - p)^gamma + gamma * (1 - p)^(gamma - 1) * p * CE) * (softmax_j - [j == t])        (d(1 - p)/dCE = p)
+__global__ __launch_bounds__(256) void focal_loss_kernel(int N, int C, const float* __restrict__ logits, long ld,
+                                                         const int* __restrict__ target, float gamma, float scale,
+                                                         float* __restrict__ row_loss, float* __restrict__ dlogits, long ld_d) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= N) return;
+  const float* x = logits + (long)r * ld;
+  const int t = target[r];
+  float m = -FLT_MAX;
+  for (int j = lane; j < C; j += 64) m = fmaxf(m, x[j]);
+  m = wave_reduce_max(m);
+  float se = 0.f;
+  for (int j = lane; j < C; j += 64) se += expf(x[j] - m);
+  se = wave_reduce_sum(se);
+  const float lse = m + logf(se);
+  const float ce = lse - x[t];
+  const float p = expf(-ce);
+  const float om = fmaxf(1.f - p, 0.f);
+  const float w = powf(om, gamma);
+  if (lane == 0) row_loss[r] = w * ce;
+  if (dlogits) {
+    const float dw = (gamma > 0.f && om > 0.f) ? gamma * powf(om, gamma - 1.f) * p * ce : 0.f;
+    const float g = scale * (w + dw);
+    float* d = dlogits + (long)r * ld_d;
+    for (int j = lane; j < C; j += 64) d[j] = g * (expf(x[j] - lse) - (j == t ? 1.f : 0.f));
+  }
+}
+
+__global__ __launch_bounds__(1024) void focal_reduce_kernel(int N, float scale, const float* __restrict__ row_loss,
+                                                            float* __restrict__ loss) {
+  __shared__ float red[32];
+  float s = 0.f;
+  for (int r = threadIdx.x; r < N; r += blockDim.x) s += row_loss[r];
+  s = block_reduce_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = s * scale;
+}
+
 // ------------------------------------------------------------------------------------------- mining + labelling
 __device__ __forceinline__ unsigned int orderable(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -812,6 +855,19 @@ extern "C" int sw_oicr_mine_label(int R, int ncol, int K, int n_rounds, const fl
   hipLaunchKernelGGL(kern, dim3(n_rounds), dim3(1024), lds, stream, R, ncol, K, scores, gt_classes, G, boxes,
                      top_k, score_thresh, nms_thresh, iou_bg, iou_fg, lab_class, lab_weight, lab_index, pgt_count,
                      pgt_index, pgt_class, pgt_score, (char*)workspace, sw_mine_workspace_bytes(R, top_k, G), in_ws, batch);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_focal_loss(int N, int C, const float* logits, long ld, const int32_t* targets, float gamma, float* loss,
+                             float* dlogits, long ld_d, float* workspace, hipStream_t stream) {
+  SW_ENTER();
+  if (N <= 0 || C <= 0) return -1;           // the reference returns 0 * logits.sum() for an empty batch: the caller's branch
+  const float scale = 1.0f / (float)N;       // total_loss / gt_classes.shape[0]
+  hipLaunchKernelGGL(focal_loss_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, N, C, logits, ld, targets, gamma, scale, workspace,
+                     dlogits, ld_d);
+  SW_CHECK_LAUNCH();
+  hipLaunchKernelGGL(focal_reduce_kernel, dim3(1), dim3(1024), 0, stream, N, scale, workspace, loss);
   SW_CHECK_LAUNCH();
   return 0;
 }

@@ -519,6 +519,16 @@ def copy_multi(pairs):
     check(lib.sw_copy_multi(len(pairs), arr, _stream()), "sw_copy_multi")
 
 
+def focal_loss(logits, targets_i32, gamma, loss, dlogits=None):
+    """loss[0] = sum_r (1 - p_r)^gamma CE_r / N (sw_focal_loss); dlogits (N, C) f32 optional"""
+    _need_gpu(logits, targets_i32, loss)
+    N, C = logits.shape
+    ws = torch.empty(N, device=logits.device, dtype=torch.float32)
+    check(lib.sw_focal_loss(N, C, _p(logits), logits.stride(0), _p(targets_i32), float(gamma), _p(loss), _p(dlogits),
+                            0 if dlogits is None else dlogits.stride(0), _p(ws), _stream()), "sw_focal_loss")
+    return loss
+
+
 def counter_add(counter_u64, increment):
     """*counter += increment in stream order (the device-resident dropout stream position)"""
     check(lib.sw_counter_add(_p(counter_u64), int(increment), _stream()), "sw_counter_add")

@@ -4,7 +4,9 @@ reference unbias/ubteacher/engine/trainer.py:436-549 `run_step_full_semisup`, :3
 What is here: the step's control flow behind the reference's interface (`model(data, branch=...) -> (record_dict, proposals_rpn,
 proposals_roih, _)` for student and teacher), the teacher refresh as ONE multi-tensor HIP launch per 48 parameters
 (`sw_ema_multi`), pseudo-label thresholding as a device-side stable compaction (`sw_threshold_select`: no `.nonzero()` host
-sync per image), and the loss weighting.  What is NOT here yet: the ResNet-50-FPN Faster-RCNN the reference plugs in as
+sync per image), the loss weighting, the ROI heads' focal classification loss (`FocalLoss`, `fast_rcnn_focal_loss`: one HIP
+kernel for loss + gradient, fast_rcnn.py:73-105), the teacher / student container (`EnsembleTSModel`, ts_ensemble.py) and the
+branch dispatch of the meta-architecture (`TwoStagePseudoLabRCNN`, meta_arch/rcnn.py:8-107).  What is NOT here yet: the ResNet-50-FPN Faster-RCNN the reference plugs in as
 student / teacher — the step takes any module with that call signature.  Parity of this half is restatement-only
 (oracle/semisup_oracle.py explains why no fixture could be generated)."""
 from typing import Dict, List, Optional
@@ -82,6 +84,89 @@ def weight_losses(record: Dict[str, torch.Tensor], unsup_loss_weight: float) -> 
             else:
                 out[key] = v * 1
     return out
+
+
+class _FocalLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, gamma):
+        x = logits.detach().float().contiguous()
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        dl = torch.empty_like(x) if logits.requires_grad else None
+        ops.focal_loss(x, target.to(torch.int32).contiguous(), gamma, loss, dl)
+        ctx.dl, ctx.in_dtype = dl, logits.dtype
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None if ctx.dl is None else (ctx.dl * g).to(ctx.in_dtype)), None, None
+
+
+class FocalLoss(torch.nn.Module):
+    """fast_rcnn.py:85-105: `forward(input, target)` = sum_r (1 - p_r)^gamma * CE_r  (the caller divides by the row count; here the
+    division is part of the kernel and undone for the module's own contract)."""
+
+    def __init__(self, weight=None, gamma=1.0, num_classes=80):
+        super().__init__()
+        assert gamma >= 0 and weight is None
+        self.gamma, self.num_classes = gamma, num_classes
+
+    def forward(self, input, target):
+        return _FocalLossFunction.apply(input, target, self.gamma) * input.shape[0]
+
+
+def fast_rcnn_focal_loss(pred_class_logits, gt_classes, gamma=1.5):
+    """FastRCNNFocalLoss.comput_focal_loss (fast_rcnn.py:73-83): focal loss summed over the sampled proposals / their number;
+    `0.0 * logits.sum()` for an empty batch, as the reference."""
+    if gt_classes.numel() == 0:
+        return 0.0 * pred_class_logits.sum()
+    return _FocalLossFunction.apply(pred_class_logits, gt_classes, gamma)
+
+
+class EnsembleTSModel(torch.nn.Module):
+    """ts_ensemble.py:6-15: the checkpointed container `modelTeacher` / `modelStudent` (DDP / DataParallel wrappers peeled off)."""
+
+    def __init__(self, modelTeacher, modelStudent):
+        super().__init__()
+        wrappers = (torch.nn.parallel.DistributedDataParallel, torch.nn.DataParallel)
+        self.modelTeacher = modelTeacher.module if isinstance(modelTeacher, wrappers) else modelTeacher
+        self.modelStudent = modelStudent.module if isinstance(modelStudent, wrappers) else modelStudent
+
+
+class TwoStagePseudoLabRCNN(torch.nn.Module):
+    """The branch dispatch of TwoStagePseudoLabGeneralizedRCNN.forward (meta_arch/rcnn.py:8-107) over any backbone / proposal
+    generator / ROI heads with the reference's call signatures (PseudoLabRPN.forward(images, features, gt, compute_loss=,
+    compute_val_loss=), StandardROIHeadsPseudoLab.forward(images, features, proposals, targets, compute_loss=, branch=,
+    compute_val_loss=)); `preprocess` maps batched_inputs to the images object the parts take."""
+
+    def __init__(self, backbone, proposal_generator, roi_heads, preprocess, inference=None):
+        super().__init__()
+        self.backbone, self.proposal_generator, self.roi_heads = backbone, proposal_generator, roi_heads
+        self.preprocess_image, self._inference = preprocess, inference
+
+    def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False):
+        if (not self.training) and (not val_mode):
+            return self._inference(batched_inputs)
+        images = self.preprocess_image(batched_inputs)
+        gt_instances = [x["instances"] for x in batched_inputs] if "instances" in batched_inputs[0] else None
+        features = self.backbone(getattr(images, "tensor", images))
+        if branch == "supervised":
+            proposals_rpn, proposal_losses = self.proposal_generator(images, features, gt_instances)
+            _, detector_losses = self.roi_heads(images, features, proposals_rpn, gt_instances, branch=branch)
+            losses = {}
+            losses.update(detector_losses); losses.update(proposal_losses)
+            return losses, [], [], None
+        if branch == "unsup_data_weak":                       # the teacher's pass: proposals and predictions, no losses
+            proposals_rpn, _ = self.proposal_generator(images, features, None, compute_loss=False)
+            proposals_roih, roi_predictions = self.roi_heads(images, features, proposals_rpn, targets=None, compute_loss=False,
+                                                             branch=branch)
+            return {}, proposals_rpn, proposals_roih, roi_predictions
+        if branch == "val_loss":
+            proposals_rpn, proposal_losses = self.proposal_generator(images, features, gt_instances, compute_val_loss=True)
+            _, detector_losses = self.roi_heads(images, features, proposals_rpn, gt_instances, branch=branch, compute_val_loss=True)
+            losses = {}
+            losses.update(detector_losses); losses.update(proposal_losses)
+            return losses, [], [], None
+        raise ValueError(f"unknown branch {branch!r}")
 
 
 class SemiSupStep:

@@ -99,3 +99,71 @@ def test_semisup_step_control_flow_and_loss_weights():
         want = SO.weight_losses({k: float(v) for k, v in record.items() if isinstance(v, torch.Tensor)}, 4.0)
         assert {k: float(v) for k, v in loss_dict.items()} == pytest.approx(want)
         assert float(loss_dict["loss_box_reg_pseudo"]) == 0.0 and float(loss_dict["loss_cls_pseudo"]) == 8.0
+
+
+@pytest.mark.parametrize("N,C", [(512, 21), (2048, 81), (7, 3), (1, 2)])
+def test_focal_loss_vs_oracle_and_torch(N, C):
+    """fast_rcnn.py:73-105: value and gradient of the ROI heads' focal loss (gamma 1.5) against the float64 restatement and against
+    the reference's own torch expression evaluated in fp32 on the CPU; tolerance 1e-5 relative (f32 exp / log / pow)."""
+    from sos_wsod_amd.semisup import FocalLoss, fast_rcnn_focal_loss
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn(N, C, generator=g) * 3
+    x[0, :] = 0.0                                            # uniform row
+    if N > 2:
+        x[1, 0] = 40.0                                       # saturated: p -> 1 (target 0) resp. 0
+    t = torch.randint(0, C, (N,), generator=g)
+    t[0] = C - 1
+    if N > 2:
+        t[1] = 0; t[2] = (int(x[2].argmax()) + 1) % C
+    want, want_g = SO.focal_loss(x.numpy(), t.numpy(), 1.5)
+    xd = x.cuda().requires_grad_(True)
+    loss = fast_rcnn_focal_loss(xd, t.cuda(), 1.5)
+    loss.backward()
+    assert abs(float(loss) - want) <= 1e-5 * max(abs(want), 1e-3)
+    assert np.abs(xd.grad.cpu().numpy() - want_g).max() <= 1e-5 * max(np.abs(want_g).max(), 1e-6)
+    # the reference's expression, fp32 torch on the CPU
+    xc = x.clone().requires_grad_(True)
+    ce = torch.nn.functional.cross_entropy(xc, t, reduction="none")
+    ref = ((1 - torch.exp(-ce)) ** 1.5 * ce).sum() / N
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 2e-5 * max(abs(float(ref)), 1e-3)
+    assert (xd.grad.cpu() - xc.grad).abs().max() <= 2e-5 * max(float(xc.grad.abs().max()), 1e-6)
+    # module contract: FocalLoss.forward returns the SUM (the caller divides)
+    m = FocalLoss(gamma=1.5, num_classes=C - 1)
+    assert abs(float(m(x.cuda(), t.cuda())) - want * N) <= 1e-5 * max(abs(want * N), 1e-3)
+    assert float(fast_rcnn_focal_loss(x.cuda()[:0], t.cuda()[:0])) == 0.0
+
+
+def test_two_stage_branch_dispatch_and_ensemble():
+    """meta_arch/rcnn.py:8-107 branch interface + ts_ensemble.py: what each branch calls and returns"""
+    from sos_wsod_amd.semisup import EnsembleTSModel, TwoStagePseudoLabRCNN
+    calls = []
+
+    class RPN(torch.nn.Module):
+        def forward(self, images, features, gt, compute_loss=True, compute_val_loss=False):
+            calls.append(("rpn", gt is not None, compute_loss, compute_val_loss))
+            return ["props"], ({"loss_rpn_cls": torch.ones(())} if (compute_loss and gt is not None) or compute_val_loss else {})
+
+    class Heads(torch.nn.Module):
+        def forward(self, images, features, proposals, targets=None, compute_loss=True, branch="", compute_val_loss=False):
+            calls.append(("roi", targets is not None, compute_loss, branch, compute_val_loss))
+            if branch == "unsup_data_weak":
+                return ["roih"], "pred"
+            return proposals, {"loss_cls": torch.ones(())}
+
+    m = TwoStagePseudoLabRCNN(torch.nn.Identity(), RPN(), Heads(), preprocess=lambda b: torch.zeros(1), inference=lambda b: "inf")
+    m.train()
+    batch = [{"instances": "gt"}]
+    rec, a, b, c = m(batch, branch="supervised")
+    assert set(rec) == {"loss_cls", "loss_rpn_cls"} and a == [] and b == [] and c is None
+    rec, prpn, proih, pred = m([{}], branch="unsup_data_weak")
+    assert rec == {} and prpn == ["props"] and proih == ["roih"] and pred == "pred"
+    rec, *_ = m(batch, branch="val_loss")
+    assert set(rec) == {"loss_cls", "loss_rpn_cls"}
+    assert calls == [("rpn", True, True, False), ("roi", True, True, "supervised", False), ("rpn", False, False, False),
+                     ("roi", False, False, "unsup_data_weak", False), ("rpn", True, True, True), ("roi", True, True, "val_loss", True)]
+    m.eval()
+    assert m(batch) == "inf"
+    ddp_like = torch.nn.DataParallel(torch.nn.Linear(2, 2))
+    ens = EnsembleTSModel(ddp_like, torch.nn.Linear(2, 2))
+    assert isinstance(ens.modelTeacher, torch.nn.Linear) and set(k.split(".")[0] for k in ens.state_dict()) == {"modelTeacher", "modelStudent"}
