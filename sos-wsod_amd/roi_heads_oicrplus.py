@@ -218,6 +218,20 @@ class OICRPlusHeads(nn.Module):
         self.n_head_cols = 2 * K + refine_K * (5 * K + 1)
         self.ld_head = (self.n_head_cols + 7) // 8 * 8
 
+    @property
+    def gt_classes_img_int(self):
+        """roi_heads_oicrplus.py:206: the image-level classes of the last training forward, int64 per image (built on access:
+        the step itself launches no conversion kernel)"""
+        v = self.__dict__.get("_gt_int64")
+        if v is None and self.__dict__.get("_gt_int32") is not None:
+            v = [g.to(torch.int64) for g in self._gt_int32]
+        return v
+
+    @gt_classes_img_int.setter
+    def gt_classes_img_int(self, value):
+        self.__dict__["_gt_int64"] = value
+        self.__dict__["_gt_int32"] = None
+
     # ------------------------------------------------------------------ dropout stream state
     def _dropout_stream_seed(self):
         if self.dropout_seed is None:
@@ -701,7 +715,8 @@ class OICRPlusHeads(nn.Module):
         inp = prepared if prepared is not None else self._prepare_inputs(proposals_list, targets1, feats[0].device,
                                                                          need_grad=torch.is_grad_enabled())
         assert len(feats) == 2 * inp["B"]
-        self.gt_classes_img_int = [g.to(torch.int64) for g in inp["gt_int32"]]
+        self.__dict__["_gt_int64"] = None
+        self._gt_int32 = inp["gt_int32"]            # `gt_classes_img_int` (the reference's attribute) converts on access
         params = self._flat_params()              # fc6 W, b, fc7 W, b, then the predictors' (W, b) pairs
         box = [None]
         h0 = _HeadsPoolFunction.apply(self, inp, params, box, *feats)
