@@ -165,8 +165,11 @@ class _HeadsLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_losses, g_total):
         st = ctx.box[0]
-        if (g_losses is None and g_total is None) or st is None:
+        if g_losses is None and g_total is None:
             return (None,) * (3 + len(ctx.params))
+        if st is None or "dz1" in st:
+            raise RuntimeError("OICRPlusHeads: the activations of this iteration were released by its first backward pass "
+                               "(a second backward through the same forward is not supported)")
         dparams = ctx.heads._train_backward_top(st, ctx.params, g_losses, g_total)
         return (None, None, ctx.heads._handle(st["pooled"].device)) + tuple(dparams)
 
