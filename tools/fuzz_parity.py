@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Randomised parity sweep of the integer / index kernels against the oracle (development aid, not a test: the pytest suite
 holds the fixed cases).  ROIPool forward over random map sizes (plane / band / narrow-slab / gather forms), dtypes, ROI sets with
-degenerate and out-of-image boxes: bins, argmax and values bit-exact vs oracle/roipool_oracle.c; mining + labelling over random
+degenerate and out-of-image boxes: bins, argmax and values bit-exact vs oracle/roipool_oracle.c, the backward within the
+storage type's rounding; mining + labelling over random
 proposal counts, class counts, tied scores: kept indices / classes / scores / labels bit-exact vs oracle.get_pgt_mist +
 label_proposals.   usage: fuzz_parity.py [seconds] [seed]"""
 import os, sys, time
@@ -42,6 +43,14 @@ def fuzz_roi():
     got_arg = ops.argmax_to_int32(arg).cpu().numpy().reshape(ref_arg.shape)
     assert np.array_equal(got_arg, ref_arg), ("argmax", H, W, C, n, R, dtype, adt)
     assert torch.equal(out.cpu().float().reshape(ref_out.shape), torch.from_numpy(ref_out).to(dtype).float()), ("values", H, W, C, n, R, dtype)
+    # backward (fixed-point scatter) on the same argmax: against the C oracle's float scatter-add
+    dout = torch.from_numpy(rng.randn(R, C * 49).astype(np.float32)).to(dtype)
+    ref_d = O.roi_pool_bwd(dout.float().numpy().reshape(R, C, 7, 7), ref_arg, rois, (n, C, H, W))
+    dfeat = torch.full((n, H, W, C), float("nan"), device="cuda", dtype=dtype)
+    ops.roi_pool_bwd(dout.cuda(), arg, torch.from_numpy(rois).cuda(), dfeat, 7, 7)
+    got_d = dfeat.permute(0, 3, 1, 2).float().cpu().numpy()
+    tol = (2e-2 if dtype == torch.bfloat16 else 2e-5) * max(np.abs(ref_d).max(), 1e-6)
+    assert np.isfinite(got_d).all() and np.abs(got_d - ref_d).max() <= tol, ("bwd", H, W, C, n, R, dtype, np.abs(got_d - ref_d).max(), tol)
 
 
 def fuzz_mine():
