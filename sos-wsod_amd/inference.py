@@ -43,6 +43,8 @@ def oicr_inference(heads, features, proposals):
     all_boxes = torch.empty(R, 4 * K, device=dev, dtype=torch.float32)
     ops.oicr_predict(logits, R, K, heads.refine_K, 2 * K, 5 * K + 1, boxes, heads.bbox_reg_weights, SCALE_CLAMP, all_scores,
                      all_boxes)
+    if getattr(heads, "test_scores_only", False):       # TTA: the per-view scores / boxes are averaged, per-view detections unused
+        return [None], all_scores.unsqueeze(0), all_boxes.unsqueeze(0)
     H, W = prop.image_size
     cnt, dboxes, dscores, dclasses, drows = ops.detect_postprocess(all_scores, all_boxes, H, W, heads.test_score_thresh,
                                                                    heads.test_nms_thresh, heads.test_topk_per_image)

@@ -110,16 +110,20 @@ class GeneralizedRCNNWithTTAAVG(torch.nn.Module):
         heads = self.model.roi_heads
         K = heads.num_classes
         sum_scores = sum_boxes = None
-        for view, tfm in views:
-            _, scores, boxes = self.model.inference([view], do_postprocess=False)       # (1, R, K+1), (1, R, 4K), view coordinates
-            scores, boxes = scores[0], boxes[0]
-            R = boxes.shape[0]
-            back = tfm.inverse_box(boxes.reshape(R * K, 4)).reshape(R, 4 * K)
-            if (tfm.orig_hw != orig):                        # the mapper resized from the tensor's size, not the dataset's
-                sx, sy = orig[1] / tfm.orig_hw[1], orig[0] / tfm.orig_hw[0]
-                back = (back.reshape(R * K, 4) * back.new_tensor([sx, sy, sx, sy])).reshape(R, 4 * K)
-            sum_scores = scores.clone() if sum_scores is None else sum_scores + scores
-            sum_boxes = back if sum_boxes is None else sum_boxes + back
+        heads.test_scores_only = True             # per-view NMS / top-k (and their host sync) would be thrown away
+        try:
+            for view, tfm in views:
+                _, scores, boxes = self.model.inference([view], do_postprocess=False)       # (1, R, K+1), (1, R, 4K), view coordinates
+                scores, boxes = scores[0], boxes[0]
+                R = boxes.shape[0]
+                back = tfm.inverse_box(boxes.reshape(R * K, 4)).reshape(R, 4 * K)
+                if (tfm.orig_hw != orig):                        # the mapper resized from the tensor's size, not the dataset's
+                    sx, sy = orig[1] / tfm.orig_hw[1], orig[0] / tfm.orig_hw[0]
+                    back = (back.reshape(R * K, 4) * back.new_tensor([sx, sy, sx, sy])).reshape(R, 4 * K)
+                sum_scores = scores.clone() if sum_scores is None else sum_scores + scores
+                sum_boxes = back if sum_boxes is None else sum_boxes + back
+        finally:
+            heads.test_scores_only = False
         n = float(len(views))
         all_scores, all_boxes = (sum_scores / n).contiguous(), (sum_boxes / n).contiguous()
         cnt, dboxes, dscores, dclasses, _ = ops.detect_postprocess(all_scores, all_boxes, int(orig[0]), int(orig[1]),
