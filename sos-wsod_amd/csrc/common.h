@@ -29,11 +29,13 @@ template <> struct Elem<float> {
   static constexpr int kDtype = SW_F32;
   __device__ static __forceinline__ float load(const float* p) { return *p; }
   __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ void store_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }     // written once, read by a later kernel
 };
 template <> struct Elem<unsigned short> {   // bf16 carried as raw 16-bit words
   static constexpr int kDtype = SW_BF16;
   __device__ static __forceinline__ float load(const unsigned short* p) { return bf16_bits_to_f32(*p); }
   __device__ static __forceinline__ void store(unsigned short* p, float v) { *p = f32_to_bf16_bits(v); }
+  __device__ static __forceinline__ void store_nt(unsigned short* p, float v) { __builtin_nontemporal_store(f32_to_bf16_bits(v), p); }
 };
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {

@@ -590,7 +590,13 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
               for (int t = 0; t < 4; ++t) if (nb + t < g.N) atomicAdd((float*)g.C + o + t, v[t]);
             } else {                                               // f32 rows (plain or K-split slab)
               float* dst = (float*)g.C + o + (g.slab_stride > 0 ? (long)zsplit * g.slab_stride : 0);
+              // nontemporal: the tile is written once and read by a later kernel; as ordinary stores the 33-68 MB every round of
+              // tiles writes pushed the operand panels out of the XCDs' L2s (fc6 data gradient 1.36 -> 1.25 ms, -D SW_EP_PLAIN_STORES)
+#ifndef SW_EP_PLAIN_STORES
+              if (full && vec_ok) __builtin_nontemporal_store(*(const f32x4*)&v[0], (f32x4*)dst);
+#else
               if (full && vec_ok) *(f32x4*)dst = *(const f32x4*)&v[0];
+#endif
               else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) if (nb + t < g.N) dst[t] = v[t];
@@ -602,7 +608,11 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
               u32x4 w;
 #pragma unroll
               for (int t = 0; t < 4; ++t) w[t] = (unsigned)f32_to_bf16_bits(v[2 * t]) | ((unsigned)f32_to_bf16_bits(v[2 * t + 1]) << 16);
+#ifndef SW_EP_PLAIN_STORES
+              __builtin_nontemporal_store(w, (u32x4*)dst);
+#else
               *(u32x4*)dst = w;
+#endif
             } else {
 #pragma unroll
               for (int t = 0; t < CP; ++t) if (nb + t < g.N) dst[t] = f32_to_bf16_bits(v[t]);
@@ -655,10 +665,17 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
         if (staged) { stile[lrow * WTN + j * TS + r] = f32_to_bf16_bits(v); continue; }
         if (!ok) continue;
         const long o = (long)m * g.ldc + n;
+#ifndef SW_EP_PLAIN_STORES
+        if (g.slab_stride > 0) __builtin_nontemporal_store(v, (float*)g.C + o + (long)zsplit * g.slab_stride);   // slabs: written once, folded once
+        else if (g.atomic) atomicAdd((float*)g.C + o, v);
+        else if (g.out_bf16) __builtin_nontemporal_store(f32_to_bf16_bits(v), (unsigned short*)g.C + o);
+        else __builtin_nontemporal_store(v, (float*)g.C + o);
+#else
         if (g.slab_stride > 0) ((float*)g.C)[o + (long)zsplit * g.slab_stride] = v;
         else if (g.atomic) atomicAdd((float*)g.C + o, v);
         else if (g.out_bf16) ((unsigned short*)g.C)[o] = f32_to_bf16_bits(v);
         else ((float*)g.C)[o] = v;
+#endif
       }
     }
   if (staged) {
@@ -668,8 +685,13 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
     for (int q = 0; q < (WTM * CPRW) / 64; ++q) {
       const int idx = q * 64 + lane, lrow = idx / CPRW, ch = idx % CPRW;
       const int m = m0 + wm * WTM + lrow, n = n0t + wn * WTN + ch * 8;
-      if (m < g.M && n < g.N)
+      if (m < g.M && n < g.N) {
+#ifndef SW_EP_PLAIN_STORES
+        __builtin_nontemporal_store(*(const u32x4*)(stile + lrow * WTN + ch * 8), (u32x4*)((unsigned short*)g.C + (long)m * g.ldc + n));
+#else
         *(u32x4*)((unsigned short*)g.C + (long)m * g.ldc + n) = *(const u32x4*)(stile + lrow * WTN + ch * 8);
+#endif
+      }
     }
   }
   }
