@@ -597,7 +597,8 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
     }
     // 2 x CB two-byte stores per task (a 64-lane wave writes one contiguous 98-byte run per channel and ROI): measured 45 us of the
     // 260 us a 4000-ROI call takes (stores compiled out: 215 us), the rest is the scan's VALU issue — staging the rows through LDS
-    // for 16-byte stores would need 31 KiB more LDS and drop 63x63 maps to one workgroup per CU, so the stores stay direct
+    // for 16-byte stores would need 31 KiB more LDS and drop 63x63 maps to one workgroup per CU (measured with padded LDS: +10 %),
+    // so the stores stay direct
     const float mul = s_mul[li];
     const long o = (long)r * ld + (long)c0 * nb + b;
 #pragma unroll
