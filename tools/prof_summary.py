@@ -9,6 +9,8 @@ tot = sum(int(r["TotalDurationNs"]) for r in rows)
 with open(out, "w") as f:
     f.write(f"# source: {stats}  (rocprofv3 --kernel-trace --stats; {steps:g} bench steps incl. warm-up)\n")
     f.write(f"# total GPU time per step: {tot / steps / 1e6:.3f} ms\n")
+    f.write("# rows with < 1 call per step (at::native fills / random init, conv_weight_prep, ...) run once, before the first step:\n")
+    f.write("# model construction, input synthesis, the first staging of the compute-dtype weights\n")
     f.write("kernel,calls_per_step,ms_per_step,avg_us,percent\n")
     for r in rows:
         n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
