@@ -4,7 +4,7 @@ holds the fixed cases).  ROIPool forward over random map sizes (plane / band / n
 degenerate and out-of-image boxes: bins, argmax and values bit-exact vs oracle/roipool_oracle.c, the backward within the
 storage type's rounding; mining + labelling over random
 proposal counts, class counts, tied scores: kept indices / classes / scores / labels bit-exact vs oracle.get_pgt_mist +
-label_proposals.   usage: fuzz_parity.py [seconds] [seed]"""
+label_proposals; the inference post-processing (per-class NMS, merge, top-k) vs the oracle's NMS.   usage: fuzz_parity.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -84,7 +84,37 @@ def fuzz_mine():
     assert np.array_equal(lab_w.cpu().numpy(), lab["gt_weights"]), ("weights", tag)
 
 
+def fuzz_detect():
+    """per-class NMS on class-offset clipped boxes + global top-k (fast_rcnn_oicr.py:86-148): detections and their order"""
+    R = int(rng.randint(1, 500)); K = int(rng.choice([3, 20, 80]))
+    sc = torch.softmax(torch.from_numpy(rng.randn(R, K + 1).astype(np.float32)) * float(rng.choice([1, 3, 8])), 1)
+    if rng.rand() < 0.4:
+        sc = torch.round(sc * 50) / 50                              # tied scores
+    H, W = int(rng.randint(60, 400)), int(rng.randint(60, 400))
+    ctr = torch.from_numpy(rng.rand(R, K, 2).astype(np.float32)) * torch.tensor([float(W), float(H)])
+    wh = torch.from_numpy(rng.rand(R, K, 2).astype(np.float32)) * 120 + 4
+    bx = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).reshape(R, 4 * K)
+    thr, nms_thr, topk = float(rng.choice([1e-5, 0.02, 0.2])), float(rng.choice([0.3, 0.5])), int(rng.choice([5, 100]))
+    s = sc[:, :-1].numpy(); pb = bx.numpy().reshape(R, K, 4).copy()
+    pb[..., 0::2] = pb[..., 0::2].clip(0, W); pb[..., 1::2] = pb[..., 1::2].clip(0, H)
+    r_idx, c_idx = np.nonzero(s > np.float32(thr))
+    cnt, dboxes, dscores, dclasses, drows = ops.detect_postprocess(sc.cuda(), bx.cuda(), H, W, thr, nms_thr, topk)
+    n = int(cnt.item())
+    if len(r_idx) == 0:
+        assert n == 0, ("detect empty", R, K)
+        return
+    bsel, ssel = pb[r_idx, c_idx], s[r_idx, c_idx]
+    off = c_idx.astype(np.float32) * np.float32(bsel.max() + 1)
+    keep = O.nms_keep((bsel + off[:, None]).astype(np.float32), ssel, nms_thr)[:topk]
+    tag = (R, K, H, W, thr, nms_thr, topk)
+    assert n == len(keep), ("detect count", tag, n, len(keep))
+    assert np.array_equal(dclasses[:n].cpu().numpy(), c_idx[keep]) and np.array_equal(drows[:n].cpu().numpy(), r_idx[keep]), ("detect order", tag)
+    assert np.array_equal(dscores[:n].cpu().numpy(), ssel[keep]) and np.array_equal(dboxes[:n].cpu().numpy(), bsel[keep]), ("detect values", tag)
+
+
+n_det = 0
 while time.time() < t_end:
     fuzz_roi(); n_roi += 1
     fuzz_mine(); n_mine += 1
-print(f"fuzz ok: {n_roi} ROIPool cases, {n_mine} mining cases")
+    fuzz_detect(); n_det += 1
+print(f"fuzz ok: {n_roi} ROIPool cases, {n_mine} mining cases, {n_det} detection post-processing cases")
