@@ -590,8 +590,10 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
               for (int t = 0; t < 4; ++t) if (nb + t < g.N) atomicAdd((float*)g.C + o + t, v[t]);
             } else {                                               // f32 rows (plain or K-split slab)
               float* dst = (float*)g.C + o + (g.slab_stride > 0 ? (long)zsplit * g.slab_stride : 0);
-              // nontemporal: the tile is written once and read by a later kernel; as ordinary stores the 33-68 MB every round of
-              // tiles writes pushed the operand panels out of the XCDs' L2s (fc6 data gradient 1.36 -> 1.25 ms, -D SW_EP_PLAIN_STORES)
+              // nontemporal: the 33-68 MB burst a round of tiles writes retires faster streamed past the write-back L2s, and the next
+              // tiles' loads queue behind it on the in-order vmcnt (fc6 data gradient 1.36 -> 1.25 ms; -D SW_EP_PLAIN_STORES for A/B).
+              // Unconditional on purpose: `if (flag) nontemporal else plain` is merged into one plain store by the optimiser, and
+              // arms kept apart by an asm barrier stop the pieces' LDS reads and stores from overlapping (no gain left)
 #ifndef SW_EP_PLAIN_STORES
               if (full && vec_ok) __builtin_nontemporal_store(*(const f32x4*)&v[0], (f32x4*)dst);
 #else
