@@ -27,35 +27,50 @@ constexpr int NWAVE = 16;      // 1024-thread workgroups
 constexpr int WS_CH = 256;     // rows per workgroup
 constexpr int WS_VMAX = 8;     // views held in registers by the scores kernel
 
-// block-wide column reduction of one value per thread and column index c (result[c] valid after the call)
-template <bool IS_MAX>
-__device__ __forceinline__ void chunk_reduce_store(float v, int c, float (*part)[KMAX]) {
-  v = IS_MAX ? wave_reduce_max(v) : wave_reduce_sum(v);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][c] = v;
-}
-
+// Column statistics of one chunk of rows: the chunk's detection logits are copied into LDS by a flat, coalesced sweep (a thread
+// walking its own row issued K dependent 4-byte loads 1.7 KB apart), then K x G threads reduce column k over row group g and the G
+// partials are combined in group order (deterministic).
+constexpr int WS_GMAX = 16;
 __global__ __launch_bounds__(WS_CH) void wsddn_stats_kernel(int R, int K, const float* __restrict__ logits, long ld,
                                                             int det_col, float* __restrict__ pm, float* __restrict__ ps) {
-  __shared__ float part[WS_CH / 64][KMAX];
+  extern __shared__ float tile[];                        // [WS_CH][K]
+  __shared__ float s_part[WS_GMAX][KMAX];
   __shared__ float s_m[KMAX];
   const int chunk = blockIdx.x, v = blockIdx.y, nchunk = gridDim.x;
-  const int r = chunk * WS_CH + threadIdx.x;
-  const float* d = logits + ((long)v * R + min(r, R - 1)) * ld + det_col;
-  for (int k = 0; k < K; ++k) chunk_reduce_store<true>(r < R ? d[k] : -FLT_MAX, k, part);
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += WS_CH) {
-    float m = part[0][k];
-    for (int w = 1; w < WS_CH / 64; ++w) m = fmaxf(m, part[w][k]);
-    s_m[k] = m;
+  const int row0 = chunk * WS_CH, nrow = min(WS_CH, R - row0);
+  const float* L = logits + ((long)v * R + row0) * ld + det_col;
+  for (int i = threadIdx.x; i < nrow * K; i += WS_CH) {
+    const int r = i / K, k = i - r * K;
+    tile[i] = L[(long)r * ld + k];
   }
   __syncthreads();
-  for (int k = 0; k < K; ++k) chunk_reduce_store<false>(r < R ? expf(d[k] - s_m[k]) : 0.f, k, part);
+  const int G = min(WS_GMAX, WS_CH / K), rpg = (nrow + G - 1) / G;
+  const int t = threadIdx.x, k = t % K, g = t / K;
+  const int ra = min(nrow, g * rpg), rb = min(nrow, ra + rpg);
+  if (t < G * K) {
+    float m = -FLT_MAX;
+    for (int r = ra; r < rb; ++r) m = fmaxf(m, tile[r * K + k]);
+    s_part[g][k] = m;
+  }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += WS_CH) {
-    float z = part[0][k];
-    for (int w = 1; w < WS_CH / 64; ++w) z += part[w][k];
-    pm[((long)v * nchunk + chunk) * K + k] = s_m[k];
-    ps[((long)v * nchunk + chunk) * K + k] = z;
+  if (t < K) {
+    float m = s_part[0][t];
+    for (int w = 1; w < G; ++w) m = fmaxf(m, s_part[w][t]);
+    s_m[t] = m;
+  }
+  __syncthreads();
+  if (t < G * K) {
+    float z = 0.f;
+    const float m = s_m[k];
+    for (int r = ra; r < rb; ++r) z += expf(tile[r * K + k] - m);
+    s_part[g][k] = z;
+  }
+  __syncthreads();
+  if (t < K) {
+    float z = s_part[0][t];
+    for (int w = 1; w < G; ++w) z += s_part[w][t];
+    pm[((long)v * nchunk + chunk) * K + t] = s_m[t];
+    ps[((long)v * nchunk + chunk) * K + t] = z;
   }
 }
 
@@ -765,9 +780,13 @@ extern "C" int sw_wsddn_mil(int V, int R, int K, const float* logits, long ld, i
   float* pS = ps + (long)V * nchunk * K;
   float* cm = pS + (long)V * nchunk * K;
   float* cz = cm + (long)V * K;
-  hipLaunchKernelGGL(wsddn_stats_kernel, dim3(nchunk, V), dim3(WS_CH), 0, stream, R, K, logits, ld, det_col, pm, ps);
-  SW_CHECK_LAUNCH();
   const size_t lds_sc = (size_t)WS_CH * K * sizeof(float);
+  if (lds_sc > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)wsddn_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(wsddn_stats_kernel, dim3(nchunk, V), dim3(WS_CH), lds_sc, stream, R, K, logits, ld, det_col, pm, ps);
+  SW_CHECK_LAUNCH();
   if (lds_sc > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)wsddn_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc);
     if (e != hipSuccess) return (int)e;
