@@ -18,20 +18,20 @@ What differs is the execution plan (MI355X-first, not a translation):
 Reference quirks kept on purpose: losses_k2_flip pairs predictions_k2 with the flipped targets
 (#1), pseudo-GT weights = scores (#2), class-agnostic NMS at 0.01 (#3), int() truncation of R*0.1 and rank-0
 always kept (#4), CE mean over all R / box loss / R, L1 (#5), targets are proposals[gt_index] (#6)."""
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import ops
-from .box_head import DiscriminativeAdaptionNeck
+from .box_head import DiscriminativeAdaptionNeck  # noqa: F401  (registers the box head the configs name)
 from .events import get_event_storage, has_event_storage
 from .fast_rcnn_oicr import OICROutputLayers
 from .fast_rcnn_wsddn import WSDDNOutputLayers
 from .poolers import ROIPooler
 from .registry import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
-from .structures import Boxes, Instances, ShapeSpec
+from .structures import ShapeSpec
 
 LOSS_NAMES_FMT = ["loss_cls"]
 

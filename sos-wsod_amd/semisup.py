@@ -9,7 +9,7 @@ kernel for loss + gradient, fast_rcnn.py:73-105), the teacher / student containe
 branch dispatch of the meta-architecture (`TwoStagePseudoLabRCNN`, meta_arch/rcnn.py:8-107).  What is NOT here yet: the ResNet-50-FPN Faster-RCNN the reference plugs in as
 student / teacher — the step takes any module with that call signature.  Parity of this half is restatement-only
 (oracle/semisup_oracle.py explains why no fixture could be generated)."""
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 
