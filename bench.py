@@ -292,6 +292,8 @@ def main():
                              for t in ("fc6_fwd", "fc6_dgrad", "fc6_wgrad")},
             "roofline_conv5_3": dict(roof("plain5.conv3_fwd"), note="inside the step: two streams share the CUs"),
             "roofline_conv5_3_alone": {"kernel": "conv5_3 fwd, batch 2, 63x63, 512->512, dilation 2", "bound": "mfma",
+                                       "traffic": (traffic.get("conv5_3") or {}).get("hbm_bytes_per_launch"),
+                                       "algorithmic_bytes": (traffic.get("conv5_3") or {}).get("algorithmic_bytes"),
                                        "achieved": round(flops["plain5.conv3_fwd"] / (conv_alone_ms * 1e-3) / 1e12, 2),
                                        "peak": peak, "unit": "TFLOP/s",
                                        "frac": round(flops["plain5.conv3_fwd"] / (conv_alone_ms * 1e-3) / 1e12 / peak, 4),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-side traffic of the fc6 GEMMs (separate --pmc passes, as MI355X_MICROARCH.md prescribes) -> profiles/pmc_traffic.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for shape in fc6_fwd fc6_dgrad fc6_wgrad roi_fwd roi_bwd wgrad_grouped; do
+for shape in fc6_fwd fc6_dgrad fc6_wgrad roi_fwd roi_bwd wgrad_grouped conv5_3; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmct_${shape}_$c
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmct_${shape}_$c -- python tools/one_kernel.py $shape 3 > /dev/null 2>&1
@@ -16,9 +16,10 @@ LW = [(2*128*128, 128, 256), (2*128*128, 256, 256), (2*128*128, 256, 256), (2*64
       (2*63*63, 512, 512), (2*63*63, 512, 512), (2*63*63, 512, 512)]
 alg = {"fc6_fwd": 2*(M*D0 + D1*D0 + M*D1), "fc6_dgrad": 2*(M*D1 + D1*D0 + M*D0), "fc6_wgrad": 2*(M*D1 + M*D0) + 4*D1*D0,
        "roi_fwd": R2*25088*4 + FM, "roi_bwd": R2*25088*4 + 2*FM,
-       "wgrad_grouped": sum(2 * (2*p*(ci + co)) + 2 * 4*co*9*ci for p, ci, co in LW)}     # 2 view batches: operands once, one slab each
-name = {"roi_fwd": "roi_pool_fwd", "roi_bwd": "roi_pool_bwd", "wgrad_grouped": "gemm2_grouped"}
-for shape in ("fc6_fwd", "fc6_dgrad", "fc6_wgrad", "roi_fwd", "roi_bwd", "wgrad_grouped"):
+       "wgrad_grouped": sum(2 * (2*p*(ci + co)) + 2 * 4*co*9*ci for p, ci, co in LW),     # 2 view batches: operands once, one slab each
+       "conv5_3": 2 * (2*63*63*512) * 2 + 512*9*512*2}                                    # bf16 map in + out (batch 2), weights once
+name = {"roi_fwd": "roi_pool_fwd", "roi_bwd": "roi_pool_bwd", "wgrad_grouped": "gemm2_grouped", "conv5_3": "conv3x3_direct"}
+for shape in ("fc6_fwd", "fc6_dgrad", "fc6_wgrad", "roi_fwd", "roi_bwd", "wgrad_grouped", "conv5_3"):
     v = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         vals = []
