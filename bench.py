@@ -185,29 +185,33 @@ def main():
     for i in range(args.warmup):
         trainer.run_step(batches[i % 2])
     tags = ["fc6_fwd", "fc6_dgrad", "fc6_wgrad", "plain5.conv3_fwd", "roi_fwd", "roi_bwd"]
-    if graphs is None:
-        ops.TIMER = ops.KernelTimer(tags)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         trainer.run_step(batches[i % 2])
     sync()
     dt = time.perf_counter() - t0
-    eager_ms = None
-    n_timer_steps = args.steps
-    if graphs is not None:
-        # per-kernel durations need HIP events between launches, which a graph replay has no place for: the same kernels are
-        # timed in a few eager steps after the measured region (same shapes, same data)
+    # per-kernel durations need HIP events between launches: a graph replay has no place for them, and in an eager run they are
+    # instrumentation (~0.3 ms of stream time per step) — so the same kernels are timed in a few eager steps AFTER the measured
+    # region (same shapes, same data, every rank alike so that the collectives stay in step)
+    replays = captures = None
+    n_timer_steps = 8
+    eager_ms = dt / args.steps * 1e3
+    if graphs is not None:                       # the same step issued launch by launch, for the record
         replays, captures = graphs.replays, graphs.captures
-        trainer._graphs = None
+        graphs.enabled = False                   # same trainer, same stream, no replay
         trainer.run_step(batches[0])
-        ops.TIMER = ops.KernelTimer(tags)
-        n_timer_steps = 8
         sync(); t1 = time.perf_counter()
         for i in range(n_timer_steps):
             trainer.run_step(batches[i % 2])
         sync()
         eager_ms = (time.perf_counter() - t1) / n_timer_steps * 1e3
+    ops.TIMER = ops.KernelTimer(tags)
+    sync(); t1 = time.perf_counter()
+    for i in range(n_timer_steps):
+        trainer.run_step(batches[i % 2])
+    sync()
+    instrumented_ms = (time.perf_counter() - t1) / n_timer_steps * 1e3
     times = ops.TIMER.summary_ms()
     ops.TIMER = None
     if world > 1:
@@ -306,7 +310,9 @@ def main():
             # whole step as ONE captured hipGraph (forward + backward + SGD; ms_per_step above) vs the same step issued launch by
             # launch from Python (what DDP runs use); per-kernel figures come from the eager steps
             "step_launch": ({"mode": "hipGraph replay", "graph_replays": replays, "graph_captures": captures,
-                             "eager_ms_per_step": round(eager_ms, 3)} if graphs is not None else {"mode": "eager launches"}),
+                             "eager_ms_per_step": round(eager_ms, 3), "instrumented_ms_per_step": round(instrumented_ms, 3)}
+                            if graphs is not None else
+                            {"mode": "eager launches", "instrumented_ms_per_step": round(instrumented_ms, 3)}),
         }
         if world == 1 and dtype == torch.bfloat16 and not args.no_fp32_line:
             # the reference's own precision (fp32 storage, exact-f32 MFMA: 1/16 of the bf16 rate), a short run for the record

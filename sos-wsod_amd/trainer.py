@@ -218,6 +218,7 @@ class _StepGraphs:
         self.labels = torch.zeros(4096, dtype=torch.float32, device=self.dev)
         self.stream = torch.cuda.Stream(device=self.dev)
         self.replays = self.captures = 0
+        self.enabled = True                  # False: every step runs eagerly (on the same stream) — measurements, debugging
 
     VIEW_KEYS = ("1", "1_flip", "2", "2_flip")
 
@@ -269,6 +270,8 @@ class _StepGraphs:
 
     def step(self, data):
         """-> (loss_dict, total) after replaying (or capturing + replaying) this step's graph, or None: run eagerly"""
+        if not self.enabled:
+            return None
         sig = self._signature(data)
         if sig is None:
             return None
