@@ -618,6 +618,15 @@ def test_step_graph_replay_equals_eager_steps(golden_dir):
     bad = [n for n in we if not torch.equal(we[n], wg[n])]
     assert not bad, bad
     assert tr_g.raw_model.roi_heads._drop_counter == tr_e.raw_model.roi_heads._drop_counter > 0
+    # the reference's attribute (roi_heads_oicrplus.py:206) is built on access, from the labels of the last forward
+    gt = tr_e.raw_model.roi_heads.gt_classes_img_int
+    assert isinstance(gt, list) and gt[0].dtype == torch.int64 and sorted(gt[0].tolist()) == sorted({(3 + 5) % K, (11 + 10) % K})
+    # replay switched off: the same trainer runs the step eagerly on its stream (bench.py's launch-by-launch comparison) and
+    # continues the same trajectory as an all-eager trainer given the same extra batch
+    extra = batches()[0]
+    tr_g._graphs.enabled = False
+    la, lb = tr_g.run_step(extra).vector.clone(), tr_e.run_step(extra).vector.clone()
+    assert tr_g._graphs.replays == 4 and torch.equal(la, lb)
 
 
 def test_two_images_per_gpu_equal_the_mean_of_two_single_image_iterations():
