@@ -116,6 +116,10 @@ int sw_maxpool2x2_bwd(int dtype, int nimg, int H, int W, int C, int stride, cons
  * mean3/std3 are HOST float[3] (configuration constants, passed by value into the launch). */
 int sw_preprocess(int dtype, int H, int W, int cpad, const uint8_t* img_chw, const float* mean3,
                   const float* std3, void* out_nhwc, sw_stream_t stream);
+/* The same for n images of one size in ONE launch (a view batch): imgs_chw = HOST array of n device pointers,
+ * out_nhwc [n][H][W][cpad]. */
+int sw_preprocess_multi(int dtype, int n, int H, int W, int cpad, const uint8_t* const* imgs_chw, const float* mean3,
+                        const float* std3, void* out_nhwc, sw_stream_t stream);
 
 /* ---- max ROI pooling (reference: torchvision.ops.RoIPool called at wsl/modeling/poolers.py:183-186,267-270;
  *      arithmetic as stated in wsl/layers/csrc/ROILoopPool/ROILoopPool_cpu.cpp:26-79 fwd, :98-123 bwd) -------

@@ -81,6 +81,7 @@ SIGNATURES = {
     "sw_maxpool2x2_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p]),
     "sw_preprocess": (c_int, [c_int, c_int, c_int, c_int, c_void_p, _F4, _F4, c_void_p, c_void_p]),
+    "sw_preprocess_multi": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p), _F4, _F4, c_void_p, c_void_p]),
     "sw_roi_pool_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
                                 c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "sw_roi_pool_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_long, c_void_p, c_int,

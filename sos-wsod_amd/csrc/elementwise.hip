@@ -26,6 +26,25 @@ __global__ void preprocess_kernel(int H, int W, int cpad, const uint8_t* __restr
   }
 }
 
+// several images of one size in one launch (a view batch = a view and its flipped copy, x B images): blockIdx.y = image
+constexpr int PRE_MAX = 16;
+struct PreArgs { const uint8_t* img[PRE_MAX]; };
+template <typename T>
+__global__ void preprocess_multi_kernel(int H, int W, int cpad, PreArgs a, float m0, float m1, float m2, float s0, float s1, float s2,
+                                        T* __restrict__ out) {
+  const long npix = (long)H * W;
+  const uint8_t* __restrict__ img = a.img[blockIdx.y];
+  T* o_img = out + (long)blockIdx.y * npix * cpad;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    const float v0 = __fdiv_rn((float)img[p] - m0, s0);
+    const float v1 = __fdiv_rn((float)img[npix + p] - m1, s1);
+    const float v2 = __fdiv_rn((float)img[2 * npix + p] - m2, s2);
+    T* o = o_img + p * cpad;
+    Elem<T>::store(o + 0, v0); Elem<T>::store(o + 1, v1); Elem<T>::store(o + 2, v2);
+    for (int c = 3; c < cpad; ++c) Elem<T>::store(o + c, 0.f);
+  }
+}
+
 // ---------------------------------------------------------------- maxpool 2x2 (vgg.py:99-100)
 template <typename T>
 __global__ void maxpool_fwd_kernel(int nimg, int H, int W, int C, int stride, int OH, int OW, const T* __restrict__ in,
@@ -750,6 +769,29 @@ extern "C" int sw_preprocess(int dtype, int H, int W, int cpad, const uint8_t* i
     hipLaunchKernelGGL(preprocess_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, H, W, cpad, img,
                        mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (float*)out));
   SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_preprocess_multi(int dtype, int n, int H, int W, int cpad, const uint8_t* const* imgs_chw, const float* mean3,
+                                   const float* std3, void* out_nhwc, hipStream_t stream) {
+  SW_ENTER();
+  if (n <= 0) return 0;
+  if (cpad < 3) return -1;
+  const long npix = (long)H * W;
+  const long es = dtype == SW_BF16 ? 2 : 4;
+  for (int base = 0; base < n; base += PRE_MAX) {
+    PreArgs a = {};
+    const int m = n - base < PRE_MAX ? n - base : PRE_MAX;
+    for (int i = 0; i < m; ++i) a.img[i] = imgs_chw[base + i];
+    void* out = (char*)out_nhwc + (long)base * npix * cpad * es;
+    long bx = grid_for(npix); if (bx > 512) bx = 512;
+    DISPATCH_T(dtype,
+      hipLaunchKernelGGL(preprocess_multi_kernel<unsigned short>, dim3((unsigned)bx, (unsigned)m), dim3(256), 0, stream, H, W, cpad, a,
+                         mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (unsigned short*)out),
+      hipLaunchKernelGGL(preprocess_multi_kernel<float>, dim3((unsigned)bx, (unsigned)m), dim3(256), 0, stream, H, W, cpad, a,
+                         mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (float*)out));
+    SW_CHECK_LAUNCH();
+  }
   return 0;
 }
 

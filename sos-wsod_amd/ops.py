@@ -267,6 +267,18 @@ def preprocess(img_u8_chw, out_hwc, mean, std):
     return out_hwc
 
 
+def preprocess_multi(imgs_u8_chw, out_nhwc, mean, std):
+    """n u8 CHW images of one size -> out [n][H][W][cpad], one launch"""
+    _need_gpu(out_nhwc, *imgs_u8_chw)
+    n, H, W, cpad = out_nhwc.shape
+    assert len(imgs_u8_chw) == n and all(im.is_contiguous() and tuple(im.shape) == (3, H, W) for im in imgs_u8_chw)
+    ptrs = (ctypes.c_void_p * n)(*[im.data_ptr() for im in imgs_u8_chw])
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(lib.sw_preprocess_multi(dt(out_nhwc), n, H, W, cpad, ptrs, m, s, _p(out_nhwc), _stream()), "sw_preprocess_multi")
+    return out_nhwc
+
+
 def roi_pool_fwd(feat, rois, out, argmax, spatial_scale, PH, PW, row_scale=None, row_scale_add=0.0, tag=None):
     """feat [n][H][W][C], rois [R][5] f32, out [R][C*PH*PW]; argmax same shape, int32 (h*W+w or -1) or int16/uint16
     storage holding uint16 (h*W+w or 0xFFFF; see argmax_to_int32)"""

@@ -74,9 +74,11 @@ class MultiInputRCNN(nn.Module):
         cpad = 8 if dt_ == torch.bfloat16 else 4
         H, W = imgs_u8[0].shape[-2:]
         out = torch.empty(len(imgs_u8), H, W, cpad, device=self.device, dtype=dt_)
-        for i, im in enumerate(imgs_u8):
+        ims = []
+        for im in imgs_u8:
             assert im.dtype == torch.uint8 and tuple(im.shape[-2:]) == (H, W)
-            ops.preprocess(im.to(self.device, non_blocking=True).contiguous(), out[i], self._mean_host, self._std_host)
+            ims.append(im.to(self.device, non_blocking=True).contiguous())
+        ops.preprocess_multi(ims, out, self._mean_host, self._std_host)       # the whole view batch in one launch
         return out
 
     def preprocess_image(self, batched_inputs):

@@ -703,3 +703,21 @@ def test_copy_multi_and_relu_bwd_out(ops):
         out = ops.relu_bwd(ref, gr, out=torch.full_like(gr, float("nan")))
         assert torch.equal(gr, keep) and torch.equal(out, torch.where(ref > 0, gr, torch.zeros_like(gr)))
         assert ops.relu_bwd(ref, gr) is gr and torch.equal(gr, out)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_preprocess_multi_equals_single_image_launches(ops, dtype):
+    """sw_preprocess_multi (a view batch in one launch, also more images than one launch carries) == sw_preprocess per image == the oracle"""
+    g = torch.Generator().manual_seed(8)
+    H, W, n = 37, 53, 19
+    cpad = 8 if dtype == torch.bfloat16 else 4
+    imgs = [torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8).cuda() for _ in range(n)]
+    mean, std = [103.939, 116.779, 123.68], [1.0, 57.375, 1.0]
+    out = torch.full((n, H, W, cpad), float("nan"), device="cuda", dtype=dtype)
+    ops.preprocess_multi(imgs, out, mean, std)
+    for i, im in enumerate(imgs):
+        one = torch.empty(H, W, cpad, device="cuda", dtype=dtype)
+        ops.preprocess(im, one, mean, std)
+        assert torch.equal(out[i], one)
+        want = ((im.float().cpu() - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)).permute(1, 2, 0).to(dtype)
+        assert torch.equal(out[i, :, :, :3].cpu(), want) and float(out[i, :, :, 3:].abs().max()) == 0.0
