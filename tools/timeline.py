@@ -8,8 +8,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "preprocess_kernel" in r["Kernel_Name"]]
-steps = starts[::4]                                  # 4 views per step
+starts = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
+multi = any("preprocess_multi" in rows[i]["Kernel_Name"] for i in starts)
+steps = starts[::2 if multi else 4]                  # one launch per view batch (2 per step) / per view (4, older builds)
 lo, hi = steps[-back - 1], steps[-back]
 t0 = int(rows[lo]["Start_Timestamp"])
 last_end = t0
