@@ -316,6 +316,8 @@ typedef struct {
   void* stage1;
   int d0, d1, d2;
   long ld0, ld1;
+  const float* hyper_dev;   /* optional DEVICE pointer to {lr, weight_decay}: read by the kernel instead of the two fields above, so
+                             * that a captured hipGraph of the step survives learning-rate schedule changes */
 } sw_sgd_tensor;
 int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float momentum, float grad_scale, sw_stream_t stream);
 /* out[i] = mean over the n_images images of (sum_v loss_view[b][i][v] / V)   (loss assembly, roi_heads_oicrplus.py:283-288,

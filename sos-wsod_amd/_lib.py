@@ -59,6 +59,7 @@ class SgdTensor(ctypes.Structure):
         ("param", c_void_p), ("grad", c_void_p), ("momentum_buf", c_void_p), ("n", c_long), ("lr", c_float),
         ("weight_decay", c_float), ("first_step", c_int), ("stage_kind", c_int), ("stage_dtype", c_int),
         ("stage0", c_void_p), ("stage1", c_void_p), ("d0", c_int), ("d1", c_int), ("d2", c_int), ("ld0", c_long), ("ld1", c_long),
+        ("hyper_dev", c_void_p),
     ]
 
 

@@ -470,13 +470,14 @@ __device__ __forceinline__ void sgd_conv_tile(const sw_sgd_tensor& d, int blk, f
   const int cib = d.d1 / 32;
   const int co0 = (blk / cib) * 32, ci0 = (blk % cib) * 32;
   const int Cin = d.d1, Cout = d.d0;
+  const float lr = d.hyper_dev ? d.hyper_dev[0] : d.lr, wd = d.hyper_dev ? d.hyper_dev[1] : d.weight_decay;
   for (int idx = threadIdx.x; idx < 32 * 288; idx += 256) {
     const int co_l = idx / 288, rem = idx - co_l * 288;                 // rem = ci_l * 9 + tap
     const long o = ((long)(co0 + co_l) * Cin + ci0) * 9 + rem;
     const float w0 = d.param[o];
-    const float dd = d.grad[o] * gscale + d.weight_decay * w0;
+    const float dd = d.grad[o] * gscale + wd * w0;
     const float m = d.first_step ? dd : mom * d.momentum_buf[o] + dd;
-    const float w1 = w0 - d.lr * m;
+    const float w1 = w0 - lr * m;
     d.momentum_buf[o] = m; d.param[o] = w1;
     tile[co_l][rem] = w1;
   }
@@ -509,6 +510,9 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdBatch b, float mom, f
     else sgd_conv_tile<float>(d, (int)blockIdx.x - b.block_start[ti], mom, gscale, conv_tile);
     return;
   }
+  // learning rate / weight decay: kernel arguments, or (hyper_dev) two floats in device memory — a captured hipGraph of the
+  // step then stays valid when the schedule changes them
+  const float lr = d.hyper_dev ? d.hyper_dev[0] : d.lr, wd = d.hyper_dev ? d.hyper_dev[1] : d.weight_decay;
   const long base = (long)((int)blockIdx.x - b.block_start[ti]) * SGD_CHUNK;
   const long end = min(d.n, base + SGD_CHUNK);
   const bool vec = ((((uintptr_t)d.param) | ((uintptr_t)d.grad) | ((uintptr_t)d.momentum_buf)) & 15) == 0;
@@ -522,9 +526,9 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdBatch b, float mom, f
         float m[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float dd = g[e] * gscale + d.weight_decay * w[e];
+          const float dd = g[e] * gscale + wd * w[e];
           m[e] = d.first_step ? dd : mom * m[e] + dd;
-          w[e] = w[e] - d.lr * m[e];
+          w[e] = w[e] - lr * m[e];
         }
         *(float4*)(d.momentum_buf + i) = make_float4(m[0], m[1], m[2], m[3]);
         *(float4*)(d.param + i) = make_float4(w[0], w[1], w[2], w[3]);
@@ -544,9 +548,9 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdBatch b, float mom, f
       } else {
         for (long j = i; j < end; ++j) {
           const float w0 = d.param[j];
-          const float dd = d.grad[j] * gscale + d.weight_decay * w0;
+          const float dd = d.grad[j] * gscale + wd * w0;
           const float m = d.first_step ? dd : mom * d.momentum_buf[j] + dd;
-          const float w1 = w0 - d.lr * m;
+          const float w1 = w0 - lr * m;
           d.momentum_buf[j] = m; d.param[j] = w1;
           if (d.stage_kind) { if (d.stage_dtype == SW_BF16) sgd_stage<unsigned short>(d, j, w1); else sgd_stage<float>(d, j, w1); }
         }
@@ -555,9 +559,9 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdBatch b, float mom, f
   } else {
     for (long j = base + threadIdx.x; j < end; j += 256) {
       const float w0 = d.param[j];
-      const float dd = d.grad[j] * gscale + d.weight_decay * w0;
+      const float dd = d.grad[j] * gscale + wd * w0;
       const float m = d.first_step ? dd : mom * d.momentum_buf[j] + dd;
-      const float w1 = w0 - d.lr * m;
+      const float w1 = w0 - lr * m;
       d.momentum_buf[j] = m; d.param[j] = w1;
       if (d.stage_kind) { if (d.stage_dtype == SW_BF16) sgd_stage<unsigned short>(d, j, w1); else sgd_stage<float>(d, j, w1); }
     }
@@ -570,8 +574,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void sgd_tile_t_kernel(int rows, int cols, float* __restrict__ param,
                                                          const float* __restrict__ grad, float* __restrict__ buf, long ld_src,
                                                          float lr, float wd, int first, float mom, float gscale,
-                                                         T* __restrict__ st0, long ld0, T* __restrict__ st1, long ld1) {
+                                                         T* __restrict__ st0, long ld0, T* __restrict__ st1, long ld1,
+                                                         const float* __restrict__ hyper) {
   __shared__ float tile[64][65];
+  if (hyper) { lr = hyper[0]; wd = hyper[1]; }
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;
 #pragma unroll
@@ -1068,9 +1074,9 @@ extern "C" int sw_convert_2d_t(int dtype, int rows, int cols, const float* src, 
   dim3 grid(cols / 64, rows / 64);
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(sgd_tile_t_kernel<unsigned short>, grid, dim3(256), 0, stream, rows, cols, (float*)src, (const float*)nullptr,
-                       (float*)nullptr, ld_src, 0.f, 0.f, 0, 0.f, 0.f, (unsigned short*)nullptr, 0L, (unsigned short*)dst, ld_dst),
+                       (float*)nullptr, ld_src, 0.f, 0.f, 0, 0.f, 0.f, (unsigned short*)nullptr, 0L, (unsigned short*)dst, ld_dst, (const float*)nullptr),
     hipLaunchKernelGGL(sgd_tile_t_kernel<float>, grid, dim3(256), 0, stream, rows, cols, (float*)src, (const float*)nullptr,
-                       (float*)nullptr, ld_src, 0.f, 0.f, 0, 0.f, 0.f, (float*)nullptr, 0L, (float*)dst, ld_dst));
+                       (float*)nullptr, ld_src, 0.f, 0.f, 0, 0.f, 0.f, (float*)nullptr, 0L, (float*)dst, ld_dst, (const float*)nullptr));
   SW_CHECK_LAUNCH();
   return 0;
 }
@@ -1094,11 +1100,11 @@ extern "C" int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float m
         if (d.stage_dtype == SW_BF16)
           hipLaunchKernelGGL(sgd_tile_t_kernel<unsigned short>, grid, dim3(256), 0, stream, (int)rows, d.d0, d.param, d.grad,
                              d.momentum_buf, (long)d.d0, d.lr, d.weight_decay, d.first_step, momentum, grad_scale,
-                             (unsigned short*)d.stage0, d.ld0, (unsigned short*)d.stage1, d.ld1);
+                             (unsigned short*)d.stage0, d.ld0, (unsigned short*)d.stage1, d.ld1, d.hyper_dev);
         else
           hipLaunchKernelGGL(sgd_tile_t_kernel<float>, grid, dim3(256), 0, stream, (int)rows, d.d0, d.param, d.grad,
                              d.momentum_buf, (long)d.d0, d.lr, d.weight_decay, d.first_step, momentum, grad_scale,
-                             (float*)d.stage0, d.ld0, (float*)d.stage1, d.ld1);
+                             (float*)d.stage0, d.ld0, (float*)d.stage1, d.ld1, d.hyper_dev);
         SW_CHECK_LAUNCH();
         continue;
       }

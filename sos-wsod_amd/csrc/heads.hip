@@ -344,6 +344,14 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(int N, int C, const flo
   if (r >= N) return;
   const float* x = logits + (long)r * ld;
   const int t = target[r];
+  if ((unsigned)t >= (unsigned)C) {
+    // a class outside [0, C): torch's cross_entropy device-asserts here (the reference); this kernel must neither read out of
+    // bounds nor return a plausible number — the row's loss and gradient become NaN, which the trainer's finite check reports
+    const float nan = __uint_as_float(0x7FC00000u);
+    if (lane == 0) row_loss[r] = nan;
+    if (dlogits) for (int j = lane; j < C; j += 64) dlogits[(long)r * ld_d + j] = nan;
+    return;
+  }
   float m = -FLT_MAX;
   for (int j = lane; j < C; j += 64) m = fmaxf(m, x[j]);
   m = wave_reduce_max(m);

@@ -15,6 +15,7 @@
 // no global atomics, no cross-workgroup traffic (a per-channel argmax scatters 64 lanes to 64 different
 // rows, which global float atomics serve ~17x below their peak rate).
 #include <float.h>
+#include <type_traits>
 #include <stdlib.h>
 #include "common.h"
 #include "soswsod_hip.h"
@@ -201,12 +202,17 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
 // argmax words of 4 ROIs (16-byte aligned, 8 loads in flight) before scattering.
 constexpr int FX_CHUNK = 1024;          // ROIs per compaction round of the fixed-point backward
 
-// ACC = unsigned long long: 40 fractional-range bits per term (fp32 mode).  ACC = unsigned int (bf16 mode): a pixel-channel
-// receives at most PH*PW bins of every ROI of its image, so with bits = ceil(log2(PH*PW*R_image)) a term may use 30 - bits bits
-// (13 for R_image = 2000: 2^-13 of the largest term, against bf16's 2^-8 outputs) and the sum cannot overflow whatever the ROI
-// sizes; the conversion is then ONE v_cvt_i32_f32 instead
-// of an emulated f32 -> i64 (the kernel is VALU-issue bound: 88 M wave instructions per 4000 ROIs).
-template <typename T, typename IT, typename ACC>
+// Accumulator forms (ACCMODE):
+//   0  one 64-bit word, 40 bits per term (fp32 mode): room for 2^23 terms.
+//   2  a PAIR of 32-bit words (bf16 mode, the default): a pixel-channel receives at most PH*PW bins of every ROI of its image, so
+//      with bits = ceil(log2(PH*PW*R_image)) a word may take 30 - bits bits per term without overflow whatever the ROI sizes
+//      (13 at R_image = 2000).  13 bits relative to the GLOBAL max|dpooled|*max|objectness+1| are a dead zone of max/16384 on a
+//      gradient whose per-row weights span 30 decades (ignored / background rows), so the term is split: hi = rint(t * 2^frac),
+//      lo = rint((t * 2^frac - hi) * 2^bits') with |lo| <= 2^(bits'-1): two v_cvt_i32_f32 + two 32-bit LDS atomics = 2 x (30 - bits)
+//      bits per term (26 at R_image = 2000, 24 at 4000: 2^-26 of the largest term against bf16's 2^-8 outputs), still without the
+//      emulated f32 -> i64 conversion (the kernel is VALU-issue bound: 88 M wave instructions per 4000 ROIs).
+//   1  one 32-bit word (round 2's form, 30 - bits bits per term): kept behind SW_ROI_BWD_ACC32 for A/B timing only.
+template <typename T, typename IT, int ACCMODE>
 __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int C, long ld, int nb, int CB,
                                                                const T* __restrict__ dout, const IT* __restrict__ argmax,
                                                                const float* __restrict__ rois, int R,
@@ -221,12 +227,14 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   const int npix_all = H * W;
   const int px_per = (npix_all + gridDim.z - 1) / gridDim.z;
   const int p0 = blockIdx.z * px_per, p1 = min(npix_all, p0 + px_per);
+  typedef typename std::conditional<ACCMODE == 0, unsigned long long, unsigned int>::type ACC;
+  constexpr int ACC_BYTES = ACCMODE == 1 ? 4 : 8;                // per pixel-channel
   ACC* acc = (ACC*)smem;          // [CB][H*W] two's-complement fixed point: the lanes of a wave
                                                                 // hold bins of ONE channel => neighbouring pixels => distinct banks
                                                                 // (pixel-major [H*W][CB] put them 64 B apart: 8-16-way conflicts)
   const int img = blockIdx.y, c0 = blockIdx.x * CB;
   const int npix = max(p1 - p0, 0);
-  for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) acc[i] = (ACC)0;
+  for (int i = threadIdx.x; i < npix * CB * (ACCMODE == 2 ? 2 : 1); i += blockDim.x) acc[i] = (ACC)0;     // mode 2: hi words, then lo words
   float smax = 0.f;                                             // max |row_scale + add| (wave/block reduce, tiny)
   if (row_scale) { for (int r = threadIdx.x; r < R; r += blockDim.x) smax = fmaxf(smax, fabsf(row_scale[r] + row_scale_add)); }
   else smax = 1.f;
@@ -246,7 +254,8 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   n_img = __shfl(n_img, 0, 64);
   const unsigned terms = (unsigned)max(nb * max(n_img, 1), 1);
   int frac = 0;
-  const int term_bits = sizeof(ACC) == 8 ? 40 : max(30 - (32 - __clz(terms)), 1);
+  const int term_bits = ACCMODE == 0 ? 40 : max(30 - (32 - __clz(terms)), 1);
+  const int lo_off = npix * CB;                                  // mode 2: index distance hi -> lo word
   if (bound > 0.f && !poisoned) frac = term_bits - (ilogbf(bound) + 1);
   __syncthreads();
   // ROIs are taken in chunks of FX_CHUNK: the workgroup first compacts (roi, scale) of the ROIs of ITS image into LDS,
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   // does not depend on it.
   const int nvec = (CB * nb) / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-  int* s_r = (int*)(smem + (size_t)px_per * CB * sizeof(ACC));
+  int* s_r = (int*)(smem + (size_t)px_per * CB * ACC_BYTES);
   float* s_m = (float*)(s_r + FX_CHUNK);
   for (int rc = 0; rc < R; rc += FX_CHUNK) {
     __syncthreads();                            // previous chunk's list fully consumed (and acc zeroed, first time)
@@ -312,12 +321,18 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
             if (sizeof(T) == 2) d = __uint_as_float((e & 1) ? (dv[u][e >> 1] & 0xFFFF0000u) : (dv[u][e >> 1] << 16));
             else d = __uint_as_float(dv[u][e]);
             if (rel < (unsigned)npix) {
-              if (sizeof(ACC) == 8) {
+              if (ACCMODE == 0) {
                 const long long q = __float2ll_rn(scalbnf(__fmul_rn(d, mul), frac));
                 atomicAdd((unsigned long long*)&acc[crow[e] + (int)rel], (unsigned long long)q);
-              } else {
+              } else if (ACCMODE == 1) {
                 const int q = __float2int_rn(scalbnf(__fmul_rn(d, mul), frac));
                 atomicAdd((unsigned int*)&acc[crow[e] + (int)rel], (unsigned int)q);
+              } else {
+                const float t = scalbnf(__fmul_rn(d, mul), frac);            // |t| < 2^term_bits
+                const float hf = rintf(t);                                    // v_rndne_f32; t - hf is exact, |t - hf| <= 0.5
+                const int qh = __float2int_rn(hf), ql = __float2int_rn(scalbnf(t - hf, term_bits));
+                atomicAdd((unsigned int*)&acc[crow[e] + (int)rel], (unsigned int)qh);
+                atomicAdd((unsigned int*)&acc[lo_off + crow[e] + (int)rel], (unsigned int)ql);
               }
             }
           }
@@ -330,8 +345,11 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   const T* rimg = relu_ref ? relu_ref + ((long)img * npix_all + p0) * C : nullptr;
   for (int i = threadIdx.x; i < npix * CB; i += blockDim.x) {
     const int p = i / CB, cc = i - p * CB;
-    float v = sizeof(ACC) == 8 ? scalbnf((float)(long long)acc[cc * npix + p], -frac)
-                               : scalbnf((float)(int)acc[cc * npix + p], -frac);
+    float v;
+    if (ACCMODE == 0) v = scalbnf((float)(long long)acc[cc * npix + p], -frac);
+    else if (ACCMODE == 1) v = scalbnf((float)(int)acc[cc * npix + p], -frac);
+    else v = scalbnf((float)(((long long)(int)acc[cc * npix + p] << term_bits) + (long long)(int)acc[lo_off + cc * npix + p]),
+                     -(frac + term_bits));
     if (rimg && !(Elem<T>::load(rimg + (long)p * C + c0 + cc) > 0.f)) v = 0.f;
     if (poisoned) v = __uint_as_float(0x7FC00000u);
     Elem<T>::store(dimg + (long)p * C + c0 + cc, v);
@@ -759,11 +777,13 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, con
                      void* dfeat, hipStream_t stream) {
   // fixed-point path: CB in {8, 4} with H*W*CB*8 bytes of LDS; needs max|dout| (device scalar)
   static const bool float_atomics = getenv("SW_ROI_FLOAT_ATOMICS") != nullptr;    // development switch
-  // bf16: 32-bit accumulators (see the kernel) when PH*PW*R terms (every bin of every ROI on one pixel: the worst case) leave
-  // >= 10 bits per term; fp32: 64-bit
-  const bool acc32 = sizeof(T) == 2 && R > 0 && (long)PH * PW * R < (1L << 30) &&
-                     (30 - (32 - __builtin_clz((unsigned)(PH * PW * R)))) >= 10;
-  const size_t ab = acc32 ? 4 : 8;
+  // bf16: a hi/lo pair of 32-bit accumulators (see the kernel) when PH*PW*R terms (every bin of every ROI on one pixel: the worst
+  // case) leave >= 8 bits per word; fp32: one 64-bit word.  SW_ROI_BWD_ACC32: round 2's single 32-bit word (A/B timing only)
+  static const bool acc32_single = getenv("SW_ROI_BWD_ACC32") != nullptr;          // development switch
+  const bool small_terms = sizeof(T) == 2 && R > 0 && (long)PH * PW * R < (1L << 30) &&
+                           (30 - (32 - __builtin_clz((unsigned)(PH * PW * R)))) >= 8;
+  const int accmode = !small_terms ? 0 : (acc32_single ? 1 : 2);
+  const size_t ab = accmode == 1 ? 4 : 8;
   int cbx = 8;
   while (cbx > 4 && ((size_t)H * W * cbx * ab > 128 * 1024 || (C % cbx) || (C / cbx) * nimg < 256)) cbx >>= 1;
   if (C % cbx) cbx = 0;
@@ -774,19 +794,16 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, con
     const size_t ldsx = (size_t)px_per * cbx * ab + FX_CHUNK * 8;
     dim3 gridx(C / cbx, nimg, nsplit), blockx(1024);
     hipError_t ex;
-    if (acc32) {
-      auto k = roi_pool_bwd_fx_kernel<T, IT, unsigned int>;
-      ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
-      if (ex != hipSuccess) return (int)ex;
-      hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, ld, PH * PW, cbx, (const T*)dout, (const IT*)argmax, rois, R,
-                         row_scale, row_scale_add, dout_absmax, (const T*)relu_ref, (T*)dfeat);
-    } else {
-      auto k = roi_pool_bwd_fx_kernel<T, IT, unsigned long long>;
-      ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
-      if (ex != hipSuccess) return (int)ex;
-      hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, ld, PH * PW, cbx, (const T*)dout, (const IT*)argmax, rois, R,
-                         row_scale, row_scale_add, dout_absmax, (const T*)relu_ref, (T*)dfeat);
+#define SW_BWD_FX(MODE)                                                                                                       \
+    {                                                                                                                           \
+      auto k = roi_pool_bwd_fx_kernel<T, IT, MODE>;                                                                             \
+      ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);                          \
+      if (ex != hipSuccess) return (int)ex;                                                                                     \
+      hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, ld, PH * PW, cbx, (const T*)dout, (const IT*)argmax, rois, R, \
+                         row_scale, row_scale_add, dout_absmax, (const T*)relu_ref, (T*)dfeat);                                 \
     }
+    if (accmode == 2) SW_BWD_FX(2) else if (accmode == 1) SW_BWD_FX(1) else SW_BWD_FX(0)
+#undef SW_BWD_FX
     SW_CHECK_LAUNCH();
     return 0;
   }

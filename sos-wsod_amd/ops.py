@@ -353,7 +353,8 @@ def wsddn_mil(logits, V, R, K, cls_col, det_col, gt_onehot, scores, loss_view, d
 
 
 def sgd_multi(entries, momentum, grad_scale=1.0):
-    """entries: list of dict(param, grad, buf, lr, weight_decay, first, staging=None|STAGING entry).  One launch per 24."""
+    """entries: list of dict(param, grad, buf, lr, weight_decay, first, staging=None|STAGING entry, hyper=None|device tensor
+    {lr, weight_decay} read by the kernel instead of the two floats).  One launch per 24."""
     from ._lib import SgdTensor
     n = len(entries)
     if n == 0:
@@ -363,6 +364,8 @@ def sgd_multi(entries, momentum, grad_scale=1.0):
         p, d = e["param"], arr[i]
         d.param, d.grad, d.momentum_buf, d.n = p.data_ptr(), e["grad"].data_ptr(), e["buf"].data_ptr(), p.numel()
         d.lr, d.weight_decay, d.first_step = float(e["lr"]), float(e["weight_decay"]), int(e["first"])
+        hy = e.get("hyper")
+        d.hyper_dev = None if hy is None else hy.data_ptr()
         st = e.get("staging")
         if st is None:
             d.stage_kind = 0

@@ -5,9 +5,13 @@ expose them — for callers that drive a predictor directly instead of through O
 Same kernels as the fused path: `_HipLinear` is an autograd node around sw_gemm (forward, data gradient, weight gradient) +
 sw_colsum; the WSDDN image-level loss and the OICR weighted-CE / L1 losses are the fused loss kernels (sw_wsddn_mil,
 sw_oicr_refine_loss), which emit the loss AND its logit gradient in one sweep — their autograd nodes only scale that gradient
-by the incoming cotangent.  `forward` returns plain tensors like the reference; the tensors remember the f32 logits they were
-computed from (attribute `_sw_logits`), which is what `losses` differentiates through.  `scores` of the WSDDN predictor is
-returned detached, as every consumer in the reference uses it (mining reads `.detach()`, the loss goes through `losses`)."""
+by the incoming cotangent.  `forward` returns plain tensors like the reference.  Every returned tensor is a real autograd output
+of the f32 logits (the OICR pair are column slices of them; the WSDDN scores leave `_WsddnScores`, whose backward is the analytic
+gradient of softmax(dim=1) * softmax(dim=0)), so caller-side losses built from them train the layer.  The tensors also remember
+their logits (attribute `_sw_logits`), which lets `losses` / `inference` run the FUSED kernels; a caller that dropped the
+attribute on the way (`.detach()`, slicing, `torch.cat` over images) still gets the same values: the OICR functions re-join
+`scores | deltas`, the WSDDN loss falls back to the reference's own expression on the scores.
+The compute-dtype copy of a layer's weights is cached on the layer until a parameter changes (ops.param_key)."""
 import torch
 
 from . import ops
@@ -17,7 +21,7 @@ class _HipLinear(torch.autograd.Function):
     """y (N, out) f32 = x (N, in) @ W^T + b through the MFMA GEMM; explicit backward"""
 
     @staticmethod
-    def forward(ctx, x, w, b, compute_dtype):
+    def forward(ctx, x, w, b, compute_dtype, staged=None):
         ops._need_gpu(x, w)
         N, D = x.shape
         out_f = w.shape[0]
@@ -25,8 +29,13 @@ class _HipLinear(torch.autograd.Function):
         if xs.dtype != compute_dtype:
             xs = xs.to(compute_dtype)
         ld = (out_f + 7) // 8 * 8                                            # 16-byte K pieces for the data-gradient GEMM
-        ws = torch.zeros(ld, D, device=x.device, dtype=compute_dtype)        # rows beyond out_f stay zero
-        ops.convert_2d(w.detach().float().contiguous(), ws, out_f, D)
+        if staged is not None and staged[0] is not None:
+            ws = staged[0]                                                   # the layer's cached copy (still current)
+        else:
+            ws = torch.zeros(ld, D, device=x.device, dtype=compute_dtype)    # rows beyond out_f stay zero
+            ops.convert_2d(w.detach().float().contiguous(), ws, out_f, D)
+            if staged is not None:
+                staged[0] = ws
         y = torch.empty(N, ld, device=x.device, dtype=torch.float32)[:, :out_f]
         ops.gemm(xs, ws, y, N, out_f, D, ep=ops.make_epilogue(bias=None if b is None else b.detach().float().contiguous(),
                                                               out_dtype=torch.float32))
@@ -57,7 +66,7 @@ class _HipLinear(torch.autograd.Function):
             dbp = torch.empty(ld, device=g.device, dtype=torch.float32)
             ops.colsum(gs, N, ld, dbp)
             db = dbp[:out_f]
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _LossFromUnitGrad(torch.autograd.Function):
@@ -78,23 +87,61 @@ def _splits(proposals, n):
     return [n] if proposals is None else [len(p) for p in proposals]
 
 
+def _linear_cached(layer, names, x, compute_dtype):
+    """x @ cat(weights)^T + cat(biases) with the compute-dtype operand cached on the layer while no parameter changed"""
+    ws_ = [getattr(layer, n).weight for n in names]
+    bs_ = [getattr(layer, n).bias for n in names]
+    key = (tuple(ops.param_key(p) for p in ws_), compute_dtype, x.device)
+    hit = layer.__dict__.get("_api_stage")
+    box = [hit[1] if (hit is not None and hit[0] == key) else None]
+    y = _HipLinear.apply(x, torch.cat(ws_, 0), torch.cat(bs_, 0), compute_dtype, box)
+    layer.__dict__["_api_stage"] = (key, box[0])
+    return y
+
+
+class _WsddnScores(torch.autograd.Function):
+    """scores = softmax(C, dim=1) * softmax(D, dim=0) per image (fast_rcnn_wsddn.py:564-567): forward by the MIL kernel, backward the
+    analytic gradient — with A = softmax_k(C), B = softmax_r(D) and g the cotangent:
+    dC = A * (gB - sum_k A gB),  dD = B * (gA - sum_r B gA)."""
+
+    @staticmethod
+    def forward(ctx, logits, K, sizes):
+        N = logits.shape[0]
+        scores = torch.empty(N, K, device=logits.device, dtype=torch.float32)
+        zeros_oh = torch.zeros(K, device=logits.device)
+        lg, off = logits.detach(), 0
+        for n in sizes:
+            lv = torch.empty(1, device=logits.device)
+            ops.wsddn_mil(lg[off:off + n], 1, n, K, 0, K, zeros_oh, scores[off:off + n].view(1, n, K), lv)
+            off += n
+        ctx.save_for_backward(lg)
+        ctx.K, ctx.sizes = K, tuple(sizes)
+        return scores
+
+    @staticmethod
+    def backward(ctx, g):
+        (lg,) = ctx.saved_tensors
+        K = ctx.K
+        d = torch.zeros_like(lg)
+        off = 0
+        for n in ctx.sizes:
+            A = torch.softmax(lg[off:off + n, :K], dim=1); B = torch.softmax(lg[off:off + n, K:2 * K], dim=0)
+            gB, gA = g[off:off + n] * B, g[off:off + n] * A
+            d[off:off + n, :K] = A * (gB - (A * gB).sum(1, keepdim=True))
+            d[off:off + n, K:2 * K] = B * (gA - (B * gA).sum(0, keepdim=True))
+            off += n
+        return d, None, None
+
+
 # ------------------------------------------------------------------------------------------------ WSDDN predictor
 def wsddn_forward(layer, x, proposals=None, compute_dtype=torch.float32):
     """fast_rcnn_wsddn.py:542-589: scores = softmax(cls(x), dim=1) * softmax(det(x), dim=0) per image; zero deltas"""
     if x.dim() > 2:
         x = torch.flatten(x, start_dim=1)
     K = layer.num_classes
-    w = torch.cat([layer.cls.weight, layer.det.weight], 0)
-    b = torch.cat([layer.cls.bias, layer.det.bias], 0)
-    logits = _HipLinear.apply(x, w, b, compute_dtype)                        # (N, 2K): [cls | det]
+    logits = _linear_cached(layer, ("cls", "det"), x, compute_dtype)          # (N, 2K): [cls | det]
     N = logits.shape[0]
-    scores = torch.empty(N, K, device=x.device, dtype=torch.float32)
-    zeros_oh = torch.zeros(K, device=x.device)
-    off = 0
-    for n in _splits(proposals, N):
-        lv = torch.empty(1, device=x.device)
-        ops.wsddn_mil(logits.detach()[off:off + n], 1, n, K, 0, K, zeros_oh, scores[off:off + n].view(1, n, K), lv)
-        off += n
+    scores = _WsddnScores.apply(logits, K, _splits(proposals, N))
     scores._sw_logits = logits
     deltas = torch.zeros(N, 4 * K, device=x.device, dtype=torch.float32)      # :579-585
     return scores, deltas
@@ -103,8 +150,18 @@ def wsddn_forward(layer, x, proposals=None, compute_dtype=torch.float32):
 def wsddn_losses(layer, predictions, proposals, gt_classes_img_oh):
     """fast_rcnn_wsddn.py:658-681 -> {"loss_cls": BCE(clamp(sum_r scores), onehot, mean over K) / N_img} (MEAN_LOSS True)"""
     scores, _ = predictions
-    logits = scores._sw_logits
+    logits = getattr(scores, "_sw_logits", None)
     K = layer.num_classes
+    if logits is None:
+        # the scores reached us without their logits (detached / sliced / re-concatenated by the caller): the reference's own
+        # expression (:340-375) on the scores — differentiable through _WsddnScores when they still carry a graph
+        total, off = 0.0, 0
+        sizes = _splits(proposals, scores.shape[0])
+        for i, n in enumerate(sizes):
+            p = scores[off:off + n].sum(0).clamp(1e-6, 1 - 1e-6)
+            total = total + torch.nn.functional.binary_cross_entropy(p, gt_classes_img_oh[i].float().to(p.device), reduction="mean")
+            off += n
+        return {"loss_cls": total / len(sizes) * layer.loss_weight.get("loss_cls", 1.0)}
     N = logits.shape[0]
     sizes = _splits(proposals, N)
     dev = logits.device
@@ -130,19 +187,24 @@ def oicr_forward(layer, x, compute_dtype=torch.float32):
     if x.dim() > 2:
         x = torch.flatten(x, start_dim=1)
     K = layer.num_classes
-    w = torch.cat([layer.cls_score.weight, layer.bbox_pred.weight], 0)
-    b = torch.cat([layer.cls_score.bias, layer.bbox_pred.bias], 0)
-    logits = _HipLinear.apply(x, w, b, compute_dtype)                        # (N, 5K+1): [cls_score | bbox_pred]
+    logits = _linear_cached(layer, ("cls_score", "bbox_pred"), x, compute_dtype)    # (N, 5K+1): [cls_score | bbox_pred]
     scores, deltas = logits[:, :K + 1], logits[:, K + 1:]
     scores._sw_logits = logits
     return scores, deltas
 
 
+def _oicr_logits(predictions):
+    """the (N, 5K+1) logits behind a (scores, deltas) pair: remembered by forward, or re-joined (differentiably) if a caller
+    handed in tensors that lost the attribute"""
+    scores, deltas = predictions
+    logits = getattr(scores, "_sw_logits", None)
+    return logits if logits is not None else torch.cat([scores, deltas], 1).float().contiguous()
+
+
 def oicr_losses(layer, predictions, proposals):
     """fast_rcnn_oicr.py:530-554 (OICROutputs :157-352): proposals carry proposal_boxes, gt_boxes, gt_classes, gt_weights.
     loss_cls = mean_r(CE(ignore -1) * w), loss_box_reg = sum_fg L1(deltas[gt class] - get_deltas(proposal, gt_box)) / R"""
-    scores, _ = predictions
-    logits = scores._sw_logits
+    logits = _oicr_logits(predictions)
     K = layer.num_classes
     dev = logits.device
     N = logits.shape[0]
@@ -181,9 +243,8 @@ def oicr_inference(layer, predictions, proposals):
     """fast_rcnn_oicr.py:584-614 -> (list[Instances], list[kept proposal rows]) : softmax scores, decoded + clipped boxes,
     score threshold, per-class NMS, top-k (fast_rcnn_inference :46-148)"""
     from .structures import Boxes, Instances
-    scores, _ = predictions
     K = layer.num_classes
-    logits = scores._sw_logits.detach()
+    logits = _oicr_logits(predictions).detach()
     results, kept = [], []
     off = 0
     import math

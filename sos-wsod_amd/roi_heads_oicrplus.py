@@ -90,15 +90,37 @@ def _splitmix64(x):
     return x ^ (x >> 31)
 
 
+def _current_rank():
+    import torch.distributed as dist
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def derive_dropout_seed(base, rank):
+    """per-rank dropout stream from the rank-independent base seed (engine/defaults.py:147 seeds SEED + rank)"""
+    return _splitmix64(_splitmix64(base & 0xFFFFFFFFFFFFFFFF) ^ (0x5051 + rank))
+
+
 class _DropoutStream:
+    """Checkpointable dropout stream.  The file is written by rank 0 only (DetectionCheckpointer.save), so what it holds is the
+    RANK-INDEPENDENT base seed + the stream position; every rank re-derives its own seed from (base, its rank) on load — a
+    resumed multi-rank run keeps one stream per rank (rank 0 continues its stream exactly; the others restart theirs at rank 0's
+    position, which differs from their own only when the ranks saw different proposal counts)."""
+
     def __init__(self, heads):
         self.heads = heads
 
     def state_dict(self):
-        return {"dropout_seed": self.heads.dropout_seed, "drop_counter": int(self.heads._drop_counter)}
+        self.heads._dropout_stream_seed()
+        return {"base_seed": self.heads._dropout_base, "dropout_seed": self.heads.dropout_seed,
+                "drop_counter": int(self.heads._drop_counter)}
 
     def load_state_dict(self, state):
-        self.heads.dropout_seed = state.get("dropout_seed", self.heads.dropout_seed)
+        if "base_seed" in state:
+            self.heads._dropout_base = int(state["base_seed"])
+            self.heads.dropout_seed = derive_dropout_seed(self.heads._dropout_base, _current_rank())
+        elif "dropout_seed" in state:                  # files written before the base seed was stored: rank 0's seed
+            rank = _current_rank()
+            self.heads.dropout_seed = state["dropout_seed"] if rank == 0 else derive_dropout_seed(state["dropout_seed"], rank)
         self.heads._drop_counter = int(state.get("drop_counter", self.heads._drop_counter))
 
 
@@ -211,6 +233,7 @@ class OICRPlusHeads(nn.Module):
         self.seed = int(seed)
         self.train_dropout = True         # tests: switch the fc6 / fc7 dropout off (box_head.py:90 always drops 0.5 in training)
         self.dropout_seed = None
+        self._dropout_base = None         # rank-independent seed the per-rank stream seeds derive from (checkpointed)
         self._drop_counter_host = 0       # stream position; lives in a device scalar once the first training forward ran, so that
         self._drop_ctr_dev = None         # a captured hipGraph of the step draws a fresh mask on every replay
         self._prestaged_labels = None     # graph capture / replay: (static device buffer, per-image class counts), see stage_labels
@@ -238,10 +261,11 @@ class OICRPlusHeads(nn.Module):
     # ------------------------------------------------------------------ dropout stream state
     def _dropout_stream_seed(self):
         if self.dropout_seed is None:
-            import torch.distributed as dist
-            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-            base = self.seed if self.seed >= 0 else torch.initial_seed()
-            self.dropout_seed = _splitmix64(_splitmix64(base & 0xFFFFFFFFFFFFFFFF) ^ (0x5051 + rank))
+            if self._dropout_base is None:
+                self._dropout_base = self.seed if self.seed >= 0 else torch.initial_seed()
+            self.dropout_seed = derive_dropout_seed(self._dropout_base, _current_rank())
+        elif self._dropout_base is None:
+            self._dropout_base = self.seed if self.seed >= 0 else torch.initial_seed()
         return self.dropout_seed
 
     @property
@@ -728,7 +752,8 @@ class OICRPlusHeads(nn.Module):
         names = loss_names(self.refine_K)
         losses = LossDict(names, vec, total, self._last_finite)
         self.iter = self.iter + 1
-        if has_event_storage():
+        if has_event_storage() and not (feats[0].is_cuda and torch.cuda.is_current_stream_capturing()):
+            # (inside a hipGraph capture these are static graph outputs: the trainer records snapshots of them after each replay)
             st = get_event_storage()
             for k, r in enumerate(self.last_aux["rounds"]):
                 st.put_scalar(f"roi_head/num_pgt_r{k}", r["pgt_count"])      # device scalars: no host sync here

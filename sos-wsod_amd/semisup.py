@@ -91,7 +91,7 @@ class _FocalLossFunction(torch.autograd.Function):
     def forward(ctx, logits, target, gamma):
         x = logits.detach().float().contiguous()
         loss = torch.empty(1, device=x.device, dtype=torch.float32)
-        dl = torch.empty_like(x) if logits.requires_grad else None
+        dl = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ops.focal_loss(x, target.to(torch.int32).contiguous(), gamma, loss, dl)
         ctx.dl, ctx.in_dtype = dl, logits.dtype
         return loss.view(())

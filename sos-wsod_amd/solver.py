@@ -14,8 +14,30 @@ class HipSGD(torch.optim.Optimizer):
     """SGD + momentum + weight decay; state and hyper-parameters follow torch.optim.SGD so that schedulers and
     checkpoints interoperate.  One fused elementwise launch per parameter tensor (no host sync)."""
 
-    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, device_hyper=False):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        # device_hyper: every group's (lr, weight_decay) lives in a small device buffer the update kernel reads, refreshed by
+        # sync_hyper() when a scheduler changed them — a captured hipGraph of the step is then independent of the schedule
+        self.device_hyper = bool(device_hyper)
+        self._hyper_dev = None
+        self._hyper_host = None
+
+    def sync_hyper(self):
+        """bring the device copy of every group's (lr, weight_decay) up to date (one small async copy, only after a change);
+        call it in stream order before a replay of a captured step"""
+        if not self.device_hyper:
+            return
+        vals = [(float(g["lr"]), float(g["weight_decay"])) for g in self.param_groups]
+        if self._hyper_dev is None:
+            dev = next(p.device for g in self.param_groups for p in g["params"])
+            self._hyper_dev = torch.zeros(len(vals), 2, dtype=torch.float32, device=dev)
+            self._hyper_host = None
+        if vals != self._hyper_host:
+            host = torch.tensor(vals, dtype=torch.float32)
+            if self._hyper_dev.is_cuda:
+                host = host.pin_memory()
+            self._hyper_dev.copy_(host, non_blocking=True)
+            self._hyper_host = vals
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
@@ -23,7 +45,9 @@ class HipSGD(torch.optim.Optimizer):
         copies (ops.STAGING) get those rewritten from the updated values in the same pass."""
         ops.PARAM_EPOCH += 1
         by_mom = {}
-        for group in self.param_groups:
+        if self.device_hyper and (self._hyper_dev is None or not torch.cuda.is_current_stream_capturing()):
+            self.sync_hyper()                  # (inside a capture the copy would freeze today's values into the graph)
+        for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -39,7 +63,7 @@ class HipSGD(torch.optim.Optimizer):
                     staging = None
                 by_mom.setdefault(float(group["momentum"]), []).append(
                     dict(param=p, grad=g, buf=st["momentum_buffer"], lr=group["lr"], weight_decay=group["weight_decay"],
-                         first=first, staging=staging))
+                         first=first, staging=staging, hyper=self._hyper_dev[gi] if self.device_hyper else None))
         for mom, entries in by_mom.items():
             ops.sgd_multi(entries, mom, grad_scale)
             for e in entries:

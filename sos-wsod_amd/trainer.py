@@ -10,6 +10,7 @@ RCCL (xGMI).  Gradients leave the model's autograd nodes in the order they are p
 Step rule as the reference wrote it: optimizer.step() when `iter % ITER_SIZE == 0` (:149), the LR scheduler advances every
 iteration (its hook), gradients are zeroed at the start iteration and after every step."""
 import os
+from collections import OrderedDict
 
 import torch
 import torch.distributed as dist
@@ -148,7 +149,9 @@ class Trainer:
             self._raise_if_nonfinite()
             ff = getattr(loss_dict, "finite_flag", None)
             flag = ff() if callable(ff) else None
-            self._finite_flag = (self.iter, torch.isfinite(losses.detach()).all() if flag is None else flag)
+            # a SNAPSHOT: under hipGraph replay the flag is a static output of the graph that every later replay overwrites, and
+            # the check reads it `check_finite_every` iterations from now
+            self._finite_flag = (self.iter, torch.isfinite(losses.detach()).all() if flag is None else flag.detach().clone())
         if self.metrics_period and (self.iter + 1) % self.metrics_period == 0:
             self._write_metrics(loss_dict)
         self.storage.step()
@@ -173,11 +176,13 @@ class Trainer:
         vec = getattr(loss_dict, "vector", None)
         if vec is None:
             vec = torch.stack([v.detach() for v in loss_dict.values()])
-        vec = vec.detach()
+        # snapshots, not views: under hipGraph replay the loss vector and its sum are STATIC outputs of the captured graph (every
+        # later replay of that graph overwrites them; an EventStorage holding the views would show the last step's values in every
+        # history entry) — 11 floats per metrics_period iterations
+        vec = vec.detach().clone()
         total = getattr(loss_dict, "total", None)
-        tot = total().detach() if callable(total) else None
+        tot = total().detach().clone() if callable(total) else None
         if self.world > 1:
-            vec = vec.clone()
             dist.all_reduce(vec)
             vec /= self.world
             tot = None
@@ -185,6 +190,11 @@ class Trainer:
             for i, k in enumerate(loss_dict.keys()):
                 self.storage.put_scalar(k, vec[i])
             self.storage.put_scalar("total_loss", vec.sum() if tot is None else tot)
+            if self._graphs is not None and self._graphs.last_step_replayed:
+                # a replay does not run the heads' Python (which records these in eager steps): the counts are static graph outputs
+                aux = getattr(self.raw_model.roi_heads, "last_aux", None) or {}
+                for k, r in enumerate(aux.get("rounds", [])):
+                    self.storage.put_scalar(f"roi_head/num_pgt_r{k}", r["pgt_count"].detach().clone())
 
     def finish(self):
         """call after the last step: surfaces a pending non-finite flag"""
@@ -198,9 +208,12 @@ class _StepGraphs:
     backbone forward's 40 short kernels — is issue bound).
 
     A graph is valid for one input SIGNATURE: the four view sizes and the proposal count of every image (buffer shapes), the
-    number of image-level classes per image (a kernel argument of the mining kernel), the learning rates / weight decays of the
-    optimizer groups (kernel arguments of the update).  A signature is captured the second time it is seen; other steps run
-    eagerly.  What varies from step to step travels through device memory the graph reads: the images and proposals are copied
+    number of image-level classes per image (a kernel argument of the mining kernel) and the optimizer's momentum (a kernel
+    argument of the update).  Learning rates and weight decays are NOT part of it: a HipSGD under a graph-enabled trainer keeps
+    them in a device buffer the update kernel reads (HipSGD.device_hyper, refreshed by sync_hyper() before a replay when the
+    scheduler moved them), so warm-up and LR milestones neither invalidate the captured graphs nor fill the signature table.
+    A signature is captured the second time it is seen; other steps run eagerly.  At MAX_GRAPHS the least recently replayed
+    graph is dropped (its memory returns to the shared capture pool).  What varies from step to step travels through device memory the graph reads: the images and proposals are copied
     into the graph's static input tensors, the image-level labels into a static label buffer (OICRPlusHeads.stage_labels), and
     the dropout stream position is a device counter the graph itself advances (sw_counter_add).  One image-size bucket of a
     real training run = one graph; a run whose every image has its own size simply never replays."""
@@ -213,8 +226,13 @@ class _StepGraphs:
         self.heads = self.model.roi_heads
         self.dev = next(self.model.parameters()).device
         self.seen = {}
-        self.graphs = {}
+        self.graphs = OrderedDict()           # signature -> captured step, least recently used first
         self.pool = None
+        self.last_step_replayed = False
+        self.evictions = 0
+        self.lr_in_signature = not hasattr(trainer.optimizer, "sync_hyper")
+        if not self.lr_in_signature:
+            trainer.optimizer.device_hyper = True
         self.labels = torch.zeros(4096, dtype=torch.float32, device=self.dev)
         self.stream = torch.cuda.Stream(device=self.dev)
         self.replays = self.captures = 0
@@ -232,7 +250,10 @@ class _StepGraphs:
                 sig.append((tuple(im.shape), len(p)))
             g = x["instances1"].gt_classes
             sig.append(int(torch.unique(g.detach().cpu()).numel()))
-        opt = tuple((float(g["lr"]), float(g["weight_decay"]), float(g.get("momentum", 0.0))) for g in self.tr.optimizer.param_groups)
+        if self.lr_in_signature:             # a foreign optimizer: its hyper-parameters are frozen into the capture
+            opt = tuple((float(g["lr"]), float(g["weight_decay"]), float(g.get("momentum", 0.0))) for g in self.tr.optimizer.param_groups)
+        else:
+            opt = tuple(float(g.get("momentum", 0.0)) for g in self.tr.optimizer.param_groups)
         return (tuple(sig), opt, self.model.training)
 
     @staticmethod
@@ -270,6 +291,7 @@ class _StepGraphs:
 
     def step(self, data):
         """-> (loss_dict, total) after replaying (or capturing + replaying) this step's graph, or None: run eagerly"""
+        self.last_step_replayed = False
         if not self.enabled:
             return None
         sig = self._signature(data)
@@ -279,20 +301,27 @@ class _StepGraphs:
         if hit is None:
             n = self.seen.get(sig, 0) + 1
             self.seen[sig] = n
-            if n < 2 or len(self.graphs) >= self.MAX_GRAPHS:
+            if n < 2:
                 if len(self.seen) > 4096:
                     self.seen.clear()
                 return None
+            while len(self.graphs) >= self.MAX_GRAPHS:            # least recently replayed signature makes room
+                self.graphs.popitem(last=False)
+                self.evictions += 1
             hit = self._capture(sig, data)
             if hit is None:
                 return None
+        self.graphs.move_to_end(sig)
         graph, static, loss_dict, losses = hit
         try:
             self._stage(static, data)
+            if not self.lr_in_signature:
+                self.tr.optimizer.sync_hyper()                    # in stream order before the replay reads the buffer
             graph.replay()
         finally:
             self.heads._prestaged_labels = None
         self.replays += 1
+        self.last_step_replayed = True
         return loss_dict, losses
 
     def _capture(self, sig, data):
@@ -300,6 +329,8 @@ class _StepGraphs:
         for p in self.model.parameters():                      # the captured optimizer must not create state
             if p.requires_grad and "momentum_buffer" not in tr.optimizer.state.get(p, {}):
                 return None
+        if not self.lr_in_signature:
+            tr.optimizer.sync_hyper()                          # today's values, OUTSIDE the capture (the captured update only reads the buffer)
         static = self._clone_inputs(data)
         self.heads.stage_labels([x["instances1"] for x in data], self.labels)
         torch.cuda.synchronize()

@@ -32,11 +32,15 @@ def main():
     dev = torch.device("cuda", int(os.environ.get("SW_BENCH_DEVICE", 0)))
     torch.cuda.set_device(dev)
     dtype = torch.float32 if dtype_name == "fp32" else torch.bfloat16
-    K, R, H, W, dan = 20, 60, 96, 128, (256, 256)
+    full = len(sys.argv) > 3 and sys.argv[3] == "full"
+    # "full": BASELINE config #3's per-rank shape once (512x512 views, 2000 proposals, fc 4096/4096: the 411 MB fc6 gradient is a
+    # bucket of its own, the real bucket order and sizes), one step; default: a toy shape, three steps
+    K, R, H, W, dan = (20, 2000, 512, 512, (4096, 4096)) if full else (20, 60, 96, 128, (256, 256))
     P = O.make_params(K, dan, tag="pddp", head_scale=20.0)
 
     def data_of(r, step):
-        views, gt = O.make_views(H + 16 * r, W, R + 7 * r, n_gt=2, K=K, tag=f"vddp{r}_{step}")   # ranks see different sizes
+        views, gt = O.make_views(H + 16 * r, W, R + 7 * r, n_gt=2, K=K, scale2=1.0 if full else 1.25,
+                                 tag=f"vddp{r}_{step}")                                       # ranks see different sizes
         return to_batched_inputs(views, gt)
 
     def fresh():
@@ -55,12 +59,12 @@ def main():
         hd.seed = 1234
         hd.dropout_seed = None
         import sos_wsod_amd.roi_heads_oicrplus as rh
-        hd.dropout_seed = rh._splitmix64(rh._splitmix64(1234) ^ (0x5051 + r))
+        hd.dropout_seed = rh.derive_dropout_seed(1234, r)
         hd._drop_counter = counter
 
     from sos_wsod_amd.events import EventStorage
     # ---- single-process replica: per step the mean of both ranks' gradients, own HipSGD
-    N_STEPS = 3
+    N_STEPS = 1 if full else 3
     rep = fresh()
     rep_opt = HipSGD(groups(rep), 1e-2, momentum=0.9)
     counters = [0, 0]

@@ -108,3 +108,40 @@ def test_detection_wire_format_and_postprocess(tmp_path):
     assert json.load(open(tmp_path / "det.json")) == [
         {"image_id": 12, "category_id": 1, "score": 0.5, "bbox": [381.0, 181.0, 400.0, 200.0]},
         {"image_id": 12, "category_id": 4, "score": 0.988, "bbox": [21.0, 41.0, 100.0, 120.0]}]
+
+
+def _resume_worker(rank, world, port, ckdir, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sos_wsod_amd.checkpoint import DetectionCheckpointer
+    m = _model()
+    m.roi_heads.seed = 1234
+    first = m.roi_heads._dropout_stream_seed()
+    m.roi_heads._drop_counter = 777 + rank                         # ranks at different stream positions
+    if rank == 0:                                                  # the reference saves on rank 0 only
+        DetectionCheckpointer(m, ckdir).save("model_0000009", iteration=9)
+    dist.barrier()
+    m2 = _model()
+    DetectionCheckpointer(m2, ckdir).resume_or_load("", resume=True)
+    torch.save({"first": first, "resumed": m2.roi_heads._dropout_stream_seed(), "counter": m2.roi_heads._drop_counter},
+               f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_resume_keeps_one_dropout_stream_per_rank(tmp_path):
+    """the checkpoint file is written by rank 0; after a resume every rank must again draw its OWN masks (seed derived from the
+    rank-independent base seed in the file and the rank), not rank 0's"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "res")
+    mp.spawn(_resume_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["first"] != r1["first"]
+    assert r0["resumed"] == r0["first"] and r1["resumed"] == r1["first"]     # each rank continues with its own seed
+    assert r0["counter"] == 777 and r1["counter"] == 777                      # the position saved by rank 0

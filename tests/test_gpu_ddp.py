@@ -44,6 +44,20 @@ def test_real_model_two_ranks_gradients_and_parameters(tmp_path, dtype):
         assert len(res["metrics"]) == 9 and all(v == v for v in res["metrics"].values())
 
 
+def test_real_model_two_ranks_at_config3_per_gpu_size(tmp_path):
+    """the same check once at BASELINE config #3's per-rank shape (512x512 views, R = 2000, fc 4096/4096, bf16): 543 MB of
+    gradients through DDP's real bucket layout (fc1.weight a 411 MB bucket of its own)"""
+    out = str(tmp_path / "ddpfull")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_real_worker.py"), out, "bf16", "full"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    for rank in range(2):
+        res = torch.load(f"{out}.rank{rank}")
+        assert max(res["grad_err"]) <= 1e-6, max(res["grad_err"])
+        assert res["same_across_ranks"] and res["replica_err"] <= 1e-6 and res["moved"] > 0
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it prints one line with n_gpus 2 (both ranks on cuda:0 over gloo here)"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]

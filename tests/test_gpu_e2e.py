@@ -82,7 +82,7 @@ def test_bf16_iteration_close_to_bf16_emulating_oracle(case, golden_dir):
     from sos_wsod_amd.events import EventStorage
     g, P, views, gt, masks, model = _setup(case, golden_dir, torch.bfloat16)
     K = int(g["K"])
-    ol, oaux, _ = O.oicr_plus_iteration(P, views, gt, masks, K=K, bf16=True)
+    ol, oaux, ograds = O.oicr_plus_iteration(P, views, gt, masks, K=K, bf16=True, want_grads=True)
     with EventStorage(0):
         losses = model(to_batched_inputs(views, gt))
         sum(losses.values()).backward()
@@ -93,11 +93,32 @@ def test_bf16_iteration_close_to_bf16_emulating_oracle(case, golden_dir):
     for k in range(4):
         n = int(aux["rounds"][k]["pgt_count"].item())
         assert np.array_equal(aux["rounds"][k]["pgt_index"][:n].cpu().numpy(), oaux["rounds"][k]["pgt"]["index"])
+    # EVERY gradient of the benchmarked mode against the oracle's autograd over the same bf16 storage points (the oracle's
+    # backward itself runs in f32; the HIP path also rounds dZ / dpooled / dfeat to bf16 at layer boundaries, 2^-9 each):
+    # relative L2 <= 2e-2 and cosine >= 0.999 per tensor, backbone included.  d(det.bias) is analytically 0 (the softmax over
+    # proposals is shift invariant): both sides hold rounding noise there, compared on an absolute scale instead.
     sd = dict(model.named_parameters())
-    gref = g["grad/roi_heads.box_head.fc2.bias"]
-    got = sd["roi_heads.box_head.fc2.bias"].grad.cpu().numpy()
-    cos = float((got * gref).sum() / (np.linalg.norm(got) * np.linalg.norm(gref) + 1e-30))
-    assert cos > 0.99, cos
+    report, bad = [], []
+    for name, p in sd.items():
+        ref = ograds.get(name)
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        assert ref is not None and p.grad is not None, name
+        got, ref = p.grad.double().cpu().numpy().ravel(), ref.astype(np.float64).ravel()
+        nr = np.linalg.norm(ref)
+        if name.endswith("box_predictor.det.bias"):
+            assert np.abs(got).max() <= 1e-4 and np.abs(ref).max() <= 1e-4, name
+            continue
+        rel = float(np.linalg.norm(got - ref) / (nr + 1e-300))
+        cos = float((got * ref).sum() / (np.linalg.norm(got) * nr + 1e-300))
+        report.append((name, rel, cos))
+        if not (rel <= 2e-2 and cos >= 0.999):
+            bad.append((name, rel, cos))
+    print("bf16 gradient report (name, relative L2, cosine):")
+    for r in report:
+        print("   %-55s %.3e %.6f" % r)
+    assert not bad, bad
 
 
 def test_backbone_standalone_api_and_roipooler(golden_dir):
@@ -578,7 +599,7 @@ def test_step_graph_replay_equals_eager_steps(golden_dir):
     """Trainer(use_graph=True): after the second sight of an input signature the whole step (forward, backward, HipSGD) replays
     as one hipGraph.  Same start, same data sequence, same dropout stream => losses and weights of every step are bitwise those
     of the eager run, for new images / proposals / labels copied into the graph's static inputs each step."""
-    from sos_wsod_amd.solver import HipSGD
+    from sos_wsod_amd.solver import HipSGD, WarmupMultiStepLR
     from sos_wsod_amd.trainer import Trainer
     K, dan, R, H, W = 20, (256, 256), 80, 96, 128
     P = O.make_params(K, dan, tag="pgraph", head_scale=3.0)
@@ -601,7 +622,11 @@ def test_step_graph_replay_equals_eager_steps(golden_dir):
         model.train()
         model.roi_heads.seed = 77
         groups = [{"params": [p], "lr": 1e-3, "weight_decay": 5e-4} for p in model.parameters() if p.requires_grad]
-        tr = Trainer(model, HipSGD(groups, 1e-3, momentum=0.9), use_graph=use_graph, check_finite_every=2, metrics_period=2)
+        opt = HipSGD(groups, 1e-3, momentum=0.9)
+        # the learning rate moves DURING the replayed steps (milestones at 3 and 4): it reaches the captured update through the
+        # optimizer's device buffer, not through kernel arguments — still one capture, still bitwise the eager run
+        sched = WarmupMultiStepLR(opt, [3, 4], gamma=0.5, warmup_iters=0)
+        tr = Trainer(model, opt, scheduler=sched, use_graph=use_graph, check_finite_every=2, metrics_period=1)
         losses = []
         for b in batches():
             ld = tr.run_step(b)
@@ -613,8 +638,16 @@ def test_step_graph_replay_equals_eager_steps(golden_dir):
     tr_g, lg, wg = run(True)
     assert tr_e._graphs is None and tr_g._graphs is not None
     assert tr_g._graphs.captures == 1 and tr_g._graphs.replays == 4          # steps 0, 1 eager (step 1 = first sight), 2..5 replayed
+    assert abs(tr_g.optimizer.param_groups[0]["lr"] - 0.25e-3) < 1e-12
     for i, (a, b) in enumerate(zip(le, lg)):
         assert torch.equal(a, b), (i, a, b)
+    # the metric sink holds every step's OWN values (snapshots of the graph's static outputs, not views of them)
+    for tr_, ls in ((tr_e, le), (tr_g, lg)):
+        hist = tr_.storage.history("loss_cls")
+        assert [it for it, _ in hist] == list(range(6))
+        assert [float(v) for _, v in hist] == [float(l[0]) for l in ls]
+        assert [float(v) for _, v in tr_.storage.history("total_loss")] == pytest.approx([float(l.sum()) for l in ls], rel=1e-6)
+    assert len(tr_g.storage.history("roi_head/num_pgt_r0")) == 6
     bad = [n for n in we if not torch.equal(we[n], wg[n])]
     assert not bad, bad
     assert tr_g.raw_model.roi_heads._drop_counter == tr_e.raw_model.roi_heads._drop_counter > 0

@@ -102,3 +102,75 @@ def test_oicr_layer_forward_losses_probs_inference():
         assert len(d) == len(k_) <= 100 and (d.scores[:-1] >= d.scores[1:]).all()
         bx = d.pred_boxes.tensor
         assert (bx[:, 0] >= 0).all() and (bx[:, 2] <= 160).all() and (bx[:, 3] <= 120).all()
+
+
+def test_predictions_survive_caller_side_tensor_ops():
+    """the logits travel as a Python attribute on `scores`; a caller that slices / re-concatenates the predictions
+    (torch.cat over images drops attributes) must still get the same losses and gradients, and a loss the caller builds itself
+    from the WSDDN scores must train the layer (the scores are a real autograd output, not a detached tensor)."""
+    from sos_wsod_amd.fast_rcnn_oicr import OICROutputLayers
+    from sos_wsod_amd.fast_rcnn_wsddn import WSDDNOutputLayers
+    from sos_wsod_amd.structures import Boxes, Instances
+    torch.manual_seed(3)
+    K, D, sizes = 20, 128, [40, 25]
+    N = sum(sizes)
+    props = []
+    for n in sizes:
+        p = Instances((100, 100)); p.proposal_boxes = Boxes((torch.rand(n, 4) * 50 + torch.tensor([0.0, 0.0, 50.0, 50.0])).cuda())
+        p.gt_boxes = Boxes(p.proposal_boxes.tensor + 1.0); p.gt_classes = torch.randint(-1, K + 1, (n,)).cuda()
+        p.gt_weights = torch.rand(n).cuda(); props.append(p)
+    oh = torch.zeros(2, K, device="cuda"); oh[0, 3] = 1; oh[1, [5, 9]] = 1
+    x = torch.randn(N, D, device="cuda")
+
+    def grads(layer):
+        g = [p.grad.clone() for p in layer.parameters()]
+        for p in layer.parameters():
+            p.grad = None
+        return g
+    # ---- WSDDN: fused path vs predictions rebuilt by the caller (attribute gone) vs the caller's own loss on the scores
+    wl = WSDDNOutputLayers(D, num_classes=K).cuda()
+    with torch.no_grad():
+        wl.cls.weight.mul_(8); wl.det.weight.mul_(8)
+    s, d = wl(x, props)
+    assert s.requires_grad
+    l0 = wl.losses((s, d), props, oh)["loss_cls"]; l0.backward(); g0 = grads(wl)
+    s, d = wl(x, props)
+    s2 = torch.cat([s[:sizes[0]], s[sizes[0]:]], 0)                       # what per-image post-processing does
+    assert not hasattr(s2, "_sw_logits")
+    l1 = wl.losses((s2, d), props, oh)["loss_cls"]; l1.backward(); g1 = grads(wl)
+    assert abs(float(l1) - float(l0)) <= 1e-5 * abs(float(l0))
+    for a, b in zip(g0, g1):
+        assert _rel(b, a) < 1e-4
+    # reference-style code that builds its own loss from `scores` (this trained with zero gradient before)
+    xc = x.detach().cpu()
+    Wc = {n: p.detach().cpu().requires_grad_(True) for n, p in wl.named_parameters()}
+    C = F.linear(xc, Wc["cls.weight"], Wc["cls.bias"]); Dd = F.linear(xc, Wc["det.weight"], Wc["det.bias"])
+    ref = torch.cat([F.softmax(C[:sizes[0]], 1) * F.softmax(Dd[:sizes[0]], 0), F.softmax(C[sizes[0]:], 1) * F.softmax(Dd[sizes[0]:], 0)])
+    wgt = torch.rand(N, K)
+    (ref * wgt).sum().backward()
+    s, _ = wl(x, props)
+    (s * wgt.cuda()).sum().backward()
+    for n, p in wl.named_parameters():
+        assert _rel(p.grad.cpu(), Wc[n].grad) < 2e-4, n
+    # ---- OICR: fused path vs detached-and-rejoined predictions
+    ol = OICROutputLayers(D, num_classes=K, refine_k=0, refine_reg=[True]).cuda()
+    with torch.no_grad():
+        ol.cls_score.weight.mul_(30); ol.bbox_pred.weight.mul_(30)
+    sc, dl = ol(x)
+    la = ol.losses((sc, dl), props); (la["loss_cls"] + la["loss_box_reg"]).backward(); ga = grads(ol)
+    sc, dl = ol(x)
+    sc2, dl2 = sc[:, :].clone(), dl * 1.0                                # new tensors, graph kept, attribute lost
+    lb = ol.losses((sc2, dl2), props); (lb["loss_cls"] + lb["loss_box_reg"]).backward(); gb = grads(ol)
+    assert abs(float(la["loss_cls"]) - float(lb["loss_cls"])) <= 1e-6 * abs(float(la["loss_cls"]))
+    for a, b in zip(ga, gb):
+        assert _rel(b, a) < 1e-5
+    dets, _ = ol.inference((sc.detach(), dl.detach()), props)            # detached predictions: no AttributeError
+    assert len(dets) == 2
+    # the staged weight copy is cached until a parameter changes
+    st = ol.__dict__["_api_stage"][1]
+    ol(x)
+    assert ol.__dict__["_api_stage"][1] is st
+    with torch.no_grad():
+        ol.cls_score.weight.add_(1.0)
+    ol(x)
+    assert ol.__dict__["_api_stage"][1] is not st
