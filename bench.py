@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--images-per-gpu", type=int, default=1,
                     help="images (4-view sets) per GPU per step; BASELINE config #3 = --gpus 8 --images-per-gpu 2")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the short fp32 timing (extra key fp32_ms_per_step)")
+    ap.add_argument("--no-extra-shapes", action="store_true",
+                    help="skip the short runs of config #3's / #4's per-GPU shapes (extra keys b2_ms_per_step, coco_ms_per_step)")
     ap.add_argument("--graph", type=int, default=None,
                     help="1: replay the step as a captured hipGraph (default for --gpus 1), 0: eager launches (default under DDP)")
     args = ap.parse_args()
@@ -316,7 +318,7 @@ def main():
         }
         if world == 1 and dtype == torch.bfloat16 and not args.no_fp32_line:
             # the reference's own precision (fp32 storage, exact-f32 MFMA: 1/16 of the bf16 rate), a short run for the record
-            del trainer, opt, model
+            trainer = opt = model = graphs = None
             torch.cuda.empty_cache()
             m32 = build(device, torch.float32); m32.train()
             g32 = [{"params": [p], "lr": 2e-3 if n.endswith(".bias") else 1e-3, "weight_decay": 0.0 if n.endswith(".bias") else 5e-4}
@@ -330,6 +332,37 @@ def main():
             torch.cuda.synchronize()
             out["fp32_ms_per_step"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
             del t32, m32
+        if world == 1 and dtype == torch.bfloat16 and not args.no_extra_shapes:
+            # the other BASELINE shapes on one GPU, for the record (not the metric): config #3's per-GPU shape = 2 images per step,
+            # config #4's = 800x1333 views / 4000 proposals / 80 classes / FREEZE_AT 3.  Same trainer mode as the headline.
+            trainer = opt = model = graphs = None
+            torch.cuda.empty_cache()
+
+            def short_run(m, data2, n=8):
+                m.train()
+                gs = [{"params": [p], "lr": 2e-3 if nm.endswith(".bias") else 1e-3, "weight_decay": 0.0 if nm.endswith(".bias") else 5e-4}
+                      for nm, p in m.named_parameters() if p.requires_grad]
+                t = Trainer(m, HipSGD(gs, 1e-3, momentum=0.9), use_graph=use_graph)
+                for i in range(6):
+                    t.run_step(data2[i % 2])
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for i in range(n):
+                    t.run_step(data2[i % 2])
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / n * 1e3
+            mb = build(device, dtype)
+            ms = short_run(mb, [make_inputs(device, 300 + 2 * i) + make_inputs(device, 1300 + 2 * i) for i in range(2)])
+            out["b2_ms_per_step"] = round(ms, 3)
+            out["b2_images_per_s"] = round(8.0 / ms * 1e3, 1)
+            del mb
+            torch.cuda.empty_cache()
+            mc = build(device, dtype, K=80, freeze_at=3)
+            ms = short_run(mc, [make_inputs(device, 500 + i, H=800, W=1333, R=4000, K=80, n_gt=5) for i in range(2)], n=5)
+            out["coco_ms_per_step"] = round(ms, 3)
+            out["extra_shapes"] = {"b2": "BASELINE configs[2] per GPU: 2 images = 8 views 512x512, R=2000, K=20",
+                                   "coco": "BASELINE configs[3] per GPU: 4 views 800x1333 (99x165 maps), R=4000, K=80, FREEZE_AT 3"}
+            del mc
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -208,8 +208,8 @@ constexpr int FX_CHUNK = 1024;          // ROIs per compaction round of the fixe
 //      with bits = ceil(log2(PH*PW*R_image)) a word may take 30 - bits bits per term without overflow whatever the ROI sizes
 //      (13 at R_image = 2000).  13 bits relative to the GLOBAL max|dpooled|*max|objectness+1| are a dead zone of max/16384 on a
 //      gradient whose per-row weights span 30 decades (ignored / background rows), so the term is split: hi = rint(t * 2^frac),
-//      lo = rint((t * 2^frac - hi) * 2^bits') with |lo| <= 2^(bits'-1): two v_cvt_i32_f32 + two 32-bit LDS atomics = 2 x (30 - bits)
-//      bits per term (26 at R_image = 2000, 24 at 4000: 2^-26 of the largest term against bf16's 2^-8 outputs), still without the
+//      lo = rint((t * 2^frac - hi) * 2^bits') with |lo| <= 2^(bits'-1): two v_cvt_i32_f32 + two 32-bit LDS atomics = 2 x (30 - bits) + 1
+//      bits per term (27 at R_image = 2000, 25 at 4000: 2^-26 of the largest term against bf16's 2^-8 outputs), still without the
 //      emulated f32 -> i64 conversion (the kernel is VALU-issue bound: 88 M wave instructions per 4000 ROIs).
 //   1  one 32-bit word (round 2's form, 30 - bits bits per term): kept behind SW_ROI_BWD_ACC32 for A/B timing only.
 template <typename T, typename IT, int ACCMODE>
@@ -256,6 +256,9 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
   int frac = 0;
   const int term_bits = ACCMODE == 0 ? 40 : max(30 - (32 - __clz(terms)), 1);
   const int lo_off = npix * CB;                                  // mode 2: index distance hi -> lo word
+  // mode 2, lo word: |t - rint(t)| <= 1/2, so with lo_bits = term_bits + 1 a term is at most 2^term_bits and `terms` of them
+  // stay below 2^30 like the hi word's
+  const int lo_bits = term_bits + 1;
   if (bound > 0.f && !poisoned) frac = term_bits - (ilogbf(bound) + 1);
   __syncthreads();
   // ROIs are taken in chunks of FX_CHUNK: the workgroup first compacts (roi, scale) of the ROIs of ITS image into LDS,
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
               } else {
                 const float t = scalbnf(__fmul_rn(d, mul), frac);            // |t| < 2^term_bits
                 const float hf = rintf(t);                                    // v_rndne_f32; t - hf is exact, |t - hf| <= 0.5
-                const int qh = __float2int_rn(hf), ql = __float2int_rn(scalbnf(t - hf, term_bits));
+                const int qh = __float2int_rn(hf), ql = __float2int_rn(scalbnf(t - hf, lo_bits));
                 atomicAdd((unsigned int*)&acc[crow[e] + (int)rel], (unsigned int)qh);
                 atomicAdd((unsigned int*)&acc[lo_off + crow[e] + (int)rel], (unsigned int)ql);
               }
@@ -348,8 +351,8 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
     float v;
     if (ACCMODE == 0) v = scalbnf((float)(long long)acc[cc * npix + p], -frac);
     else if (ACCMODE == 1) v = scalbnf((float)(int)acc[cc * npix + p], -frac);
-    else v = scalbnf((float)(((long long)(int)acc[cc * npix + p] << term_bits) + (long long)(int)acc[lo_off + cc * npix + p]),
-                     -(frac + term_bits));
+    else v = scalbnf((float)(((long long)(int)acc[cc * npix + p] << lo_bits) + (long long)(int)acc[lo_off + cc * npix + p]),
+                     -(frac + lo_bits));
     if (rimg && !(Elem<T>::load(rimg + (long)p * C + c0 + cc) > 0.f)) v = 0.f;
     if (poisoned) v = __uint_as_float(0x7FC00000u);
     Elem<T>::store(dimg + (long)p * C + c0 + cc, v);
@@ -782,7 +785,8 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, con
   static const bool acc32_single = getenv("SW_ROI_BWD_ACC32") != nullptr;          // development switch
   const bool small_terms = sizeof(T) == 2 && R > 0 && (long)PH * PW * R < (1L << 30) &&
                            (30 - (32 - __builtin_clz((unsigned)(PH * PW * R)))) >= 8;
-  const int accmode = !small_terms ? 0 : (acc32_single ? 1 : 2);
+  static const bool acc64 = getenv("SW_ROI_BWD_ACC64") != nullptr;                 // development switch: the fp32 form for bf16 too
+  const int accmode = (!small_terms || acc64) ? 0 : (acc32_single ? 1 : 2);
   const size_t ab = accmode == 1 ? 4 : 8;
   int cbx = 8;
   while (cbx > 4 && ((size_t)H * W * cbx * ab > 128 * 1024 || (C % cbx) || (C / cbx) * nimg < 256)) cbx >>= 1;

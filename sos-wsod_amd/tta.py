@@ -126,6 +126,7 @@ class GeneralizedRCNNWithTTAAVG(torch.nn.Module):
             heads.test_scores_only = False
         n = float(len(views))
         all_scores, all_boxes = (sum_scores / n).contiguous(), (sum_boxes / n).contiguous()
+        self.last_avg = (all_scores, all_boxes)                    # tests: the view-averaged matrices that enter the merge
         cnt, dboxes, dscores, dclasses, _ = ops.detect_postprocess(all_scores, all_boxes, int(orig[0]), int(orig[1]),
                                                                    heads.test_score_thresh, heads.test_nms_thresh,
                                                                    heads.test_topk_per_image)

