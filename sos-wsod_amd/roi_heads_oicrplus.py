@@ -402,6 +402,22 @@ class OICRPlusHeads(nn.Module):
             row += n
         return Wh, flat_b
 
+    def _head_weights_t(self, Wh, device):
+        """(D, ld_head) transposed copy of the packed predictor operand for the logits' data gradient, rebuilt (one 64x64-tiled
+        launch over 3.6 MB) when a predictor weight changed; None when ld_head is not a multiple of 64 (the transposing kernel's
+        tile) — the data gradient then reads Wh K-strided."""
+        LD, D = Wh.shape
+        if LD % 64 or D % 64 or not hasattr(self, "_head_flat"):
+            return None
+        keys = list(self._stage_cache["heads"][0])
+        hit = self._stage_cache.get("heads_t")
+        if hit is not None and hit[0] == keys and hit[1].dtype == Wh.dtype and hit[1].device == device:
+            return hit[1]
+        buf = hit[1] if (hit is not None and hit[1].dtype == Wh.dtype and hit[1].device == device) else _padded(D, LD, device, Wh.dtype)
+        ops.convert_2d_t(self._head_flat[0], buf, LD, D)
+        self._stage_cache["heads_t"] = (keys, buf)
+        return buf
+
     def _staged_matrix(self, name, w, device, transposed=False):
         """persistent compute-dtype copy (padded row pitch) of an fc weight; see _pack_head_weights.  transposed=True
         also keeps the (cols, rows) transposed copy: the data-gradient GEMM then reads the weight K-contiguous like the
@@ -468,7 +484,10 @@ class OICRPlusHeads(nn.Module):
                 hashes = [(seed, 0, 0.5, ctr), (seed, M * D1, 0.5, ctr)]       # position = device counter + offset inside the step
         W1 = self._staged_matrix("fc1", fc1w, dev, transposed=inp["need_grad"])
         W1, W1T = W1 if isinstance(W1, tuple) else (W1, None)
-        W2 = self._staged_matrix("fc2", fc2w, dev)
+        # fc7's weight also keeps a transposed copy when a backward follows: its data gradient then reads the weight K-contiguous
+        # (NT form, ping-pong loop) like fc6's — as a K-strided operand it ran 289 us against the forward's 261
+        W2 = self._staged_matrix("fc2", fc2w, dev, transposed=inp["need_grad"])
+        W2, W2T = W2 if isinstance(W2, tuple) else (W2, None)
         h1 = _padded(M, D1, dev, dt_)
         ops.gemm(pooled, W1, h1, M, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], drop_hash=hashes[0], out_dtype=dt_),
                  tag="fc6_fwd")
@@ -529,7 +548,7 @@ class OICRPlusHeads(nn.Module):
         self.last_aux = aux
         self._last_finite = finite
         return dict(losses=losses, total=total, feats=feats, pooled=pooled, argmax=argmax, h1=h1, h2=h2, W1=W1, W1T=W1T, W2=W2,
-                    Wh=Wh, dlogits=dlogits, inp=inp, train_dropout=training_dropout)
+                    W2T=W2T, Wh=Wh, dlogits=dlogits, inp=inp, train_dropout=training_dropout)
 
     def _col_to_loss(self, device):
         """loss index of every packed logit column (each column belongs to exactly one loss term)."""
@@ -577,7 +596,11 @@ class OICRPlusHeads(nn.Module):
         dWh = torch.empty(LD, D2, device=dev, dtype=torch.float32)
         ops.gemm(dl, h2, dWh, LD, D2, M, a_kstrided=True, b_kstrided=True, splitk=4)      # slabs + ordered fold (deterministic)
         dz2 = _padded(M, D2, dev, dt_)
-        ops.gemm(dl, Wh, dz2, M, D2, LD, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h2, ref_scale=rs, out_dtype=dt_))
+        WhT = self._head_weights_t(Wh, dev)
+        if WhT is not None:                  # NT on the transposed packed predictor matrix (K = ld_head contiguous): 116 -> ~70 us
+            ops.gemm(dl, WhT, dz2, M, D2, LD, ep=ops.make_epilogue(relu_ref=h2, ref_scale=rs, out_dtype=dt_))
+        else:
+            ops.gemm(dl, Wh, dz2, M, D2, LD, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h2, ref_scale=rs, out_dtype=dt_))
         # fc7
         db2 = torch.empty(D2, device=dev, dtype=torch.float32); ops.colsum(dz2, M, D2, db2)
         # weight gradients read dZ^T (one 64x64-tiled transpose, 65 MB) so that the GEMM's A operand is K-contiguous: the
@@ -594,7 +617,10 @@ class OICRPlusHeads(nn.Module):
         else:
             ops.gemm(dz2, h1, dW2, D2, D1, M, a_kstrided=True, b_kstrided=True)
         dz1 = _padded(M, D1, dev, dt_)
-        ops.gemm(dz2, W2, dz1, M, D1, D2, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h1, ref_scale=rs, out_dtype=dt_))
+        if st.get("W2T") is not None:
+            ops.gemm(dz2, st["W2T"], dz1, M, D1, D2, ep=ops.make_epilogue(relu_ref=h1, ref_scale=rs, out_dtype=dt_))
+        else:
+            ops.gemm(dz2, W2, dz1, M, D1, D2, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h1, ref_scale=rs, out_dtype=dt_))
         st["dz1"] = dz1
         # split the packed gradients back onto the 10 predictor tensors (row slices are contiguous views)
         dparams = [dW2, db2]

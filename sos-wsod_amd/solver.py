@@ -21,6 +21,8 @@ class HipSGD(torch.optim.Optimizer):
         self.device_hyper = bool(device_hyper)
         self._hyper_dev = None
         self._hyper_host = None
+        self._done = set()                # ids of the parameters step_params() updated since the last step()
+        self._group_of = None
 
     def sync_hyper(self):
         """bring the device copy of every group's (lr, weight_decay) up to date (one small async copy, only after a change);
@@ -42,28 +44,51 @@ class HipSGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         """One launch (sw_sgd_multi) per 24 parameter tensors.  Parameters whose module registered compute-dtype staging
-        copies (ops.STAGING) get those rewritten from the updated values in the same pass."""
+        copies (ops.STAGING) get those rewritten from the updated values in the same pass.  Parameters already updated in this
+        iteration by step_params() (the data-parallel trainer's per-bucket update) are skipped."""
+        done, self._done = self._done, set()
+        self._update([(group, gi, p, p.grad) for gi, group in enumerate(self.param_groups) for p in group["params"]
+                      if p.grad is not None and id(p) not in done], grad_scale)
+
+    @torch.no_grad()
+    def step_params(self, params, grads=None, grad_scale=1.0):
+        """The same update for a SUBSET of the parameters, now — the data-parallel trainer calls it from DistributedDataParallel's
+        communication hook as soon as a gradient bucket has been all-reduced, so that e.g. fc6's 411 MB are updated while the
+        convolution backward still runs; the step() that follows the backward then skips them.  grads: the reduced gradients
+        (default: each parameter's .grad)."""
+        if self._group_of is None:
+            self._group_of = {id(p): (group, gi) for gi, group in enumerate(self.param_groups) for p in group["params"]}
+        items = []
+        for i, p in enumerate(params):
+            g = p.grad if grads is None else grads[i]
+            ent = self._group_of.get(id(p))
+            if ent is None or g is None or id(p) in self._done:
+                continue
+            items.append((ent[0], ent[1], p, g.view_as(p)))
+            self._done.add(id(p))
+        self._update(items, grad_scale)
+
+    def _update(self, items, grad_scale):
+        if not items:
+            return
         ops.PARAM_EPOCH += 1
         by_mom = {}
         if self.device_hyper and (self._hyper_dev is None or not torch.cuda.is_current_stream_capturing()):
             self.sync_hyper()                  # (inside a capture the copy would freeze today's values into the graph)
-        for gi, group in enumerate(self.param_groups):
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise TypeError("HipSGD updates contiguous float32 master parameters")
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                st = self.state[p]
-                first = "momentum_buffer" not in st
-                if first:
-                    st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
-                staging = ops.STAGING.get(id(p))
-                if staging is not None and (staging["param"] is not p or not self._staging_usable(staging, p)):
-                    staging = None
-                by_mom.setdefault(float(group["momentum"]), []).append(
-                    dict(param=p, grad=g, buf=st["momentum_buffer"], lr=group["lr"], weight_decay=group["weight_decay"],
-                         first=first, staging=staging, hyper=self._hyper_dev[gi] if self.device_hyper else None))
+        for group, gi, p, grad in items:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise TypeError("HipSGD updates contiguous float32 master parameters")
+            g = grad if grad.is_contiguous() else grad.contiguous()
+            st = self.state[p]
+            first = "momentum_buffer" not in st
+            if first:
+                st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
+            staging = ops.STAGING.get(id(p))
+            if staging is not None and (staging["param"] is not p or not self._staging_usable(staging, p)):
+                staging = None
+            by_mom.setdefault(float(group["momentum"]), []).append(
+                dict(param=p, grad=g, buf=st["momentum_buffer"], lr=group["lr"], weight_decay=group["weight_decay"],
+                     first=first, staging=staging, hyper=self._hyper_dev[gi] if self.device_hyper else None))
         for mom, entries in by_mom.items():
             ops.sgd_multi(entries, mom, grad_scale)
             for e in entries:

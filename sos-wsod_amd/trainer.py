@@ -55,7 +55,7 @@ class Trainer:
 
     def __init__(self, model, optimizer, data_iter=None, iter_size=1, scheduler=None, ddp=None, find_unused=False,
                  check_finite_every=20, grad_compress=None, metrics_period=20, bucket_cap_mb=None, start_iter=0,
-                 use_graph=None):
+                 use_graph=None, overlap_update=None):
         self.raw_model = model
         self.optimizer, self.scheduler = optimizer, scheduler
         self.iter_size = max(int(iter_size), 1)
@@ -95,10 +95,33 @@ class Trainer:
             # opt-in (NOT the reference's numerics): all-reduce the gradient buckets as bf16 — half the bytes on the xGMI
             # ring (the fc6 weight gradient alone is 411 MB per step); the sum is formed in bf16, the result returns as f32
             grad_compress = grad_compress or os.environ.get("SW_DDP_GRAD_COMPRESS")
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
             if grad_compress:
                 assert grad_compress == "bf16", f"unknown gradient compression {grad_compress!r}"
-                from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-                self.model.register_comm_hook(None, default_hooks.bf16_compress_hook)
+                reduce_hook = default_hooks.bf16_compress_hook
+            else:
+                reduce_hook = default_hooks.allreduce_hook
+            # Update as the buckets return (MI355X-first; the reference steps after the whole backward, train_net_multi.py:157-164):
+            # the optimizer's kernel for the parameters of a bucket is queued right behind that bucket's all-reduce — fc6's 411 MB
+            # (76 % of the bytes, reduced 3.3 ms before the backward ends) are updated while the convolution backward still runs,
+            # and only the backbone's 59 MB remain for after the backward.  Same arithmetic, same result bit for bit (the update
+            # of a parameter depends on its own reduced gradient only); needs an optimizer with step_params (HipSGD) and
+            # ITER_SIZE 1 (with accumulation the reference's rule steps every ITER_SIZE-th iteration only).
+            if overlap_update is None:
+                overlap_update = os.environ.get("SW_DDP_OVERLAP_UPDATE", "1") == "1"
+            self.overlap_update = bool(overlap_update) and hasattr(optimizer, "step_params") and self.iter_size == 1
+            if self.overlap_update:
+                opt = self.optimizer
+
+                def hook(state, bucket, reduce_hook=reduce_hook, opt=opt):
+                    def update(fut):
+                        v = fut.value()
+                        opt.step_params(bucket.parameters(), bucket.gradients())     # views of the (now reduced) bucket buffer
+                        return v[0] if isinstance(v, (list, tuple)) else v
+                    return reduce_hook(state, bucket).then(update)
+                self.model.register_comm_hook(None, hook)
+            elif grad_compress:
+                self.model.register_comm_hook(None, reduce_hook)
         else:
             self.model = model
         if self._want_graph and not use_ddp and self.iter_size == 1 and hasattr(model, "roi_heads") and \

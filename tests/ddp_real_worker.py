@@ -97,7 +97,7 @@ def main():
     assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
     flat_w, _ = model.roi_heads._head_flat                           # flattened BEFORE the DDP wrap (prepare_for_training)
     assert model.roi_heads.box_predictor.cls.weight.data_ptr() == flat_w.data_ptr()
-    res = {"grad_err": [], "rank": rank}
+    res = {"grad_err": [], "rank": rank, "overlap_update": tr.overlap_update, "left_for_step": []}
     for step in range(N_STEPS):
         # look at the all-reduced gradients of this step before the optimizer consumes them
         seen = {}
@@ -107,6 +107,7 @@ def main():
             for n, p in model.named_parameters():
                 if p.grad is not None:
                     seen[n] = p.grad.detach().clone()
+            res["left_for_step"].append(sum(1 for p in model.parameters() if p.grad is not None and id(p) not in opt._done))
             return orig_step(*a, **k)
         opt.step = spy_step
         tr.run_step(data_of(rank, step))

@@ -25,6 +25,19 @@ def _env():
     return dict(os.environ, SW_DIST_BACKEND="gloo", SW_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
 
 
+def test_real_model_two_ranks_update_after_the_backward(tmp_path):
+    """SW_DDP_OVERLAP_UPDATE=0: the reference's order (all-reduce everything, then one optimizer step) gives the same parameters"""
+    out = str(tmp_path / "ddpseq")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_real_worker.py"), out, "bf16"]
+    r = subprocess.run(cmd, env=dict(_env(), SW_DDP_OVERLAP_UPDATE="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    for rank in range(2):
+        res = torch.load(f"{out}.rank{rank}")
+        assert not res["overlap_update"] and all(n > 0 for n in res["left_for_step"])
+        assert max(res["grad_err"]) <= 1e-6 and res["same_across_ranks"] and res["replica_err"] <= 1e-6
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_real_model_two_ranks_gradients_and_parameters(tmp_path, dtype):
     out = str(tmp_path / "ddp")
@@ -42,6 +55,8 @@ def test_real_model_two_ranks_gradients_and_parameters(tmp_path, dtype):
         assert res["moved"] > 0
         assert res["dropout_seeds_differ"]
         assert len(res["metrics"]) == 9 and all(v == v for v in res["metrics"].values())
+        # the update ran bucket by bucket inside DDP's communication hook: nothing was left for the step() after the backward
+        assert res["overlap_update"] and res["left_for_step"] == [0, 0, 0], res["left_for_step"]
 
 
 def test_real_model_two_ranks_at_config3_per_gpu_size(tmp_path):

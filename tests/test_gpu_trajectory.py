@@ -170,9 +170,10 @@ def test_bf16_loss_drift_from_fp32_over_five_steps(golden_dir):
 def test_bf16_five_sgd_steps_track_the_bf16_emulating_oracle(golden_dir):
     """The benchmarked mode over several steps, teacher forced like the fp32 test: at every step the oracle — emulating the
     same bf16 storage points — starts from the HIP run's current f32 masters.  Per step: the 9 losses within 2e-2 (the
-    single-iteration bar of test_gpu_e2e.py), the mined pseudo boxes identical, and every tensor's UPDATE (lr x momentum buffer
-    fed by bf16-path gradients) against the oracle's — which is what a stale bf16 weight copy after an update, a wrong dropout
-    rescale or a lost gradient term would break.  The bound on the update is 2e-2 + 2 x the oracle's OWN decorrelation floor at
+    single-iteration bar of test_gpu_e2e.py), the mined pseudo boxes identical, the weights moved by exactly lr x the optimizer's
+    momentum buffer, and every tensor's GRADIENT of that step (recovered from the momentum buffers before / after) against the
+    oracle's — which is what a stale bf16 weight copy after an update, a wrong dropout rescale or a lost gradient term would
+    break.  The bound on the gradient is 2e-2 + 2 x the oracle's OWN decorrelation floor at
     that step: two bf16 evaluations of this network whose f32 inputs differ in the last bit (here: the backbone weights
     perturbed by 1e-6 relative) round differently from the first layers on, their activations separate to ~0.5 % and their
     weight gradients — sums over proposals / pixels with heavy cancellation — to 5-12 % (see
@@ -182,9 +183,12 @@ def test_bf16_five_sgd_steps_track_the_bf16_emulating_oracle(golden_dir):
     try:
         (P, views, gt, masks, K), model, tr, data = _setup("s0", golden_dir, torch.bfloat16)
         frozen = {n for n, p in model.named_parameters() if not p.requires_grad}
-        buf, report = {}, []
+        report = []
+        named = dict(model.named_parameters())
         for step in range(N_STEPS):
             W = _weights(model)
+            buf_before = {n: (tr.optimizer.state[p]["momentum_buffer"].detach().cpu().numpy().copy()
+                              if "momentum_buffer" in tr.optimizer.state.get(p, {}) else None) for n, p in named.items()}
             ld = tr.run_step(data)
             hip_losses = {k: float(v) for k, v in ld.items()}
             aux = model.roi_heads.last_aux
@@ -204,23 +208,29 @@ def test_bf16_five_sgd_steps_track_the_bf16_emulating_oracle(golden_dir):
                       else v) for k, v in W.items()}
             _, _, base_grads = O.oicr_plus_iteration(W, views, gt, masks, K=K, bf16=True, want_grads=True)
             _, _, floor_grads = O.oicr_plus_iteration(Wp, views, gt, masks, K=K, bf16=True, want_grads=True)     # both free running
-            want = _sgd_update(W, grads, buf, frozen)
             got = _weights(model)
-            for n in want:
+            for n, p in named.items():
                 if n in frozen:
                     assert np.array_equal(got[n], P[n]), n
                     continue
-                du_w, du_g = (want[n] - W[n]).astype(np.float64).ravel(), (got[n] - W[n]).astype(np.float64).ravel()
-                if float(np.abs(grads[n]).max()) <= 1e-6:      # analytically zero gradients (det.bias): weight decay only / noise
+                # this step's gradient as the optimizer consumed it, recovered from its state: buf' = mu * buf + (g + wd * w)
+                buf_after = tr.optimizer.state[p]["momentum_buffer"].detach().cpu().numpy().astype(np.float64)
+                g_hip = buf_after - (MOM * buf_before[n].astype(np.float64) if buf_before[n] is not None else 0.0) \
+                    - (0.0 if n.endswith(".bias") else WD) * W[n].astype(np.float64)
+                # ... and the weights moved by exactly lr * buf' (stale compute copies / wrong groups would show in the next loss)
+                lr = 2 * LR if n.endswith(".bias") else LR
+                np.testing.assert_allclose(got[n], (W[n].astype(np.float64) - lr * buf_after).astype(np.float32), rtol=0, atol=3e-7 * max(1.0, float(np.abs(W[n]).max())))
+                if float(np.abs(grads[n]).max()) <= 1e-6:      # analytically zero gradients (det.bias): noise
                     continue
-                rel = float(np.linalg.norm(du_g - du_w) / (np.linalg.norm(du_w) + 1e-300))
+                ref = grads[n].astype(np.float64).ravel()
+                rel = float(np.linalg.norm(g_hip.ravel() - ref) / (np.linalg.norm(ref) + 1e-300))
                 gf = floor_grads[n].astype(np.float64).ravel() - base_grads[n].astype(np.float64).ravel()
                 floor = float(np.linalg.norm(gf) / (np.linalg.norm(base_grads[n].astype(np.float64)) + 1e-300))
                 report.append((step, n, rel, floor))
                 assert rel <= 2e-2 + 2.0 * floor, (step, n, rel, floor)
         tr.finish()
         w = max(report, key=lambda t: t[2])
-        print(f"\n5 teacher-forced bf16 steps: worst update error, relative L2 {w[2]:.2e} at an oracle floor of "
+        print(f"\n5 teacher-forced bf16 steps: worst gradient error, relative L2 {w[2]:.2e} at an oracle floor of "
               f"{w[3]:.2e} ({w[1]})")
     finally:
         torch.set_num_threads(nthreads)
