@@ -345,6 +345,55 @@ int sw_resize_pass_u8(int C, int H, int W, int out_size, int horizontal, const u
 int sw_pack_views(int R, const float* const* box_ptrs4, const float* const* obj_ptrs4, float* boxes, float* obj,
                   float* rois, sw_stream_t stream);
 
+/* ==== Stage-3 detector: the ResNet-50-FPN Faster R-CNN of the Unbiased-Teacher step =====================
+ * Reference: unbias/ubteacher/modeling/ over the second tree's detectron2/detectron2/modeling/ (v0.4).  Dense layers
+ * reuse sw_gemm (1x1 convolutions on NHWC pixels, fc) and sw_conv3x3_igemm / _wgrad; the entry points below are what that
+ * model needs on top (csrc/detector.hip).  All activations NHWC. */
+/* img u8 [3][h][w] -> out [H][W][4] = (img - mean) / std inside the image, 0 in the padding (ImageList.from_tensors pads at the
+ * bottom / right to the size divisibility) and in channel 3 (meta_arch/rcnn.py:220-228, structures/image_list.py:60-124). */
+int sw_preprocess_pad(int dtype, int h, int w, int H, int W, const uint8_t* img_chw, const float* mean3, const float* std3,
+                      void* out_nhwc4, sw_stream_t stream);
+/* BasicStem.conv1 (backbone/resnet.py:334-359): 7x7, stride 2, padding 3, 3 -> 64 channels, then y * scale[c] + bias[c] (the
+ * FrozenBatchNorm2d fold, layers/batch_norm.py:52-58) and ReLU.  in [N][H][W][4], w f32 OIHW [64][3][7][7], out [N][OH][OW][64]
+ * with OH = (H - 1) / 2 + 1.  Forward only: the stem is frozen (FREEZE_AT 2). */
+int sw_stem_conv7x7(int dtype, int N, int H, int W, const void* in_nhwc4, const float* w_oihw, const float* scale,
+                    const float* bias, void* out_nhwc64, sw_stream_t stream);
+/* F.max_pool2d(kernel 3, stride 2, padding 1) (resnet.py:358): out [N][(H - 1) / 2 + 1][(W - 1) / 2 + 1][C] */
+int sw_maxpool3x3s2(int dtype, int N, int H, int W, int C, const void* in, void* out, sw_stream_t stream);
+/* out[n][y][x][:] = in[n][2y][2x][:], out [N][(H + 1) / 2][(W + 1) / 2][C]: the pixels a 1x1 stride-2 convolution reads (bottleneck
+ * conv1 / shortcut with STRIDE_IN_1X1, resnet.py:146-166) and FPN's p6 = max_pool2d(p5, kernel 1, stride 2) (fpn.py:188-189);
+ * sw_scatter2x is its backward: out [N][H][W][C] = g at the even pixels, 0 elsewhere (fully written). */
+int sw_subsample2x(int dtype, int N, int H, int W, int C, const void* in, void* out, sw_stream_t stream);
+int sw_scatter2x(int dtype, int N, int H, int W, int C, const void* g, void* out, sw_stream_t stream);
+/* out = a + b, with ReLU when relu != 0 (the residual join of a bottleneck block, resnet.py:209-211) */
+int sw_add_relu(int dtype, long n, const void* a, const void* b, void* out, int relu, sw_stream_t stream);
+/* FPN top-down pathway (fpn.py:142-144): out [N][2h][2w][C] = lateral + nearest-neighbour 2x upsampling of top [N][h][w][C];
+ * sw_downsample2x_sum is the upsampling's backward: out [N][h][w][C] = sum over each 2x2 block of g [N][2h][2w][C]. */
+int sw_upsample2x_add(int dtype, int N, int h, int w, int C, const void* lateral, const void* top, void* out, sw_stream_t stream);
+int sw_downsample2x_sum(int dtype, int N, int h, int w, int C, const void* g, void* out, sw_stream_t stream);
+/* ROIAlign, aligned = True (poolers.py:204-213 "ROIAlignV2" -> layers/roi_align.py:7-74 -> torchvision.ops.roi_align; the
+ * arithmetic as stated in-tree at uwsod/detectron2/layers/csrc/ROIAlign/ROIAlign_cpu.cpp:20-400).  feat [N][H][W][C] of ONE
+ * FPN level; rois [R][5] (batch, x1, y1, x2, y2); sel [n_sel] int32 = the rows of `rois` / `out` assigned to this level
+ * (poolers.py:232-250 loops over the levels); out [R][C][PH][PW] with row pitch ld_out (rows not in `sel` are not touched).
+ * Backward: dfeat_f32 [N][H][W][C] float32, zero-filled by the caller, accumulated with f32 atomics. */
+int sw_roi_align_fwd(int dtype, int H, int W, int C, int PH, int PW, float spatial_scale, int sampling_ratio, const void* feat,
+                     const float* rois, const int32_t* sel, int n_sel, void* out, long ld_out, sw_stream_t stream);
+int sw_roi_align_bwd(int dtype, int H, int W, int C, int PH, int PW, float spatial_scale, int sampling_ratio, const void* gout,
+                     long ld, const float* rois, const int32_t* sel, int n_sel, float* dfeat_f32, sw_stream_t stream);
+/* Box2BoxTransform.apply_deltas (box_regression.py:76-116): out[i] = decode(deltas[i], boxes[i % n_boxes]); deltas row pitch
+ * ld_deltas floats; weights4: HOST float[4]; dw, dh clamped to scale_clamp. */
+int sw_decode_boxes(long n, long n_boxes, const float* deltas, long ld_deltas, const float* boxes, const float* weights4,
+                    float scale_clamp, float* out, sw_stream_t stream);
+/* RPN losses (proposal_generator/rpn.py:362-420, box_regression.py:229-260) over n = N * A anchors: losses2[0] = sum over
+ * label >= 0 of BCE-with-logits(logit, label) * inv_norm, losses2[1] = sum over label == 1 of |delta - get_deltas(anchor, gt)|_1
+ * * inv_norm (smooth-L1 with beta 0), and their unit gradients dlogits [n], ddeltas [n][4] (either may be NULL).  anchors
+ * [n_anchors][4] repeat over the images (row i uses anchor i % n_anchors), matched_gt_boxes [n][4], labels int8 in {-1, 0, 1}.
+ * Ordered two-stage reduction: deterministic.  workspace: sw_rpn_loss_workspace_floats() floats. */
+long sw_rpn_loss_workspace_floats(void);
+int sw_rpn_loss(long n, long n_anchors, const float* logits, const float* deltas, const int8_t* labels, const float* anchors,
+                const float* matched_gt_boxes, const float* weights4, float inv_norm, float* losses2, float* dlogits,
+                float* ddeltas, float* workspace, sw_stream_t stream);
+
 const char* sw_version(void);
 
 #ifdef __cplusplus

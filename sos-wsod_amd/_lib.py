@@ -141,6 +141,23 @@ SIGNATURES = {
     "sw_copy_multi": (c_int, [c_int, ctypes.POINTER(CopyDesc), c_void_p]),
     "sw_pack_views": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
                               c_void_p]),
+    # ---- Stage-3 detector (csrc/detector.hip)
+    "sw_preprocess_pad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, _F4, _F4, c_void_p, c_void_p]),
+    "sw_stem_conv7x7": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sw_maxpool3x3s2": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_subsample2x": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_scatter2x": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_add_relu": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "sw_upsample2x_add": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sw_downsample2x_sum": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_roi_align_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_long, c_void_p]),
+    "sw_roi_align_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p, c_void_p,
+                                 c_int, c_void_p, c_void_p]),
+    "sw_decode_boxes": (c_int, [c_long, c_long, c_void_p, c_long, c_void_p, _F4, c_float, c_void_p, c_void_p]),
+    "sw_rpn_loss_workspace_floats": (c_long, []),
+    "sw_rpn_loss": (c_int, [c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _F4, c_float, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_void_p]),
     "sw_version": (ctypes.c_char_p, []),
 }
 

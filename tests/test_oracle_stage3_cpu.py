@@ -1,0 +1,61 @@
+"""The Stage-3 oracle (oracle/frcnn_oracle.py) against the fixtures written by RUNNING the reference's own detector
+(tests/golden/make_stage3_golden.py: unbias/ubteacher/modeling/** over detectron2/detectron2/modeling/**) — runs without a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import frcnn_oracle as FO
+
+
+def _same_boxes(a, b, atol=1e-2):
+    if len(a) != len(b):
+        return False
+    d = np.abs(a[:, None, :] - b[None, :, :]).max(2)
+    return bool((d.min(1) <= atol).all() and (d.min(0) <= atol).all())
+
+
+def _images(tag, t):
+    return [FO.make_image(int(h), int(w), f"{tag}{i}") for i, (h, w) in enumerate(t["sizes"])]
+
+
+def test_supervised_branch_matches_the_reference_fixture(golden_dir):
+    t = np.load(os.path.join(golden_dir, "stage3_a.npz"))
+    K = int(t["K"])
+    P = FO.make_params(K, tag="s3a", head_scale=float(t["head_scale"]))
+    imgs = _images("s3a", t)
+    gts = [FO.make_gt(int(h), int(w), int(n), K, f"s3a{i}") for i, ((h, w), n) in enumerate(zip(t["sizes"], t["n_gt"]))]
+    losses, aux, grads = FO.supervised_forward(P, imgs, gts, K, FO.Perm("s3a"), want_grads=True)
+    for k, v in losses.items():
+        assert abs(v - float(t["loss/" + k])) <= 1e-5 * abs(float(t["loss/" + k])), k
+    for i in range(2):
+        assert np.array_equal(aux["rpn_labels"][i], t[f"rpn_labels{i}"])
+        assert _same_boxes(aux["proposals"][i]["boxes"], t[f"prop_boxes{i}"])
+        assert np.array_equal(aux["sampled"][i]["gt_classes"], t[f"samp_classes{i}"])
+        np.testing.assert_allclose(aux["sampled"][i]["boxes"], t[f"samp_boxes{i}"], atol=1e-2)
+    np.testing.assert_allclose(aux["scores"], t["scores"], rtol=1e-4, atol=1e-4)
+    for key in t.files:
+        if key.startswith("grad/"):
+            ref, got = t[key], grads[key[5:]]
+        elif key.startswith("grads/"):
+            ref, got = t[key], grads[key[6:]].ravel()[::997]
+        else:
+            continue
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-9, key      # f32 summation order (threads) on the CPU itself
+    for name in t["frozen"]:
+        assert str(name).startswith("backbone.bottom_up.stem") or str(name).startswith("backbone.bottom_up.res2")     # FREEZE_AT 2
+
+
+def test_teacher_weak_branch_and_threshold_match_the_reference_fixture(golden_dir):
+    t = np.load(os.path.join(golden_dir, "stage3_w.npz"))
+    K = int(t["K"])
+    P = FO.make_params(K, tag="s3w", head_scale=float(t["head_scale"]))
+    props, dets = FO.weak_forward(P, _images("s3w", t), K)
+    for i in range(2):
+        assert _same_boxes(props[i]["boxes"], t[f"prop_boxes{i}"])
+        assert np.array_equal(dets[i]["pred_classes"], t[f"det_classes{i}"])
+        np.testing.assert_allclose(dets[i]["scores"], t[f"det_scores{i}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(dets[i]["pred_boxes"], t[f"det_boxes{i}"], rtol=1e-4, atol=1e-2)
+        keep = dets[i]["scores"] > 0.7                                         # ubteacher/engine/trainer.py:361-403
+        assert int(keep.sum()) == len(t[f"pseudo_boxes{i}"]) == 3
+        assert np.array_equal(dets[i]["pred_classes"][keep], t[f"pseudo_classes{i}"])
