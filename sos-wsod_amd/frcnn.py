@@ -1,0 +1,769 @@
+"""Stage-3 detector on gfx950 (BASELINE config #5): the ResNet-50-FPN Faster R-CNN that the
+Unbiased-Teacher step trains — `TwoStagePseudoLabGeneralizedRCNN` (unbias/ubteacher/modeling/meta_arch/rcnn.py:8-107) over
+`build_resnet_fpn_backbone` (detectron2/detectron2/modeling/backbone/{resnet,fpn}.py, second tree, v0.4), `PseudoLabRPN`
+(unbias/ubteacher/modeling/proposal_generator/rpn.py over detectron2/.../proposal_generator/{rpn,proposal_utils}.py,
+anchor_generator.py) and `StandardROIHeadsPseudoLab` with the focal classification loss (unbias/.../roi_heads/{roi_heads,
+fast_rcnn}.py over detectron2/.../{poolers,roi_heads/box_head,roi_heads/fast_rcnn}.py).  Same module tree / state-dict names
+as the reference model (backbone.bottom_up.res3.0.conv1.{weight,norm.*}, backbone.fpn_lateral2, proposal_generator.rpn_head.*,
+roi_heads.box_head.fc1, roi_heads.box_predictor.{cls_score,bbox_pred}), same branch interface
+(`forward(batched_inputs, branch=...)`), so semisup.SemiSupStep drives it like the reference's trainer drives its model.
+
+Execution plan (MI355X-first): NHWC activations end to end; a 1x1 convolution is sw_gemm over the pixels (stride 2 = a pixel
+subsample in front, STRIDE_IN_1X1), a 3x3 convolution the implicit-GEMM / direct MFMA kernel with bias + ReLU fused, FrozenBN is
+folded into the weight and bias; the frozen stem + res2 run without autograd; ROIAlign, the FPN joins, the RPN losses, the focal
+/ L1 losses, box decoding and NMS are kernels of csrc/detector.hip / heads.hip.  Every dense layer is a torch.autograd.Function
+around those kernels with an explicit backward; autograd only links the nodes.  What still runs as torch-ROCm tensor ops:
+anchor <-> ground-truth matching, the label sampling and the per-level top-k sort (integer / index logic on a few thousand to
+a few hundred thousand elements, host-synchronising exactly where the reference's `nonzero` does) — see DESIGN.md §8.
+
+Random sampling (detectron2/modeling/sampling.py:49-50 draws torch.randperm): `sampler.priorities(n)` supplies one random key
+per candidate, the `num` smallest win; tests inject the closed-form keys the fixtures were generated with."""
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import META_ARCH_REGISTRY
+from .structures import Boxes, Instances
+
+R50_STAGES = [("res2", 3, 64, 256, 1), ("res3", 4, 128, 512, 2), ("res4", 6, 256, 1024, 2), ("res5", 3, 512, 2048, 2)]
+FPN_STAGES = (2, 3, 4, 5)
+STRIDES = (4, 8, 16, 32, 64)
+SCALE_CLAMP = math.log(1000.0 / 16)
+GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))        # proposal_utils.py:170
+
+
+def _epc(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+# ====================================================================================================== autograd nodes
+class _LinearFn(torch.autograd.Function):
+    """y (P, out) = x (P, in) @ W^T (+ b) (ReLU): sw_gemm with the epilogue fused; explicit backward (dgrad, wgrad GEMMs, column
+    sums).  x compute dtype, W / b f32 masters, y compute dtype or f32 (out_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, out_f32):
+        P, D = x.shape
+        out_f = w.shape[0]
+        cd = x.dtype
+        ld = (out_f + 7) // 8 * 8
+        ws = torch.zeros(ld, D, device=x.device, dtype=cd)
+        ops.convert_2d(w.detach().contiguous(), ws, out_f, D)
+        ydt = torch.float32 if out_f32 else cd
+        assert not (relu and out_f32)
+        ybuf = torch.zeros(P, ld, device=x.device, dtype=ydt)           # columns beyond out_f stay 0
+        y = ybuf[:, :out_f]
+        if P > 0:
+            ops.gemm(x, ws, y, P, out_f, D, ep=ops.make_epilogue(bias=None if b is None else b.detach().contiguous(), relu=relu,
+                                                                out_dtype=ydt))
+        ctx.save_for_backward(x, ws, ybuf if relu else None)
+        ctx.has_bias, ctx.relu, ctx.out_f = b is not None, relu, out_f
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ws, ybuf = ctx.saved_tensors
+        P, D = x.shape
+        out_f, ld, cd = ctx.out_f, ws.shape[0], x.dtype
+        gs = torch.zeros(P, ld, device=g.device, dtype=cd)
+        if P > 0:
+            gs[:, :out_f] = g
+            if ctx.relu:
+                ops.relu_bwd(ybuf, gs)                                  # in place on the padded buffers (pad columns: 0 stays 0)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(P, D, device=g.device, dtype=cd)
+            if P > 0:
+                ops.gemm(gs, ws, dx, P, D, ld, b_kstrided=True)
+            else:
+                dx.zero_()
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros(ld, D, device=g.device, dtype=torch.float32)
+            if P > 0:
+                Pp = (P + _epc(cd) - 1) // _epc(cd) * _epc(cd)            # K-strided operands: 16-byte row pieces
+                if Pp != P:
+                    gs = torch.cat([gs, torch.zeros(Pp - P, ld, device=g.device, dtype=cd)], 0)
+                    x = torch.cat([x, torch.zeros(Pp - P, D, device=g.device, dtype=cd)], 0)
+                ops.gemm(gs, x, dwp, ld, D, Pp, a_kstrided=True, b_kstrided=True)
+            dw = dwp[:out_f]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbp = torch.zeros(ld, device=g.device, dtype=torch.float32)
+            if P > 0:
+                ops.colsum(gs, gs.shape[0], ld, dbp)
+            db = dbp[:out_f]
+        return dx, dw, db, None, None
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """3x3, stride 1, padding 1 on NHWC: sw_conv3x3_igemm (+ bias, ReLU fused); backward = weight gradient (split-K slabs,
+    ordered fold), column sums, data gradient through the flipped-weight layout."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        n, H, W, cin = x.shape
+        cout = w.shape[0]
+        cd = x.dtype
+        wk = torch.zeros(cout, 9, cin, device=x.device, dtype=cd)
+        ops.conv_weight_prep(w.detach().contiguous(), wk, 0, cin)
+        out = torch.empty(n, H, W, cout, device=x.device, dtype=cd)
+        ops.conv3x3(x, wk, out, 1, ops.make_epilogue(bias=None if b is None else b.detach().contiguous(), relu=relu, out_dtype=cd))
+        ctx.save_for_backward(x, w, out if relu else None)
+        ctx.relu, ctx.has_bias = relu, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, out = ctx.saved_tensors
+        n, H, W, cin = x.shape
+        cout = w.shape[0]
+        cd = x.dtype
+        g = g.contiguous()
+        dz = ops.relu_bwd(out, g, out=torch.empty_like(g)) if ctx.relu else g
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(cout, cin, 3, 3, device=g.device, dtype=torch.float32)
+            npix = n * H * W
+            if (64 // W) + 1 > 2 * H:
+                # maps of a few pixels (p5 / p6 of small images: 4x4, 2x2) are below the gathering loader's tile geometry
+                # (sw_conv3x3_wgrad returns -6): the <= 128 pixels are unfolded into (ci, ky, kx) patch rows and the gradient is
+                # one K-strided GEMM dz^T @ patches
+                pat = torch.nn.functional.unfold(x.permute(0, 3, 1, 2), kernel_size=3, padding=1)       # (n, cin*9, H*W)
+                pat = pat.permute(0, 2, 1).reshape(npix, cin * 9)
+                e = _epc(cd)
+                Pp = (npix + e - 1) // e * e
+                A = torch.zeros(Pp, cout, device=g.device, dtype=cd); A[:npix] = dz.view(npix, cout)
+                B = torch.zeros(Pp, cin * 9, device=g.device, dtype=cd); B[:npix] = pat
+                ops.gemm(A, B, dw.view(cout, cin * 9), cout, cin * 9, Pp, a_kstrided=True, b_kstrided=True)
+            else:
+                tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
+                ops.conv3x3_wgrad(x, dz, dw, 1, splitk=max(1, min(32, 512 // tiles, max(1, npix // 1024))))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(cout, device=g.device, dtype=torch.float32)
+            ops.colsum(dz.view(n * H * W, cout), n * H * W, cout, db)
+        if ctx.needs_input_grad[0]:
+            wkd = torch.zeros(cin, 9, cout, device=g.device, dtype=cd)
+            ops.conv_weight_prep(w.detach().contiguous(), wkd, 1)
+            dx = torch.empty(n, H, W, cin, device=g.device, dtype=cd)
+            ops.conv3x3(dz, wkd, dx, 1, ops.make_epilogue(out_dtype=cd))
+        return dx, dw, db, None
+
+
+class _Subsample2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, H, W, C = x.shape
+        ctx.shape = tuple(x.shape)
+        return ops.subsample2x(x, torch.empty(n, (H + 1) // 2, (W + 1) // 2, C, device=x.device, dtype=x.dtype))
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.scatter2x(g.contiguous(), torch.empty(ctx.shape, device=g.device, dtype=g.dtype))
+
+
+class _AddReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = ops.add_relu(a, b, torch.empty_like(a), relu=True)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        dz = ops.relu_bwd(out, g.contiguous(), out=torch.empty_like(out))
+        return dz, dz
+
+
+class _UpsampleAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lateral, top):
+        ctx.top_shape = tuple(top.shape)
+        return ops.upsample2x_add(lateral, top, torch.empty_like(lateral))
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return g, ops.downsample2x_sum(g, torch.empty(ctx.top_shape, device=g.device, dtype=g.dtype))
+
+
+class _RoIAlignFn(torch.autograd.Function):
+    """(rois (R,5), per-level row lists, scales, *level features NHWC) -> pooled (R, C*7*7) in the reference's (C,7,7) order"""
+
+    @staticmethod
+    def forward(ctx, rois, sels, scales, *feats):
+        R = rois.shape[0]
+        C = feats[0].shape[3]
+        out = torch.zeros(R, C * 49, device=feats[0].device, dtype=feats[0].dtype)
+        for f, sel, sc in zip(feats, sels, scales):
+            if sel.numel():
+                ops.roi_align_fwd(f, rois, sel, out, sc)
+        ctx.rois, ctx.sels, ctx.scales = rois, sels, scales
+        ctx.shapes = [tuple(f.shape) for f in feats]
+        ctx.dtype = feats[0].dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        grads = []
+        for shp, sel, sc, need in zip(ctx.shapes, ctx.sels, ctx.scales, ctx.needs_input_grad[3:]):
+            if not need:
+                grads.append(None)
+                continue
+            d = torch.zeros(shp, device=g.device, dtype=torch.float32)
+            if sel.numel():
+                ops.roi_align_bwd(g, ctx.rois, sel, d, sc)
+            grads.append(d if ctx.dtype == torch.float32 else d.to(ctx.dtype))
+        return (None, None, None) + tuple(grads)
+
+
+class _RpnLossFn(torch.autograd.Function):
+    """(logits (n,), deltas (n,4)) -> (loss_rpn_cls, loss_rpn_loc): one kernel for both values and both unit gradients"""
+
+    @staticmethod
+    def forward(ctx, logits, deltas, labels_i8, anchors, matched, weights, inv_norm):
+        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        dl = torch.empty_like(logits); dd = torch.empty_like(deltas)
+        ops.rpn_loss(logits, deltas, labels_i8, anchors, matched, weights, inv_norm, out, dl, dd)
+        ctx.save_for_backward(dl, dd)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_loc):
+        dl, dd = ctx.saved_tensors
+        return dl * g_cls, dd * g_loc, None, None, None, None, None
+
+
+class _RoiLossFn(torch.autograd.Function):
+    """packed logits (R, >= 5K+1) f32 = [cls_score K+1 | bbox_pred 4K] -> (focal loss_cls, L1 loss_box_reg), both / R
+    (unbias/ubteacher/modeling/roi_heads/fast_rcnn.py:73-105; detectron2/modeling/roi_heads/fast_rcnn.py:245-317)"""
+
+    @staticmethod
+    def forward(ctx, logits, K, gt_classes_i32, prop_boxes, gt_boxes, reg_weights, gamma):
+        R = logits.shape[0]
+        dev = logits.device
+        loss_cls = torch.zeros(1, device=dev)
+        unit = torch.zeros_like(logits)
+        lg = logits.detach()
+        ops.focal_loss(lg[:, :K + 1], gt_classes_i32, gamma, loss_cls, unit[:, :K + 1])
+        # box term through the refinement-loss kernel: targets boxes[R + i], class-specific columns, L1 / R (CE weights 0)
+        boxes = torch.cat([prop_boxes, gt_boxes], 0).contiguous()
+        idx = (torch.arange(R, device=dev, dtype=torch.int32) + R).contiguous()
+        lv = torch.empty(1, 2, 1, device=dev)
+        ubox = torch.zeros_like(logits)
+        ops.oicr_refine_loss(lg, 1, R, K, 0, K + 1, boxes, gt_classes_i32.view(1, R), torch.zeros(1, R, device=dev), idx.view(1, R),
+                             torch.zeros(1, dtype=torch.int32, device=dev), reg_weights, lv, ubox, torch.ones(2, device=dev))
+        unit[:, K + 1:5 * K + 1] = ubox[:, K + 1:5 * K + 1]
+        ctx.save_for_backward(unit)
+        ctx.K = K
+        return loss_cls[0], lv[0, 1, 0].clone()
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box):
+        (unit,) = ctx.saved_tensors
+        K = ctx.K
+        d = unit.clone()
+        d[:, :K + 1] *= g_cls
+        d[:, K + 1:] *= g_box
+        return d, None, None, None, None, None, None
+
+
+# ====================================================================================================== modules
+class FrozenBatchNorm2d(nn.Module):
+    """layers/batch_norm.py:15-100: buffers only; folded into the convolution in front of it"""
+
+    def __init__(self, c):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(c)); self.register_buffer("bias", torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c)); self.register_buffer("running_var", torch.ones(c) - 1e-5)
+
+    def fold(self):
+        scale = self.weight * torch.rsqrt(self.running_var + 1e-5)
+        return scale, self.bias - self.running_mean * scale
+
+
+class ConvBN(nn.Module):
+    """Conv2d(bias=False, norm=FrozenBN) of the reference: parameter `weight` (OIHW) + submodule `norm`"""
+
+    def __init__(self, cin, cout, k, stride=1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+        self.norm = FrozenBatchNorm2d(cout)
+        self.k, self.stride = k, stride
+
+    def forward(self, x, relu):
+        scale, shift = self.norm.fold()
+        w = self.weight * scale.view(-1, 1, 1, 1)                 # the FrozenBN fold: d/dweight = scale * d/dw_eff through autograd
+        if self.k == 3:
+            return _Conv3x3Fn.apply(x, w, shift, relu)
+        if self.stride == 2:
+            x = _Subsample2Fn.apply(x)
+        n, H, W, C = x.shape
+        y = _LinearFn.apply(x.reshape(n * H * W, C), w.view(w.shape[0], C), shift, relu, False)
+        return y.reshape(n, H, W, w.shape[0])
+
+
+class Conv(nn.Module):
+    """plain Conv2d with bias (FPN laterals / outputs, RPN head)"""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k)); self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.kaiming_uniform_(self.weight, a=1)
+        self.k = k
+
+    def forward(self, x, relu=False):
+        if self.k == 3:
+            return _Conv3x3Fn.apply(x, self.weight, self.bias, relu)
+        n, H, W, C = x.shape
+        return _LinearFn.apply(x.reshape(n * H * W, C), self.weight.view(-1, C), self.bias, relu, False).reshape(n, H, W, -1)
+
+
+class BottleneckBlock(nn.Module):
+    """backbone/resnet.py:100-213 with STRIDE_IN_1X1 (the stride sits in conv1 and in the shortcut)"""
+
+    def __init__(self, cin, cout, mid, stride):
+        super().__init__()
+        self.shortcut = ConvBN(cin, cout, 1, stride) if cin != cout else None
+        self.conv1 = ConvBN(cin, mid, 1, stride); self.conv2 = ConvBN(mid, mid, 3); self.conv3 = ConvBN(mid, cout, 1)
+
+    def forward(self, x):
+        out = self.conv3(self.conv2(self.conv1(x, True), True), False)
+        sc = self.shortcut(x, False) if self.shortcut is not None else x
+        return _AddReluFn.apply(out, sc)
+
+
+class BasicStem(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = ConvBN(3, 64, 7, 2)
+
+    def forward(self, x4):                                          # (N, H, W, 4) normalised + padded -> (N, H/4, W/4, 64)
+        n, H, W, _ = x4.shape
+        scale, shift = self.conv1.norm.fold()
+        y = ops.stem_conv7x7(x4, self.conv1.weight.detach().contiguous(), scale.contiguous(), shift.contiguous(),
+                             torch.empty(n, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, device=x4.device, dtype=x4.dtype))
+        return ops.maxpool3x3s2(y, torch.empty(n, (y.shape[1] - 1) // 2 + 1, (y.shape[2] - 1) // 2 + 1, 64, device=y.device, dtype=y.dtype))
+
+
+class ResNet(nn.Module):
+    def __init__(self, freeze_at=2):
+        super().__init__()
+        self.stem = BasicStem()
+        cin = 64
+        self.stage_names = []
+        for name, nblk, mid, cout, stride in R50_STAGES:
+            blocks = [BottleneckBlock(cin if b == 0 else cout, cout, mid, stride if b == 0 else 1) for b in range(nblk)]
+            self.add_module(name, nn.Sequential(*blocks))
+            self.stage_names.append(name)
+            cin = cout
+        self.freeze_at = freeze_at
+        if freeze_at >= 1:
+            for p in self.stem.parameters():
+                p.requires_grad = False
+        for i, name in enumerate(self.stage_names, start=2):
+            if freeze_at >= i:
+                for p in getattr(self, name).parameters():
+                    p.requires_grad = False
+
+    def forward(self, x4):
+        feats = {}
+        with torch.no_grad():
+            x = self.stem(x4)
+        for i, name in enumerate(self.stage_names, start=2):
+            if self.freeze_at >= i:
+                with torch.no_grad():
+                    x = getattr(self, name)(x)
+            else:
+                x = getattr(self, name)(x)
+            feats[name] = x
+        return feats
+
+
+class FPN(nn.Module):
+    """backbone/fpn.py:18-188: laterals 1x1, top-down nearest upsampling + add, outputs 3x3, p6 = p5 subsampled (LastLevelMaxPool)"""
+    size_divisibility = 32
+
+    def __init__(self, bottom_up):
+        super().__init__()
+        self.bottom_up = bottom_up
+        for s, c in zip(FPN_STAGES, (256, 512, 1024, 2048)):
+            self.add_module(f"fpn_lateral{s}", Conv(c, 256, 1)); self.add_module(f"fpn_output{s}", Conv(256, 256, 3))
+
+    def forward(self, x4):
+        c = self.bottom_up(x4)
+        outs, prev = [], None
+        for s in reversed(FPN_STAGES):
+            lat = getattr(self, f"fpn_lateral{s}")(c[f"res{s}"])
+            prev = lat if prev is None else _UpsampleAddFn.apply(lat, prev)
+            outs.insert(0, getattr(self, f"fpn_output{s}")(prev))
+        outs.append(_Subsample2Fn.apply(outs[-1]))
+        return outs                                                  # [p2, p3, p4, p5, p6] NHWC
+
+
+class StandardRPNHead(nn.Module):
+    def __init__(self, num_anchors=3):
+        super().__init__()
+        self.conv = Conv(256, 256, 3)
+        self.objectness_logits = Conv(256, num_anchors, 1); self.anchor_deltas = Conv(256, 4 * num_anchors, 1)
+        for m in (self.conv, self.objectness_logits, self.anchor_deltas):
+            nn.init.normal_(m.weight, std=0.01)
+        self.A = num_anchors
+
+    def forward(self, feats):
+        """-> per level logits (N, Hi*Wi*A) f32, deltas (N, Hi*Wi*A, 4) f32: the two 1x1 convolutions as ONE GEMM of 5A (+ pad) columns"""
+        A = self.A
+        w = torch.cat([self.objectness_logits.weight.view(A, -1), self.anchor_deltas.weight.view(4 * A, -1)], 0)
+        b = torch.cat([self.objectness_logits.bias, self.anchor_deltas.bias], 0)
+        logits, deltas = [], []
+        for f in feats:
+            t = self.conv(f, relu=True)
+            n, H, W, C = t.shape
+            y = _LinearFn.apply(t.reshape(n * H * W, C), w, b, False, True)              # (P, 5A) f32, channel = [a | a*4 + b]
+            logits.append(y[:, :A].reshape(n, H * W * A))
+            deltas.append(y[:, A:].reshape(n, H * W * A, 4))
+        return logits, deltas
+
+
+class Sampler:
+    """random keys for the label sampling (sampling.py:49-50).  Default: torch's generator on the device."""
+
+    def __init__(self, seed=0):
+        self.gen, self.seed = None, seed
+
+    def priorities(self, n, device):
+        if self.gen is None or self.gen.device != device:
+            self.gen = torch.Generator(device=device); self.gen.manual_seed(self.seed)
+        return torch.rand(n, generator=self.gen, device=device)
+
+
+def pairwise_iou(b1, b2):
+    """structures/boxes.py:337-370, float32"""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1]); a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    wh = (torch.min(b1[:, None, 2:], b2[None, :, 2:]) - torch.max(b1[:, None, :2], b2[None, :, :2])).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    return torch.where(inter > 0, inter / (a1[:, None] + a2[None, :] - inter), torch.zeros((), device=b1.device))
+
+
+def match(iou, thresholds, labels, allow_low_quality):
+    """modeling/matcher.py:60-126 -> (matched gt index (N,), label (N,) int8)"""
+    n = iou.shape[1]
+    if iou.numel() == 0:
+        return torch.zeros(n, dtype=torch.int64, device=iou.device), torch.full((n,), labels[0], dtype=torch.int8, device=iou.device)
+    vals, matches = iou.max(dim=0)
+    out = torch.ones(n, dtype=torch.int8, device=iou.device)
+    th = [-float("inf")] + list(thresholds) + [float("inf")]
+    for l, lo, hi in zip(labels, th[:-1], th[1:]):
+        out[(vals >= lo) & (vals < hi)] = l
+    if allow_low_quality:
+        best = iou.max(dim=1).values
+        out[(iou == best[:, None]).any(dim=0)] = 1
+    return matches, out
+
+
+def subsample_labels(labels, num_samples, positive_fraction, bg_label, sampler):
+    """modeling/sampling.py:8-54: the `num` candidates with the smallest random keys (keys drawn per candidate list, like
+    randperm(len(list))[:num])"""
+    positive = torch.nonzero((labels != -1) & (labels != bg_label)).flatten()
+    negative = torch.nonzero(labels == bg_label).flatten()
+    num_pos = min(positive.numel(), int(num_samples * positive_fraction))
+    num_neg = min(negative.numel(), num_samples - num_pos)
+    p1 = torch.argsort(sampler.priorities(positive.numel(), labels.device), stable=True)[:num_pos]
+    p2 = torch.argsort(sampler.priorities(negative.numel(), labels.device), stable=True)[:num_neg]
+    return positive[p1], negative[p2]
+
+
+class PseudoLabRPN(nn.Module):
+    """unbias/ubteacher/modeling/proposal_generator/rpn.py:11-57 over detectron2's RPN"""
+
+    def __init__(self, sampler, batch_size_per_image=256, positive_fraction=0.25, pre_nms_topk=(2000, 1000), post_nms_topk=(1000, 1000),
+                 nms_thresh=0.7, anchor_sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.5, 1.0, 2.0)):
+        super().__init__()
+        self.rpn_head = StandardRPNHead(len(aspect_ratios))
+        self.sampler = sampler
+        self.batch_size_per_image, self.positive_fraction = batch_size_per_image, positive_fraction
+        self.pre_nms_topk, self.post_nms_topk, self.nms_thresh = pre_nms_topk, post_nms_topk, nms_thresh
+        self.anchor_sizes, self.aspect_ratios = anchor_sizes, aspect_ratios
+        self.bbox_weights = (1.0, 1.0, 1.0, 1.0)
+        self._anchor_cache = {}
+
+    def anchors(self, grid_sizes, device):
+        """anchor_generator.py:17-31,134-199 (offset 0): per level (Hi*Wi*A, 4), location-major"""
+        key = (tuple(grid_sizes), str(device))
+        hit = self._anchor_cache.get(key)
+        if hit is None:
+            res = []
+            for (gh, gw), stride, size in zip(grid_sizes, STRIDES, self.anchor_sizes):
+                cell = []
+                for r in self.aspect_ratios:
+                    w = math.sqrt(size ** 2.0 / r); h = r * w
+                    cell.append([-w / 2.0, -h / 2.0, w / 2.0, h / 2.0])
+                cell = torch.tensor(cell, dtype=torch.float32, device=device)
+                sx = torch.arange(0, gw * stride, step=stride, dtype=torch.float32, device=device)
+                sy = torch.arange(0, gh * stride, step=stride, dtype=torch.float32, device=device)
+                yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+                shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
+                res.append((shifts.view(-1, 1, 4) + cell.view(1, -1, 4)).reshape(-1, 4).contiguous())
+            hit = self._anchor_cache[key] = res
+        return hit
+
+    @torch.no_grad()
+    def label_and_sample_anchors(self, anchors_all, gt_boxes_list):
+        """detectron2 rpn.py:305-360: IoU thresholds [0.3, 0.7], labels [0, -1, 1], low-quality matches; 256 per image, <= 25 % positive"""
+        labels, matched = [], []
+        for gtb in gt_boxes_list:
+            m, lab = match(pairwise_iou(gtb, anchors_all), (0.3, 0.7), (0, -1, 1), True)
+            pos, neg = subsample_labels(lab.to(torch.int64), self.batch_size_per_image, self.positive_fraction, 0, self.sampler)
+            out = torch.full_like(lab, -1); out[pos] = 1; out[neg] = 0
+            labels.append(out)
+            matched.append(gtb[m] if len(gtb) else torch.zeros_like(anchors_all))
+        return torch.stack(labels), torch.stack(matched)
+
+    @torch.no_grad()
+    def predict_proposals(self, anchors, logits, deltas, image_sizes):
+        """detectron2 rpn.py:478-533 + proposal_utils.py:20-130: decode, per-level top-k (sort, stable: ties -> ascending index), clip, drop
+        empty boxes, NMS per level (sw_detect_postprocess with level = class), the best post_nms_topk per image"""
+        N = logits[0].shape[0]
+        pre, post = self.pre_nms_topk[0 if self.training else 1], self.post_nms_topk[0 if self.training else 1]
+        L = len(anchors)
+        per_level = []
+        for a, lg, dl in zip(anchors, logits, deltas):
+            k = min(lg.shape[1], pre)
+            sc, idx = lg.detach().sort(descending=True, dim=1, stable=True)
+            sc, idx = sc[:, :k], idx[:, :k]
+            boxes = ops.decode_boxes(dl.detach().reshape(-1, 4).contiguous(), a, self.bbox_weights, SCALE_CLAMP,
+                                     torch.empty(N * a.shape[0], 4, device=a.device)).view(N, -1, 4)
+            per_level.append((sc, torch.gather(boxes, 1, idx[:, :, None].expand(-1, -1, 4))))
+        out = []
+        for n, (h, w) in enumerate(image_sizes):
+            sc = torch.cat([p[0][n] for p in per_level]); bx = torch.cat([p[1][n] for p in per_level], 0)
+            lvl = torch.cat([torch.full((p[0].shape[1],), i, dtype=torch.int64, device=sc.device) for i, p in enumerate(per_level)])
+            if not bool(torch.isfinite(bx).all() & torch.isfinite(sc).all()):
+                if self.training:
+                    raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
+                ok = torch.isfinite(bx).all(1) & torch.isfinite(sc)
+                sc, bx, lvl = sc[ok], bx[ok], lvl[ok]
+            cw = bx[:, 2].clamp(0, w) - bx[:, 0].clamp(0, w); ch = bx[:, 3].clamp(0, h) - bx[:, 1].clamp(0, h)
+            R = sc.numel()
+            ninf = torch.full((), -float("inf"), device=sc.device)
+            scores = ninf.expand(R, L + 1).clone()
+            scores[torch.arange(R, device=sc.device), lvl] = torch.where((cw > 0) & (ch > 0), sc, ninf)     # nonempty(threshold 0)
+            boxes = bx[:, None, :].expand(R, L, 4).reshape(R, 4 * L).contiguous()
+            cnt, dboxes, dscores, _, _ = ops.detect_postprocess(scores, boxes, int(h), int(w), -3.0e38, self.nms_thresh, post)
+            k = int(cnt.item())
+            p = Instances((int(h), int(w)))
+            p.proposal_boxes = Boxes(dboxes[:k].clone()); p.objectness_logits = dscores[:k].clone()
+            out.append(p)
+        return out
+
+    def forward(self, image_sizes, feats, gt_instances=None, compute_loss=True, compute_val_loss=False):
+        dev = feats[0].device
+        anchors = self.anchors([tuple(f.shape[1:3]) for f in feats], dev)
+        logits, deltas = self.rpn_head(feats)
+        losses = {}
+        if (self.training and compute_loss) or compute_val_loss:
+            anchors_all = torch.cat(anchors, 0)
+            labels, matched = self.label_and_sample_anchors(anchors_all, [g.gt_boxes.tensor.to(dev).float() for g in gt_instances])
+            lg = torch.cat(logits, 1).reshape(-1).contiguous(); dl = torch.cat(deltas, 1).reshape(-1, 4).contiguous()
+            n_img = labels.shape[0]
+            l_cls, l_loc = _RpnLossFn.apply(lg, dl, labels.reshape(-1).contiguous(), anchors_all.contiguous(),
+                                            matched.reshape(-1, 4).contiguous(), self.bbox_weights,
+                                            1.0 / (self.batch_size_per_image * n_img))
+            losses = {"loss_rpn_cls": l_cls, "loss_rpn_loc": l_loc}
+            self.last_labels = labels
+        proposals = self.predict_proposals(anchors, logits, deltas, image_sizes)
+        return proposals, losses
+
+
+class FastRCNNConvFCHead(nn.Module):
+    def __init__(self, d_in=256 * 7 * 7, fc_dim=1024):
+        super().__init__()
+        self.fc1 = nn.Linear(d_in, fc_dim); self.fc2 = nn.Linear(fc_dim, fc_dim)
+        for m in (self.fc1, self.fc2):
+            nn.init.kaiming_uniform_(m.weight, a=1); nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        x = _LinearFn.apply(x, self.fc1.weight, self.fc1.bias, True, False)
+        return _LinearFn.apply(x, self.fc2.weight, self.fc2.bias, True, False)
+
+
+class FastRCNNFocaltLossOutputLayers(nn.Module):
+    """unbias/ubteacher/modeling/roi_heads/fast_rcnn.py:12-40 over detectron2's FastRCNNOutputLayers"""
+
+    def __init__(self, d_in, num_classes, test_score_thresh=0.05, test_nms_thresh=0.5, test_topk_per_image=100):
+        super().__init__()
+        self.cls_score = nn.Linear(d_in, num_classes + 1); self.bbox_pred = nn.Linear(d_in, 4 * num_classes)
+        nn.init.normal_(self.cls_score.weight, std=0.01); nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        nn.init.constant_(self.cls_score.bias, 0); nn.init.constant_(self.bbox_pred.bias, 0)
+        self.num_classes = num_classes
+        self.bbox_weights = (10.0, 10.0, 5.0, 5.0)
+        self.test_score_thresh, self.test_nms_thresh, self.test_topk_per_image = test_score_thresh, test_nms_thresh, test_topk_per_image
+
+    def forward(self, x):
+        """-> packed f32 logits (R, 5K+1) = [cls_score | bbox_pred]: one GEMM"""
+        w = torch.cat([self.cls_score.weight, self.bbox_pred.weight], 0); b = torch.cat([self.cls_score.bias, self.bbox_pred.bias], 0)
+        return _LinearFn.apply(x, w, b, False, True)
+
+
+class StandardROIHeadsPseudoLab(nn.Module):
+    """unbias/ubteacher/modeling/roi_heads/roi_heads.py:377-546"""
+
+    def __init__(self, num_classes, sampler, batch_size_per_image=512, positive_fraction=0.25, proposal_append_gt=True):
+        super().__init__()
+        self.box_head = FastRCNNConvFCHead()
+        self.box_predictor = FastRCNNFocaltLossOutputLayers(1024, num_classes)
+        self.num_classes, self.sampler = num_classes, sampler
+        self.batch_size_per_image, self.positive_fraction, self.proposal_append_gt = batch_size_per_image, positive_fraction, proposal_append_gt
+
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals, targets, append_gt):
+        K = self.num_classes
+        out = []
+        for prop, tgt in zip(proposals, targets):
+            dev = prop.proposal_boxes.tensor.device
+            gtb = tgt.gt_boxes.tensor.to(dev).float(); gtc = tgt.gt_classes.to(dev)
+            boxes = torch.cat([prop.proposal_boxes.tensor, gtb], 0) if append_gt else prop.proposal_boxes.tensor
+            has_gt = gtb.shape[0] > 0
+            m, lab = match(pairwise_iou(gtb, boxes) if has_gt else torch.zeros(0, boxes.shape[0], device=dev), (0.5,), (0, 1), False)
+            if has_gt:
+                cls = gtc[m].clone(); cls[lab == 0] = K; cls[lab == -1] = -1
+            else:
+                cls = torch.zeros_like(m) + K
+            fg, bg = subsample_labels(cls, self.batch_size_per_image, self.positive_fraction, K, self.sampler)
+            idx = torch.cat([fg, bg])
+            s = Instances(prop.image_size)
+            s.proposal_boxes = Boxes(boxes[idx]); s.gt_classes = cls[idx]
+            s.gt_boxes = Boxes(gtb[m[idx]] if has_gt else torch.zeros(idx.numel(), 4, device=dev))
+            out.append(s)
+        return out
+
+    def _pool(self, feats, boxes_per_image):
+        """poolers.py:17-50,196-250: level = floor(4 + log2(sqrt(area) / 224 + 1e-8)) clamped to [2, 5]; ROIAlign 7x7 per level"""
+        dev = feats[0].device
+        rois = torch.cat([torch.cat([torch.full((b.shape[0], 1), float(i), device=dev), b], 1) for i, b in enumerate(boxes_per_image)], 0).contiguous()
+        bx = rois[:, 1:]
+        sizes = torch.sqrt((bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1]))
+        lv = torch.clamp(torch.floor(4 + torch.log2(sizes / 224 + 1e-8)), min=2, max=5).to(torch.int64) - 2
+        sels = [torch.nonzero(lv == l).flatten().to(torch.int32).contiguous() for l in range(4)]
+        self.last_levels = lv
+        return _RoIAlignFn.apply(rois, sels, [1.0 / s for s in STRIDES[:4]], *feats[:4])
+
+    def forward(self, feats, proposals, targets=None, compute_loss=True, branch="", compute_val_loss=False):
+        if self.training and compute_loss:
+            proposals = self.label_and_sample_proposals(proposals, targets, self.proposal_append_gt)
+        elif compute_val_loss:
+            proposals = self.label_and_sample_proposals(proposals, targets, False)
+        pooled = self._pool(feats, [p.proposal_boxes.tensor for p in proposals])
+        logits = self.box_predictor(self.box_head(pooled))
+        K = self.num_classes
+        if (self.training and compute_loss) or compute_val_loss:
+            gtc = torch.cat([p.gt_classes for p in proposals]).to(torch.int32).contiguous()
+            self.last_sampled, self.last_logits = proposals, logits
+            if gtc.numel() == 0:
+                z = 0.0 * logits.sum()
+                return proposals, {"loss_cls": z, "loss_box_reg": z}
+            l_cls, l_box = _RoiLossFn.apply(logits, K, gtc, torch.cat([p.proposal_boxes.tensor for p in proposals]).contiguous(),
+                                            torch.cat([p.gt_boxes.tensor for p in proposals]).contiguous(),
+                                            self.box_predictor.bbox_weights, 1.5)
+            return proposals, {"loss_cls": l_cls, "loss_box_reg": l_box}
+        # inference form (fast_rcnn.py:44-160): softmax, decode, clip, score > 0.05, per-class NMS 0.5, top 100
+        pred, off = [], 0
+        lg = logits.detach()
+        bp = self.box_predictor
+        for p in proposals:
+            n = len(p)
+            h, w = p.image_size
+            sc = torch.empty(n, K + 1, device=lg.device); bx = torch.empty(n, 4 * K, device=lg.device)
+            r = Instances((h, w))
+            if n:
+                ops.oicr_predict(lg[off:off + n], n, K, 1, 0, 5 * K + 1, p.proposal_boxes.tensor.float().contiguous(), bp.bbox_weights,
+                                 SCALE_CLAMP, sc, bx)
+                cnt, b, s, c, _ = ops.detect_postprocess(sc, bx, int(h), int(w), bp.test_score_thresh, bp.test_nms_thresh, bp.test_topk_per_image)
+                k = int(cnt.item())
+                r.pred_boxes = Boxes(b[:k].clone()); r.scores = s[:k].clone(); r.pred_classes = c[:k].to(torch.int64)
+            else:
+                r.pred_boxes = Boxes(torch.zeros(0, 4, device=lg.device)); r.scores = torch.zeros(0, device=lg.device)
+                r.pred_classes = torch.zeros(0, dtype=torch.int64, device=lg.device)
+            pred.append(r)
+            off += n
+        return pred, logits
+
+
+@META_ARCH_REGISTRY.register()
+class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
+    """unbias/ubteacher/modeling/meta_arch/rcnn.py:8-107.  `TwoStagePseudoLabGeneralizedRCNN(cfg)` (the registry call of
+    rcnn_multi.build_model, selected by MODEL.META_ARCHITECTURE of unbias/configs/code_release/voc_ssod.yaml) or explicit arguments."""
+
+    def __init__(self, cfg=None, *, num_classes=20, compute_dtype=torch.float32, freeze_at=2, sampler=None,
+                 pixel_mean=(103.530, 116.280, 123.675), pixel_std=(1.0, 1.0, 1.0)):
+        super().__init__()
+        if cfg is not None:
+            M = cfg.MODEL
+            # the configuration this class implements (Base-RCNN-FPN.yaml + voc_ssod.yaml); anything else is refused, not ignored
+            assert M.BACKBONE.get("NAME", "build_resnet_fpn_backbone") == "build_resnet_fpn_backbone"
+            assert M.get("PROPOSAL_GENERATOR", {}).get("NAME", "PseudoLabRPN") == "PseudoLabRPN"
+            assert M.ROI_HEADS.get("NAME", "StandardROIHeadsPseudoLab") == "StandardROIHeadsPseudoLab"
+            assert M.ROI_HEADS.get("LOSS", "FocalLoss") == "FocalLoss" and M.get("RPN", {}).get("LOSS", "CrossEntropy") == "CrossEntropy"
+            num_classes, freeze_at = M.ROI_HEADS.NUM_CLASSES, M.BACKBONE.get("FREEZE_AT", 2)
+            pixel_mean, pixel_std = M.PIXEL_MEAN, M.PIXEL_STD
+            dt_name = M.get("AMD", {}).get("COMPUTE_DTYPE", "fp32")
+            compute_dtype = torch.bfloat16 if dt_name == "bf16" else torch.float32
+            sampler = Sampler(int(cfg.get("SEED", 0)) if int(cfg.get("SEED", 0)) >= 0 else 0)
+        sampler = sampler if sampler is not None else Sampler()
+        self.backbone = FPN(ResNet(freeze_at))
+        self.proposal_generator = PseudoLabRPN(sampler)
+        self.roi_heads = StandardROIHeadsPseudoLab(num_classes, sampler)
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
+        self.compute_dtype = compute_dtype
+        self.sampler = sampler
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess_image(self, batched_inputs):
+        """-> (N, H, W, 4) normalised, padded to the size divisibility, and the image sizes"""
+        ims = [x["image"].to(self.device) for x in batched_inputs]
+        sizes = [tuple(int(v) for v in im.shape[1:]) for im in ims]
+        d = self.backbone.size_divisibility
+        H = (max(s[0] for s in sizes) + d - 1) // d * d; W = (max(s[1] for s in sizes) + d - 1) // d * d
+        out = torch.empty(len(ims), H, W, 4, device=self.device, dtype=self.compute_dtype)
+        mean, std = self.pixel_mean.flatten().tolist(), self.pixel_std.flatten().tolist()
+        for i, im in enumerate(ims):
+            ops.preprocess_pad(im.contiguous(), out[i], mean, std)
+        return out, sizes
+
+    def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False):
+        if (not self.training) and (not val_mode):
+            return self.inference(batched_inputs)
+        x4, sizes = self.preprocess_image(batched_inputs)
+        gt = [x["instances"] for x in batched_inputs] if "instances" in batched_inputs[0] else None
+        feats = self.backbone(x4)
+        if branch == "supervised":
+            proposals, rpn_losses = self.proposal_generator(sizes, feats, gt)
+            _, det_losses = self.roi_heads(feats, proposals, gt, branch=branch)
+            losses = dict(det_losses); losses.update(rpn_losses)
+            return losses, [], [], None
+        if branch == "unsup_data_weak":
+            proposals, _ = self.proposal_generator(sizes, feats, None, compute_loss=False)
+            dets, preds = self.roi_heads(feats, proposals, targets=None, compute_loss=False, branch=branch)
+            return {}, proposals, dets, preds
+        if branch == "val_loss":
+            proposals, rpn_losses = self.proposal_generator(sizes, feats, gt, compute_val_loss=True)
+            _, det_losses = self.roi_heads(feats, proposals, gt, branch=branch, compute_val_loss=True)
+            losses = dict(det_losses); losses.update(rpn_losses)
+            return losses, [], [], None
+        raise ValueError(branch)
+
+    @torch.no_grad()
+    def inference(self, batched_inputs):
+        x4, sizes = self.preprocess_image(batched_inputs)
+        feats = self.backbone(x4)
+        proposals, _ = self.proposal_generator(sizes, feats, None, compute_loss=False)
+        dets, _ = self.roi_heads(feats, proposals, targets=None, compute_loss=False)
+        return [{"instances": d} for d in dets]

@@ -604,3 +604,93 @@ def detect_postprocess(all_scores, all_boxes, img_h, img_w, score_thresh, nms_th
                                     float(nms_thresh), int(topk), _p(cnt), _p(boxes), _p(scores), _p(classes), _p(rows), _p(ws),
                                     _stream()), "sw_detect_postprocess")
     return cnt, boxes, scores, classes, rows
+
+
+# ------------------------------------------------------------------------------------------------ Stage-3 detector (csrc/detector.hip)
+def preprocess_pad(img_u8_chw, out_hw4, mean, std):
+    """u8 (3, h, w) -> out (H, W, 4) = (img - mean) / std, zero padding (bottom / right) and zero 4th channel"""
+    _need_gpu(img_u8_chw, out_hw4)
+    h, w = img_u8_chw.shape[1:]
+    H, W = out_hw4.shape[:2]
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean]); s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(lib.sw_preprocess_pad(dt(out_hw4), h, w, H, W, _p(img_u8_chw), m, s, _p(out_hw4), _stream()), "sw_preprocess_pad")
+    return out_hw4
+
+
+def stem_conv7x7(x_nhwc4, w_oihw, scale, bias, out):
+    n, H, W, _ = x_nhwc4.shape
+    check(lib.sw_stem_conv7x7(dt(x_nhwc4), n, H, W, _p(x_nhwc4), _p(w_oihw), _p(scale), _p(bias), _p(out), _stream()), "sw_stem_conv7x7")
+    return out
+
+
+def maxpool3x3s2(x, out):
+    n, H, W, C = x.shape
+    check(lib.sw_maxpool3x3s2(dt(x), n, H, W, C, _p(x), _p(out), _stream()), "sw_maxpool3x3s2")
+    return out
+
+
+def subsample2x(x, out):
+    n, H, W, C = x.shape
+    check(lib.sw_subsample2x(dt(x), n, H, W, C, _p(x), _p(out), _stream()), "sw_subsample2x")
+    return out
+
+
+def scatter2x(g, out):
+    """out (n, H, W, C) fully written: g (n, ceil(H/2), ceil(W/2), C) at the even pixels, 0 elsewhere"""
+    n, H, W, C = out.shape
+    check(lib.sw_scatter2x(dt(out), n, H, W, C, _p(g), _p(out), _stream()), "sw_scatter2x")
+    return out
+
+
+def add_relu(a, b, out, relu=True):
+    check(lib.sw_add_relu(dt(a), a.numel(), _p(a), _p(b), _p(out), int(relu), _stream()), "sw_add_relu")
+    return out
+
+
+def upsample2x_add(lateral, top, out):
+    n, h, w, C = top.shape
+    assert tuple(lateral.shape) == (n, 2 * h, 2 * w, C), (tuple(lateral.shape), tuple(top.shape))
+    check(lib.sw_upsample2x_add(dt(top), n, h, w, C, _p(lateral), _p(top), _p(out), _stream()), "sw_upsample2x_add")
+    return out
+
+
+def downsample2x_sum(g, out):
+    n, h, w, C = out.shape
+    check(lib.sw_downsample2x_sum(dt(g), n, h, w, C, _p(g), _p(out), _stream()), "sw_downsample2x_sum")
+    return out
+
+
+def roi_align_fwd(feat, rois, sel_i32, out, scale, PH=7, PW=7, sampling_ratio=0):
+    """feat (N, H, W, C) of one level; rois (R, 5) f32; sel int32 rows of this level; out (R, C*PH*PW)"""
+    _need_gpu(feat, rois, sel_i32, out)
+    n, H, W, C = feat.shape
+    check(lib.sw_roi_align_fwd(dt(feat), H, W, C, PH, PW, float(scale), sampling_ratio, _p(feat), _p(rois), _p(sel_i32),
+                               sel_i32.numel(), _p(out), out.stride(0), _stream()), "sw_roi_align_fwd")
+    return out
+
+
+def roi_align_bwd(gout, rois, sel_i32, dfeat_f32, scale, PH=7, PW=7, sampling_ratio=0):
+    _need_gpu(gout, rois, sel_i32, dfeat_f32)
+    n, H, W, C = dfeat_f32.shape
+    check(lib.sw_roi_align_bwd(dt(gout), H, W, C, PH, PW, float(scale), sampling_ratio, _p(gout), gout.stride(0), _p(rois),
+                               _p(sel_i32), sel_i32.numel(), _p(dfeat_f32), _stream()), "sw_roi_align_bwd")
+    return dfeat_f32
+
+
+def decode_boxes(deltas, boxes, weights, scale_clamp, out):
+    """deltas (n, >=4) f32 rows; boxes (n_boxes, 4), row i uses boxes[i % n_boxes]; out (n, 4)"""
+    _need_gpu(deltas, boxes, out)
+    rw = (ctypes.c_float * 4)(*[float(v) for v in weights])
+    check(lib.sw_decode_boxes(out.shape[0], boxes.shape[0], _p(deltas), deltas.stride(0), _p(boxes), rw, float(scale_clamp), _p(out),
+                              _stream()), "sw_decode_boxes")
+    return out
+
+
+def rpn_loss(logits, deltas, labels_i8, anchors, matched_gt, weights, inv_norm, losses2, dlogits=None, ddeltas=None):
+    """logits (n,), deltas (n, 4), labels int8 (n,), anchors (A, 4) repeating over the images, matched_gt (n, 4) -> losses2 (2,)"""
+    _need_gpu(logits, deltas, labels_i8, anchors, matched_gt, losses2)
+    rw = (ctypes.c_float * 4)(*[float(v) for v in weights])
+    ws = torch.empty(int(lib.sw_rpn_loss_workspace_floats()), device=logits.device, dtype=torch.float32)
+    check(lib.sw_rpn_loss(logits.numel(), anchors.shape[0], _p(logits), _p(deltas), _p(labels_i8), _p(anchors), _p(matched_gt), rw,
+                          float(inv_norm), _p(losses2), _p(dlogits), _p(ddeltas), _p(ws), _stream()), "sw_rpn_loss")
+    return losses2

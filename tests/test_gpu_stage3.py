@@ -1,0 +1,287 @@
+"""GPU: the Stage-3 detector (sos-wsod_amd/frcnn.py: ResNet-50-FPN Faster R-CNN of the Unbiased-Teacher step) against
+(a) the fixtures written by RUNNING the reference's own detector (tests/golden/make_stage3_golden.py -> stage3_a / stage3_w) and
+(b) the oracle (oracle/frcnn_oracle.py, itself pinned by those fixtures) — kernels first, then the branches, then one burn-in and
+one semi-supervised iteration of semisup.SemiSupStep on the real modules (unbias/ubteacher/engine/trainer.py:436-549)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import frcnn_oracle as FO  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import sos_wsod_amd  # noqa: F401
+    import sos_wsod_amd.ops as ops
+    return ops
+
+
+class _Keys:
+    """the closed-form sampling keys of the fixtures (oracle.frcnn_oracle.Perm) as the product's sampler"""
+
+    def __init__(self, tag):
+        self.perm = FO.Perm(tag)
+
+    def priorities(self, n, device):
+        return torch.from_numpy(self.perm.priorities(n)).to(device)
+
+
+def _same_boxes(a, b, atol=1e-2):
+    if len(a) != len(b):
+        return False
+    if len(a) == 0:
+        return True
+    d = np.abs(a[:, None, :] - b[None, :, :]).max(2)
+    return bool((d.min(1) <= atol).all() and (d.min(0) <= atol).all())
+
+
+def _model(K, P, tag, dtype=torch.float32):
+    from sos_wsod_amd.frcnn import TwoStagePseudoLabGeneralizedRCNN
+    m = TwoStagePseudoLabGeneralizedRCNN(num_classes=K, compute_dtype=dtype, sampler=_Keys(tag)).cuda()
+    sd = m.state_dict()
+    assert set(sd) == set(P), (sorted(set(sd) - set(P))[:5], sorted(set(P) - set(sd))[:5])       # the reference's state-dict names
+    with torch.no_grad():
+        for k, v in P.items():
+            assert tuple(sd[k].shape) == tuple(v.shape), k
+            sd[k].copy_(torch.from_numpy(v))
+    return m
+
+
+def _inputs(tag, t, K, with_gt=True):
+    from sos_wsod_amd.structures import Boxes, Instances
+    data, gts = [], []
+    n_gt = t["n_gt"] if "n_gt" in t.files else [0] * len(t["sizes"])
+    for i, ((h, w), n) in enumerate(zip(t["sizes"], n_gt)):
+        h, w = int(h), int(w)
+        d = {"image": torch.from_numpy(FO.make_image(h, w, f"{tag}{i}")).cuda(), "height": h, "width": w}
+        if with_gt:
+            b, c = FO.make_gt(h, w, int(n), K, f"{tag}{i}")
+            inst = Instances((h, w)); inst.gt_boxes = Boxes(torch.from_numpy(b).cuda()); inst.gt_classes = torch.from_numpy(c).cuda()
+            d["instances"] = inst
+            gts.append((b, c))
+        data.append(d)
+    return data, gts
+
+
+# ------------------------------------------------------------------------------------------ kernels
+def test_roi_align_forward_backward_against_the_c_oracle(ops):
+    torch.manual_seed(0)
+    N, C, H, W, R = 2, 16, 20, 28, 120
+    feat = torch.randn(N, C, H, W)
+    x1 = torch.rand(R) * 180; y1 = torch.rand(R) * 120
+    rois = torch.stack([(torch.arange(R) % N).float(), x1, y1, x1 + 2 + torch.rand(R) * 150, y1 + 2 + torch.rand(R) * 100], 1)
+    rois[:4, 1:] = torch.tensor([[-30.0, -20.0, 10.0, 12.0], [200.0, 140.0, 260.0, 190.0], [5.0, 5.0, 5.5, 5.5], [0.0, 0.0, 224.0, 160.0]])
+    scale = 1.0 / 8
+    ref = FO.roi_align_fwd(feat.numpy(), rois.numpy(), scale)
+    f = feat.permute(0, 2, 3, 1).contiguous().cuda()
+    sel = torch.arange(R, dtype=torch.int32).cuda()
+    out = torch.zeros(R, C * 49, device="cuda")
+    ops.roi_align_fwd(f, rois.cuda(), sel, out, scale)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(ref.shape), ref, rtol=1e-5, atol=1e-6)
+    # only the listed rows are written
+    out2 = torch.full((R, C * 49), 7.0, device="cuda")
+    ops.roi_align_fwd(f, rois.cuda(), sel[::2].contiguous(), out2, scale)
+    assert torch.equal(out2[1::2], torch.full_like(out2[1::2], 7.0)) and torch.equal(out2[::2], out[::2])
+    g = torch.randn(R, C, 7, 7)
+    gref = FO.roi_align_bwd(g.numpy(), rois.numpy(), scale, feat.shape)
+    d = torch.zeros(N, H, W, C, device="cuda")
+    ops.roi_align_bwd(g.view(R, -1).cuda().contiguous(), rois.cuda(), sel, d, scale)
+    np.testing.assert_allclose(d.permute(0, 3, 1, 2).cpu().numpy(), gref, rtol=1e-4, atol=1e-5)
+
+
+def test_stem_pool_and_join_kernels_against_torch(ops):
+    torch.manual_seed(1)
+    # stem: 7x7 s2 p3 + affine + ReLU, then 3x3 s2 p1 max pool (resnet.py:334-359)
+    N, H, W = 2, 70, 96
+    x = torch.randn(N, 3, H, W) * 50
+    w = torch.randn(64, 3, 7, 7) * 0.05; sc = torch.rand(64) + 0.5; sh = torch.randn(64) * 0.1
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, stride=2, padding=3) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    x4 = torch.zeros(N, H, W, 4); x4[..., :3] = x.permute(0, 2, 3, 1)
+    y = ops.stem_conv7x7(x4.cuda(), w.cuda(), sc.cuda(), sh.cuda(), torch.empty(N, ref.shape[2], ref.shape[3], 64, device="cuda"))
+    assert float((y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    pref = F.max_pool2d(ref.float(), kernel_size=3, stride=2, padding=1)
+    p = ops.maxpool3x3s2(y, torch.empty(N, pref.shape[2], pref.shape[3], 64, device="cuda"))
+    assert float((p.cpu().permute(0, 3, 1, 2) - pref).abs().max()) < 1e-4
+    # subsample / scatter (odd sizes), residual join, FPN top-down join and its backward
+    a = torch.randn(2, 9, 13, 16)
+    s = ops.subsample2x(a.cuda(), torch.empty(2, 5, 7, 16, device="cuda"))
+    assert torch.equal(s.cpu(), a[:, ::2, ::2])
+    back = ops.scatter2x(s, torch.full((2, 9, 13, 16), 5.0, device="cuda")).cpu()
+    want = torch.zeros_like(a); want[:, ::2, ::2] = a[:, ::2, ::2]
+    assert torch.equal(back, want)
+    b = torch.randn_like(a)
+    assert torch.equal(ops.add_relu(a.cuda(), b.cuda(), torch.empty_like(a).cuda()).cpu(), F.relu(a + b))
+    top = torch.randn(2, 4, 6, 8); lat = torch.randn(2, 8, 12, 8)
+    up = ops.upsample2x_add(lat.cuda(), top.cuda(), torch.empty_like(lat).cuda()).cpu()
+    want = lat + F.interpolate(top.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(up, want)
+    g = torch.randn_like(lat)
+    ds = ops.downsample2x_sum(g.cuda(), torch.empty_like(top).cuda()).cpu()
+    want = F.avg_pool2d(g.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1) * 4
+    assert float((ds - want).abs().max()) < 1e-5
+    # padded preprocess (rcnn.py:220-228 + image_list.py)
+    img = torch.randint(0, 256, (3, 37, 50), dtype=torch.uint8)
+    o = ops.preprocess_pad(img.cuda(), torch.empty(64, 64, 4, device="cuda"), FO.PIXEL_MEAN, FO.PIXEL_STD).cpu()
+    ref, _ = FO.preprocess([img.numpy()])
+    assert torch.equal(o[:37, :50, :3].permute(2, 0, 1), ref[0, :, :37, :50]) and float(o[37:].abs().max()) == 0 and float(o[..., 3].abs().max()) == 0
+
+
+def test_rpn_loss_kernel_against_the_oracle(ops):
+    torch.manual_seed(2)
+    N = 2
+    anchors = np.concatenate(FO.grid_anchors([(10, 10), (5, 5), (3, 3), (2, 2), (1, 1)]), 0)
+    A = len(anchors)
+    logits = torch.randn(N, A) * 2; deltas = torch.randn(N, A, 4) * 0.3
+    labels = torch.randint(-1, 2, (N, A))
+    gt = torch.from_numpy(anchors)[None].repeat(N, 1, 1) + torch.randn(N, A, 4) * 2
+    gt[..., 2:] = torch.maximum(gt[..., 2:], gt[..., :2] + 1)
+    ref = FO.rpn_losses(anchors, [logits.clone().requires_grad_(True)], [deltas.clone().requires_grad_(True)],
+                        [labels[i].numpy() for i in range(N)], [gt[i].numpy() for i in range(N)], batch_size=256)
+    lt = logits.clone().requires_grad_(True); dt_ = deltas.clone().requires_grad_(True)
+    r2 = FO.rpn_losses(anchors, [lt], [dt_], [labels[i].numpy() for i in range(N)], [gt[i].numpy() for i in range(N)], batch_size=256)
+    (r2["loss_rpn_cls"] + 3.0 * r2["loss_rpn_loc"]).backward()
+    out = torch.empty(2, device="cuda"); dl = torch.empty(N * A, device="cuda"); dd = torch.empty(N * A, 4, device="cuda")
+    ops.rpn_loss(logits.reshape(-1).cuda(), deltas.reshape(-1, 4).cuda(), labels.reshape(-1).to(torch.int8).cuda(),
+                 torch.from_numpy(anchors).cuda(), gt.reshape(-1, 4).cuda(), FO.RPN_BBOX_WEIGHTS, 1.0 / (256 * N), out, dl, dd)
+    assert abs(float(out[0]) - float(ref["loss_rpn_cls"])) <= 1e-5 * abs(float(ref["loss_rpn_cls"]))
+    assert abs(float(out[1]) - float(ref["loss_rpn_loc"])) <= 1e-5 * abs(float(ref["loss_rpn_loc"]))
+    np.testing.assert_allclose(dl.cpu().numpy().reshape(N, A), lt.grad.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(3.0 * dd.cpu().numpy().reshape(N, A, 4), dt_.grad.numpy(), rtol=1e-4, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------ branches against the reference fixtures
+def test_supervised_branch_matches_the_reference_generated_fixture(golden_dir):
+    t = np.load(os.path.join(golden_dir, "stage3_a.npz"))
+    K = int(t["K"])
+    P = FO.make_params(K, tag="s3a", head_scale=float(t["head_scale"]))
+    model = _model(K, P, "s3a")
+    model.train()
+    data, gts = _inputs("s3a", t, K)
+    losses, _, _, _ = model(data, branch="supervised")
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    assert set(losses) == {"loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"}
+    for k, v in losses.items():
+        ref = float(t["loss/" + k])
+        assert abs(float(v) - ref) <= 1e-4 * abs(ref), (k, float(v), ref)
+    lab = model.proposal_generator.last_labels.cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(lab[i], t[f"rpn_labels{i}"]), i                                   # sampled anchor labels: bit exact
+        s = model.roi_heads.last_sampled[i]
+        assert np.array_equal(s.gt_classes.cpu().numpy(), t[f"samp_classes{i}"]), i              # sampled proposals' classes: bit exact
+        np.testing.assert_allclose(s.proposal_boxes.tensor.cpu().numpy(), t[f"samp_boxes{i}"], atol=1e-2)
+    K1 = K + 1
+    lg = model.roi_heads.last_logits.detach().cpu().numpy()
+    np.testing.assert_allclose(lg[:, :K1], t["scores"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(lg[:, K1:5 * K + 1], t["deltas"], rtol=1e-3, atol=1e-3)
+    sd = dict(model.named_parameters())
+    worst = ("", 0.0)
+    for key in t.files:
+        if key.startswith("grad/"):
+            ref, got = t[key], sd[key[5:]].grad.cpu().numpy()
+        elif key.startswith("grads/"):
+            ref, got = t[key], sd[key[6:]].grad.cpu().numpy().ravel()[::997]
+        else:
+            continue
+        err = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+        worst = max(worst, (key, err), key=lambda x: x[1])
+        assert err <= 2e-3, (key, err)
+    for name in t["frozen"]:
+        assert sd[str(name)].grad is None                                                        # FREEZE_AT 2: stem + res2
+    print(f"stage-3 supervised branch: losses {dict((k, round(float(v), 6)) for k, v in losses.items())}; worst gradient error {worst[1]:.1e} ({worst[0]})")
+
+
+def test_teacher_weak_branch_and_pseudo_labels_match_the_reference_generated_fixture(golden_dir):
+    from sos_wsod_amd.semisup import process_pseudo_label
+    t = np.load(os.path.join(golden_dir, "stage3_w.npz"))
+    K = int(t["K"])
+    P = FO.make_params(K, tag="s3w", head_scale=float(t["head_scale"]))
+    model = _model(K, P, "s3w")
+    model.train()                                   # the teacher stays in training mode (trainer.py:474-477): train top-k counts
+    data, _ = _inputs("s3w", t, K, with_gt=False)
+    with torch.no_grad():
+        _, props, dets, _ = model(data, branch="unsup_data_weak")
+    pseudo, _ = process_pseudo_label(data, dets, 0.7, "roih")
+    for i in range(2):
+        assert _same_boxes(props[i].proposal_boxes.tensor.cpu().numpy(), t[f"prop_boxes{i}"])
+        assert np.array_equal(dets[i].pred_classes.cpu().numpy(), t[f"det_classes{i}"])
+        np.testing.assert_allclose(dets[i].scores.cpu().numpy(), t[f"det_scores{i}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(dets[i].pred_boxes.tensor.cpu().numpy(), t[f"det_boxes{i}"], rtol=1e-4, atol=1e-2)
+        assert len(pseudo[i]) == len(t[f"pseudo_boxes{i}"]) == 3
+        assert np.array_equal(pseudo[i].gt_classes.cpu().numpy(), t[f"pseudo_classes{i}"])
+        np.testing.assert_allclose(pseudo[i].gt_boxes.tensor.cpu().numpy(), t[f"pseudo_boxes{i}"], rtol=1e-4, atol=1e-2)
+
+
+# ------------------------------------------------------------------------------------------ the step on the real modules
+def test_semisup_step_burn_in_and_semi_supervised_iteration_on_the_real_detector():
+    """unbias/ubteacher/engine/trainer.py:436-549 with the real student / teacher: iteration 0 = burn-in (supervised branch on the
+    strong + weak labelled views), iteration 1 = teacher copy (keep rate 0), teacher's weak pass, 0.7 thresholding, student on the
+    labelled views and on the strongly augmented unlabelled views with the pseudo boxes, loss weights (pseudo box losses x 0, other
+    pseudo losses x UNSUP_LOSS_WEIGHT 2).  Every recorded loss against the oracle evaluated at the student's / teacher's current
+    weights with the same sampling keys: 1e-4 relative."""
+    from sos_wsod_amd.semisup import SemiSupStep
+    from sos_wsod_amd.structures import Boxes, Instances
+    K = 20
+    P = FO.make_params(K, tag="s3s", head_scale=14.0)
+    student, teacher = _model(K, P, "s3s"), _model(K, P, "s3s")
+    student.train(); teacher.train()
+    keys = student.sampler
+    student.proposal_generator.sampler = student.roi_heads.sampler = keys
+    opt = torch.optim.SGD([p for p in student.parameters() if p.requires_grad], lr=1e-5, momentum=0.9)      # (the fixture is touchy: at 1e-4 one step pushes every teacher score below 0.7)
+    step = SemiSupStep(student, teacher, opt, burn_up_step=1, ema_keep_rate=0.9996, bbox_threshold=0.7, unsup_loss_weight=2.0)
+    sizes = [(96, 128), (128, 112)]
+
+    def batch(tag, n_gt):
+        out, gts, imgs = [], [], []
+        for i, (h, w) in enumerate(sizes):
+            img = FO.make_image(h, w, f"{tag}{i}")
+            d = {"image": torch.from_numpy(img).cuda(), "height": h, "width": w}
+            if n_gt:
+                b, c = FO.make_gt(h, w, n_gt, K, f"{tag}{i}")
+                inst = Instances((h, w)); inst.gt_boxes = Boxes(torch.from_numpy(b).cuda()); inst.gt_classes = torch.from_numpy(c).cuda()
+                d["instances"] = inst
+                gts.append((b, c))
+            out.append(d); imgs.append(img)
+        return out, gts, imgs
+    lq, gq, iq = batch("s3s_lq", 2); lk, gk, ik = batch("s3s_lk", 3)
+    uq, _, iuq = batch("s3s_uq", 0); uk, _, iuk = batch("s3s_uk", 0)
+
+    def weights(m):
+        return {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    # ---- iteration 0: burn-in
+    W0 = weights(student)
+    record, loss_dict = step.run_step((lq, lk, uq, uk))
+    ref, _, _ = FO.supervised_forward(W0, iq + ik, gq + gk, K, FO.Perm("s3s"))
+    for k in ref:
+        assert abs(float(record[k]) - ref[k]) <= 1e-4 * abs(ref[k]), (k, float(record[k]), ref[k])
+    assert any(not np.array_equal(W0[k], v) for k, v in weights(student).items())                    # the optimizer moved the student
+    # ---- iteration 1: teacher <- student, pseudo labels, student on labelled + pseudo-labelled data
+    W1 = weights(student)
+    perm = FO.Perm("s3s"); perm.k = keys.perm.k                                                       # the key stream continues
+    record, loss_dict = step.run_step((lq, lk, uq, uk))
+    for k, v in weights(teacher).items():
+        assert np.array_equal(v, W1[k]), k                                                            # keep rate 0: an exact copy
+    _, dets = FO.weak_forward(W1, iuk, K)
+    pseudo = [(d["pred_boxes"][d["scores"] > 0.7], d["pred_classes"][d["scores"] > 0.7]) for d in dets]
+    assert sum(len(p[0]) for p in pseudo) > 0
+    for d, p in zip(uq, pseudo):
+        assert len(d["instances"]) == len(p[0])                                                       # add_label put the pseudo boxes on the strong views
+    ref_l, _, _ = FO.supervised_forward(W1, iq + ik, gq + gk, K, perm)
+    ref_u, _, _ = FO.supervised_forward(W1, iuq, pseudo, K, perm)
+    want = dict(ref_l); want.update({k + "_pseudo": v for k, v in ref_u.items()})
+    assert set(k for k in record if k.startswith("loss")) == set(want)
+    for k, v in want.items():
+        # RPN losses 1e-4.  The ROI-head losses of this iteration get 2e-3: the label sampling picks candidates by POSITION in
+        # the proposal list (sampling.py:49-53 indexes the list with randperm), and two RPN logits equal to ~1e-7 order
+        # differently on the two sides (measured: one swapped pair -> one other background row among 512, loss_cls 3e-4);
+        # with identical sampled sets the bar is 1e-4 (iteration 0 above and the reference-generated fixture).
+        tol = 1e-4 if "rpn" in k else 2e-3
+        assert abs(float(record[k]) - v) <= tol * abs(v) + 1e-7, (k, float(record[k]), v)
+    assert float(loss_dict["loss_box_reg_pseudo"]) == 0.0 and float(loss_dict["loss_rpn_loc_pseudo"]) == 0.0
+    assert abs(float(loss_dict["loss_cls_pseudo"]) - 2.0 * want["loss_cls_pseudo"]) <= 4e-3 * abs(want["loss_cls_pseudo"])
+    print("semi-supervised iteration:", {k: round(float(v), 5) for k, v in record.items() if k.startswith("loss")})
