@@ -87,7 +87,10 @@ class _LinearFn(torch.autograd.Function):
                 if Pp != P:
                     gs = torch.cat([gs, torch.zeros(Pp - P, ld, device=g.device, dtype=cd)], 0)
                     x = torch.cat([x, torch.zeros(Pp - P, D, device=g.device, dtype=cd)], 0)
-                ops.gemm(gs, x, dwp, ld, D, Pp, a_kstrided=True, b_kstrided=True)
+                # K = pixels (10^4 .. 10^5 for a 1x1 convolution), M x N = a handful of 128x128 tiles: split K so that tiles x splits
+                # fill the chip (slabs + ordered fold inside sw_gemm: deterministic); unsplit, 4 workgroups walked 60 000 pixels
+                tiles = ((ld + 127) // 128) * ((D + 127) // 128)
+                ops.gemm(gs, x, dwp, ld, D, Pp, a_kstrided=True, b_kstrided=True, splitk=max(1, min(64, 512 // tiles, Pp // 512)))
             dw = dwp[:out_f]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbp = torch.zeros(ld, device=g.device, dtype=torch.float32)
@@ -281,8 +284,16 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(c)); self.register_buffer("running_var", torch.ones(c) - 1e-5)
 
     def fold(self):
-        scale = self.weight * torch.rsqrt(self.running_var + 1e-5)
-        return scale, self.bias - self.running_mean * scale
+        """(scale, shift) of y = x * scale + shift; cached: the statistics are frozen buffers (rebuilt when one of them was written,
+        e.g. by load_state_dict or the teacher's EMA, which bump the tensors' version counters)"""
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version, self.weight.device,
+               ops.PARAM_EPOCH)            # (PARAM_EPOCH: kernels that write state behind torch's counters — HipSGD, the teacher EMA)
+        hit = self.__dict__.get("_fold")
+        if hit is None or hit[0] != key:
+            scale = self.weight * torch.rsqrt(self.running_var + 1e-5)
+            hit = (key, (scale.contiguous(), (self.bias - self.running_mean * scale).contiguous()))
+            self.__dict__["_fold"] = hit
+        return hit[1]
 
 
 class ConvBN(nn.Module):
