@@ -6,9 +6,10 @@ proposals_roih, _)` for student and teacher), the teacher refresh as ONE multi-t
 (`sw_ema_multi`), pseudo-label thresholding as a device-side stable compaction (`sw_threshold_select`: no `.nonzero()` host
 sync per image), the loss weighting, the ROI heads' focal classification loss (`FocalLoss`, `fast_rcnn_focal_loss`: one HIP
 kernel for loss + gradient, fast_rcnn.py:73-105), the teacher / student container (`EnsembleTSModel`, ts_ensemble.py) and the
-branch dispatch of the meta-architecture (`TwoStagePseudoLabRCNN`, meta_arch/rcnn.py:8-107).  What is NOT here yet: the ResNet-50-FPN Faster-RCNN the reference plugs in as
-student / teacher — the step takes any module with that call signature.  Parity of this half is restatement-only
-(oracle/semisup_oracle.py explains why no fixture could be generated)."""
+branch dispatch of the meta-architecture over arbitrary parts (`TwoStagePseudoLabRCNN`, meta_arch/rcnn.py:8-107).  The detector the
+reference plugs in as student / teacher — the ResNet-50-FPN Faster R-CNN — is `frcnn.TwoStagePseudoLabGeneralizedRCNN`; the step
+takes any module with that call signature.  Parity: the step on the real detector is checked against oracle/frcnn_oracle.py, which
+is pinned by fixtures the reference's own detector wrote (tests/golden/make_stage3_golden.py, tests/test_gpu_stage3.py)."""
 from typing import Dict, Optional
 
 import torch
