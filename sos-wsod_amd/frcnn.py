@@ -39,22 +39,37 @@ def _epc(dtype):
     return 8 if dtype == torch.bfloat16 else 4
 
 
+def _stage_linear(w, cd):
+    """compute-dtype copy of an (out, in) f32 weight, rows padded to a multiple of 8 (zero rows)"""
+    out_f, D = w.shape
+    ws = torch.zeros((out_f + 7) // 8 * 8, D, device=w.device, dtype=cd)
+    ops.convert_2d(w.detach().contiguous(), ws, out_f, D)
+    return ws
+
+
+def _stage_conv3(w, cd):
+    """forward kernel layout [co][tap][ci] of an OIHW 3x3 weight"""
+    cout, cin = w.shape[:2]
+    wk = torch.empty(cout, 9, cin, device=w.device, dtype=cd)
+    ops.conv_weight_prep(w.detach().contiguous(), wk, 0, cin)
+    return wk
+
+
 # ====================================================================================================== autograd nodes
 class _LinearFn(torch.autograd.Function):
     """y (P, out) = x (P, in) @ W^T (+ b) (ReLU): sw_gemm with the epilogue fused; explicit backward (dgrad, wgrad GEMMs, column
     sums).  x compute dtype, W / b f32 masters, y compute dtype or f32 (out_f32)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, out_f32):
+    def forward(ctx, x, w, b, relu, out_f32, staged=None):
         P, D = x.shape
         out_f = w.shape[0]
         cd = x.dtype
         ld = (out_f + 7) // 8 * 8
-        ws = torch.zeros(ld, D, device=x.device, dtype=cd)
-        ops.convert_2d(w.detach().contiguous(), ws, out_f, D)
+        ws = staged if staged is not None else _stage_linear(w, cd)
         ydt = torch.float32 if out_f32 else cd
         assert not (relu and out_f32)
-        ybuf = torch.zeros(P, ld, device=x.device, dtype=ydt)           # columns beyond out_f stay 0
+        ybuf = (torch.zeros if ld != out_f else torch.empty)(P, ld, device=x.device, dtype=ydt)     # columns beyond out_f stay 0
         y = ybuf[:, :out_f]
         if P > 0:
             ops.gemm(x, ws, y, P, out_f, D, ep=ops.make_epilogue(bias=None if b is None else b.detach().contiguous(), relu=relu,
@@ -68,7 +83,7 @@ class _LinearFn(torch.autograd.Function):
         x, ws, ybuf = ctx.saved_tensors
         P, D = x.shape
         out_f, ld, cd = ctx.out_f, ws.shape[0], x.dtype
-        gs = torch.zeros(P, ld, device=g.device, dtype=cd)
+        gs = (torch.zeros if ld != out_f else torch.empty)(P, ld, device=g.device, dtype=cd)
         if P > 0:
             gs[:, :out_f] = g
             if ctx.relu:
@@ -97,7 +112,7 @@ class _LinearFn(torch.autograd.Function):
             if P > 0:
                 ops.colsum(gs, gs.shape[0], ld, dbp)
             db = dbp[:out_f]
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class _Conv3x3Fn(torch.autograd.Function):
@@ -105,12 +120,11 @@ class _Conv3x3Fn(torch.autograd.Function):
     ordered fold), column sums, data gradient through the flipped-weight layout."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, staged=None):
         n, H, W, cin = x.shape
         cout = w.shape[0]
         cd = x.dtype
-        wk = torch.zeros(cout, 9, cin, device=x.device, dtype=cd)
-        ops.conv_weight_prep(w.detach().contiguous(), wk, 0, cin)
+        wk = staged if staged is not None else _stage_conv3(w, cd)
         out = torch.empty(n, H, W, cout, device=x.device, dtype=cd)
         ops.conv3x3(x, wk, out, 1, ops.make_epilogue(bias=None if b is None else b.detach().contiguous(), relu=relu, out_dtype=cd))
         ctx.save_for_backward(x, w, out if relu else None)
@@ -151,7 +165,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             ops.conv_weight_prep(w.detach().contiguous(), wkd, 1)
             dx = torch.empty(n, H, W, cin, device=g.device, dtype=cd)
             ops.conv3x3(dz, wkd, dx, 1, ops.make_epilogue(out_dtype=cd))
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _Subsample2Fn(torch.autograd.Function):
@@ -308,13 +322,26 @@ class ConvBN(nn.Module):
 
     def forward(self, x, relu):
         scale, shift = self.norm.fold()
-        w = self.weight * scale.view(-1, 1, 1, 1)                 # the FrozenBN fold: d/dweight = scale * d/dw_eff through autograd
+        staged = None
+        if not (torch.is_grad_enabled() and self.weight.requires_grad):
+            # no gradient will be asked of this layer (frozen stem / res2, the teacher's passes): folded + staged weights are kept
+            # until the parameter or the statistics change
+            key = (ops.param_key(self.weight), id(scale), x.dtype)
+            hit = self.__dict__.get("_staged")
+            if hit is None or hit[0] != key:
+                w = (self.weight.detach() * scale.view(-1, 1, 1, 1))
+                st = _stage_conv3(w, x.dtype) if self.k == 3 else _stage_linear(w.view(w.shape[0], -1), x.dtype)
+                hit = (key, w, st)
+                self.__dict__["_staged"] = hit
+            w, staged = hit[1], hit[2]
+        else:
+            w = self.weight * scale.view(-1, 1, 1, 1)             # the FrozenBN fold: d/dweight = scale * d/dw_eff through autograd
         if self.k == 3:
-            return _Conv3x3Fn.apply(x, w, shift, relu)
+            return _Conv3x3Fn.apply(x, w, shift, relu, staged)
         if self.stride == 2:
             x = _Subsample2Fn.apply(x)
         n, H, W, C = x.shape
-        y = _LinearFn.apply(x.reshape(n * H * W, C), w.view(w.shape[0], C), shift, relu, False)
+        y = _LinearFn.apply(x.reshape(n * H * W, C), w.view(w.shape[0], C), shift, relu, False, staged)
         return y.reshape(n, H, W, w.shape[0])
 
 
