@@ -264,6 +264,10 @@ int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, float
  * `_fold` adds n_partial_rows consecutive rows (of one or several matrices) in fixed order */
 int sw_colsum_partial(int dtype, int M, int N, const void* X, long ld, float* workspace, sw_stream_t stream);
 int sw_colsum_fold(int N, int n_partial_rows, const float* workspace, float* out, sw_stream_t stream);
+/* n `_partial` calls in ONE launch (every bias gradient of a backward pass: conv layers x view batches); `parts` is a HOST array;
+ * problem i writes sw_colsum_workspace_floats(dtype, M, N) / N partial rows at its workspace */
+typedef struct { int M, N; const void* X; long ld; float* workspace; } sw_colsum_part_desc;
+int sw_colsum_partial_multi(int dtype, int n, const sw_colsum_part_desc* parts, sw_stream_t stream);
 /* n folds in ONE launch; `folds` is a HOST array */
 typedef struct { int N, n_partial_rows; const float* workspace; float* out; } sw_colsum_fold_desc;
 int sw_colsum_fold_multi(int n, const sw_colsum_fold_desc* folds, sw_stream_t stream);

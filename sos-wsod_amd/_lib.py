@@ -48,6 +48,11 @@ class CopyDesc(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_long)]
 
 
+class ColsumPart(ctypes.Structure):
+    """struct sw_colsum_part_desc"""
+    _fields_ = [("M", c_int), ("N", c_int), ("X", c_void_p), ("ld", c_long), ("workspace", c_void_p)]
+
+
 class ColsumFold(ctypes.Structure):
     """sw_colsum_fold_desc"""
     _fields_ = [("N", ctypes.c_int), ("n_partial_rows", ctypes.c_int), ("workspace", ctypes.c_void_p), ("out", ctypes.c_void_p)]
@@ -114,6 +119,7 @@ SIGNATURES = {
     "sw_conv3x3_wgrad_fold": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_conv3x3_wgrad_fold_multi": (c_int, [c_int, ctypes.POINTER(WgradFold), c_void_p]),
     "sw_colsum_fold_multi": (c_int, [c_int, ctypes.POINTER(ColsumFold), c_void_p]),
+    "sw_colsum_partial_multi": (c_int, [c_int, c_int, ctypes.POINTER(ColsumPart), c_void_p]),
     "sw_conv3x3_wgrad_grouped": (c_int, [c_int, c_int, ctypes.POINTER(WgradProblem), c_void_p]),
     "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

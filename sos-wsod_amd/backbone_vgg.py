@@ -185,6 +185,7 @@ class _VGGFunction(torch.autograd.Function):
         grouped = module.grouped_wgrad
         bk = 64 if dtype == torch.bfloat16 else 32
         deferred = []
+        module._colsum_deferred = []
         target = module.wgrad_target_ktiles
         if grouped and target <= 0:             # pick the K-tiles per item for THIS set of (layer, view batch) problems
             shapes = []
@@ -241,7 +242,9 @@ class _VGGFunction(torch.autograd.Function):
             main.wait_stream(side)
         if deferred:
             ops.conv3x3_wgrad_grouped(deferred)
+            ops.colsum_partial_multi(module._colsum_deferred)
             deferred.clear()
+        module._colsum_deferred = []
         # ---- one ordered fold per parameter over the slabs / partial rows of every view batch: all of them in two launches
         ops.conv3x3_wgrad_fold_multi([(pl["ws"], pl["nslab"], pl["dw"]) for pl in plan.values()])
         ops.colsum_fold_multi([(pl["rows"], pl["nrow"], pl["db"]) for pl in plan.values()])
@@ -278,7 +281,11 @@ class _VGGFunction(torch.autograd.Function):
                         if consumer_stream is not None:
                             x_in.record_stream(consumer_stream); dz.record_stream(consumer_stream)
                         deferred.append((x_in, dz, pl["ws"][pl["slab_off"][i]:], blk.dilation, pl["splits"][i]))
-                    ops.colsum_partial(dz.view(npix, blk.out_channels), npix, blk.out_channels, pl["rows"][pl["row_off"][i]:])
+                    if deferred is None:
+                        ops.colsum_partial(dz.view(npix, blk.out_channels), npix, blk.out_channels, pl["rows"][pl["row_off"][i]:])
+                    else:       # bias partial rows of every layer x view batch: ONE launch behind the chains (18 launches before, each
+                        #             in front of a data-gradient convolution on its stream's critical path)
+                        module._colsum_deferred.append((dz.view(npix, blk.out_channels), pl["rows"][pl["row_off"][i]:]))
                 if (si, ci) == first_trainable:
                     return
                 # data gradient: conv with flipped/transposed weights; ReLU mask of the producer fused when the

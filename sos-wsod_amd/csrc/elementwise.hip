@@ -332,12 +332,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, int rows_per_
 // (A single launch whose last workgroup folds — ticket counter + __threadfence — was measured 20 us SLOWER per call: an
 // agent-scope release on this part writes the XCD's whole L2 back, once per workgroup.)
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_ws_kernel(int M, int N, int rows_per_chunk, const T* __restrict__ X, long ld,
-                                                        float* __restrict__ ws) {
+__device__ __forceinline__ void colsum_ws_body(int M, int N, int rows_per_chunk, const T* __restrict__ X, long ld,
+                                               float* __restrict__ ws, const int slab, const int chunk) {
   constexpr int VEC = 16 / (int)sizeof(T), SLAB = 32 * VEC;
   __shared__ float part[8][SLAB + 4];
   const int tid = threadIdx.x, l32 = tid & 31, rsub = tid >> 5;
-  const int slab = blockIdx.x, chunk = blockIdx.y;
   const int c0 = slab * SLAB + l32 * VEC;
   const int m0 = chunk * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
   float acc[VEC];
@@ -369,6 +368,30 @@ __global__ __launch_bounds__(256) void colsum_ws_kernel(int M, int N, int rows_p
     for (int r = 0; r < 8; ++r) s += part[r][c];
     if (slab * SLAB + c < N) ws[(long)chunk * N + slab * SLAB + c] = s;
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_ws_kernel(int M, int N, int rows_per_chunk, const T* __restrict__ X, long ld,
+                                                        float* __restrict__ ws) {
+  colsum_ws_body<T>(M, N, rows_per_chunk, X, ld, ws, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// several matrices in ONE launch (the bias gradients of every conv layer x view batch of a backward pass): workgroup -> (problem,
+// slab, chunk) through a prefix table in the kernel arguments
+constexpr int CPART_MAX = 40;
+struct ColsumPartMulti {
+  int n;
+  int M[CPART_MAX], N[CPART_MAX], rpc[CPART_MAX], slabs[CPART_MAX], first_wg[CPART_MAX + 1];
+  long ld[CPART_MAX];
+  const void* X[CPART_MAX];
+  float* ws[CPART_MAX];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_ws_multi_kernel(ColsumPartMulti f) {
+  int i = 0;
+  while (i + 1 < f.n && (int)blockIdx.x >= f.first_wg[i + 1]) ++i;
+  const int w = (int)blockIdx.x - f.first_wg[i];
+  colsum_ws_body<T>(f.M[i], f.N[i], f.rpc[i], (const T*)f.X[i], f.ld[i], f.ws[i], w % f.slabs[i], w / f.slabs[i]);
 }
 
 // out[n] = sum_c ws[c][n]: a workgroup owns 16 columns x 16 chunk-lanes (the <= 128 partial rows are 8 loads deep per
@@ -984,6 +1007,33 @@ extern "C" int sw_colsum_partial(int dtype, int M, int N, const void* X, long ld
                        workspace),
     hipLaunchKernelGGL(colsum_ws_kernel<float>, grid, dim3(256), 0, stream, M, N, rpc, (const float*)X, ld, workspace));
   SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_colsum_partial_multi(int dtype, int n, const sw_colsum_part_desc* parts, hipStream_t stream) {
+  SW_ENTER();
+  if (dtype != SW_BF16 && dtype != SW_F32) return -1;
+  const int vec = dtype == SW_BF16 ? 8 : 4;
+  for (int base = 0; base < n; base += CPART_MAX) {
+    ColsumPartMulti f = {};
+    f.n = n - base < CPART_MAX ? n - base : CPART_MAX;
+    long wgs = 0;
+    for (int i = 0; i < f.n; ++i) {
+      const sw_colsum_part_desc& q = parts[base + i];
+      if (!q.workspace || q.M <= 0 || q.N <= 0 || (q.N % vec) || (q.ld % vec) || (((uintptr_t)q.X) & 15)) return -5;
+      int slabs, chunks, rpc;
+      colsum_ws_geometry(dtype, q.M, q.N, &slabs, &chunks, &rpc);
+      f.M[i] = q.M; f.N[i] = q.N; f.rpc[i] = rpc; f.slabs[i] = slabs; f.ld[i] = q.ld; f.X[i] = q.X; f.ws[i] = q.workspace;
+      f.first_wg[i] = (int)wgs;
+      wgs += (long)slabs * chunks;
+      if (wgs > 2147483647L) return -6;
+    }
+    f.first_wg[f.n] = (int)wgs;
+    DISPATCH_T(dtype,
+      hipLaunchKernelGGL(colsum_ws_multi_kernel<unsigned short>, dim3((unsigned)wgs), dim3(256), 0, stream, f),
+      hipLaunchKernelGGL(colsum_ws_multi_kernel<float>, dim3((unsigned)wgs), dim3(256), 0, stream, f));
+    SW_CHECK_LAUNCH();
+  }
   return 0;
 }
 

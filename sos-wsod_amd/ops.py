@@ -233,6 +233,21 @@ def colsum_partial(X, M, N, workspace, ld=None):
           "sw_colsum_partial")
 
 
+def colsum_partial_multi(parts):
+    """parts: list of (X 2-D view (M, N) with unit inner stride, workspace f32) — every colsum_partial of a backward pass in ONE launch"""
+    from ._lib import ColsumPart
+    n = len(parts)
+    if n == 0:
+        return
+    arr = (ColsumPart * n)()
+    for i, (X, ws) in enumerate(parts):
+        _need_gpu(X, ws)
+        q = arr[i]
+        q.M, q.N = X.shape
+        q.X, q.ld, q.workspace = X.data_ptr(), X.stride(0), ws.data_ptr()
+    check(lib.sw_colsum_partial_multi(dt(parts[0][0]), n, arr, _stream()), "sw_colsum_partial_multi")
+
+
 def colsum_fold(workspace, n_rows, out):
     check(lib.sw_colsum_fold(out.numel(), n_rows, _p(workspace), _p(out), _stream()), "sw_colsum_fold")
     return out
