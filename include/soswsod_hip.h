@@ -135,12 +135,16 @@ int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, fl
                     void* argmax, int argmax_bits, long ld_out, sw_stream_t stream);
 /* dfeat [nimg][H][W][C] (dtype, fully overwritten) = scatter-add of dout by argmax, times the same row scale,
  * times (relu_ref > 0) when relu_ref != NULL (relu_ref has feat's layout/dtype).
- * dout_absmax (device scalar >= max|dout|, e.g. from sw_absmax or a GEMM epilogue; may be NULL): selects the
- * 64-bit fixed-point LDS accumulation (bitwise reproducible, ~3x faster than LDS float atomics); NULL => f32 atomics.
- * ld_in: row pitch (elements) of dout AND argmax, 0 = C*PH*PW. */
+ * dout_absmax (device scalar >= max|dout|, e.g. from sw_absmax or a GEMM epilogue; may be NULL): selects the fixed-point LDS
+ * accumulation (one 64-bit word per pixel-channel in f32 mode, a hi / lo pair of 32-bit words in bf16 mode: >= 25 bits per term;
+ * bitwise reproducible, ~3x faster than LDS float atomics); NULL => f32 atomics.
+ * ld_in: row pitch (elements) of dout AND argmax, 0 = C*PH*PW.
+ * spatial_scale: the forward's scale, or 0.  With it, on maps whose accumulators need several pixel ranges per plane, a
+ * workgroup streams only the ROIs whose rows reach its range (any value yields the same result; 0 streams all ROIs). */
 int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
                     const void* argmax, int argmax_bits, long ld_in, const float* rois, int R, const float* row_scale,
-                    float row_scale_add, const void* relu_ref, const float* dout_absmax, void* dfeat, sw_stream_t stream);
+                    float row_scale_add, const void* relu_ref, const float* dout_absmax, void* dfeat, float spatial_scale,
+                    sw_stream_t stream);
 /* out[0] = max |x[i]| (f32 device scalar, overwritten). */
 int sw_absmax(int dtype, long n, const void* x, float* out, sw_stream_t stream);
 

@@ -91,7 +91,7 @@ SIGNATURES = {
     "sw_roi_pool_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
                                 c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "sw_roi_pool_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_long, c_void_p, c_int,
-                                c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "sw_absmax": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "sw_wsddn_workspace_floats": (c_long, [c_int, c_int, c_int]),
     "sw_wsddn_mil": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p,

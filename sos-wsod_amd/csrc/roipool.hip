@@ -218,7 +218,8 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
                                                                const float* __restrict__ rois, int R,
                                                                const float* __restrict__ row_scale, float row_scale_add,
                                                                const float* __restrict__ dout_absmax,
-                                                               const T* __restrict__ relu_ref, T* __restrict__ dfeat) {
+                                                               const T* __restrict__ relu_ref, T* __restrict__ dfeat,
+                                                               float spatial_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[32];
   __shared__ int s_cnt;
@@ -276,6 +277,14 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_fx_kernel(int H, int W, int
     __syncthreads();
     for (int r = rc + threadIdx.x; r < min(R, rc + FX_CHUNK); r += blockDim.x)
       if ((int)rois[(long)r * 5] == img) {
+        if (gridDim.z > 1 && spatial_scale > 0.f) {
+          // large maps (several pixel ranges per plane): a workgroup lists only the ROIs whose rows can reach its range — every
+          // argmax of a ROI lies in rows [rs, max(re, rs)] (ROILoopPool_cpu.cpp:36-52) — instead of streaming the gradients of
+          // ALL ROIs of the image once per range (99x165 map, 2 x 4000 ROIs, 4 ranges: 765 -> ~400 us)
+          const int rs = (int)roundf(__fmul_rn(rois[(long)r * 5 + 2], spatial_scale));
+          const int re = max((int)roundf(__fmul_rn(rois[(long)r * 5 + 4], spatial_scale)), rs);
+          if (re < p0 / W || rs > (p1 - 1) / W) continue;
+        }
         const int k = atomicAdd(&s_cnt, 1);
         s_r[k] = r;
         s_m[k] = row_scale ? (row_scale[r] + row_scale_add) : 1.0f;
@@ -777,7 +786,7 @@ int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, long ld, int PH, 
 template <typename T, typename IT>
 int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, const void* dout, const void* argmax, const float* rois,
                      int R, const float* row_scale, float row_scale_add, const void* relu_ref, const float* dout_absmax,
-                     void* dfeat, hipStream_t stream) {
+                     void* dfeat, float spatial_scale, hipStream_t stream) {
   // fixed-point path: CB in {8, 4} with H*W*CB*8 bytes of LDS; needs max|dout| (device scalar)
   static const bool float_atomics = getenv("SW_ROI_FLOAT_ATOMICS") != nullptr;    // development switch
   // bf16: a hi/lo pair of 32-bit accumulators (see the kernel) when PH*PW*R terms (every bin of every ROI on one pixel: the worst
@@ -789,9 +798,10 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, con
   const int accmode = (!small_terms || acc64) ? 0 : (acc32_single ? 1 : 2);
   const size_t ab = accmode == 1 ? 4 : 8;
   int cbx = 8;
-  while (cbx > 4 && ((size_t)H * W * cbx * ab > 128 * 1024 || (C % cbx) || (C / cbx) * nimg < 256)) cbx >>= 1;
+  constexpr size_t ACC_BUDGET = 150 * 1024;        // of the CU's 160 KiB: + 8 KiB ROI list + the static reduction scratch
+  while (cbx > 4 && ((size_t)H * W * cbx * ab > ACC_BUDGET || (C % cbx) || (C / cbx) * nimg < 256)) cbx >>= 1;
   if (C % cbx) cbx = 0;
-  const int nsplit = cbx ? (int)(((size_t)H * W * cbx * ab + 128 * 1024 - 1) / (128 * 1024)) : 1;   // pixel ranges per plane
+  const int nsplit = cbx ? (int)(((size_t)H * W * cbx * ab + ACC_BUDGET - 1) / ACC_BUDGET) : 1;   // pixel ranges per plane
   if (cbx >= 4 && nsplit <= 16 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) && (ld % 4) == 0 &&
       !float_atomics) {
     const int px_per = (H * W + nsplit - 1) / nsplit;
@@ -804,7 +814,7 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, con
       ex = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);                          \
       if (ex != hipSuccess) return (int)ex;                                                                                     \
       hipLaunchKernelGGL(k, gridx, blockx, ldsx, stream, H, W, C, ld, PH * PW, cbx, (const T*)dout, (const IT*)argmax, rois, R, \
-                         row_scale, row_scale_add, dout_absmax, (const T*)relu_ref, (T*)dfeat);                                 \
+                         row_scale, row_scale_add, dout_absmax, (const T*)relu_ref, (T*)dfeat, spatial_scale);                  \
     }
     if (accmode == 2) SW_BWD_FX(2) else if (accmode == 1) SW_BWD_FX(1) else SW_BWD_FX(0)
 #undef SW_BWD_FX
@@ -849,14 +859,14 @@ extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH,
 extern "C" int sw_roi_pool_bwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, const void* dout,
                                const void* argmax, int argmax_bits, long ld_in, const float* rois, int R,
                                const float* row_scale, float row_scale_add, const void* relu_ref,
-                               const float* dout_absmax, void* dfeat, hipStream_t stream) {
+                               const float* dout_absmax, void* dfeat, float spatial_scale, hipStream_t stream) {
   SW_ENTER();
   const long ld = ld_in > 0 ? ld_in : (long)C * PH * PW;
   if (ld < (long)C * PH * PW) return -5;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
   if (argmax_bits != 32 && argmax_bits != 16) return -1;
 #define SW_BWD(T, IT) return roi_bwd_dispatch<T, IT>(nimg, H, W, C, ld, PH, PW, dout, argmax, rois, R, row_scale, row_scale_add, \
-                                                     relu_ref, dout_absmax, dfeat, stream)
+                                                     relu_ref, dout_absmax, dfeat, spatial_scale, stream)
   if (dtype == SW_BF16) { if (argmax_bits == 32) SW_BWD(unsigned short, int); SW_BWD(unsigned short, unsigned short); }
   if (argmax_bits == 32) SW_BWD(float, int);
   SW_BWD(float, unsigned short);

@@ -341,9 +341,9 @@ def absmax(x, out=None):
 
 
 def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_add=0.0, relu_ref=None, dout_absmax="auto",
-                 tag=None):
+                 tag=None, spatial_scale=0.0):
     """dout_absmax: device scalar >= max|dout| (selects the fixed-point accumulation), "auto" = compute it here,
-    None = LDS float atomics."""
+    None = LDS float atomics.  spatial_scale: the forward's scale (lets large maps skip ROIs outside a workgroup's pixel range)."""
     _need_gpu(dout, argmax, rois, dfeat)
     n, H, W, C = dfeat.shape
     R = rois.shape[0]
@@ -351,7 +351,8 @@ def roi_pool_bwd(dout, argmax, rois, dfeat, PH, PW, row_scale=None, row_scale_ad
         dout_absmax = absmax(dout)
     check(_launch(tag, lambda: lib.sw_roi_pool_bwd(dt(dfeat), n, H, W, C, PH, PW, _p(dout), _p(argmax), _argmax_bits(argmax),
                                                    _roi_pitch(dout, argmax), _p(rois), R, _p(row_scale), float(row_scale_add),
-                                                   _p(relu_ref), _p(dout_absmax), _p(dfeat), _stream())), "sw_roi_pool_bwd")
+                                                   _p(relu_ref), _p(dout_absmax), _p(dfeat), float(spatial_scale), _stream())),
+          "sw_roi_pool_bwd")
     return dfeat
 
 

@@ -26,14 +26,14 @@ class _RoIPoolFunction(torch.autograd.Function):
                           dtype=ops.roi_argmax_dtype(feat_nhwc.shape[1], feat_nhwc.shape[2]))
         ops.roi_pool_fwd(feat_nhwc, rois, out, arg, scale, out_size, out_size)
         ctx.save_for_backward(arg, rois)
-        ctx.shape, ctx.out_size = feat_nhwc.shape, out_size
+        ctx.shape, ctx.out_size, ctx.scale = feat_nhwc.shape, out_size, scale
         return out.view(R, C, out_size, out_size)
 
     @staticmethod
     def backward(ctx, g):
         arg, rois = ctx.saved_tensors
         dfeat = torch.empty(ctx.shape, device=g.device, dtype=g.dtype)
-        ops.roi_pool_bwd(g.contiguous().view(g.shape[0], -1), arg, rois, dfeat, ctx.out_size, ctx.out_size)
+        ops.roi_pool_bwd(g.contiguous().view(g.shape[0], -1), arg, rois, dfeat, ctx.out_size, ctx.out_size, spatial_scale=ctx.scale)
         return dfeat, None, None, None
 
 

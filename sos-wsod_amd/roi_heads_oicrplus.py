@@ -678,7 +678,7 @@ class OICRPlusHeads(nn.Module):
                     r0 = off + 2 * s * R
                     ops.roi_pool_bwd(dpooled[r0:r0 + 2 * R], st["argmax"][r0:r0 + 2 * R], inp["rois"][b][s], df, P, P,
                                      row_scale=inp["obj"][b][2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0, relu_ref=f,
-                                     dout_absmax=amax, tag="roi_bwd")
+                                     dout_absmax=amax, tag="roi_bwd", spatial_scale=self.box_pooler.scale)
                     dfeats[2 * b + s] = df
         return dfeats
 

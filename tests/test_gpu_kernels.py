@@ -327,12 +327,13 @@ def test_roi_pool_backward_heavy_tailed_gradients_bf16(ops, shape):
     ref = O.roi_pool_bwd((g * (torch.from_numpy(obj) + 1).view(-1, 1, 1, 1)).numpy(), ref_arg, rois, feat.shape)
     ref = _nhwc(torch.from_numpy(ref)).double()
     got = []
-    for _ in range(2):
+    for sc in (0.0, 0.0, 1.0 / 8):            # with the forward's scale a workgroup lists only the ROIs that reach its pixel range
         dfeat = torch.empty(n, H, W, C, device="cuda", dtype=dtype)
         ops.roi_pool_bwd(g.to(dtype).view(n * R, -1).cuda().contiguous(), arg, torch.from_numpy(rois).cuda(), dfeat, 7, 7,
-                         row_scale=torch.from_numpy(obj).cuda(), row_scale_add=1.0)
+                         row_scale=torch.from_numpy(obj).cuda(), row_scale_add=1.0, spatial_scale=sc)
         got.append(dfeat.cpu())
     assert torch.equal(got[0].view(torch.int16), got[1].view(torch.int16))   # integer accumulation: bitwise reproducible
+    assert torch.equal(got[0].view(torch.int16), got[2].view(torch.int16))   # ... and the ROI filter changes nothing
     d = got[0].double()
     rel_l2 = float((d - ref).norm() / ref.norm())
     assert rel_l2 <= 2.0 ** -8, rel_l2

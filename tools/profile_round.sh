@@ -8,7 +8,7 @@ for w in $what; do
   case $w in
     stats)
       rm -rf gpurun_out/prof_round
-      rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_round -- python bench.py --no-fp32-line --no-cpu-baseline --steps 30 --warmup 6 > gpurun_out/round_bench_under_rocprof.json 2> gpurun_out/round_prof_err.log
+      rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_round -- python bench.py --no-fp32-line --no-cpu-baseline --no-extra-shapes --steps 30 --warmup 6 > gpurun_out/round_bench_under_rocprof.json 2> gpurun_out/round_prof_err.log
       f=$(ls gpurun_out/prof_round/*/*kernel_stats.csv | head -1)
       n=$(python - <<PY
 import csv

@@ -18,6 +18,6 @@ def t(fn, n=10):
     a.record(); [fn() for _ in range(n)]; b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / n
 tf = t(lambda: ops.roi_pool_fwd(feat, rois, out, arg, 0.125, 7, 7, row_scale=obj, row_scale_add=1.0))
 amax = ops.absmax(dout)
-tb = t(lambda: ops.roi_pool_bwd(dout, arg, rois, dfeat, 7, 7, row_scale=obj, row_scale_add=1.0, relu_ref=feat, dout_absmax=amax))
+tb = t(lambda: ops.roi_pool_bwd(dout, arg, rois, dfeat, 7, 7, row_scale=obj, row_scale_add=1.0, relu_ref=feat, dout_absmax=amax, spatial_scale=0.0 if os.environ.get('NOSCALE') else 0.125))
 gb = R * C * 49 * (2 + arg.element_size()) / 1e9
 print(f"roi_pool fwd {tf*1e3:.0f} us ({gb/tf:.2f} TB/s of out+argmax)   bwd {tb*1e3:.0f} us ({gb/tb:.2f} TB/s)")
