@@ -294,7 +294,11 @@ def main():
             "roofline": roofline,
             # the other two launches of the same GEMM family (`roofline` above is the costliest of the three)
             "roofline_fc6": {t: dict({k: v for k, v in roof(t).items() if k in ("achieved", "frac", "avg_ms")},
-                                     mfma_busy_counter=(busy_of(t) or {}).get("mfma_busy_frac"))
+                                     mfma_busy_counter=(busy_of(t) or {}).get("mfma_busy_frac"),
+                                     traffic=(traffic.get(t) or {}).get("hbm_bytes_per_launch"),
+                                     algorithmic_bytes=(traffic.get(t) or {}).get("algorithmic_bytes"),
+                                     traffic_over_algorithmic=(round(traffic[t]["hbm_bytes_per_launch"] / traffic[t]["algorithmic_bytes"], 2)
+                                                               if t in traffic else None))
                              for t in ("fc6_fwd", "fc6_dgrad", "fc6_wgrad")},
             "roofline_conv5_3": dict(roof("plain5.conv3_fwd"), note="inside the step: two streams share the CUs"),
             "roofline_conv5_3_alone": {"kernel": "conv5_3 fwd, batch 2, 63x63, 512->512, dilation 2", "bound": "mfma",
