@@ -707,6 +707,46 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
   }
   __syncthreads();
   bitonic_sort<true>(keys, NP);
+  // the candidates (score > thresh) lead the sorted keys; when the unused tail of the key array can hold their boxes (n <= NP/3:
+  // the RPN's per-level lists, a class's detections), the greedy loop below reads LDS instead of global memory
+  __shared__ int s_valid;
+  if (tid == 0) s_valid = 0;
+  __syncthreads();
+  for (int i = tid; i < R; i += blockDim.x)
+    if (keys[i] != ~0ull && (i + 1 == R || keys[i + 1] == ~0ull)) s_valid = i + 1;
+  __syncthreads();
+  const int nv = s_valid;
+  if ((long)nv * 16 + 16 <= (long)(NP - nv) * 8) {
+    float4* sb = (float4*)(((uintptr_t)(keys + nv) + 15) & ~(uintptr_t)15);
+    for (int u = tid; u < nv; u += blockDim.x) {
+      const int q = (int)(keys[u] & 0xFFFFFFFFu);
+      const float* bq = boxes + (long)q * 4 * K + 4 * c;
+      sb[u] = make_float4(__fadd_rn(clipf(bq[0], imw), off), __fadd_rn(clipf(bq[1], imh), off), __fadd_rn(clipf(bq[2], imw), off),
+                          __fadd_rn(clipf(bq[3], imh), off));
+      sup[u] = 0;                                                   // here the flags go by sorted position
+    }
+    __syncthreads();
+    int nk = 0;
+    for (int t = 0; t < nv && nk < topk; ++t) {
+      if (sup[t]) continue;                                         // uniform
+      if (tid == 0) {
+        const int p = (int)(keys[t] & 0xFFFFFFFFu);
+        cls_rows[c * topk + nk] = p; cls_scores[c * topk + nk] = scores[(long)p * (K + 1) + c];
+      }
+      ++nk;
+      const float4 av = sb[t];
+      float a[4] = {av.x, av.y, av.z, av.w};
+      for (int u = t + 1 + tid; u < nv; u += blockDim.x) {
+        if (sup[u]) continue;
+        const float4 bv = sb[u];
+        float b[4] = {bv.x, bv.y, bv.z, bv.w};
+        if (iou_nms(a, b) > nms_thresh) sup[u] = 1;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) cls_count[c] = nk;
+    return;
+  }
   int nk = 0;
   for (int t = 0; t < R && nk < topk; ++t) {
     const unsigned long long key = keys[t];
