@@ -252,6 +252,22 @@ int sw_ema_multi(int n_tensors, float* const* teacher, const float* const* stude
 int sw_threshold_select(int n, const float* scores, const int32_t* classes, const float* boxes, float thres,
                         const int32_t* allowed_classes, int n_allowed, int32_t* out_count, float* out_boxes,
                         int32_t* out_classes, float* out_scores, int32_t* out_index, sw_stream_t stream);
+/* sw_stage_weights_multi: the compute-dtype copies of EVERY weight of a detector in one launch (replaces, per layer and per
+ * forward call, the reference's implicit `conv.weight` reads + FrozenBatchNorm2d.forward's scale / bias arithmetic,
+ * detectron2/layers/batch_norm.py:52-60, wrappers.py Conv2d.forward).  `descs_dev` is a DEVICE array of n entries ordered by
+ * block_start (entry i owns workgroups [block_start_i, block_start_i + sw_stage_blocks(kind, rows, cols))); total_blocks = their sum.
+ * kind 0: (rows, cols) f32 -> dst rows of pitch cols; 1: OIHW 3x3 -> [co][tap][ci]; 2: OIHW 3x3 -> [ci][8 - tap][co] (data
+ * gradient); 3: f32 copy.  rows = Cout, cols = Cin.  bn_* (all four or none): the folded weight w * scale[co] is staged and
+ * scale / shift (optional outputs, rows floats) are written: scale = bn_weight * rsqrt(bn_var + eps), shift = bn_bias - bn_mean * scale. */
+typedef struct sw_stage_desc {
+  const float* w;
+  const float* bn_weight; const float* bn_bias; const float* bn_mean; const float* bn_var;
+  float* scale; float* shift;
+  void* dst;
+  int32_t kind, rows, cols, block_start;
+} sw_stage_desc;
+int sw_stage_blocks(int kind, int rows, int cols);
+int sw_stage_weights_multi(int dtype, int n, const sw_stage_desc* descs_dev, int total_blocks, float eps, sw_stream_t stream);
 /* *counter += increment, in stream order (one thread): the dropout stream position of sw_epilogue.drop_offset_dev */
 int sw_counter_add(uint64_t* counter, uint64_t increment, sw_stream_t stream);
 /* n device-to-device byte copies in one launch (input staging into a captured step's static buffers; replaces n

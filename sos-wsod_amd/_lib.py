@@ -53,6 +53,13 @@ class ColsumPart(ctypes.Structure):
     _fields_ = [("M", c_int), ("N", c_int), ("X", c_void_p), ("ld", c_long), ("workspace", c_void_p)]
 
 
+class StageDesc(ctypes.Structure):
+    """struct sw_stage_desc"""
+    _fields_ = [("w", c_void_p), ("bn_weight", c_void_p), ("bn_bias", c_void_p), ("bn_mean", c_void_p), ("bn_var", c_void_p),
+                ("scale", c_void_p), ("shift", c_void_p), ("dst", c_void_p),
+                ("kind", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("block_start", ctypes.c_int32)]
+
+
 class ColsumFold(ctypes.Structure):
     """sw_colsum_fold_desc"""
     _fields_ = [("N", ctypes.c_int), ("n_partial_rows", ctypes.c_int), ("workspace", ctypes.c_void_p), ("out", ctypes.c_void_p)]
@@ -139,6 +146,8 @@ SIGNATURES = {
     "sw_resize_pass_u8": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_void_p]),
     "sw_transpose_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "sw_stage_blocks": (c_int, [c_int, c_int, c_int]),
+    "sw_stage_weights_multi": (c_int, [c_int, c_int, c_void_p, c_int, c_float, c_void_p]),
     "sw_ema_multi": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_long), ctypes.c_double, c_void_p]),
     "sw_threshold_select": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),

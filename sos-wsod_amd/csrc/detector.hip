@@ -342,6 +342,51 @@ __global__ void rpn_loss_fold_kernel(int nblocks, const float* __restrict__ part
 }
 constexpr int RPN_LOSS_BLOCKS = 256;
 
+// ---------------------------------------------------------------- every weight of a detector staged by ONE launch
+// entry kinds: 0 linear (rows, cols) f32 -> compute dtype rows of pitch cols; 1 conv3x3 OIHW -> [co][tap][ci]; 2 conv3x3 OIHW ->
+// [ci][8 - tap][co] (data-gradient layout); 3 f32 copy (bias pieces of packed heads).  With FrozenBN buffers the folded weight
+// w * scale[co] is staged (scale = bn_weight * rsqrt(bn_var + eps), layers/batch_norm.py:52-60; rsqrt = 1 / sqrt with both steps
+// correctly rounded, which is what the reference's CPU path computes) and scale / shift are written.
+constexpr int STAGE_CHUNK = 4096;
+template <typename T>
+__global__ __launch_bounds__(256) void stage_weights_multi_kernel(int n, const sw_stage_desc* __restrict__ descs, float eps) {
+  int lo = 0, hi = n - 1;                                     // the last entry whose block_start <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const sw_stage_desc d = descs[lo];
+  const int rows = d.rows, cols = d.cols;
+  const bool bn = d.bn_weight != nullptr;
+  const int blk = (int)blockIdx.x - d.block_start;
+  if (bn && blk == 0 && d.scale)
+    for (int r = threadIdx.x; r < rows; r += 256) {
+      const float sc = __fmul_rn(d.bn_weight[r], __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(d.bn_var[r], eps))));
+      d.scale[r] = sc;
+      if (d.shift) d.shift[r] = __fsub_rn(d.bn_bias[r], __fmul_rn(d.bn_mean[r], sc));
+    }
+  const long per = d.kind == 0 || d.kind == 3 ? (long)cols : 9L * cols;     // source elements per output channel
+  const long total = (long)rows * per;
+  const long base = (long)blk * STAGE_CHUNK;
+  for (long i = base + threadIdx.x; i < base + STAGE_CHUNK && i < total; i += 256) {
+    long src; int co;
+    if (d.kind == 0 || d.kind == 3) { src = i; co = (int)(i / cols); }
+    else if (d.kind == 1) {
+      const int ci = (int)(i % cols); const long t = i / cols;
+      const int tap = (int)(t % 9); co = (int)(t / 9);
+      src = ((long)co * cols + ci) * 9 + tap;
+    } else {
+      co = (int)(i % rows); const long t = i / rows;
+      const int tapf = (int)(t % 9); const int ci = (int)(t / 9);
+      src = ((long)co * cols + ci) * 9 + (8 - tapf);
+    }
+    float v = d.w[src];
+    if (bn) v = __fmul_rn(v, __fmul_rn(d.bn_weight[co], __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(d.bn_var[co], eps)))));
+    if (d.kind == 3) ((float*)d.dst)[i] = v;
+    else Elem<T>::store((T*)d.dst + i, v);
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
@@ -514,6 +559,22 @@ extern "C" int sw_rpn_loss(long n, long n_anchors, const float* logits, const fl
                      anchors, matched_gt_boxes, weights4[0], weights4[1], weights4[2], weights4[3], inv_norm, workspace, dlogits,
                      ddeltas);
   hipLaunchKernelGGL(rpn_loss_fold_kernel, dim3(1), dim3(64), 0, stream, blocks, (const float*)workspace, inv_norm, losses2);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_stage_blocks(int kind, int rows, int cols) {
+  const long total = (long)rows * (kind == 0 || kind == 3 ? (long)cols : 9L * cols);
+  return (int)((total + STAGE_CHUNK - 1) / STAGE_CHUNK);
+}
+
+extern "C" int sw_stage_weights_multi(int dtype, int n, const sw_stage_desc* descs_dev, int total_blocks, float eps,
+                                      hipStream_t stream) {
+  SW_ENTER();
+  if (n <= 0 || total_blocks <= 0) return 0;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(stage_weights_multi_kernel<unsigned short>, dim3(total_blocks), dim3(256), 0, stream, n, descs_dev, eps),
+             hipLaunchKernelGGL(stage_weights_multi_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, n, descs_dev, eps));
   SW_CHECK_LAUNCH();
   return 0;
 }

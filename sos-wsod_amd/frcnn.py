@@ -39,108 +39,162 @@ def _epc(dtype):
     return 8 if dtype == torch.bfloat16 else 4
 
 
-def _stage_linear(w, cd):
-    """compute-dtype copy of an (out, in) f32 weight, rows padded to a multiple of 8 (zero rows)"""
-    out_f, D = w.shape
-    ws = torch.zeros((out_f + 7) // 8 * 8, D, device=w.device, dtype=cd)
-    ops.convert_2d(w.detach().contiguous(), ws, out_f, D)
-    return ws
+def _pad8(n):
+    return (n + 7) // 8 * 8
 
 
-def _stage_conv3(w, cd):
-    """forward kernel layout [co][tap][ci] of an OIHW 3x3 weight"""
-    cout, cin = w.shape[:2]
-    wk = torch.empty(cout, 9, cin, device=w.device, dtype=cd)
-    ops.conv_weight_prep(w.detach().contiguous(), wk, 0, cin)
-    return wk
+class _Staged:
+    """what one layer reads from the model's stage plan: w (+ wd: 3x3 data-gradient layout), scale / shift (FrozenBN) or packed bias"""
+    __slots__ = ("w", "wd", "scale", "shift", "bias")
+
+    def __init__(self, w=None, wd=None, scale=None, shift=None, bias=None):
+        self.w, self.wd, self.scale, self.shift, self.bias = w, wd, scale, shift, bias
+
+
+def _staged_of(module):
+    st = module.__dict__.get("_st")
+    if st is None:
+        raise RuntimeError(f"{type(module).__name__}: no staged weights — the detector's layers run under TwoStagePseudoLabGeneralizedRCNN, "
+                           "whose forward refreshes the stage plan (sw_stage_weights_multi)")
+    return st
+
+
+class WeightStage:
+    """Compute-dtype copies of every weight of one detector, rewritten by ONE launch (ops.StagePlan / sw_stage_weights_multi) when a
+    parameter or a FrozenBN buffer changed: optimizer step (version counters / ops.PARAM_EPOCH), teacher EMA (ops.PARAM_EPOCH and
+    ops.BUFFER_EPOCH), load_state_dict.  Replaces, per layer and per forward call, the fold `weight * scale`, the dtype conversion
+    and the layout change (and their autograd nodes: the layers' backward multiplies by `scale` itself)."""
+
+    def __init__(self, model, compute_dtype):
+        self.layers = [m for m in model.modules() if hasattr(m, "_stage_entries")]
+        entries = []
+        for m in self.layers:
+            entries += m._stage_entries(compute_dtype)
+        self.plan = ops.StagePlan(entries, compute_dtype)
+        self.sources = []
+        for e in entries:
+            self.sources.append(e["w"])
+            if e.get("bn") is not None:
+                self.sources += list(e["bn"])
+        self.key = None
+
+    def valid_for(self, compute_dtype):
+        return self.plan.dtype == compute_dtype and all(e[0].data_ptr() == p for e, p in zip(self.plan._keep, self.plan.ptrs))
+
+    def refresh(self):
+        key = (ops.PARAM_EPOCH, ops.BUFFER_EPOCH, tuple(t._version for t in self.sources))
+        if key != self.key:
+            self.plan.run()
+            self.key = key
 
 
 # ====================================================================================================== autograd nodes
 class _LinearFn(torch.autograd.Function):
-    """y (P, out) = x (P, in) @ W^T (+ b) (ReLU): sw_gemm with the epilogue fused; explicit backward (dgrad, wgrad GEMMs, column
-    sums).  x compute dtype, W / b f32 masters, y compute dtype or f32 (out_f32)."""
+    """y (P, out) = x (P, in) @ W_eff^T (+ bias) (ReLU): sw_gemm with the epilogue fused; explicit backward (dgrad, wgrad GEMMs, column
+    sums).  `staged` (ld, in) is the compute-dtype copy of the effective weight (rows beyond `out` zero), written by the model's
+    stage plan; `bias` f32 or None; `scale` (out,) f32 or None = the FrozenBN fold (W_eff = W * scale: dW = scale * dW_eff).
+    `splits`: the row counts of the parameters packed into `staged`; `params`: those weight parameters in packing order, then their
+    bias parameters if they have any — autograd routes the gradient pieces to them.  y compute dtype or f32 (out_f32)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, out_f32, staged=None):
+    def forward(ctx, x, staged, bias, scale, relu, out_f32, splits, *params):
         P, D = x.shape
-        out_f = w.shape[0]
+        out_f = sum(splits)
         cd = x.dtype
-        ld = (out_f + 7) // 8 * 8
-        ws = staged if staged is not None else _stage_linear(w, cd)
+        ld = staged.shape[0]
         ydt = torch.float32 if out_f32 else cd
-        assert not (relu and out_f32)
+        assert not (relu and out_f32) and ld == (out_f + 7) // 8 * 8 and staged.dtype == cd
         ybuf = (torch.zeros if ld != out_f else torch.empty)(P, ld, device=x.device, dtype=ydt)     # columns beyond out_f stay 0
         y = ybuf[:, :out_f]
         if P > 0:
-            ops.gemm(x, ws, y, P, out_f, D, ep=ops.make_epilogue(bias=None if b is None else b.detach().contiguous(), relu=relu,
-                                                                out_dtype=ydt))
-        ctx.save_for_backward(x, ws, ybuf if relu else None)
-        ctx.has_bias, ctx.relu, ctx.out_f = b is not None, relu, out_f
+            ops.gemm(x, staged, y, P, out_f, D, ep=ops.make_epilogue(bias=bias, relu=relu, out_dtype=ydt))
+        ctx.save_for_backward(x, staged, ybuf if relu else None, scale)
+        ctx.relu, ctx.out_f, ctx.splits = relu, out_f, tuple(splits)
+        ctx.shapes = [tuple(p.shape) for p in params]
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, ws, ybuf = ctx.saved_tensors
+        x, ws, ybuf, scale = ctx.saved_tensors
         P, D = x.shape
-        out_f, ld, cd = ctx.out_f, ws.shape[0], x.dtype
-        gs = (torch.zeros if ld != out_f else torch.empty)(P, ld, device=g.device, dtype=cd)
-        if P > 0:
-            gs[:, :out_f] = g
+        out_f, ld, cd, nw = ctx.out_f, ws.shape[0], x.dtype, len(ctx.splits)
+        need = ctx.needs_input_grad
+        need_w = any(need[7:7 + nw]); need_b = any(need[7 + nw:])
+        if ld == out_f:
             if ctx.relu:
-                ops.relu_bwd(ybuf, gs)                                  # in place on the padded buffers (pad columns: 0 stays 0)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+                gs = ops.relu_bwd(ybuf, g.contiguous(), out=torch.empty(P, ld, device=g.device, dtype=cd)) if P > 0 else g.contiguous()
+            else:
+                gs = g.contiguous() if g.dtype == cd else g.to(cd)
+        else:
+            gs = torch.zeros(P, ld, device=g.device, dtype=cd)
+            if P > 0:
+                gs[:, :out_f] = g
+                if ctx.relu:
+                    ops.relu_bwd(ybuf, gs)                              # in place on the padded buffers (pad columns: 0 stays 0)
+        dx = None
+        if need[0]:
             dx = torch.empty(P, D, device=g.device, dtype=cd)
             if P > 0:
                 ops.gemm(gs, ws, dx, P, D, ld, b_kstrided=True)
             else:
                 dx.zero_()
-        if ctx.needs_input_grad[1]:
-            dwp = torch.zeros(ld, D, device=g.device, dtype=torch.float32)
+        dws, dbs = [None] * nw, [None] * (len(ctx.shapes) - nw)
+        if need_w:
+            dwp = torch.empty(ld, D, device=g.device, dtype=torch.float32)
             if P > 0:
-                Pp = (P + _epc(cd) - 1) // _epc(cd) * _epc(cd)            # K-strided operands: 16-byte row pieces
-                if Pp != P:
-                    gs = torch.cat([gs, torch.zeros(Pp - P, ld, device=g.device, dtype=cd)], 0)
-                    x = torch.cat([x, torch.zeros(Pp - P, D, device=g.device, dtype=cd)], 0)
                 # K = pixels (10^4 .. 10^5 for a 1x1 convolution), M x N = a handful of 128x128 tiles: split K so that tiles x splits
                 # fill the chip (slabs + ordered fold inside sw_gemm: deterministic); unsplit, 4 workgroups walked 60 000 pixels
                 tiles = ((ld + 127) // 128) * ((D + 127) // 128)
-                ops.gemm(gs, x, dwp, ld, D, Pp, a_kstrided=True, b_kstrided=True, splitk=max(1, min(64, 512 // tiles, Pp // 512)))
-            dw = dwp[:out_f]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbp = torch.zeros(ld, device=g.device, dtype=torch.float32)
+                ops.gemm(gs, x, dwp, ld, D, P, a_kstrided=True, b_kstrided=True, splitk=max(1, min(64, 512 // tiles, P // 512)))
+                if scale is not None:
+                    dwp[:out_f].mul_(scale[:, None])
+            else:
+                dwp.zero_()
+            r0 = 0
+            for i, n in enumerate(ctx.splits):
+                if need[7 + i]:
+                    dws[i] = dwp[r0:r0 + n].view(ctx.shapes[i])
+                r0 += n
+        if need_b:
+            dbp = torch.empty(ld, device=g.device, dtype=torch.float32)
             if P > 0:
-                ops.colsum(gs, gs.shape[0], ld, dbp)
-            db = dbp[:out_f]
-        return dx, dw, db, None, None, None
+                ops.colsum(gs, P, ld, dbp)
+            else:
+                dbp.zero_()
+            r0 = 0
+            for i, n in enumerate(ctx.splits):
+                if i < len(dbs) and need[7 + nw + i]:
+                    dbs[i] = dbp[r0:r0 + n]
+                r0 += n
+        return (dx, None, None, None, None, None, None) + tuple(dws) + tuple(dbs)
 
 
 class _Conv3x3Fn(torch.autograd.Function):
-    """3x3, stride 1, padding 1 on NHWC: sw_conv3x3_igemm (+ bias, ReLU fused); backward = weight gradient (split-K slabs,
-    ordered fold), column sums, data gradient through the flipped-weight layout."""
+    """3x3, stride 1, padding 1 on NHWC: sw_conv3x3_igemm (+ bias, ReLU fused) on the staged [co][tap][ci] copy of the effective
+    weight; backward = weight gradient (split-K slabs, ordered fold; x FrozenBN scale), column sums, data gradient through the
+    staged flipped-tap layout `staged_d` [ci][tap][co].  `w` / `b`: the parameters the gradients go to (b may be None)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, staged=None):
+    def forward(ctx, x, staged, staged_d, bias, scale, relu, w, b):
         n, H, W, cin = x.shape
         cout = w.shape[0]
         cd = x.dtype
-        wk = staged if staged is not None else _stage_conv3(w, cd)
         out = torch.empty(n, H, W, cout, device=x.device, dtype=cd)
-        ops.conv3x3(x, wk, out, 1, ops.make_epilogue(bias=None if b is None else b.detach().contiguous(), relu=relu, out_dtype=cd))
-        ctx.save_for_backward(x, w, out if relu else None)
-        ctx.relu, ctx.has_bias = relu, b is not None
+        ops.conv3x3(x, staged, out, 1, ops.make_epilogue(bias=bias, relu=relu, out_dtype=cd))
+        ctx.save_for_backward(x, staged_d, out if relu else None, scale)
+        ctx.relu, ctx.cout = relu, cout
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, w, out = ctx.saved_tensors
+        x, wkd, out, scale = ctx.saved_tensors
         n, H, W, cin = x.shape
-        cout = w.shape[0]
+        cout = ctx.cout
         cd = x.dtype
         g = g.contiguous()
         dz = ops.relu_bwd(out, g, out=torch.empty_like(g)) if ctx.relu else g
         dx = dw = db = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[6]:
             dw = torch.empty(cout, cin, 3, 3, device=g.device, dtype=torch.float32)
             npix = n * H * W
             if (64 // W) + 1 > 2 * H:
@@ -148,24 +202,20 @@ class _Conv3x3Fn(torch.autograd.Function):
                 # (sw_conv3x3_wgrad returns -6): the <= 128 pixels are unfolded into (ci, ky, kx) patch rows and the gradient is
                 # one K-strided GEMM dz^T @ patches
                 pat = torch.nn.functional.unfold(x.permute(0, 3, 1, 2), kernel_size=3, padding=1)       # (n, cin*9, H*W)
-                pat = pat.permute(0, 2, 1).reshape(npix, cin * 9)
-                e = _epc(cd)
-                Pp = (npix + e - 1) // e * e
-                A = torch.zeros(Pp, cout, device=g.device, dtype=cd); A[:npix] = dz.view(npix, cout)
-                B = torch.zeros(Pp, cin * 9, device=g.device, dtype=cd); B[:npix] = pat
-                ops.gemm(A, B, dw.view(cout, cin * 9), cout, cin * 9, Pp, a_kstrided=True, b_kstrided=True)
+                pat = pat.permute(0, 2, 1).reshape(npix, cin * 9).contiguous()
+                ops.gemm(dz.view(npix, cout), pat, dw.view(cout, cin * 9), cout, cin * 9, npix, a_kstrided=True, b_kstrided=True)
             else:
                 tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
                 ops.conv3x3_wgrad(x, dz, dw, 1, splitk=max(1, min(32, 512 // tiles, max(1, npix // 1024))))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if scale is not None:
+                dw.mul_(scale.view(-1, 1, 1, 1))
+        if ctx.needs_input_grad[7]:
             db = torch.empty(cout, device=g.device, dtype=torch.float32)
             ops.colsum(dz.view(n * H * W, cout), n * H * W, cout, db)
         if ctx.needs_input_grad[0]:
-            wkd = torch.zeros(cin, 9, cout, device=g.device, dtype=cd)
-            ops.conv_weight_prep(w.detach().contiguous(), wkd, 1)
             dx = torch.empty(n, H, W, cin, device=g.device, dtype=cd)
             ops.conv3x3(dz, wkd, dx, 1, ops.make_epilogue(out_dtype=cd))
-        return dx, dw, db, None, None
+        return dx, None, None, None, None, None, dw, db
 
 
 class _Subsample2Fn(torch.autograd.Function):
@@ -301,7 +351,7 @@ class FrozenBatchNorm2d(nn.Module):
         """(scale, shift) of y = x * scale + shift; cached: the statistics are frozen buffers (rebuilt when one of them was written,
         e.g. by load_state_dict or the teacher's EMA, which bump the tensors' version counters)"""
         key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version, self.weight.device,
-               ops.PARAM_EPOCH)            # (PARAM_EPOCH: kernels that write state behind torch's counters — HipSGD, the teacher EMA)
+               ops.BUFFER_EPOCH)           # (BUFFER_EPOCH: the teacher EMA writes the buffers behind torch's version counters)
         hit = self.__dict__.get("_fold")
         if hit is None or hit[0] != key:
             scale = self.weight * torch.rsqrt(self.running_var + 1e-5)
@@ -311,7 +361,8 @@ class FrozenBatchNorm2d(nn.Module):
 
 
 class ConvBN(nn.Module):
-    """Conv2d(bias=False, norm=FrozenBN) of the reference: parameter `weight` (OIHW) + submodule `norm`"""
+    """Conv2d(bias=False, norm=FrozenBN) of the reference: parameter `weight` (OIHW) + submodule `norm`.  The FrozenBN fold lives in
+    the staged weight (W * scale) and the epilogue bias (shift); d/dweight = scale * d/dW_eff in the layer's backward."""
 
     def __init__(self, cin, cout, k, stride=1):
         super().__init__()
@@ -320,45 +371,84 @@ class ConvBN(nn.Module):
         self.norm = FrozenBatchNorm2d(cout)
         self.k, self.stride = k, stride
 
-    def forward(self, x, relu):
-        scale, shift = self.norm.fold()
-        staged = None
-        if not (torch.is_grad_enabled() and self.weight.requires_grad):
-            # no gradient will be asked of this layer (frozen stem / res2, the teacher's passes): folded + staged weights are kept
-            # until the parameter or the statistics change
-            key = (ops.param_key(self.weight), id(scale), x.dtype)
-            hit = self.__dict__.get("_staged")
-            if hit is None or hit[0] != key:
-                w = (self.weight.detach() * scale.view(-1, 1, 1, 1))
-                st = _stage_conv3(w, x.dtype) if self.k == 3 else _stage_linear(w.view(w.shape[0], -1), x.dtype)
-                hit = (key, w, st)
-                self.__dict__["_staged"] = hit
-            w, staged = hit[1], hit[2]
-        else:
-            w = self.weight * scale.view(-1, 1, 1, 1)             # the FrozenBN fold: d/dweight = scale * d/dw_eff through autograd
+    def _stage_entries(self, cd):
+        if self.k == 7:
+            return []                                               # the stem kernel reads the f32 weight and the fold directly
+        cout, cin = self.weight.shape[:2]
+        dev = self.weight.device
+        n = self.norm
+        bn = (n.weight, n.bias, n.running_mean, n.running_var)
+        st = _Staged(scale=torch.empty(cout, device=dev), shift=torch.empty(cout, device=dev))
         if self.k == 3:
-            return _Conv3x3Fn.apply(x, w, shift, relu, staged)
+            st.w = torch.empty(cout, 9, cin, device=dev, dtype=cd)
+            ent = [dict(kind=1, w=self.weight, dst=st.w, bn=bn, scale=st.scale, shift=st.shift)]
+            if self.weight.requires_grad:
+                st.wd = torch.empty(cin, 9, cout, device=dev, dtype=cd)
+                ent.append(dict(kind=2, w=self.weight, dst=st.wd, bn=bn))
+        else:
+            st.w = torch.zeros(_pad8(cout), cin, device=dev, dtype=cd)
+            ent = [dict(kind=0, w=self.weight, dst=st.w, bn=bn, scale=st.scale, shift=st.shift)]
+        self.__dict__["_st"] = st
+        return ent
+
+    def forward(self, x, relu):
+        st = _staged_of(self)
+        if self.k == 3:
+            return _Conv3x3Fn.apply(x, st.w, st.wd, st.shift, st.scale, relu, self.weight, None)
         if self.stride == 2:
             x = _Subsample2Fn.apply(x)
         n, H, W, C = x.shape
-        y = _LinearFn.apply(x.reshape(n * H * W, C), w.view(w.shape[0], C), shift, relu, False, staged)
-        return y.reshape(n, H, W, w.shape[0])
+        cout = self.weight.shape[0]
+        y = _LinearFn.apply(x.reshape(n * H * W, C), st.w, st.shift, st.scale, relu, False, (cout,), self.weight)
+        return y.reshape(n, H, W, cout)
 
 
 class Conv(nn.Module):
-    """plain Conv2d with bias (FPN laterals / outputs, RPN head)"""
+    """plain Conv2d with bias (FPN laterals / outputs, RPN head).  packed=True: staged by the owner as part of a packed GEMM."""
 
-    def __init__(self, cin, cout, k):
+    def __init__(self, cin, cout, k, packed=False):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k)); self.bias = nn.Parameter(torch.zeros(cout))
         nn.init.kaiming_uniform_(self.weight, a=1)
-        self.k = k
+        self.k, self.packed = k, packed
+
+    def _stage_entries(self, cd):
+        if self.packed:
+            return []
+        cout, cin = self.weight.shape[:2]
+        dev = self.weight.device
+        st = _Staged()
+        if self.k == 3:
+            st.w = torch.empty(cout, 9, cin, device=dev, dtype=cd); st.wd = torch.empty(cin, 9, cout, device=dev, dtype=cd)
+            ent = [dict(kind=1, w=self.weight, dst=st.w), dict(kind=2, w=self.weight, dst=st.wd)]
+        else:
+            st.w = torch.zeros(_pad8(cout), cin, device=dev, dtype=cd)
+            ent = [dict(kind=0, w=self.weight, dst=st.w)]
+        self.__dict__["_st"] = st
+        return ent
 
     def forward(self, x, relu=False):
+        st = _staged_of(self)
         if self.k == 3:
-            return _Conv3x3Fn.apply(x, self.weight, self.bias, relu)
+            return _Conv3x3Fn.apply(x, st.w, st.wd, self.bias.detach(), None, relu, self.weight, self.bias)
         n, H, W, C = x.shape
-        return _LinearFn.apply(x.reshape(n * H * W, C), self.weight.view(-1, C), self.bias, relu, False).reshape(n, H, W, -1)
+        cout = self.weight.shape[0]
+        y = _LinearFn.apply(x.reshape(n * H * W, C), st.w, self.bias.detach(), None, relu, False, (cout,), self.weight, self.bias)
+        return y.reshape(n, H, W, cout)
+
+
+def _packed_linear_entries(weights, biases, cd):
+    """stage entries of several (out_i, in) weights stacked into one (pad8(sum out_i), in) GEMM operand + their biases in one f32 row"""
+    rows = [w.shape[0] for w in weights]
+    cin = weights[0].numel() // rows[0]
+    dev = weights[0].device
+    st = _Staged(w=torch.zeros(_pad8(sum(rows)), cin, device=dev, dtype=cd), bias=torch.zeros(_pad8(sum(rows)), device=dev))
+    ent, r0 = [], 0
+    for w, b, n in zip(weights, biases, rows):
+        ent.append(dict(kind=0, w=w, dst=st.w[r0:r0 + n]))
+        ent.append(dict(kind=3, w=b, dst=st.bias[r0:r0 + n]))
+        r0 += n
+    return st, ent
 
 
 class BottleneckBlock(nn.Module):
@@ -447,23 +537,33 @@ class StandardRPNHead(nn.Module):
     def __init__(self, num_anchors=3):
         super().__init__()
         self.conv = Conv(256, 256, 3)
-        self.objectness_logits = Conv(256, num_anchors, 1); self.anchor_deltas = Conv(256, 4 * num_anchors, 1)
+        self.objectness_logits = Conv(256, num_anchors, 1, packed=True); self.anchor_deltas = Conv(256, 4 * num_anchors, 1, packed=True)
         for m in (self.conv, self.objectness_logits, self.anchor_deltas):
             nn.init.normal_(m.weight, std=0.01)
         self.A = num_anchors
 
+    def _stage_entries(self, cd):
+        st, ent = _packed_linear_entries([self.objectness_logits.weight, self.anchor_deltas.weight],
+                                         [self.objectness_logits.bias, self.anchor_deltas.bias], cd)
+        self.__dict__["_st"] = st
+        return ent
+
     def forward(self, feats):
-        """-> per level logits (N, Hi*Wi*A) f32, deltas (N, Hi*Wi*A, 4) f32: the two 1x1 convolutions as ONE GEMM of 5A (+ pad) columns"""
+        """-> per level logits (N, Hi*Wi*A) f32, deltas (N, Hi*Wi*A, 4) f32: the two 1x1 convolutions of ALL levels as ONE GEMM of 5A
+        (+ pad) columns over the concatenated pixels"""
         A = self.A
-        w = torch.cat([self.objectness_logits.weight.view(A, -1), self.anchor_deltas.weight.view(4 * A, -1)], 0)
-        b = torch.cat([self.objectness_logits.bias, self.anchor_deltas.bias], 0)
-        logits, deltas = [], []
-        for f in feats:
-            t = self.conv(f, relu=True)
-            n, H, W, C = t.shape
-            y = _LinearFn.apply(t.reshape(n * H * W, C), w, b, False, True)              # (P, 5A) f32, channel = [a | a*4 + b]
-            logits.append(y[:, :A].reshape(n, H * W * A))
-            deltas.append(y[:, A:].reshape(n, H * W * A, 4))
+        st = _staged_of(self)
+        ts = [self.conv(f, relu=True) for f in feats]
+        C = ts[0].shape[3]
+        rows = [t.shape[0] * t.shape[1] * t.shape[2] for t in ts]
+        y = _LinearFn.apply(torch.cat([t.reshape(r, C) for t, r in zip(ts, rows)], 0), st.w, st.bias, None, False, True, (A, 4 * A),
+                            self.objectness_logits.weight, self.anchor_deltas.weight, self.objectness_logits.bias, self.anchor_deltas.bias)
+        logits, deltas, r0 = [], [], 0
+        for t, r in zip(ts, rows):                                   # channel = [a | a*4 + b]
+            n, H, W, _ = t.shape
+            logits.append(y[r0:r0 + r, :A].reshape(n, H * W * A))
+            deltas.append(y[r0:r0 + r, A:].reshape(n, H * W * A, 4))
+            r0 += r
         return logits, deltas
 
 
@@ -624,9 +724,20 @@ class FastRCNNConvFCHead(nn.Module):
         for m in (self.fc1, self.fc2):
             nn.init.kaiming_uniform_(m.weight, a=1); nn.init.constant_(m.bias, 0)
 
+    def _stage_entries(self, cd):
+        st = []
+        ent = []
+        for m in (self.fc1, self.fc2):
+            o, i = m.weight.shape
+            st.append(_Staged(w=torch.zeros(_pad8(o), i, device=m.weight.device, dtype=cd)))
+            ent.append(dict(kind=0, w=m.weight, dst=st[-1].w))
+        self.__dict__["_st"] = st
+        return ent
+
     def forward(self, x):
-        x = _LinearFn.apply(x, self.fc1.weight, self.fc1.bias, True, False)
-        return _LinearFn.apply(x, self.fc2.weight, self.fc2.bias, True, False)
+        s1, s2 = _staged_of(self)
+        x = _LinearFn.apply(x, s1.w, self.fc1.bias.detach(), None, True, False, (self.fc1.out_features,), self.fc1.weight, self.fc1.bias)
+        return _LinearFn.apply(x, s2.w, self.fc2.bias.detach(), None, True, False, (self.fc2.out_features,), self.fc2.weight, self.fc2.bias)
 
 
 class FastRCNNFocaltLossOutputLayers(nn.Module):
@@ -641,10 +752,17 @@ class FastRCNNFocaltLossOutputLayers(nn.Module):
         self.bbox_weights = (10.0, 10.0, 5.0, 5.0)
         self.test_score_thresh, self.test_nms_thresh, self.test_topk_per_image = test_score_thresh, test_nms_thresh, test_topk_per_image
 
+    def _stage_entries(self, cd):
+        st, ent = _packed_linear_entries([self.cls_score.weight, self.bbox_pred.weight], [self.cls_score.bias, self.bbox_pred.bias], cd)
+        self.__dict__["_st"] = st
+        return ent
+
     def forward(self, x):
         """-> packed f32 logits (R, 5K+1) = [cls_score | bbox_pred]: one GEMM"""
-        w = torch.cat([self.cls_score.weight, self.bbox_pred.weight], 0); b = torch.cat([self.cls_score.bias, self.bbox_pred.bias], 0)
-        return _LinearFn.apply(x, w, b, False, True)
+        st = _staged_of(self)
+        K = self.num_classes
+        return _LinearFn.apply(x, st.w, st.bias, None, False, True, (K + 1, 4 * K), self.cls_score.weight, self.bbox_pred.weight,
+                               self.cls_score.bias, self.bbox_pred.bias)
 
 
 class StandardROIHeadsPseudoLab(nn.Module):
@@ -760,6 +878,13 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
         self.compute_dtype = compute_dtype
         self.sampler = sampler
 
+    def refresh_staged_weights(self):
+        """the layers' compute-dtype weight copies follow the parameters: one launch when anything changed since the last call"""
+        ws = self.__dict__.get("_weight_stage")
+        if ws is None or not ws.valid_for(self.compute_dtype):
+            ws = self.__dict__["_weight_stage"] = WeightStage(self, self.compute_dtype)
+        ws.refresh()
+
     @property
     def device(self):
         return self.pixel_mean.device
@@ -779,6 +904,7 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
     def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False):
         if (not self.training) and (not val_mode):
             return self.inference(batched_inputs)
+        self.refresh_staged_weights()
         x4, sizes = self.preprocess_image(batched_inputs)
         gt = [x["instances"] for x in batched_inputs] if "instances" in batched_inputs[0] else None
         feats = self.backbone(x4)
@@ -800,6 +926,7 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
 
     @torch.no_grad()
     def inference(self, batched_inputs):
+        self.refresh_staged_weights()
         x4, sizes = self.preprocess_image(batched_inputs)
         feats = self.backbone(x4)
         proposals, _ = self.proposal_generator(sizes, feats, None, compute_loss=False)

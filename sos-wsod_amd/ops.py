@@ -59,6 +59,7 @@ class KernelTimer:
 
 TIMER = None
 PARAM_EPOCH = 0        # bumped by HipSGD.step (the kernel updates parameters behind torch's version counter)
+BUFFER_EPOCH = 0       # bumped by kernels that write module BUFFERS behind torch's version counters (the Stage-3 teacher EMA)
 
 
 def param_key(p):
@@ -510,6 +511,51 @@ def transpose_2d(src, dst, rows, cols):
     _need_gpu(src, dst)
     check(lib.sw_transpose_2d(dt(src), rows, cols, _p(src), src.stride(0), _p(dst), dst.stride(0), _stream()), "sw_transpose_2d")
     return dst
+
+
+class StagePlan:
+    """The device-resident entry table of sw_stage_weights_multi for one model and compute dtype: built once (the tensors it points
+    at must stay where they are: parameters / buffers are updated in place, the destinations are owned by the plan's entries),
+    run() = one launch.  entries: dicts(kind, w, dst, bn=None | (weight, bias, mean, var), scale=None, shift=None)."""
+
+    def __init__(self, entries, compute_dtype, eps=1e-5):
+        from ._lib import StageDesc
+        n = len(entries)
+        arr = (StageDesc * max(n, 1))()
+        blocks = 0
+        keep = []
+        for i, e in enumerate(entries):
+            w = e["w"]
+            _need_gpu(w, e["dst"])
+            if w.dtype != torch.float32 or not w.is_contiguous() or not e["dst"].is_contiguous():
+                raise TypeError("stage plan takes contiguous float32 sources and contiguous destinations")
+            kind = int(e["kind"])
+            rows, cols = (w.shape[0], w.numel() // w.shape[0]) if kind in (0, 3) else (w.shape[0], w.shape[1])
+            want = torch.float32 if kind == 3 else compute_dtype
+            if e["dst"].dtype != want or e["dst"].numel() < w.numel():
+                raise TypeError("stage plan destination has the wrong dtype or size")
+            d = arr[i]
+            d.w, d.dst, d.kind, d.rows, d.cols, d.block_start = w.data_ptr(), e["dst"].data_ptr(), kind, rows, cols, blocks
+            bn = e.get("bn")
+            if bn is not None:
+                for t in bn:
+                    if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != rows:
+                        raise TypeError("FrozenBN buffers must be contiguous float32 of Cout elements")
+                d.bn_weight, d.bn_bias, d.bn_mean, d.bn_var = (t.data_ptr() for t in bn)
+                d.scale = None if e.get("scale") is None else e["scale"].data_ptr()
+                d.shift = None if e.get("shift") is None else e["shift"].data_ptr()
+            blocks += int(lib.sw_stage_blocks(kind, rows, cols))
+            keep.append((w, e["dst"], bn, e.get("scale"), e.get("shift")))
+        self.n, self.blocks, self.eps, self.dtype = n, blocks, float(eps), compute_dtype
+        self._keep = keep
+        self.ptrs = tuple(w.data_ptr() for w, *_ in keep)
+        raw = bytes(arr) if n else b""
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(entries[0]["w"].device) if n else None
+
+    def run(self):
+        if self.n:
+            check(lib.sw_stage_weights_multi(dt(self.dtype), self.n, self.table.data_ptr(), self.blocks, self.eps, _stream()),
+                  "sw_stage_weights_multi")
 
 
 def ema_multi(teacher, student, keep_rate):
