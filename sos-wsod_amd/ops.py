@@ -558,20 +558,30 @@ class StagePlan:
                   "sw_stage_weights_multi")
 
 
+class EmaPlan:
+    """the host-side argument arrays of sw_ema_multi for fixed lists of tensors (built once: ~600 state-dict entries of a detector)"""
+
+    def __init__(self, teacher, student):
+        n = len(teacher)
+        assert n == len(student)
+        for t, s_ in zip(teacher, student):
+            _need_gpu(t, s_)
+            if t.dtype != torch.float32 or s_.dtype != torch.float32 or not t.is_contiguous() or not s_.is_contiguous() or t.numel() != s_.numel():
+                raise TypeError("ema_multi takes matching contiguous float32 tensors")
+        self.n = n
+        self.tp = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in teacher])
+        self.sp = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in student])
+        self.ne = (ctypes.c_long * max(n, 1))(*[t.numel() for t in teacher])
+        self._keep = (list(teacher), list(student))
+
+    def run(self, keep_rate):
+        if self.n:
+            check(lib.sw_ema_multi(self.n, self.tp, self.sp, self.ne, float(keep_rate), _stream()), "sw_ema_multi")
+
+
 def ema_multi(teacher, student, keep_rate):
     """teacher[i] <- student[i] * (1 - keep_rate) + teacher[i] * keep_rate over lists of contiguous f32 tensors (sw_ema_multi)"""
-    n = len(teacher)
-    assert n == len(student)
-    if n == 0:
-        return
-    for t, s_ in zip(teacher, student):
-        _need_gpu(t, s_)
-        if t.dtype != torch.float32 or s_.dtype != torch.float32 or not t.is_contiguous() or not s_.is_contiguous() or t.numel() != s_.numel():
-            raise TypeError("ema_multi takes matching contiguous float32 tensors")
-    tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in teacher])
-    sp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in student])
-    ne = (ctypes.c_long * n)(*[t.numel() for t in teacher])
-    check(lib.sw_ema_multi(n, tp, sp, ne, float(keep_rate), _stream()), "sw_ema_multi")
+    EmaPlan(teacher, student).run(keep_rate)
 
 
 def threshold_select(scores, classes, boxes, thres, allowed=None):

@@ -18,24 +18,36 @@ from . import ops
 from .structures import Boxes, Instances
 
 
+def _storage_ptrs(m):
+    return tuple(t.data_ptr() for t in m.parameters()) + tuple(t.data_ptr() for t in m.buffers())
+
+
 @torch.no_grad()
 def update_teacher_model(student: torch.nn.Module, teacher: torch.nn.Module, keep_rate: float = 0.996):
     """trainer.py:588-604.  Every float32 entry of the state dicts in one fused pass; other dtypes (integer buffers such as
     BatchNorm's num_batches_tracked, which the reference blends in floating point and load_state_dict casts back) are blended
-    the reference's way with torch ops."""
+    the reference's way with torch ops.  The pairing of the two state dicts (two ~600-entry dict builds, 11 ms of host time on the
+    ResNet-50-FPN detector) is kept between calls for as long as both models' tensors stay where they are."""
     if isinstance(student, torch.nn.parallel.DistributedDataParallel):
         student = student.module
-    sd_s, sd_t = student.state_dict(), teacher.state_dict()
-    fused_t, fused_s = [], []
-    for k, v in sd_t.items():
-        if k not in sd_s:
-            raise Exception("{} is not found in student model".format(k))
-        s = sd_s[k]
-        if v.is_cuda and v.dtype == torch.float32 and s.dtype == torch.float32 and v.is_contiguous() and s.is_contiguous():
-            fused_t.append(v); fused_s.append(s)
-        else:
-            v.copy_(s * (1 - keep_rate) + v * keep_rate)
-    ops.ema_multi(fused_t, fused_s, keep_rate)
+    ptrs = (_storage_ptrs(student), _storage_ptrs(teacher))
+    hit = teacher.__dict__.get("_ema_plan")
+    if hit is None or hit[0] is not student or hit[1] != ptrs:
+        sd_s, sd_t = student.state_dict(), teacher.state_dict()
+        fused_t, fused_s, rest = [], [], []
+        for k, v in sd_t.items():
+            if k not in sd_s:
+                raise Exception("{} is not found in student model".format(k))
+            s = sd_s[k]
+            if v.is_cuda and v.dtype == torch.float32 and s.dtype == torch.float32 and v.is_contiguous() and s.is_contiguous():
+                fused_t.append(v); fused_s.append(s)
+            else:
+                rest.append((v, s))
+        hit = (student, ptrs, ops.EmaPlan(fused_t, fused_s), rest)
+        teacher.__dict__["_ema_plan"] = hit
+    for v, s in hit[3]:
+        v.copy_(s * (1 - keep_rate) + v * keep_rate)
+    hit[2].run(keep_rate)
     ops.PARAM_EPOCH += 1; ops.BUFFER_EPOCH += 1       # the kernel wrote the teacher's state behind torch's version counters: cached copies are stale
 
 
