@@ -687,7 +687,13 @@ __global__ void det_maxcoord_kernel(int R, int K, float thresh, float imw, float
 }
 
 // one workgroup per class: score filter, sort (score desc, proposal asc), greedy NMS on the class-offset boxes exactly as
-// torchvision batched_nms forms them (box + class * (max_coord + 1)), keep the first `topk` (fast_rcnn_oicr.py:124-140)
+// torchvision batched_nms forms them (box + class * (max_coord + 1)), keep the first `topk` (fast_rcnn_oicr.py:124-140).
+// The candidates (score > thresh) are compacted before the sort (a class's candidates are a fraction of the R rows: the sort runs on
+// next_pow2(candidates) keys, not next_pow2(R)).  When the unused tail of the key array can hold their boxes (n <= NP/3: the RPN's
+// per-level lists, a class's detections) the suppression runs on LDS boxes in chunks of 64 sorted candidates: the 64 x 64 IoU matrix
+// of a chunk by ballots (wave w: rows 4w .. 4w+3), one wave resolves the chunk serially on 64-bit masks, then every thread tests
+// its later candidates against the chunk's kept boxes — the same keep set as the one-box-at-a-time greedy loop (a candidate falls
+// iff an earlier KEPT box overlaps it), in nv/64 rounds instead of one round per kept box.
 __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float thresh, float nms_thresh, int topk,
                                                              float imw, float imh, const float* __restrict__ scores,
                                                              const float* __restrict__ boxes,
@@ -695,27 +701,31 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
                                                              int* __restrict__ cls_count, int* __restrict__ cls_rows,
                                                              float* __restrict__ cls_scores) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int c = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NP = next_pow2(R);
   unsigned long long* keys = (unsigned long long*)smem;           // [NP]
   unsigned char* sup = (unsigned char*)(smem + (size_t)NP * 8);     // [R]
+  __shared__ int s_valid, s_nk;
+  __shared__ unsigned long long s_row[64], s_kept;
   const float off = __fmul_rn((float)c, __fadd_rn(maxcoord[0], 1.0f));
-  for (int i = tid; i < NP; i += blockDim.x) {
+  if (tid == 0) { s_valid = 0; s_nk = 0; }
+  __syncthreads();
+  for (int i0 = 0; i0 < R; i0 += blockDim.x) {                      // compaction (any order: the keys are unique, the sort orders them)
+    const int i = i0 + tid;
     const bool ok = i < R && scores[(long)i * (K + 1) + c] > thresh;
-    keys[i] = ok ? make_key(scores[(long)i * (K + 1) + c], (unsigned)i) : ~0ull;
+    const unsigned long long m = __ballot(ok);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&s_valid, __popcll(m));
+    base = __shfl(base, 0);
+    if (ok) keys[base + __popcll(m & ((1ull << lane) - 1))] = make_key(scores[(long)i * (K + 1) + c], (unsigned)i);
     if (i < R) sup[i] = 0;
   }
   __syncthreads();
-  bitonic_sort<true>(keys, NP);
-  // the candidates (score > thresh) lead the sorted keys; when the unused tail of the key array can hold their boxes (n <= NP/3:
-  // the RPN's per-level lists, a class's detections), the greedy loop below reads LDS instead of global memory
-  __shared__ int s_valid;
-  if (tid == 0) s_valid = 0;
-  __syncthreads();
-  for (int i = tid; i < R; i += blockDim.x)
-    if (keys[i] != ~0ull && (i + 1 == R || keys[i + 1] == ~0ull)) s_valid = i + 1;
-  __syncthreads();
   const int nv = s_valid;
+  const int NPV = next_pow2(nv);
+  for (int i = nv + tid; i < NPV; i += blockDim.x) keys[i] = ~0ull;
+  __syncthreads();
+  bitonic_sort<true>(keys, NPV);
   if ((long)nv * 16 + 16 <= (long)(NP - nv) * 8) {
     float4* sb = (float4*)(((uintptr_t)(keys + nv) + 15) & ~(uintptr_t)15);
     for (int u = tid; u < nv; u += blockDim.x) {
@@ -726,42 +736,67 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
       sup[u] = 0;                                                   // here the flags go by sorted position
     }
     __syncthreads();
-    int nk = 0;
-    for (int t = 0; t < nv && nk < topk; ++t) {
-      if (sup[t]) continue;                                         // uniform
-      if (tid == 0) {
-        const int p = (int)(keys[t] & 0xFFFFFFFFu);
-        cls_rows[c * topk + nk] = p; cls_scores[c * topk + nk] = scores[(long)p * (K + 1) + c];
-      }
-      ++nk;
-      const float4 av = sb[t];
-      float a[4] = {av.x, av.y, av.z, av.w};
-      for (int u = t + 1 + tid; u < nv; u += blockDim.x) {
-        if (sup[u]) continue;
-        const float4 bv = sb[u];
+    for (int c0 = 0; c0 < nv; c0 += 64) {
+      if (s_nk >= topk) break;                                      // uniform (s_nk is written before the barriers below)
+      const int cn = min(64, nv - c0);
+      // chunk matrix: bit j of s_row[i] = IoU(box c0+i, box c0+j) > nms_thresh
+      {
+        const bool in = lane < cn;
+        const float4 bv = sb[c0 + (in ? lane : 0)];
         float b[4] = {bv.x, bv.y, bv.z, bv.w};
-        if (iou_nms(a, b) > nms_thresh) sup[u] = 1;
+        for (int r = 0; r < 4; ++r) {
+          const int i = wave * 4 + r;
+          if (i < cn) {                                             // wave-uniform
+            const float4 av = sb[c0 + i];
+            float a[4] = {av.x, av.y, av.z, av.w};
+            const unsigned long long m = __ballot(in && lane > i && iou_nms(a, b) > nms_thresh);
+            if (lane == 0) s_row[i] = m;
+          }
+        }
       }
       __syncthreads();
+      if (wave == 0) {
+        unsigned long long alive = __ballot(lane < cn && !sup[c0 + lane]);
+        unsigned long long kept = 0;
+        int nk = s_nk;
+        for (int i = 0; i < cn && nk < topk; ++i)
+          if ((alive >> i) & 1ull) { kept |= 1ull << i; alive &= ~s_row[i]; ++nk; }
+        if ((kept >> lane) & 1ull) {
+          const int o = s_nk + __popcll(kept & ((1ull << lane) - 1));
+          const int p = (int)(keys[c0 + lane] & 0xFFFFFFFFu);
+          cls_rows[c * topk + o] = p; cls_scores[c * topk + o] = scores[(long)p * (K + 1) + c];
+        }
+        if (lane == 0) { s_kept = kept; s_nk = nk; }
+      }
+      __syncthreads();
+      const unsigned long long kept = s_kept;
+      if (kept && s_nk < topk)
+        for (int u = c0 + 64 + tid; u < nv; u += blockDim.x) {
+          if (sup[u]) continue;
+          const float4 bv = sb[u];
+          float b[4] = {bv.x, bv.y, bv.z, bv.w};
+          for (unsigned long long m = kept; m; m &= m - 1) {
+            const float4 av = sb[c0 + __builtin_ctzll(m)];
+            float a[4] = {av.x, av.y, av.z, av.w};
+            if (iou_nms(a, b) > nms_thresh) { sup[u] = 1; break; }
+          }
+        }
+      __syncthreads();
     }
-    if (tid == 0) cls_count[c] = nk;
+    if (tid == 0) cls_count[c] = s_nk;
     return;
   }
   int nk = 0;
-  for (int t = 0; t < R && nk < topk; ++t) {
-    const unsigned long long key = keys[t];
-    if (key == ~0ull) break;                                        // uniform
-    const int p = (int)(key & 0xFFFFFFFFu);
+  for (int t = 0; t < nv && nk < topk; ++t) {
+    const int p = (int)(keys[t] & 0xFFFFFFFFu);
     if (sup[p]) continue;
     if (tid == 0) { cls_rows[c * topk + nk] = p; cls_scores[c * topk + nk] = scores[(long)p * (K + 1) + c]; }
     ++nk;
     const float* bp = boxes + (long)p * 4 * K + 4 * c;
     float a[4] = {__fadd_rn(clipf(bp[0], imw), off), __fadd_rn(clipf(bp[1], imh), off), __fadd_rn(clipf(bp[2], imw), off),
                   __fadd_rn(clipf(bp[3], imh), off)};
-    for (int u = t + 1 + tid; u < R; u += blockDim.x) {
-      const unsigned long long ku = keys[u];
-      if (ku == ~0ull) continue;
-      const int q = (int)(ku & 0xFFFFFFFFu);
+    for (int u = t + 1 + tid; u < nv; u += blockDim.x) {
+      const int q = (int)(keys[u] & 0xFFFFFFFFu);
       if (sup[q]) continue;
       const float* bq = boxes + (long)q * 4 * K + 4 * c;
       float b[4] = {__fadd_rn(clipf(bq[0], imw), off), __fadd_rn(clipf(bq[1], imh), off), __fadd_rn(clipf(bq[2], imw), off),
