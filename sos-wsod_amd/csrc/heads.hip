@@ -759,8 +759,14 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
         unsigned long long alive = __ballot(lane < cn && !sup[c0 + lane]);
         unsigned long long kept = 0;
         int nk = s_nk;
+        const unsigned long long myrow = lane < cn ? s_row[lane] : 0ull;       // row i lives in lane i: the serial walk reads registers
+        const int row_lo = (int)(unsigned int)myrow, row_hi = (int)(unsigned int)(myrow >> 32);
         for (int i = 0; i < cn && nk < topk; ++i)
-          if ((alive >> i) & 1ull) { kept |= 1ull << i; alive &= ~s_row[i]; ++nk; }
+          if ((alive >> i) & 1ull) {
+            const unsigned long long ri = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(row_lo, i) |
+                                          ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(row_hi, i) << 32);
+            kept |= 1ull << i; alive &= ~ri; ++nk;
+          }
         if ((kept >> lane) & 1ull) {
           const int o = s_nk + __popcll(kept & ((1ull << lane) - 1));
           const int p = (int)(keys[c0 + lane] & 0xFFFFFFFFu);

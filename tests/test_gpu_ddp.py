@@ -83,3 +83,18 @@ def test_bench_launches_its_own_ranks():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp2"
+
+
+def test_stage3_semisup_step_two_ranks(tmp_path):
+    """the Unbiased-Teacher iteration with the student detector inside DistributedDataParallel (two student forward passes, one
+    backward): all-reduced gradients == the mean of the ranks' single-process gradients, student and EMA teacher identical across ranks"""
+    out = str(tmp_path / "s3ddp")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_stage3_worker.py"), out]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    for rank in range(2):
+        res = torch.load(f"{out}.rank{rank}")
+        assert res["n_grads"] >= 60 and max(res["grad_err"]) <= 1e-6, max(res["grad_err"])
+        assert res["same_across_ranks"] and res["finite"]
+        assert any(k.endswith("_pseudo") for k in res["losses"])
