@@ -131,7 +131,7 @@ def main():
                     help="images (4-view sets) per GPU per step; BASELINE config #3 = --gpus 8 --images-per-gpu 2")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the short fp32 timing (extra key fp32_ms_per_step)")
     ap.add_argument("--no-extra-shapes", action="store_true",
-                    help="skip the short runs of config #3's / #4's per-GPU shapes (extra keys b2_ms_per_step, coco_ms_per_step)")
+                    help="skip the short runs of config #3's / #4's / #5's per-GPU shapes (extra keys b2_ms_per_step, coco_ms_per_step, stage3_ms_per_iter)")
     ap.add_argument("--graph", type=int, default=None,
                     help="1: replay the step as a captured hipGraph (default for --gpus 1), 0: eager launches (default under DDP)")
     args = ap.parse_args()
@@ -366,6 +366,15 @@ def main():
             out["extra_shapes"] = {"b2": "BASELINE configs[2] per GPU: 2 images = 8 views 512x512, R=2000, K=20",
                                    "coco": "BASELINE configs[3] per GPU: 4 views 800x1333 (99x165 maps), R=4000, K=80, FREEZE_AT 3"}
             del mc
+            torch.cuda.empty_cache()
+            # BASELINE configs[4] (Stage 3, Unbiased Teacher): one GPU's share of an iteration — teacher forward on 1 view, student
+            # forward + backward on 3, SGD, teacher EMA — on the ResNet-50-FPN detector of sos-wsod_amd/frcnn.py
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            import stage3_step
+            ms, _ = stage3_step.time_step(torch.bfloat16, 800, 1216, dev=device, warm=3, n=6)
+            out["stage3_ms_per_iter"] = round(ms, 2)
+            out["extra_shapes"]["stage3"] = ("BASELINE configs[4] per GPU: 1 labelled + 1 unlabelled image, strong + weak view each (800x1216), "
+                                             "R50-FPN Faster R-CNN student / EMA teacher, K=20")
             torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
