@@ -772,3 +772,64 @@ def test_two_images_per_gpu_equal_the_mean_of_two_single_image_iterations():
         assert float((gr2[n] - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-8, n
     aux = model.roi_heads.last_aux
     assert len(aux["images"]) == 2 and aux["images"][1]["scores"].shape == (4, 53, K)
+
+
+@pytest.mark.parametrize("R,K,n_gt,H,W", [(1, 20, 1, 96, 128), (7, 3, 2, 96, 128), (37, 1, 1, 80, 112), (23, 20, 5, 112, 96)])
+def test_small_and_degenerate_view_sets_against_the_oracle(R, K, n_gt, H, W):
+    """The ragged end of the input range (the reference's loader can hand over any of these): ONE proposal per view (top-k =
+    max(int(R * 0.1), 1) = 1, every softmax over proposals is over a single row), fewer proposals than ROIs a wave holds, a single
+    class (K = 1: 2-column refinement heads, 4-column box deltas), more gt classes than the usual 1-2, non-square small maps.  Losses
+    1e-4 against the CPU oracle, pseudo labels and proposal labels bit exact, every head gradient within 2e-3 of its scale (the
+    bound of the full-size fp32 test).  Backbone gradients: with a handful of ROIs ONE pooling argmax that lands on the other of two
+    pixels tied to the last ulp (the CPU convolution and the MFMA one sum in different orders) is visible — measured at R = 1:
+    conv5_3's weight gradient is off by 1.3e-2 in exactly one output channel and <= 1.2e-4 in the other 511, its bias gradient
+    (blind to WHERE a gradient lands) by 1.1e-4 — so they are held to 2e-2 in relative L2 and conv5_3's bias to 2e-3."""
+    from sos_wsod_amd.events import EventStorage
+    dan = (256, 256)
+    tag = f"edge{R}_{K}_{n_gt}"
+    P = O.make_params(K, dan, tag="p" + tag, head_scale=20.0)
+    views, gt = O.make_views(H, W, R, n_gt=min(n_gt, K), K=K, scale2=1.25, tag="v" + tag)
+    masks = O.make_masks(R, dan, tag="m" + tag)
+    ol, oaux, ograd = O.oicr_plus_iteration(P, views, gt, masks, K=K, want_grads=True)
+    model = build_model(K, dan, torch.float32)
+    load_params(model, P)
+    model.train()
+    model.roi_heads.debug_drop_masks = [[torch.from_numpy(m) for m in v] for v in masks]
+    with EventStorage(0):
+        losses = model(to_batched_inputs(views, gt))
+        sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    assert set(losses) == set(ol)
+    for k, v in losses.items():
+        assert np.isfinite(v.item()) and abs(v.item() - ol[k]) <= 1e-4 * abs(ol[k]) + 1e-7, (k, v.item(), ol[k])
+    aux = model.roi_heads.last_aux
+    for k in range(4):
+        r, o = aux["rounds"][k], oaux["rounds"][k]
+        n = int(r["pgt_count"].item())
+        assert n == len(o["pgt"]["index"]) >= 1
+        assert np.array_equal(r["pgt_index"][:n].cpu().numpy(), o["pgt"]["index"])
+        assert np.array_equal(r["pgt_class"][:n].cpu().numpy(), o["pgt"]["classes"])
+        assert np.array_equal(r["lab_class"].cpu().numpy(), o["labels"]["gt_classes"])
+        assert np.array_equal(r["lab_index"].cpu().numpy(), o["labels"]["gt_index"])
+    sd = dict(model.named_parameters())
+    checked, worst = 0, ("", 0.0)
+    for name, g in ograd.items():
+        if name in sd and sd[name].grad is not None:
+            got = sd[name].grad.cpu().numpy()
+            scale = np.abs(g).max()
+            if name.startswith("backbone.") and name != "backbone.plain5.0.conv3.bias":
+                err = float(np.linalg.norm(got - g) / (np.linalg.norm(g) + 1e-30))
+                assert err <= 2e-2, (name, err)
+            elif name == "roi_heads.box_predictor.det.bias":
+                # a constant added to a column of the detection stream cancels in the softmax over proposals: the true gradient is 0 and
+                # both sides hold rounding noise, measured against the scale of the weight gradient next to it
+                ref_scale = np.abs(ograd["roi_heads.box_predictor.det.weight"]).max()
+                err = float(max(np.abs(got).max(), np.abs(g).max()) / (ref_scale + 1e-30)) if ref_scale > 0 else 0.0
+                assert err <= 1e-4, (name, err)
+            else:
+                err = float(np.abs(got - g).max() / (scale + 1e-30)) if scale > 1e-6 else 0.0
+                assert np.abs(got - g).max() <= 2e-3 * scale + 1e-7, (name, err)
+            worst = max(worst, (name, err), key=lambda x: x[1])
+            checked += 1
+    assert checked >= 20
+    print(f"R={R} K={K} gt={list(gt)}: worst gradient error {worst[1]:.1e} ({worst[0]})")
