@@ -833,3 +833,50 @@ def test_small_and_degenerate_view_sets_against_the_oracle(R, K, n_gt, H, W):
             checked += 1
     assert checked >= 20
     print(f"R={R} K={K} gt={list(gt)}: worst gradient error {worst[1]:.1e} ({worst[0]})")
+
+
+def test_trainer_skips_images_without_labels_and_iter_size_accumulates():
+    """train_net_multi.py:121-127 (an image whose `instances1` is empty is skipped: the next one from the loader is taken) and
+    :146-168 (ITER_SIZE: losses / ITER_SIZE, the optimizer steps when iter % ITER_SIZE == 0 — so, as written there, at iteration 0
+    already and then after every second one): a loader that yields [unlabelled, A, unlabelled, unlabelled, B, C] through
+    Trainer(iter_size=2) ends where a replica ends that is handed A, B, C."""
+    from sos_wsod_amd.solver import HipSGD
+    from sos_wsod_amd.structures import Instances, Boxes
+    from sos_wsod_amd.trainer import Trainer
+    K, dan = 20, (256, 256)
+    P = O.make_params(K, dan, tag="pskip", head_scale=20.0)
+
+    def item(tag, labelled=True):
+        views, gt = O.make_views(96, 128, 40, n_gt=2, K=K, scale2=1.25, tag=tag)
+        d = to_batched_inputs(views, gt)
+        if not labelled:
+            for n in ["1", "1_flip", "2", "2_flip"]:
+                h, w = views[0]["image"].shape[1:]
+                t = Instances((h, w)); t.gt_boxes = Boxes(torch.zeros(0, 4)); t.gt_classes = torch.zeros(0, dtype=torch.int64)
+                d[0]["instances" + n] = t
+        return d
+
+    def fresh():
+        m = build_model(K, dan, torch.float32); load_params(m, P); m.train()
+        m.roi_heads.seed = 77
+        groups = [{"params": [p], "lr": 2e-3 if nm.endswith(".bias") else 1e-3, "weight_decay": 0.0 if nm.endswith(".bias") else 5e-4}
+                  for nm, p in m.named_parameters() if p.requires_grad]
+        return m, HipSGD(groups, 1e-3, momentum=0.9)
+    A, B, C = item("skipA"), item("skipB"), item("skipC")
+    m1, o1 = fresh()
+    tr = Trainer(m1, o1, iter_size=2, use_graph=False)
+    tr.data_iter = iter([item("skipU0", False), A, item("skipU1", False), item("skipU2", False), B, C])
+    w0 = m1.roi_heads.box_head.fc1.weight.detach().clone()
+    tr.run_step()
+    w1 = m1.roi_heads.box_head.fc1.weight.detach().clone()
+    assert not torch.equal(w1, w0)                                              # iteration 0: 0 % 2 == 0, the reference steps
+    tr.run_step()
+    assert torch.equal(m1.roi_heads.box_head.fc1.weight.detach(), w1)          # iteration 1 only accumulates
+    tr.run_step()
+    assert not torch.equal(m1.roi_heads.box_head.fc1.weight.detach(), w1)      # iteration 2 applies B + C
+    m2, o2 = fresh()
+    tr2 = Trainer(m2, o2, iter_size=2, use_graph=False)
+    tr2.run_step(A); tr2.run_step(B); tr2.run_step(C)
+    torch.cuda.synchronize()
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p1.detach(), p2.detach()), n1
