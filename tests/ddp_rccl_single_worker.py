@@ -1,0 +1,80 @@
+"""The data-parallel Trainer over the REAL RCCL backend on the one GPU a test box has: a `nccl` process group of world size 1.
+The all-reduce moves nothing, but everything around it is the multi-GPU code path — ProcessGroupNCCL's streams and CUDA futures,
+DistributedDataParallel's reducer and bucket views, the communication hook that queues HipSGD's update behind each bucket
+(`Trainer(overlap_update=True)`), the device-side metrics all-reduce — none of which the gloo tests run.  Check: after 3 steps
+the parameters are bit-identical to a plain (non-DDP, eager) Trainer fed the same data."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    out_path, dtype_name = sys.argv[1], sys.argv[2]
+    import sos_wsod_amd  # noqa: F401
+    from helpers import build_model, load_params, to_batched_inputs
+    from oracle import oicr_oracle as O                      # closed-form parameters / views only (test infrastructure)
+    from sos_wsod_amd.solver import HipSGD
+    from sos_wsod_amd.trainer import Trainer, init_distributed
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[3])
+    os.environ["WORLD_SIZE"] = "1"; os.environ["RANK"] = "0"; os.environ["LOCAL_RANK"] = "0"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    dtype = torch.float32 if dtype_name == "fp32" else torch.bfloat16
+    K, R, H, W, dan = 20, 60, 96, 128, (256, 256)
+    P = O.make_params(K, dan, tag="prccl", head_scale=20.0)
+
+    def data_of(step):
+        views, gt = O.make_views(H, W, R, n_gt=2, K=K, scale2=1.25, tag=f"vrccl_{step}")
+        return to_batched_inputs(views, gt)
+
+    def fresh():
+        m = build_model(K, dan, dtype, device=dev)
+        load_params(m, P)
+        m.train()
+        m.roi_heads.seed = 4321
+        return m
+
+    def groups(m):
+        return [{"params": [p], "lr": 2e-2 if n.endswith(".bias") else 1e-2, "weight_decay": 0.0 if n.endswith(".bias") else 5e-4}
+                for n, p in m.named_parameters() if p.requires_grad]
+
+    def run(ddp):
+        m = fresh()
+        opt = HipSGD(groups(m), 1e-2, momentum=0.9)
+        tr = Trainer(m, opt, ddp=ddp, use_graph=False, check_finite_every=1, metrics_period=1)
+        left = []
+        for step in range(3):
+            orig = opt.step
+
+            def spy(*a, **k):
+                left.append(sum(1 for p in m.parameters() if p.grad is not None and id(p) not in opt._done))
+                return orig(*a, **k)
+            opt.step = spy
+            tr.run_step(data_of(step))
+            opt.step = orig
+        tr.finish()
+        torch.cuda.synchronize()
+        return m, tr, left
+
+    m_ddp, tr_ddp, left = run(True)
+    assert isinstance(tr_ddp.model, torch.nn.parallel.DistributedDataParallel)
+    m_ref, tr_ref, _ = run(False)
+    same = all(torch.equal(a.detach(), b.detach()) for a, b in zip(m_ddp.parameters(), m_ref.parameters()))
+    moved = float((m_ddp.roi_heads.box_head.fc1.weight.detach() - torch.from_numpy(P["roi_heads.box_head.fc1.weight"]).to(dev)).abs().max())
+    torch.save({"same": same, "moved": moved, "overlap_update": tr_ddp.overlap_update, "left_for_step": left,
+                "backend": dist.get_backend(),
+                "metrics": {k: float(v) for k, v in tr_ddp.storage.latest().items() if k.startswith("loss")},
+                "metrics_ref": {k: float(v) for k, v in tr_ref.storage.latest().items() if k.startswith("loss")}}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,3 +98,18 @@ def test_stage3_semisup_step_two_ranks(tmp_path):
         assert res["n_grads"] >= 60 and max(res["grad_err"]) <= 1e-6, max(res["grad_err"])
         assert res["same_across_ranks"] and res["finite"]
         assert any(k.endswith("_pseudo") for k in res["losses"])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_ddp_trainer_over_rccl_world_size_one(tmp_path, dtype):
+    """the multi-GPU code path on the real RCCL backend (ProcessGroupNCCL streams / futures, DDP reducer, the per-bucket update hook,
+    the metrics all-reduce) with the one GPU a test box has: bit-identical parameters to the plain Trainer"""
+    out = str(tmp_path / "rccl1.pt")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "ddp_rccl_single_worker.py"), out, dtype, str(_free_port())]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    res = torch.load(out)
+    assert res["backend"] == "nccl" and res["same"] and res["moved"] > 0
+    assert res["overlap_update"] and res["left_for_step"] == [0, 0, 0], res["left_for_step"]
+    assert res["metrics"] == res["metrics_ref"] and len(res["metrics"]) == 9
