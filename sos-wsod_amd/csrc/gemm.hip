@@ -845,7 +845,10 @@ int launch_auto(GemmArgs& g, int splitk, hipStream_t s) {
   static const char* v = getenv("SW_GEMM_V");               // development switch (tile override)
   const long sk = splitk < 1 ? 1 : splitk;
   auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * sk; };
-  const bool big = (v && v[0] == '4') ? true : (v && v[0] == '8') ? false : (g.N > 128 && tiles(256, 256) >= 200);
+  // the 256x256 tile pays off once the K loop is long enough to hide its prologue / epilogue: the 1x1 convolutions of a ResNet
+  // (121 600 pixels x 256 channels, K = 64 .. 256: memory bound) ran 4x slower on it than on the 128x128 tile, two workgroups per
+  // CU (244 vs 57 us; tools/gemm_1x1_probe.py).  Every fc / conv shape of the OICR+ step has K >= 1152.
+  const bool big = (v && v[0] == '4') ? true : (v && v[0] == '8') ? false : (g.N > 128 && tiles(256, 256) >= 200 && g.K >= 1024);
   if (big) {
     static const char* pp = getenv("SW_GEMM_PP");             // development switch: "0" = the 16-wave loop
     // ping-pong form (8 waves of 128x64, two staggered groups): forward / data-gradient shapes (A K-contiguous) run 4-6 % faster
