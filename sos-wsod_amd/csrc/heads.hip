@@ -446,6 +446,15 @@ __device__ __forceinline__ float iou_nms(const float* a, const float* b) {
   const float inter = __fmul_rn(w, h);
   return __fdiv_rn(inter, __fadd_rn(box_area(a), box_area(b)) - inter);
 }
+// iou_nms(a, b) > thresh for thresh >= 0, without the division for disjoint boxes: inter == 0 gives 0 / union = 0 (or 0 / 0 = NaN for
+// two empty boxes), never > thresh — most pairs of a 2000-candidate list are disjoint
+__device__ __forceinline__ bool iou_nms_above(const float* a, const float* b, float thresh) {
+  const float w = fminf(a[2], b[2]) - fmaxf(a[0], b[0]);
+  const float h = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
+  if (!(w > 0.f && h > 0.f)) return false;
+  const float inter = __fmul_rn(w, h);
+  return __fdiv_rn(inter, __fadd_rn(box_area(a), box_area(b)) - inter) > thresh;
+}
 // detectron2 pairwise_iou (structures/boxes.py:329-361): 0 where inter <= 0
 __device__ __forceinline__ float iou_pair(const float* gtb, const float* pb) {
   const float w = fmaxf(fminf(gtb[2], pb[2]) - fmaxf(gtb[0], pb[0]), 0.f);
@@ -708,6 +717,13 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
   __shared__ int s_valid, s_nk;
   __shared__ unsigned long long s_row[64], s_kept;
   const float off = __fmul_rn((float)c, __fadd_rn(maxcoord[0], 1.0f));
+  const bool pos_thresh = nms_thresh >= 0.f;
+#ifdef SW_NMS_TIMING
+  long long tt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long t0 = wall_clock64();
+#define SW_T(k) { const long long t1 = wall_clock64(); tt[k] += t1 - t0; t0 = t1; }
+#else
+#define SW_T(k)
+#endif
   if (tid == 0) { s_valid = 0; s_nk = 0; }
   __syncthreads();
   for (int i0 = 0; i0 < R; i0 += blockDim.x) {                      // compaction (any order: the keys are unique, the sort orders them)
@@ -725,7 +741,9 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
   const int NPV = next_pow2(nv);
   for (int i = nv + tid; i < NPV; i += blockDim.x) keys[i] = ~0ull;
   __syncthreads();
+  SW_T(0)
   bitonic_sort<true>(keys, NPV);
+  SW_T(1)
   if ((long)nv * 16 + 16 <= (long)(NP - nv) * 8) {
     float4* sb = (float4*)(((uintptr_t)(keys + nv) + 15) & ~(uintptr_t)15);
     for (int u = tid; u < nv; u += blockDim.x) {
@@ -736,6 +754,7 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
       sup[u] = 0;                                                   // here the flags go by sorted position
     }
     __syncthreads();
+    SW_T(2)
     for (int c0 = 0; c0 < nv; c0 += 64) {
       if (s_nk >= topk) break;                                      // uniform (s_nk is written before the barriers below)
       const int cn = min(64, nv - c0);
@@ -749,46 +768,73 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
           if (i < cn) {                                             // wave-uniform
             const float4 av = sb[c0 + i];
             float a[4] = {av.x, av.y, av.z, av.w};
-            const unsigned long long m = __ballot(in && lane > i && iou_nms(a, b) > nms_thresh);
+            const unsigned long long m = __ballot(in && lane > i && (pos_thresh ? iou_nms_above(a, b, nms_thresh) : iou_nms(a, b) > nms_thresh));
             if (lane == 0) s_row[i] = m;
           }
         }
       }
       __syncthreads();
+      SW_T(3)
       if (wave == 0) {
+        // serial walk over the chunk on wave-uniform 64-bit masks (scalar registers): take the first live candidate, drop what
+        // its row suppresses; row i lives in lane i and is fetched by v_readlane
         unsigned long long alive = __ballot(lane < cn && !sup[c0 + lane]);
         unsigned long long kept = 0;
-        int nk = s_nk;
-        const unsigned long long myrow = lane < cn ? s_row[lane] : 0ull;       // row i lives in lane i: the serial walk reads registers
+        const int nk0 = __builtin_amdgcn_readfirstlane(s_nk);
+        int nk = nk0;
+        const unsigned long long myrow = lane < cn ? s_row[lane] : 0ull;
         const int row_lo = (int)(unsigned int)myrow, row_hi = (int)(unsigned int)(myrow >> 32);
-        for (int i = 0; i < cn && nk < topk; ++i)
-          if ((alive >> i) & 1ull) {
-            const unsigned long long ri = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(row_lo, i) |
-                                          ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(row_hi, i) << 32);
-            kept |= 1ull << i; alive &= ~ri; ++nk;
-          }
+        while (alive && nk < topk) {
+          const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
+          const unsigned long long ri = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(row_lo, i) |
+                                        ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(row_hi, i) << 32);
+          kept |= 1ull << i; ++nk;
+          alive &= ~(ri | (1ull << i));
+        }
         if ((kept >> lane) & 1ull) {
-          const int o = s_nk + __popcll(kept & ((1ull << lane) - 1));
-          const int p = (int)(keys[c0 + lane] & 0xFFFFFFFFu);
-          cls_rows[c * topk + o] = p; cls_scores[c * topk + o] = scores[(long)p * (K + 1) + c];
+          const int o = nk0 + __popcll(kept & ((1ull << lane) - 1));
+          const unsigned long long key = keys[c0 + lane];
+          cls_rows[c * topk + o] = (int)(key & 0xFFFFFFFFu);
+          cls_scores[c * topk + o] = from_orderable(~(unsigned int)(key >> 32));            // the key holds the score bit for bit
         }
         if (lane == 0) { s_kept = kept; s_nk = nk; }
       }
       __syncthreads();
+      SW_T(4)
       const unsigned long long kept = s_kept;
-      if (kept && s_nk < topk)
-        for (int u = c0 + 64 + tid; u < nv; u += blockDim.x) {
-          if (sup[u]) continue;
-          const float4 bv = sb[u];
+      if (kept && s_nk < topk) {
+        // later candidates against the chunk's kept boxes: a lane holds one candidate (64 per wave and pass), the kept boxes
+        // come out of the registers of the lanes that hold the chunk (v_readlane): no LDS access and no divergence inside the
+        // loop over the kept boxes.  (A wave-per-candidate form — one broadcast LDS read, 64 tests, one ballot — was bound by
+        // the LDS latency of each step: 23 us per chunk against 1 us for the chunk's own 64 x 64 matrix.)
+        const unsigned int klo = __builtin_amdgcn_readfirstlane((unsigned int)kept), khi = __builtin_amdgcn_readfirstlane((unsigned int)(kept >> 32));
+        const float4 kv = sb[c0 + (lane < cn ? lane : 0)];
+        for (int u0 = c0 + 64 + wave * 64; u0 < nv; u0 += 16 * 64) {
+          const int u = u0 + lane;
+          const bool live = u < nv && !sup[u];
+          if (!__ballot(live)) continue;
+          const float4 bv = sb[live ? u : c0];
           float b[4] = {bv.x, bv.y, bv.z, bv.w};
-          for (unsigned long long m = kept; m; m &= m - 1) {
-            const float4 av = sb[c0 + __builtin_ctzll(m)];
-            float a[4] = {av.x, av.y, av.z, av.w};
-            if (iou_nms(a, b) > nms_thresh) { sup[u] = 1; break; }
-          }
+          bool hit = false;
+#pragma unroll
+          for (int half = 0; half < 2; ++half)
+            for (unsigned int m = half ? khi : klo; m; m &= m - 1) {
+              const int k = __builtin_amdgcn_readfirstlane(__builtin_ctz(m)) + 32 * half;
+              float a[4] = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(kv.x), k)),
+                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kv.y), k)),
+                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kv.z), k)),
+                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kv.w), k))};
+              hit = hit || (pos_thresh ? iou_nms_above(a, b, nms_thresh) : iou_nms(a, b) > nms_thresh);
+            }
+          if (live && hit) sup[u] = 1;
         }
+      }
       __syncthreads();
+      SW_T(5)
     }
+#ifdef SW_NMS_TIMING
+    if (tid == 0 && c == 0) printf("nms level 0 (nv %d, kept %d): compaction %lld sort %lld stage %lld matrix %lld resolve %lld apply %lld  (100 MHz ticks)\n", nv, s_nk, tt[0], tt[1], tt[2], tt[3], tt[4], tt[5]);
+#endif
     if (tid == 0) cls_count[c] = s_nk;
     return;
   }
