@@ -860,6 +860,152 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
   if (tid == 0) cls_count[c] = nk;
 }
 
+// ---------------------------------------------------------------- the same per-class NMS spread over the chip (mask form)
+// One workgroup per class is bound by that one CU once a class has ~2000 candidates (N^2 / 2 IoU tests: the RPN's per-level lists;
+// measured 23 us per 64-candidate chunk, 0.4-0.7 ms per call).  Mask form, the arithmetic and the keep set unchanged:
+//   det_prep_kernel     per class: candidates compacted + sorted (as above), sorted keys and clipped, class-offset boxes -> global
+//   det_mask_kernel     tiles of 64 x 64 sorted candidates over ALL CUs: bit j of MT[class][col block][row i] = IoU(i, j) > thresh, j > i
+//   det_resolve_kernel  per class one wave walks the chunks of 64 in order: suppressed = OR over the kept rows before the chunk of
+//                       their mask words for this chunk (read coalesced: the matrix is stored column-block major), the chunk itself
+//                       resolved on wave-uniform 64-bit masks as above; three loader waves stage the next chunk's column meanwhile
+__global__ __launch_bounds__(1024) void det_prep_kernel(int R, int K, float thresh, float imw, float imh,
+                                                        const float* __restrict__ scores, const float* __restrict__ boxes,
+                                                        const float* __restrict__ maxcoord, int* __restrict__ nvalid,
+                                                        unsigned long long* __restrict__ skeys, float4* __restrict__ sboxes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  unsigned long long* keys = (unsigned long long*)smem;           // [next_pow2(R)]
+  __shared__ int s_valid;
+  const float off = __fmul_rn((float)c, __fadd_rn(maxcoord[0], 1.0f));
+  if (tid == 0) s_valid = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < R; i0 += blockDim.x) {
+    const int i = i0 + tid;
+    const bool ok = i < R && scores[(long)i * (K + 1) + c] > thresh;
+    const unsigned long long m = __ballot(ok);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&s_valid, __popcll(m));
+    base = __shfl(base, 0);
+    if (ok) keys[base + __popcll(m & ((1ull << lane) - 1))] = make_key(scores[(long)i * (K + 1) + c], (unsigned)i);
+  }
+  __syncthreads();
+  const int nv = s_valid;
+  const int NPV = next_pow2(nv);
+  for (int i = nv + tid; i < NPV; i += blockDim.x) keys[i] = ~0ull;
+  __syncthreads();
+  bitonic_sort<true>(keys, NPV);
+  for (int u = tid; u < nv; u += blockDim.x) {
+    const unsigned long long key = keys[u];
+    const int q = (int)(key & 0xFFFFFFFFu);
+    const float* bq = boxes + (long)q * 4 * K + 4 * c;
+    skeys[(long)c * R + u] = key;
+    sboxes[(long)c * R + u] = make_float4(__fadd_rn(clipf(bq[0], imw), off), __fadd_rn(clipf(bq[1], imh), off),
+                                          __fadd_rn(clipf(bq[2], imw), off), __fadd_rn(clipf(bq[3], imh), off));
+  }
+  if (tid == 0) nvalid[c] = nv;
+}
+
+__global__ __launch_bounds__(64) void det_mask_kernel(int R, int K, float nms_thresh, const int* __restrict__ nvalid,
+                                                      const float4* __restrict__ sboxes, unsigned long long* __restrict__ MT, int NB) {
+  __shared__ float4 s_col[64];
+  const int lane = threadIdx.x;
+  const bool pos_thresh = nms_thresh >= 0.f;
+  for (long t = blockIdx.x;; t += gridDim.x) {                     // tile list: per class the (row block <= column block) pairs
+    long rem = t;
+    int c = 0, nv = 0;
+    for (; c < K; ++c) {
+      nv = nvalid[c];
+      const long nb = (nv + 63) >> 6, tri = nb * (nb + 1) / 2;
+      if (rem < tri) break;
+      rem -= tri;
+    }
+    if (c >= K) return;                                            // uniform
+    int cb = (int)((sqrtf(8.f * (float)rem + 1.f) - 1.f) * 0.5f);
+    while ((long)cb * (cb + 1) / 2 > rem) --cb;
+    while ((long)(cb + 1) * (cb + 2) / 2 <= rem) ++cb;
+    const int rb = (int)(rem - (long)cb * (cb + 1) / 2);
+    const int j0 = cb * 64, i = rb * 64 + lane;
+    const float4* sb = sboxes + (long)c * R;
+    __syncthreads();
+    s_col[lane] = j0 + lane < nv ? sb[j0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (i < nv) {
+      const float4 av = sb[i];
+      float a[4] = {av.x, av.y, av.z, av.w};
+      const int jn = min(64, nv - j0);
+      unsigned long long bits = 0;
+      for (int jj = max(0, i + 1 - j0); jj < jn; ++jj) {
+        const float4 bv = s_col[jj];
+        float b[4] = {bv.x, bv.y, bv.z, bv.w};
+        if (pos_thresh ? iou_nms_above(a, b, nms_thresh) : iou_nms(a, b) > nms_thresh) bits |= 1ull << jj;
+      }
+      MT[((long)c * NB + cb) * R + i] = bits;
+    }
+  }
+}
+
+constexpr int RES_CAP = 4096;                                       // rows of a chunk's mask column staged in LDS
+__global__ __launch_bounds__(256) void det_resolve_kernel(int R, int K, int topk, int NB, const int* __restrict__ nvalid,
+                                                          const unsigned long long* __restrict__ skeys,
+                                                          const unsigned long long* __restrict__ MT, int* __restrict__ cls_count,
+                                                          int* __restrict__ cls_rows, float* __restrict__ cls_scores) {
+  __shared__ unsigned long long s_buf[2][RES_CAP];
+  __shared__ unsigned long long s_keptm[256];
+  __shared__ int s_stop, s_nk;
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nv = nvalid[c], nb = (nv + 63) >> 6;
+  const unsigned long long* col = MT + (long)c * NB * R;          // col[w * R + i]: mask word of row i for column block w
+  auto stage = [&](int w, int first, int step) {                   // rows [0, (w + 1) * 64) of column block w
+    const int nrows = min(min(nv, (w + 1) * 64), RES_CAP);
+    for (int i = first; i < nrows; i += step) s_buf[w & 1][i] = col[(long)w * R + i];
+  };
+  if (tid == 0) { s_stop = 0; s_nk = 0; }
+  if (nb > 0) stage(0, tid, 256);
+  __syncthreads();
+  for (int w = 0; w < nb; ++w) {
+    if (wave != 0) {
+      if (w + 1 < nb) stage(w + 1, tid - 64, 192);
+    } else {
+      const unsigned long long* buf = s_buf[w & 1];
+      unsigned long long acc = 0;
+      for (int p = 0; p < w; ++p) {                                 // kept rows before this chunk: their words for this chunk
+        const int i = p * 64 + lane;
+        const unsigned long long v = i < RES_CAP ? buf[i] : col[(long)w * R + i];
+        if ((s_keptm[p] >> lane) & 1ull) acc |= v;
+      }
+      unsigned int lo = (unsigned int)acc, hi = (unsigned int)(acc >> 32);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { lo |= (unsigned int)__shfl_xor((int)lo, o); hi |= (unsigned int)__shfl_xor((int)hi, o); }
+      const unsigned long long removed = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)hi) << 32) |
+                                         (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)lo);
+      const int i = w * 64 + lane;
+      const unsigned long long myrow = i < nv ? (i < RES_CAP ? buf[i] : col[(long)w * R + i]) : 0ull;
+      unsigned long long alive = __ballot(i < nv) & ~removed;
+      unsigned long long kept = 0;
+      const int nk0 = __builtin_amdgcn_readfirstlane(s_nk);
+      int nk = nk0;
+      const int row_lo = (int)(unsigned int)myrow, row_hi = (int)(unsigned int)(myrow >> 32);
+      while (alive && nk < topk) {
+        const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
+        const unsigned long long ri = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(row_lo, b) |
+                                      ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(row_hi, b) << 32);
+        kept |= 1ull << b; ++nk;
+        alive &= ~(ri | (1ull << b));
+      }
+      if ((kept >> lane) & 1ull) {
+        const int o = nk0 + __popcll(kept & ((1ull << lane) - 1));
+        const unsigned long long key = skeys[(long)c * R + i];
+        cls_rows[c * topk + o] = (int)(key & 0xFFFFFFFFu);
+        cls_scores[c * topk + o] = from_orderable(~(unsigned int)(key >> 32));
+      }
+      if (lane == 0) { s_keptm[w & 255] = kept; s_nk = nk; s_stop = nk >= topk ? 1 : 0; }
+    }
+    __syncthreads();
+    if (s_stop) break;
+  }
+  if (tid == 0) cls_count[c] = s_nk;
+}
+
 // merge the per-class lists: global order = score desc, ties by filtered position (r*K + c) asc; first topk
 __global__ __launch_bounds__(1024) void det_merge_kernel(int K, int topk, float imw, float imh, const float* __restrict__ boxes,
                                                          const int* __restrict__ cls_count, const int* __restrict__ cls_rows,
@@ -1053,11 +1199,26 @@ extern "C" int sw_oicr_predict(int R, int K, int refine_k, const float* logits, 
 
 extern "C" long sw_detect_workspace_bytes(int K, int topk) { return (long)K * topk * 8 + (long)K * 4 + 64; }
 
-extern "C" int sw_detect_postprocess(int R, int K, const float* all_scores, const float* all_boxes, int img_h, int img_w,
-                                     float score_thresh, float nms_thresh, int topk, int32_t* det_count, float* det_boxes,
-                                     float* det_scores, int32_t* det_classes, int32_t* det_rows, void* workspace,
-                                     hipStream_t stream) {
-  SW_ENTER();
+namespace {
+inline long align256(long v) { return (v + 255) / 256 * 256; }
+// extra workspace of the mask form: nvalid[K] | sorted keys [K][R] | sorted boxes [K][R] float4 | MT [K][NB][R] u64; 0 = not offered
+inline long detect_mask_bytes(int R, int K) {
+  if (R < 1 || K < 1 || R > 16384) return 0;
+  const long NB = (R + 63) / 64;
+  if (NB > 256) return 0;
+  const long b = align256((long)K * 4) + align256((long)K * R * 8) + align256((long)K * R * 16) + (long)K * NB * R * 8;
+  return b <= (96L << 20) ? b : 0;
+}
+}  // namespace
+
+extern "C" long sw_detect_workspace_bytes2(int R, int K, int topk) {
+  return align256(sw_detect_workspace_bytes(K, topk)) + detect_mask_bytes(R, K);
+}
+
+static int detect_postprocess_impl(int R, int K, const float* all_scores, const float* all_boxes, int img_h, int img_w,
+                                   float score_thresh, float nms_thresh, int topk, int32_t* det_count, float* det_boxes,
+                                   float* det_scores, int32_t* det_classes, int32_t* det_rows, void* workspace, long workspace_bytes,
+                                   hipStream_t stream) {
   if (R > 16384 || (long)K * topk > 16384 || topk < 1) return -6;
   char* ws = (char*)workspace;
   float* maxcoord = (float*)ws;                                    // [1] (+pad)
@@ -1073,12 +1234,37 @@ extern "C" int sw_detect_postprocess(int R, int K, const float* all_scores, cons
                      (float)img_h, all_scores, all_boxes, maxcoord);
   SW_CHECK_LAUNCH();
   int np = 64; while (np < R) np <<= 1;
-  const size_t lds1 = (size_t)np * 8 + (size_t)R;
-  e = hipFuncSetAttribute((const void*)det_class_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(det_class_nms_kernel, dim3(K), dim3(1024), lds1, stream, R, K, score_thresh, nms_thresh, topk,
-                     (float)img_w, (float)img_h, all_scores, all_boxes, maxcoord, cls_count, cls_rows, cls_scores);
-  SW_CHECK_LAUNCH();
+  static const bool no_mask = getenv("SW_NMS_NO_MASK") != nullptr;            // development switch
+  const long base = align256(sw_detect_workspace_bytes(K, topk)), mask_need = detect_mask_bytes(R, K);
+  // the mask form pays once a class can hold a few hundred candidates; small calls keep the single launch
+  if (!no_mask && mask_need > 0 && workspace_bytes >= base + mask_need && R >= 256) {
+    char* m = ws + base;
+    int* nvalid = (int*)m; m += align256((long)K * 4);
+    unsigned long long* skeys = (unsigned long long*)m; m += align256((long)K * R * 8);
+    float4* sboxes = (float4*)m; m += align256((long)K * R * 16);
+    unsigned long long* MT = (unsigned long long*)m;
+    const int NB = (R + 63) / 64;
+    const size_t ldsp = (size_t)np * 8;
+    e = hipFuncSetAttribute((const void*)det_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(det_prep_kernel, dim3(K), dim3(1024), ldsp, stream, R, K, score_thresh, (float)img_w, (float)img_h, all_scores,
+                       all_boxes, maxcoord, nvalid, skeys, sboxes);
+    SW_CHECK_LAUNCH();
+    const long max_tiles = (long)NB * (NB + 1) / 2;               // every candidate in one class
+    const int mgrid = (int)(max_tiles < 4096 ? max_tiles : 4096);
+    hipLaunchKernelGGL(det_mask_kernel, dim3(mgrid), dim3(64), 0, stream, R, K, nms_thresh, nvalid, sboxes, MT, NB);
+    SW_CHECK_LAUNCH();
+    hipLaunchKernelGGL(det_resolve_kernel, dim3(K), dim3(256), 0, stream, R, K, topk, NB, nvalid, skeys, MT, cls_count, cls_rows,
+                       cls_scores);
+    SW_CHECK_LAUNCH();
+  } else {
+    const size_t lds1 = (size_t)np * 8 + (size_t)R;
+    e = hipFuncSetAttribute((const void*)det_class_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(det_class_nms_kernel, dim3(K), dim3(1024), lds1, stream, R, K, score_thresh, nms_thresh, topk,
+                       (float)img_w, (float)img_h, all_scores, all_boxes, maxcoord, cls_count, cls_rows, cls_scores);
+    SW_CHECK_LAUNCH();
+  }
   int np2 = 64; while (np2 < K * topk) np2 <<= 1;
   const size_t lds2 = (size_t)np2 * 8;
   e = hipFuncSetAttribute((const void*)det_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -1087,4 +1273,22 @@ extern "C" int sw_detect_postprocess(int R, int K, const float* all_scores, cons
                      cls_count, cls_rows, cls_scores, det_count, det_boxes, det_scores, det_classes, det_rows);
   SW_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int sw_detect_postprocess(int R, int K, const float* all_scores, const float* all_boxes, int img_h, int img_w,
+                                     float score_thresh, float nms_thresh, int topk, int32_t* det_count, float* det_boxes,
+                                     float* det_scores, int32_t* det_classes, int32_t* det_rows, void* workspace,
+                                     hipStream_t stream) {
+  SW_ENTER();
+  return detect_postprocess_impl(R, K, all_scores, all_boxes, img_h, img_w, score_thresh, nms_thresh, topk, det_count, det_boxes,
+                                 det_scores, det_classes, det_rows, workspace, 0, stream);
+}
+
+extern "C" int sw_detect_postprocess2(int R, int K, const float* all_scores, const float* all_boxes, int img_h, int img_w,
+                                      float score_thresh, float nms_thresh, int topk, int32_t* det_count, float* det_boxes,
+                                      float* det_scores, int32_t* det_classes, int32_t* det_rows, void* workspace,
+                                      long workspace_bytes, hipStream_t stream) {
+  SW_ENTER();
+  return detect_postprocess_impl(R, K, all_scores, all_boxes, img_h, img_w, score_thresh, nms_thresh, topk, det_count, det_boxes,
+                                 det_scores, det_classes, det_rows, workspace, workspace_bytes, stream);
 }

@@ -671,10 +671,11 @@ def detect_postprocess(all_scores, all_boxes, img_h, img_w, score_thresh, nms_th
     cnt = torch.zeros(1, device=dev, dtype=torch.int32)
     boxes = torch.zeros(topk, 4, device=dev); scores = torch.zeros(topk, device=dev)
     classes = torch.zeros(topk, device=dev, dtype=torch.int32); rows = torch.zeros(topk, device=dev, dtype=torch.int32)
-    ws = torch.empty(int(lib.sw_detect_workspace_bytes(K, topk)), device=dev, dtype=torch.uint8)
-    check(lib.sw_detect_postprocess(R, K, _p(all_scores), _p(all_boxes), int(img_h), int(img_w), float(score_thresh),
-                                    float(nms_thresh), int(topk), _p(cnt), _p(boxes), _p(scores), _p(classes), _p(rows), _p(ws),
-                                    _stream()), "sw_detect_postprocess")
+    nbytes = int(lib.sw_detect_workspace_bytes2(R, K, topk))
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    check(lib.sw_detect_postprocess2(R, K, _p(all_scores), _p(all_boxes), int(img_h), int(img_w), float(score_thresh),
+                                     float(nms_thresh), int(topk), _p(cnt), _p(boxes), _p(scores), _p(classes), _p(rows), _p(ws),
+                                     nbytes, _stream()), "sw_detect_postprocess2")
     return cnt, boxes, scores, classes, rows
 
 

@@ -699,6 +699,62 @@ def test_detect_postprocess_vs_oracle(ops, R, K):
     assert np.array_equal(dscores[:n].cpu().numpy(), ssel[keep]) and np.array_equal(dboxes[:n].cpu().numpy(), bsel[keep])
 
 
+@pytest.mark.parametrize("case", ["rpn", "classes", "one_class_beyond_lds", "ragged"])
+def test_detect_postprocess_mask_form_equals_single_workgroup_form(ops, case):
+    """sw_detect_postprocess2 (mask form: prep / 64x64 IoU tiles over the chip / one resolving wave per class) against
+    sw_detect_postprocess (one workgroup per class, itself pinned by the oracle above and by tools/fuzz_parity.py): every output bit
+    for bit — the RPN's use (5 levels as classes, 8741 candidates, best 1000 at IoU 0.7), 20 classes x 2000 proposals at the
+    detector's thresholds, ONE class of 5000 candidates (rows beyond the resolver's 4096-row LDS window), classes of 0 / 1 / 65
+    candidates."""
+    import ctypes
+    from sos_wsod_amd._lib import lib
+    g = torch.Generator().manual_seed(71)
+    if case == "rpn":
+        counts, sizes, H, W, thr, nms_thr, topk = [2000, 2000, 2000, 2000, 741], [32, 64, 128, 256, 512], 800, 1216, -3.0e38, 0.7, 1000
+    elif case == "classes":
+        counts, sizes, H, W, thr, nms_thr, topk = None, None, 375, 500, 1e-5, 0.3, 100
+    elif case == "one_class_beyond_lds":
+        counts, sizes, H, W, thr, nms_thr, topk = [5000], [40], 600, 900, -3.0e38, 0.5, 2000
+    else:
+        counts, sizes, H, W, thr, nms_thr, topk = [0, 1, 65, 300, 0, 64], [16, 16, 30, 60, 10, 20], 300, 400, -3.0e38, 0.5, 50
+    if counts is not None:
+        L = len(counts)
+        sc, bx, lv = [], [], []
+        for i, (n, s) in enumerate(zip(counts, sizes)):
+            cx = torch.rand(n, generator=g) * W; cy = torch.rand(n, generator=g) * H
+            w = s * (0.5 + torch.rand(n, generator=g)); h = s * (0.5 + torch.rand(n, generator=g))
+            bx.append(torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1))
+            v = torch.randn(n, generator=g)
+            if n > 10:
+                v[n // 2] = v[n // 3]                                                        # a tied score: proposal order decides
+            sc.append(v); lv.append(torch.full((n,), i, dtype=torch.int64))
+        sc, bx, lv = torch.cat(sc), torch.cat(bx), torch.cat(lv)
+        R = sc.numel()
+        scores = torch.full((R, L + 1), -float("inf")); scores[torch.arange(R), lv] = sc
+        boxes = bx[:, None, :].expand(R, L, 4).reshape(R, 4 * L).contiguous()
+        K = L
+    else:
+        R, K = 2000, 20
+        scores = torch.softmax(torch.randn(R, K + 1, generator=g) * 3, 1)
+        ctr = torch.rand(R, K, 2, generator=g) * torch.tensor([float(W), float(H)]); wh = torch.rand(R, K, 2, generator=g) * 150 + 4
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).reshape(R, 4 * K)
+    scores, boxes = scores.cuda().contiguous(), boxes.cuda().contiguous()
+    assert int(lib.sw_detect_workspace_bytes2(R, K, topk)) > int(lib.sw_detect_workspace_bytes(K, topk)) + 1024       # the mask form is on offer
+    got = ops.detect_postprocess(scores, boxes, H, W, thr, nms_thr, topk)
+    dev = scores.device
+    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    b = torch.zeros(topk, 4, device=dev); s_ = torch.zeros(topk, device=dev)
+    c_ = torch.zeros(topk, device=dev, dtype=torch.int32); r_ = torch.zeros(topk, device=dev, dtype=torch.int32)
+    ws = torch.empty(int(lib.sw_detect_workspace_bytes(K, topk)), device=dev, dtype=torch.uint8)
+    rc = lib.sw_detect_postprocess(R, K, scores.data_ptr(), boxes.data_ptr(), H, W, thr, nms_thr, topk, cnt.data_ptr(), b.data_ptr(),
+                                   s_.data_ptr(), c_.data_ptr(), r_.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    n = int(cnt.item())
+    assert n == int(got[0].item()) and n > 0
+    for x, y in zip(got[1:], (b, s_, c_, r_)):
+        assert torch.equal(x[:n], y[:n])
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,pad", [(8192, 512, 0), (8000, 4096, 128), (32768, 256, 0), (1, 64, 0), (33, 264, 8), (1001, 130, 0),
                                      (700, 24, 4), (5000, 20000, 0)])
