@@ -233,8 +233,8 @@ int sw_detect_postprocess(int R, int K, const float* all_scores, const float* al
                           float score_thresh, float nms_thresh, int topk, int32_t* det_count, float* det_boxes,
                           float* det_scores, int32_t* det_classes, int32_t* det_rows, void* workspace,
                           sw_stream_t stream);
-/* The same, told how large the workspace is: with workspace_bytes >= sw_detect_workspace_bytes2(R, K, topk) and R >= 256 the
- * per-class NMS runs in its mask form — candidates sorted per class, the 64 x 64 IoU tiles of every class computed over all CUs,
+/* The same, told how large the workspace is: with workspace_bytes >= sw_detect_workspace_bytes2(R, K, topk) the per-class NMS of
+ * every class that holds >= 256 candidates runs in its mask form — candidates sorted per class, the 64 x 64 IoU tiles of every class computed over all CUs,
  * one wave per class resolving the chunks in order — instead of one workgroup per class doing its N^2 / 2 tests alone (the RPN's
  * per-level lists of detectron2's find_top_rpn_proposals, proposal_utils.py:20-130: 2000 candidates per level; 20-80 classes of
  * fast_rcnn_inference_single_image).  Identical outputs.  sw_detect_workspace_bytes2 returns the plain size when the mask

@@ -708,7 +708,9 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
                                                              const float* __restrict__ boxes,
                                                              const float* __restrict__ maxcoord,
                                                              int* __restrict__ cls_count, int* __restrict__ cls_rows,
-                                                             float* __restrict__ cls_scores) {
+                                                             float* __restrict__ cls_scores, int* __restrict__ nvalid,
+                                                             unsigned long long* __restrict__ skeys, float4* __restrict__ sboxes,
+                                                             int mask_min) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NP = next_pow2(R);
@@ -744,6 +746,23 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
   SW_T(0)
   bitonic_sort<true>(keys, NPV);
   SW_T(1)
+  if (nvalid) {
+    // mask form on offer (sw_detect_postprocess2): a class with mask_min or more candidates hands its sorted list to det_mask_kernel /
+    // det_resolve_kernel (nvalid = count); a smaller one is finished right here (nvalid = -1: the two kernels skip it)
+    if (nv >= mask_min) {
+      for (int u = tid; u < nv; u += blockDim.x) {
+        const unsigned long long key = keys[u];
+        const int q = (int)(key & 0xFFFFFFFFu);
+        const float* bq = boxes + (long)q * 4 * K + 4 * c;
+        skeys[(long)c * R + u] = key;
+        sboxes[(long)c * R + u] = make_float4(__fadd_rn(clipf(bq[0], imw), off), __fadd_rn(clipf(bq[1], imh), off),
+                                              __fadd_rn(clipf(bq[2], imw), off), __fadd_rn(clipf(bq[3], imh), off));
+      }
+      if (tid == 0) nvalid[c] = nv;
+      return;
+    }
+    if (tid == 0) nvalid[c] = -1;
+  }
   if ((long)nv * 16 + 16 <= (long)(NP - nv) * 8) {
     float4* sb = (float4*)(((uintptr_t)(keys + nv) + 15) & ~(uintptr_t)15);
     for (int u = tid; u < nv; u += blockDim.x) {
@@ -863,48 +882,12 @@ __global__ __launch_bounds__(1024) void det_class_nms_kernel(int R, int K, float
 // ---------------------------------------------------------------- the same per-class NMS spread over the chip (mask form)
 // One workgroup per class is bound by that one CU once a class has ~2000 candidates (N^2 / 2 IoU tests: the RPN's per-level lists;
 // measured 23 us per 64-candidate chunk, 0.4-0.7 ms per call).  Mask form, the arithmetic and the keep set unchanged:
-//   det_prep_kernel     per class: candidates compacted + sorted (as above), sorted keys and clipped, class-offset boxes -> global
+//   det_class_nms_kernel (above) per class: candidates compacted + sorted; >= mask_min of them: sorted keys and clipped,
+//                       class-offset boxes -> global; fewer: finished there, in LDS
 //   det_mask_kernel     tiles of 64 x 64 sorted candidates over ALL CUs: bit j of MT[class][col block][row i] = IoU(i, j) > thresh, j > i
 //   det_resolve_kernel  per class one wave walks the chunks of 64 in order: suppressed = OR over the kept rows before the chunk of
 //                       their mask words for this chunk (read coalesced: the matrix is stored column-block major), the chunk itself
 //                       resolved on wave-uniform 64-bit masks as above; three loader waves stage the next chunk's column meanwhile
-__global__ __launch_bounds__(1024) void det_prep_kernel(int R, int K, float thresh, float imw, float imh,
-                                                        const float* __restrict__ scores, const float* __restrict__ boxes,
-                                                        const float* __restrict__ maxcoord, int* __restrict__ nvalid,
-                                                        unsigned long long* __restrict__ skeys, float4* __restrict__ sboxes) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  unsigned long long* keys = (unsigned long long*)smem;           // [next_pow2(R)]
-  __shared__ int s_valid;
-  const float off = __fmul_rn((float)c, __fadd_rn(maxcoord[0], 1.0f));
-  if (tid == 0) s_valid = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < R; i0 += blockDim.x) {
-    const int i = i0 + tid;
-    const bool ok = i < R && scores[(long)i * (K + 1) + c] > thresh;
-    const unsigned long long m = __ballot(ok);
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(&s_valid, __popcll(m));
-    base = __shfl(base, 0);
-    if (ok) keys[base + __popcll(m & ((1ull << lane) - 1))] = make_key(scores[(long)i * (K + 1) + c], (unsigned)i);
-  }
-  __syncthreads();
-  const int nv = s_valid;
-  const int NPV = next_pow2(nv);
-  for (int i = nv + tid; i < NPV; i += blockDim.x) keys[i] = ~0ull;
-  __syncthreads();
-  bitonic_sort<true>(keys, NPV);
-  for (int u = tid; u < nv; u += blockDim.x) {
-    const unsigned long long key = keys[u];
-    const int q = (int)(key & 0xFFFFFFFFu);
-    const float* bq = boxes + (long)q * 4 * K + 4 * c;
-    skeys[(long)c * R + u] = key;
-    sboxes[(long)c * R + u] = make_float4(__fadd_rn(clipf(bq[0], imw), off), __fadd_rn(clipf(bq[1], imh), off),
-                                          __fadd_rn(clipf(bq[2], imw), off), __fadd_rn(clipf(bq[3], imh), off));
-  }
-  if (tid == 0) nvalid[c] = nv;
-}
-
 __global__ __launch_bounds__(64) void det_mask_kernel(int R, int K, float nms_thresh, const int* __restrict__ nvalid,
                                                       const float4* __restrict__ sboxes, unsigned long long* __restrict__ MT, int NB) {
   __shared__ float4 s_col[64];
@@ -914,7 +897,7 @@ __global__ __launch_bounds__(64) void det_mask_kernel(int R, int K, float nms_th
     long rem = t;
     int c = 0, nv = 0;
     for (; c < K; ++c) {
-      nv = nvalid[c];
+      nv = max(nvalid[c], 0);
       const long nb = (nv + 63) >> 6, tri = nb * (nb + 1) / 2;
       if (rem < tri) break;
       rem -= tri;
@@ -953,6 +936,7 @@ __global__ __launch_bounds__(256) void det_resolve_kernel(int R, int K, int topk
   __shared__ unsigned long long s_keptm[256];
   __shared__ int s_stop, s_nk;
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (nvalid[c] < 0) return;                                     // finished by det_class_nms_kernel (uniform)
   const int nv = nvalid[c], nb = (nv + 63) >> 6;
   const unsigned long long* col = MT + (long)c * NB * R;          // col[w * R + i]: mask word of row i for column block w
   auto stage = [&](int w, int first, int step) {                   // rows [0, (w + 1) * 64) of column block w
@@ -1235,34 +1219,30 @@ static int detect_postprocess_impl(int R, int K, const float* all_scores, const 
   SW_CHECK_LAUNCH();
   int np = 64; while (np < R) np <<= 1;
   static const bool no_mask = getenv("SW_NMS_NO_MASK") != nullptr;            // development switch
+  static const int mask_min = getenv("SW_NMS_MASK_MIN") ? atoi(getenv("SW_NMS_MASK_MIN")) : 256;     // development switch
   const long base = align256(sw_detect_workspace_bytes(K, topk)), mask_need = detect_mask_bytes(R, K);
-  // the mask form pays once a class can hold a few hundred candidates; small calls keep the single launch
-  if (!no_mask && mask_need > 0 && workspace_bytes >= base + mask_need && R >= 256) {
-    char* m = ws + base;
-    int* nvalid = (int*)m; m += align256((long)K * 4);
-    unsigned long long* skeys = (unsigned long long*)m; m += align256((long)K * R * 8);
-    float4* sboxes = (float4*)m; m += align256((long)K * R * 16);
-    unsigned long long* MT = (unsigned long long*)m;
+  const bool mask = !no_mask && mask_need > 0 && workspace_bytes >= base + mask_need && R >= mask_min;
+  char* m = ws + base;
+  int* nvalid = mask ? (int*)m : nullptr; m += align256((long)K * 4);
+  unsigned long long* skeys = (unsigned long long*)m; m += align256((long)K * R * 8);
+  float4* sboxes = (float4*)m; m += align256((long)K * R * 16);
+  unsigned long long* MT = (unsigned long long*)m;
+  const size_t lds1 = (size_t)np * 8 + (size_t)R;
+  e = hipFuncSetAttribute((const void*)det_class_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(det_class_nms_kernel, dim3(K), dim3(1024), lds1, stream, R, K, score_thresh, nms_thresh, topk,
+                     (float)img_w, (float)img_h, all_scores, all_boxes, maxcoord, cls_count, cls_rows, cls_scores, nvalid, skeys, sboxes,
+                     mask_min);
+  SW_CHECK_LAUNCH();
+  if (mask) {
+    // classes of >= mask_min candidates: the 64 x 64 IoU tiles over the chip, then one resolving wave per class
     const int NB = (R + 63) / 64;
-    const size_t ldsp = (size_t)np * 8;
-    e = hipFuncSetAttribute((const void*)det_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(det_prep_kernel, dim3(K), dim3(1024), ldsp, stream, R, K, score_thresh, (float)img_w, (float)img_h, all_scores,
-                       all_boxes, maxcoord, nvalid, skeys, sboxes);
-    SW_CHECK_LAUNCH();
     const long max_tiles = (long)NB * (NB + 1) / 2;               // every candidate in one class
     const int mgrid = (int)(max_tiles < 4096 ? max_tiles : 4096);
     hipLaunchKernelGGL(det_mask_kernel, dim3(mgrid), dim3(64), 0, stream, R, K, nms_thresh, nvalid, sboxes, MT, NB);
     SW_CHECK_LAUNCH();
     hipLaunchKernelGGL(det_resolve_kernel, dim3(K), dim3(256), 0, stream, R, K, topk, NB, nvalid, skeys, MT, cls_count, cls_rows,
                        cls_scores);
-    SW_CHECK_LAUNCH();
-  } else {
-    const size_t lds1 = (size_t)np * 8 + (size_t)R;
-    e = hipFuncSetAttribute((const void*)det_class_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(det_class_nms_kernel, dim3(K), dim3(1024), lds1, stream, R, K, score_thresh, nms_thresh, topk,
-                       (float)img_w, (float)img_h, all_scores, all_boxes, maxcoord, cls_count, cls_rows, cls_scores);
     SW_CHECK_LAUNCH();
   }
   int np2 = 64; while (np2 < K * topk) np2 <<= 1;
