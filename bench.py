@@ -149,6 +149,13 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.run(cmd, env=env).returncode)
 
+    # stdout carries ONE line, the JSON record.  Libraries write to file descriptor 1 behind Python's back (RCCL prints a
+    # five-line version banner there when its first communicator comes up): from here on descriptor 1 is stderr, and the record
+    # goes to the saved descriptor at the end.  (After the self-launch above: the children must inherit the real stdout.)
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     import sos_wsod_amd  # noqa: F401  (fails loudly if the HIP extension is missing)
     import sos_wsod_amd.ops as ops
     from sos_wsod_amd.solver import HipSGD
@@ -376,9 +383,38 @@ def main():
             out["extra_shapes"]["stage3"] = ("BASELINE configs[4] per GPU: 1 labelled + 1 unlabelled image, strong + weak view each (800x1216), "
                                              "R50-FPN Faster R-CNN student / EMA teacher, K=20")
             torch.cuda.empty_cache()
+            # The multi-GPU step on this one GPU: the same model inside Trainer's DistributedDataParallel over a real RCCL process
+            # group of world size 1 (reducer, bucket views, per-bucket HipSGD update from the communication hook, launches issued
+            # from Python — no step graph): what a rank pays per step at N > 1 before any bytes cross xGMI.  Best effort: the key is
+            # simply absent if the rendezvous cannot be set up.
+            try:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+                dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+                try:
+                    md = build(device, dtype); md.train()
+                    gs = [{"params": [p], "lr": 2e-3 if nm.endswith(".bias") else 1e-3, "weight_decay": 0.0 if nm.endswith(".bias") else 5e-4}
+                          for nm, p in md.named_parameters() if p.requires_grad]
+                    td = Trainer(md, HipSGD(gs, 1e-3, momentum=0.9), ddp=True, use_graph=False)
+                    for i in range(6):
+                        td.run_step(batches[i % 2])
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    for i in range(20):
+                        td.run_step(batches[i % 2])
+                    torch.cuda.synchronize()
+                    out["ddp_rccl_world1_ms_per_step"] = round((time.perf_counter() - t1) / 20 * 1e3, 3)
+                    td.finish()
+                    del td, md
+                finally:
+                    dist.destroy_process_group()
+            except Exception as ex:                                  # noqa: BLE001 — an extra, never the reason a bench run fails
+                out["ddp_rccl_world1_error"] = repr(ex)[:200]
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

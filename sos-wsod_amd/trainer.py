@@ -96,11 +96,20 @@ class Trainer:
             # ring (the fc6 weight gradient alone is 411 MB per step); the sum is formed in bf16, the result returns as f32
             grad_compress = grad_compress or os.environ.get("SW_DDP_GRAD_COMPRESS")
             from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            self._seed_scale = 1.0
             if grad_compress:
                 assert grad_compress == "bf16", f"unknown gradient compression {grad_compress!r}"
                 reduce_hook = default_hooks.bf16_compress_hook
             else:
-                reduce_hook = default_hooks.allreduce_hook
+                # mean over the ranks without the averaging pass: DDP's default (and default_hooks.allreduce_hook) divides every
+                # bucket by the world size before the all-reduce — a read + write of all 543 MB of gradients per step.  Here the
+                # backward is seeded with 1 / (ITER_SIZE * world) instead, so the gradients leave the kernels already divided
+                # (exact for the power-of-two world sizes of a node) and the hook all-reduces with SUM.
+                self._seed_scale = 1.0 / self.world
+                pg = dist.group.WORLD
+
+                def reduce_hook(state, bucket, pg=pg):
+                    return dist.all_reduce(bucket.buffer(), group=pg, async_op=True).get_future().then(lambda f: f.value()[0])
             # Update as the buckets return (MI355X-first; the reference steps after the whole backward, train_net_multi.py:157-164):
             # the optimizer's kernel for the parameters of a bucket is queued right behind that bucket's all-reduce — fc6's 411 MB
             # (76 % of the bytes, reduced 3.3 ms before the backward ends) are updated while the convolution backward still runs,
@@ -120,7 +129,7 @@ class Trainer:
                         return v[0] if isinstance(v, (list, tuple)) else v
                     return reduce_hook(state, bucket).then(update)
                 self.model.register_comm_hook(None, hook)
-            elif grad_compress:
+            else:
                 self.model.register_comm_hook(None, reduce_hook)
         else:
             self.model = model
@@ -132,7 +141,7 @@ class Trainer:
         """cotangent of the summed loss: 1 / ITER_SIZE as a cached device scalar (train_net_multi.py:146 `losses / iter_size`
         without the division kernel and without autograd's ones_like fill)"""
         if self._grad_seed is None or self._grad_seed.device != total.device or self._grad_seed.dtype != total.dtype:
-            self._grad_seed = torch.full_like(total, 1.0 / self.iter_size)
+            self._grad_seed = torch.full_like(total, getattr(self, "_seed_scale", 1.0) / self.iter_size)
         return self._grad_seed
 
     def _raise_if_nonfinite(self):
