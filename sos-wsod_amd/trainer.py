@@ -76,7 +76,11 @@ class Trainer:
         if callable(prepare):
             prepare()                       # flat predictor master, compute-dtype weight copies: BEFORE DDP looks at the parameters
         use_ddp = ddp if ddp is not None else self.world > 1
+        self._bucket_views = []
         if use_ddp:
+            if os.environ.get("SW_DDP_GRAD_IN_BUCKET", "1") == "1" and hasattr(model, "roi_heads") and hasattr(model.roi_heads, "box_head"):
+                bh = model.roi_heads.box_head
+                self._bucket_views = [m.weight for m in (getattr(bh, "fc1", None), getattr(bh, "fc2", None)) if m is not None]
             dev = next(model.parameters()).device
             ids = [dev.index] if dev.type == "cuda" else None
             # broadcast_buffers=False as the reference (train_net_multi.py:76-78); every trainable parameter is used
@@ -200,6 +204,12 @@ class Trainer:
             losses.backward(gradient=self._seed_grad(losses))             # :146-147  (losses / iter_size).backward()
         if self.iter % self.iter_size == 0:                                # :149 — the reference's rule, first step at iter 0
             self.optimizer.step()
+            if self._bucket_views:
+                # the reducer has re-pointed every .grad at its bucket view: remember them, the next backward writes its weight
+                # gradients there (roi_heads_oicrplus._grad_target) and the reducer's copy into the bucket disappears
+                for p in self._bucket_views:
+                    if p.grad is not None:
+                        p.__dict__["_sw_grad_view"] = p.grad
             self.optimizer.zero_grad()
         return loss_dict, losses
 
