@@ -104,11 +104,16 @@ class Trainer:
             if grad_compress:
                 assert grad_compress == "bf16", f"unknown gradient compression {grad_compress!r}"
                 reduce_hook = default_hooks.bf16_compress_hook
+            elif self.iter_size > 1:
+                # gradient accumulation: a bucket holds the previous micro-steps' (already averaged) sum plus the new local gradient,
+                # and only "divide, then sum over the ranks" leaves the first part unchanged — the stock hook
+                reduce_hook = default_hooks.allreduce_hook
             else:
                 # mean over the ranks without the averaging pass: DDP's default (and default_hooks.allreduce_hook) divides every
                 # bucket by the world size before the all-reduce — a read + write of all 543 MB of gradients per step.  Here the
-                # backward is seeded with 1 / (ITER_SIZE * world) instead, so the gradients leave the kernels already divided
-                # (exact for the power-of-two world sizes of a node) and the hook all-reduces with SUM.
+                # backward is seeded with 1 / world instead, so the gradients leave the kernels already divided (exact for the
+                # power-of-two world sizes of a node) and the hook all-reduces with SUM.  (ITER_SIZE 1: a bucket holds this step's
+                # gradients only.)
                 self._seed_scale = 1.0 / self.world
                 pg = dist.group.WORLD
 
