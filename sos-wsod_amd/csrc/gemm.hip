@@ -850,6 +850,12 @@ int launch_auto(GemmArgs& g, int splitk, hipStream_t s) {
   // CU (244 vs 57 us; tools/gemm_1x1_probe.py).  Every fc / conv shape of the OICR+ step has K >= 1152.
   const bool big = (v && v[0] == '4') ? true : (v && v[0] == '8') ? false : (g.N > 128 && tiles(256, 256) >= 200 && g.K >= 1024);
   if (big) {
+#ifdef SW_GEMM_TRY_4WAVE
+    // experiment (tools/build_variant.sh w4 -DSW_GEMM_TRY_4WAVE, SW_GEMM_W4=1): four waves of 128x128, 256 accumulator registers per lane
+    { static const bool w4 = getenv("SW_GEMM_W4") != nullptr;
+      if constexpr (sizeof(T) == 2 && AMODE == OP_KCONTIG && BMODE == OP_KCONTIG)
+        if (w4 && sk == 1) return launch2<T, AMODE, BMODE, 256, 256, 2, 128, 128>(g, splitk, s); }
+#endif
     static const char* pp = getenv("SW_GEMM_PP");             // development switch: "0" = the 16-wave loop
     // ping-pong form (8 waves of 128x64, two staggered groups): forward / data-gradient shapes (A K-contiguous) run 4-6 % faster
     // on it; the weight gradients (both operands transposed on the fly: twice the LDS instructions per fragment in the load
