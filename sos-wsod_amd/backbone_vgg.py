@@ -221,7 +221,7 @@ class _VGGFunction(torch.autograd.Function):
                     plan[pidx] = dict(ws=torch.empty(nslab, cout * 9 * cin, device=dev, dtype=torch.float32),
                                       rows=torch.empty(nrow, cout, device=dev, dtype=torch.float32), slab_off=slab_off,
                                       row_off=row_off, nslab=nslab, nrow=nrow, splits=splits, cin=cin,
-                                      dw=torch.empty(cout, cin, 3, 3, device=dev, dtype=torch.float32),
+                                      dw=ops.grad_target(w, (cout, cin, 3, 3), dev),
                                       db=torch.empty(cout, device=dev, dtype=torch.float32))
                 if (si, ci) == first_trainable:
                     break

@@ -68,6 +68,18 @@ def param_key(p):
     return (p.data_ptr(), p._version, PARAM_EPOCH if p.requires_grad else -1)
 
 
+def grad_target(param, shape, dev):
+    """Where a weight-gradient GEMM writes.  Under DistributedDataParallel(gradient_as_bucket_view=True) the Trainer remembers the
+    bucket view each parameter's gradient lived in last step (`param._sw_grad_view`); writing the new gradient THERE lets the
+    reducer find `grad.is_alias_of(bucket_view)` and skip its copy of the tensor into the bucket (fc6: 411 MB read + written per
+    step).  Only when the parameter holds no gradient (no accumulation in flight) and the view still fits; else a fresh tensor."""
+    view = param.__dict__.get("_sw_grad_view")
+    if (view is not None and param.grad is None and tuple(view.shape) == tuple(shape) and view.device == dev
+            and view.dtype == torch.float32 and view.is_contiguous()):
+        return view.detach()          # a tensor object of its own on the bucket's storage: autograd adopts a gradient only if nobody else holds it
+    return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+
 # Weight staging registry: id(parameter) -> dict(kind, dtype, stage0, stage1, d0, d1, d2, ld0, stamp).  Modules register the
 # persistent compute-dtype copies of their weights here; HipSGD's fused step (sw_sgd_multi) then rewrites those copies from
 # the freshly updated values and calls stamp(key) so that the module's cache sees them as current.

@@ -95,18 +95,6 @@ def _current_rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
-def _grad_target(param, shape, dev):
-    """Where a weight-gradient GEMM writes.  Under DistributedDataParallel(gradient_as_bucket_view=True) the Trainer remembers the
-    bucket view each parameter's gradient lived in last step (`param._sw_grad_view`); writing the new gradient THERE lets the
-    reducer find `grad.is_alias_of(bucket_view)` and skip its copy of the tensor into the bucket (fc6: 411 MB read + written per
-    step).  Only when the parameter holds no gradient (no accumulation in flight) and the view still fits; else a fresh tensor."""
-    view = param.__dict__.get("_sw_grad_view")
-    if (view is not None and param.grad is None and tuple(view.shape) == tuple(shape) and view.device == dev
-            and view.dtype == torch.float32 and view.is_contiguous()):
-        return view.detach()          # a tensor object of its own on the bucket's storage: autograd adopts a gradient only if nobody else holds it
-    return torch.empty(*shape, device=dev, dtype=torch.float32)
-
-
 def derive_dropout_seed(base, rank):
     """per-rank dropout stream from the rank-independent base seed (engine/defaults.py:147 seeds SEED + rank)"""
     return _splitmix64(_splitmix64(base & 0xFFFFFFFFFFFFFFFF) ^ (0x5051 + rank))
@@ -623,7 +611,7 @@ class OICRPlusHeads(nn.Module):
 
         def dz_t(dz, D):
             return ops.transpose_2d(dz, torch.empty(D, M + 8 * epc, device=dev, dtype=dt_)[:, :M], M, D)
-        dW2 = _grad_target(self.box_head.fc2.weight, (D2, D1), dev)
+        dW2 = ops.grad_target(self.box_head.fc2.weight, (D2, D1), dev)
         if wgrad_nn:
             ops.gemm(dz_t(dz2, D2), h1, dW2, D2, D1, M, b_kstrided=True)
         else:
@@ -651,7 +639,7 @@ class OICRPlusHeads(nn.Module):
         D0, D1 = pooled.shape[1], dz1.shape[1]
         epc = 8 if dt_ == torch.bfloat16 else 4
         db1 = torch.empty(D1, device=dev, dtype=torch.float32); ops.colsum(dz1, M, D1, db1)
-        dW1 = _grad_target(self.box_head.fc1.weight, (D1, D0), dev)
+        dW1 = ops.grad_target(self.box_head.fc1.weight, (D1, D0), dev)
         if M % epc == 0:                                 # dZ^T as in stage 1; the tagged region holds the transpose too: one "fc6_wgrad" measurement
             def nn():
                 dzt = ops.transpose_2d(dz1, torch.empty(D1, M + 8 * epc, device=dev, dtype=dt_)[:, :M], M, D1)

@@ -78,9 +78,8 @@ class Trainer:
         use_ddp = ddp if ddp is not None else self.world > 1
         self._bucket_views = []
         if use_ddp:
-            if os.environ.get("SW_DDP_GRAD_IN_BUCKET", "1") == "1" and hasattr(model, "roi_heads") and hasattr(model.roi_heads, "box_head"):
-                bh = model.roi_heads.box_head
-                self._bucket_views = [m.weight for m in (getattr(bh, "fc1", None), getattr(bh, "fc2", None)) if m is not None]
+            if os.environ.get("SW_DDP_GRAD_IN_BUCKET", "1") == "1":
+                self._bucket_views = [p for p in model.parameters() if p.requires_grad and p.dim() >= 2]     # (ops.grad_target users: fc / conv weights)
             dev = next(model.parameters()).device
             ids = [dev.index] if dev.type == "cuda" else None
             # broadcast_buffers=False as the reference (train_net_multi.py:76-78); every trainable parameter is used
@@ -211,7 +210,7 @@ class Trainer:
             self.optimizer.step()
             if self._bucket_views:
                 # the reducer has re-pointed every .grad at its bucket view: remember them, the next backward writes its weight
-                # gradients there (roi_heads_oicrplus._grad_target) and the reducer's copy into the bucket disappears
+                # gradients there (ops.grad_target) and the reducer's copy into the bucket disappears
                 for p in self._bucket_views:
                     if p.grad is not None:
                         p.__dict__["_sw_grad_view"] = p.grad
