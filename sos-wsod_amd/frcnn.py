@@ -595,19 +595,23 @@ def match(iou, thresholds, labels, allow_low_quality):
     vals, matches = iou.max(dim=0)
     out = torch.ones(n, dtype=torch.int8, device=iou.device)
     th = [-float("inf")] + list(thresholds) + [float("inf")]
-    for l, lo, hi in zip(labels, th[:-1], th[1:]):
-        out[(vals >= lo) & (vals < hi)] = l
+    for l, lo, hi in zip(labels, th[:-1], th[1:]):                  # (torch.where, not masked assignment: no host synchronisation)
+        out = torch.where((vals >= lo) & (vals < hi), torch.full_like(out, l), out)
     if allow_low_quality:
         best = iou.max(dim=1).values
-        out[(iou == best[:, None]).any(dim=0)] = 1
+        out = torch.where((iou == best[:, None]).any(dim=0), torch.ones_like(out), out)
     return matches, out
 
 
 def subsample_labels(labels, num_samples, positive_fraction, bg_label, sampler):
     """modeling/sampling.py:8-54: the `num` candidates with the smallest random keys (keys drawn per candidate list, like
     randperm(len(list))[:num])"""
-    positive = torch.nonzero((labels != -1) & (labels != bg_label)).flatten()
-    negative = torch.nonzero(labels == bg_label).flatten()
+    # one host round trip for both candidate lists (the reference's two `nonzero` calls are two): a stable sort by
+    # (positive, negative, other) lists both in ascending index order, the two counts come back together
+    is_pos, is_neg = (labels != -1) & (labels != bg_label), labels == bg_label
+    order = torch.argsort(torch.where(is_pos, 0, torch.where(is_neg, 1, 2)), stable=True)
+    n_pos, n_neg = torch.stack([is_pos.sum(), is_neg.sum()]).tolist()
+    positive, negative = order[:n_pos], order[n_pos:n_pos + n_neg]
     num_pos = min(positive.numel(), int(num_samples * positive_fraction))
     num_neg = min(negative.numel(), num_samples - num_pos)
     p1 = torch.argsort(sampler.priorities(positive.numel(), labels.device), stable=True)[:num_pos]
@@ -680,9 +684,8 @@ class PseudoLabRPN(nn.Module):
         for n, (h, w) in enumerate(image_sizes):
             sc = torch.cat([p[0][n] for p in per_level]); bx = torch.cat([p[1][n] for p in per_level], 0)
             lvl = torch.cat([torch.full((p[0].shape[1],), i, dtype=torch.int64, device=sc.device) for i, p in enumerate(per_level)])
-            if not bool(torch.isfinite(bx).all() & torch.isfinite(sc).all()):
-                if self.training:
-                    raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
+            finite = torch.isfinite(bx).all() & torch.isfinite(sc).all()
+            if not self.training and not bool(finite):               # (training reads the flag with the count below: one round trip)
                 ok = torch.isfinite(bx).all(1) & torch.isfinite(sc)
                 sc, bx, lvl = sc[ok], bx[ok], lvl[ok]
             cw = bx[:, 2].clamp(0, w) - bx[:, 0].clamp(0, w); ch = bx[:, 3].clamp(0, h) - bx[:, 1].clamp(0, h)
@@ -692,7 +695,9 @@ class PseudoLabRPN(nn.Module):
             scores[torch.arange(R, device=sc.device), lvl] = torch.where((cw > 0) & (ch > 0), sc, ninf)     # nonempty(threshold 0)
             boxes = bx[:, None, :].expand(R, L, 4).reshape(R, 4 * L).contiguous()
             cnt, dboxes, dscores, _, _ = ops.detect_postprocess(scores, boxes, int(h), int(w), -3.0e38, self.nms_thresh, post)
-            k = int(cnt.item())
+            k, fin = torch.stack([cnt[0], finite.to(torch.int32)]).tolist()
+            if self.training and not fin:
+                raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
             p = Instances((int(h), int(w)))
             p.proposal_boxes = Boxes(dboxes[:k].clone()); p.objectness_logits = dscores[:k].clone()
             out.append(p)
@@ -804,7 +809,11 @@ class StandardROIHeadsPseudoLab(nn.Module):
         bx = rois[:, 1:]
         sizes = torch.sqrt((bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1]))
         lv = torch.clamp(torch.floor(4 + torch.log2(sizes / 224 + 1e-8)), min=2, max=5).to(torch.int64) - 2
-        sels = [torch.nonzero(lv == l).flatten().to(torch.int32).contiguous() for l in range(4)]
+        order = torch.argsort(lv, stable=True).to(torch.int32)                                       # per level ascending row order, as nonzero lists it
+        counts = torch.bincount(lv, minlength=4).tolist()                                            # one host round trip for the four lists
+        sels, r0 = [], 0
+        for c_ in counts:
+            sels.append(order[r0:r0 + c_].contiguous()); r0 += c_
         self.last_levels = lv
         return _RoIAlignFn.apply(rois, sels, [1.0 / s for s in STRIDES[:4]], *feats[:4])
 
@@ -896,7 +905,11 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
         d = self.backbone.size_divisibility
         H = (max(s[0] for s in sizes) + d - 1) // d * d; W = (max(s[1] for s in sizes) + d - 1) // d * d
         out = torch.empty(len(ims), H, W, 4, device=self.device, dtype=self.compute_dtype)
-        mean, std = self.pixel_mean.flatten().tolist(), self.pixel_std.flatten().tolist()
+        key = (self.pixel_mean._version, self.pixel_std._version, self.pixel_mean.data_ptr())
+        hit = self.__dict__.get("_mean_std")
+        if hit is None or hit[0] != key:                                 # (a device -> host read: once, not per call)
+            hit = self.__dict__["_mean_std"] = (key, self.pixel_mean.flatten().tolist(), self.pixel_std.flatten().tolist())
+        mean, std = hit[1], hit[2]
         for i, im in enumerate(ims):
             ops.preprocess_pad(im.contiguous(), out[i], mean, std)
         return out, sizes
