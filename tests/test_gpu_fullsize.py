@@ -327,3 +327,45 @@ def test_stage3_supervised_branch_at_config5_image_size_against_the_oracle():
         assert err <= (2e-2 if unmatched else 2e-3), (k, err, unmatched)
     print(f"stage-3 at 800x1216 / 768x1024: losses {dict((k, round(float(v), 5)) for k, v in losses.items())}, sampled ROIs not in the oracle's set: "
           f"{unmatched} of 1024, worst gradient relL2 {worst[1]:.1e} ({worst[0]})")
+
+
+def test_stage3_teacher_weak_branch_at_config5_image_size_against_the_oracle():
+    """The teacher's pass of config #5 at 800 x 1216 (training-mode top-k as the reference runs it, trainer.py:474-477): the 1000
+    proposals as a set (1e-2 px; ulp-tied candidates may trade places at the cut), the <= 100 detections — classes, scores 1e-4,
+    boxes 1e-2 px — and the pseudo labels that pass the 0.7 threshold."""
+    from oracle import frcnn_oracle as FO
+    from sos_wsod_amd.frcnn import TwoStagePseudoLabGeneralizedRCNN
+    from sos_wsod_amd.semisup import process_pseudo_label
+    K = 20
+    P = FO.make_params(K, tag="s3wfull", head_scale=14.0)
+    H, W = 800, 1216
+    img = FO.make_image(H, W, "s3wfull0")
+    props_ref, dets_ref = FO.weak_forward(P, [img], K)
+    model = TwoStagePseudoLabGeneralizedRCNN(num_classes=K, compute_dtype=torch.float32).cuda()
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in P.items():
+            sd[k].copy_(torch.from_numpy(v))
+    model.train()
+    data = [{"image": torch.from_numpy(img).cuda(), "height": H, "width": W}]
+    with torch.no_grad():
+        _, props, dets, _ = model(data, branch="unsup_data_weak")
+    pb = props[0].proposal_boxes.tensor.cpu().numpy()
+    rb = props_ref[0]["boxes"]
+    assert len(pb) == len(rb) == 1000
+    d = np.abs(pb[:, None, :] - rb[None, :, :]).max(2)
+    assert int((d.min(1) > 1e-2).sum()) <= 5 and int((d.min(0) > 1e-2).sum()) <= 5
+    want = dets_ref[0]
+    got_b, got_s, got_c = dets[0].pred_boxes.tensor.cpu().numpy(), dets[0].scores.cpu().numpy(), dets[0].pred_classes.cpu().numpy()
+    assert len(got_b) == len(want["pred_boxes"]) > 0
+    # detections in score order; neighbours whose scores tie to 1e-6 may swap
+    order_ok = np.array_equal(got_c, want["pred_classes"])
+    if not order_ok:
+        assert sorted(got_c.tolist()) == sorted(want["pred_classes"].tolist())
+    np.testing.assert_allclose(np.sort(got_s), np.sort(want["scores"]), rtol=1e-4, atol=1e-6)
+    dd = np.abs(got_b[:, None, :] - want["pred_boxes"][None, :, :]).max(2)
+    assert (dd.min(1) <= 1e-2 + 1e-4 * np.abs(got_b).max()).all()
+    pseudo, _ = process_pseudo_label(data, dets, 0.7, "roih")
+    keep = want["scores"] > 0.7
+    assert len(pseudo[0]) == int(keep.sum())
+    print(f"stage-3 teacher at 800x1216: {len(got_b)} detections, {int(keep.sum())} pseudo labels above 0.7, order identical: {order_ok}")
