@@ -755,6 +755,38 @@ def test_detect_postprocess_mask_form_equals_single_workgroup_form(ops, case):
         assert torch.equal(x[:n], y[:n])
 
 
+def test_detect_postprocess_mask_form_randomised(ops):
+    """12 random shapes (R 256 .. 3000, K 1 .. 24, thresholds, box scales, top-k): sw_detect_postprocess2 == sw_detect_postprocess"""
+    from sos_wsod_amd._lib import lib
+    rng = np.random.RandomState(5)
+    used_mask = 0
+    for case in range(12):
+        R = int(rng.randint(256, 3000)); K = int(rng.choice([1, 2, 5, 20, 24]))
+        H, W = int(rng.randint(100, 900)), int(rng.randint(100, 1300))
+        topk = int(rng.choice([10, 100, 600])); topk = min(topk, 16384 // K)
+        thr = float(rng.choice([-3.0e38, 1e-5, 0.05])); nms_thr = float(rng.choice([0.3, 0.5, 0.7]))
+        g = torch.Generator().manual_seed(1000 + case)
+        scores = torch.softmax(torch.randn(R, K + 1, generator=g) * float(rng.choice([1, 4])), 1)
+        scale = float(rng.choice([20, 80, 300]))
+        ctr = torch.rand(R, K, 2, generator=g) * torch.tensor([float(W), float(H)]); wh = torch.rand(R, K, 2, generator=g) * scale + 2
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).reshape(R, 4 * K)
+        scores, boxes = scores.cuda().contiguous(), boxes.cuda().contiguous()
+        used_mask += int(lib.sw_detect_workspace_bytes2(R, K, topk)) > int(lib.sw_detect_workspace_bytes(K, topk)) + 1024
+        got = ops.detect_postprocess(scores, boxes, H, W, thr, nms_thr, topk)
+        dev = scores.device
+        cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+        b = torch.zeros(topk, 4, device=dev); s_ = torch.zeros(topk, device=dev)
+        c_ = torch.zeros(topk, device=dev, dtype=torch.int32); r_ = torch.zeros(topk, device=dev, dtype=torch.int32)
+        ws = torch.empty(int(lib.sw_detect_workspace_bytes(K, topk)), device=dev, dtype=torch.uint8)
+        assert lib.sw_detect_postprocess(R, K, scores.data_ptr(), boxes.data_ptr(), H, W, thr, nms_thr, topk, cnt.data_ptr(), b.data_ptr(),
+                                         s_.data_ptr(), c_.data_ptr(), r_.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        n = int(cnt.item())
+        assert n == int(got[0].item()), (case, R, K, n, int(got[0].item()))
+        for x, y in zip(got[1:], (b, s_, c_, r_)):
+            assert torch.equal(x[:n], y[:n]), (case, R, K)
+    assert used_mask == 12
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,pad", [(8192, 512, 0), (8000, 4096, 128), (32768, 256, 0), (1, 64, 0), (33, 264, 8), (1001, 130, 0),
                                      (700, 24, 4), (5000, 20000, 0)])
