@@ -545,24 +545,36 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
         constexpr int CP = decltype(cpc)::value;
         constexpr bool PLAIN = decltype(plainc)::value != 0;
         constexpr int PPR = WTN / CP;
+        // 64 % PPR == 0: a lane keeps the SAME CP columns for every row piece it handles — its bias values are loaded once per
+        // quarter, not once per element, and the ReLU-mask reference of a full 16-byte-aligned piece is ONE load (fc6's data
+        // gradient 1.258 -> 1.23 ms inside the step; tools/fc7_probe.py: a bias / ReLU / mask epilogue costs 10 us per round of
+        // 256x256 tiles over the plain one)
+        const int c0 = (lane % PPR) * CP;
+        const int nb = n0t + wn * WTN + c0;
+        float bcol[CP];
+#pragma unroll
+        for (int t = 0; t < CP; ++t) bcol[t] = (!PLAIN && g.bias && nb + t < g.N) ? g.bias[nb + t] : 0.f;
+        const bool ref_vec = !PLAIN && g.ref && g.ref_bf16 && CP == 8 && (g.ldr % 8) == 0 && ((((uintptr_t)g.ref) & 15) == 0);
 #pragma unroll
         for (int it = 0; it < (32 * PPR) / 64; ++it) {
           const int pc = it * 64 + lane;
-          const int row = pc / PPR, c0 = (pc % PPR) * CP;
+          const int row = pc / PPR;
           const int m = m0 + wm * WTM + q * 32 + row;
-          const int nb = n0t + wn * WTN + c0;
           if (m >= g.M || nb >= g.N) continue;
           float v[CP];
           *(f32x4*)&v[0] = *(const f32x4*)&wt[row * LDW + c0];
           if (CP == 8) *(f32x4*)&v[CP - 4] = *(const f32x4*)&wt[row * LDW + c0 + 4];
           const bool full = nb + CP <= g.N;
+          u32x4 refw = {0u, 0u, 0u, 0u};
+          const bool ref_piece = ref_vec && full;
+          if (ref_piece) refw = *(const u32x4*)((const unsigned short*)g.ref + (long)m * g.ldr + nb);
 #pragma unroll
           for (int t = 0; t < CP; ++t) {
             const int n = nb + t;
             const bool ok = n < g.N;
             float x = v[t];
             if (!PLAIN) {
-              x += (g.bias && ok) ? g.bias[n] : 0.f;
+              x += bcol[t];
               if (g.relu) x = fmaxf(x, 0.f);
               if (g.drop && ok) x = g.drop[(long)m * g.ldd + n] ? x * g.drop_scale : 0.f;
               if (g.drop_p > 0.f && ok) {                          // identical Bernoulli stream to dropout_mask_kernel (elementwise.hip)
@@ -575,8 +587,10 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
                 x = u >= g.drop_p ? x * g.drop_scale : 0.f;
               }
               if (g.ref && ok) {
-                const float rv = g.ref_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.ref)[(long)m * g.ldr + n])
-                                            : ((const float*)g.ref)[(long)m * g.ldr + n];
+                float rv;
+                if (ref_piece) rv = __uint_as_float((t & 1) ? (refw[(t >> 1) & 3] & 0xFFFF0000u) : (refw[(t >> 1) & 3] << 16));
+                else rv = g.ref_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.ref)[(long)m * g.ldr + n])
+                                     : ((const float*)g.ref)[(long)m * g.ldr + n];
                 x = rv > 0.f ? x * g.ref_scale : 0.f;
               }
             }
