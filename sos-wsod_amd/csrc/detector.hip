@@ -239,7 +239,36 @@ __global__ void roi_align_fwd_kernel(int H, int W, int C, int PH, int PW, float 
     Elem<T>::store(out + (long)row * ld + ((long)c * PH + ph) * PW + pw, __fdiv_rn(v, g.count));
   }
 }
-// backward: dfeat f32 [N][H][W][C] (caller zero-fills) += w * g / count by f32 atomics (ROIAlign_cpu.cpp:286-400)
+// backward: dfeat f32 [N][H][W][C] (caller zero-fills) += w * g / count by f32 atomics (ROIAlign_cpu.cpp:286-400).
+// The bilinear weight of a sample factors into a row part and a column part, and validity / border clamping act per axis, so the
+// contributions of a bin's grid_h x grid_w samples to pixel (Y, X) sum to (sum_iy wy_iy(Y)) * (sum_ix wx_ix(X)) * g / count: with the
+// per-axis sums in registers a bin issues (rows touched) x (columns touched) <= (grid_h + 1)(grid_w + 1) atomics instead of
+// 4 * grid_h * grid_w (grid 4 x 4: 25 for 64).  Sample spacing is bin / ceil(bin) <= 1 pixel, so the touched rows are consecutive.
+// Grids above AXIS_MAX - 1 per axis (a ROI far too large for its level) take the sample-by-sample form.
+constexpr int AXIS_MAX = 9;
+struct AxisW { float w[AXIS_MAX]; int base; };
+__device__ __forceinline__ AxisW align_axis_weights(float start, int p, float bin, int grid, int size) {
+  AxisW a;
+#pragma unroll
+  for (int s = 0; s < AXIS_MAX; ++s) a.w[s] = 0.f;
+  a.base = -1;
+  for (int i = 0; i < grid; ++i) {
+    float y = align_coord(start, p, bin, i, grid);
+    if (y < -1.0f || y > (float)size) continue;
+    if (y <= 0) y = 0;
+    int lo = (int)y, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; y = (float)lo; } else hi = lo + 1;
+    const float l = __fsub_rn(y, (float)lo), h = __fsub_rn(1.0f, l);
+    if (a.base < 0) a.base = lo;
+    const int k0 = lo - a.base, k1 = hi - a.base;
+#pragma unroll
+    for (int s = 0; s < AXIS_MAX; ++s) {                     // (static register indices: a dynamic one would put the array in scratch)
+      if (s == k0) a.w[s] += h;
+      if (s == k1) a.w[s] += l;
+    }
+  }
+  return a;
+}
 template <typename T>
 __global__ void roi_align_bwd_kernel(int H, int W, int C, int PH, int PW, float scale, int sampling_ratio,
                                      const T* __restrict__ gout, long ld, const float* __restrict__ rois,
@@ -253,6 +282,22 @@ __global__ void roi_align_bwd_kernel(int H, int W, int C, int PH, int PW, float 
     const AlignGeom g = align_geom(rois + (long)row * 5, scale, PH, PW, sampling_ratio);
     const float go = Elem<T>::load(gout + (long)row * ld + ((long)c * PH + ph) * PW + pw);
     float* d = dfeat + (long)g.batch * H * W * C + c;
+    if (g.grid_h < AXIS_MAX && g.grid_w < AXIS_MAX && g.bin_h <= (float)g.grid_h && g.bin_w <= (float)g.grid_w) {     // (sample spacing <= 1)
+      const AxisW ay = align_axis_weights(g.start_h, ph, g.bin_h, g.grid_h, H);
+      const AxisW ax = align_axis_weights(g.start_w, pw, g.bin_w, g.grid_w, W);
+      if (ay.base < 0 || ax.base < 0) continue;
+      const float gs = __fdiv_rn(go, g.count);
+#pragma unroll
+      for (int ry = 0; ry < AXIS_MAX; ++ry) {
+        if (ay.w[ry] == 0.f) continue;
+        const float gy = __fmul_rn(gs, ay.w[ry]);
+        float* drow = d + (long)(ay.base + ry) * W * C;
+#pragma unroll
+        for (int rx = 0; rx < AXIS_MAX; ++rx)
+          if (ax.w[rx] != 0.f) atomicAdd(drow + (long)(ax.base + rx) * C, __fmul_rn(gy, ax.w[rx]));
+      }
+      continue;
+    }
     for (int iy = 0; iy < g.grid_h; ++iy) {
       const float y = align_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
       for (int ix = 0; ix < g.grid_w; ++ix) {
