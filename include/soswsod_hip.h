@@ -56,6 +56,11 @@ typedef struct sw_epilogue {
    * slab of this workspace (sw_gemm_splitk_workspace_floats floats), a second kernel adds the slabs in fixed order into C
    * (overwritten) — no atomics.  Also used, when given, for the tail peel of the large f32-output GEMMs (see sw_gemm). */
   float* splitk_workspace;
+  /* residual [M][ld_res] or NULL (dtype res_dtype): v = v + bias + residual before the ReLU — the shortcut add of a ResNet
+   * bottleneck (detectron2/modeling/backbone/resnet.py:205-212 `out += shortcut; out = F.relu_(out)`) inside the 1x1 conv3 GEMM */
+  const void* residual;
+  long ld_res;
+  int res_dtype;
 } sw_epilogue;
 
 /* ---- dense contractions (reference: cuBLAS via torch Linear — box_head.py:88-90,

@@ -27,6 +27,7 @@ class Epilogue(ctypes.Structure):
         ("out_dtype", c_int), ("accumulate_atomic", c_int), ("absmax_out", c_void_p),
         ("drop_seed", c_u64), ("drop_offset", c_u64), ("drop_hash_p", c_float), ("drop_offset_dev", c_void_p),
         ("splitk_workspace", c_void_p),
+        ("residual", c_void_p), ("ld_res", c_long), ("res_dtype", c_int),
     ]
 
 

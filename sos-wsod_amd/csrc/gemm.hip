@@ -36,6 +36,7 @@ struct GemmArgs {
   unsigned long long drop_seed_mixed, drop_offset; float drop_p;   // hash dropout: splitmix64(seed) pre-mixed on the host side
   const unsigned long long* drop_offset_dev;                       // optional device-resident part of the stream position
   const void* ref; long ldr; float ref_scale; int ref_bf16;
+  const void* res; long ldres; int res_bf16;            // residual added before the ReLU
   int relu, out_bf16, atomic, oihw_cin, staged_out;
   unsigned a_bytes, b_bytes;       // extents of the A / B operands (buffer descriptors' num_records)
   long slab_stride;                // > 0: split z stores its partial tile to C + z*slab_stride (plain stores, no atomics)
@@ -575,6 +576,8 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
             float x = v[t];
             if (!PLAIN) {
               x += bcol[t];
+              if (g.res && ok) x += g.res_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.res)[(long)m * g.ldres + n])
+                                               : ((const float*)g.res)[(long)m * g.ldres + n];
               if (g.relu) x = fmaxf(x, 0.f);
               if (g.drop && ok) x = g.drop[(long)m * g.ldd + n] ? x * g.drop_scale : 0.f;
               if (g.drop_p > 0.f && ok) {                          // identical Bernoulli stream to dropout_mask_kernel (elementwise.hip)
@@ -636,7 +639,7 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
           }
         }
       };
-      const bool plain_ep = !g.bias && !g.relu && !g.drop && !(g.drop_p > 0.f) && !g.ref;
+      const bool plain_ep = !g.bias && !g.relu && !g.drop && !(g.drop_p > 0.f) && !g.ref && !g.res;
       const bool bf16_rows = g.out_bf16 && g.slab_stride <= 0 && !g.atomic;
       if (bf16_rows) { if (plain_ep) pieces(IntC<8>{}, IntC<1>{}); else pieces(IntC<8>{}, IntC<0>{}); }
       else { if (plain_ep) pieces(IntC<4>{}, IntC<1>{}); else pieces(IntC<4>{}, IntC<0>{}); }
@@ -661,6 +664,8 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
         const int m = m0 + wm * WTM + lrow;
         const bool ok = nok && m < g.M;
         float v = acc[i][j][e] + bcol;
+        if (g.res && ok) v += g.res_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.res)[(long)m * g.ldres + n])
+                                         : ((const float*)g.res)[(long)m * g.ldres + n];
         if (g.relu) v = fmaxf(v, 0.f);
         if (g.drop && ok) v = g.drop[(long)m * g.ldd + n] ? v * g.drop_scale : 0.f;
         if (g.drop_p > 0.f && ok) {                        // identical Bernoulli stream to dropout_mask_kernel (elementwise.hip)
@@ -976,7 +981,7 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
   // launch on 128x128 tiles with split-K sized to fill the chip once: deterministic slabs + ordered fold when the caller
   // gave a split-K workspace, else f32 atomics into the zeroed column block.
   const bool plain = (!ep || (ep->out_dtype == SW_F32 && !ep->bias && !ep->relu && !ep->drop_mask && !(ep->drop_hash_p > 0.f) && !ep->relu_ref &&
-                              !ep->accumulate_atomic && !ep->absmax_out));
+                              !ep->accumulate_atomic && !ep->absmax_out && !ep->residual));
   float* const det_ws = (ep && plain) ? ep->splitk_workspace : nullptr;
   {
     static const bool no_peel = getenv("SW_GEMM_NO_PEEL") != nullptr;    // development switch
@@ -1011,6 +1016,7 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
   if (ep) {
     g.bias = ep->bias; g.drop = ep->drop_mask; g.ldd = ep->ld_drop; g.drop_scale = ep->drop_scale;
     g.ref = ep->relu_ref; g.ldr = ep->ld_ref; g.ref_scale = ep->ref_scale; g.ref_bf16 = ep->ref_dtype == SW_BF16;
+    g.res = ep->residual; g.ldres = ep->ld_res; g.res_bf16 = ep->res_dtype == SW_BF16;
     g.relu = ep->relu; g.out_bf16 = ep->out_dtype == SW_BF16; g.atomic = ep->accumulate_atomic; g.absmax = ep->absmax_out;
     if (!ep->drop_mask && ep->drop_hash_p > 0.f) {
       unsigned long long x = ep->drop_seed;                  // splitmix64(seed), as the mask kernel mixes it

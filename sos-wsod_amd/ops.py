@@ -104,7 +104,7 @@ def _need_gpu(*ts):
 
 
 def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_ref=None, ref_scale=1.0,
-                  out_dtype=torch.float32, atomic=False, absmax_out=None, drop_hash=None, splitk_workspace=None):
+                  out_dtype=torch.float32, atomic=False, absmax_out=None, drop_hash=None, splitk_workspace=None, residual=None):
     """drop_hash=(seed, offset, p[, device counter]): dropout decided in the epilogue by the hash that sw_dropout_mask uses (no
     mask tensor); with a device counter (uint64 scalar tensor) the stream position is offset + *counter at run time"""
     ep = Epilogue()
@@ -125,7 +125,10 @@ def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_re
         ep.drop_seed, ep.drop_offset, ep.drop_hash_p = int(drop_hash[0]) & (2 ** 64 - 1), int(drop_hash[1]), float(drop_hash[2])
         if len(drop_hash) > 3 and drop_hash[3] is not None:
             ep.drop_offset_dev = drop_hash[3].data_ptr()
-    ep._keepalive = (bias, drop_mask, relu_ref, absmax_out, splitk_workspace, drop_hash)     # the struct holds raw pointers only
+    ep.residual = None if residual is None else residual.data_ptr()
+    ep.ld_res = 0 if residual is None else residual.stride(0)
+    ep.res_dtype = SW_F32 if residual is None else dt(residual)
+    ep._keepalive = (bias, drop_mask, relu_ref, absmax_out, splitk_workspace, drop_hash, residual)     # the struct holds raw pointers only
     return ep
 
 

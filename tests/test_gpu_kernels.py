@@ -755,6 +755,25 @@ def test_detect_postprocess_mask_form_equals_single_workgroup_form(ops, case):
         assert torch.equal(x[:n], y[:n])
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(7600, 1024, 256), (8000, 4096, 1024), (300, 72, 64)])
+def test_gemm_epilogue_residual_add(ops, dtype, M, N, K):
+    """sw_epilogue.residual: y = relu(x @ W^T + bias + residual) — the bottleneck's shortcut add inside conv3's GEMM (resnet.py:205-212);
+    the 128x128 tile (K < 1024), the ping-pong 256x256 tile and a ragged small shape"""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(M, K, generator=g).cuda().to(dtype); w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().to(dtype)
+    b = torch.randn(N, generator=g).cuda(); res = torch.randn(M, N, generator=g).cuda().to(dtype)
+    y = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(x, w, y, M, N, K, ep=ops.make_epilogue(bias=b, relu=True, out_dtype=dtype, residual=res))
+    ref = torch.relu(x.double() @ w.double().t() + b.double() + res.double())
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    assert float((y.double() - ref).abs().max()) <= tol * float(ref.abs().max())
+    y2 = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(x, w, y2, M, N, K, ep=ops.make_epilogue(bias=b, relu=False, out_dtype=dtype, residual=res))
+    ref2 = x.double() @ w.double().t() + b.double() + res.double()
+    assert float((y2.double() - ref2).abs().max()) <= tol * float(ref2.abs().max())
+
+
 def test_detect_postprocess_mask_form_randomised(ops):
     """12 random shapes (R 256 .. 3000, K 1 .. 24, thresholds, box scales, top-k): sw_detect_postprocess2 == sw_detect_postprocess"""
     from sos_wsod_amd._lib import lib

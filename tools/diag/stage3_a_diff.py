@@ -43,7 +43,7 @@ with torch.no_grad():
     for f, l in zip(feats, lg):
         tt = head.conv(f, relu=True)
         n, H, W, C = tt.shape
-        y = frcnn._LinearFn.apply(tt.reshape(n * H * W, C), st.w, st.bias, None, False, True, (3, 12), head.objectness_logits.weight,
+        y = frcnn._LinearFn.apply(tt.reshape(n * H * W, C), st.w, st.bias, None, False, True, (3, 12), None, head.objectness_logits.weight,
                                   head.anchor_deltas.weight, head.objectness_logits.bias, head.anchor_deltas.bias)
         print("level", H, W, "logits differing between per-level and concatenated GEMM:", int((y[:, :3].reshape(n, -1) != l).sum()), "of", l.numel())
 # --- the proposals themselves
