@@ -391,7 +391,9 @@ def main():
                 import socket
                 with socket.socket() as sk:
                     sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
-                dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+                import datetime
+                dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                        timeout=datetime.timedelta(seconds=60))
                 try:
                     md = build(device, dtype); md.train()
                     gs = [{"params": [p], "lr": 2e-3 if nm.endswith(".bias") else 1e-3, "weight_decay": 0.0 if nm.endswith(".bias") else 5e-4}
