@@ -20,6 +20,6 @@ PY
       python tools/prof_summary.py $f $n gpurun_out/round_kernel_stats.csv | head -45
       rm -rf gpurun_out/prof_round ;;
     traffic) bash tools/pmc_traffic.sh | tail -40 ;;
-    mfma) bash tools/pmc_mfma.sh | tail -60 ;;
+    mfma) bash tools/pmc_mfma.sh fc6_fwd fc6_dgrad fc6_wgrad conv5_3 wgrad_grouped | tail -60 ;;
   esac
 done
