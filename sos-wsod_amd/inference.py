@@ -56,6 +56,45 @@ def oicr_inference(heads, features, proposals):
     return [result], all_scores.unsqueeze(0), all_boxes.unsqueeze(0)
 
 
+@torch.no_grad()
+def oicr_view_scores(heads, feat_nhwc, proposals):
+    """The scores-only inference of several views of ONE size in one pass (the TTA wrapper's flip pairs): feat_nhwc (N, H, W, C),
+    proposals: N Instances.  Same arithmetic per view as oicr_inference — ROIPool with the objectness prior, fc6 / fc7, the packed
+    predictor GEMM, sw_oicr_predict — on stacked rows; -> [(all_scores (R_i, K+1), all_boxes (R_i, 4K))] per view."""
+    dt_ = heads.compute_dtype
+    dev = feat_nhwc.device
+    feat = feat_nhwc.contiguous()
+    if feat.dtype != dt_:
+        feat = feat.to(dt_)
+    assert len(proposals) == feat.shape[0]
+    K = heads.num_classes
+    boxes = [p.proposal_boxes.tensor.to(device=dev, dtype=torch.float32) for p in proposals]
+    obj = torch.cat([p.objectness_logits.to(device=dev, dtype=torch.float32) for p in proposals]).contiguous()
+    counts = [b.shape[0] for b in boxes]
+    allb = torch.cat(boxes, 0).contiguous()
+    R = allb.shape[0]
+    P = heads.box_pooler.output_size
+    C = feat.shape[3]
+    idx = torch.cat([torch.full((n, 1), float(i), device=dev) for i, n in enumerate(counts)], 0)
+    rois = torch.cat([idx, allb], 1).contiguous()
+    pooled = torch.empty(R, C * P * P, device=dev, dtype=dt_)
+    argmax = torch.empty(R, C * P * P, device=dev, dtype=ops.roi_argmax_dtype(feat.shape[1], feat.shape[2]))
+    ops.roi_pool_fwd(feat, rois, pooled, argmax, heads.box_pooler.scale, P, P, row_scale=obj, row_scale_add=1.0)
+    h = heads.box_head(pooled)
+    params = [p.detach() for p in heads._flat_params()]
+    Wh, bh = heads._pack_head_weights(params, dev)
+    LD = heads.ld_head
+    logits = torch.empty(R, LD, device=dev, dtype=torch.float32)
+    ops.gemm(h, Wh, logits, R, LD, h.shape[1], ep=ops.make_epilogue(bias=bh, out_dtype=torch.float32))
+    all_scores = torch.empty(R, K + 1, device=dev, dtype=torch.float32)
+    all_boxes = torch.empty(R, 4 * K, device=dev, dtype=torch.float32)
+    ops.oicr_predict(logits, R, K, heads.refine_K, 2 * K, 5 * K + 1, allb, heads.bbox_reg_weights, SCALE_CLAMP, all_scores, all_boxes)
+    out, r0 = [], 0
+    for n in counts:
+        out.append((all_scores[r0:r0 + n], all_boxes[r0:r0 + n])); r0 += n
+    return out
+
+
 def detector_postprocess(results, output_height, output_width):
     """modeling/postprocessing.py:9-44 (boxes only): scale the detections from the network's input resolution to the
     requested output resolution, clip, drop empty boxes."""

@@ -135,6 +135,15 @@ class MultiInputRCNN(nn.Module):
             return MultiInputRCNN._postprocess(results, batched_inputs, image_sizes)
         return results, all_scores, all_boxes
 
+    @torch.no_grad()
+    def view_scores(self, views):
+        """per-view class scores and decoded boxes of several views of ONE size in one pass (test-time augmentation: a view and its
+        flip): backbone on the batch, heads on stacked rows -> [(scores (R, K+1), boxes (R, 4K))] in view coordinates"""
+        from .inference import oicr_view_scores
+        assert not self.training and len({tuple(v["image"].shape[-2:]) for v in views}) == 1
+        f = self.backbone.forward_nhwc(self._views_to_nhwc([v["image"] for v in views]))
+        return oicr_view_scores(self.roi_heads, f, [v["proposals"] for v in views])
+
     @staticmethod
     def _postprocess(instances, batched_inputs, image_sizes):
         """rcnn_multi.py:276-291: rescale the detections to the dataset image size (`height`/`width` of the input dict)"""

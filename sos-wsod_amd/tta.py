@@ -90,12 +90,13 @@ class DeviceTTAMapper:
 class GeneralizedRCNNWithTTAAVG(torch.nn.Module):
     """same call interface as the model's inference forward; `tta_mapper(dict) -> [(view dict, ViewTransform)]`"""
 
-    def __init__(self, model, tta_mapper=None):
+    def __init__(self, model, tta_mapper=None, batch_views=True):
         super().__init__()
         if isinstance(model, torch.nn.parallel.DistributedDataParallel):
             model = model.module
         self.model = model
         self.tta_mapper = tta_mapper if tta_mapper is not None else DeviceTTAMapper()
+        self.batch_views = bool(batch_views)
 
     @torch.no_grad()
     def __call__(self, batched_inputs: List[dict]):
@@ -112,9 +113,24 @@ class GeneralizedRCNNWithTTAAVG(torch.nn.Module):
         sum_scores = sum_boxes = None
         heads.test_scores_only = True             # per-view NMS / top-k (and their host sync) would be thrown away
         try:
-            for view, tfm in views:
-                _, scores, boxes = self.model.inference([view], do_postprocess=False)       # (1, R, K+1), (1, R, 4K), view coordinates
-                scores, boxes = scores[0], boxes[0]
+            # consecutive views of one size (a scale and its flip) run as one batch: the batch-1 launches of a 375 x 500 image's
+            # views fill half the chip (12 views: 26.6 -> see tools/infer_bench.py); the per-view results enter the sums in the
+            # mapper's order either way
+            per_view = []
+            i = 0
+            while i < len(views):
+                j = i + 1
+                while (self.batch_views and j < len(views) and j - i < 2
+                       and views[j][0]["image"].shape == views[i][0]["image"].shape):
+                    j += 1
+                if j - i > 1 and hasattr(self.model, "view_scores"):
+                    per_view += self.model.view_scores([v for v, _ in views[i:j]])
+                else:
+                    for v, _ in views[i:j]:
+                        _, sc, bx = self.model.inference([v], do_postprocess=False)       # (1, R, K+1), (1, R, 4K), view coordinates
+                        per_view.append((sc[0], bx[0]))
+                i = j
+            for (view, tfm), (scores, boxes) in zip(views, per_view):
                 R = boxes.shape[0]
                 back = tfm.inverse_box(boxes.reshape(R * K, 4)).reshape(R, 4 * K)
                 if (tfm.orig_hw != orig):                        # the mapper resized from the tensor's size, not the dataset's

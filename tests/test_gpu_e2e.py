@@ -880,3 +880,34 @@ def test_trainer_skips_images_without_labels_and_iter_size_accumulates():
     torch.cuda.synchronize()
     for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.equal(p1.detach(), p2.detach()), n1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tta_flip_pairs_as_one_batch_equal_single_view_calls(dtype):
+    """GeneralizedRCNNWithTTAAVG(batch_views=True) runs a scale and its flip as one batch of two: the view-averaged score / box matrices
+    equal the one-view-per-call form (fp32: 1e-5; bf16: the batch-2 convolutions may take another kernel variant, 2e-2) and the
+    merged detections agree"""
+    from sos_wsod_amd.structures import Boxes, Instances
+    from sos_wsod_amd.tta import DeviceTTAMapper, GeneralizedRCNNWithTTAAVG
+    K, dan = 20, (256, 256)
+    P = O.make_params(K, dan, tag="pttab", head_scale=20.0)
+    model = build_model(K, dan, dtype); load_params(model, P); model.eval()
+    g = torch.Generator().manual_seed(4)
+    H, W, R = 120, 160, 150
+    x1 = torch.rand(R, generator=g) * (W - 32); y1 = torch.rand(R, generator=g) * (H - 32)
+    b = torch.stack([x1, y1, x1 + 16 + torch.rand(R, generator=g) * (W - x1 - 16), y1 + 16 + torch.rand(R, generator=g) * (H - y1 - 16)], 1)
+    p = Instances((H, W)); p.proposal_boxes = Boxes(b.cuda()); p.objectness_logits = torch.rand(R, generator=g).cuda()
+    inp = {"image": torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8).cuda(), "proposals": p, "height": H, "width": W}
+    mapper = DeviceTTAMapper(min_sizes=(96, 128, 176), max_size=400, flip=True)
+    outs = {}
+    for mode in (True, False):
+        tta = GeneralizedRCNNWithTTAAVG(model, mapper, batch_views=mode)
+        det = tta([inp])[0]["instances"]
+        outs[mode] = (tta.last_avg[0].clone(), tta.last_avg[1].clone(), det)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a, c in zip(outs[True][:2], outs[False][:2]):
+        assert float((a - c).abs().max()) <= tol * float(c.abs().max())
+    if dtype == torch.float32:
+        da, dc = outs[True][2], outs[False][2]
+        assert len(da) == len(dc) and torch.equal(da.pred_classes, dc.pred_classes)
+        assert float((da.pred_boxes.tensor - dc.pred_boxes.tensor).abs().max()) <= 1e-2
