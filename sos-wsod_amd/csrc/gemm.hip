@@ -651,6 +651,23 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
   const bool staged = g.staged_out;                          // host: bf16 out, plain store, N % 8 == 0, ldc % 8 == 0
   unsigned short* stile = (unsigned short*)smem + wave * (WTM * WTN);
   if (staged) __syncthreads();                               // every wave is done reading the last K-tile
+  // residual of a staged bf16 tile: fetched with the store phase's 16-byte row pieces INTO the staging tile, read per element from
+  // LDS and overwritten in place by the result (per-element 2-byte global loads cost the memory-bound 1x1-convolution GEMMs
+  // 0.7 ms per Stage-3 iteration); the wave's own LDS accesses execute in order: no barrier
+  const bool res_staged = staged && g.res && g.res_bf16 && (g.ldres % 8) == 0 && ((((uintptr_t)g.res) & 15) == 0);
+  if (res_staged) {
+    constexpr int CPRW = WTN / 8;
+#pragma unroll
+    for (int q = 0; q < (WTM * CPRW) / 64; ++q) {
+      const int idx = q * 64 + lane, lrow = idx / CPRW, ch = idx % CPRW;
+      const int m = m0 + wm * WTM + lrow, n = n0t + wn * WTN + ch * 8;
+      u32x4 rv = {0u, 0u, 0u, 0u};
+      if (m < g.M && n < g.N) rv = *(const u32x4*)((const unsigned short*)g.res + (long)m * g.ldres + n);
+      *(u32x4*)(stile + lrow * WTN + ch * 8) = rv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (also keeps the compiler from moving the 2-byte reads above these stores)
+    __builtin_amdgcn_wave_barrier();
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -664,8 +681,9 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
         const int m = m0 + wm * WTM + lrow;
         const bool ok = nok && m < g.M;
         float v = acc[i][j][e] + bcol;
-        if (g.res && ok) v += g.res_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.res)[(long)m * g.ldres + n])
-                                         : ((const float*)g.res)[(long)m * g.ldres + n];
+        if (res_staged) v += bf16_bits_to_f32(stile[lrow * WTN + j * TS + r]);
+        else if (g.res && ok) v += g.res_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.res)[(long)m * g.ldres + n])
+                                              : ((const float*)g.res)[(long)m * g.ldres + n];
         if (g.relu) v = fmaxf(v, 0.f);
         if (g.drop && ok) v = g.drop[(long)m * g.ldd + n] ? v * g.drop_scale : 0.f;
         if (g.drop_p > 0.f && ok) {                        // identical Bernoulli stream to dropout_mask_kernel (elementwise.hip)
