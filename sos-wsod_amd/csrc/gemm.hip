@@ -655,14 +655,18 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
   // LDS and overwritten in place by the result (per-element 2-byte global loads cost the memory-bound 1x1-convolution GEMMs
   // 0.7 ms per Stage-3 iteration); the wave's own LDS accesses execute in order: no barrier
   const bool res_staged = staged && g.res && g.res_bf16 && (g.ldres % 8) == 0 && ((((uintptr_t)g.res) & 15) == 0);
-  if (res_staged) {
+  // the same for the ReLU-mask reference when there is no residual (a data gradient masked by its consumer's input)
+  const bool ref_staged = staged && !g.res && g.ref && g.ref_bf16 && (g.ldr % 8) == 0 && ((((uintptr_t)g.ref) & 15) == 0);
+  if (res_staged || ref_staged) {
+    const unsigned short* src = (const unsigned short*)(res_staged ? g.res : g.ref);
+    const long lds_ = res_staged ? g.ldres : g.ldr;
     constexpr int CPRW = WTN / 8;
 #pragma unroll
     for (int q = 0; q < (WTM * CPRW) / 64; ++q) {
       const int idx = q * 64 + lane, lrow = idx / CPRW, ch = idx % CPRW;
       const int m = m0 + wm * WTM + lrow, n = n0t + wn * WTN + ch * 8;
       u32x4 rv = {0u, 0u, 0u, 0u};
-      if (m < g.M && n < g.N) rv = *(const u32x4*)((const unsigned short*)g.res + (long)m * g.ldres + n);
+      if (m < g.M && n < g.N) rv = *(const u32x4*)(src + (long)m * lds_ + n);
       *(u32x4*)(stile + lrow * WTN + ch * 8) = rv;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (also keeps the compiler from moving the 2-byte reads above these stores)
@@ -695,7 +699,9 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
           const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
           v = u >= g.drop_p ? v * g.drop_scale : 0.f;
         }
-        if (g.ref && ok) {
+        if (ref_staged) {
+          v = bf16_bits_to_f32(stile[lrow * WTN + j * TS + r]) > 0.f ? v * g.ref_scale : 0.f;
+        } else if (g.ref && ok) {
           const float rv = g.ref_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.ref)[(long)m * g.ldr + n])
                                       : ((const float*)g.ref)[(long)m * g.ldr + n];
           v = rv > 0.f ? v * g.ref_scale : 0.f;
