@@ -376,9 +376,17 @@ int sw_scale_cols_loss(int dtype, int M, int N, int n_valid, const float* in, lo
  * DatasetMapperTTAAVG test_time_augmentation_avg.py:199-310): out = clip8((2^21 + sum_t in[first + t] * kk[o][t]) >> 22) along
  * x (horizontal != 0: out (C, H, out_size)) or y (out (C, out_size, W)).  bounds int32 [out_size][2] = (first input index, tap
  * count), kk int32 [out_size][ksize] = 22-bit fixed-point weights, both DEVICE arrays computed by the caller as Pillow's
- * precompute_coeffs does.  out_flip (optional): the same rows mirrored in x.  Bit exact with Pillow (tests/golden/resize_*.npz). */
-int sw_resize_pass_u8(int C, int H, int W, int out_size, int horizontal, const uint8_t* in, const int32_t* bounds,
-                      const int32_t* kk, int ksize, uint8_t* out, uint8_t* out_flip, sw_stream_t stream);
+ * precompute_coeffs does.  in_ld / in_plane: row and plane strides of `in` in bytes (a crop window of a larger image — the mapper's
+ * CropTransform, dataset_mapper.py:278-285 — is `in` offset to its first pixel with the parent's strides).  out_flip (optional): the
+ * same rows mirrored in x.  Bit exact with Pillow (tests/golden/resize_*.npz). */
+int sw_resize_pass_u8(int C, int H, int W, long in_ld, long in_plane, int out_size, int horizontal, const uint8_t* in,
+                      const int32_t* bounds, const int32_t* kk, int ksize, uint8_t* out, uint8_t* out_flip, sw_stream_t stream);
+/* RandomBrightness + RandomSaturation of the 4-view training mapper (uwsod/detectron2/data/transforms/augmentation_impl.py:403-455
+ * through fvcore's BlendTransform on a uint8 image): mode bit 0 = brightness `u8(clip(f32(w_bright) * px))`, bit 1 = saturation
+ * `u8(clip(src_w_sat * grey + f64(f32(w_sat) * px)))` with grey = px0 * 0.299 + px1 * 0.587 + px2 * 0.114 in double on the
+ * brightened pixels, src_w_sat = 1 - w (host double).  in / out planar u8 [3][H][W]; out_flip (optional): rows mirrored in x. */
+int sw_color_jitter_u8(int H, int W, int mode, const uint8_t* in, float w_bright, double src_w_sat, float w_sat, uint8_t* out,
+                       uint8_t* out_flip, sw_stream_t stream);
 /* The four views' (R,4) proposal boxes and (R,) objectness logits of one image (box_ptrs4 / obj_ptrs4: HOST arrays of 4
  * device pointers) -> boxes [4][R][4], obj [4][R], rois [2][2R][5] = (batch index 0 | 1, box) per scale
  * (poolers.py:81-108 convert_boxes_to_pooler_format for the view / flipped-view pair of a scale). */

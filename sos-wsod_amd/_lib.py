@@ -147,8 +147,9 @@ SIGNATURES = {
     "sw_loss_finalize": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_scale_cols_loss": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_float,
                                    c_void_p, c_long, c_void_p]),
-    "sw_resize_pass_u8": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                  c_void_p]),
+    "sw_resize_pass_u8": (c_int, [c_int, c_int, c_int, c_long, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                  c_void_p, c_void_p]),
+    "sw_color_jitter_u8": (c_int, [c_int, c_int, c_int, c_void_p, c_float, ctypes.c_double, c_float, c_void_p, c_void_p, c_void_p]),
     "sw_transpose_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "sw_stage_blocks": (c_int, [c_int, c_int, c_int]),
     "sw_stage_weights_multi": (c_int, [c_int, c_int, c_void_p, c_int, c_float, c_void_p]),

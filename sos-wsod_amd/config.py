@@ -107,7 +107,8 @@ def get_cfg() -> CfgNode:
                           POOLER_SAMPLING_RATIO=0, POOLER_TYPE="ROIAlignV2", NUM_FC=0, FC_DIM=1024, NUM_CONV=0,
                           CONV_DIM=256, NORM="", CLS_AGNOSTIC_BBOX_REG=False, TRAIN_ON_PRED_BOXES=False),
     ))
-    C.INPUT = CN(dict(FORMAT="BGR", MIN_SIZE_TRAIN=(800,), MAX_SIZE_TRAIN=1333, MIN_SIZE_TEST=800, MAX_SIZE_TEST=1333))
+    C.INPUT = CN(dict(FORMAT="BGR", MIN_SIZE_TRAIN=(800,), MAX_SIZE_TRAIN=1333, MIN_SIZE_TRAIN_SAMPLING="choice", MIN_SIZE_TEST=800,
+                      MAX_SIZE_TEST=1333, CROP=dict(ENABLED=False, TYPE="relative_range", SIZE=[0.9, 0.9])))
     C.DATASETS = CN(dict(TRAIN=(), TEST=(), PROPOSAL_FILES_TRAIN=(), PROPOSAL_FILES_TEST=(),
                          PRECOMPUTED_PROPOSAL_TOPK_TRAIN=2000, PRECOMPUTED_PROPOSAL_TOPK_TEST=1000))
     C.DATALOADER = CN(dict(NUM_WORKERS=4))

@@ -723,9 +723,9 @@ __global__ void pack_views_kernel(int R, PackViewsArgs a, float* __restrict__ bo
 // `bounds` (first input index, tap count) and the 22-bit fixed-point coefficients `kk` come from the host, computed in double
 // precision exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do (sos_wsod_amd.resize).  out_flip (optional) also
 // receives the row mirrored in x: the h-flipped view of the multi-view mapper in the same launch.
-__global__ void resize_pass_u8_kernel(int C, int H, int W, int OH, int OW, int horizontal, const uint8_t* __restrict__ in,
-                                      const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
-                                      uint8_t* __restrict__ out, uint8_t* __restrict__ out_flip) {
+__global__ void resize_pass_u8_kernel(int C, int H, int W, long in_ld, long in_plane, int OH, int OW, int horizontal,
+                                      const uint8_t* __restrict__ in, const int* __restrict__ bounds, const int* __restrict__ kk,
+                                      int ksize, uint8_t* __restrict__ out, uint8_t* __restrict__ out_flip) {
   const long total = (long)C * OH * OW;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int x = (int)(i % OW); const long t = i / OW;
@@ -735,16 +735,55 @@ __global__ void resize_pass_u8_kernel(int C, int H, int W, int OH, int OW, int h
     const int* k = kk + (long)o * ksize;
     int ss = 1 << 21;
     if (horizontal) {
-      const uint8_t* p = in + ((long)c * H + y) * W + first;
+      const uint8_t* p = in + (long)c * in_plane + (long)y * in_ld + first;
       for (int j = 0; j < n; ++j) ss += (int)p[j] * k[j];
     } else {
-      const uint8_t* p = in + ((long)c * H + first) * W + x;
-      for (int j = 0; j < n; ++j) ss += (int)p[(long)j * W] * k[j];
+      const uint8_t* p = in + (long)c * in_plane + (long)first * in_ld + x;
+      for (int j = 0; j < n; ++j) ss += (int)p[(long)j * in_ld] * k[j];
     }
     int v = ss >> 22;
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
     out[i] = (uint8_t)v;
     if (out_flip) out_flip[((long)c * OH + y) * OW + (OW - 1 - x)] = (uint8_t)v;
+  }
+}
+
+// RandomBrightness then RandomSaturation of the training mapper (augmentation_impl.py:403-455), each a fvcore BlendTransform on
+// a uint8 HWC image: `np.clip(src_weight * src_image + dst_weight * img.astype(float32), 0, 255).astype(uint8)`.
+//   brightness: src_image = 0 -> float32 product w * px, clipped, truncated.
+//   saturation: src_image = img.dot([0.299, 0.587, 0.114]) of the brightened uint8 image in DOUBLE (channel 0 takes 0.299 whatever
+//   the channel order is), src_weight = 1 - w a python double, dst_weight * img a float32 product -> the sum is a double.
+// Planar (3, H, W) in / out; out_flip (optional) receives the rows mirrored in x (the mapper's HFlipTransform comes after the blends).
+__global__ void color_jitter_u8_kernel(int H, int W, int mode, const uint8_t* __restrict__ in, float w_bright, double src_w_sat,
+                                       float w_sat, uint8_t* __restrict__ out, uint8_t* __restrict__ out_flip) {
+  const long plane = (long)H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+    uint8_t b[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      b[c] = in[c * plane + i];
+      if (mode & 1) {
+        float f = __fmul_rn(w_bright, (float)b[c]);
+        f = fminf(fmaxf(f, 0.f), 255.f);
+        b[c] = (uint8_t)(int)f;
+      }
+    }
+    if (mode & 2) {
+      const double g = __dadd_rn(__dadd_rn(__dmul_rn((double)b[0], 0.299), __dmul_rn((double)b[1], 0.587)), __dmul_rn((double)b[2], 0.114));
+      const double sg = __dmul_rn(src_w_sat, g);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double v = __dadd_rn(sg, (double)__fmul_rn(w_sat, (float)b[c]));
+        v = fmin(fmax(v, 0.0), 255.0);
+        b[c] = (uint8_t)(int)v;
+      }
+    }
+    const int x = (int)(i % W); const long row = i - x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      out[c * plane + i] = b[c];
+      if (out_flip) out_flip[c * plane + row + (W - 1 - x)] = b[c];
+    }
   }
 }
 
@@ -1210,14 +1249,25 @@ extern "C" int sw_scale_cols_loss(int dtype, int M, int N, int n_valid, const fl
   return 0;
 }
 
-extern "C" int sw_resize_pass_u8(int C, int H, int W, int out_size, int horizontal, const uint8_t* in, const int32_t* bounds,
-                                 const int32_t* kk, int ksize, uint8_t* out, uint8_t* out_flip, hipStream_t stream) {
+extern "C" int sw_resize_pass_u8(int C, int H, int W, long in_ld, long in_plane, int out_size, int horizontal, const uint8_t* in,
+                                 const int32_t* bounds, const int32_t* kk, int ksize, uint8_t* out, uint8_t* out_flip,
+                                 hipStream_t stream) {
   SW_ENTER();
-  if (C < 1 || H < 1 || W < 1 || out_size < 1 || ksize < 1) return -5;
+  if (C < 1 || H < 1 || W < 1 || out_size < 1 || ksize < 1 || in_ld < W || in_plane < (long)(H - 1) * in_ld + W) return -5;
   const int OH = horizontal ? H : out_size, OW = horizontal ? out_size : W;
   const long n = (long)C * OH * OW;
-  hipLaunchKernelGGL(resize_pass_u8_kernel, dim3(grid_for(n)), dim3(256), 0, stream, C, H, W, OH, OW, horizontal, in, bounds, kk,
-                     ksize, out, out_flip);
+  hipLaunchKernelGGL(resize_pass_u8_kernel, dim3(grid_for(n)), dim3(256), 0, stream, C, H, W, in_ld, in_plane, OH, OW, horizontal, in,
+                     bounds, kk, ksize, out, out_flip);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_color_jitter_u8(int H, int W, int mode, const uint8_t* in, float w_bright, double src_w_sat, float w_sat,
+                                  uint8_t* out, uint8_t* out_flip, hipStream_t stream) {
+  SW_ENTER();
+  if (H < 1 || W < 1 || (mode & ~3)) return -5;
+  hipLaunchKernelGGL(color_jitter_u8_kernel, dim3(grid_for((long)H * W)), dim3(256), 0, stream, H, W, mode, in, w_bright, src_w_sat,
+                     w_sat, out, out_flip);
   SW_CHECK_LAUNCH();
   return 0;
 }

@@ -932,10 +932,18 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
         raise ValueError(branch)
 
     @torch.no_grad()
-    def inference(self, batched_inputs):
+    def inference(self, batched_inputs, do_postprocess=True):
+        """GeneralizedRCNN.inference (detectron2/detectron2/modeling/meta_arch/rcnn.py:177-219): detections of the ROI heads, then
+        `_postprocess` (:243-259) -> `detector_postprocess` (modeling/postprocessing.py:9-59): boxes rescaled from the network's
+        input resolution to each input's "height" / "width" (the dataset image: MIN_SIZE_TEST resizes every test image), clipped,
+        empty ones dropped.  do_postprocess=False returns the raw list[Instances] in network-input coordinates."""
+        from .inference import detector_postprocess
         self.refresh_staged_weights()
         x4, sizes = self.preprocess_image(batched_inputs)
         feats = self.backbone(x4)
         proposals, _ = self.proposal_generator(sizes, feats, None, compute_loss=False)
         dets, _ = self.roi_heads(feats, proposals, targets=None, compute_loss=False)
-        return [{"instances": d} for d in dets]
+        if not do_postprocess:
+            return dets
+        return [{"instances": detector_postprocess(d, inp.get("height", s[0]), inp.get("width", s[1]))}
+                for d, inp, s in zip(dets, batched_inputs, sizes)]

@@ -512,13 +512,32 @@ def scale_cols_loss(src_f32, g_losses, g_total, col_to_loss_i32, mul, dst, M, N,
 
 
 def resize_pass_u8(src, dst, bounds_i32, kk_i32, ksize, horizontal, dst_flip=None):
-    """one pass of Pillow's 8-bit resize (sw_resize_pass_u8): src (C,H,W) u8 -> dst (C,H,out) / (C,out,W)"""
+    """one pass of Pillow's 8-bit resize (sw_resize_pass_u8): src (C,H,W) u8 -> dst (C,H,out) / (C,out,W).  `src` may be a
+    window of a larger planar image (unit pixel stride, the parent's row / plane strides): a crop costs no copy"""
     _need_gpu(src, dst, bounds_i32, kk_i32)
     C, H, W = src.shape
+    assert src.stride(2) == 1 and dst.is_contiguous() and (dst_flip is None or dst_flip.is_contiguous())
     out_size = dst.shape[2] if horizontal else dst.shape[1]
-    check(lib.sw_resize_pass_u8(C, H, W, out_size, int(horizontal), _p(src), _p(bounds_i32), _p(kk_i32), int(ksize), _p(dst),
-                                _p(dst_flip), _stream()), "sw_resize_pass_u8")
+    check(lib.sw_resize_pass_u8(C, H, W, src.stride(1), src.stride(0), out_size, int(horizontal), _p(src), _p(bounds_i32),
+                                _p(kk_i32), int(ksize), _p(dst), _p(dst_flip), _stream()), "sw_resize_pass_u8")
     return dst
+
+
+def color_jitter_u8(src, w_bright=None, w_sat=None, with_flip=False):
+    """RandomBrightness / RandomSaturation blends on a planar (3,H,W) u8 image (sw_color_jitter_u8); weights None = that blend
+    is skipped.  -> out, or (out, x-mirrored out)"""
+    import numpy as np
+    _need_gpu(src)
+    assert src.dtype == torch.uint8 and src.dim() == 3 and src.shape[0] == 3 and src.is_contiguous()
+    out = torch.empty_like(src)
+    flip = torch.empty_like(src) if with_flip else None
+    mode = (1 if w_bright is not None else 0) | (2 if w_sat is not None else 0)
+    wb = float(np.float32(w_bright)) if w_bright is not None else 1.0        # numpy scales the float32 image by float32(w)
+    ws = float(np.float32(w_sat)) if w_sat is not None else 1.0
+    src_w = (1 - float(w_sat)) if w_sat is not None else 0.0                   # `1 - w`: a python double in the reference
+    check(lib.sw_color_jitter_u8(src.shape[1], src.shape[2], mode, _p(src), wb, src_w, ws, _p(out), _p(flip), _stream()),
+          "sw_color_jitter_u8")
+    return (out, flip) if with_flip else out
 
 
 def transpose_2d(src, dst, rows, cols):

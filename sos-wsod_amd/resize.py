@@ -69,8 +69,9 @@ def resize_bilinear_u8(img: torch.Tensor, out_hw, with_flip=False):
     with_flip: also return the x-mirrored result (written by the same launch)."""
     assert img.dtype == torch.uint8 and img.dim() == 3
     ops._need_gpu(img)
-    img = img.contiguous()
-    C, H, W = img.shape
+    if img.stride(2) != 1:
+        img = img.contiguous()
+    C, H, W = img.shape                                 # a crop window keeps its parent's strides: the kernel takes them
     oh, ow = int(out_hw[0]), int(out_hw[1])
     dev = img.device
     cur = img
@@ -81,7 +82,7 @@ def resize_bilinear_u8(img: torch.Tensor, out_hw, with_flip=False):
         passes.append((0, H, oh))
     flip = None
     if not passes:                                      # Pillow returns a copy
-        cur = img.clone()
+        cur = img.contiguous().clone() if not img.is_contiguous() else img.clone()
         return (cur, cur.flip(-1).contiguous()) if with_flip else cur
     for i, (horizontal, n_in, n_out) in enumerate(passes):
         bounds, kk, ksize = _tables(n_in, n_out, dev)

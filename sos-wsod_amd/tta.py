@@ -21,13 +21,18 @@ from .structures import Boxes, Instances
 
 
 class ViewTransform:
-    """resize (orig h,w -> new h,w) followed by an optional horizontal flip in the resized frame"""
+    """[crop: shift by -(x0, y0) into a window of size orig_hw (fvcore CropTransform.apply_coords),] resize (orig h,w -> new h,w),
+    then an optional horizontal flip in the resized frame; every step in the boxes' own dtype, as numpy does it"""
 
-    def __init__(self, orig_hw: Tuple[int, int], new_hw: Tuple[int, int], flip: bool):
+    def __init__(self, orig_hw: Tuple[int, int], new_hw: Tuple[int, int], flip: bool, crop_xy=None):
         self.orig_hw, self.new_hw, self.flip = tuple(orig_hw), tuple(new_hw), bool(flip)
+        self.crop_xy = None if crop_xy is None else (int(crop_xy[0]), int(crop_xy[1]))
 
     def apply_box(self, boxes: torch.Tensor) -> torch.Tensor:
         sx, sy = self.new_hw[1] / self.orig_hw[1], self.new_hw[0] / self.orig_hw[0]
+        if self.crop_xy is not None:
+            x0, y0 = self.crop_xy
+            boxes = boxes - boxes.new_tensor([x0, y0, x0, y0])
         b = boxes * boxes.new_tensor([sx, sy, sx, sy])
         if self.flip:                                        # HFlipTransform.apply_box: x -> W - x, corners re-sorted
             w = float(self.new_hw[1])
@@ -35,6 +40,7 @@ class ViewTransform:
         return b
 
     def inverse_box(self, boxes: torch.Tensor) -> torch.Tensor:
+        assert self.crop_xy is None, "the test-time views are not cropped"
         b = boxes
         if self.flip:
             w = float(self.new_hw[1])

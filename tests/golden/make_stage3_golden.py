@@ -10,6 +10,9 @@ Cases
      labels, proposals, sampled ROIs and their classes, FPN level of every ROI, predictions, gradient samples.
   w  "unsup_data_weak" branch of the TEACHER (trainer.py:478-486): RPN proposals + ROI-head detections with peaky heads, then the
      0.7 score threshold of `process_pseudo_label` (trainer.py:361-403) -> pseudo boxes.
+  e  eval mode (`GeneralizedRCNN.inference`, detectron2/detectron2/modeling/meta_arch/rcnn.py:177-219, what VOCeval consumes): the
+     same model as w switched to eval (test top-k of the RPN), dataset "height" / "width" DIFFERENT from the network input size,
+     through the reference's own `_postprocess` / `detector_postprocess` (modeling/postprocessing.py:9-59): rescaled, clipped boxes.
 
 torch.randperm inside detectron2/modeling/sampling.py is replaced by the closed-form permutation oracle.frcnn_oracle.Perm
 (the sampling of the reference is not reproducible across implementations otherwise); everything else is the reference's code.
@@ -187,9 +190,38 @@ def run_weak():
     assert okp and okd
 
 
+EVAL_OUT = [(131, 175), (100, 70)]                 # dataset sizes of the two eval inputs: an up-scale and an anisotropic down-scale
+
+
+def run_eval():
+    P = FO.make_params(K, tag="s3w", head_scale=12.0)
+    model = ref_shim_d2.build_reference_model(ns, K)
+    load_params(model, P)
+    model.eval()
+    data, _ = inputs("s3w", with_gt=False)
+    for d, (oh, ow) in zip(data, EVAL_OUT):
+        d["height"], d["width"] = oh, ow
+    with ns.events.EventStorage(0), torch.no_grad():
+        res = model(data)
+        raw = model.inference(data, do_postprocess=False)
+    out = {"K": np.array(K), "sizes": np.array(SIZES), "out_sizes": np.array(EVAL_OUT), "head_scale": np.array(12.0)}
+    for i, r in enumerate(res):
+        inst = r["instances"]
+        assert tuple(inst.image_size) == EVAL_OUT[i]
+        out[f"det_boxes{i}"] = inst.pred_boxes.tensor.numpy().copy()
+        out[f"det_scores{i}"] = inst.scores.numpy().copy()
+        out[f"det_classes{i}"] = inst.pred_classes.numpy().copy()
+        out[f"raw_boxes{i}"] = raw[i].pred_boxes.tensor.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "stage3_e.npz"), **out)
+    print(f"[stage3 e] eval detections {[len(out[f'det_scores{i}']) for i in range(2)]} (raw {[len(out[f'raw_boxes{i}']) for i in range(2)]}) "
+          f"in frames {EVAL_OUT}; top scores {[out[f'det_scores{i}'][:2].round(3).tolist() for i in range(2)]}")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["a", "w"]
+    which = sys.argv[1:] or ["a", "w", "e"]
+    if "e" in which:
+        run_eval()
     if "a" in which:
         run_supervised()
     if "w" in which:

@@ -204,7 +204,7 @@ def install():
     sp = _load("detectron2.modeling.sampling", D2 + "/modeling/sampling.py")
     ag = _load("detectron2.modeling.anchor_generator", D2 + "/modeling/anchor_generator.py")
     pl = _load("detectron2.modeling.poolers", D2 + "/modeling/poolers.py")
-    pp = _pkg("detectron2.modeling.postprocessing"); pp.detector_postprocess = lambda r_, h, w_: r_
+    pp = _load("detectron2.modeling.postprocessing", D2 + "/modeling/postprocessing.py")     # the real detector_postprocess (eval mode)
     bb = _pkg("detectron2.modeling.backbone", D2 + "/modeling/backbone")
     bbb = _load("detectron2.modeling.backbone.backbone", D2 + "/modeling/backbone/backbone.py")
     bbuild = _pkg("detectron2.modeling.backbone.build"); bbuild.BACKBONE_REGISTRY = Registry("BACKBONE")

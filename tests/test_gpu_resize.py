@@ -66,3 +66,64 @@ def test_mappers_emit_pillow_pixels(golden_dir):
         hh, ww = tfm.new_hw
         want = oracle_resize(img, hh, ww)
         assert np.array_equal(view["image"].cpu().numpy(), want[:, :, ::-1] if tfm.flip else want)
+
+
+def test_resize_of_a_crop_window_takes_strides():
+    """a crop (CropTransform: image[y0:y0+h, x0:x0+w]) reaches the kernel as pointer + parent strides; same bits as the copy"""
+    from sos_wsod_amd.resize import resize_bilinear_u8
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 256, (3, 211, 307)).astype(np.uint8)
+    t = torch.from_numpy(img).cuda()
+    for (y0, x0, ch, cw), out in (((7, 13, 190, 280), (384, 566)), ((0, 0, 211, 300), (100, 142)), ((20, 30, 100, 200), (100, 300)),
+                                  ((20, 30, 100, 200), (100, 200))):
+        win = t[:, y0:y0 + ch, x0:x0 + cw]
+        assert not win.is_contiguous() or (x0 == 0 and cw == 307)
+        got, flip = resize_bilinear_u8(win, out, with_flip=True)
+        want = oracle_resize(np.ascontiguousarray(img[:, y0:y0 + ch, x0:x0 + cw]), out[0], out[1])
+        assert np.array_equal(got.cpu().numpy(), want) and np.array_equal(flip.cpu().numpy(), want[:, :, ::-1])
+
+
+def test_color_jitter_equals_the_blend_restatement():
+    """sw_color_jitter_u8 against oracle.input_oracle.blend_u8 (itself equal to the reference run's pixels, tests/test_mapper_cpu.py):
+    random pixels, grey pixels (B = G = R: the blend is mathematically the identity there, float rounding decides), saturated
+    weights that clip at both ends, brightness-only / saturation-only"""
+    from oracle import input_oracle as IO
+    from sos_wsod_amd import ops
+    rng = np.random.RandomState(11)
+    h, w = 67, 131
+    img = rng.randint(0, 256, (3, h, w)).astype(np.uint8)
+    img[:, :20] = rng.randint(0, 256, (1, 20, w))                # grey rows
+    img[:, 20:24] = 255; img[:, 24:28] = 0
+    t = torch.from_numpy(img).cuda()
+    hwc = np.ascontiguousarray(img.transpose(1, 2, 0))
+    for wb, ws in ((0.9233439722, 0.8865590297), (1.5, 1.5), (1 / 1.5, 1 / 1.5), (1.0, 1.0), (1.4136172, 0.7), (0.7, 1.4999)):
+        got, flip = ops.color_jitter_u8(t, wb, ws, with_flip=True)
+        want = IO.blend_u8(hwc, wb, ws).transpose(2, 0, 1)
+        assert np.array_equal(got.cpu().numpy(), want), (wb, ws)
+        assert np.array_equal(flip.cpu().numpy(), want[:, :, ::-1])
+    only_b = ops.color_jitter_u8(t, 1.3, None).cpu().numpy()
+    assert np.array_equal(only_b, np.clip(np.float32(1.3) * img.astype(np.float32), 0, 255).astype(np.uint8))
+    only_s = ops.color_jitter_u8(t, None, 0.8).cpu().numpy()
+    g = (hwc[..., 0] * 0.299 + hwc[..., 1] * 0.587) + hwc[..., 2] * 0.114
+    v = (1 - 0.8) * g[..., None] + (np.float32(0.8) * hwc.astype(np.float32)).astype(np.float64)
+    assert np.array_equal(only_s, np.clip(v, 0, 255).astype(np.uint8).transpose(2, 0, 1))
+
+
+@pytest.mark.parametrize("case", ["a", "v", "m"])
+def test_multi_input_mapper_matches_the_reference_run(case):
+    """the whole training mapper on the device — RandomCrop window, two PIL resizes, brightness + saturation blends, flips, the
+    four index-aligned proposal sets, annotations — against fixtures written by RUNNING the reference's
+    DatasetMapperMultiInput.__call__ (dataset_mapper.py:272-439; tests/golden/make_mapper_golden.py): same numpy seed -> same
+    draws; boxes bit exact; pixels bit identical (case a: every pixel; v, m: CRC32 of each view)"""
+    import zlib
+    from test_mapper_cpu import VIEW_KEYS, check_mapper_boxes_against_reference_run
+    g, out = check_mapper_boxes_against_reference_run(case, "cuda")
+    for key in VIEW_KEYS:
+        px = out["image" + key]
+        assert px.is_cuda and px.dtype == torch.uint8 and px.is_contiguous()
+        arr = px.cpu().numpy()
+        if "image" + key in g:
+            assert np.array_equal(arr, g["image" + key]), key
+        assert zlib.crc32(arr.tobytes()) == int(g["crc_" + key]), key
+    # and the model accepts what the mapper emits (4 views, aligned proposals)
+    assert len({len(out["proposals" + k]) for k in VIEW_KEYS}) == 1

@@ -135,3 +135,109 @@ def test_proposal_file_reader(tmp_path):
     want[:, 0::2] = want[:, 0::2].clip(0, 300); want[:, 1::2] = want[:, 1::2].clip(0, 200)
     got = out["proposals1"].proposal_boxes.tensor.numpy()
     assert got.shape[0] <= len(b) and all(any(np.allclose(g, w_) for w_ in want) for g in got)
+
+
+# ---- the whole mapper (RandomCrop, two scales, brightness / saturation blends, flips) against fixtures written by RUNNING the
+# reference's DatasetMapperMultiInput.__call__ (tests/golden/make_mapper_golden.py)
+MAPPER_CASES = ("a", "v", "m")
+VIEW_KEYS = ("1", "2", "1_flip", "2_flip")
+
+
+def mapper_fixture(case):
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", f"mapper_{case}.npz"))
+
+
+def mapper_for_fixture(g, resize_pixels):
+    from sos_wsod_amd.mapper import DeviceMultiInputMapper
+    return DeviceMultiInputMapper(min_sizes=tuple(int(s) for s in g["min_sizes"]), max_size=int(g["max_size"]),
+                                  proposal_topk=int(g["topk"]), seed=int(g["seed"]), resize_pixels=resize_pixels,
+                                  crop=("relative_range", [0.9, 0.9]), brightness=(1.0 / 1.5, 1.5), saturation=(1.0 / 1.5, 1.5))
+
+
+def fixture_dataset_dict(g, device):
+    annos = [{"bbox": [float(v) for v in b], "category_id": int(c), "iscrowd": int(k)}
+             for b, c, k in zip(g["anno_boxes"], g["anno_classes"], g["anno_crowd"])]
+    return {"image": torch.from_numpy(g["image"]).to(device), "proposal_boxes": g["boxes"], "proposal_objectness_logits": g["logits"],
+            "annotations": annos, "image_id": 17}
+
+
+def check_mapper_boxes_against_reference_run(case, device):
+    """same numpy seed as the reference run -> the same crop window, view shapes and blend weights (to the bit), the same four
+    proposal sets (float32, bit exact) and annotation sets; returns (fixture, mapper output) for the pixel checks"""
+    g = mapper_fixture(case)
+    m = mapper_for_fixture(g, resize_pixels=device != "cpu")
+    out = m(fixture_dataset_dict(g, device))
+    dr = m.last_draws
+    assert tuple(dr["crop"]) == tuple(int(v) for v in g["crop"])
+    assert tuple(dr["hw1"]) == tuple(g["hw1"]) and tuple(dr["hw2"]) == tuple(g["hw2"])
+    assert tuple(dr["blend1"]) == tuple(g["blend1"]) and tuple(dr["blend2"]) == tuple(g["blend2"])      # float64, exact
+    assert out["height"] == g["image"].shape[1] and out["width"] == g["image"].shape[2]                  # the uncropped size
+    for key in VIEW_KEYS:
+        p = out["proposals" + key]
+        assert tuple(p.image_size) == tuple(g["psize_" + key]) == tuple(g["hw_" + key])
+        assert np.array_equal(p.proposal_boxes.tensor.cpu().numpy(), g["pboxes_" + key])
+        assert np.array_equal(p.objectness_logits.cpu().numpy(), g["plogits_" + key])
+        inst = out["instances" + key]
+        assert np.array_equal(inst.gt_boxes.tensor.cpu().numpy(), g["gboxes_" + key])
+        assert np.array_equal(inst.gt_classes.cpu().numpy(), g["gclasses_" + key])
+        assert tuple(out["image" + key].shape[1:]) == tuple(g["hw_" + key])
+    assert 0 < len(g["plogits_1"]) < len(g["logits"])           # the crop + the masks did drop proposals
+    return g, out
+
+
+@pytest.mark.parametrize("case", MAPPER_CASES)
+def test_mapper_matches_the_reference_run_cpu(case):
+    check_mapper_boxes_against_reference_run(case, "cpu")
+
+
+@pytest.mark.parametrize("case", MAPPER_CASES)
+def test_input_oracle_matches_the_reference_run(case):
+    """the numpy restatement (draw order, crop + resize + flip box maps, masks, blends + PIL resize -> pixels) against the same
+    fixtures; this is the checker the GPU tests use beyond the fixtures' sizes"""
+    import zlib
+    from PIL import Image
+    from oracle import input_oracle as IO
+    g = mapper_fixture(case)
+    h, w = g["image"].shape[1:]
+    dr = IO.draw_views(int(g["seed"]), h, w, [int(s) for s in g["min_sizes"]], int(g["max_size"]))
+    assert dr["crop"] == tuple(int(v) for v in g["crop"]) and dr["hw1"] == tuple(g["hw1"]) and dr["hw2"] == tuple(g["hw2"])
+    assert dr["blend1"] == tuple(g["blend1"]) and dr["blend2"] == tuple(g["blend2"]) and dr["tries2"] == int(g["n_tries2"])
+    y0, x0, ch, cw = dr["crop"]
+    res, keep = IO.multi_input_proposals(g["boxes"], g["logits"], (ch, cw), dr["hw1"], dr["hw2"], int(g["topk"]), crop_xy=(x0, y0))
+    live = g["anno_crowd"] == 0
+    for key, hw, flip, blend in (("1", dr["hw1"], False, dr["blend1"]), ("2", dr["hw2"], False, dr["blend2"]),
+                                 ("1_flip", dr["hw1"], True, dr["blend1"]), ("2_flip", dr["hw2"], True, dr["blend2"])):
+        b, l = res["proposals" + key]
+        assert np.array_equal(b, g["pboxes_" + key]) and np.array_equal(l, g["plogits_" + key])
+        want = IO.transform_annotation_boxes(g["anno_boxes"][live], (ch, cw), hw, flip, crop_xy=(x0, y0))
+        assert np.array_equal(want, g["gboxes_" + key])
+        win = np.ascontiguousarray(g["image"].transpose(1, 2, 0)[y0:y0 + ch, x0:x0 + cw])
+        px = IO.blend_u8(np.asarray(Image.fromarray(win).resize((hw[1], hw[0]), Image.BILINEAR)), *blend)
+        px = np.ascontiguousarray((px[:, ::-1] if flip else px).transpose(2, 0, 1))
+        assert zlib.crc32(px.tobytes()) == int(g["crc_" + key])
+        if "image" + key in g:
+            assert np.array_equal(px, g["image" + key])
+
+
+def test_mapper_from_config_builds_the_reference_recipe():
+    """voc07_oicr_plus.yaml:29-35: INPUT.CROP.ENABLED True with the defaults relative_range [0.9, 0.9] (config/defaults.py:63-74)"""
+    from sos_wsod_amd.config import get_cfg, add_wsl_config
+    from sos_wsod_amd.mapper import DeviceMultiInputMapper
+    cfg = add_wsl_config(get_cfg())
+    cfg.merge_from_list(["INPUT.CROP.ENABLED", "True", "INPUT.MIN_SIZE_TRAIN", "(480, 512, 544)", "INPUT.MAX_SIZE_TRAIN", "2000",
+                         "MODEL.LOAD_PROPOSALS", "True", "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TRAIN", "4000"])
+    m = DeviceMultiInputMapper.from_config(cfg, seed=0, resize_pixels=False)
+    assert m.crop == ("relative_range", (0.9, 0.9)) and m.min_sizes == (480, 512, 544) and m.max_size == 2000
+    assert m.proposal_topk == 4000 and m.brightness == (1.0 / 1.5, 1.5) and m.saturation == (1.0 / 1.5, 1.5)
+    cfg.INPUT.CROP.ENABLED = False
+    assert DeviceMultiInputMapper.from_config(cfg, resize_pixels=False).crop is None
+    # the other crop rules of RandomCrop.get_crop_size
+    from sos_wsod_amd.mapper import crop_size_rule
+    rng = np.random.RandomState(0)
+    assert crop_size_rule("relative", (0.5, 0.25), 100, 200, rng) == (50, 50)
+    assert crop_size_rule("absolute", (64, 300), 100, 200, rng) == (64, 200)
+    ch, cw = crop_size_rule("absolute_range", (50, 150), 100, 200, rng)
+    assert 50 <= ch <= 100 and 50 <= cw <= 150
+    for _ in range(50):
+        ch, cw = crop_size_rule("relative_range", (0.9, 0.9), 375, 500, rng)
+        assert int(375 * 0.9) <= ch <= 375 and int(500 * 0.9) <= cw <= 500
