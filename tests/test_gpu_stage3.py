@@ -253,6 +253,35 @@ def test_teacher_weak_branch_and_pseudo_labels_match_the_reference_generated_fix
         np.testing.assert_allclose(pseudo[i].gt_boxes.tensor.cpu().numpy(), t[f"pseudo_boxes{i}"], rtol=1e-4, atol=1e-2)
 
 
+def test_eval_mode_inference_rescales_to_the_dataset_frame_like_the_reference(golden_dir):
+    """`GeneralizedRCNN.inference` -> `_postprocess` -> `detector_postprocess` (detectron2/detectron2/modeling/meta_arch/rcnn.py:177-259,
+    modeling/postprocessing.py:9-59): eval mode (RPN test top-k), "height" / "width" different from the network input; fixture
+    written by running the reference model in eval mode with its own detector_postprocess (make_stage3_golden.py case e)"""
+    t = np.load(os.path.join(golden_dir, "stage3_e.npz"))
+    K = int(t["K"])
+    P = FO.make_params(K, tag="s3w", head_scale=float(t["head_scale"]))
+    model = _model(K, P, "s3w")
+    model.eval()
+    data, _ = _inputs("s3w", t, K, with_gt=False)
+    for d, (oh, ow) in zip(data, t["out_sizes"]):
+        d["height"], d["width"] = int(oh), int(ow)
+    res = model(data)
+    raw = model.inference(data, do_postprocess=False)
+    for i, r in enumerate(res):
+        inst = r["instances"]
+        assert tuple(inst.image_size) == tuple(int(v) for v in t["out_sizes"][i])
+        assert np.array_equal(inst.pred_classes.cpu().numpy(), t[f"det_classes{i}"])
+        np.testing.assert_allclose(inst.scores.cpu().numpy(), t[f"det_scores{i}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(inst.pred_boxes.tensor.cpu().numpy(), t[f"det_boxes{i}"], rtol=1e-4, atol=1e-2)
+        np.testing.assert_allclose(raw[i].pred_boxes.tensor.cpu().numpy(), t[f"raw_boxes{i}"], rtol=1e-4, atol=1e-2)
+        b = inst.pred_boxes.tensor
+        assert float(b[:, 0::2].max()) <= t["out_sizes"][i][1] and float(b[:, 1::2].max()) <= t["out_sizes"][i][0]
+    # inputs without "height" / "width": the network-input frame, as the reference defaults
+    plain = model([{"image": d["image"]} for d in data])
+    for i in range(2):
+        assert tuple(plain[i]["instances"].image_size) == tuple(int(v) for v in t["sizes"][i])
+
+
 # ------------------------------------------------------------------------------------------ the step on the real modules
 def test_semisup_step_burn_in_and_semi_supervised_iteration_on_the_real_detector():
     """unbias/ubteacher/engine/trainer.py:436-549 with the real student / teacher: iteration 0 = burn-in (supervised branch on the
