@@ -369,3 +369,79 @@ def test_stage3_teacher_weak_branch_at_config5_image_size_against_the_oracle():
     keep = want["scores"] > 0.7
     assert len(pseudo[0]) == int(keep.sum())
     print(f"stage-3 teacher at 800x1216: {len(got_b)} detections, {int(keep.sum())} pseudo labels above 0.7, order identical: {order_ok}")
+
+
+def test_config2_bf16_backbone_backward_teacher_forced_against_the_oracle():
+    """The bf16 conv backward — the benchmarked mode's data-gradient / weight-gradient / pool-routing kernels at config #2's
+    real size — isolated against the ORACLE (vgg.py:104-122 through autograd on the host): the bf16-emulating oracle runs the
+    whole config-#2 iteration, and its OWN stored activations (plain2's pooled output .. conv5_3, both backbone calls) and its
+    OWN gradient at the backbone's output are fed to `VGG16`'s explicit backward.  Teacher forcing at the backbone boundary, as
+    test_gpu_e2e.py does at fc7: ReLU masks, pool routes and the incoming gradient are the oracle's, so the chaos floor of two
+    free-running bf16 evaluations (5-19 % per tensor) is gone and what is left is the kernels' own arithmetic: every
+    plain3..plain5 weight / bias gradient within 2e-2 relative L2 and cosine >= 0.999 of the oracle's."""
+    from types import SimpleNamespace
+    from helpers import build_model, load_params
+    from sos_wsod_amd.backbone_vgg import _VGGFunction
+    K, R, H, W, dan = 20, 2000, 512, 512, (4096, 4096)
+    nthreads = torch.get_num_threads()
+    P = O.make_params(K, dan, tag="pcfg2", head_scale=30.0)
+    views, gt = O.make_views(H, W, R, n_gt=3, K=K, scale2=1.0, tag="vcfg2")
+    masks = O.make_masks(R, dan, tag="mcfg2")
+    trace = {}
+    _, _, og = O.oicr_plus_iteration(P, views, gt, masks, K=K, bf16=True, want_grads=True, trace=trace)
+    model = build_model(K, dan, torch.bfloat16)
+    load_params(model, P)
+    bb = model.backbone
+    bb.stage_all_weights(with_dgrad=True)
+    dev = torch.device("cuda", 0)
+
+    def nhwc(a):                                     # the oracle's stored activations are bf16 values held in f32: lossless
+        t = torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 3, 1))).to(dev)
+        tb = t.to(torch.bfloat16)
+        assert torch.equal(tb.float(), t), "the bf16-emulating oracle must store bf16-representable activations"
+        return tb
+
+    infos, gs = [], []
+    for c in (0, 1):
+        acts = trace["acts"][c]
+        stage_info = []
+        prev = None
+        for si, (stage, cin, cout, nconv, pool_stride, dil) in enumerate(O.VGG_CFG):
+            if si < 2:                               # frozen stages (FREEZE_AT 2): the backward never reads them
+                stage_info.append(([(torch.empty(0, dtype=torch.bfloat16, device=dev), None)], None))
+                prev = nhwc(acts["plain2"]) if si == 1 else None
+                continue
+            conv_io, cur = [], prev
+            for i in range(nconv):
+                out = nhwc(acts[f"backbone.{stage}.0.conv{i + 1}"])
+                conv_io.append((cur, out))
+                cur = out
+            pre_pool = cur if pool_stride is not None else None
+            stage_info.append((conv_io, pre_pool))
+            prev = nhwc(acts[stage])
+        infos.append(stage_info)
+        g = torch.from_numpy(np.ascontiguousarray(trace["dfeat"][c].transpose(0, 2, 3, 1))).to(dev)      # f32: the backward rounds it
+        gs.append(g)
+    params = tuple(bb._flat_params())
+    ctx = SimpleNamespace(module=bb, infos=infos, params=params)
+    res = _VGGFunction.backward(ctx, *gs)
+    torch.cuda.synchronize()
+    grads = res[2 + len(gs):]
+    names = [n for blk_name, _, _, nconv, _, _ in O.VGG_CFG for i in range(nconv)
+             for n in (f"backbone.{blk_name}.0.conv{i + 1}.weight", f"backbone.{blk_name}.0.conv{i + 1}.bias")]
+    rows, bad = [], []
+    for name, got in zip(names, grads):
+        if name.startswith(("backbone.plain1", "backbone.plain2")):
+            assert got is None
+            continue
+        a, b = got.double().cpu().numpy().ravel(), np.asarray(og[name], np.float64).ravel()
+        rel = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+        cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+        rows.append((name, rel, cos))
+        if not (rel <= 2e-2 and cos >= 0.999):
+            bad.append((name, rel, cos))
+    print("bf16 conv backward, teacher forced at the backbone boundary (config #2): name | rel L2 | cosine")
+    for n, r, c in rows:
+        print("   %-40s %.3e %.6f" % (n, r, c))
+    assert len(rows) == 18 and not bad, bad
+    torch.set_num_threads(nthreads)
