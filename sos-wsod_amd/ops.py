@@ -434,10 +434,11 @@ def oicr_mine_label(scores, gt_classes_i32, boxes, K, top_k, thresh, nms_thresh,
     n_rounds = 1 if scores.dim() == 2 else scores.shape[0]
     R, ncol = scores.shape[-2:]
     G = gt_classes_i32.numel()
-    check(lib.sw_oicr_mine_label(R, ncol, K, n_rounds, _p(scores), _p(gt_classes_i32), G, _p(boxes), int(top_k),
-                                 float(thresh), float(nms_thresh), float(iou_bg), float(iou_fg), _p(lab_class),
-                                 _p(lab_weight), _p(lab_index), _p(pgt_count), _p(pgt_index), _p(pgt_class), _p(pgt_score),
-                                 _p(workspace), _stream()), "sw_oicr_mine_label")
+    _launch("mine_label", lambda: check(
+        lib.sw_oicr_mine_label(R, ncol, K, n_rounds, _p(scores), _p(gt_classes_i32), G, _p(boxes), int(top_k),
+                               float(thresh), float(nms_thresh), float(iou_bg), float(iou_fg), _p(lab_class),
+                               _p(lab_weight), _p(lab_index), _p(pgt_count), _p(pgt_index), _p(pgt_class), _p(pgt_score),
+                               _p(workspace), _stream()), "sw_oicr_mine_label"))
 
 
 def oicr_refine_loss(logits, V, R, K, cls_col, box_col, boxes, lab_class, lab_weight, lab_index, pred_view, reg_weights,
