@@ -222,7 +222,7 @@ class _VGGFunction(torch.autograd.Function):
                                       rows=torch.empty(nrow, cout, device=dev, dtype=torch.float32), slab_off=slab_off,
                                       row_off=row_off, nslab=nslab, nrow=nrow, splits=splits, cin=cin,
                                       dw=ops.grad_target(w, (cout, cin, 3, 3), dev),
-                                      db=torch.empty(cout, device=dev, dtype=torch.float32))
+                                      db=ops.grad_target(params[pidx + 1], (cout,), dev))
                 if (si, ci) == first_trainable:
                     break
             if si == first_trainable[0]:

@@ -143,7 +143,7 @@ class DetectionCheckpointer:
                 incorrect.append((k, tuple(sd[k].shape), tuple(model_sd[k].shape)))
                 sd.pop(k)
         res = self.model.load_state_dict(sd, strict=False)
-        ops.PARAM_EPOCH += 1; ops.BUFFER_EPOCH += 1            # every cached compute-dtype weight copy is stale now
+        ops.invalidate_all_staged(); ops.BUFFER_EPOCH += 1      # every cached compute-dtype weight copy is stale now
         missing = [k for k in res.missing_keys if k not in ("pixel_mean", "pixel_std")]     # initialised from the config anyway
         if missing:
             self.logger.warning("missing keys: %s", missing)

@@ -58,14 +58,30 @@ class KernelTimer:
 
 
 TIMER = None
-PARAM_EPOCH = 0        # bumped by HipSGD.step (the kernel updates parameters behind torch's version counter)
+PARAM_EPOCH = 0        # bumped whenever a kernel writes parameters behind torch's version counters ("something changed": HipSGD, EMA, ...)
 BUFFER_EPOCH = 0       # bumped by kernels that write module BUFFERS behind torch's version counters (the Stage-3 teacher EMA)
+INVALIDATE_EPOCH = 0   # bumped when EVERY cached compute-dtype copy is stale (checkpoint load, teacher EMA, re-homed parameter storage)
+
+
+def invalidate_all_staged():
+    """every cached compute-dtype weight copy is stale (parameters were written wholesale behind the version counters)"""
+    global PARAM_EPOCH, INVALIDATE_EPOCH
+    PARAM_EPOCH += 1
+    INVALIDATE_EPOCH += 1
+
+
+def mark_updated(p):
+    """a kernel (HipSGD) has just rewritten THIS parameter behind torch's version counter: its own cached copies are stale unless
+    the kernel rewrote them too and stamps them with the new key.  Per parameter: under the data-parallel trainer the update runs
+    bucket by bucket, several calls per step — a global counter made every call invalidate the stamps of the buckets before it, and
+    all but the last bucket's weights were re-staged in the next forward (12 staging launches and 0.3 ms per step)."""
+    p.__dict__["_sw_epoch"] = PARAM_EPOCH
 
 
 def param_key(p):
-    """cache key of a parameter's current value (compute-dtype weight copies are rebuilt only when it changes); frozen
-    parameters are not touched by the optimizer, so its epoch does not invalidate their copies"""
-    return (p.data_ptr(), p._version, PARAM_EPOCH if p.requires_grad else -1)
+    """cache key of a parameter's current value (compute-dtype weight copies are rebuilt only when it changes): storage, torch's
+    version counter, the epoch of the last wholesale invalidation and of the parameter's own last kernel update"""
+    return (p.data_ptr(), p._version, INVALIDATE_EPOCH, p.__dict__.get("_sw_epoch", 0))
 
 
 def grad_target(param, shape, dev):

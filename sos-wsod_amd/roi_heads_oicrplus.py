@@ -362,7 +362,7 @@ class OICRPlusHeads(nn.Module):
                 row += n
         assert row == self.n_head_cols
         self._head_flat = (flat_w, flat_b)
-        ops.PARAM_EPOCH += 1
+        ops.invalidate_all_staged()
 
     def _head_flat_ok(self, params, device):
         flat = getattr(self, "_head_flat", None)
@@ -602,7 +602,7 @@ class OICRPlusHeads(nn.Module):
         else:
             ops.gemm(dl, Wh, dz2, M, D2, LD, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h2, ref_scale=rs, out_dtype=dt_))
         # fc7
-        db2 = torch.empty(D2, device=dev, dtype=torch.float32); ops.colsum(dz2, M, D2, db2)
+        db2 = ops.grad_target(self.box_head.fc2.bias, (D2,), dev); ops.colsum(dz2, M, D2, db2)
         # weight gradients read dZ^T (one 64x64-tiled transpose, 65 MB) so that the GEMM's A operand is K-contiguous: the
         # forward-style kernel instead of transposing both operands on the fly inside LDS (fc6: 1.63 -> ~1.3 ms)
         # (needs 16-byte K pieces: M a multiple of 8 bf16 / 4 f32 rows — else both operands stay K-strided)
@@ -638,7 +638,7 @@ class OICRPlusHeads(nn.Module):
         dev, M = pooled.device, st["inp"]["M"]
         D0, D1 = pooled.shape[1], dz1.shape[1]
         epc = 8 if dt_ == torch.bfloat16 else 4
-        db1 = torch.empty(D1, device=dev, dtype=torch.float32); ops.colsum(dz1, M, D1, db1)
+        db1 = ops.grad_target(self.box_head.fc1.bias, (D1,), dev); ops.colsum(dz1, M, D1, db1)
         dW1 = ops.grad_target(self.box_head.fc1.weight, (D1, D0), dev)
         if M % epc == 0:                                 # dZ^T as in stage 1; the tagged region holds the transpose too: one "fc6_wgrad" measurement
             def nn():

@@ -48,7 +48,7 @@ def update_teacher_model(student: torch.nn.Module, teacher: torch.nn.Module, kee
     for v, s in hit[3]:
         v.copy_(s * (1 - keep_rate) + v * keep_rate)
     hit[2].run(keep_rate)
-    ops.PARAM_EPOCH += 1; ops.BUFFER_EPOCH += 1       # the kernel wrote the teacher's state behind torch's version counters: cached copies are stale
+    ops.invalidate_all_staged(); ops.BUFFER_EPOCH += 1     # the kernel wrote the teacher's state behind torch's version counters: cached copies are stale
 
 
 def threshold_bbox(data_inst: Optional[dict], proposals: Instances, thres: float = 0.7, proposal_type: str = "roih",

@@ -92,6 +92,8 @@ class HipSGD(torch.optim.Optimizer):
         for mom, entries in by_mom.items():
             ops.sgd_multi(entries, mom, grad_scale)
             for e in entries:
+                ops.mark_updated(e["param"])
+            for e in entries:
                 if e["staging"] is not None and e["staging"]["stamp"] is not None:
                     e["staging"]["stamp"](ops.param_key(e["param"]))
 

@@ -79,7 +79,10 @@ class Trainer:
         self._bucket_views = []
         if use_ddp:
             if os.environ.get("SW_DDP_GRAD_IN_BUCKET", "1") == "1":
-                self._bucket_views = [p for p in model.parameters() if p.requires_grad and p.dim() >= 2]     # (ops.grad_target users: fc / conv weights)
+                # ops.grad_target users: fc / conv weights and biases (the 20 predictor tensors are row slices of ONE packed gradient
+                # matrix; the reducer copies those into its bucket)
+                self._bucket_views = [p for n, p in model.named_parameters()
+                                      if p.requires_grad and ("backbone." in n or ".box_head." in n)]
             dev = next(model.parameters()).device
             ids = [dev.index] if dev.type == "cuda" else None
             # broadcast_buffers=False as the reference (train_net_multi.py:76-78); every trainable parameter is used

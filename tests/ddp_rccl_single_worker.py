@@ -65,10 +65,25 @@ def main():
 
     m_ddp, tr_ddp, left = run(True)
     assert isinstance(tr_ddp.model, torch.nn.parallel.DistributedDataParallel)
+    # the bucket-by-bucket update (several HipSGD calls per step) must leave EVERY staged compute-dtype weight copy current: a
+    # forward after the steps re-stages nothing (a global update counter once invalidated all but the last bucket's stamps)
+    import sos_wsod_amd.ops as ops
+    bb, hd = m_ddp.backbone, m_ddp.roi_heads
+    stale = []
+    for (wid, mode), (key, buf) in bb._wk_cache.items():
+        w = next(c.weight for blk in bb.blocks for c in blk.convs() if id(c.weight) == wid)
+        if w.requires_grad and key[0] != ops.param_key(w):
+            stale.append(("conv", mode))
+    if hd._stage_cache["fc1"][0] != [ops.param_key(hd.box_head.fc1.weight)]:
+        stale.append("fc1")
+    if hd._stage_cache["fc2"][0] != [ops.param_key(hd.box_head.fc2.weight)]:
+        stale.append("fc2")
+    if hd._stage_cache["heads"][0] != [ops.param_key(p) for p in hd._flat_params()[4::2]]:
+        stale.append("heads")
     m_ref, tr_ref, _ = run(False)
     same = all(torch.equal(a.detach(), b.detach()) for a, b in zip(m_ddp.parameters(), m_ref.parameters()))
     moved = float((m_ddp.roi_heads.box_head.fc1.weight.detach() - torch.from_numpy(P["roi_heads.box_head.fc1.weight"]).to(dev)).abs().max())
-    torch.save({"same": same, "moved": moved, "overlap_update": tr_ddp.overlap_update, "left_for_step": left,
+    torch.save({"same": same, "moved": moved, "overlap_update": tr_ddp.overlap_update, "left_for_step": left, "stale_staged": stale,
                 "backend": dist.get_backend(),
                 "metrics": {k: float(v) for k, v in tr_ddp.storage.latest().items() if k.startswith("loss")},
                 "metrics_ref": {k: float(v) for k, v in tr_ref.storage.latest().items() if k.startswith("loss")}}, out_path)

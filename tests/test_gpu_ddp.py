@@ -112,4 +112,5 @@ def test_ddp_trainer_over_rccl_world_size_one(tmp_path, dtype):
     res = torch.load(out)
     assert res["backend"] == "nccl" and res["same"] and res["moved"] > 0
     assert res["overlap_update"] and res["left_for_step"] == [0, 0, 0], res["left_for_step"]
+    assert res["stale_staged"] == [], res["stale_staged"]        # every bucket's update stamped its weight copies; none re-staged
     assert res["metrics"] == res["metrics_ref"] and len(res["metrics"]) == 9
