@@ -863,6 +863,7 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
         if cfg is not None:
             M = cfg.MODEL
             # the configuration this class implements (Base-RCNN-FPN.yaml + voc_ssod.yaml); anything else is refused, not ignored
+            # (the RPN / ROI-head / test keys: _cfg_kwargs)
             assert M.BACKBONE.get("NAME", "build_resnet_fpn_backbone") == "build_resnet_fpn_backbone"
             assert M.get("PROPOSAL_GENERATOR", {}).get("NAME", "PseudoLabRPN") == "PseudoLabRPN"
             assert M.ROI_HEADS.get("NAME", "StandardROIHeadsPseudoLab") == "StandardROIHeadsPseudoLab"
@@ -872,14 +873,58 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
             dt_name = M.get("AMD", {}).get("COMPUTE_DTYPE", "fp32")
             compute_dtype = torch.bfloat16 if dt_name == "bf16" else torch.float32
             sampler = Sampler(int(cfg.get("SEED", 0)) if int(cfg.get("SEED", 0)) >= 0 else 0)
+            rpn_kw, roi_kw, pred_kw = self._cfg_kwargs(M, cfg.get("TEST", {}))
+        else:
+            rpn_kw, roi_kw, pred_kw = {}, {}, {}
         sampler = sampler if sampler is not None else Sampler()
         self.backbone = FPN(ResNet(freeze_at))
-        self.proposal_generator = PseudoLabRPN(sampler)
-        self.roi_heads = StandardROIHeadsPseudoLab(num_classes, sampler)
+        self.proposal_generator = PseudoLabRPN(sampler, **rpn_kw)
+        self.roi_heads = StandardROIHeadsPseudoLab(num_classes, sampler, **roi_kw)
+        bp = self.roi_heads.box_predictor
+        for k, v in pred_kw.items():
+            setattr(bp, k, v)
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
         self.compute_dtype = compute_dtype
         self.sampler = sampler
+
+    @staticmethod
+    def _cfg_kwargs(M, T):
+        """The detectron2 keys this detector takes from a config (detectron2/detectron2/config/defaults.py values as defaults):
+        passed on where the implementation is parametric, REFUSED where it is fixed — a config that changes one of them must not
+        silently train or evaluate something else."""
+        def get(node, key, default):
+            return node.get(key, default) if hasattr(node, "get") else default
+        R, H, B, A = get(M, "RPN", {}), get(M, "ROI_HEADS", {}), get(M, "ROI_BOX_HEAD", {}), get(M, "ANCHOR_GENERATOR", {})
+        rpn_kw = dict(batch_size_per_image=get(R, "BATCH_SIZE_PER_IMAGE", 256), positive_fraction=get(R, "POSITIVE_FRACTION", 0.25),
+                      pre_nms_topk=(get(R, "PRE_NMS_TOPK_TRAIN", 2000), get(R, "PRE_NMS_TOPK_TEST", 1000)),
+                      post_nms_topk=(get(R, "POST_NMS_TOPK_TRAIN", 1000), get(R, "POST_NMS_TOPK_TEST", 1000)),
+                      nms_thresh=get(R, "NMS_THRESH", 0.7),
+                      anchor_sizes=tuple(s_[0] for s_ in get(A, "SIZES", [[32], [64], [128], [256], [512]])),
+                      aspect_ratios=tuple(get(A, "ASPECT_RATIOS", [[0.5, 1.0, 2.0]])[0]))
+        roi_kw = dict(batch_size_per_image=get(H, "BATCH_SIZE_PER_IMAGE", 512), positive_fraction=get(H, "POSITIVE_FRACTION", 0.25),
+                      proposal_append_gt=get(H, "PROPOSAL_APPEND_GT", True))
+        pred_kw = dict(test_score_thresh=get(H, "SCORE_THRESH_TEST", 0.05), test_nms_thresh=get(H, "NMS_THRESH_TEST", 0.5),
+                       test_topk_per_image=get(T, "DETECTIONS_PER_IMAGE", 100))
+        fixed = [(get(R, "IOU_THRESHOLDS", [0.3, 0.7]), [0.3, 0.7], "RPN.IOU_THRESHOLDS"), (get(R, "IOU_LABELS", [0, -1, 1]), [0, -1, 1], "RPN.IOU_LABELS"),
+                 (get(R, "SMOOTH_L1_BETA", 0.0), 0.0, "RPN.SMOOTH_L1_BETA"), (get(R, "BBOX_REG_LOSS_TYPE", "smooth_l1"), "smooth_l1", "RPN.BBOX_REG_LOSS_TYPE"),
+                 (tuple(get(R, "BBOX_REG_WEIGHTS", (1.0, 1.0, 1.0, 1.0))), (1.0, 1.0, 1.0, 1.0), "RPN.BBOX_REG_WEIGHTS"),
+                 (get(R, "LOSS_WEIGHT", 1.0), 1.0, "RPN.LOSS_WEIGHT"), (get(R, "BBOX_REG_LOSS_WEIGHT", 1.0), 1.0, "RPN.BBOX_REG_LOSS_WEIGHT"),
+                 (get(R, "BOUNDARY_THRESH", -1), -1, "RPN.BOUNDARY_THRESH"),
+                 (list(get(H, "IOU_THRESHOLDS", [0.5])), [0.5], "ROI_HEADS.IOU_THRESHOLDS"), (list(get(H, "IOU_LABELS", [0, 1])), [0, 1], "ROI_HEADS.IOU_LABELS"),
+                 (get(B, "FC_DIM", 1024), 1024, "ROI_BOX_HEAD.FC_DIM"), (get(B, "NUM_FC", 2), 2, "ROI_BOX_HEAD.NUM_FC"), (get(B, "NUM_CONV", 0), 0, "ROI_BOX_HEAD.NUM_CONV"),
+                 (get(B, "POOLER_RESOLUTION", 7), 7, "ROI_BOX_HEAD.POOLER_RESOLUTION"), (get(B, "POOLER_SAMPLING_RATIO", 0), 0, "ROI_BOX_HEAD.POOLER_SAMPLING_RATIO"),
+                 (get(B, "POOLER_TYPE", "ROIAlignV2"), "ROIAlignV2", "ROI_BOX_HEAD.POOLER_TYPE"), (get(B, "SMOOTH_L1_BETA", 0.0), 0.0, "ROI_BOX_HEAD.SMOOTH_L1_BETA"),
+                 (get(B, "BBOX_REG_LOSS_TYPE", "smooth_l1"), "smooth_l1", "ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE"),
+                 (tuple(get(B, "BBOX_REG_WEIGHTS", (10.0, 10.0, 5.0, 5.0))), (10.0, 10.0, 5.0, 5.0), "ROI_BOX_HEAD.BBOX_REG_WEIGHTS"),
+                 (get(B, "CLS_AGNOSTIC_BBOX_REG", False), False, "ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG"), (get(B, "TRAIN_ON_PRED_BOXES", False), False, "ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES")]
+        for got, want, name in fixed:
+            if isinstance(want, float):
+                ok = abs(float(got) - want) < 1e-12
+            else:
+                ok = (list(got) == list(want)) if isinstance(want, (list, tuple)) else got == want
+            assert ok, f"MODEL.{name} = {got!r} is not implemented by this detector (implemented: {want!r})"
+        return rpn_kw, roi_kw, pred_kw
 
     def refresh_staged_weights(self):
         """the layers' compute-dtype weight copies follow the parameters: one launch when anything changed since the last call"""

@@ -12,10 +12,15 @@ takes any module with that call signature.  Parity: the step on the real detecto
 is pinned by fixtures the reference's own detector wrote (tests/golden/make_stage3_golden.py, tests/test_gpu_stage3.py)."""
 from typing import Dict, Optional
 
+import weakref
+
 import torch
 
 from . import ops
 from .structures import Boxes, Instances
+
+
+_EMA_PLANS = weakref.WeakKeyDictionary()       # teacher module -> (weakref to the student, storage pointers, EmaPlan, rest)
 
 
 def _storage_ptrs(m):
@@ -31,8 +36,10 @@ def update_teacher_model(student: torch.nn.Module, teacher: torch.nn.Module, kee
     if isinstance(student, torch.nn.parallel.DistributedDataParallel):
         student = student.module
     ptrs = (_storage_ptrs(student), _storage_ptrs(teacher))
-    hit = teacher.__dict__.get("_ema_plan")
-    if hit is None or hit[0] is not student or hit[1] != ptrs:
+    # the plan lives OUTSIDE the modules (weakly keyed by the teacher, holding the student weakly): a module attribute made the
+    # teacher own the student and carry ctypes pointer arrays that copy.deepcopy / torch.save of the teacher cannot handle
+    hit = _EMA_PLANS.get(teacher)
+    if hit is None or hit[0]() is not student or hit[1] != ptrs:
         sd_s, sd_t = student.state_dict(), teacher.state_dict()
         fused_t, fused_s, rest = [], [], []
         for k, v in sd_t.items():
@@ -43,8 +50,8 @@ def update_teacher_model(student: torch.nn.Module, teacher: torch.nn.Module, kee
                 fused_t.append(v); fused_s.append(s)
             else:
                 rest.append((v, s))
-        hit = (student, ptrs, ops.EmaPlan(fused_t, fused_s), rest)
-        teacher.__dict__["_ema_plan"] = hit
+        hit = (weakref.ref(student), ptrs, ops.EmaPlan(fused_t, fused_s), rest)
+        _EMA_PLANS[teacher] = hit
     for v, s in hit[3]:
         v.copy_(s * (1 - keep_rate) + v * keep_rate)
     hit[2].run(keep_rate)

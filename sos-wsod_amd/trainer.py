@@ -129,7 +129,10 @@ class Trainer:
             # ITER_SIZE 1 (with accumulation the reference's rule steps every ITER_SIZE-th iteration only).
             if overlap_update is None:
                 overlap_update = os.environ.get("SW_DDP_OVERLAP_UPDATE", "1") == "1"
-            self.overlap_update = bool(overlap_update) and hasattr(optimizer, "step_params") and self.iter_size == 1
+            # find_unused_parameters: the reducer leaves .grad None for parameters no rank used and the reference's optimizer.step()
+            # skips them; bucket.gradients() would still hand the hook zero views (weight decay + momentum applied) — so no overlap
+            self.overlap_update = (bool(overlap_update) and hasattr(optimizer, "step_params") and self.iter_size == 1
+                                   and not find_unused)
             if self.overlap_update:
                 opt = self.optimizer
 
@@ -355,8 +358,9 @@ class _StepGraphs:
                     self.seen.clear()
                 return None
             while len(self.graphs) >= self.MAX_GRAPHS:            # least recently replayed signature makes room
-                self.graphs.popitem(last=False)
-                self.evictions += 1
+                old_sig, _ = self.graphs.popitem(last=False)
+                self.seen[old_sig] = 0                            # it has to recur twice again: with more live size buckets than graphs
+                self.evictions += 1                               # the steps run eagerly instead of re-capturing (and evicting) every time
             hit = self._capture(sig, data)
             if hit is None:
                 return None

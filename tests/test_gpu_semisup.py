@@ -25,6 +25,17 @@ def test_teacher_ema_bit_exact():
         for k, v in want.items():
             assert np.array_equal(got[k].cpu().numpy(), v), (keep, k)
     assert int(teacher[1].num_batches_tracked) == 5                        # keep 0: the copy at the end of burn-in
+    # the EMA plan is cached outside the modules: the teacher neither owns the student nor carries ctypes arrays — it still
+    # deep-copies and pickles after an EMA step, and the cache entry dies with it
+    import copy, gc, io
+    from sos_wsod_amd import semisup
+    twin = copy.deepcopy(teacher)
+    assert all(torch.equal(a, b) for a, b in zip(twin.state_dict().values(), teacher.state_dict().values()))
+    buf = io.BytesIO(); torch.save(teacher, buf)
+    assert "_ema_plan" not in teacher.__dict__ and teacher in semisup._EMA_PLANS
+    n = len(semisup._EMA_PLANS)
+    del teacher, twin; gc.collect()
+    assert len(semisup._EMA_PLANS) == n - 1
 
 
 @pytest.mark.parametrize("n", [0, 1, 77, 1024, 2500])

@@ -77,3 +77,25 @@ def test_product_detector_has_the_reference_state_dict_and_registry_name():
     frozen = {n for n, p in m.named_parameters() if not p.requires_grad}
     assert frozen and all(n.startswith(("backbone.bottom_up.stem", "backbone.bottom_up.res2")) for n in frozen)
     assert sum(p.numel() for p in m.parameters()) == sum(v.size for k, v in P.items() if ".norm." not in k)
+
+
+def test_detector_config_keys_are_read_or_refused():
+    """TwoStagePseudoLabGeneralizedRCNN(cfg): the RPN / ROI-head / test keys of detectron2/detectron2/config/defaults.py either reach
+    the modules or are refused when the implementation is fixed — never silently ignored (host logic, no GPU)"""
+    import pytest
+    from sos_wsod_amd.config import CfgNode
+    from sos_wsod_amd.frcnn import TwoStagePseudoLabGeneralizedRCNN as D
+    M = CfgNode({"RPN": {"PRE_NMS_TOPK_TRAIN": 3000, "POST_NMS_TOPK_TEST": 500, "NMS_THRESH": 0.6, "BATCH_SIZE_PER_IMAGE": 128},
+                 "ROI_HEADS": {"BATCH_SIZE_PER_IMAGE": 256, "SCORE_THRESH_TEST": 0.01, "NMS_THRESH_TEST": 0.4, "PROPOSAL_APPEND_GT": False},
+                 "ANCHOR_GENERATOR": {"SIZES": [[16], [32], [64], [128], [256]], "ASPECT_RATIOS": [[0.5, 1.0, 2.0]]}})
+    rpn, roi, pred = D._cfg_kwargs(M, CfgNode({"DETECTIONS_PER_IMAGE": 300}))
+    assert rpn["pre_nms_topk"] == (3000, 1000) and rpn["post_nms_topk"] == (1000, 500) and rpn["nms_thresh"] == 0.6
+    assert rpn["batch_size_per_image"] == 128 and rpn["anchor_sizes"] == (16, 32, 64, 128, 256) and rpn["aspect_ratios"] == (0.5, 1.0, 2.0)
+    assert roi == {"batch_size_per_image": 256, "positive_fraction": 0.25, "proposal_append_gt": False}
+    assert pred == {"test_score_thresh": 0.01, "test_nms_thresh": 0.4, "test_topk_per_image": 300}
+    rpn, roi, pred = D._cfg_kwargs(CfgNode({}), {})                                     # defaults = the reference recipe
+    assert rpn["pre_nms_topk"] == (2000, 1000) and roi["batch_size_per_image"] == 512 and pred["test_topk_per_image"] == 100
+    for bad in ({"ROI_BOX_HEAD": {"FC_DIM": 2048}}, {"RPN": {"IOU_THRESHOLDS": [0.3, 0.6]}}, {"ROI_BOX_HEAD": {"SMOOTH_L1_BETA": 0.5}},
+                {"ROI_HEADS": {"IOU_THRESHOLDS": [0.6]}}, {"ROI_BOX_HEAD": {"CLS_AGNOSTIC_BBOX_REG": True}}):
+        with pytest.raises(AssertionError, match="not implemented"):
+            D._cfg_kwargs(CfgNode(bad), {})
