@@ -432,6 +432,43 @@ int sw_roi_align_bwd(int dtype, int H, int W, int C, int PH, int PW, float spati
  * ld_deltas floats; weights4: HOST float[4]; dw, dh clamped to scale_clamp. */
 int sw_decode_boxes(long n, long n_boxes, const float* deltas, long ld_deltas, const float* boxes, const float* weights4,
                     float scale_clamp, float* out, sw_stream_t stream);
+/* ---- Stage-3 detector, index side (csrc/proposals.hip): the reference's torch sort / nonzero / randperm logic as device code.
+ * RPN proposal selection (detectron2/detectron2/modeling/proposal_generator/proposal_utils.py:22-130 find_top_rpn_proposals, up to its
+ * batched_nms): for every image and level the pre_topk highest objectness logits (= sort(descending, stable)[:k]: ties -> ascending
+ * anchor index), their boxes decoded (box_regression.py:88-116, weights4, scale_clamp), and the candidate rows written in the form
+ * sw_detect_postprocess2 takes with "class" = level: image `i` owns rows [i * L * pre_topk, (i + 1) * L * pre_topk), level l the
+ * pre_topk rows from l * pre_topk, in descending score order; cand_scores [rows][L + 1] = -inf except column l (-inf there too for
+ * unused rows and for boxes that are empty after clipping to img_hw_dev[i] = (h, w): proposal_utils.py:96-106), cand_boxes
+ * [rows][4 L] the box repeated.  finite_dev[i] = 0 if a selected box / logit is not finite (:86-94), else nonzero.
+ * logits / deltas / anchors: HOST arrays of L device pointers, level l: logits [N][n_l], deltas [N][n_l][4], anchors [n_l][4].
+ * sel_idx: int32 [N * L][pre_topk] scratch.  pre_topk <= 16384, N * L <= 40. */
+long sw_rpn_select_workspace_bytes(int N, int L, const int* n_per_level);
+int sw_rpn_select_pack(int N, int L, const float* const* logits, const float* const* deltas, const float* const* anchors,
+                       const int* n_per_level, int pre_topk, const float* weights4, float scale_clamp, const int* img_hw_dev,
+                       float* cand_scores, float* cand_boxes, int* finite_dev, int* sel_idx, void* workspace, long workspace_bytes,
+                       sw_stream_t stream);
+/* RPN anchor labels (detectron2/.../proposal_generator/rpn.py:305-360 label_and_sample_anchors): IoU of every anchor [A][4] with the
+ * image's ground-truth boxes (gt_boxes: the images' boxes back to back, gt_count_per_image HOST array), Matcher thresholds
+ * [thr_lo, thr_hi] with labels [0, -1, 1] and low-quality matches (matcher.py:60-126), then subsample_labels (sampling.py:8-54):
+ * up to max_pos = int(batch_size * positive_fraction) positives and batch_size - that many negatives per image, drawn as the
+ * candidates with the smallest random keys  key(position in the ascending-index candidate list) = splitmix64(seed + position) >> 40
+ * (= argsort(keys, stable)[:num], the fixtures' closed-form stand-in for torch.randperm); seeds: HOST u64 [2 N] = (positives,
+ * negatives) per image.  labels int8 [N][A] in {-1, 0, 1}; matched f32 [N][A][4] = the box of the arg-max-IoU gt (0 without gt). */
+long sw_rpn_label_workspace_bytes(int N, long A, int total_gt);
+int sw_rpn_label_anchors(int N, long A, const float* anchors, const float* gt_boxes, const int* gt_count_per_image, float thr_lo,
+                         float thr_hi, int batch_size, int max_pos, const uint64_t* seeds, int8_t* labels, float* matched,
+                         void* workspace, long workspace_bytes, sw_stream_t stream);
+/* ROI-head label + sample (unbias/ubteacher/modeling/roi_heads/roi_heads.py:324-375 label_and_sample_proposals): image i's
+ * proposals are the first p_cnt_dev[i] rows (a DEVICE count: it comes from the RPN's NMS) of proposals [n_img][p_stride][4] (+ its
+ * ground-truth boxes appended when append_gt); IoU >= iou_thresh -> foreground with the matched box's class, else background
+ * `num_classes`; up to max_pos foreground and batch_size - that many background rows by the random-key rule of sw_rpn_label_anchors
+ * (seeds: HOST u64 [2 n_img]), foreground list first, each list in key order.  gt_boxes / gt_classes: the images' ground truth back to
+ * back, g_off / g_cnt HOST int arrays.  p_stride + g_cnt[i] <= 4096, n_img <= 8.  Outputs, image i at rows [i * out_stride, ...):
+ * out_count [n_img], out_index (row in the image's candidate list), out_classes, out_boxes [..][4], out_gt_boxes [..][4]. */
+int sw_roi_label_sample(int n_img, const int* p_cnt_dev, int p_stride, const float* proposals, const int* g_off, const int* g_cnt,
+                        const float* gt_boxes, const int32_t* gt_classes, int append_gt, float iou_thresh, int num_classes,
+                        int batch_size, int max_pos, const uint64_t* seeds, int out_stride, int32_t* out_count, int32_t* out_index,
+                        int32_t* out_classes, float* out_boxes, float* out_gt_boxes, sw_stream_t stream);
 /* RPN losses (proposal_generator/rpn.py:362-420, box_regression.py:229-260) over n = N * A anchors: losses2[0] = sum over
  * label >= 0 of BCE-with-logits(logit, label) * inv_norm, losses2[1] = sum over label == 1 of |delta - get_deltas(anchor, gt)|_1
  * * inv_norm (smooth-L1 with beta 0), and their unit gradients dlogits [n], ddeltas [n][4] (either may be NULL).  anchors

@@ -175,6 +175,16 @@ SIGNATURES = {
     "sw_roi_align_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p, c_void_p,
                                  c_int, c_void_p, c_void_p]),
     "sw_decode_boxes": (c_int, [c_long, c_long, c_void_p, c_long, c_void_p, _F4, c_float, c_void_p, c_void_p]),
+    "sw_rpn_select_workspace_bytes": (c_long, [c_int, c_int, ctypes.POINTER(c_int)]),
+    "sw_rpn_select_pack": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                   ctypes.POINTER(c_int), c_int, _F4, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_long, c_void_p]),
+    "sw_rpn_label_workspace_bytes": (c_long, [c_int, c_long, c_int]),
+    "sw_rpn_label_anchors": (c_int, [c_int, c_long, c_void_p, c_void_p, ctypes.POINTER(c_int), c_float, c_float, c_int, c_int,
+                                     ctypes.POINTER(c_u64), c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "sw_roi_label_sample": (c_int, [c_int, c_void_p, c_int, c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_void_p, c_int,
+                                    c_float, c_int, c_int, c_int, ctypes.POINTER(c_u64), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
     "sw_rpn_loss_workspace_floats": (c_long, []),
     "sw_rpn_loss": (c_int, [c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _F4, c_float, c_void_p, c_void_p,
                             c_void_p, c_void_p, c_void_p]),

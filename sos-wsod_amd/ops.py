@@ -810,6 +810,71 @@ def decode_boxes(deltas, boxes, weights, scale_clamp, out):
     return out
 
 
+def rpn_select_pack(logits, deltas, anchors, pre_topk, weights, scale_clamp, img_hw_dev):
+    """RPN proposal selection up to the NMS (sw_rpn_select_pack).  logits: per level (N, n_l) f32; deltas: per level (N, n_l, 4) f32;
+    anchors: per level (n_l, 4); img_hw_dev (N, 2) int32 device.  -> cand_scores (N, L * pre_topk, L + 1), cand_boxes
+    (N, L * pre_topk, 4 L) in sw_detect_postprocess2's form (class = level), finite (N,) int32"""
+    L, N = len(logits), logits[0].shape[0]
+    dev = logits[0].device
+    for t in list(logits) + list(deltas) + list(anchors):
+        _need_gpu(t)
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    n_l = (ctypes.c_int * L)(*[int(a.shape[0]) for a in anchors])
+    arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+    nbytes = int(lib.sw_rpn_select_workspace_bytes(N, L, n_l))
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    rows = L * pre_topk
+    sc = torch.empty(N, rows, L + 1, device=dev); bx = torch.empty(N, rows, 4 * L, device=dev)
+    fin = torch.empty(N, device=dev, dtype=torch.int32); sel = torch.empty(N * L, pre_topk, device=dev, dtype=torch.int32)
+    rw = (ctypes.c_float * 4)(*[float(v) for v in weights])
+    check(lib.sw_rpn_select_pack(N, L, arr(logits), arr(deltas), arr(anchors), n_l, int(pre_topk), rw, float(scale_clamp), _p(img_hw_dev),
+                                 _p(sc), _p(bx), _p(fin), _p(sel), _p(ws), nbytes, _stream()), "sw_rpn_select_pack")
+    return sc, bx, fin
+
+
+def rpn_label_anchors(anchors, gt_boxes, gt_counts, seeds, batch_size, max_pos, thr_lo=0.3, thr_hi=0.7):
+    """RPN anchor labels + matched boxes (sw_rpn_label_anchors).  anchors (A, 4); gt_boxes (sum G_i, 4) the images' boxes back to back;
+    gt_counts: host ints per image; seeds: host ints, (positives, negatives) per image.  -> labels int8 (N, A), matched (N, A, 4)"""
+    _need_gpu(anchors)
+    N, A = len(gt_counts), anchors.shape[0]
+    dev = anchors.device
+    tot = int(sum(gt_counts))
+    assert anchors.dtype == torch.float32 and anchors.is_contiguous() and len(seeds) == 2 * N
+    assert tot == 0 or (gt_boxes.is_cuda and gt_boxes.dtype == torch.float32 and gt_boxes.is_contiguous() and gt_boxes.shape[0] == tot)
+    nbytes = int(lib.sw_rpn_label_workspace_bytes(N, A, tot))
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    labels = torch.empty(N, A, device=dev, dtype=torch.int8); matched = torch.empty(N, A, 4, device=dev)
+    cnt = (ctypes.c_int * N)(*[int(c) for c in gt_counts])
+    sd = (ctypes.c_uint64 * (2 * N))(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds])
+    check(lib.sw_rpn_label_anchors(N, A, _p(anchors), _p(gt_boxes) if tot else None, cnt, float(thr_lo), float(thr_hi), int(batch_size),
+                                   int(max_pos), sd, _p(labels), _p(matched), _p(ws), nbytes, _stream()), "sw_rpn_label_anchors")
+    return labels, matched
+
+
+def roi_label_sample(p_cnt_dev, proposals, gt_boxes, gt_classes_i32, gt_counts, seeds, append_gt, iou_thresh, num_classes, batch_size, max_pos):
+    """ROI-head matching + sampling (sw_roi_label_sample).  proposals (N, p_stride, 4) with device counts p_cnt_dev (N,) int32; gt_boxes
+    (sum G_i, 4) / gt_classes_i32 back to back, gt_counts host ints.  -> count (N,) i32, index / classes (N, batch) i32, boxes / gt_boxes
+    (N, batch, 4): image i's sampled rows are the first count[i] (foreground list, then background, each in random-key order)"""
+    _need_gpu(p_cnt_dev, proposals)
+    N, ps = proposals.shape[0], proposals.shape[1]
+    dev = proposals.device
+    tot = int(sum(gt_counts))
+    assert proposals.dtype == torch.float32 and proposals.is_contiguous() and p_cnt_dev.dtype == torch.int32 and len(seeds) == 2 * N
+    offs, r = [], 0
+    for c in gt_counts:
+        offs.append(r); r += int(c)
+    g_off = (ctypes.c_int * N)(*offs); g_cnt = (ctypes.c_int * N)(*[int(c) for c in gt_counts])
+    sd = (ctypes.c_uint64 * (2 * N))(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds])
+    cnt = torch.empty(N, device=dev, dtype=torch.int32)
+    idx = torch.empty(N, batch_size, device=dev, dtype=torch.int32); cls = torch.empty(N, batch_size, device=dev, dtype=torch.int32)
+    bx = torch.empty(N, batch_size, 4, device=dev); gb = torch.empty(N, batch_size, 4, device=dev)
+    check(lib.sw_roi_label_sample(N, _p(p_cnt_dev), ps, _p(proposals), g_off, g_cnt, _p(gt_boxes) if tot else None,
+                                  _p(gt_classes_i32) if tot else None, int(bool(append_gt)), float(iou_thresh), int(num_classes),
+                                  int(batch_size), int(max_pos), sd, batch_size, _p(cnt), _p(idx), _p(cls), _p(bx), _p(gb), _stream()),
+          "sw_roi_label_sample")
+    return cnt, idx, cls, bx, gb
+
+
 def rpn_loss(logits, deltas, labels_i8, anchors, matched_gt, weights, inv_norm, losses2, dlogits=None, ddeltas=None):
     """logits (n,), deltas (n, 4), labels int8 (n,), anchors (A, 4) repeating over the images, matched_gt (n, 4) -> losses2 (2,)"""
     _need_gpu(logits, deltas, labels_i8, anchors, matched_gt, losses2)

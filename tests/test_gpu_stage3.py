@@ -282,6 +282,133 @@ def test_eval_mode_inference_rescales_to_the_dataset_frame_like_the_reference(go
         assert tuple(plain[i]["instances"].image_size) == tuple(int(v) for v in t["sizes"][i])
 
 
+# ------------------------------------------------------------------------------------------ index-side kernels (csrc/proposals.hip)
+def _seed(tag, k):
+    from oracle import detgen
+    return detgen.fnv1a64(f"{tag}perm{k}")
+
+
+@pytest.mark.parametrize("hw,n_gt", [((96, 128), [3, 0]), ((160, 224), [5, 1]), ((800, 1216), [4, 2])])
+def test_rpn_label_anchors_kernel_against_the_oracle(ops, hw, n_gt):
+    """sw_rpn_label_anchors: IoU matching with low-quality matches + the random-key label sampling on the device, against
+    oracle.frcnn_oracle.rpn_label_and_sample (rpn.py:305-360, matcher.py:60-126, sampling.py:8-54) — labels of EVERY anchor equal,
+    matched boxes equal; up to 242 991 anchors per image, an image without ground truth included"""
+    h, w = hw
+    grids = [((h + s - 1) // s, (w + s - 1) // s) for s in (4, 8, 16, 32, 64)]
+    anchors = np.concatenate(FO.grid_anchors(grids), 0).astype(np.float32)
+    A = anchors.shape[0]
+    rng = np.random.RandomState(h + sum(n_gt))
+    gts = []
+    for n in n_gt:
+        x1 = rng.rand(n) * (w - 40); y1 = rng.rand(n) * (h - 40)
+        b = np.stack([x1, y1, x1 + 16 + rng.rand(n) * (w - x1 - 16), y1 + 16 + rng.rand(n) * (h - y1 - 16)], 1).astype(np.float32)
+        if n:
+            b[0] = anchors[A // 3]                              # one box that IS an anchor: IoU 1.0, ties with the low-quality rule
+        gts.append(b)
+    tag = f"lab{h}"
+    perm = FO.Perm(tag)
+    want_labels, want_matched = FO.rpn_label_and_sample(anchors, gts, perm)
+    seeds = [_seed(tag, k) for k in range(2 * len(gts))]
+    cat = torch.from_numpy(np.concatenate(gts, 0)).cuda() if sum(n_gt) else torch.zeros(0, 4, device="cuda")
+    labels, matched = ops.rpn_label_anchors(torch.from_numpy(anchors).cuda(), cat, n_gt, seeds, 256, 64)
+    torch.cuda.synchronize()
+    for i in range(len(gts)):
+        got = labels[i].cpu().numpy().astype(np.int64)
+        assert np.array_equal(got, want_labels[i]), (i, int((got != want_labels[i]).sum()))
+        assert (got == 1).sum() <= 64 and (got >= 0).sum() == min(256, A)
+        pos = got == 1
+        assert np.array_equal(matched[i].cpu().numpy()[pos], want_matched[i][pos])
+        if n_gt[i]:
+            assert np.array_equal(matched[i].cpu().numpy(), want_matched[i])
+
+
+def test_rpn_select_pack_kernel_against_the_oracle(ops):
+    """sw_rpn_select_pack: per (image, level) the pre_topk best logits with torch.sort(descending, stable) ties, decoded, clipped and
+    packed for the per-level NMS — against oracle find_top_rpn_proposals' selection stage (proposal_utils.py:22-106).  Logits are
+    quantised so that thousands of exact ties straddle the cut; one level is shorter than pre_topk; a NaN delta must clear `finite`."""
+    rng = np.random.RandomState(5)
+    N, pre = 2, 1000
+    n_l = [30000, 7500, 1900, 480, 120]
+    H, W = 200, 304
+    anchors, logits, deltas = [], [], []
+    for n in n_l:
+        x1 = rng.rand(n) * (W - 20); y1 = rng.rand(n) * (H - 20)
+        anchors.append(np.stack([x1 - 10, y1 - 10, x1 + 8 + rng.rand(n) * 120, y1 + 8 + rng.rand(n) * 90], 1).astype(np.float32))
+        logits.append((np.round(rng.randn(N, n) * 8) / 8).astype(np.float32))            # many exact ties
+        deltas.append((rng.randn(N, n, 4) * 0.4).astype(np.float32))
+    logits[1][0, :3000] = 2.5                                                             # 3000 tied values right at the top of a level
+    img_hw = torch.tensor([[H, W], [H - 40, W - 64]], dtype=torch.int32).cuda()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    sc, bx, fin = ops.rpn_select_pack([t(l) for l in logits], [t(d) for d in deltas], [t(a) for a in anchors], pre, (1.0, 1.0, 1.0, 1.0),
+                                      float(np.log(1000.0 / 16)), img_hw)
+    torch.cuda.synchronize()
+    assert all(v != 0 for v in fin.tolist())
+    L = len(n_l)
+    sc, bx = sc.cpu().numpy(), bx.cpu().numpy()
+    for img in range(N):
+        h, w = (int(v) for v in img_hw[img].tolist())
+        for l, n in enumerate(n_l):
+            k = min(n, pre)
+            idx = FO._sort_desc_stable(logits[l][img])[:k]
+            props = FO.O.apply_deltas(torch.from_numpy(deltas[l][img]), torch.from_numpy(anchors[l]), (1.0, 1.0, 1.0, 1.0)).numpy()[idx]
+            rows = slice(l * pre, l * pre + k)
+            got_b = bx[img, rows, 4 * l:4 * l + 4]
+            np.testing.assert_allclose(got_b, props, rtol=1e-5, atol=1e-3)
+            assert np.array_equal(bx[img, rows, :4], got_b)                              # the box is repeated in every level's columns
+            cb = props.copy(); cb[:, 0::2] = cb[:, 0::2].clip(0, w); cb[:, 1::2] = cb[:, 1::2].clip(0, h)
+            keep = ((cb[:, 2] - cb[:, 0]) > 0) & ((cb[:, 3] - cb[:, 1]) > 0)
+            want_s = np.where(keep, logits[l][img][idx], -np.inf).astype(np.float32)
+            got_s = sc[img, rows, l]
+            edge = np.abs((cb[:, 2] - cb[:, 0])) < 1e-3                                    # expf ulps may move a box across "empty"
+            assert np.array_equal(got_s[~edge], want_s[~edge]), (img, l)
+            other = np.delete(sc[img, rows], l, axis=1)
+            assert np.isneginf(other).all() and np.isneginf(sc[img, l * pre + k:(l + 1) * pre]).all()
+    deltas[2][1, 7, 2] = np.nan
+    logits[2][1, 7] = 100.0                                                               # make sure the NaN row is selected
+    _, _, fin = ops.rpn_select_pack([t(l) for l in logits], [t(d) for d in deltas], [t(a) for a in anchors], pre, (1.0, 1.0, 1.0, 1.0),
+                                    float(np.log(1000.0 / 16)), img_hw)
+    assert fin.tolist()[0] != 0 and fin.tolist()[1] == 0
+
+
+@pytest.mark.parametrize("P,n_gt,append", [(300, [3, 0], True), (1000, [5, 2], True), (1000, [4, 1], False), (2000, [6, 3], True)])
+def test_roi_label_sample_kernel_against_the_oracle(ops, P, n_gt, append):
+    """sw_roi_label_sample against oracle.frcnn_oracle.roi_label_and_sample (roi_heads.py:324-375): sampled rows in the same ORDER
+    (foreground by random key, then background), classes, boxes and matched ground truth equal; device-side proposal counts"""
+    K = 20
+    rng = np.random.RandomState(P + sum(n_gt))
+    H, W = 400, 600
+    props, gts, cnts = [], [], []
+    for n in n_gt:
+        x1 = rng.rand(n) * (W - 150); y1 = rng.rand(n) * (H - 150)
+        gb = np.stack([x1, y1, x1 + 60 + rng.rand(n) * 80, y1 + 60 + rng.rand(n) * 80], 1).astype(np.float32)
+        gc = rng.randint(0, K, n)
+        cnt = P - rng.randint(0, 40)                              # the RPN kept fewer than the stride for this image
+        x1 = rng.rand(cnt) * (W - 30); y1 = rng.rand(cnt) * (H - 30)
+        pb = np.stack([x1, y1, x1 + 10 + rng.rand(cnt) * 200, y1 + 10 + rng.rand(cnt) * 200], 1).astype(np.float32)
+        if n:
+            pb[:40] = gb[rng.randint(0, n, 40)] + rng.randn(40, 4).astype(np.float32) * 4     # foreground candidates
+        props.append(pb); gts.append((gb, gc)); cnts.append(cnt)
+    tag = f"roi{P}{int(append)}"
+    want = FO.roi_label_and_sample([{"boxes": p} for p in props], gts, K, FO.Perm(tag), append_gt=append)
+    N = len(n_gt)
+    buf = np.zeros((N, P, 4), np.float32)
+    for i, p in enumerate(props):
+        buf[i, :len(p)] = p
+    cat_b = torch.from_numpy(np.concatenate([g[0] for g in gts], 0)).cuda()
+    cat_c = torch.from_numpy(np.concatenate([g[1] for g in gts], 0).astype(np.int32)).cuda()
+    cnt, idx, cls, bx, gb = ops.roi_label_sample(torch.tensor(cnts, dtype=torch.int32).cuda(), torch.from_numpy(buf).cuda(), cat_b, cat_c, n_gt,
+                                                 [_seed(tag, k) for k in range(2 * N)], append, 0.5, K, 512, 128)
+    torch.cuda.synchronize()
+    for i in range(N):
+        n = int(cnt[i])
+        assert n == len(want[i]["sampled_idx"]) == min(512, cnts[i] + (n_gt[i] if append else 0))
+        assert np.array_equal(idx[i, :n].cpu().numpy(), want[i]["sampled_idx"])
+        assert np.array_equal(cls[i, :n].cpu().numpy(), want[i]["gt_classes"])
+        assert np.array_equal(bx[i, :n].cpu().numpy(), want[i]["boxes"])
+        assert np.array_equal(gb[i, :n].cpu().numpy(), want[i]["gt_boxes"])
+        assert (cls[i, :n] != K).sum() <= 128
+
+
 # ------------------------------------------------------------------------------------------ the step on the real modules
 def test_semisup_step_burn_in_and_semi_supervised_iteration_on_the_real_detector():
     """unbias/ubteacher/engine/trainer.py:436-549 with the real student / teacher: iteration 0 = burn-in (supervised branch on the
