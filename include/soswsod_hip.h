@@ -423,11 +423,14 @@ int sw_downsample2x_sum(int dtype, int N, int h, int w, int C, const void* g, vo
  * arithmetic as stated in-tree at uwsod/detectron2/layers/csrc/ROIAlign/ROIAlign_cpu.cpp:20-400).  feat [N][H][W][C] of ONE
  * FPN level; rois [R][5] (batch, x1, y1, x2, y2); sel [n_sel] int32 = the rows of `rois` / `out` assigned to this level
  * (poolers.py:232-250 loops over the levels); out [R][C][PH][PW] with row pitch ld_out (rows not in `sel` are not touched).
+ * n_sel_dev (may be NULL): DEVICE int holding the real length of `sel` (sw_roi_assign_levels' sel_cnt); n_sel is then its host bound.
  * Backward: dfeat_f32 [N][H][W][C] float32, zero-filled by the caller, accumulated with f32 atomics. */
 int sw_roi_align_fwd(int dtype, int H, int W, int C, int PH, int PW, float spatial_scale, int sampling_ratio, const void* feat,
-                     const float* rois, const int32_t* sel, int n_sel, void* out, long ld_out, sw_stream_t stream);
+                     const float* rois, const int32_t* sel, int n_sel, const int32_t* n_sel_dev, void* out, long ld_out,
+                     sw_stream_t stream);
 int sw_roi_align_bwd(int dtype, int H, int W, int C, int PH, int PW, float spatial_scale, int sampling_ratio, const void* gout,
-                     long ld, const float* rois, const int32_t* sel, int n_sel, float* dfeat_f32, sw_stream_t stream);
+                     long ld, const float* rois, const int32_t* sel, int n_sel, const int32_t* n_sel_dev, float* dfeat_f32,
+                     sw_stream_t stream);
 /* Box2BoxTransform.apply_deltas (box_regression.py:76-116): out[i] = decode(deltas[i], boxes[i % n_boxes]); deltas row pitch
  * ld_deltas floats; weights4: HOST float[4]; dw, dh clamped to scale_clamp. */
 int sw_decode_boxes(long n, long n_boxes, const float* deltas, long ld_deltas, const float* boxes, const float* weights4,
@@ -440,13 +443,15 @@ int sw_decode_boxes(long n, long n_boxes, const float* deltas, long ld_deltas, c
  * pre_topk rows from l * pre_topk, in descending score order; cand_scores [rows][L + 1] = -inf except column l (-inf there too for
  * unused rows and for boxes that are empty after clipping to img_hw_dev[i] = (h, w): proposal_utils.py:96-106), cand_boxes
  * [rows][4 L] the box repeated.  finite_dev[i] = 0 if a selected box / logit is not finite (:86-94), else nonzero.
- * logits / deltas / anchors: HOST arrays of L device pointers, level l: logits [N][n_l], deltas [N][n_l][4], anchors [n_l][4].
+ * logits / deltas / anchors: HOST arrays of L device pointers, level l: logits [N][n_l], deltas [N][n_l][4], anchors [n_l][4];
+ * img_stride != 0: image i's row of level l starts img_stride anchors after image i-1's (the levels are column ranges of ONE
+ * [N][sum n_l] array, sw_rpn_unpack's output), 0: every level is dense on its own.
  * sel_idx: int32 [N * L][pre_topk] scratch.  pre_topk <= 16384, N * L <= 40. */
 long sw_rpn_select_workspace_bytes(int N, int L, const int* n_per_level);
 int sw_rpn_select_pack(int N, int L, const float* const* logits, const float* const* deltas, const float* const* anchors,
-                       const int* n_per_level, int pre_topk, const float* weights4, float scale_clamp, const int* img_hw_dev,
-                       float* cand_scores, float* cand_boxes, int* finite_dev, int* sel_idx, void* workspace, long workspace_bytes,
-                       sw_stream_t stream);
+                       const int* n_per_level, long img_stride, int pre_topk, const float* weights4, float scale_clamp,
+                       const int* img_hw_dev, float* cand_scores, float* cand_boxes, int* finite_dev, int* sel_idx, void* workspace,
+                       long workspace_bytes, sw_stream_t stream);
 /* RPN anchor labels (detectron2/.../proposal_generator/rpn.py:305-360 label_and_sample_anchors): IoU of every anchor [A][4] with the
  * image's ground-truth boxes (gt_boxes: the images' boxes back to back, gt_count_per_image HOST array), Matcher thresholds
  * [thr_lo, thr_hi] with labels [0, -1, 1] and low-quality matches (matcher.py:60-126), then subsample_labels (sampling.py:8-54):
@@ -469,6 +474,23 @@ int sw_roi_label_sample(int n_img, const int* p_cnt_dev, int p_stride, const flo
                         const float* gt_boxes, const int32_t* gt_classes, int append_gt, float iou_thresh, int num_classes,
                         int batch_size, int max_pos, const uint64_t* seeds, int out_stride, int32_t* out_count, int32_t* out_index,
                         int32_t* out_classes, float* out_boxes, float* out_gt_boxes, sw_stream_t stream);
+/* The RPN head's output in anchor order.  y [rows][ld] f32 is ONE GEMM over the pixels of all levels (row = level offset + image *
+ * hw_per_level[l] + pixel; columns [objectness a | delta 4 a + b], A anchors per location); logits [N][At], deltas [N][At][4] with
+ * At = A * sum hw: level-major, location-major, anchor-minor — the order of rpn.py:230-260 / anchor_generator.py.  _bwd: dy from the
+ * two gradients (either may be NULL), each times its DEVICE scalar g_*_dev (NULL = 1: the losses' cotangents), every column written
+ * (padding 0). */
+int sw_rpn_unpack(int N, int L, int A, const int* hw_per_level, const float* y, long ld, float* logits, float* deltas, sw_stream_t stream);
+int sw_rpn_unpack_bwd(int N, int L, int A, const int* hw_per_level, const float* dlogits, const float* ddeltas,
+                      const float* g_logits_dev, const float* g_deltas_dev, float* dy, long ld, sw_stream_t stream);
+/* FPN level of every ROI (poolers.py:17-50,196-250): image i contributes row_cnt[i] boxes starting at boxes + box_off_floats[i]
+ * (HOST arrays); rois [R][5] = (image, box) dense, level_of [R] in 0..3 (= level 2..5), sel [4][R] the rows of each level in ascending
+ * order, sel_cnt [4] their counts (DEVICE: sw_roi_align_* read them).  R <= 8192. */
+int sw_roi_assign_levels(int n_img, const int* row_cnt, const long* box_off_floats, const float* boxes, float* rois, int32_t* level_of,
+                         int32_t* sel, int32_t* sel_cnt, sw_stream_t stream);
+/* out[m][n] = in[m][n] * (n < split ? g0_dev[0] : g1_dev[0]) for n < N, 0 for the padding columns N <= n < ld (in and out share the row
+ * pitch ld): the cotangents of the ROI heads' two losses (fast_rcnn.py:73-105) applied to the unit gradient of the packed logits. */
+int sw_scale_col_blocks(long M, int N, int split, const float* in, long ld, const float* g0_dev, const float* g1_dev, float* out,
+                        sw_stream_t stream);
 /* RPN losses (proposal_generator/rpn.py:362-420, box_regression.py:229-260) over n = N * A anchors: losses2[0] = sum over
  * label >= 0 of BCE-with-logits(logit, label) * inv_norm, losses2[1] = sum over label == 1 of |delta - get_deltas(anchor, gt)|_1
  * * inv_norm (smooth-L1 with beta 0), and their unit gradients dlogits [n], ddeltas [n][4] (either may be NULL).  anchors

@@ -171,13 +171,19 @@ SIGNATURES = {
     "sw_upsample2x_add": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_downsample2x_sum": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_roi_align_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int,
-                                 c_void_p, c_long, c_void_p]),
+                                 c_void_p, c_void_p, c_long, c_void_p]),
     "sw_roi_align_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p, c_void_p,
-                                 c_int, c_void_p, c_void_p]),
+                                 c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_scale_col_blocks": (c_int, [c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sw_rpn_unpack": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "sw_rpn_unpack_bwd": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long,
+                                  c_void_p]),
+    "sw_roi_assign_levels": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_long), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
     "sw_decode_boxes": (c_int, [c_long, c_long, c_void_p, c_long, c_void_p, _F4, c_float, c_void_p, c_void_p]),
     "sw_rpn_select_workspace_bytes": (c_long, [c_int, c_int, ctypes.POINTER(c_int)]),
     "sw_rpn_select_pack": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
-                                   ctypes.POINTER(c_int), c_int, _F4, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   ctypes.POINTER(c_int), c_long, c_int, _F4, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_long, c_void_p]),
     "sw_rpn_label_workspace_bytes": (c_long, [c_int, c_long, c_int]),
     "sw_rpn_label_anchors": (c_int, [c_int, c_long, c_void_p, c_void_p, ctypes.POINTER(c_int), c_float, c_float, c_int, c_int,

@@ -212,8 +212,8 @@ __device__ __forceinline__ float align_coord(float start, int p, float bin, int 
 template <typename T>
 __global__ void roi_align_fwd_kernel(int H, int W, int C, int PH, int PW, float scale, int sampling_ratio,
                                      const T* __restrict__ feat, const float* __restrict__ rois, const int* __restrict__ sel,
-                                     int n_sel, T* __restrict__ out, long ld) {
-  const long n = (long)n_sel * PH * PW * C;
+                                     int n_sel, const int* __restrict__ n_sel_dev, T* __restrict__ out, long ld) {
+  const long n = (long)(n_sel_dev ? min(n_sel_dev[0], n_sel) : n_sel) * PH * PW * C;     // device count: no host round trip for the level lists
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C); long r = i / C;
     const int pw = (int)(r % PW); r /= PW;
@@ -272,8 +272,8 @@ __device__ __forceinline__ AxisW align_axis_weights(float start, int p, float bi
 template <typename T>
 __global__ void roi_align_bwd_kernel(int H, int W, int C, int PH, int PW, float scale, int sampling_ratio,
                                      const T* __restrict__ gout, long ld, const float* __restrict__ rois,
-                                     const int* __restrict__ sel, int n_sel, float* __restrict__ dfeat) {
-  const long n = (long)n_sel * PH * PW * C;
+                                     const int* __restrict__ sel, int n_sel, const int* __restrict__ n_sel_dev, float* __restrict__ dfeat) {
+  const long n = (long)(n_sel_dev ? min(n_sel_dev[0], n_sel) : n_sel) * PH * PW * C;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C); long r = i / C;
     const int pw = (int)(r % PW); r /= PW;
@@ -549,7 +549,7 @@ extern "C" int sw_downsample2x_sum(int dtype, int N, int h, int w, int C, const 
 }
 
 extern "C" int sw_roi_align_fwd(int dtype, int H, int W, int C, int PH, int PW, float spatial_scale, int sampling_ratio,
-                                const void* feat, const float* rois, const int32_t* sel, int n_sel, void* out, long ld_out,
+                                const void* feat, const float* rois, const int32_t* sel, int n_sel, const int32_t* n_sel_dev, void* out, long ld_out,
                                 hipStream_t stream) {
   SW_ENTER();
   if (n_sel <= 0) return 0;
@@ -557,15 +557,15 @@ extern "C" int sw_roi_align_fwd(int dtype, int H, int W, int C, int PH, int PW, 
   const long n = (long)n_sel * PH * PW * C;
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(roi_align_fwd_kernel<unsigned short>, dim3(grid_for_n(n)), dim3(256), 0, stream, H, W, C, PH, PW,
-                       spatial_scale, sampling_ratio, (const unsigned short*)feat, rois, sel, n_sel, (unsigned short*)out, ld_out),
+                       spatial_scale, sampling_ratio, (const unsigned short*)feat, rois, sel, n_sel, n_sel_dev, (unsigned short*)out, ld_out),
     hipLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3(grid_for_n(n)), dim3(256), 0, stream, H, W, C, PH, PW, spatial_scale,
-                       sampling_ratio, (const float*)feat, rois, sel, n_sel, (float*)out, ld_out));
+                       sampling_ratio, (const float*)feat, rois, sel, n_sel, n_sel_dev, (float*)out, ld_out));
   SW_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int sw_roi_align_bwd(int dtype, int H, int W, int C, int PH, int PW, float spatial_scale, int sampling_ratio,
-                                const void* gout, long ld, const float* rois, const int32_t* sel, int n_sel, float* dfeat_f32,
+                                const void* gout, long ld, const float* rois, const int32_t* sel, int n_sel, const int32_t* n_sel_dev, float* dfeat_f32,
                                 hipStream_t stream) {
   SW_ENTER();
   if (n_sel <= 0) return 0;
@@ -573,9 +573,9 @@ extern "C" int sw_roi_align_bwd(int dtype, int H, int W, int C, int PH, int PW, 
   const long n = (long)n_sel * PH * PW * C;
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(roi_align_bwd_kernel<unsigned short>, dim3(grid_for_n(n)), dim3(256), 0, stream, H, W, C, PH, PW,
-                       spatial_scale, sampling_ratio, (const unsigned short*)gout, ld, rois, sel, n_sel, dfeat_f32),
+                       spatial_scale, sampling_ratio, (const unsigned short*)gout, ld, rois, sel, n_sel, n_sel_dev, dfeat_f32),
     hipLaunchKernelGGL(roi_align_bwd_kernel<float>, dim3(grid_for_n(n)), dim3(256), 0, stream, H, W, C, PH, PW, spatial_scale,
-                       sampling_ratio, (const float*)gout, ld, rois, sel, n_sel, dfeat_f32));
+                       sampling_ratio, (const float*)gout, ld, rois, sel, n_sel, n_sel_dev, dfeat_f32));
   SW_CHECK_LAUNCH();
   return 0;
 }

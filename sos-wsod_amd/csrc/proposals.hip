@@ -281,12 +281,13 @@ struct RpnLevels {
   const float* anchors[8];     // per level [n_l][4]
   int n[8];
   int L, N;
+  long img_stride;             // anchors between two images' rows (0: n[l], i.e. each level dense on its own)
 };
 // keys of every (image, level) segment, segment-major: seg = img * L + level
 __global__ void rpn_keys_kernel(RpnLevels lv, SegTab t, unsigned* __restrict__ keys) {
   const int s = blockIdx.y, img = s / lv.L, l = s - img * lv.L;
   const int n = lv.n[l];
-  const float* lg = lv.logits[l] + (long)img * n;
+  const float* lg = lv.logits[l] + (long)img * (lv.img_stride ? lv.img_stride : n);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[t.s[s].off + i] = desc_key(lg[i]);
 }
 
@@ -333,9 +334,10 @@ __global__ __launch_bounds__(1024) void rpn_sort_pack_kernel(int CAP, RpnLevels 
     for (int c = 0; c <= L; ++c) sc[c] = ninf;
     if (r >= n_sel) { for (int c = 0; c < 4 * L; ++c) bx[c] = 0.f; continue; }
     const int a = (int)(sk[r] & 0xFFFFFFFFu);
-    const float* d = lv.deltas[l] + ((long)img * n + a) * 4;
+    const long irow = (long)img * (lv.img_stride ? lv.img_stride : n) + a;
+    const float* d = lv.deltas[l] + irow * 4;
     const float* an = lv.anchors[l] + (long)a * 4;
-    const float logit = lv.logits[l][(long)img * n + a];
+    const float logit = lv.logits[l][irow];
     // apply_deltas: widths / heights / centres of the anchor, deltas / weights, clamp dw, dh
     const float aw = __fsub_rn(an[2], an[0]), ah = __fsub_rn(an[3], an[1]);
     const float cx = __fadd_rn(an[0], __fmul_rn(0.5f, aw)), cy = __fadd_rn(an[1], __fmul_rn(0.5f, ah));
@@ -562,6 +564,108 @@ __global__ __launch_bounds__(1024) void roi_sample_kernel(RoiSampleArgs ra, cons
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- RPN head output <-> anchor order
+// The RPN head's two 1x1 convolutions run as ONE GEMM over the pixels of all levels: y [rows][ld] f32, row = row_off[l] + img * hw[l] +
+// pixel, columns [objectness a | delta a * 4 + b] (A anchors per location).  The losses and the proposal selection want the anchor order
+// of the reference (level-major, location-major, anchor-minor per image): logits [N][At], deltas [N][At][4].
+struct RpnMap { int row_off[8], hw[8], a_off[9]; int L, N, A; long ld; };
+__global__ void rpn_unpack_kernel(RpnMap m, const float* __restrict__ y, float* __restrict__ logits, float* __restrict__ deltas) {
+  const long At = m.a_off[m.L];
+  const long total = (long)m.N * At;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int img = (int)(i / At); const int j = (int)(i - (long)img * At);
+    int l = 0;
+    while (l + 1 < m.L && j >= m.a_off[l + 1]) ++l;
+    const int q = j - m.a_off[l], pix = q / m.A, a = q - pix * m.A;
+    const float* row = y + ((long)m.row_off[l] + (long)img * m.hw[l] + pix) * m.ld;
+    logits[i] = row[a];
+    const float* d = row + m.A + 4 * a;
+    ((float4*)deltas)[i] = make_float4(d[0], d[1], d[2], d[3]);
+  }
+}
+// dy [rows][ld] from (dlogits, ddeltas) (either may be NULL = zero); padding columns written as 0
+__global__ void rpn_unpack_bwd_kernel(RpnMap m, long rows, const float* __restrict__ dlogits, const float* __restrict__ ddeltas,
+                                      const float* __restrict__ g_logits, const float* __restrict__ g_deltas, float* __restrict__ dy) {
+  const long At = m.a_off[m.L];
+  const long total = rows * m.ld;
+  const float sl = g_logits ? g_logits[0] : 1.f, sd = g_deltas ? g_deltas[0] : 1.f;     // cotangents of the two losses (device scalars)
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / m.ld; const int c = (int)(i - r * m.ld);
+    float v = 0.f;
+    if (c < 5 * m.A) {
+      int l = 0;
+      while (l + 1 < m.L && r >= m.row_off[l + 1]) ++l;
+      const long rr = r - m.row_off[l];
+      const int img = (int)(rr / m.hw[l]), pix = (int)(rr - (long)img * m.hw[l]);
+      if (c < m.A) { if (dlogits) v = __fmul_rn(dlogits[(long)img * At + m.a_off[l] + (long)pix * m.A + c], sl); }
+      else {
+        const int a = (c - m.A) >> 2, b = (c - m.A) & 3;
+        if (ddeltas) v = __fmul_rn(ddeltas[((long)img * At + m.a_off[l] + (long)pix * m.A + a) * 4 + b], sd);
+      }
+    }
+    dy[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- FPN level of every ROI
+// poolers.py:17-50 assign_boxes_to_levels + convert_boxes_to_pooler_format: dense ROI rows [R][5] = (image, box) gathered from the
+// images' box blocks, level = clamp(floor(4 + log2(sqrt(area) / 224 + 1e-8)), 2, 5) - 2, and per level the rows of that level in
+// ascending order (as nonzero lists them) with their count — one workgroup, R <= 8192.
+struct LevelArgs { int n_img; int row_off[8], row_cnt[8]; long box_off[8]; };
+__global__ __launch_bounds__(1024) void roi_levels_kernel(LevelArgs g, int R, const float* __restrict__ boxes, float* __restrict__ rois,
+                                                          int* __restrict__ level_of, int* __restrict__ sel /*[4][R]*/, int* __restrict__ sel_cnt) {
+  __shared__ unsigned sh[1024];
+  __shared__ int s_base[4];
+  if (threadIdx.x < 4) s_base[threadIdx.x] = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < R; r0 += 1024) {
+    const int r = r0 + threadIdx.x;
+    int lv = -1;
+    if (r < R) {
+      int img = 0;
+      while (img + 1 < g.n_img && r >= g.row_off[img + 1]) ++img;
+      const float4 b = ((const float4*)(boxes + g.box_off[img]))[r - g.row_off[img]];
+      float* o = rois + (long)r * 5;
+      o[0] = (float)img; o[1] = b.x; o[2] = b.y; o[3] = b.z; o[4] = b.w;
+      const float size = sqrtf(__fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y)));
+      const float t = floorf(__fadd_rn(4.0f, log2f(__fadd_rn(__fdiv_rn(size, 224.0f), 1e-8f))));
+      lv = (int)fminf(fmaxf(t, 2.0f), 5.0f) - 2;                 // (a NaN size — a degenerate box — lands on level 0 like torch.clamp of NaN -> ... see test)
+      level_of[r] = lv;
+    }
+    for (int l = 0; l < 4; ++l) {
+      const unsigned f = lv == l ? 1u : 0u;
+      sh[threadIdx.x] = f;
+      __syncthreads();
+      for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+      }
+      const unsigned incl = sh[threadIdx.x], tot = sh[1023];
+      __syncthreads();
+      if (f) sel[(long)l * R + s_base[l] + incl - 1] = r;
+      __syncthreads();
+      if (threadIdx.x == 0) s_base[l] += (int)tot;
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x < 4) sel_cnt[threadIdx.x] = s_base[threadIdx.x];
+}
+
+// out[m][n] = in[m][n] * (n < split ? g0[0] : g1[0]): the two cotangents of the ROI heads' (classification, box) losses applied to the
+// unit gradient of the packed logits in one pass
+__global__ void scale_col_blocks_kernel(long M, int N, int split, const float* __restrict__ in, long ld, const float* __restrict__ g0,
+                                        const float* __restrict__ g1, float* __restrict__ out) {
+  const float a = g0[0], b = g1[0];
+  const long total = M * ld;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % ld);
+    out[i] = n < N ? __fmul_rn(in[i], n < split ? a : b) : 0.f;
+  }
+}
+
 }  // namespace
 
 // =================================================================================================== entry points
@@ -573,14 +677,14 @@ extern "C" long sw_rpn_select_workspace_bytes(int N, int L, const int* n_per_lev
 }
 
 extern "C" int sw_rpn_select_pack(int N, int L, const float* const* logits, const float* const* deltas, const float* const* anchors,
-                                  const int* n_per_level, int pre_topk, const float* weights4, float scale_clamp, const int* img_hw_dev,
-                                  float* cand_scores, float* cand_boxes, int* finite_dev, int* sel_idx, void* workspace,
-                                  long workspace_bytes, hipStream_t stream) {
+                                  const int* n_per_level, long img_stride, int pre_topk, const float* weights4, float scale_clamp,
+                                  const int* img_hw_dev, float* cand_scores, float* cand_boxes, int* finite_dev, int* sel_idx,
+                                  void* workspace, long workspace_bytes, hipStream_t stream) {
   SW_ENTER();
-  if (N < 1 || L < 1 || L > 8 || N * L > MAX_SEG || pre_topk < 1 || pre_topk > 16384) return -5;
+  if (N < 1 || L < 1 || L > 8 || N * L > MAX_SEG || pre_topk < 1 || pre_topk > 16384 || img_stride < 0) return -5;
   if (workspace_bytes < sw_rpn_select_workspace_bytes(N, L, n_per_level)) return -6;
   RpnLevels lv = {};
-  lv.L = L; lv.N = N;
+  lv.L = L; lv.N = N; lv.img_stride = img_stride;
   long tot = 0; int mx = 0;
   for (int l = 0; l < L; ++l) {
     lv.logits[l] = logits[l]; lv.deltas[l] = deltas[l]; lv.anchors[l] = anchors[l]; lv.n[l] = n_per_level[l];
@@ -681,6 +785,67 @@ extern "C" int sw_roi_label_sample(int n_img, const int* p_cnt_dev, int p_stride
   }
   hipLaunchKernelGGL(roi_sample_kernel<4096>, dim3(n_img), dim3(1024), 0, stream, ra, p_cnt_dev, proposals, gt_boxes, gt_classes, append_gt,
                      iou_thresh, num_classes, batch_size, max_pos, out_stride, out_count, out_index, out_classes, out_boxes, out_gt_boxes);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+static RpnMap make_rpn_map(int N, int L, int A, const int* hw_per_level, long ld) {
+  RpnMap m = {};
+  m.L = L; m.N = N; m.A = A; m.ld = ld;
+  int ro = 0, ao = 0;
+  for (int l = 0; l < L; ++l) { m.row_off[l] = ro; m.hw[l] = hw_per_level[l]; m.a_off[l] = ao; ro += N * hw_per_level[l]; ao += hw_per_level[l] * A; }
+  m.a_off[L] = ao;
+  return m;
+}
+
+extern "C" int sw_rpn_unpack(int N, int L, int A, const int* hw_per_level, const float* y, long ld, float* logits, float* deltas,
+                             hipStream_t stream) {
+  SW_ENTER();
+  if (N < 1 || L < 1 || L > 8 || A < 1 || ld < 5 * A) return -5;
+  const RpnMap m = make_rpn_map(N, L, A, hw_per_level, ld);
+  const long total = (long)N * m.a_off[L];
+  const long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(rpn_unpack_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, m, y, logits, deltas);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_rpn_unpack_bwd(int N, int L, int A, const int* hw_per_level, const float* dlogits, const float* ddeltas,
+                                 const float* g_logits_dev, const float* g_deltas_dev, float* dy, long ld, hipStream_t stream) {
+  SW_ENTER();
+  if (N < 1 || L < 1 || L > 8 || A < 1 || ld < 5 * A) return -5;
+  const RpnMap m = make_rpn_map(N, L, A, hw_per_level, ld);
+  long rows = 0;
+  for (int l = 0; l < L; ++l) rows += (long)N * hw_per_level[l];
+  const long blocks = (rows * ld + 255) / 256;
+  hipLaunchKernelGGL(rpn_unpack_bwd_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, m, rows, dlogits, ddeltas, g_logits_dev, g_deltas_dev, dy);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_roi_assign_levels(int n_img, const int* row_cnt, const long* box_off_floats, const float* boxes, float* rois,
+                                    int32_t* level_of, int32_t* sel, int32_t* sel_cnt, hipStream_t stream) {
+  SW_ENTER();
+  if (n_img < 1 || n_img > 8) return -5;
+  LevelArgs g = {};
+  g.n_img = n_img;
+  int R = 0;
+  for (int i = 0; i < n_img; ++i) { g.row_off[i] = R; g.row_cnt[i] = row_cnt[i]; g.box_off[i] = box_off_floats[i]; R += row_cnt[i]; }
+  if (R > 8192) return -6;
+  if (R == 0) return (int)hipMemsetAsync(sel_cnt, 0, 16, stream);
+  hipLaunchKernelGGL(roi_levels_kernel, dim3(1), dim3(1024), 0, stream, g, R, boxes, rois, level_of, sel, sel_cnt);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_scale_col_blocks(long M, int N, int split, const float* in, long ld, const float* g0_dev, const float* g1_dev, float* out,
+                                   hipStream_t stream) {
+  SW_ENTER();
+  if (M <= 0) return 0;
+  if (N < 1 || ld < N || split < 0 || split > N) return -5;
+  const long blocks = (M * ld + 255) / 256;
+  hipLaunchKernelGGL(scale_col_blocks_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, M, N, split, in, ld,
+                     g0_dev, g1_dev, out);
   SW_CHECK_LAUNCH();
   return 0;
 }

@@ -12,12 +12,13 @@ Execution plan (MI355X-first): NHWC activations end to end; a 1x1 convolution is
 subsample in front, STRIDE_IN_1X1), a 3x3 convolution the implicit-GEMM / direct MFMA kernel with bias + ReLU fused, FrozenBN is
 folded into the weight and bias; the frozen stem + res2 run without autograd; ROIAlign, the FPN joins, the RPN losses, the focal
 / L1 losses, box decoding and NMS are kernels of csrc/detector.hip / heads.hip.  Every dense layer is a torch.autograd.Function
-around those kernels with an explicit backward; autograd only links the nodes.  What still runs as torch-ROCm tensor ops:
-anchor <-> ground-truth matching, the label sampling and the per-level top-k sort (integer / index logic on a few thousand to
-a few hundred thousand elements, host-synchronising exactly where the reference's `nonzero` does) — see DESIGN.md §8.
+around those kernels with an explicit backward; autograd only links the nodes.  The index side — per-level top-k of the RPN,
+anchor <-> ground-truth matching, the label sampling of RPN and ROI heads, FPN level assignment — is device code as well
+(csrc/proposals.hip); one host read per RPN call (the proposal counts after NMS) remains, where the reference has a dozen.
 
-Random sampling (detectron2/modeling/sampling.py:49-50 draws torch.randperm): `sampler.priorities(n)` supplies one random key
-per candidate, the `num` smallest win; tests inject the closed-form keys the fixtures were generated with."""
+Random sampling (detectron2/modeling/sampling.py:49-50 draws torch.randperm per candidate list): `sampler.next_seed()` supplies one
+64-bit seed per list, the kernels give the candidate at position i of the list the key splitmix64(seed + i) >> 40 and the `num`
+smallest keys win; tests inject the seeds of the closed-form keys the fixtures were generated with."""
 import math
 from typing import Dict, List
 
@@ -248,17 +249,18 @@ class _UpsampleAddFn(torch.autograd.Function):
 
 
 class _RoIAlignFn(torch.autograd.Function):
-    """(rois (R,5), per-level row lists, scales, *level features NHWC) -> pooled (R, C*7*7) in the reference's (C,7,7) order"""
+    """(rois (R,5), per-level row lists sel (4, R) + their DEVICE lengths, scales, *level features NHWC) -> pooled (R, C*7*7) in the
+    reference's (C,7,7) order.  Every row belongs to exactly one level, so the four launches together write every row."""
 
     @staticmethod
-    def forward(ctx, rois, sels, scales, *feats):
+    def forward(ctx, rois, sel, sel_cnt, scales, *feats):
         R = rois.shape[0]
         C = feats[0].shape[3]
-        out = torch.zeros(R, C * 49, device=feats[0].device, dtype=feats[0].dtype)
-        for f, sel, sc in zip(feats, sels, scales):
-            if sel.numel():
-                ops.roi_align_fwd(f, rois, sel, out, sc)
-        ctx.rois, ctx.sels, ctx.scales = rois, sels, scales
+        out = torch.empty(R, C * 49, device=feats[0].device, dtype=feats[0].dtype)
+        if R:
+            for l, (f, sc) in enumerate(zip(feats, scales)):
+                ops.roi_align_fwd(f, rois, sel[l], out, sc, n_sel_dev=sel_cnt[l:l + 1])
+        ctx.rois, ctx.sel, ctx.sel_cnt, ctx.scales = rois, sel, sel_cnt, scales
         ctx.shapes = [tuple(f.shape) for f in feats]
         ctx.dtype = feats[0].dtype
         return out
@@ -267,66 +269,86 @@ class _RoIAlignFn(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         grads = []
-        for shp, sel, sc, need in zip(ctx.shapes, ctx.sels, ctx.scales, ctx.needs_input_grad[3:]):
+        R = ctx.rois.shape[0]
+        for l, (shp, sc, need) in enumerate(zip(ctx.shapes, ctx.scales, ctx.needs_input_grad[4:])):
             if not need:
                 grads.append(None)
                 continue
-            d = torch.zeros(shp, device=g.device, dtype=torch.float32)
-            if sel.numel():
-                ops.roi_align_bwd(g, ctx.rois, sel, d, sc)
-            grads.append(d if ctx.dtype == torch.float32 else d.to(ctx.dtype))
-        return (None, None, None) + tuple(grads)
+            d = ops.fill_zero(torch.empty(shp, device=g.device, dtype=torch.float32))
+            if R:
+                ops.roi_align_bwd(g, ctx.rois, ctx.sel[l], d, sc, n_sel_dev=ctx.sel_cnt[l:l + 1])
+            grads.append(d if ctx.dtype == torch.float32 else ops.convert_flat(d, ctx.dtype))
+        return (None, None, None, None) + tuple(grads)
 
 
 class _RpnLossFn(torch.autograd.Function):
-    """(logits (n,), deltas (n,4)) -> (loss_rpn_cls, loss_rpn_loc): one kernel for both values and both unit gradients"""
+    """y (rows, 5A) = the RPN head's packed output; logits (N, At) / deltas (N, At, 4) = its anchor-order form (ops.rpn_unpack, computed
+    once outside autograd: the proposal selection reads it too) -> (loss_rpn_cls, loss_rpn_loc): one kernel for both values and both
+    unit gradients; the backward maps them back onto y's layout, times the two cotangents, in one kernel"""
 
     @staticmethod
-    def forward(ctx, logits, deltas, labels_i8, anchors, matched, weights, inv_norm):
+    def forward(ctx, y, logits, deltas, labels_i8, anchors, matched, weights, inv_norm, meta):
         out = torch.empty(2, device=logits.device, dtype=torch.float32)
         dl = torch.empty_like(logits); dd = torch.empty_like(deltas)
-        ops.rpn_loss(logits, deltas, labels_i8, anchors, matched, weights, inv_norm, out, dl, dd)
+        ops.rpn_loss(logits.reshape(-1), deltas.reshape(-1, 4), labels_i8, anchors, matched, weights, inv_norm, out, dl.reshape(-1),
+                     dd.reshape(-1, 4))
         ctx.save_for_backward(dl, dd)
+        ctx.meta = meta + (y.shape[0], y.shape[1], y.stride(0))
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g_cls, g_loc):
         dl, dd = ctx.saved_tensors
-        return dl * g_cls, dd * g_loc, None, None, None, None, None
+        N, A, hw, rows, cols, ld = ctx.meta
+        dy = ops.rpn_unpack_bwd(dl, dd, N, A, hw, rows, ld, dl.device, g_logits=g_cls.contiguous(), g_deltas=g_loc.contiguous())
+        return dy[:, :cols], None, None, None, None, None, None, None, None
 
 
 class _RoiLossFn(torch.autograd.Function):
     """packed logits (R, >= 5K+1) f32 = [cls_score K+1 | bbox_pred 4K] -> (focal loss_cls, L1 loss_box_reg), both / R
-    (unbias/ubteacher/modeling/roi_heads/fast_rcnn.py:73-105; detectron2/modeling/roi_heads/fast_rcnn.py:245-317)"""
+    (unbias/ubteacher/modeling/roi_heads/fast_rcnn.py:73-105; detectron2/modeling/roi_heads/fast_rcnn.py:245-317).
+    boxes2 (2R, 4) = the sampled proposal boxes followed by their matched gt boxes (row R + i is row i's target)."""
 
     @staticmethod
-    def forward(ctx, logits, K, gt_classes_i32, prop_boxes, gt_boxes, reg_weights, gamma):
+    def forward(ctx, logits, K, gt_classes_i32, boxes2, reg_weights, gamma):
         R = logits.shape[0]
         dev = logits.device
-        loss_cls = torch.zeros(1, device=dev)
-        unit = torch.zeros_like(logits)
+        c = _consts(dev, R)
+        loss_cls = ops.fill_zero(torch.empty(1, device=dev))
+        unit = ops.fill_zero(torch.empty_like(logits))
         lg = logits.detach()
-        ops.focal_loss(lg[:, :K + 1], gt_classes_i32, gamma, loss_cls, unit[:, :K + 1])
-        # box term through the refinement-loss kernel: targets boxes[R + i], class-specific columns, L1 / R (CE weights 0)
-        boxes = torch.cat([prop_boxes, gt_boxes], 0).contiguous()
-        idx = (torch.arange(R, device=dev, dtype=torch.int32) + R).contiguous()
+        # box term through the refinement-loss kernel: targets boxes2[R + i], class-specific columns, L1 / R (CE weights 0); it writes the
+        # box columns of `unit` (and zeros into the class columns, which the focal kernel then overwrites)
         lv = torch.empty(1, 2, 1, device=dev)
-        ubox = torch.zeros_like(logits)
-        ops.oicr_refine_loss(lg, 1, R, K, 0, K + 1, boxes, gt_classes_i32.view(1, R), torch.zeros(1, R, device=dev), idx.view(1, R),
-                             torch.zeros(1, dtype=torch.int32, device=dev), reg_weights, lv, ubox, torch.ones(2, device=dev))
-        unit[:, K + 1:5 * K + 1] = ubox[:, K + 1:5 * K + 1]
+        ops.oicr_refine_loss(lg, 1, R, K, 0, K + 1, boxes2, gt_classes_i32.view(1, R), c["zero_w"].view(1, R), c["idx"].view(1, R),
+                             c["zero_i"], reg_weights, lv, unit, c["ones2"])
+        ops.focal_loss(lg[:, :K + 1], gt_classes_i32, gamma, loss_cls, unit[:, :K + 1])
         ctx.save_for_backward(unit)
         ctx.K = K
-        return loss_cls[0], lv[0, 1, 0].clone()
+        return loss_cls[0], lv[0, 1, 0]
 
     @staticmethod
     def backward(ctx, g_cls, g_box):
         (unit,) = ctx.saved_tensors
         K = ctx.K
-        d = unit.clone()
-        d[:, :K + 1] *= g_cls
-        d[:, K + 1:] *= g_box
-        return d, None, None, None, None, None, None
+        d = torch.empty_like(unit)
+        ops.scale_col_blocks(unit, d, K + 1, g_cls.contiguous(), g_box.contiguous())
+        return d, None, None, None, None, None
+
+
+_CONSTS = {}
+
+
+def _consts(dev, R):
+    """small constant device tensors of the ROI loss (zero CE weights, target row indices R + i, ...), built once per (device, R)"""
+    key = (str(dev), R)
+    hit = _CONSTS.get(key)
+    if hit is None:
+        if len(_CONSTS) > 64:
+            _CONSTS.clear()
+        hit = _CONSTS[key] = dict(zero_w=torch.zeros(R, device=dev), idx=(torch.arange(R, device=dev, dtype=torch.int32) + R).contiguous(),
+                                  zero_i=torch.zeros(1, dtype=torch.int32, device=dev), ones2=torch.ones(2, device=dev))
+    return hit
 
 
 # ====================================================================================================== modules
@@ -543,74 +565,62 @@ class StandardRPNHead(nn.Module):
         return ent
 
     def forward(self, feats):
-        """-> per level logits (N, Hi*Wi*A) f32, deltas (N, Hi*Wi*A, 4) f32: the two 1x1 convolutions of ALL levels as ONE GEMM of 5A
-        (+ pad) columns over the concatenated pixels"""
+        """-> (y (rows, 5A) f32, N, pixels per level): the two 1x1 convolutions of ALL levels as ONE GEMM of 5A (+ pad) columns over the
+        concatenated pixels (row = level offset + image * Hi*Wi + pixel, columns [objectness a | delta 4a + b]); ops.rpn_unpack re-orders
+        it into the reference's anchor order for the losses and the proposal selection"""
         A = self.A
         st = _staged_of(self)
         ts = [self.conv(f, relu=True) for f in feats]
         C = ts[0].shape[3]
-        rows = [t.shape[0] * t.shape[1] * t.shape[2] for t in ts]
-        y = _LinearFn.apply(torch.cat([t.reshape(r, C) for t, r in zip(ts, rows)], 0), st.w, st.bias, None, False, True, (A, 4 * A), None,
-                            self.objectness_logits.weight, self.anchor_deltas.weight, self.objectness_logits.bias, self.anchor_deltas.bias)
-        logits, deltas, r0 = [], [], 0
-        for t, r in zip(ts, rows):                                   # channel = [a | a*4 + b]
-            n, H, W, _ = t.shape
-            logits.append(y[r0:r0 + r, :A].reshape(n, H * W * A))
-            deltas.append(y[r0:r0 + r, A:].reshape(n, H * W * A, 4))
-            r0 += r
-        return logits, deltas
+        N = ts[0].shape[0]
+        hw = [t.shape[1] * t.shape[2] for t in ts]
+        rows = sum(N * v for v in hw)
+        x = torch.empty(rows, C, device=ts[0].device, dtype=ts[0].dtype)
+        y = _LinearFn.apply(_CatRowsFn.apply(x, *[t.reshape(N * v, C) for t, v in zip(ts, hw)]), st.w, st.bias, None, False, True,
+                            (A, 4 * A), None, self.objectness_logits.weight, self.anchor_deltas.weight, self.objectness_logits.bias,
+                            self.anchor_deltas.bias)
+        return y, N, tuple(hw)
+
+
+class _CatRowsFn(torch.autograd.Function):
+    """rows of several (r_i, C) matrices back to back in `buf` (one copy launch, sw_copy_multi); backward: row slices of the gradient"""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        r0, pairs = 0, []
+        for p in parts:
+            pairs.append((p.contiguous(), buf[r0:r0 + p.shape[0]]))
+            r0 += p.shape[0]
+        ops.copy_multi(pairs)
+        ctx.rows = [p.shape[0] for p in parts]
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        out, r0 = [], 0
+        for r in ctx.rows:
+            out.append(g[r0:r0 + r]); r0 += r
+        return (None,) + tuple(out)
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
 
 
 class Sampler:
-    """random keys for the label sampling (sampling.py:49-50).  Default: torch's generator on the device."""
+    """seeds of the label sampling (sampling.py:49-50 draws one torch.randperm per candidate list): one 64-bit seed per list; the
+    kernels derive every candidate's random key from (seed, position in the list)"""
 
     def __init__(self, seed=0):
-        self.gen, self.seed = None, seed
+        self.seed, self.k = int(seed), 0
 
-    def priorities(self, n, device):
-        if self.gen is None or self.gen.device != device:
-            self.gen = torch.Generator(device=device); self.gen.manual_seed(self.seed)
-        return torch.rand(n, generator=self.gen, device=device)
-
-
-def pairwise_iou(b1, b2):
-    """structures/boxes.py:337-370, float32"""
-    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1]); a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
-    wh = (torch.min(b1[:, None, 2:], b2[None, :, 2:]) - torch.max(b1[:, None, :2], b2[None, :, :2])).clamp(min=0)
-    inter = wh[..., 0] * wh[..., 1]
-    return torch.where(inter > 0, inter / (a1[:, None] + a2[None, :] - inter), torch.zeros((), device=b1.device))
-
-
-def match(iou, thresholds, labels, allow_low_quality):
-    """modeling/matcher.py:60-126 -> (matched gt index (N,), label (N,) int8)"""
-    n = iou.shape[1]
-    if iou.numel() == 0:
-        return torch.zeros(n, dtype=torch.int64, device=iou.device), torch.full((n,), labels[0], dtype=torch.int8, device=iou.device)
-    vals, matches = iou.max(dim=0)
-    out = torch.ones(n, dtype=torch.int8, device=iou.device)
-    th = [-float("inf")] + list(thresholds) + [float("inf")]
-    for l, lo, hi in zip(labels, th[:-1], th[1:]):                  # (torch.where, not masked assignment: no host synchronisation)
-        out = torch.where((vals >= lo) & (vals < hi), torch.full_like(out, l), out)
-    if allow_low_quality:
-        best = iou.max(dim=1).values
-        out = torch.where((iou == best[:, None]).any(dim=0), torch.ones_like(out), out)
-    return matches, out
-
-
-def subsample_labels(labels, num_samples, positive_fraction, bg_label, sampler):
-    """modeling/sampling.py:8-54: the `num` candidates with the smallest random keys (keys drawn per candidate list, like
-    randperm(len(list))[:num])"""
-    # one host round trip for both candidate lists (the reference's two `nonzero` calls are two): a stable sort by
-    # (positive, negative, other) lists both in ascending index order, the two counts come back together
-    is_pos, is_neg = (labels != -1) & (labels != bg_label), labels == bg_label
-    order = torch.argsort(torch.where(is_pos, 0, torch.where(is_neg, 1, 2)), stable=True)
-    n_pos, n_neg = torch.stack([is_pos.sum(), is_neg.sum()]).tolist()
-    positive, negative = order[:n_pos], order[n_pos:n_pos + n_neg]
-    num_pos = min(positive.numel(), int(num_samples * positive_fraction))
-    num_neg = min(negative.numel(), num_samples - num_pos)
-    p1 = torch.argsort(sampler.priorities(positive.numel(), labels.device), stable=True)[:num_pos]
-    p2 = torch.argsort(sampler.priorities(negative.numel(), labels.device), stable=True)[:num_neg]
-    return positive[p1], negative[p2]
+    def next_seed(self):
+        self.k += 1
+        return _splitmix64(((self.seed & 0xFFFFFFFF) << 32) ^ self.k)
 
 
 class PseudoLabRPN(nn.Module):
@@ -644,72 +654,67 @@ class PseudoLabRPN(nn.Module):
                 yy, xx = torch.meshgrid(sy, sx, indexing="ij")
                 shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
                 res.append((shifts.view(-1, 1, 4) + cell.view(1, -1, 4)).reshape(-1, 4).contiguous())
-            hit = self._anchor_cache[key] = res
+            hit = self._anchor_cache[key] = (res, torch.cat(res, 0).contiguous())
         return hit
 
     @torch.no_grad()
     def label_and_sample_anchors(self, anchors_all, gt_boxes_list):
-        """detectron2 rpn.py:305-360: IoU thresholds [0.3, 0.7], labels [0, -1, 1], low-quality matches; 256 per image, <= 25 % positive"""
-        labels, matched = [], []
-        for gtb in gt_boxes_list:
-            m, lab = match(pairwise_iou(gtb, anchors_all), (0.3, 0.7), (0, -1, 1), True)
-            pos, neg = subsample_labels(lab.to(torch.int64), self.batch_size_per_image, self.positive_fraction, 0, self.sampler)
-            out = torch.full_like(lab, -1); out[pos] = 1; out[neg] = 0
-            labels.append(out)
-            matched.append(gtb[m] if len(gtb) else torch.zeros_like(anchors_all))
-        return torch.stack(labels), torch.stack(matched)
+        """detectron2 rpn.py:305-360: IoU thresholds [0.3, 0.7], labels [0, -1, 1], low-quality matches; 256 per image, <= 25 % positive.
+        One launch sequence for all images (sw_rpn_label_anchors): -> labels int8 (N, A), matched gt boxes (N, A, 4); no host sync"""
+        counts = [int(g.shape[0]) for g in gt_boxes_list]
+        gts = [g for g in gt_boxes_list if g.shape[0]]
+        gt_cat = gts[0].contiguous() if len(gts) == 1 else (torch.cat(gts, 0).contiguous() if gts else None)
+        seeds = [self.sampler.next_seed() for _ in range(2 * len(counts))]          # (positives, negatives) per image, in that order
+        return ops.rpn_label_anchors(anchors_all, gt_cat, counts, seeds, self.batch_size_per_image,
+                                     int(self.batch_size_per_image * self.positive_fraction))
+
+    def _image_hw(self, image_sizes, device):
+        key = (tuple((int(h), int(w)) for h, w in image_sizes), str(device))
+        hit = self.__dict__.get("_hw_cache")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_hw_cache"] = (key, torch.tensor([list(k) for k in key[0]], dtype=torch.int32).to(device))
+        return hit[1]
 
     @torch.no_grad()
     def predict_proposals(self, anchors, logits, deltas, image_sizes):
-        """detectron2 rpn.py:478-533 + proposal_utils.py:20-130: decode, per-level top-k (sort, stable: ties -> ascending index), clip, drop
-        empty boxes, NMS per level (sw_detect_postprocess with level = class), the best post_nms_topk per image"""
-        N = logits[0].shape[0]
+        """detectron2 rpn.py:478-533 + proposal_utils.py:20-130: per-level top-k (sort, stable: ties -> ascending index), decode, clip, drop
+        empty boxes (sw_rpn_select_pack), NMS per level (sw_detect_postprocess2 with level = class), the best post_nms_topk per image.
+        logits (N, At), deltas (N, At, 4) in anchor order.  ONE host read per call: the images' proposal counts and finite flags."""
+        N = logits.shape[0]
+        dev = logits.device
         pre, post = self.pre_nms_topk[0 if self.training else 1], self.post_nms_topk[0 if self.training else 1]
         L = len(anchors)
-        per_level = []
-        for a, lg, dl in zip(anchors, logits, deltas):
-            k = min(lg.shape[1], pre)
-            sc, idx = lg.detach().sort(descending=True, dim=1, stable=True)
-            sc, idx = sc[:, :k], idx[:, :k]
-            boxes = ops.decode_boxes(dl.detach().reshape(-1, 4).contiguous(), a, self.bbox_weights, SCALE_CLAMP,
-                                     torch.empty(N * a.shape[0], 4, device=a.device)).view(N, -1, 4)
-            per_level.append((sc, torch.gather(boxes, 1, idx[:, :, None].expand(-1, -1, 4))))
+        ints = torch.empty(2 * N, device=dev, dtype=torch.int32)                          # proposal counts | finite flags
+        sc, bx, _ = ops.rpn_select_pack(logits, deltas, anchors, pre, self.bbox_weights, SCALE_CLAMP, self._image_hw(image_sizes, dev),
+                                        ints_out=ints[N:])
+        dboxes = torch.empty(N, post, 4, device=dev); dscores = torch.empty(N, post, device=dev)
+        scratch = torch.empty(2, post, device=dev, dtype=torch.int32)
+        for n, (h, w) in enumerate(image_sizes):
+            ops.detect_postprocess(sc[n], bx[n], int(h), int(w), -3.0e38, self.nms_thresh, post,
+                                   out=(ints[n:n + 1], dboxes[n], dscores[n], scratch[0], scratch[1]))
+        host = ints.tolist()
         out = []
         for n, (h, w) in enumerate(image_sizes):
-            sc = torch.cat([p[0][n] for p in per_level]); bx = torch.cat([p[1][n] for p in per_level], 0)
-            lvl = torch.cat([torch.full((p[0].shape[1],), i, dtype=torch.int64, device=sc.device) for i, p in enumerate(per_level)])
-            finite = torch.isfinite(bx).all() & torch.isfinite(sc).all()
-            if not self.training and not bool(finite):               # (training reads the flag with the count below: one round trip)
-                ok = torch.isfinite(bx).all(1) & torch.isfinite(sc)
-                sc, bx, lvl = sc[ok], bx[ok], lvl[ok]
-            cw = bx[:, 2].clamp(0, w) - bx[:, 0].clamp(0, w); ch = bx[:, 3].clamp(0, h) - bx[:, 1].clamp(0, h)
-            R = sc.numel()
-            ninf = torch.full((), -float("inf"), device=sc.device)
-            scores = ninf.expand(R, L + 1).clone()
-            scores[torch.arange(R, device=sc.device), lvl] = torch.where((cw > 0) & (ch > 0), sc, ninf)     # nonempty(threshold 0)
-            boxes = bx[:, None, :].expand(R, L, 4).reshape(R, 4 * L).contiguous()
-            cnt, dboxes, dscores, _, _ = ops.detect_postprocess(scores, boxes, int(h), int(w), -3.0e38, self.nms_thresh, post)
-            k, fin = torch.stack([cnt[0], finite.to(torch.int32)]).tolist()
+            k, fin = host[n], host[N + n]
             if self.training and not fin:
                 raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
             p = Instances((int(h), int(w)))
-            p.proposal_boxes = Boxes(dboxes[:k].clone()); p.objectness_logits = dscores[:k].clone()
+            p.proposal_boxes = Boxes(dboxes[n, :k]); p.objectness_logits = dscores[n, :k]
+            p._sw_src = (dboxes, ints, n, k)              # the (N, post, 4) block + device counts: the ROI heads sample from it directly
             out.append(p)
         return out
 
     def forward(self, image_sizes, feats, gt_instances=None, compute_loss=True, compute_val_loss=False):
         dev = feats[0].device
-        anchors = self.anchors([tuple(f.shape[1:3]) for f in feats], dev)
-        logits, deltas = self.rpn_head(feats)
+        anchors, anchors_all = self.anchors([tuple(f.shape[1:3]) for f in feats], dev)
+        y, N, hw = self.rpn_head(feats)
+        A = self.rpn_head.A
+        logits, deltas = ops.rpn_unpack(y.detach(), N, A, hw)                              # (N, At), (N, At, 4), anchor order
         losses = {}
         if (self.training and compute_loss) or compute_val_loss:
-            anchors_all = torch.cat(anchors, 0)
             labels, matched = self.label_and_sample_anchors(anchors_all, [g.gt_boxes.tensor.to(dev).float() for g in gt_instances])
-            lg = torch.cat(logits, 1).reshape(-1).contiguous(); dl = torch.cat(deltas, 1).reshape(-1, 4).contiguous()
-            n_img = labels.shape[0]
-            l_cls, l_loc = _RpnLossFn.apply(lg, dl, labels.reshape(-1).contiguous(), anchors_all.contiguous(),
-                                            matched.reshape(-1, 4).contiguous(), self.bbox_weights,
-                                            1.0 / (self.batch_size_per_image * n_img))
+            l_cls, l_loc = _RpnLossFn.apply(y, logits, deltas, labels.reshape(-1), anchors_all, matched.reshape(-1, 4), self.bbox_weights,
+                                            1.0 / (self.batch_size_per_image * N), (N, A, hw))
             losses = {"loss_rpn_cls": l_cls, "loss_rpn_loc": l_loc}
             self.last_labels = labels
         proposals = self.predict_proposals(anchors, logits, deltas, image_sizes)
@@ -776,40 +781,50 @@ class StandardROIHeadsPseudoLab(nn.Module):
 
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals, targets, append_gt):
-        K = self.num_classes
+        """roi_heads.py:324-375 for all images in ONE launch (sw_roi_label_sample): append the gt boxes, IoU-match at 0.5 (labels [0, 1], no
+        low-quality matches), sample batch_size_per_image rows with at most positive_fraction foreground by the random-key rule; no host
+        round trip (the proposal counts are read on the device where the RPN's NMS left them)"""
+        K, B = self.num_classes, self.batch_size_per_image
+        N = len(proposals)
+        dev = proposals[0].proposal_boxes.tensor.device
+        src = [getattr(p, "_sw_src", None) for p in proposals]
+        if all(s_ is not None for s_ in src) and all(s_[0] is src[0][0] and s_[2] == i for i, s_ in enumerate(src)) and src[0][0].shape[0] == N:
+            buf, cnt_dev = src[0][0], src[0][1][:N]
+        else:                                                     # proposals from somewhere else: pack them into one block
+            ps = max(max(len(p) for p in proposals), 1)
+            buf = torch.empty(N, ps, 4, device=dev)
+            pairs = [(p.proposal_boxes.tensor.float().contiguous(), buf[i, :len(p)]) for i, p in enumerate(proposals) if len(p)]
+            if pairs:
+                ops.copy_multi(pairs)
+            cnt_dev = torch.tensor([len(p) for p in proposals], dtype=torch.int32).to(dev)
+        counts = [len(t) for t in targets]
+        gts = [(t.gt_boxes.tensor.to(dev).float(), t.gt_classes.to(dev)) for t in targets if len(t)]
+        if gts:
+            gt_b = gts[0][0].contiguous() if len(gts) == 1 else torch.cat([g[0] for g in gts], 0).contiguous()
+            gt_c = (gts[0][1] if len(gts) == 1 else torch.cat([g[1] for g in gts], 0)).to(torch.int32).contiguous()
+        else:
+            gt_b = gt_c = None
+        seeds = [self.sampler.next_seed() for _ in range(2 * N)]                            # (foreground, background) per image
+        cnt, idx, cls, both = ops.roi_label_sample(cnt_dev, buf, gt_b, gt_c, counts, seeds, append_gt, 0.5, K, B, int(B * self.positive_fraction))
         out = []
-        for prop, tgt in zip(proposals, targets):
-            dev = prop.proposal_boxes.tensor.device
-            gtb = tgt.gt_boxes.tensor.to(dev).float(); gtc = tgt.gt_classes.to(dev)
-            boxes = torch.cat([prop.proposal_boxes.tensor, gtb], 0) if append_gt else prop.proposal_boxes.tensor
-            has_gt = gtb.shape[0] > 0
-            m, lab = match(pairwise_iou(gtb, boxes) if has_gt else torch.zeros(0, boxes.shape[0], device=dev), (0.5,), (0, 1), False)
-            if has_gt:
-                cls = gtc[m].clone(); cls[lab == 0] = K; cls[lab == -1] = -1
-            else:
-                cls = torch.zeros_like(m) + K
-            fg, bg = subsample_labels(cls, self.batch_size_per_image, self.positive_fraction, K, self.sampler)
-            idx = torch.cat([fg, bg])
-            s = Instances(prop.image_size)
-            s.proposal_boxes = Boxes(boxes[idx]); s.gt_classes = cls[idx]
-            s.gt_boxes = Boxes(gtb[m[idx]] if has_gt else torch.zeros(idx.numel(), 4, device=dev))
-            out.append(s)
+        for i, p in enumerate(proposals):
+            n = min(B, len(p) + (counts[i] if append_gt else 0))        # every candidate is foreground or background: the count is known
+            s_ = Instances(p.image_size)
+            s_.proposal_boxes = Boxes(both[0, i, :n]); s_.gt_classes = cls[i, :n]; s_.gt_boxes = Boxes(both[1, i, :n])
+            s_._sw_dense = (both, cls, i, n)
+            out.append(s_)
         return out
 
     def _pool(self, feats, boxes_per_image):
-        """poolers.py:17-50,196-250: level = floor(4 + log2(sqrt(area) / 224 + 1e-8)) clamped to [2, 5]; ROIAlign 7x7 per level"""
-        dev = feats[0].device
-        rois = torch.cat([torch.cat([torch.full((b.shape[0], 1), float(i), device=dev), b], 1) for i, b in enumerate(boxes_per_image)], 0).contiguous()
-        bx = rois[:, 1:]
-        sizes = torch.sqrt((bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1]))
-        lv = torch.clamp(torch.floor(4 + torch.log2(sizes / 224 + 1e-8)), min=2, max=5).to(torch.int64) - 2
-        order = torch.argsort(lv, stable=True).to(torch.int32)                                       # per level ascending row order, as nonzero lists it
-        counts = torch.bincount(lv, minlength=4).tolist()                                            # one host round trip for the four lists
-        sels, r0 = [], 0
-        for c_ in counts:
-            sels.append(order[r0:r0 + c_].contiguous()); r0 += c_
+        """poolers.py:17-50,196-250: level = floor(4 + log2(sqrt(area) / 224 + 1e-8)) clamped to [2, 5]; ROIAlign 7x7 per level.  The dense
+        (image, box) rows, the levels and the per-level row lists come from one kernel (sw_roi_assign_levels), the list lengths stay on the
+        device (sw_roi_align_* read them): no host round trip"""
+        bs = [b if (b.dtype == torch.float32 and b.dim() == 2 and (b.shape[0] == 0 or (b.stride(1) == 1 and b.stride(0) == 4))) else
+              b.float().contiguous() for b in boxes_per_image]
+        base = min((b for b in bs if b.shape[0]), key=lambda t: t.data_ptr(), default=bs[0])
+        rois, lv, sel, cnt = ops.roi_assign_levels(base, [b.shape[0] for b in bs], [(b.data_ptr() - base.data_ptr()) // 4 for b in bs])
         self.last_levels = lv
-        return _RoIAlignFn.apply(rois, sels, [1.0 / s for s in STRIDES[:4]], *feats[:4])
+        return _RoIAlignFn.apply(rois, sel, cnt, [1.0 / s for s in STRIDES[:4]], *feats[:4])
 
     def forward(self, feats, proposals, targets=None, compute_loss=True, branch="", compute_val_loss=False):
         if self.training and compute_loss:
@@ -820,14 +835,20 @@ class StandardROIHeadsPseudoLab(nn.Module):
         logits = self.box_predictor(self.box_head(pooled))
         K = self.num_classes
         if (self.training and compute_loss) or compute_val_loss:
-            gtc = torch.cat([p.gt_classes for p in proposals]).to(torch.int32).contiguous()
             self.last_sampled, self.last_logits = proposals, logits
-            if gtc.numel() == 0:
+            R = logits.shape[0]
+            if R == 0:
                 z = 0.0 * logits.sum()
                 return proposals, {"loss_cls": z, "loss_box_reg": z}
-            l_cls, l_box = _RoiLossFn.apply(logits, K, gtc, torch.cat([p.proposal_boxes.tensor for p in proposals]).contiguous(),
-                                            torch.cat([p.gt_boxes.tensor for p in proposals]).contiguous(),
-                                            self.box_predictor.bbox_weights, 1.5)
+            dense = [getattr(p, "_sw_dense", None) for p in proposals]
+            B = self.batch_size_per_image
+            if all(d is not None and d[0] is dense[0][0] and d[3] == B for d in dense) and dense[0][0].shape[1] == len(proposals):
+                both, cls = dense[0][0], dense[0][1]             # every image sampled a full batch: the sampler's blocks ARE the dense rows
+                boxes2, gtc = both.view(2 * R, 4), cls.view(R)
+            else:
+                boxes2 = torch.cat([p.proposal_boxes.tensor for p in proposals] + [p.gt_boxes.tensor for p in proposals]).contiguous()
+                gtc = torch.cat([p.gt_classes for p in proposals]).to(torch.int32).contiguous()
+            l_cls, l_box = _RoiLossFn.apply(logits, K, gtc, boxes2, self.box_predictor.bbox_weights, 1.5)
             return proposals, {"loss_cls": l_cls, "loss_box_reg": l_box}
         # inference form (fast_rcnn.py:44-160): softmax, decode, clip, score > 0.05, per-class NMS 0.5, top 100
         pred, off = [], 0

@@ -714,14 +714,18 @@ def oicr_predict(logits, R, K, refine_k, base_col, round_stride, boxes, reg_weig
                               float(scale_clamp), _p(all_scores), _p(all_boxes), _stream()), "sw_oicr_predict")
 
 
-def detect_postprocess(all_scores, all_boxes, img_h, img_w, score_thresh, nms_thresh, topk):
-    """-> (count[1] i32, boxes [topk,4], scores [topk], classes [topk] i32, rows [topk] i32) device tensors"""
+def detect_postprocess(all_scores, all_boxes, img_h, img_w, score_thresh, nms_thresh, topk, out=None):
+    """-> (count[1] i32, boxes [topk,4], scores [topk], classes [topk] i32, rows [topk] i32) device tensors.  out: optional
+    preallocated (count, boxes, scores, classes, rows) — only the first count[0] rows are written (without `out` the rest is zero)"""
     R, K1 = all_scores.shape
     K = K1 - 1
     dev = all_scores.device
-    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
-    boxes = torch.zeros(topk, 4, device=dev); scores = torch.zeros(topk, device=dev)
-    classes = torch.zeros(topk, device=dev, dtype=torch.int32); rows = torch.zeros(topk, device=dev, dtype=torch.int32)
+    if out is not None:
+        cnt, boxes, scores, classes, rows = out
+    else:
+        cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+        boxes = torch.zeros(topk, 4, device=dev); scores = torch.zeros(topk, device=dev)
+        classes = torch.zeros(topk, device=dev, dtype=torch.int32); rows = torch.zeros(topk, device=dev, dtype=torch.int32)
     nbytes = int(lib.sw_detect_workspace_bytes2(R, K, topk))
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     check(lib.sw_detect_postprocess2(R, K, _p(all_scores), _p(all_boxes), int(img_h), int(img_w), float(score_thresh),
@@ -784,21 +788,77 @@ def downsample2x_sum(g, out):
     return out
 
 
-def roi_align_fwd(feat, rois, sel_i32, out, scale, PH=7, PW=7, sampling_ratio=0):
-    """feat (N, H, W, C) of one level; rois (R, 5) f32; sel int32 rows of this level; out (R, C*PH*PW)"""
+def roi_align_fwd(feat, rois, sel_i32, out, scale, PH=7, PW=7, sampling_ratio=0, n_sel_dev=None):
+    """feat (N, H, W, C) of one level; rois (R, 5) f32; sel int32 rows of this level; out (R, C*PH*PW).  n_sel_dev: device int32 [1]
+    holding the real length of `sel` (then sel.numel() is only its bound: no host round trip for the level lists)"""
     _need_gpu(feat, rois, sel_i32, out)
     n, H, W, C = feat.shape
     check(lib.sw_roi_align_fwd(dt(feat), H, W, C, PH, PW, float(scale), sampling_ratio, _p(feat), _p(rois), _p(sel_i32),
-                               sel_i32.numel(), _p(out), out.stride(0), _stream()), "sw_roi_align_fwd")
+                               sel_i32.numel(), _p(n_sel_dev), _p(out), out.stride(0), _stream()), "sw_roi_align_fwd")
     return out
 
 
-def roi_align_bwd(gout, rois, sel_i32, dfeat_f32, scale, PH=7, PW=7, sampling_ratio=0):
+def roi_align_bwd(gout, rois, sel_i32, dfeat_f32, scale, PH=7, PW=7, sampling_ratio=0, n_sel_dev=None):
     _need_gpu(gout, rois, sel_i32, dfeat_f32)
     n, H, W, C = dfeat_f32.shape
     check(lib.sw_roi_align_bwd(dt(gout), H, W, C, PH, PW, float(scale), sampling_ratio, _p(gout), gout.stride(0), _p(rois),
-                               _p(sel_i32), sel_i32.numel(), _p(dfeat_f32), _stream()), "sw_roi_align_bwd")
+                               _p(sel_i32), sel_i32.numel(), _p(n_sel_dev), _p(dfeat_f32), _stream()), "sw_roi_align_bwd")
     return dfeat_f32
+
+
+def scale_col_blocks(src, dst, split, g0, g1):
+    """dst[:, :split] = src[:, :split] * g0, dst[:, split:] = src[:, split:] * g1 (device scalars); src / dst (M, N) f32 views of
+    buffers with one row pitch, padding columns of dst zeroed"""
+    _need_gpu(src, dst, g0, g1)
+    M, N = src.shape
+    assert src.stride(0) == dst.stride(0) and src.dtype == dst.dtype == torch.float32
+    check(lib.sw_scale_col_blocks(M, N, int(split), _p(src), src.stride(0), _p(g0), _p(g1), _p(dst), _stream()), "sw_scale_col_blocks")
+    return dst
+
+
+def convert_flat(src_f32, dtype):
+    """a float32 tensor in another compute dtype (same shape), through sw_convert_2d"""
+    _need_gpu(src_f32)
+    out = torch.empty(src_f32.shape, device=src_f32.device, dtype=dtype)
+    c = src_f32.shape[-1]
+    r = src_f32.numel() // c
+    check(lib.sw_convert_2d(dt(out), r, c, _p(src_f32), c, _p(out), c, _stream()), "sw_convert_2d")
+    return out
+
+
+def rpn_unpack(y, N, A, hw_per_level):
+    """y (rows, ld) f32, the RPN head's packed GEMM output -> logits (N, At), deltas (N, At, 4) in anchor order (sw_rpn_unpack)"""
+    _need_gpu(y)
+    L = len(hw_per_level)
+    At = A * int(sum(hw_per_level))
+    hw = (ctypes.c_int * L)(*[int(v) for v in hw_per_level])
+    logits = torch.empty(N, At, device=y.device); deltas = torch.empty(N, At, 4, device=y.device)
+    check(lib.sw_rpn_unpack(N, L, A, hw, _p(y), y.stride(0), _p(logits), _p(deltas), _stream()), "sw_rpn_unpack")
+    return logits, deltas
+
+
+def rpn_unpack_bwd(dlogits, ddeltas, N, A, hw_per_level, rows, ld, device, g_logits=None, g_deltas=None):
+    """gradient of rpn_unpack's input: dy (rows, ld) f32 from dlogits (N, At) / ddeltas (N, At, 4), each times a device scalar"""
+    L = len(hw_per_level)
+    hw = (ctypes.c_int * L)(*[int(v) for v in hw_per_level])
+    dy = torch.empty(rows, ld, device=device)
+    check(lib.sw_rpn_unpack_bwd(N, L, A, hw, _p(dlogits), _p(ddeltas), _p(g_logits), _p(g_deltas), _p(dy), ld, _stream()),
+          "sw_rpn_unpack_bwd")
+    return dy
+
+
+def roi_assign_levels(boxes_base, row_cnt, box_off_floats):
+    """dense ROI rows + FPN levels (sw_roi_assign_levels).  boxes_base: a f32 tensor the images' box blocks live in; image i contributes
+    row_cnt[i] boxes starting box_off_floats[i] floats into it.  -> rois (R, 5), level_of (R,), sel (4, R) int32, sel_cnt (4,) int32"""
+    _need_gpu(boxes_base)
+    n = len(row_cnt)
+    R = int(sum(row_cnt))
+    dev = boxes_base.device
+    rois = torch.empty(R, 5, device=dev); lv = torch.empty(R, device=dev, dtype=torch.int32)
+    sel = torch.empty(4, max(R, 1), device=dev, dtype=torch.int32); cnt = torch.empty(4, device=dev, dtype=torch.int32)
+    rc = (ctypes.c_int * n)(*[int(v) for v in row_cnt]); bo = (ctypes.c_long * n)(*[int(v) for v in box_off_floats])
+    check(lib.sw_roi_assign_levels(n, rc, bo, _p(boxes_base), _p(rois), _p(lv), _p(sel), _p(cnt), _stream()), "sw_roi_assign_levels")
+    return rois, lv, sel, cnt
 
 
 def decode_boxes(deltas, boxes, weights, scale_clamp, out):
@@ -810,25 +870,42 @@ def decode_boxes(deltas, boxes, weights, scale_clamp, out):
     return out
 
 
-def rpn_select_pack(logits, deltas, anchors, pre_topk, weights, scale_clamp, img_hw_dev):
-    """RPN proposal selection up to the NMS (sw_rpn_select_pack).  logits: per level (N, n_l) f32; deltas: per level (N, n_l, 4) f32;
-    anchors: per level (n_l, 4); img_hw_dev (N, 2) int32 device.  -> cand_scores (N, L * pre_topk, L + 1), cand_boxes
-    (N, L * pre_topk, 4 L) in sw_detect_postprocess2's form (class = level), finite (N,) int32"""
-    L, N = len(logits), logits[0].shape[0]
-    dev = logits[0].device
-    for t in list(logits) + list(deltas) + list(anchors):
-        _need_gpu(t)
-        assert t.dtype == torch.float32 and t.is_contiguous()
-    n_l = (ctypes.c_int * L)(*[int(a.shape[0]) for a in anchors])
-    arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+def rpn_select_pack(logits, deltas, anchors, pre_topk, weights, scale_clamp, img_hw_dev, ints_out=None):
+    """RPN proposal selection up to the NMS (sw_rpn_select_pack).  anchors: per level (n_l, 4); img_hw_dev (N, 2) int32 device;
+    logits / deltas: either per-level lists ((N, n_l) / (N, n_l, 4) f32, each dense) or ONE pair (N, At) / (N, At, 4) in anchor order
+    (ops.rpn_unpack) whose column ranges are the levels.  -> cand_scores (N, L * pre_topk, L + 1), cand_boxes (N, L * pre_topk, 4 L) in
+    sw_detect_postprocess2's form (class = level), finite (N,) int32 (a slice of ints_out when given)"""
+    L = len(anchors)
+    dev = anchors[0].device
+    n_list = [int(a.shape[0]) for a in anchors]
+    if isinstance(logits, torch.Tensor):
+        N, At = logits.shape
+        assert At == sum(n_list) and logits.is_contiguous() and deltas.is_contiguous() and logits.dtype == deltas.dtype == torch.float32
+        _need_gpu(logits, deltas)
+        off, lp, dp = 0, [], []
+        for n in n_list:
+            lp.append(logits.data_ptr() + 4 * off); dp.append(deltas.data_ptr() + 16 * off); off += n
+        stride = At
+    else:
+        N = logits[0].shape[0]
+        for t in list(logits) + list(deltas):
+            _need_gpu(t)
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        lp, dp, stride = [t.data_ptr() for t in logits], [t.data_ptr() for t in deltas], 0
+    for a in anchors:
+        assert a.dtype == torch.float32 and a.is_contiguous()
+    n_l = (ctypes.c_int * L)(*n_list)
+    arr = lambda ps: (ctypes.c_void_p * L)(*ps)
     nbytes = int(lib.sw_rpn_select_workspace_bytes(N, L, n_l))
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     rows = L * pre_topk
     sc = torch.empty(N, rows, L + 1, device=dev); bx = torch.empty(N, rows, 4 * L, device=dev)
-    fin = torch.empty(N, device=dev, dtype=torch.int32); sel = torch.empty(N * L, pre_topk, device=dev, dtype=torch.int32)
+    fin = ints_out if ints_out is not None else torch.empty(N, device=dev, dtype=torch.int32)
+    sel = torch.empty(N * L, pre_topk, device=dev, dtype=torch.int32)
     rw = (ctypes.c_float * 4)(*[float(v) for v in weights])
-    check(lib.sw_rpn_select_pack(N, L, arr(logits), arr(deltas), arr(anchors), n_l, int(pre_topk), rw, float(scale_clamp), _p(img_hw_dev),
-                                 _p(sc), _p(bx), _p(fin), _p(sel), _p(ws), nbytes, _stream()), "sw_rpn_select_pack")
+    check(lib.sw_rpn_select_pack(N, L, arr(lp), arr(dp), arr([a.data_ptr() for a in anchors]), n_l, stride, int(pre_topk), rw,
+                                 float(scale_clamp), _p(img_hw_dev), _p(sc), _p(bx), _p(fin), _p(sel), _p(ws), nbytes, _stream()),
+          "sw_rpn_select_pack")
     return sc, bx, fin
 
 
@@ -853,8 +930,9 @@ def rpn_label_anchors(anchors, gt_boxes, gt_counts, seeds, batch_size, max_pos, 
 
 def roi_label_sample(p_cnt_dev, proposals, gt_boxes, gt_classes_i32, gt_counts, seeds, append_gt, iou_thresh, num_classes, batch_size, max_pos):
     """ROI-head matching + sampling (sw_roi_label_sample).  proposals (N, p_stride, 4) with device counts p_cnt_dev (N,) int32; gt_boxes
-    (sum G_i, 4) / gt_classes_i32 back to back, gt_counts host ints.  -> count (N,) i32, index / classes (N, batch) i32, boxes / gt_boxes
-    (N, batch, 4): image i's sampled rows are the first count[i] (foreground list, then background, each in random-key order)"""
+    (sum G_i, 4) / gt_classes_i32 back to back, gt_counts host ints.  -> count (N,) i32, index / classes (N, batch) i32, both (2, N, batch, 4)
+    = (sampled boxes, their matched gt boxes): image i's sampled rows are the first count[i] (foreground list, then background, each in
+    random-key order)"""
     _need_gpu(p_cnt_dev, proposals)
     N, ps = proposals.shape[0], proposals.shape[1]
     dev = proposals.device
@@ -867,12 +945,12 @@ def roi_label_sample(p_cnt_dev, proposals, gt_boxes, gt_classes_i32, gt_counts, 
     sd = (ctypes.c_uint64 * (2 * N))(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds])
     cnt = torch.empty(N, device=dev, dtype=torch.int32)
     idx = torch.empty(N, batch_size, device=dev, dtype=torch.int32); cls = torch.empty(N, batch_size, device=dev, dtype=torch.int32)
-    bx = torch.empty(N, batch_size, 4, device=dev); gb = torch.empty(N, batch_size, 4, device=dev)
+    both = torch.empty(2, N, batch_size, 4, device=dev)                 # [0] the sampled boxes, [1] their matched gt boxes
     check(lib.sw_roi_label_sample(N, _p(p_cnt_dev), ps, _p(proposals), g_off, g_cnt, _p(gt_boxes) if tot else None,
                                   _p(gt_classes_i32) if tot else None, int(bool(append_gt)), float(iou_thresh), int(num_classes),
-                                  int(batch_size), int(max_pos), sd, batch_size, _p(cnt), _p(idx), _p(cls), _p(bx), _p(gb), _stream()),
-          "sw_roi_label_sample")
-    return cnt, idx, cls, bx, gb
+                                  int(batch_size), int(max_pos), sd, batch_size, _p(cnt), _p(idx), _p(cls), _p(both[0]), _p(both[1]),
+                                  _stream()), "sw_roi_label_sample")
+    return cnt, idx, cls, both
 
 
 def rpn_loss(logits, deltas, labels_i8, anchors, matched_gt, weights, inv_norm, losses2, dlogits=None, ddeltas=None):

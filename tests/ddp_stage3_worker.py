@@ -36,8 +36,11 @@ def main():
         def __init__(self, tag):
             self.perm = FO.Perm(tag)
 
-        def priorities(self, n, device):
-            return torch.from_numpy(self.perm.priorities(n)).to(device)
+        def next_seed(self):
+            from oracle import detgen
+            k = self.perm.k
+            self.perm.k += 1
+            return detgen.fnv1a64(f"{self.perm.tag}perm{k}")
 
     def fresh(tag):
         m = TwoStagePseudoLabGeneralizedRCNN(num_classes=K, compute_dtype=torch.float32, sampler=Keys(tag)).to(dev)

@@ -286,8 +286,11 @@ def test_stage3_supervised_branch_at_config5_image_size_against_the_oracle():
         def __init__(self, tag):
             self.perm = FO.Perm(tag)
 
-        def priorities(self, n, device):
-            return torch.from_numpy(self.perm.priorities(n)).to(device)
+        def next_seed(self):
+            from oracle import detgen
+            k = self.perm.k
+            self.perm.k += 1
+            return detgen.fnv1a64(f"{self.perm.tag}perm{k}")
     model = TwoStagePseudoLabGeneralizedRCNN(num_classes=K, compute_dtype=torch.float32, sampler=Keys("s3full")).cuda()
     sd = model.state_dict()
     with torch.no_grad():

@@ -27,8 +27,11 @@ class _Keys:
     def __init__(self, tag):
         self.perm = FO.Perm(tag)
 
-    def priorities(self, n, device):
-        return torch.from_numpy(self.perm.priorities(n)).to(device)
+    def next_seed(self):
+        from oracle import detgen
+        k = self.perm.k
+        self.perm.k += 1
+        return detgen.fnv1a64(f"{self.perm.tag}perm{k}")
 
 
 def _same_boxes(a, b, atol=1e-2):
@@ -396,8 +399,9 @@ def test_roi_label_sample_kernel_against_the_oracle(ops, P, n_gt, append):
         buf[i, :len(p)] = p
     cat_b = torch.from_numpy(np.concatenate([g[0] for g in gts], 0)).cuda()
     cat_c = torch.from_numpy(np.concatenate([g[1] for g in gts], 0).astype(np.int32)).cuda()
-    cnt, idx, cls, bx, gb = ops.roi_label_sample(torch.tensor(cnts, dtype=torch.int32).cuda(), torch.from_numpy(buf).cuda(), cat_b, cat_c, n_gt,
-                                                 [_seed(tag, k) for k in range(2 * N)], append, 0.5, K, 512, 128)
+    cnt, idx, cls, both = ops.roi_label_sample(torch.tensor(cnts, dtype=torch.int32).cuda(), torch.from_numpy(buf).cuda(), cat_b, cat_c, n_gt,
+                                               [_seed(tag, k) for k in range(2 * N)], append, 0.5, K, 512, 128)
+    bx, gb = both[0], both[1]
     torch.cuda.synchronize()
     for i in range(N):
         n = int(cnt[i])
