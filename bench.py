@@ -474,6 +474,18 @@ def main():
             ms, _ = stage3_step.time_step(torch.bfloat16, 800, 1216, dev=device, warm=3, n=6)
             phase("stage3 run")
             out["stage3_ms_per_iter"] = round(ms, 2)
+            # the dominant kernel family of that iteration: the forward GEMMs of the 1x1 convolutions / fc layers (gemm2 128x128 tiles),
+            # timed live with HIP events on the launch stream over 3 more iterations; FLOP = 2 * pixels * Cout * Cin per launch
+            ops.TIMER = ops.KernelTimer(["s3_gemm_fwd"])
+            stage3_step.time_step(torch.bfloat16, 800, 1216, dev=device, warm=0, n=3)
+            tms = ops.TIMER.summary_ms()["s3_gemm_fwd"]; fl = ops.TIMER.work["s3_gemm_fwd"]
+            ops.TIMER = None
+            if tms:
+                ach = fl / (sum(tms) * 1e-3) / 1e12
+                out["roofline_stage3"] = {"kernel": "gemm2_kernel<bf16, 128x128>: forward GEMMs of the ResNet-50-FPN's 1x1 convolutions + fc layers",
+                                          "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "launches_per_iter": round(len(tms) / 3.0, 1),
+                                          "ms_per_iter": round(sum(tms) / 3.0, 3), "gflop_per_iter": round(fl / 3.0 / 1e9, 1)}
             out["extra_shapes"]["stage3"] = ("BASELINE configs[4] per GPU: 1 labelled + 1 unlabelled image, strong + weak view each (800x1216), "
                                              "R50-FPN Faster R-CNN student / EMA teacher, K=20")
             torch.cuda.empty_cache()

@@ -61,6 +61,11 @@ typedef struct sw_epilogue {
   const void* residual;
   long ld_res;
   int res_dtype;
+  /* deterministic split-K only (splitk_workspace given, effective splits > 1): the ordered fold writes C[m][n] = fold_row_scale[m] *
+   * sum of the slabs (DEVICE [M] or NULL) — the FrozenBN fold of a 1x1 convolution's weight gradient, dW = scale * dW_eff
+   * (detectron2/layers/batch_norm.py:52-58), without a pass of its own.  sw_gemm returns -5 when it is set and the launch does
+   * not end in that fold. */
+  const float* fold_row_scale;
 } sw_epilogue;
 
 /* ---- dense contractions (reference: cuBLAS via torch Linear — box_head.py:88-90,
@@ -87,6 +92,10 @@ int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int d
  * slabs at `workspace`; `_fold` adds `nslab` consecutive slabs in fixed order into dW (OIHW).  Several problems with the same
  * weight (the views of one iteration, possibly running on different streams) put their slabs back to back and share ONE
  * fold: the sum over views that autograd would otherwise form with one add per parameter. */
+/* sw_conv3x3_wgrad with dW[co] multiplied by cout_scale[co] (DEVICE [Cout] or NULL) inside the slab fold: the FrozenBN fold of a 3x3
+ * convolution's weight gradient */
+int sw_conv3x3_wgrad_scaled(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x, const void* dy,
+                            float* dw_oihw, float* workspace, int splitk, const float* cout_scale, sw_stream_t stream);
 int sw_conv3x3_wgrad_slabs(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                            const void* dy, float* workspace, int splitk, sw_stream_t stream);
 int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, sw_stream_t stream);

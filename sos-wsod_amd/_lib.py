@@ -28,6 +28,7 @@ class Epilogue(ctypes.Structure):
         ("drop_seed", c_u64), ("drop_offset", c_u64), ("drop_hash_p", c_float), ("drop_offset_dev", c_void_p),
         ("splitk_workspace", c_void_p),
         ("residual", c_void_p), ("ld_res", c_long), ("res_dtype", c_int),
+        ("fold_row_scale", c_void_p),
     ]
 
 
@@ -125,6 +126,8 @@ SIGNATURES = {
     "sw_colsum_workspace_floats": (c_long, [c_int, c_int, c_int]),
     "sw_colsum_partial": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_colsum_fold": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_conv3x3_wgrad_scaled": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_void_p]),
     "sw_conv3x3_wgrad_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p]),
     "sw_conv3x3_wgrad_fold": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

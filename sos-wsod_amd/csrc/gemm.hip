@@ -925,9 +925,19 @@ int dispatch_modes(GemmArgs& g, int amode, int bmode, int splitk, hipStream_t s)
   return -3;
 }
 
+__global__ void scale_rows_kernel(int M, int N, float* __restrict__ C, long ldc, const float* __restrict__ row_scale) {
+  const long total = (long)M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / N;
+    float* p = C + m * ldc + (i - m * N);
+    *p = __fmul_rn(*p, row_scale[m]);
+  }
+}
+
 // deterministic split-K: C[m][n] = sum_z ws[z][m][n], slabs added in a fixed order (pairs of four partial sums)
+// row_scale (may be NULL): C[m][n] = row_scale[m] * sum — the FrozenBN fold of a weight gradient (dW = scale * dW_eff) without a pass of its own
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int nslab, const float* __restrict__ ws,
-                                                            float* __restrict__ C, long ldc, int vec) {
+                                                            float* __restrict__ C, long ldc, int vec, const float* __restrict__ row_scale) {
   const long slab = (long)M * N;
   if (vec) {
     const long nv = slab >> 2;
@@ -942,14 +952,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ns
       }
       for (; z < nslab; ++z) a0 += src[(long)z * nv];
       const long m = q / nq; const int n4 = (int)(q - m * nq);
-      *(f32x4*)(C + m * ldc + n4 * 4) = (a0 + a1) + (a2 + a3);
+      f32x4 r = (a0 + a1) + (a2 + a3);
+      if (row_scale) { const float sc = row_scale[m]; r[0] = __fmul_rn(r[0], sc); r[1] = __fmul_rn(r[1], sc); r[2] = __fmul_rn(r[2], sc); r[3] = __fmul_rn(r[3], sc); }
+      *(f32x4*)(C + m * ldc + n4 * 4) = r;
     }
   } else {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < slab; i += (long)gridDim.x * blockDim.x) {
       float a = 0.f;
       for (int z = 0; z < nslab; ++z) a += ws[(long)z * slab + i];
       const long m = i / N;
-      C[m * ldc + (i - m * N)] = a;
+      C[m * ldc + (i - m * N)] = row_scale ? __fmul_rn(a, row_scale[m]) : a;
     }
   }
 }
@@ -1006,13 +1018,14 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
   // gave a split-K workspace, else f32 atomics into the zeroed column block.
   const bool plain = (!ep || (ep->out_dtype == SW_F32 && !ep->bias && !ep->relu && !ep->drop_mask && !(ep->drop_hash_p > 0.f) && !ep->relu_ref &&
                               !ep->accumulate_atomic && !ep->absmax_out && !ep->residual));
+  const bool has_row_scale = ep && ep->fold_row_scale;
   float* const det_ws = (ep && plain) ? ep->splitk_workspace : nullptr;
   {
     static const bool no_peel = getenv("SW_GEMM_NO_PEEL") != nullptr;    // development switch
     int r = 0; long sk = 1;
     // (Peeling the bf16-output launches the same way — fc6's data gradient has 32 x 98 tiles = 12.25 rounds — gained 3 % alone
     // and lost 1 % inside the step: the persistent form already spreads its quarter round; not done.)
-    if (!no_peel && plain && splitk <= 1 && peel_geometry(M, N, &r, &sk)) {
+    if (!no_peel && plain && !has_row_scale && splitk <= 1 && peel_geometry(M, N, &r, &sk)) {
       const long es = dtype == SW_BF16 ? 2 : 4;
       const long tn = (N + 255) / 256;
       const int N1 = (int)((tn - r) * 256), N2 = N - N1;
@@ -1064,11 +1077,22 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
   }
   const int rc = dtype == SW_BF16 ? dispatch_modes<unsigned short>(g, am, bmo, det ? eff : splitk, stream)
                                   : dispatch_modes<float>(g, am, bmo, det ? eff : splitk, stream);
-  if (rc || !det) return rc;
+  if (rc) return rc;
+  if (!det) {
+    if (ep && ep->fold_row_scale) {            // no slab fold in this launch: the row scale as a pass of its own (plain f32 C only)
+      if (!plain || ep->out_dtype != SW_F32) return -5;
+      long blocks = ((long)M * N + 255) / 256;
+      blocks = blocks > 4096 ? 4096 : blocks;
+      hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, M, N, (float*)C, ldc, ep->fold_row_scale);
+      SW_CHECK_LAUNCH();
+    }
+    return 0;
+  }
   const int vec = ((N % 4) == 0 && (ldc % 4) == 0 && (((uintptr_t)C) & 15) == 0) ? 1 : 0;
   long blocks = (((long)M * N >> (vec ? 2 : 0)) + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, M, N, eff, det_ws, (float*)C, ldc, vec);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, M, N, eff, det_ws, (float*)C, ldc, vec,
+                     ep ? ep->fold_row_scale : nullptr);
   SW_CHECK_LAUNCH();
   return 0;
 }
@@ -1132,7 +1156,8 @@ namespace {
 // 14-28 slabs), folded, transposed through LDS and written as ONE contiguous run of 16-byte stores (the direct form
 // scattered 4-byte stores 36 bytes apart: 2.4 M write transactions per conv4 layer).  Requires (Cin / gridDim.y) % 4 == 0.
 __device__ __forceinline__ void wgrad_reduce_body(int Cout, int Cin, int nslab, const float* __restrict__ slabs,
-                                                  float* __restrict__ out, int co, int parts, int part, float* s_t) {
+                                                  float* __restrict__ out, int co, int parts, int part, float* s_t,
+                                                  const float* __restrict__ cout_scale = nullptr) {
   const int CI = Cin / parts, ci0 = part * CI;
   const int cv = CI >> 2, nv = 9 * cv;                              // 16-byte pieces per tap / per workgroup
   const long slab_f = (long)Cout * 9 * Cin;
@@ -1150,7 +1175,9 @@ __device__ __forceinline__ void wgrad_reduce_body(int Cout, int Cin, int nslab, 
       a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
     }
     for (; z < nslab; ++z) a0 += *(const f32x4*)(p + (long)z * slab_f);
-    *(f32x4*)(s_t + tap * CI + c4 * 4) = (a0 + a1) + (a2 + a3);
+    f32x4 r = (a0 + a1) + (a2 + a3);
+    if (cout_scale) { const float sc = cout_scale[co]; r[0] = __fmul_rn(r[0], sc); r[1] = __fmul_rn(r[1], sc); r[2] = __fmul_rn(r[2], sc); r[3] = __fmul_rn(r[3], sc); }
+    *(f32x4*)(s_t + tap * CI + c4 * 4) = r;
   }
   __syncthreads();
   f32x4* dst = (f32x4*)(out + ((long)co * Cin + ci0) * 9);
@@ -1166,9 +1193,9 @@ __device__ __forceinline__ void wgrad_reduce_body(int Cout, int Cin, int nslab, 
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int Cout, int Cin, int nslab, const float* __restrict__ slabs,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, const float* __restrict__ cout_scale) {
   extern __shared__ __attribute__((aligned(16))) float s_t[];       // [9][CI]
-  wgrad_reduce_body(Cout, Cin, nslab, slabs, out, blockIdx.x, (int)gridDim.y, blockIdx.y, s_t);
+  wgrad_reduce_body(Cout, Cin, nslab, slabs, out, blockIdx.x, (int)gridDim.y, blockIdx.y, s_t, cout_scale);
 }
 
 // every fold of a backward pass in ONE launch: workgroup -> (parameter, output channel, input-channel range)
@@ -1229,15 +1256,21 @@ extern "C" int sw_conv3x3_wgrad_slabs(int dtype, int nimg, int H, int W, int Cin
                           : dispatch_modes<float>(g, OP_KSTRIDED, OP_CONV_B, nslab, stream);
 }
 
+static int wgrad_fold_impl(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, const float* cout_scale,
+                           hipStream_t stream);
 extern "C" int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw,
                                      hipStream_t stream) {
   SW_ENTER();
+  return wgrad_fold_impl(Cin, Cout, nslab, workspace, dw_oihw, nullptr, stream);
+}
+static int wgrad_fold_impl(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, const float* cout_scale,
+                           hipStream_t stream) {
   if (nslab < 1 || (Cin % 4)) return -5;
   if ((size_t)36 * Cin > 65536 || (((uintptr_t)dw_oihw) & 15) || (((uintptr_t)workspace) & 15)) return -5;
   int parts = 1;                                              // input-channel ranges per output channel: >= 1024 workgroups
   while (Cout * parts < 1024 && (Cin % (parts * 2 * 4)) == 0 && Cin / (parts * 2) >= 32) parts *= 2;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cout, (unsigned)parts), dim3(256), (size_t)36 * Cin / parts, stream, Cout, Cin,
-                     nslab, workspace, dw_oihw);
+                     nslab, workspace, dw_oihw, cout_scale);
   SW_CHECK_LAUNCH();
   return 0;
 }
@@ -1326,9 +1359,16 @@ extern "C" int sw_conv3x3_wgrad_fold_multi(int n, const sw_wgrad_fold* folds, hi
 
 extern "C" int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                                 const void* dy, float* dw_oihw, float* workspace, int splitk, hipStream_t stream) {
+  return sw_conv3x3_wgrad_scaled(dtype, nimg, H, W, Cin, Cout, dilation, x, dy, dw_oihw, workspace, splitk, nullptr, stream);
+}
+
+extern "C" int sw_conv3x3_wgrad_scaled(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
+                                       const void* dy, float* dw_oihw, float* workspace, int splitk, const float* cout_scale,
+                                       hipStream_t stream) {
   const int rc = sw_conv3x3_wgrad_slabs(dtype, nimg, H, W, Cin, Cout, dilation, x, dy, workspace, splitk, stream);
   if (rc) return rc;
   const long nelem = (long)Cout * 9 * Cin;
   const int nslab = (int)(sw_conv3x3_wgrad_workspace_floats(dtype, nimg, H, W, Cin, Cout, splitk) / nelem);
-  return sw_conv3x3_wgrad_fold(Cin, Cout, nslab, workspace, dw_oihw, stream);
+  if (nslab < 1 || (Cin % 4)) return -5;
+  return wgrad_fold_impl(Cin, Cout, nslab, workspace, dw_oihw, cout_scale, stream);
 }

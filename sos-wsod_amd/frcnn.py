@@ -90,6 +90,14 @@ class WeightStage:
 
 
 # ====================================================================================================== autograd nodes
+def _pad_scale(scale, ld):
+    """the FrozenBN scale (out,) as a row-scale vector of the padded (ld, in) weight gradient (pad rows: 1); out % 8 == 0 for every
+    ConvBN of the ResNet, so this is the tensor itself"""
+    if scale.shape[0] == ld:
+        return scale
+    return torch.cat([scale, torch.ones(ld - scale.shape[0], device=scale.device, dtype=scale.dtype)])
+
+
 class _LinearFn(torch.autograd.Function):
     """y (P, out) = x (P, in) @ W_eff^T (+ bias) (ReLU): sw_gemm with the epilogue fused; explicit backward (dgrad, wgrad GEMMs, column
     sums).  `staged` (ld, in) is the compute-dtype copy of the effective weight (rows beyond `out` zero), written by the model's
@@ -107,11 +115,16 @@ class _LinearFn(torch.autograd.Function):
         ld = staged.shape[0]
         ydt = torch.float32 if out_f32 else cd
         assert not (relu and out_f32) and ld == (out_f + 7) // 8 * 8 and staged.dtype == cd
-        ybuf = (torch.zeros if ld != out_f else torch.empty)(P, ld, device=x.device, dtype=ydt)     # columns beyond out_f stay 0
+        ybuf = torch.empty(P, ld, device=x.device, dtype=ydt)
+        if ld != out_f and P > 0:
+            ops.fill_zero(ybuf)                                      # columns beyond out_f stay 0
         y = ybuf[:, :out_f]
         if P > 0:
             ops.gemm(x, staged, y, P, out_f, D, ep=ops.make_epilogue(bias=bias, relu=relu, out_dtype=ydt,
-                                                                residual=None if residual is None else residual.detach()))
+                                                                residual=None if residual is None else residual.detach()),
+                     tag="s3_gemm_fwd")
+            if ops.TIMER is not None:
+                ops.TIMER.note("s3_gemm_fwd", 2.0 * P * out_f * D)
         ctx.save_for_backward(x, staged, ybuf if relu else None, scale)
         assert residual is None or (residual.shape == (P, out_f) and residual.dtype == ydt and residual.is_contiguous())
         ctx.relu, ctx.out_f, ctx.splits = relu, out_f, tuple(splits)
@@ -131,8 +144,9 @@ class _LinearFn(torch.autograd.Function):
             else:
                 gs = g.contiguous() if g.dtype == cd else g.to(cd)
         else:
-            gs = torch.zeros(P, ld, device=g.device, dtype=cd)
+            gs = torch.empty(P, ld, device=g.device, dtype=cd)
             if P > 0:
+                ops.fill_zero(gs)
                 gs[:, :out_f] = g
                 if ctx.relu:
                     ops.relu_bwd(ybuf, gs)                              # in place on the padded buffers (pad columns: 0 stays 0)
@@ -150,9 +164,10 @@ class _LinearFn(torch.autograd.Function):
                 # K = pixels (10^4 .. 10^5 for a 1x1 convolution), M x N = a handful of 128x128 tiles: split K so that tiles x splits
                 # fill the chip (slabs + ordered fold inside sw_gemm: deterministic); unsplit, 4 workgroups walked 60 000 pixels
                 tiles = ((ld + 127) // 128) * ((D + 127) // 128)
-                ops.gemm(gs, x, dwp, ld, D, P, a_kstrided=True, b_kstrided=True, splitk=max(1, min(64, 512 // tiles, P // 512)))
-                if scale is not None:
-                    dwp[:out_f].mul_(scale[:, None])
+                # (FrozenBN: dW = scale * dW_eff, applied to the rows inside the slab fold; `scale` covers the out_f real rows, the pad
+                # rows of dwp are never handed out)
+                ep = None if scale is None else ops.make_epilogue(out_dtype=torch.float32, row_scale=_pad_scale(scale, ld))
+                ops.gemm(gs, x, dwp, ld, D, P, a_kstrided=True, b_kstrided=True, splitk=max(1, min(64, 512 // tiles, P // 512)), ep=ep)
             else:
                 dwp.zero_()
             r0 = 0
@@ -212,7 +227,8 @@ class _Conv3x3Fn(torch.autograd.Function):
                 ops.gemm(dz.view(npix, cout), pat, dw.view(cout, cin * 9), cout, cin * 9, npix, a_kstrided=True, b_kstrided=True)
             else:
                 tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
-                ops.conv3x3_wgrad(x, dz, dw, 1, splitk=max(1, min(32, 512 // tiles, max(1, npix // 1024))))
+                ops.conv3x3_wgrad(x, dz, dw, 1, splitk=max(1, min(32, 512 // tiles, max(1, npix // 1024))), cout_scale=scale)
+                scale = None
             if scale is not None:
                 dw.mul_(scale.view(-1, 1, 1, 1))
         if ctx.needs_input_grad[7]:

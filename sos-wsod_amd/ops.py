@@ -41,6 +41,11 @@ class KernelTimer:
     def __init__(self, tags):
         self.tags = set(tags)
         self.pairs = {t: [] for t in tags}
+        self.work = {t: 0.0 for t in tags}        # algorithmic work (FLOP or bytes) noted by the call sites of a tag
+
+    def note(self, tag, amount):
+        if tag in self.tags:
+            self.work[tag] += float(amount)
 
     def wrap(self, tag, fn):
         if tag not in self.tags:
@@ -120,7 +125,8 @@ def _need_gpu(*ts):
 
 
 def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_ref=None, ref_scale=1.0,
-                  out_dtype=torch.float32, atomic=False, absmax_out=None, drop_hash=None, splitk_workspace=None, residual=None):
+                  out_dtype=torch.float32, atomic=False, absmax_out=None, drop_hash=None, splitk_workspace=None, residual=None,
+                  row_scale=None):
     """drop_hash=(seed, offset, p[, device counter]): dropout decided in the epilogue by the hash that sw_dropout_mask uses (no
     mask tensor); with a device counter (uint64 scalar tensor) the stream position is offset + *counter at run time"""
     ep = Epilogue()
@@ -144,7 +150,8 @@ def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_re
     ep.residual = None if residual is None else residual.data_ptr()
     ep.ld_res = 0 if residual is None else residual.stride(0)
     ep.res_dtype = SW_F32 if residual is None else dt(residual)
-    ep._keepalive = (bias, drop_mask, relu_ref, absmax_out, splitk_workspace, drop_hash, residual)     # the struct holds raw pointers only
+    ep.fold_row_scale = None if row_scale is None else row_scale.data_ptr()        # plain f32-output GEMMs: C[m][:] *= row_scale[m]
+    ep._keepalive = (bias, drop_mask, relu_ref, absmax_out, splitk_workspace, drop_hash, residual, row_scale)     # the struct holds raw pointers only
     return ep
 
 
@@ -179,16 +186,17 @@ def conv3x3(x, wk, out, dilation, ep, tag=None):
     return out
 
 
-def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1, workspace=None, tag=None):
-    """dw_oihw (Cout, Cin, 3, 3) f32 is overwritten; workspace: Cout*9*Cin floats (allocated here if None)"""
+def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1, workspace=None, tag=None, cout_scale=None):
+    """dw_oihw (Cout, Cin, 3, 3) f32 is overwritten; workspace: Cout*9*Cin floats (allocated here if None); cout_scale (Cout,) f32:
+    dw[co] *= cout_scale[co] inside the slab fold (FrozenBN fold of the gradient)"""
     _need_gpu(x, dy, dw_oihw)
     n, H, W, Cin = x.shape
     Cout = dy.shape[3]
     need = int(lib.sw_conv3x3_wgrad_workspace_floats(dt(x), n, H, W, Cin, Cout, splitk))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, device=x.device, dtype=torch.float32)
-    check(_launch(tag, lambda: lib.sw_conv3x3_wgrad(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(dy), _p(dw_oihw),
-                                                    _p(workspace), splitk, _stream())), "sw_conv3x3_wgrad")
+    check(_launch(tag, lambda: lib.sw_conv3x3_wgrad_scaled(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(dy), _p(dw_oihw),
+                                                           _p(workspace), splitk, _p(cout_scale), _stream())), "sw_conv3x3_wgrad")
     return dw_oihw
 
 
