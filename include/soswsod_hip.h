@@ -96,6 +96,10 @@ int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int d
  * convolution's weight gradient */
 int sw_conv3x3_wgrad_scaled(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x, const void* dy,
                             float* dw_oihw, float* workspace, int splitk, const float* cout_scale, sw_stream_t stream);
+/* the same weight gradient (dilation 1) for maps of a few pixels (nimg * H * W <= 4096: FPN p5 / p6 of small images, below the tile
+ * geometry of the MFMA loader: sw_conv3x3_wgrad returns -6 there): one thread per (co, ci), plain f32 sums in pixel order. */
+int sw_conv3x3_wgrad_small(int dtype, int nimg, int H, int W, int Cin, int Cout, const void* x, const void* dy,
+                           const float* cout_scale, float* dw_oihw, sw_stream_t stream);
 int sw_conv3x3_wgrad_slabs(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                            const void* dy, float* workspace, int splitk, sw_stream_t stream);
 int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, sw_stream_t stream);
@@ -177,6 +181,14 @@ int sw_wsddn_mil(int V, int R, int K, const float* logits, long ld, int cls_col,
                  float* scores, float* loss_view, float* dlogits, long ld_d, const float* grad_scale,
                  float* mean_scores, long ld_mean, float* workspace, sw_stream_t stream);
 
+/* General backward of the WSDDN scores (fast_rcnn_wsddn.py:564-567: scores = softmax(C, dim=1) * softmax(D, dim=0), ONE image's R
+ * proposals): logits [R][ld] = [C (K) | D (K) | ...], g_scores [R][ld_g] the cotangent of the scores -> dlogits [R][ld_d] columns
+ * 0..2K-1 (others untouched): dC = A (gB - sum_k A g B), dD = B (gA - sum_r B g A).  For callers of the stand-alone predictor API
+ * that build their own loss on the scores; the training path's loss gradient comes from sw_wsddn_mil.  Sums in double, fixed order:
+ * deterministic.  K <= 159 (64-bit row products in LDS); workspace 8-byte aligned. */
+long sw_wsddn_scores_bwd_workspace_floats(int R, int K);
+int sw_wsddn_scores_bwd(int R, int K, const float* logits, long ld, const float* g_scores, long ld_g, float* dlogits, long ld_d,
+                        float* workspace, sw_stream_t stream);
 /* ---- mean over V score matrices (reference: roi_heads_oicrplus.py:290-294,390-395) ----------------------- */
 int sw_mean_views(int V, long n, const float* in, float* out, sw_stream_t stream);
 

@@ -128,6 +128,7 @@ SIGNATURES = {
     "sw_colsum_fold": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_conv3x3_wgrad_scaled": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                         c_void_p, c_void_p]),
+    "sw_conv3x3_wgrad_small": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_conv3x3_wgrad_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p]),
     "sw_conv3x3_wgrad_fold": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -177,6 +178,8 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_long, c_void_p]),
     "sw_roi_align_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p, c_void_p,
                                  c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_wsddn_scores_bwd_workspace_floats": (c_long, [c_int, c_int]),
+    "sw_wsddn_scores_bwd": (c_int, [c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_scale_col_blocks": (c_int, [c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_rpn_unpack": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "sw_rpn_unpack_bwd": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long,

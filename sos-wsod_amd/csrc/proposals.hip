@@ -654,6 +654,112 @@ __global__ __launch_bounds__(1024) void roi_levels_kernel(LevelArgs g, int R, co
   if (threadIdx.x < 4) sel_cnt[threadIdx.x] = s_base[threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------------------------------- WSDDN scores, general backward
+// scores = softmax_k(C) * softmax_r(D) per image (fast_rcnn_wsddn.py:564-567), logits [R][ld] = [C (K) | D (K)].  With A = softmax_k(C),
+// B = softmax_r(D) and g the cotangent of the scores:  dC = A (gB - sum_k A g B),  dD = B (gA - sum_r B g A).
+// (The training path never needs this: sw_wsddn_mil emits the BCE loss with its own gradient.  It serves the stand-alone predictor API,
+// where a caller builds its own loss on the scores.)
+// Arithmetic in double: with peaky heads the gradient is a difference of nearly equal terms (g B - sum A g B with A ~ 1 on one class);
+// float sums left ~1e-7 of absolute noise on weight gradients that are themselves ~1e-7 (an off-path API: the cost is irrelevant).
+constexpr int WS_ROWS = 128;           // rows per workgroup of the row passes (K + 1 doubles of LDS per row: K <= 159)
+__global__ __launch_bounds__(256) void wsddn_colstat_kernel(int R, int K, const float* __restrict__ lg, long ld, double* __restrict__ colstat) {
+  __shared__ float red[32];
+  __shared__ double dred[4];
+  __shared__ float s_m;
+  const int k = blockIdx.x;
+  float m = -FLT_MAX;
+  for (int r = threadIdx.x; r < R; r += 256) m = fmaxf(m, lg[(long)r * ld + K + k]);
+  m = block_reduce_max(m, red);
+  if (threadIdx.x == 0) s_m = m;
+  __syncthreads();
+  m = s_m;
+  double s = 0.0;
+  for (int r = threadIdx.x; r < R; r += 256) s += exp((double)lg[(long)r * ld + K + k] - (double)m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { colstat[2 * k] = (double)m; colstat[2 * k + 1] = (dred[0] + dred[1]) + (dred[2] + dred[3]); }
+}
+// phase 0: dC, and per-workgroup partial column sums t_part[wg][k] = sum_r B g A; phase 1: dD with the folded t
+__global__ __launch_bounds__(WS_ROWS) void wsddn_bwd_rows_kernel(int R, int K, const float* __restrict__ lg, long ld, const float* __restrict__ g,
+                                                                 long ldg, const double* __restrict__ colstat, float* __restrict__ dl, long ldd,
+                                                                 double* __restrict__ t_part, const double* __restrict__ t_col, int phase) {
+  extern __shared__ double shd[];          // [WS_ROWS][K + 1] products B g A of this workgroup's rows (phase 0)
+  const int r = blockIdx.x * WS_ROWS + threadIdx.x;
+  const bool ok = r < R;
+  double rm = -1e300, rs = 0.0;
+  if (ok) {
+    for (int k = 0; k < K; ++k) rm = fmax(rm, (double)lg[(long)r * ld + k]);
+    for (int k = 0; k < K; ++k) rs += exp((double)lg[(long)r * ld + k] - rm);
+  }
+  if (phase == 0) {
+    double u = 0.0;
+    if (ok)
+      for (int k = 0; k < K; ++k) {
+        const double A = exp((double)lg[(long)r * ld + k] - rm) / rs, B = exp((double)lg[(long)r * ld + K + k] - colstat[2 * k]) / colstat[2 * k + 1];
+        u += A * (double)g[(long)r * ldg + k] * B;
+      }
+    for (int k = 0; k < K; ++k) {
+      double p = 0.0;
+      if (ok) {
+        const double A = exp((double)lg[(long)r * ld + k] - rm) / rs, B = exp((double)lg[(long)r * ld + K + k] - colstat[2 * k]) / colstat[2 * k + 1];
+        const double gv = (double)g[(long)r * ldg + k];
+        dl[(long)r * ldd + k] = (float)(A * (gv * B - u));
+        p = B * gv * A;
+      }
+      shd[threadIdx.x * (K + 1) + k] = p;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += WS_ROWS) {          // ordered sum over the workgroup's rows
+      double t = 0.0;
+      for (int i = 0; i < WS_ROWS; ++i) t += shd[i * (K + 1) + k];
+      t_part[(long)blockIdx.x * K + k] = t;
+    }
+  } else if (ok) {
+    for (int k = 0; k < K; ++k) {
+      const double A = exp((double)lg[(long)r * ld + k] - rm) / rs, B = exp((double)lg[(long)r * ld + K + k] - colstat[2 * k]) / colstat[2 * k + 1];
+      dl[(long)r * ldd + K + k] = (float)(B * ((double)g[(long)r * ldg + k] * A - t_col[k]));
+    }
+  }
+}
+__global__ void wsddn_tfold_kernel(int n_wg, int K, const double* __restrict__ t_part, double* __restrict__ t_col) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  double t = 0.0;
+  for (int i = 0; i < n_wg; ++i) t += t_part[(long)i * K + k];
+  t_col[k] = t;
+}
+
+// ---------------------------------------------------------------------------------------------------- 3x3 weight gradient of tiny maps
+// dw[co][ci][ty][tx] = sum over (img, y, x) of dy[img][y][x][co] * x[img][y + ty - 1][x + tx - 1][ci] for maps of a few pixels (p5 / p6
+// of small images: 4x4, 2x2 — below the tile geometry of the gathering MFMA loader): one thread per (co, ci), nine running sums over the
+// <= a few hundred pixels; the operands sit in L2.  cout_scale (may be NULL): the FrozenBN fold, dw[co] *= cout_scale[co].
+template <typename T>
+__global__ void conv3x3_wgrad_small_kernel(int N, int H, int W, int Cin, int Cout, const T* __restrict__ x, const T* __restrict__ dy,
+                                           const float* __restrict__ cout_scale, float* __restrict__ dw) {
+  const long total = (long)Cout * Cin;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), co = (int)(i / Cin);
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int img = 0; img < N; ++img)
+      for (int y = 0; y < H; ++y)
+        for (int xx = 0; xx < W; ++xx) {
+          const float g = Elem<T>::load(dy + (((long)img * H + y) * W + xx) * Cout + co);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xs = xx + t % 3 - 1;
+            if (yy >= 0 && yy < H && xs >= 0 && xs < W) acc[t] += g * Elem<T>::load(x + (((long)img * H + yy) * W + xs) * Cin + ci);
+          }
+        }
+    const float sc = cout_scale ? cout_scale[co] : 1.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw[((long)co * Cin + ci) * 9 + t] = cout_scale ? __fmul_rn(acc[t], sc) : acc[t];
+  }
+}
+
 // out[m][n] = in[m][n] * (n < split ? g0[0] : g1[0]): the two cotangents of the ROI heads' (classification, box) losses applied to the
 // unit gradient of the packed logits in one pass
 __global__ void scale_col_blocks_kernel(long M, int N, int split, const float* __restrict__ in, long ld, const float* __restrict__ g0,
@@ -846,6 +952,49 @@ extern "C" int sw_scale_col_blocks(long M, int N, int split, const float* in, lo
   const long blocks = (M * ld + 255) / 256;
   hipLaunchKernelGGL(scale_col_blocks_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, M, N, split, in, ld,
                      g0_dev, g1_dev, out);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" long sw_wsddn_scores_bwd_workspace_floats(int R, int K) {
+  const long n_wg = (R + WS_ROWS - 1) / WS_ROWS;
+  return 2 * (2L * K + n_wg * K + K) + 64;             // doubles, counted in floats
+}
+
+extern "C" int sw_wsddn_scores_bwd(int R, int K, const float* logits, long ld, const float* g_scores, long ld_g, float* dlogits, long ld_d,
+                                   float* workspace, hipStream_t stream) {
+  SW_ENTER();
+  if (R <= 0) return 0;
+  if (K < 1 || K > 1024 || ld < 2 * K || ld_d < 2 * K || ld_g < K || (((uintptr_t)workspace) & 7)) return -5;
+  const int n_wg = (R + WS_ROWS - 1) / WS_ROWS;
+  double* colstat = (double*)workspace; double* t_part = colstat + 2 * K; double* t_col = t_part + (long)n_wg * K;
+  const size_t lds = (size_t)WS_ROWS * (K + 1) * 8;
+  if (lds > 160 * 1024) return -6;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)wsddn_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(wsddn_colstat_kernel, dim3(K), dim3(256), 0, stream, R, K, logits, ld, colstat);
+  hipLaunchKernelGGL(wsddn_bwd_rows_kernel, dim3(n_wg), dim3(WS_ROWS), lds, stream, R, K, logits, ld, g_scores, ld_g, colstat, dlogits, ld_d, t_part,
+                     (const double*)nullptr, 0);
+  hipLaunchKernelGGL(wsddn_tfold_kernel, dim3((K + 63) / 64), dim3(64), 0, stream, n_wg, K, t_part, t_col);
+  hipLaunchKernelGGL(wsddn_bwd_rows_kernel, dim3(n_wg), dim3(WS_ROWS), 0, stream, R, K, logits, ld, g_scores, ld_g, colstat, dlogits, ld_d, t_part, t_col, 1);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_conv3x3_wgrad_small(int dtype, int nimg, int H, int W, int Cin, int Cout, const void* x, const void* dy,
+                                      const float* cout_scale, float* dw_oihw, hipStream_t stream) {
+  SW_ENTER();
+  if (nimg < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (long)nimg * H * W > 4096) return -5;
+  const long blocks = ((long)Cout * Cin + 255) / 256;
+  if (dtype == SW_BF16)
+    hipLaunchKernelGGL(conv3x3_wgrad_small_kernel<unsigned short>, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, nimg, H, W,
+                       Cin, Cout, (const unsigned short*)x, (const unsigned short*)dy, cout_scale, dw_oihw);
+  else if (dtype == SW_F32)
+    hipLaunchKernelGGL(conv3x3_wgrad_small_kernel<float>, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, nimg, H, W, Cin,
+                       Cout, (const float*)x, (const float*)dy, cout_scale, dw_oihw);
+  else return -1;
   SW_CHECK_LAUNCH();
   return 0;
 }

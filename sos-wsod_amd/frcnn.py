@@ -220,17 +220,11 @@ class _Conv3x3Fn(torch.autograd.Function):
             npix = n * H * W
             if (64 // W) + 1 > 2 * H:
                 # maps of a few pixels (p5 / p6 of small images: 4x4, 2x2) are below the gathering loader's tile geometry
-                # (sw_conv3x3_wgrad returns -6): the <= 128 pixels are unfolded into (ci, ky, kx) patch rows and the gradient is
-                # one K-strided GEMM dz^T @ patches
-                pat = torch.nn.functional.unfold(x.permute(0, 3, 1, 2), kernel_size=3, padding=1)       # (n, cin*9, H*W)
-                pat = pat.permute(0, 2, 1).reshape(npix, cin * 9).contiguous()
-                ops.gemm(dz.view(npix, cout), pat, dw.view(cout, cin * 9), cout, cin * 9, npix, a_kstrided=True, b_kstrided=True)
+                # (sw_conv3x3_wgrad returns -6): a direct kernel, one thread per (co, ci)
+                ops.conv3x3_wgrad_small(x, dz, dw, cout_scale=scale)
             else:
                 tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
                 ops.conv3x3_wgrad(x, dz, dw, 1, splitk=max(1, min(32, 512 // tiles, max(1, npix // 1024))), cout_scale=scale)
-                scale = None
-            if scale is not None:
-                dw.mul_(scale.view(-1, 1, 1, 1))
         if ctx.needs_input_grad[7]:
             db = torch.empty(cout, device=g.device, dtype=torch.float32)
             ops.colsum(dz.view(n * H * W, cout), n * H * W, cout, db)

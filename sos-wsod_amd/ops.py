@@ -200,6 +200,15 @@ def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1, workspace=None, tag=None, 
     return dw_oihw
 
 
+def conv3x3_wgrad_small(x, dy, dw_oihw, cout_scale=None):
+    """3x3 weight gradient of a map of a few pixels (sw_conv3x3_wgrad_small): x (n, H, W, Cin), dy (n, H, W, Cout) -> dw (Cout, Cin, 3, 3) f32"""
+    _need_gpu(x, dy, dw_oihw)
+    n, H, W, Cin = x.shape
+    check(lib.sw_conv3x3_wgrad_small(dt(x), n, H, W, Cin, dy.shape[3], _p(x), _p(dy), _p(cout_scale), _p(dw_oihw), _stream()),
+          "sw_conv3x3_wgrad_small")
+    return dw_oihw
+
+
 def conv3x3_wgrad_nslab(x, cout, splitk):
     """slabs that conv3x3_wgrad_slabs(x, dy -> cout channels, splitk) writes"""
     n, H, W, Cin = x.shape
@@ -812,6 +821,17 @@ def roi_align_bwd(gout, rois, sel_i32, dfeat_f32, scale, PH=7, PW=7, sampling_ra
     check(lib.sw_roi_align_bwd(dt(gout), H, W, C, PH, PW, float(scale), sampling_ratio, _p(gout), gout.stride(0), _p(rois),
                                _p(sel_i32), sel_i32.numel(), _p(n_sel_dev), _p(dfeat_f32), _stream()), "sw_roi_align_bwd")
     return dfeat_f32
+
+
+def wsddn_scores_bwd(logits, K, g_scores, dlogits):
+    """analytic backward of scores = softmax(C, 1) * softmax(D, 0) for ONE image's rows (sw_wsddn_scores_bwd): logits (R, >= 2K) f32,
+    g_scores (R, K) f32 -> dlogits[:, :2K]"""
+    _need_gpu(logits, g_scores, dlogits)
+    R = logits.shape[0]
+    ws = torch.empty(int(lib.sw_wsddn_scores_bwd_workspace_floats(R, K)), device=logits.device, dtype=torch.float32)
+    check(lib.sw_wsddn_scores_bwd(R, K, _p(logits), logits.stride(0), _p(g_scores), g_scores.stride(0), _p(dlogits), dlogits.stride(0),
+                                  _p(ws), _stream()), "sw_wsddn_scores_bwd")
+    return dlogits
 
 
 def scale_col_blocks(src, dst, split, g0, g1):

@@ -122,13 +122,12 @@ class _WsddnScores(torch.autograd.Function):
     def backward(ctx, g):
         (lg,) = ctx.saved_tensors
         K = ctx.K
-        d = torch.zeros_like(lg)
+        d = ops.fill_zero(torch.empty_like(lg))
+        g = g.contiguous().float()
         off = 0
-        for n in ctx.sizes:
-            A = torch.softmax(lg[off:off + n, :K], dim=1); B = torch.softmax(lg[off:off + n, K:2 * K], dim=0)
-            gB, gA = g[off:off + n] * B, g[off:off + n] * A
-            d[off:off + n, :K] = A * (gB - (A * gB).sum(1, keepdim=True))
-            d[off:off + n, K:2 * K] = B * (gA - (B * gA).sum(0, keepdim=True))
+        for n in ctx.sizes:                                  # per image: the softmax over proposals spans one image's rows
+            if n:
+                ops.wsddn_scores_bwd(lg[off:off + n], K, g[off:off + n], d[off:off + n])
             off += n
         return d, None, None
 

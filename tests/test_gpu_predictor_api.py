@@ -174,3 +174,20 @@ def test_predictions_survive_caller_side_tensor_ops():
         ol.cls_score.weight.add_(1.0)
     ol(x)
     assert ol.__dict__["_api_stage"][1] is not st
+
+
+def test_wsddn_scores_backward_kernel_against_float64():
+    """sw_wsddn_scores_bwd (the stand-alone API's gradient of softmax(C, 1) * softmax(D, 0), fast_rcnn_wsddn.py:564-567) against the
+    analytic expression in float64 — VOC and COCO class counts, a padded logit pitch, peaky logits"""
+    import sos_wsod_amd.ops as ops
+    torch.manual_seed(0)
+    for R, K, pad, amp in ((300, 20, 0, 3.0), (1000, 80, 8, 12.0), (37, 5, 3, 30.0)):
+        lg = (torch.randn(R, 2 * K + pad, device="cuda") * amp)[:, :2 * K]
+        g = torch.randn(R, K, device="cuda")
+        d = torch.zeros(R, 2 * K, device="cuda")
+        ops.wsddn_scores_bwd(lg, K, g, d)
+        A = torch.softmax(lg[:, :K].double(), 1); B = torch.softmax(lg[:, K:2 * K].double(), 0)
+        gB, gA = g.double() * B, g.double() * A
+        wc = A * (gB - (A * gB).sum(1, keepdim=True)); wd = B * (gA - (B * gA).sum(0, keepdim=True))
+        assert float((d[:, :K].double() - wc).abs().max()) <= 2e-7 * float(wc.abs().max()) + 1e-12
+        assert float((d[:, K:].double() - wd).abs().max()) <= 2e-7 * float(wd.abs().max()) + 1e-12

@@ -526,3 +526,17 @@ def test_detector_trains_the_same_under_hipsgd_and_torch_sgd(golden_dir):
     for n, p in runs["hip"][1].items():
         q = runs["torch"][1][n]
         assert float((p - q).norm()) <= 1e-4 * float(q.norm()) + 1e-9, n
+
+
+def test_small_map_weight_gradient_kernel(ops):
+    """sw_conv3x3_wgrad_small (FPN p5 / p6 of small images) against torch's conv2d weight gradient, with the FrozenBN scale"""
+    torch.manual_seed(3)
+    for (n, H, W, cin, cout), dtype in (((2, 4, 4, 64, 32), torch.float32), ((1, 2, 3, 32, 48), torch.float32), ((2, 3, 2, 64, 64), torch.bfloat16)):
+        x = torch.randn(n, H, W, cin, device="cuda").to(dtype); dy = torch.randn(n, H, W, cout, device="cuda").to(dtype)
+        scale = torch.rand(cout, device="cuda") + 0.5
+        dw = torch.empty(cout, cin, 3, 3, device="cuda")
+        ops.conv3x3_wgrad_small(x, dy, dw, cout_scale=scale)
+        w = torch.zeros(cout, cin, 3, 3, device="cuda", requires_grad=True)
+        F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+        want = w.grad * scale.view(-1, 1, 1, 1)
+        assert float((dw - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
