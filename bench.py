@@ -295,7 +295,7 @@ def main():
         e1.record(); torch.cuda.synchronize()
         conv_alone_ms = e0.elapsed_time(e1) / 20
         # HBM bytes per call from the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh): (2*FETCH_SIZE + WRITE_SIZE)*1024
-        pmc = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"))
+        pmc = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"))
                     if os.path.exists(p)), None)
         traffic = json.load(open(pmc)) if pmc else {}
         roofline = roof(dom)
@@ -315,7 +315,7 @@ def main():
         # counter-based MFMA utilisation of the same kernels run alone (tools/pmc_mfma.sh, committed under profiles/):
         # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32).  The FLOP-based `frac` prices against the 2.4 GHz peak;
         # under MFMA load the chip runs 1.6-2.0 GHz (DVFS), so the pipe is busier than `frac` says.
-        busy_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r03_mfma_busy.json", "r02_mfma_busy.json", "r01_mfma_busy.json"))
+        busy_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_mfma_busy.json", "r03_mfma_busy.json", "r02_mfma_busy.json", "r01_mfma_busy.json"))
                           if os.path.exists(p)), None)
         busy = json.load(open(busy_path)) if busy_path else {}
 
