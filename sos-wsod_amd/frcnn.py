@@ -123,8 +123,10 @@ class _LinearFn(torch.autograd.Function):
             ops.gemm(x, staged, y, P, out_f, D, ep=ops.make_epilogue(bias=bias, relu=relu, out_dtype=ydt,
                                                                 residual=None if residual is None else residual.detach()),
                      tag="s3_gemm_fwd")
-            if ops.TIMER is not None:
+            if ops.TIMER is not None:            # bench.py's roofline_stage3: algorithmic FLOP and bytes (operands once, result once) of this launch
+                es = 2 if cd == torch.bfloat16 else 4
                 ops.TIMER.note("s3_gemm_fwd", 2.0 * P * out_f * D)
+                ops.TIMER.note("s3_gemm_fwd_bytes", float(es) * (P * D + out_f * D) + (4.0 if out_f32 else es) * P * out_f)
         ctx.save_for_backward(x, staged, ybuf if relu else None, scale)
         assert residual is None or (residual.shape == (P, out_f) and residual.dtype == ydt and residual.is_contiguous())
         ctx.relu, ctx.out_f, ctx.splits = relu, out_f, tuple(splits)
