@@ -30,6 +30,7 @@ struct GemmArgs {
   int M, N, K;
   long lda, ldb, ldc;
   int tiles_m, tiles_n, patches_m, k_per_split;
+  int patch_m_log2;                // an XCD patch is (1 << patch_m_log2) x (64 >> patch_m_log2) tiles (launch2 picks the shape)
   int cH, cW, cC, cDil;            // geometry of the gathered NHWC tensor (conv modes)
   const float* bias;               // per column n (or per row m when bias_on_m)
   const uint8_t* drop; long ldd; float drop_scale;
@@ -771,8 +772,9 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 1) void gemm2_kernel(
     const int bid = vbid;
     const int swz = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int patch = swz >> 6, within = swz & 63;
-    bm = (patch % g.patches_m) * 8 + (within & 7);
-    bn = (patch / g.patches_m) * 8 + (within >> 3);
+    const int pml = g.patch_m_log2;
+    bm = ((patch % g.patches_m) << pml) + (within & ((1 << pml) - 1));
+    bn = ((patch / g.patches_m) << (6 - pml)) + (within >> pml);
     if (bm >= g.tiles_m || bn >= g.tiles_n) continue;
   }
   gemm2_tile<T, AMODE, BMODE, BM, BN, STAGES, WTM, WTN>(g, bm, bn, zsplit, smem);
@@ -839,8 +841,15 @@ int launch2(GemmArgs& g, int splitk, hipStream_t stream) {
   constexpr int NT = (BM / WTM) * (BN / WTN) * 64;
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
-  g.patches_m = (g.tiles_m + 7) / 8;
-  const int patches_n = (g.tiles_n + 7) / 8;
+  // XCD patch shape: 64 tiles as pm x pn.  8 x 8 (least operand traffic per tile) unless one side of the tile grid is shorter than
+  // 8: then the patch spans that side and grows along the other — the two tile columns of a ResNet 1x1 convolution (N = 256) under
+  // 8 x 8 patches launched 4 workgroups for every one that had a tile.
+  int pml = 3;
+  if (g.tiles_n < 8) { int l = 0; while ((1 << l) < g.tiles_n) ++l; pml = 6 - l; }
+  else if (g.tiles_m < 8) { int l = 0; while ((1 << l) < g.tiles_m) ++l; pml = l; }
+  g.patch_m_log2 = pml;
+  g.patches_m = (g.tiles_m + (1 << pml) - 1) >> pml;
+  const int patches_n = (g.tiles_n + (64 >> pml) - 1) / (64 >> pml);
   if (splitk < 1) splitk = 1;
   int kps = (g.K + splitk - 1) / splitk;
   kps = ((kps + BK - 1) / BK) * BK;
