@@ -920,6 +920,14 @@ int launch_auto(GemmArgs& g, int splitk, hipStream_t s) {
   }
   const bool narrow = (v && v[0] == '6') || (!v && g.N <= 64 && sk == 1);     // 64-wide outputs (conv1_x): no half-empty N tile
   if (narrow) return launch2<T, AMODE, BMODE, 256, 64, 2, 32, 64>(g, splitk, s);
+  // Few tiles and a long K (a ResNet's res4 / res5 1x1 convolutions at batch 1-2: 30-60 tiles x 16-32 K-tiles): one workgroup per
+  // CU at most, and its K loop runs at one memory round trip per K-tile (~1 us against 0.15 us of MFMA work) on the 2-buffer ring.
+  // A 4-buffer ring keeps three K-tiles in flight (128 KiB of LDS: fine when no second workgroup would share the CU anyway).
+  if constexpr (sizeof(T) == 2 && AMODE <= OP_KSTRIDED && BMODE <= OP_KSTRIDED) {
+    static const char* dp = getenv("SW_GEMM_DEEP");           // development switch: "0" = off, else the largest tile count
+    const long lim = dp ? atol(dp) : 256;
+    if (tiles(128, 128) <= lim && g.K >= 512) return launch2<T, AMODE, BMODE, 128, 128, 4, 32, 64>(g, splitk, s);
+  }
   return launch2<T, AMODE, BMODE, 128, 128, 2, 32, 64>(g, splitk, s);
 }
 
@@ -971,6 +979,66 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ns
       for (int z = 0; z < nslab; ++z) a += ws[(long)z * slab + i];
       const long m = i / N;
       C[m * ldc + (i - m * N)] = row_scale ? __fmul_rn(a, row_scale[m]) : a;
+    }
+  }
+}
+
+// The same ordered fold for a split-K GEMM WITH an epilogue (sw_gemm: bias / residual / ReLU / ReLU-mask reference, f32 or bf16 C):
+// x = row_scale[m] * sum + bias[n] + residual[m][n]; ReLU; mask — the order of the GEMM's own epilogue.  4 columns per thread
+// (N % 4 == 0, 16-byte aligned rows; checked by the host).  `res` may be C itself (f32 accumulation into a gradient that exists).
+struct FoldEp {
+  int M, N, nslab; const float* ws; void* C; long ldc; int out_bf16;
+  const float* bias; const float* row_scale;
+  const void* res; long ldres; int res_bf16;
+  int relu; const void* ref; long ldr; int ref_bf16; float ref_scale;
+};
+__global__ __launch_bounds__(256) void splitk_fold_ep_kernel(FoldEp f) {
+  const long nv = ((long)f.M * f.N) >> 2;
+  const int nq = f.N >> 2;
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nv; q += (long)gridDim.x * blockDim.x) {
+    const f32x4* src = (const f32x4*)f.ws + q;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    int z = 0;
+    for (; z + 4 <= f.nslab; z += 4) {
+      const f32x4 v0 = src[(long)z * nv], v1 = src[(long)(z + 1) * nv], v2 = src[(long)(z + 2) * nv], v3 = src[(long)(z + 3) * nv];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; z < f.nslab; ++z) a0 += src[(long)z * nv];
+    const long m = q / nq; const int n = (int)(q - m * nq) * 4;
+    const f32x4 r = (a0 + a1) + (a2 + a3);
+    float x[4] = {r[0], r[1], r[2], r[3]};
+    if (f.row_scale) { const float sc = f.row_scale[m];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) x[t] = __fmul_rn(x[t], sc); }
+    if (f.bias) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) x[t] += f.bias[n + t]; }
+    if (f.res) {
+      if (f.res_bf16) { const unsigned short* p = (const unsigned short*)f.res + m * f.ldres + n;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] += bf16_bits_to_f32(p[t]); }
+      else { const f32x4 v = *(const f32x4*)((const float*)f.res + m * f.ldres + n);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] += v[t]; }
+    }
+    if (f.relu) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) x[t] = fmaxf(x[t], 0.f); }
+    if (f.ref) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float rv = f.ref_bf16 ? bf16_bits_to_f32(((const unsigned short*)f.ref)[m * f.ldr + n + t]) : ((const float*)f.ref)[m * f.ldr + n + t];
+        x[t] = rv > 0.f ? x[t] * f.ref_scale : 0.f;
+      }
+    }
+    if (f.out_bf16) {
+      unsigned int w0 = (unsigned)f32_to_bf16_bits(x[0]) | ((unsigned)f32_to_bf16_bits(x[1]) << 16);
+      unsigned int w1 = (unsigned)f32_to_bf16_bits(x[2]) | ((unsigned)f32_to_bf16_bits(x[3]) << 16);
+      unsigned int* d = (unsigned int*)((unsigned short*)f.C + m * f.ldc + n);
+      d[0] = w0; d[1] = w1;
+    } else {
+      f32x4 o = {x[0], x[1], x[2], x[3]};
+      *(f32x4*)((float*)f.C + m * f.ldc + n) = o;
     }
   }
 }
@@ -1055,6 +1123,37 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
     }
   }
   const int eff = effective_splits(dtype, K, splitk);
+  // split-K with an epilogue (a few-tile, long-K GEMM whose result is not a plain f32 matrix: the 1x1 convolutions of res4 / res5, a
+  // gradient accumulated into an existing one): plain slabs, the epilogue runs in the fold
+  const bool fold_ep = ep && !plain && eff > 1 && ep->splitk_workspace && !ep->accumulate_atomic && !ep->drop_mask &&
+                       !(ep->drop_hash_p > 0.f) && !ep->absmax_out;
+  if (fold_ep) {
+    if ((N % 4) || (ldc % 4) || (((uintptr_t)C) & 7) || (((uintptr_t)ep->splitk_workspace) & 15)) return -5;
+    if (ep->residual && ((ep->ld_res % 4) || (((uintptr_t)ep->residual) & 7))) return -5;
+    float* const slabs = ep->splitk_workspace;       // (an f32 residual aliasing C is legal: the slab launch does not touch C)
+    GemmArgs gs = {};
+    gs.A = A; gs.B = B; gs.M = M; gs.N = N; gs.K = K; gs.lda = lda; gs.ldb = ldb;
+    gs.C = slabs; gs.ldc = N; gs.slab_stride = (long)M * N; gs.drop_scale = 1.f; gs.ref_scale = 1.f;
+    {
+      const long es = dtype == SW_BF16 ? 2 : 4;
+      const long ab = (long)(a_kstrided ? K : M) * lda * es, bb = (long)(b_kstrided ? K : N) * ldb * es;
+      if (ab >= 0xFFFFFF00L || bb >= 0xFFFFFF00L) return -6;
+      gs.a_bytes = (unsigned)ab; gs.b_bytes = (unsigned)bb;
+    }
+    const int am = a_kstrided ? OP_KSTRIDED : OP_KCONTIG, bmo = b_kstrided ? OP_KSTRIDED : OP_KCONTIG;
+    const int rc = dtype == SW_BF16 ? dispatch_modes<unsigned short>(gs, am, bmo, eff, stream) : dispatch_modes<float>(gs, am, bmo, eff, stream);
+    if (rc) return rc;
+    FoldEp f = {};
+    f.M = M; f.N = N; f.nslab = eff; f.ws = slabs; f.C = C; f.ldc = ldc; f.out_bf16 = ep->out_dtype == SW_BF16;
+    f.bias = ep->bias; f.row_scale = ep->fold_row_scale;
+    f.res = ep->residual; f.ldres = ep->ld_res; f.res_bf16 = ep->res_dtype == SW_BF16;
+    f.relu = ep->relu; f.ref = ep->relu_ref; f.ldr = ep->ld_ref; f.ref_bf16 = ep->ref_dtype == SW_BF16; f.ref_scale = ep->ref_scale;
+    long blocks = (((long)M * N >> 2) + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(splitk_fold_ep_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f);
+    SW_CHECK_LAUNCH();
+    return 0;
+  }
   const bool det = det_ws != nullptr && eff > 1;
   if (det && (((uintptr_t)det_ws) & 15)) return -4;
   GemmArgs g = {};

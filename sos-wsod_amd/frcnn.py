@@ -36,6 +36,9 @@ SCALE_CLAMP = math.log(1000.0 / 16)
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))        # proposal_utils.py:170
 
 
+FUSED_BLOCKS = True      # BottleneckBlock as one autograd node (_BottleneckFn); False: layer by layer (the form the fused one is tested against)
+
+
 def _epc(dtype):
     return 8 if dtype == torch.bfloat16 else 4
 
@@ -122,7 +125,7 @@ class _LinearFn(torch.autograd.Function):
         if P > 0:
             ops.gemm(x, staged, y, P, out_f, D, ep=ops.make_epilogue(bias=bias, relu=relu, out_dtype=ydt,
                                                                 residual=None if residual is None else residual.detach()),
-                     tag="s3_gemm_fwd")
+                     splitk=_few_tile_splits(P, out_f, D) if ld == out_f else 1, tag="s3_gemm_fwd")
             if ops.TIMER is not None:            # bench.py's roofline_stage3: algorithmic FLOP and bytes (operands once, result once) of this launch
                 es = 2 if cd == torch.bfloat16 else 4
                 ops.TIMER.note("s3_gemm_fwd", 2.0 * P * out_f * D)
@@ -156,7 +159,7 @@ class _LinearFn(torch.autograd.Function):
         if need[0]:
             dx = torch.empty(P, D, device=g.device, dtype=cd)
             if P > 0:
-                ops.gemm(gs, ws, dx, P, D, ld, b_kstrided=True)
+                ops.gemm(gs, ws, dx, P, D, ld, b_kstrided=True, ep=ops.make_epilogue(out_dtype=cd), splitk=_few_tile_splits(P, D, ld))
             else:
                 dx.zero_()
         dws, dbs = [None] * nw, [None] * (len(ctx.shapes) - nw)
@@ -234,6 +237,114 @@ class _Conv3x3Fn(torch.autograd.Function):
             dx = torch.empty(n, H, W, cin, device=g.device, dtype=cd)
             ops.conv3x3(dz, wkd, dx, 1, ops.make_epilogue(out_dtype=cd))
         return dx, None, None, None, None, None, dw, db
+
+
+def _few_tile_splits(P, N, K):
+    """K-splits of a bf16 / f32 GEMM with an epilogue whose tile grid fills a fraction of the chip (res5's 1x1 convolutions, the box
+    head's fc6 on 512-1024 ROIs): slabs + the epilogue in the fold (sw_gemm).  Measured (tools/gemm_splitk_ep_probe.py): pays from
+    K = 2048 on — K = 12544, 64 tiles: 103 -> 46 us; K = 2048, 32-64 tiles: 28 -> 22 us; K = 1024: 19 -> 22 us (not split)."""
+    if K < 2048:
+        return 1
+    tiles = ((P + 127) // 128) * ((N + 127) // 128)
+    return max(1, min(8, 256 // max(tiles, 1), K // 512))
+
+
+def _wgrad_1x1(gs, x, scale):
+    """dW (out, in) f32 = scale[:, None] * gs^T x over the pixels: K-split slabs + ordered fold (deterministic)"""
+    P, ld = gs.shape
+    D = x.shape[1]
+    dw = torch.empty(ld, D, device=gs.device, dtype=torch.float32)
+    tiles = ((ld + 127) // 128) * ((D + 127) // 128)
+    ep = None if scale is None else ops.make_epilogue(out_dtype=torch.float32, row_scale=scale)
+    ops.gemm(gs, x, dw, ld, D, P, a_kstrided=True, b_kstrided=True, splitk=max(1, min(64, 512 // tiles, P // 512)), ep=ep)
+    return dw
+
+
+class _BottleneckFn(torch.autograd.Function):
+    """One bottleneck block (conv1 1x1 [stride s] -> ReLU -> conv2 3x3 -> ReLU -> conv3 1x1, + shortcut, ReLU) as ONE autograd node
+    with an explicit backward.  Layer by layer (`_LinearFn` / `_Conv3x3Fn` nodes) every ReLU mask was a kernel of its own in front of
+    the layer's gradients and autograd added the two gradients of the block input with a torch kernel; here the masks of conv1's and
+    conv2's outputs run in the epilogue of the data-gradient kernel that produces the gradient (`relu_ref`), the shortcut branch's
+    gradient is the `residual` of conv1's data-gradient GEMM, and a stride-2 block subsamples its input once for conv1 and the
+    shortcut (one scatter in the backward).  Per block 2 mask kernels, 1 add (stride 2: + 1 subsample, 1 scatter, 1 add) fewer.
+    Against the layer-by-layer form (tests/test_gpu_stage3.py): same losses; fp32 gradients equal up to the association of the
+    three-term sums at the stage outputs (1e-6), bf16: the block-input gradient is rounded once instead of twice.
+    args: x NHWC, `blk` the BottleneckBlock (staged operands, strides), then conv1/conv2/conv3[/shortcut] weights for autograd."""
+
+    @staticmethod
+    def forward(ctx, x, blk, *weights):
+        c1, c2, c3, sc = blk.conv1, blk.conv2, blk.conv3, blk.shortcut
+        s1, s2, s3 = _staged_of(c1), _staged_of(c2), _staged_of(c3)
+        cd = x.dtype
+        full_shape = tuple(x.shape)
+        if c1.stride == 2:
+            n, H, W, C = x.shape
+            x = ops.subsample2x(x, torch.empty(n, (H + 1) // 2, (W + 1) // 2, C, device=x.device, dtype=cd))
+        n, H, W, cin = x.shape
+        P = n * H * W
+        mid, cout = c1.weight.shape[0], c3.weight.shape[0]
+        x2 = x.reshape(P, cin)
+
+        def lin(a, st, relu, out_f, residual=None):
+            y = torch.empty(P, out_f, device=a.device, dtype=cd)
+            D = a.shape[1]
+            ops.gemm(a, st.w, y, P, out_f, D, ep=ops.make_epilogue(bias=st.shift, relu=relu, out_dtype=cd, residual=residual),
+                     splitk=_few_tile_splits(P, out_f, D), tag="s3_gemm_fwd")
+            if ops.TIMER is not None:
+                es = 2 if cd == torch.bfloat16 else 4
+                ops.TIMER.note("s3_gemm_fwd", 2.0 * P * out_f * D)
+                ops.TIMER.note("s3_gemm_fwd_bytes", float(es) * (P * D + out_f * D + P * out_f))
+            return y
+        h1 = lin(x2, s1, True, mid)
+        h2 = torch.empty(n, H, W, mid, device=x.device, dtype=cd)
+        ops.conv3x3(h1.view(n, H, W, mid), s2.w, h2, 1, ops.make_epilogue(bias=s2.shift, relu=True, out_dtype=cd))
+        h2 = h2.view(P, mid)
+        short = x2 if sc is None else lin(x2, _staged_of(sc), False, cout)
+        out = lin(h2, s3, True, cout, residual=short)
+        ctx.save_for_backward(x2, h1, h2, out, s1.w, s2.wd, s3.w, None if sc is None else _staged_of(sc).w,
+                              s1.scale, s2.scale, s3.scale, None if sc is None else _staged_of(sc).scale)
+        ctx.geom = (n, H, W, cin, mid, cout, c1.stride, full_shape)
+        return out.view(n, H, W, cout)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, h1, h2, out, w1, w2d, w3, wsc, sc1, sc2, sc3, scs = ctx.saved_tensors
+        n, H, W, cin, mid, cout, stride, full_shape = ctx.geom
+        P = n * H * W
+        cd = x2.dtype
+        need = ctx.needs_input_grad                                   # (x, blk, w1, w2, w3[, wsc])
+        gs = ops.relu_bwd(out, g.contiguous().view(P, cout), out=torch.empty(P, cout, device=g.device, dtype=cd))
+
+        def dgrad(a, w, D, **ep):
+            d = torch.empty(P, D, device=a.device, dtype=cd)
+            K = a.shape[1]
+            ops.gemm(a, w, d, P, D, K, b_kstrided=True, ep=ops.make_epilogue(out_dtype=cd, **ep), splitk=_few_tile_splits(P, D, K))
+            return d
+        dw3 = _wgrad_1x1(gs, h2, sc3).view(cout, mid, 1, 1) if need[4] else None
+        dh2 = dgrad(gs, w3, mid, relu_ref=h2)                         # masked by conv2's ReLU
+        dw2 = None
+        if need[3]:
+            dw2 = torch.empty(mid, mid, 3, 3, device=g.device, dtype=torch.float32)
+            x4, dz4 = h1.view(n, H, W, mid), dh2.view(n, H, W, mid)
+            if (64 // W) + 1 > 2 * H:
+                ops.conv3x3_wgrad_small(x4, dz4, dw2, cout_scale=sc2)
+            else:
+                tiles = ((mid + 127) // 128) * ((9 * mid + 127) // 128)
+                ops.conv3x3_wgrad(x4, dz4, dw2, 1, splitk=max(1, min(32, 512 // tiles, max(1, P // 1024))), cout_scale=sc2)
+        dh1 = torch.empty(n, H, W, mid, device=g.device, dtype=cd)
+        ops.conv3x3(dh2.view(n, H, W, mid), w2d, dh1, 1, ops.make_epilogue(out_dtype=cd, relu_ref=h1))        # masked by conv1's ReLU
+        dh1 = dh1.view(P, mid)
+        dw1 = _wgrad_1x1(dh1, x2, sc1).view(mid, cin, 1, 1) if need[2] else None
+        dwsc = None
+        if wsc is not None and len(need) > 5 and need[5]:
+            dwsc = _wgrad_1x1(gs, x2, scs).view(cout, cin, 1, 1)
+        dx = None
+        if need[0]:
+            side = gs if wsc is None else dgrad(gs, wsc, cin)         # the shortcut branch's gradient of the (subsampled) block input
+            dx = dgrad(dh1, w1, cin, residual=side).view(n, H, W, cin)
+            if stride == 2:
+                dx = ops.scatter2x(dx, torch.empty(full_shape, device=g.device, dtype=cd))
+        return (dx, None, dw1, dw2, dw3) + ((dwsc,) if wsc is not None else ())
 
 
 class _Subsample2Fn(torch.autograd.Function):
@@ -487,6 +598,9 @@ class BottleneckBlock(nn.Module):
         self.conv1 = ConvBN(cin, mid, 1, stride); self.conv2 = ConvBN(mid, mid, 3); self.conv3 = ConvBN(mid, cout, 1)
 
     def forward(self, x):
+        if FUSED_BLOCKS:
+            ws = (self.conv1.weight, self.conv2.weight, self.conv3.weight) + (() if self.shortcut is None else (self.shortcut.weight,))
+            return _BottleneckFn.apply(x.contiguous(), self, *ws)
         sc = self.shortcut(x, False) if self.shortcut is not None else x
         # out = relu(conv3(...) + shortcut): the add and the ReLU run in conv3's GEMM epilogue (the stand-alone add + ReLU kernel
         # was 45 launches / 1.1 ms of HBM traffic per Stage-3 iteration)

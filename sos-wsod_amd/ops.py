@@ -163,9 +163,9 @@ def gemm(A, B, C, M, N, K, a_kstrided=False, b_kstrided=False, lda=None, ldb=Non
     ldc = C.stride(0) if ldc is None else ldc
     if ep is None:
         ep = make_epilogue(out_dtype=C.dtype)
-    if C.dtype == torch.float32 and not ep.accumulate_atomic and not ep.splitk_workspace:
+    if (C.dtype == torch.float32 or splitk > 1) and not ep.accumulate_atomic and not ep.splitk_workspace:
         # split-K (explicit, or the tail peel of the large weight-gradient GEMMs) through slabs + an ordered fold: no atomics,
-        # bitwise reproducible
+        # bitwise reproducible; with an epilogue (bias / residual / ReLU / mask, bf16 C) the fold applies it
         need = int(lib.sw_gemm_splitk_workspace_floats(M, N, K, splitk))
         if need > 0:
             ws = torch.empty(need, device=C.device, dtype=torch.float32)

@@ -874,3 +874,39 @@ def test_preprocess_multi_equals_single_image_launches(ops, dtype):
         assert torch.equal(out[i], one)
         want = ((im.float().cpu() - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)).permute(1, 2, 0).to(dtype)
         assert torch.equal(out[i, :, :, :3].cpu(), want) and float(out[i, :, :, 3:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("out_bf16", [True, False])
+@pytest.mark.parametrize("bk", [False, True])
+def test_gemm_split_k_with_an_epilogue_folds_like_the_single_launch(ops, out_bf16, bk):
+    """sw_gemm with splitk > 1 AND a non-plain epilogue: plain f32 slabs, then the fold applies row scale, bias, residual, ReLU, the
+    ReLU-mask reference and the output conversion in the GEMM epilogue's order.  Against torch in f64 and against the unsplit
+    launch (same epilogue in the GEMM itself); an f32 residual that IS the output accumulates in place."""
+    torch.manual_seed(5)
+    dev = "cuda"
+    M, N, K = 950, 512, 2048
+    A = torch.randn(M, K, device=dev).bfloat16()
+    B = (torch.randn(K, N, device=dev) if bk else torch.randn(N, K, device=dev)).bfloat16()
+    bias = torch.randn(N, device=dev)
+    od = torch.bfloat16 if out_bf16 else torch.float32
+    res = torch.randn(M, N, device=dev).to(od)
+    ref_t = torch.randn(M, N, device=dev).bfloat16()
+    prod = A.double() @ (B.double() if bk else B.double().t())
+    want = torch.relu(prod + bias.double() + res.double())
+    want = torch.where(ref_t.double() > 0, want, torch.zeros_like(want))
+    outs = {}
+    for sk in (1, 4, 8):
+        C = torch.full((M, N), float("nan"), device=dev, dtype=od)
+        ops.gemm(A, B, C, M, N, K, False, bk, ep=ops.make_epilogue(bias=bias, relu=True, residual=res, relu_ref=ref_t, out_dtype=od), splitk=sk)
+        torch.cuda.synchronize()
+        err = float((C.double() - want).abs().max() / want.abs().max())
+        assert err <= (6e-3 if out_bf16 else 2e-5), (sk, err)
+        outs[sk] = C
+    assert float((outs[4].float() - outs[1].float()).abs().max()) <= (0.5 if out_bf16 else 1e-3)
+    if not out_bf16:                                     # gradient accumulation: C += A B^T with C as its own residual
+        C = res.clone()
+        ops.gemm(A, B, C, M, N, K, False, bk, ep=ops.make_epilogue(residual=C, out_dtype=torch.float32), splitk=4)
+        torch.cuda.synchronize()
+        err = float((C.double() - (prod + res.double())).abs().max() / prod.abs().max())
+        assert err <= 2e-5, err
