@@ -96,10 +96,18 @@ int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int Cout, int d
  * convolution's weight gradient */
 int sw_conv3x3_wgrad_scaled(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x, const void* dy,
                             float* dw_oihw, float* workspace, int splitk, const float* cout_scale, sw_stream_t stream);
+/* sw_conv3x3_wgrad_scaled that ADDS to dw_oihw when accumulate != 0 (dw += cout_scale * fold): the second use of a convolution inside
+ * one backward pass (the Stage-3 student runs two forward passes per iteration; unbias/ubteacher/engine/trainer.py:527-538 leaves
+ * that sum to autograd). */
+int sw_conv3x3_wgrad_acc(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x, const void* dy,
+                         float* dw_oihw, float* workspace, int splitk, const float* cout_scale, int accumulate, sw_stream_t stream);
 /* the same weight gradient (dilation 1) for maps of a few pixels (nimg * H * W <= 4096: FPN p5 / p6 of small images, below the tile
  * geometry of the MFMA loader: sw_conv3x3_wgrad returns -6 there): one thread per (co, ci), plain f32 sums in pixel order. */
 int sw_conv3x3_wgrad_small(int dtype, int nimg, int H, int W, int Cin, int Cout, const void* x, const void* dy,
                            const float* cout_scale, float* dw_oihw, sw_stream_t stream);
+/* sw_conv3x3_wgrad_small that adds to dw_oihw when accumulate != 0 (see sw_conv3x3_wgrad_acc) */
+int sw_conv3x3_wgrad_small_acc(int dtype, int nimg, int H, int W, int Cin, int Cout, const void* x, const void* dy,
+                               const float* cout_scale, float* dw_oihw, int accumulate, sw_stream_t stream);
 int sw_conv3x3_wgrad_slabs(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                            const void* dy, float* workspace, int splitk, sw_stream_t stream);
 int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, sw_stream_t stream);

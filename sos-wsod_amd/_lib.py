@@ -128,7 +128,10 @@ SIGNATURES = {
     "sw_colsum_fold": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_conv3x3_wgrad_scaled": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                         c_void_p, c_void_p]),
+    "sw_conv3x3_wgrad_acc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_int, c_void_p]),
     "sw_conv3x3_wgrad_small": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sw_conv3x3_wgrad_small_acc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sw_conv3x3_wgrad_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p]),
     "sw_conv3x3_wgrad_fold": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

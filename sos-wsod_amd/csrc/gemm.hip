@@ -1125,8 +1125,9 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
   const int eff = effective_splits(dtype, K, splitk);
   // split-K with an epilogue (a few-tile, long-K GEMM whose result is not a plain f32 matrix: the 1x1 convolutions of res4 / res5, a
   // gradient accumulated into an existing one): plain slabs, the epilogue runs in the fold
-  const bool fold_ep = ep && !plain && eff > 1 && ep->splitk_workspace && !ep->accumulate_atomic && !ep->drop_mask &&
-                       !(ep->drop_hash_p > 0.f) && !ep->absmax_out;
+  // (also with ONE slab when a row scale meets a residual: C = residual + row_scale * A B has no single-launch epilogue)
+  const bool fold_ep = ep && !plain && (eff > 1 || (ep->fold_row_scale && ep->residual)) && ep->splitk_workspace &&
+                       !ep->accumulate_atomic && !ep->drop_mask && !(ep->drop_hash_p > 0.f) && !ep->absmax_out;
   if (fold_ep) {
     if ((N % 4) || (ldc % 4) || (((uintptr_t)C) & 7) || (((uintptr_t)ep->splitk_workspace) & 15)) return -5;
     if (ep->residual && ((ep->ld_res % 4) || (((uintptr_t)ep->residual) & 7))) return -5;
@@ -1265,7 +1266,7 @@ namespace {
 // scattered 4-byte stores 36 bytes apart: 2.4 M write transactions per conv4 layer).  Requires (Cin / gridDim.y) % 4 == 0.
 __device__ __forceinline__ void wgrad_reduce_body(int Cout, int Cin, int nslab, const float* __restrict__ slabs,
                                                   float* __restrict__ out, int co, int parts, int part, float* s_t,
-                                                  const float* __restrict__ cout_scale = nullptr) {
+                                                  const float* __restrict__ cout_scale = nullptr, const int accumulate = 0) {
   const int CI = Cin / parts, ci0 = part * CI;
   const int cv = CI >> 2, nv = 9 * cv;                              // 16-byte pieces per tap / per workgroup
   const long slab_f = (long)Cout * 9 * Cin;
@@ -1296,14 +1297,15 @@ __device__ __forceinline__ void wgrad_reduce_body(int Cout, int Cin, int nslab, 
       const int e = 4 * q + j, ci = e / 9, tap = e - 9 * ci;
       o[j] = s_t[tap * CI + ci];
     }
+    if (accumulate) o += dst[q];                                    // a gradient that exists already (the second pass of one backward)
     dst[q] = o;
   }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int Cout, int Cin, int nslab, const float* __restrict__ slabs,
-                                                           float* __restrict__ out, const float* __restrict__ cout_scale) {
+                                                           float* __restrict__ out, const float* __restrict__ cout_scale, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) float s_t[];       // [9][CI]
-  wgrad_reduce_body(Cout, Cin, nslab, slabs, out, blockIdx.x, (int)gridDim.y, blockIdx.y, s_t, cout_scale);
+  wgrad_reduce_body(Cout, Cin, nslab, slabs, out, blockIdx.x, (int)gridDim.y, blockIdx.y, s_t, cout_scale, accumulate);
 }
 
 // every fold of a backward pass in ONE launch: workgroup -> (parameter, output channel, input-channel range)
@@ -1365,20 +1367,20 @@ extern "C" int sw_conv3x3_wgrad_slabs(int dtype, int nimg, int H, int W, int Cin
 }
 
 static int wgrad_fold_impl(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, const float* cout_scale,
-                           hipStream_t stream);
+                           hipStream_t stream, int accumulate = 0);
 extern "C" int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw,
                                      hipStream_t stream) {
   SW_ENTER();
   return wgrad_fold_impl(Cin, Cout, nslab, workspace, dw_oihw, nullptr, stream);
 }
 static int wgrad_fold_impl(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, const float* cout_scale,
-                           hipStream_t stream) {
+                           hipStream_t stream, int accumulate) {
   if (nslab < 1 || (Cin % 4)) return -5;
   if ((size_t)36 * Cin > 65536 || (((uintptr_t)dw_oihw) & 15) || (((uintptr_t)workspace) & 15)) return -5;
   int parts = 1;                                              // input-channel ranges per output channel: >= 1024 workgroups
   while (Cout * parts < 1024 && (Cin % (parts * 2 * 4)) == 0 && Cin / (parts * 2) >= 32) parts *= 2;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cout, (unsigned)parts), dim3(256), (size_t)36 * Cin / parts, stream, Cout, Cin,
-                     nslab, workspace, dw_oihw, cout_scale);
+                     nslab, workspace, dw_oihw, cout_scale, accumulate);
   SW_CHECK_LAUNCH();
   return 0;
 }
@@ -1473,10 +1475,16 @@ extern "C" int sw_conv3x3_wgrad(int dtype, int nimg, int H, int W, int Cin, int 
 extern "C" int sw_conv3x3_wgrad_scaled(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                                        const void* dy, float* dw_oihw, float* workspace, int splitk, const float* cout_scale,
                                        hipStream_t stream) {
+  return sw_conv3x3_wgrad_acc(dtype, nimg, H, W, Cin, Cout, dilation, x, dy, dw_oihw, workspace, splitk, cout_scale, 0, stream);
+}
+
+extern "C" int sw_conv3x3_wgrad_acc(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
+                                    const void* dy, float* dw_oihw, float* workspace, int splitk, const float* cout_scale,
+                                    int accumulate, hipStream_t stream) {
   const int rc = sw_conv3x3_wgrad_slabs(dtype, nimg, H, W, Cin, Cout, dilation, x, dy, workspace, splitk, stream);
   if (rc) return rc;
   const long nelem = (long)Cout * 9 * Cin;
   const int nslab = (int)(sw_conv3x3_wgrad_workspace_floats(dtype, nimg, H, W, Cin, Cout, splitk) / nelem);
   if (nslab < 1 || (Cin % 4)) return -5;
-  return wgrad_fold_impl(Cin, Cout, nslab, workspace, dw_oihw, cout_scale, stream);
+  return wgrad_fold_impl(Cin, Cout, nslab, workspace, dw_oihw, cout_scale, stream, accumulate);
 }

@@ -737,7 +737,7 @@ __global__ void wsddn_tfold_kernel(int n_wg, int K, const double* __restrict__ t
 // <= a few hundred pixels; the operands sit in L2.  cout_scale (may be NULL): the FrozenBN fold, dw[co] *= cout_scale[co].
 template <typename T>
 __global__ void conv3x3_wgrad_small_kernel(int N, int H, int W, int Cin, int Cout, const T* __restrict__ x, const T* __restrict__ dy,
-                                           const float* __restrict__ cout_scale, float* __restrict__ dw) {
+                                           const float* __restrict__ cout_scale, float* __restrict__ dw, const int accumulate) {
   const long total = (long)Cout * Cin;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % Cin), co = (int)(i / Cin);
@@ -756,7 +756,11 @@ __global__ void conv3x3_wgrad_small_kernel(int N, int H, int W, int Cin, int Cou
         }
     const float sc = cout_scale ? cout_scale[co] : 1.f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) dw[((long)co * Cin + ci) * 9 + t] = cout_scale ? __fmul_rn(acc[t], sc) : acc[t];
+    for (int t = 0; t < 9; ++t) {
+      float* d = dw + ((long)co * Cin + ci) * 9 + t;
+      const float v = cout_scale ? __fmul_rn(acc[t], sc) : acc[t];
+      *d = accumulate ? v + *d : v;
+    }
   }
 }
 
@@ -983,18 +987,23 @@ extern "C" int sw_wsddn_scores_bwd(int R, int K, const float* logits, long ld, c
   return 0;
 }
 
-extern "C" int sw_conv3x3_wgrad_small(int dtype, int nimg, int H, int W, int Cin, int Cout, const void* x, const void* dy,
-                                      const float* cout_scale, float* dw_oihw, hipStream_t stream) {
+extern "C" int sw_conv3x3_wgrad_small_acc(int dtype, int nimg, int H, int W, int Cin, int Cout, const void* x, const void* dy,
+                                          const float* cout_scale, float* dw_oihw, int accumulate, hipStream_t stream) {
   SW_ENTER();
   if (nimg < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (long)nimg * H * W > 4096) return -5;
   const long blocks = ((long)Cout * Cin + 255) / 256;
   if (dtype == SW_BF16)
     hipLaunchKernelGGL(conv3x3_wgrad_small_kernel<unsigned short>, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, nimg, H, W,
-                       Cin, Cout, (const unsigned short*)x, (const unsigned short*)dy, cout_scale, dw_oihw);
+                       Cin, Cout, (const unsigned short*)x, (const unsigned short*)dy, cout_scale, dw_oihw, accumulate);
   else if (dtype == SW_F32)
     hipLaunchKernelGGL(conv3x3_wgrad_small_kernel<float>, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, nimg, H, W, Cin,
-                       Cout, (const float*)x, (const float*)dy, cout_scale, dw_oihw);
+                       Cout, (const float*)x, (const float*)dy, cout_scale, dw_oihw, accumulate);
   else return -1;
   SW_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int sw_conv3x3_wgrad_small(int dtype, int nimg, int H, int W, int Cin, int Cout, const void* x, const void* dy,
+                                      const float* cout_scale, float* dw_oihw, hipStream_t stream) {
+  return sw_conv3x3_wgrad_small_acc(dtype, nimg, H, W, Cin, Cout, x, dy, cout_scale, dw_oihw, 0, stream);
 }

@@ -134,6 +134,7 @@ class _LinearFn(torch.autograd.Function):
         assert residual is None or (residual.shape == (P, out_f) and residual.dtype == ydt and residual.is_contiguous())
         ctx.relu, ctx.out_f, ctx.splits = relu, out_f, tuple(splits)
         ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.wkey = id(params[0]) if params else None
         return y
 
     @staticmethod
@@ -164,20 +165,15 @@ class _LinearFn(torch.autograd.Function):
                 dx.zero_()
         dws, dbs = [None] * nw, [None] * (len(ctx.shapes) - nw)
         if need_w:
-            dwp = torch.empty(ld, D, device=g.device, dtype=torch.float32)
-            if P > 0:
-                # K = pixels (10^4 .. 10^5 for a 1x1 convolution), M x N = a handful of 128x128 tiles: split K so that tiles x splits
-                # fill the chip (slabs + ordered fold inside sw_gemm: deterministic); unsplit, 4 workgroups walked 60 000 pixels
-                tiles = ((ld + 127) // 128) * ((D + 127) // 128)
-                # (FrozenBN: dW = scale * dW_eff, applied to the rows inside the slab fold; `scale` covers the out_f real rows, the pad
-                # rows of dwp are never handed out)
-                ep = None if scale is None else ops.make_epilogue(out_dtype=torch.float32, row_scale=_pad_scale(scale, ld))
-                ops.gemm(gs, x, dwp, ld, D, P, a_kstrided=True, b_kstrided=True, splitk=max(1, min(64, 512 // tiles, P // 512)), ep=ep)
-            else:
-                dwp.zero_()
+            # K = pixels (10^4 .. 10^5 for a 1x1 convolution), M x N = a handful of 128x128 tiles: K-split slabs + ordered fold inside
+            # sw_gemm (deterministic; unsplit, 4 workgroups walked 60 000 pixels).  FrozenBN: dW = scale * dW_eff, applied to the rows
+            # inside the fold; `scale` covers the out_f real rows, the pad rows of dwp are never handed out.  None: added to the
+            # buffer an earlier node of this backward pass returned (ops.grad_scope)
+            dwp = (_wgrad_1x1(gs, x, None if scale is None else _pad_scale(scale, ld), ctx.wkey) if P > 0
+                   else torch.zeros(ld, D, device=g.device, dtype=torch.float32))
             r0 = 0
             for i, n in enumerate(ctx.splits):
-                if need[8 + i]:
+                if need[8 + i] and dwp is not None:
                     dws[i] = dwp[r0:r0 + n].view(ctx.shapes[i])
                 r0 += n
         if need_b:
@@ -208,7 +204,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         out = torch.empty(n, H, W, cout, device=x.device, dtype=cd)
         ops.conv3x3(x, staged, out, 1, ops.make_epilogue(bias=bias, relu=relu, out_dtype=cd))
         ctx.save_for_backward(x, staged_d, out if relu else None, scale)
-        ctx.relu, ctx.cout = relu, cout
+        ctx.relu, ctx.cout, ctx.wkey = relu, cout, id(w)
         return out
 
     @staticmethod
@@ -221,15 +217,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         dz = ops.relu_bwd(out, g, out=torch.empty_like(g)) if ctx.relu else g
         dx = dw = db = None
         if ctx.needs_input_grad[6]:
-            dw = torch.empty(cout, cin, 3, 3, device=g.device, dtype=torch.float32)
-            npix = n * H * W
-            if (64 // W) + 1 > 2 * H:
-                # maps of a few pixels (p5 / p6 of small images: 4x4, 2x2) are below the gathering loader's tile geometry
-                # (sw_conv3x3_wgrad returns -6): a direct kernel, one thread per (co, ci)
-                ops.conv3x3_wgrad_small(x, dz, dw, cout_scale=scale)
-            else:
-                tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
-                ops.conv3x3_wgrad(x, dz, dw, 1, splitk=max(1, min(32, 512 // tiles, max(1, npix // 1024))), cout_scale=scale)
+            dw = _wgrad_3x3(x, dz, scale, ctx.wkey)
         if ctx.needs_input_grad[7]:
             db = torch.empty(cout, device=g.device, dtype=torch.float32)
             ops.colsum(dz.view(n * H * W, cout), n * H * W, cout, db)
@@ -249,14 +237,59 @@ def _few_tile_splits(P, N, K):
     return max(1, min(8, 256 // max(tiles, 1), K // 512))
 
 
-def _wgrad_1x1(gs, x, scale):
-    """dW (out, in) f32 = scale[:, None] * gs^T x over the pixels: K-split slabs + ordered fold (deterministic)"""
+def _view4(dw, cout, cin):
+    return None if dw is None else dw.view(cout, cin, 1, 1)
+
+
+def _eff_splits(K, sk, bf16):
+    """the K-split count sw_gemm will really use (gemm.hip effective_splits)"""
+    bk = 64 if bf16 else 32
+    kps = -(-K // max(1, sk))
+    kps = -(-kps // bk) * bk
+    return -(-K // kps)
+
+
+def _wgrad_1x1(gs, x, scale, key=None):
+    """dW (out, in) f32 = scale[:, None] * gs^T x over the pixels: K-split slabs + ordered fold (deterministic).  Inside
+    ops.grad_scope a second use of the same weight (`key`) adds to the first use's buffer in the fold / epilogue and returns None
+    (ALWAYS, once a buffer is registered: autograd may already have replaced the registered tensor by a sum of its own if a later
+    use handed it a gradient too)."""
     P, ld = gs.shape
     D = x.shape[1]
-    dw = torch.empty(ld, D, device=gs.device, dtype=torch.float32)
     tiles = ((ld + 127) // 128) * ((D + 127) // 128)
+    sk = max(1, min(64, 512 // tiles, P // 512))
+    prev = ops.pending_grad(key, (ld, D))
+    if prev is not None:
+        ws = None
+        if scale is not None and _eff_splits(P, sk, gs.dtype == torch.bfloat16) == 1:
+            ws = torch.empty(ld * D, device=gs.device, dtype=torch.float32)        # one slab: row scale + residual run in the fold
+        ops.gemm(gs, x, prev, ld, D, P, a_kstrided=True, b_kstrided=True, splitk=sk,
+                 ep=ops.make_epilogue(out_dtype=torch.float32, row_scale=scale, residual=prev, splitk_workspace=ws))
+        return None
+    dw = torch.empty(ld, D, device=gs.device, dtype=torch.float32)
     ep = None if scale is None else ops.make_epilogue(out_dtype=torch.float32, row_scale=scale)
-    ops.gemm(gs, x, dw, ld, D, P, a_kstrided=True, b_kstrided=True, splitk=max(1, min(64, 512 // tiles, P // 512)), ep=ep)
+    ops.gemm(gs, x, dw, ld, D, P, a_kstrided=True, b_kstrided=True, splitk=sk, ep=ep)
+    ops.note_grad(key, dw)
+    return dw
+
+
+def _wgrad_3x3(x4, dz4, scale, key=None):
+    """dW (cout, cin, 3, 3) f32 of a 3x3 convolution (sw_conv3x3_wgrad: slabs + fold, x FrozenBN scale); grad_scope as _wgrad_1x1"""
+    n, H, W, cin = x4.shape
+    cout = dz4.shape[3]
+    prev = ops.pending_grad(key, (cout, cin, 3, 3))
+    dw = prev if prev is not None else torch.empty(cout, cin, 3, 3, device=x4.device, dtype=torch.float32)
+    if (64 // W) + 1 > 2 * H:
+        # maps of a few pixels (p5 / p6 of small images: 4x4, 2x2) are below the gathering loader's tile geometry
+        # (sw_conv3x3_wgrad returns -6): a direct kernel, one thread per (co, ci)
+        ops.conv3x3_wgrad_small(x4, dz4, dw, cout_scale=scale, accumulate=prev is not None)
+    else:
+        tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
+        sk = max(1, min(32, 512 // tiles, max(1, n * H * W // 1024)))
+        ops.conv3x3_wgrad(x4, dz4, dw, 1, splitk=sk, cout_scale=scale, accumulate=prev is not None)
+    if prev is not None:
+        return None
+    ops.note_grad(key, dw)
     return dw
 
 
@@ -304,6 +337,7 @@ class _BottleneckFn(torch.autograd.Function):
         ctx.save_for_backward(x2, h1, h2, out, s1.w, s2.wd, s3.w, None if sc is None else _staged_of(sc).w,
                               s1.scale, s2.scale, s3.scale, None if sc is None else _staged_of(sc).scale)
         ctx.geom = (n, H, W, cin, mid, cout, c1.stride, full_shape)
+        ctx.keys = tuple(id(w) for w in weights) + (None,) * (4 - len(weights))
         return out.view(n, H, W, cout)
 
     @staticmethod
@@ -320,24 +354,17 @@ class _BottleneckFn(torch.autograd.Function):
             K = a.shape[1]
             ops.gemm(a, w, d, P, D, K, b_kstrided=True, ep=ops.make_epilogue(out_dtype=cd, **ep), splitk=_few_tile_splits(P, D, K))
             return d
-        dw3 = _wgrad_1x1(gs, h2, sc3).view(cout, mid, 1, 1) if need[4] else None
+        keys = ctx.keys
+        dw3 = _view4(_wgrad_1x1(gs, h2, sc3, keys[2]), cout, mid) if need[4] else None
         dh2 = dgrad(gs, w3, mid, relu_ref=h2)                         # masked by conv2's ReLU
-        dw2 = None
-        if need[3]:
-            dw2 = torch.empty(mid, mid, 3, 3, device=g.device, dtype=torch.float32)
-            x4, dz4 = h1.view(n, H, W, mid), dh2.view(n, H, W, mid)
-            if (64 // W) + 1 > 2 * H:
-                ops.conv3x3_wgrad_small(x4, dz4, dw2, cout_scale=sc2)
-            else:
-                tiles = ((mid + 127) // 128) * ((9 * mid + 127) // 128)
-                ops.conv3x3_wgrad(x4, dz4, dw2, 1, splitk=max(1, min(32, 512 // tiles, max(1, P // 1024))), cout_scale=sc2)
+        dw2 = _wgrad_3x3(h1.view(n, H, W, mid), dh2.view(n, H, W, mid), sc2, keys[1]) if need[3] else None
         dh1 = torch.empty(n, H, W, mid, device=g.device, dtype=cd)
         ops.conv3x3(dh2.view(n, H, W, mid), w2d, dh1, 1, ops.make_epilogue(out_dtype=cd, relu_ref=h1))        # masked by conv1's ReLU
         dh1 = dh1.view(P, mid)
-        dw1 = _wgrad_1x1(dh1, x2, sc1).view(mid, cin, 1, 1) if need[2] else None
+        dw1 = _view4(_wgrad_1x1(dh1, x2, sc1, keys[0]), mid, cin) if need[2] else None
         dwsc = None
         if wsc is not None and len(need) > 5 and need[5]:
-            dwsc = _wgrad_1x1(gs, x2, scs).view(cout, cin, 1, 1)
+            dwsc = _view4(_wgrad_1x1(gs, x2, scs, keys[3]), cout, cin)
         dx = None
         if need[0]:
             side = gs if wsc is None else dgrad(gs, wsc, cin)         # the shortcut branch's gradient of the (subsampled) block input

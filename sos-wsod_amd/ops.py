@@ -89,6 +89,43 @@ def param_key(p):
     return (p.data_ptr(), p._version, INVALIDATE_EPOCH, p.__dict__.get("_sw_epoch", 0))
 
 
+GRAD_SCOPE = None      # inside `with grad_scope():` — id(parameter) -> the gradient buffer a backward node has produced in THIS backward pass
+
+
+class grad_scope:
+    """Wrap ONE `backward()` call whose graph uses parameters more than once (the Stage-3 student: two forward passes per iteration,
+    unbias/ubteacher/engine/trainer.py:527-538).  Autograd would hand every use's weight gradient to the parameter's accumulator and
+    add them with a torch kernel; inside the scope the first weight-gradient node of a parameter registers the buffer it returns
+    (`note_grad`) and every later node of the same parameter ADDS to that buffer inside its own fold / GEMM epilogue
+    (`pending_grad`) and returns no gradient.  The accumulator node runs after all of them (it waits for every incoming edge), on
+    the same stream, so it sees the sum.  Outside a scope both helpers are inert: plain autograd behaviour."""
+
+    def __enter__(self):
+        global GRAD_SCOPE
+        self._prev, GRAD_SCOPE = GRAD_SCOPE, {}
+        return self
+
+    def __exit__(self, *exc):
+        global GRAD_SCOPE
+        GRAD_SCOPE = self._prev
+        return False
+
+
+def pending_grad(key, shape):
+    """the f32 buffer an earlier node of this backward pass registered for `key` (viewed as `shape`), or None"""
+    if GRAD_SCOPE is None or key is None:
+        return None
+    buf = GRAD_SCOPE.get(key)
+    if buf is None or buf.numel() != int(torch.Size(shape).numel()) or not buf.is_contiguous():
+        return None
+    return buf.view(shape)
+
+
+def note_grad(key, buf):
+    if GRAD_SCOPE is not None and key is not None:
+        GRAD_SCOPE[key] = buf
+
+
 def grad_target(param, shape, dev):
     """Where a weight-gradient GEMM writes.  Under DistributedDataParallel(gradient_as_bucket_view=True) the Trainer remembers the
     bucket view each parameter's gradient lived in last step (`param._sw_grad_view`); writing the new gradient THERE lets the
@@ -186,26 +223,27 @@ def conv3x3(x, wk, out, dilation, ep, tag=None):
     return out
 
 
-def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1, workspace=None, tag=None, cout_scale=None):
-    """dw_oihw (Cout, Cin, 3, 3) f32 is overwritten; workspace: Cout*9*Cin floats (allocated here if None); cout_scale (Cout,) f32:
-    dw[co] *= cout_scale[co] inside the slab fold (FrozenBN fold of the gradient)"""
+def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1, workspace=None, tag=None, cout_scale=None, accumulate=False):
+    """dw_oihw (Cout, Cin, 3, 3) f32 is overwritten (accumulate: added to); workspace: Cout*9*Cin floats (allocated here if None);
+    cout_scale (Cout,) f32: dw[co] *= cout_scale[co] inside the slab fold (FrozenBN fold of the gradient)"""
     _need_gpu(x, dy, dw_oihw)
     n, H, W, Cin = x.shape
     Cout = dy.shape[3]
     need = int(lib.sw_conv3x3_wgrad_workspace_floats(dt(x), n, H, W, Cin, Cout, splitk))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, device=x.device, dtype=torch.float32)
-    check(_launch(tag, lambda: lib.sw_conv3x3_wgrad_scaled(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(dy), _p(dw_oihw),
-                                                           _p(workspace), splitk, _p(cout_scale), _stream())), "sw_conv3x3_wgrad")
+    check(_launch(tag, lambda: lib.sw_conv3x3_wgrad_acc(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(dy), _p(dw_oihw),
+                                                        _p(workspace), splitk, _p(cout_scale), int(accumulate), _stream())), "sw_conv3x3_wgrad")
     return dw_oihw
 
 
-def conv3x3_wgrad_small(x, dy, dw_oihw, cout_scale=None):
-    """3x3 weight gradient of a map of a few pixels (sw_conv3x3_wgrad_small): x (n, H, W, Cin), dy (n, H, W, Cout) -> dw (Cout, Cin, 3, 3) f32"""
+def conv3x3_wgrad_small(x, dy, dw_oihw, cout_scale=None, accumulate=False):
+    """3x3 weight gradient of a map of a few pixels (sw_conv3x3_wgrad_small): x (n, H, W, Cin), dy (n, H, W, Cout) -> dw (Cout, Cin, 3, 3) f32
+    (accumulate: added to dw)"""
     _need_gpu(x, dy, dw_oihw)
     n, H, W, Cin = x.shape
-    check(lib.sw_conv3x3_wgrad_small(dt(x), n, H, W, Cin, dy.shape[3], _p(x), _p(dy), _p(cout_scale), _p(dw_oihw), _stream()),
-          "sw_conv3x3_wgrad_small")
+    check(lib.sw_conv3x3_wgrad_small_acc(dt(x), n, H, W, Cin, dy.shape[3], _p(x), _p(dy), _p(cout_scale), _p(dw_oihw), int(accumulate),
+                                         _stream()), "sw_conv3x3_wgrad_small")
     return dw_oihw
 
 

@@ -194,8 +194,9 @@ class SemiSupStep:
     """`run_step_full_semisup` (trainer.py:436-549) over any student / teacher pair with the reference's branch interface."""
 
     def __init__(self, model, model_teacher, optimizer, *, burn_up_step, teacher_update_iter=1, ema_keep_rate=0.9996,
-                 bbox_threshold=0.7, unsup_loss_weight=4.0, burn_up_with_strong_aug=True, has_multi_label=False):
+                 bbox_threshold=0.7, unsup_loss_weight=4.0, burn_up_with_strong_aug=True, has_multi_label=False, fuse_grad_sums=True):
         self.model, self.model_teacher, self.optimizer = model, model_teacher, optimizer
+        self.fuse_grad_sums = fuse_grad_sums          # ops.grad_scope around backward (False: autograd sums the two passes' weight gradients)
         self.burn_up_step, self.teacher_update_iter, self.ema_keep_rate = burn_up_step, teacher_update_iter, ema_keep_rate
         self.bbox_threshold, self.unsup_loss_weight = bbox_threshold, unsup_loss_weight
         self.burn_up_with_strong_aug, self.has_multi_label = burn_up_with_strong_aug, has_multi_label
@@ -229,7 +230,11 @@ class SemiSupStep:
             loss_dict = weight_losses(record, self.unsup_loss_weight)
         losses = sum(loss_dict.values())
         self.optimizer.zero_grad()
-        losses.backward()
+        if self.fuse_grad_sums:
+            with ops.grad_scope():           # the student's two passes share every weight: their gradients are summed in the kernels
+                losses.backward()
+        else:
+            losses.backward()
         self.optimizer.step()
         self.iter += 1
         return record, loss_dict
