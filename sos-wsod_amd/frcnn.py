@@ -290,7 +290,9 @@ def _wgrad_3x3(x4, dz4, scale, key=None):
     if prev is not None:
         return None
     ops.note_grad(key, dw)
-    return dw
+    # (a view: the registered alias keeps `dw` itself referenced as its base, and autograd's accumulator copies a gradient whose
+    # tensor object somebody else holds instead of adopting it — 18 device-to-device copies per iteration)
+    return dw.view(cout, cin, 3, 3)
 
 
 class _BottleneckFn(torch.autograd.Function):

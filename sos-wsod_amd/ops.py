@@ -123,7 +123,9 @@ def pending_grad(key, shape):
 
 def note_grad(key, buf):
     if GRAD_SCOPE is not None and key is not None:
-        GRAD_SCOPE[key] = buf
+        # an ALIAS (its own tensor object on the same storage): autograd's accumulator adopts a gradient without copying it only
+        # when nobody else holds the tensor object it was handed (18 device-to-device copies per Stage-3 iteration otherwise)
+        GRAD_SCOPE[key] = buf.view(buf.shape)
 
 
 def grad_target(param, shape, dev):
