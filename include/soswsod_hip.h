@@ -325,6 +325,9 @@ int sw_copy_multi(int n, const sw_copy_desc* copies, sw_stream_t stream);
  * row chunk. */
 long sw_colsum_workspace_floats(int dtype, int M, int N);
 int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, float* workspace, sw_stream_t stream);
+/* sw_colsum that adds to out when accumulate != 0 (a bias gradient that exists already inside one backward pass; see
+ * sw_conv3x3_wgrad_acc) */
+int sw_colsum_acc(int dtype, int M, int N, const void* X, long ld, float* out, float* workspace, int accumulate, sw_stream_t stream);
 /* halves of the workspace form: `_partial` writes sw_colsum_workspace_floats(dtype, M, N) / N partial rows at `workspace`,
  * `_fold` adds n_partial_rows consecutive rows (of one or several matrices) in fixed order */
 int sw_colsum_partial(int dtype, int M, int N, const void* X, long ld, float* workspace, sw_stream_t stream);

@@ -123,6 +123,7 @@ SIGNATURES = {
     "sw_detect_postprocess2": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "sw_colsum": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "sw_colsum_acc": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p]),
     "sw_colsum_workspace_floats": (c_long, [c_int, c_int, c_int]),
     "sw_colsum_partial": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_colsum_fold": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),

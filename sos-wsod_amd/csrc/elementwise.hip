@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256) void colsum_ws_multi_kernel(ColsumPartMulti f)
 // out[n] = sum_c ws[c][n]: a workgroup owns 16 columns x 16 chunk-lanes (the <= 128 partial rows are 8 loads deep per
 // thread; 64 columns x 4 lanes was 32 deep on 4-8 workgroups: 11 us); chunks in fixed order per lane, lanes folded in fixed
 // order through LDS
-__device__ __forceinline__ void colsum_fold_body(int N, int nchunk, const float* __restrict__ ws, float* __restrict__ out, int wg) {
+__device__ __forceinline__ void colsum_fold_body(int N, int nchunk, const float* __restrict__ ws, float* __restrict__ out, int wg,
+                                                 const int accumulate = 0) {
   __shared__ float fold[16][17];
   const int tid = threadIdx.x, cl = tid >> 4, c16 = tid & 15, col = wg * 16 + c16;
   float f = 0.f;
@@ -409,12 +410,12 @@ __device__ __forceinline__ void colsum_fold_body(int N, int nchunk, const float*
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += fold[r][c16];
-    out[col] = s;
+    out[col] = accumulate ? out[col] + s : s;
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_fold_kernel(int N, int nchunk, const float* __restrict__ ws, float* __restrict__ out) {
-  colsum_fold_body(N, nchunk, ws, out, blockIdx.x);
+__global__ __launch_bounds__(256) void colsum_fold_kernel(int N, int nchunk, const float* __restrict__ ws, float* __restrict__ out, int accumulate) {
+  colsum_fold_body(N, nchunk, ws, out, blockIdx.x, accumulate);
 }
 
 constexpr int CFOLD_MAX = 32;
@@ -1079,7 +1080,7 @@ extern "C" int sw_colsum_partial_multi(int dtype, int n, const sw_colsum_part_de
 extern "C" int sw_colsum_fold(int N, int n_partial_rows, const float* workspace, float* out, hipStream_t stream) {
   SW_ENTER();
   if (N <= 0 || n_partial_rows < 1) return -5;
-  hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, N, n_partial_rows, workspace, out);
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, N, n_partial_rows, workspace, out, 0);
   SW_CHECK_LAUNCH();
   return 0;
 }
@@ -1105,6 +1106,11 @@ extern "C" int sw_colsum_fold_multi(int n, const sw_colsum_fold_desc* folds, hip
 }
 
 extern "C" int sw_colsum(int dtype, int M, int N, const void* X, long ld, float* out, float* workspace, hipStream_t stream) {
+  return sw_colsum_acc(dtype, M, N, X, ld, out, workspace, 0, stream);
+}
+
+extern "C" int sw_colsum_acc(int dtype, int M, int N, const void* X, long ld, float* out, float* workspace, int accumulate,
+                             hipStream_t stream) {
   SW_ENTER();
   if (N <= 0) return 0;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
@@ -1113,10 +1119,15 @@ extern "C" int sw_colsum(int dtype, int M, int N, const void* X, long ld, float*
   if (ws_form) {
     const int rc = sw_colsum_partial(dtype, M, N, X, ld, workspace, stream);
     if (rc) return rc;
-    return sw_colsum_fold(N, (int)(sw_colsum_workspace_floats(dtype, M, N) / N), workspace, out, stream);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, N, (int)(sw_colsum_workspace_floats(dtype, M, N) / N),
+                       workspace, out, accumulate);
+    SW_CHECK_LAUNCH();
+    return 0;
   }
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+  }
   if (M <= 0) return 0;
   const int slabs = (N + 63) / 64;
   int chunks = (2048 + slabs - 1) / slabs;                 // aim at ~2048 workgroups (256 CUs x 8)

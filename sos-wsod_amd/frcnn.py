@@ -135,6 +135,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.relu, ctx.out_f, ctx.splits = relu, out_f, tuple(splits)
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.wkey = id(params[0]) if params else None
+        ctx.bkey = id(params[len(splits)]) if len(params) > len(splits) else None
         return y
 
     @staticmethod
@@ -177,14 +178,10 @@ class _LinearFn(torch.autograd.Function):
                     dws[i] = dwp[r0:r0 + n].view(ctx.shapes[i])
                 r0 += n
         if need_b:
-            dbp = torch.empty(ld, device=g.device, dtype=torch.float32)
-            if P > 0:
-                ops.colsum(gs, P, ld, dbp)
-            else:
-                dbp.zero_()
+            dbp = _bias_grad(gs, ld, ctx.bkey)                          # (packed biases: one buffer, registered under the first one)
             r0 = 0
             for i, n in enumerate(ctx.splits):
-                if i < len(dbs) and need[8 + nw + i]:
+                if i < len(dbs) and need[8 + nw + i] and dbp is not None:
                     dbs[i] = dbp[r0:r0 + n]
                 r0 += n
         dres = (gs if ld == out_f else gs[:, :out_f].contiguous()) if need[7] else None       # d(residual) = the masked output gradient
@@ -204,7 +201,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         out = torch.empty(n, H, W, cout, device=x.device, dtype=cd)
         ops.conv3x3(x, staged, out, 1, ops.make_epilogue(bias=bias, relu=relu, out_dtype=cd))
         ctx.save_for_backward(x, staged_d, out if relu else None, scale)
-        ctx.relu, ctx.cout, ctx.wkey = relu, cout, id(w)
+        ctx.relu, ctx.cout, ctx.wkey, ctx.bkey = relu, cout, id(w), (None if b is None else id(b))
         return out
 
     @staticmethod
@@ -219,8 +216,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[6]:
             dw = _wgrad_3x3(x, dz, scale, ctx.wkey)
         if ctx.needs_input_grad[7]:
-            db = torch.empty(cout, device=g.device, dtype=torch.float32)
-            ops.colsum(dz.view(n * H * W, cout), n * H * W, cout, db)
+            db = _bias_grad(dz.view(n * H * W, cout), cout, ctx.bkey)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(n, H, W, cin, device=g.device, dtype=cd)
             ops.conv3x3(dz, wkd, dx, 1, ops.make_epilogue(out_dtype=cd))
@@ -271,6 +267,23 @@ def _wgrad_1x1(gs, x, scale, key=None):
     ops.gemm(gs, x, dw, ld, D, P, a_kstrided=True, b_kstrided=True, splitk=sk, ep=ep)
     ops.note_grad(key, dw)
     return dw
+
+
+def _bias_grad(gs2d, n, key=None):
+    """db (n,) f32 = column sums of the (masked) output gradient; ops.grad_scope as _wgrad_1x1 (key: the bias parameter)"""
+    P = gs2d.shape[0]
+    prev = ops.pending_grad(key, (n,))
+    if prev is not None:
+        if P > 0:
+            ops.colsum(gs2d, P, n, prev, accumulate=True)
+        return None
+    db = torch.empty(n, device=gs2d.device, dtype=torch.float32)
+    if P > 0:
+        ops.colsum(gs2d, P, n, db)
+    else:
+        db.zero_()
+    ops.note_grad(key, db)
+    return db.view(n)
 
 
 def _wgrad_3x3(x4, dz4, scale, key=None):

@@ -527,11 +527,12 @@ def oicr_refine_loss(logits, V, R, K, cls_col, box_col, boxes, lab_class, lab_we
                                   _stream()), "sw_oicr_refine_loss")
 
 
-def colsum(X, M, N, out, ld=None):
-    """out[n] = sum_m X[m, n] (f32), deterministic: partial rows per row chunk + an ordered fold (no zero fill, no atomics)"""
+def colsum(X, M, N, out, ld=None, accumulate=False):
+    """out[n] = sum_m X[m, n] (f32), deterministic: partial rows per row chunk + an ordered fold (no zero fill, no atomics);
+    accumulate: out[n] += the sum"""
     need = int(lib.sw_colsum_workspace_floats(dt(X), M, N))
     ws = torch.empty(max(need, 4), device=X.device, dtype=torch.float32)
-    check(lib.sw_colsum(dt(X), M, N, _p(X), X.stride(0) if ld is None else ld, _p(out), _p(ws), _stream()), "sw_colsum")
+    check(lib.sw_colsum_acc(dt(X), M, N, _p(X), X.stride(0) if ld is None else ld, _p(out), _p(ws), int(accumulate), _stream()), "sw_colsum")
     return out
 
 
