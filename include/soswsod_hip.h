@@ -54,7 +54,11 @@ typedef struct sw_epilogue {
   const uint64_t* drop_offset_dev;
   /* deterministic split-K (sw_gemm, f32 C, no other epilogue option): every K-split stores its partial tile into its own
    * slab of this workspace (sw_gemm_splitk_workspace_floats floats), a second kernel adds the slabs in fixed order into C
-   * (overwritten) — no atomics.  Also used, when given, for the tail peel of the large f32-output GEMMs (see sw_gemm). */
+   * (overwritten) — no atomics.  Also used, when given, for the tail peel of the large f32-output GEMMs (see sw_gemm).
+   * With OTHER epilogue options set (bias, residual, relu, relu_ref, out_dtype bf16; not the dropout / atomic / absmax ones) and
+   * effective splits > 1 the slabs stay plain f32 and the fold applies the epilogue in the GEMM's own order:
+   * x = fold_row_scale[m] * sum + bias[n] + residual[m][n]; ReLU; ReLU-mask; convert.  An f32 residual may be C itself (C += A B: a
+   * gradient added to one that exists).  One slab is legal when fold_row_scale meets a residual.  Requires N % 4 == 0, ldc % 4 == 0. */
   float* splitk_workspace;
   /* residual [M][ld_res] or NULL (dtype res_dtype): v = v + bias + residual before the ReLU — the shortcut add of a ResNet
    * bottleneck (detectron2/modeling/backbone/resnet.py:205-212 `out += shortcut; out = F.relu_(out)`) inside the 1x1 conv3 GEMM */
@@ -63,8 +67,8 @@ typedef struct sw_epilogue {
   int res_dtype;
   /* deterministic split-K only (splitk_workspace given, effective splits > 1): the ordered fold writes C[m][n] = fold_row_scale[m] *
    * sum of the slabs (DEVICE [M] or NULL) — the FrozenBN fold of a 1x1 convolution's weight gradient, dW = scale * dW_eff
-   * (detectron2/layers/batch_norm.py:52-58), without a pass of its own.  sw_gemm returns -5 when it is set and the launch does
-   * not end in that fold. */
+   * (detectron2/layers/batch_norm.py:52-58), without a pass of its own.  Without a fold (one split, plain f32 C) it runs as a
+   * row-scaling pass after the GEMM; sw_gemm returns -5 for any other combination that does not end in a fold. */
   const float* fold_row_scale;
 } sw_epilogue;
 
