@@ -390,11 +390,19 @@ constexpr int RPN_LOSS_BLOCKS = 256;
 // ---------------------------------------------------------------- every weight of a detector staged by ONE launch
 // entry kinds: 0 linear (rows, cols) f32 -> compute dtype rows of pitch cols; 1 conv3x3 OIHW -> [co][tap][ci]; 2 conv3x3 OIHW ->
 // [ci][8 - tap][co] (data-gradient layout); 3 f32 copy (bias pieces of packed heads).  With FrozenBN buffers the folded weight
-// w * scale[co] is staged (scale = bn_weight * rsqrt(bn_var + eps), layers/batch_norm.py:52-60; rsqrt = 1 / sqrt with both steps
-// correctly rounded, which is what the reference's CPU path computes) and scale / shift are written.
+// w * scale[co] is staged (scale = bn_weight * rsqrt(bn_var + eps), layers/batch_norm.py:52-60; rsqrt spelled 1 / sqrt with the
+// _rn intrinsics: within one ulp of the reference's CPU result, tests/test_gpu_stage3.py) and scale / shift are written.
 constexpr int STAGE_CHUNK = 4096;
+// block geometry per kind (sw_stage_blocks must agree):
+//   0 / 3: STAGE_CHUNK consecutive elements, 4 per thread and step (16-byte loads when a row is a multiple of 4 elements);
+//   1: one output channel x a range of <= STAGE_CI1 input channels: the [ci][tap] run is read as it lies (contiguous), turned in LDS,
+//      and written as 9 runs over ci (the first version gathered 4 bytes every 36: 9x the read transactions);
+//   2: 64 output channels x 7 input channels: 63-float runs read per output channel, written as (ci, tap) rows of 64 channels.
+constexpr int STAGE_CI1 = 448, STAGE_CO2 = 64, STAGE_CI2 = 7;
+__host__ __device__ inline int stage_ci_chunk(int cols) { return cols <= STAGE_CI1 ? cols : 256; }
 template <typename T>
 __global__ __launch_bounds__(256) void stage_weights_multi_kernel(int n, const sw_stage_desc* __restrict__ descs, float eps) {
+  __shared__ float s_t[STAGE_CO2 * (STAGE_CI2 * 9 + 2) > STAGE_CI1 * 9 ? STAGE_CO2 * (STAGE_CI2 * 9 + 2) : STAGE_CI1 * 9];
   int lo = 0, hi = n - 1;                                     // the last entry whose block_start <= blockIdx.x
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -410,25 +418,65 @@ __global__ __launch_bounds__(256) void stage_weights_multi_kernel(int n, const s
       d.scale[r] = sc;
       if (d.shift) d.shift[r] = __fsub_rn(d.bn_bias[r], __fmul_rn(d.bn_mean[r], sc));
     }
-  const long per = d.kind == 0 || d.kind == 3 ? (long)cols : 9L * cols;     // source elements per output channel
-  const long total = (long)rows * per;
-  const long base = (long)blk * STAGE_CHUNK;
-  for (long i = base + threadIdx.x; i < base + STAGE_CHUNK && i < total; i += 256) {
-    long src; int co;
-    if (d.kind == 0 || d.kind == 3) { src = i; co = (int)(i / cols); }
-    else if (d.kind == 1) {
-      const int ci = (int)(i % cols); const long t = i / cols;
-      const int tap = (int)(t % 9); co = (int)(t / 9);
-      src = ((long)co * cols + ci) * 9 + tap;
+  auto scale_of = [&](int co) { return __fmul_rn(d.bn_weight[co], __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(d.bn_var[co], eps)))); };
+  if (d.kind == 0 || d.kind == 3) {
+    const long total = (long)rows * cols;
+    const long base = (long)blk * STAGE_CHUNK;
+    const bool vec = (cols % 4) == 0 && ((((uintptr_t)d.w) & 15) == 0) && ((((uintptr_t)d.dst) & 15) == 0);
+    if (vec) {
+      for (long i = base + threadIdx.x * 4; i < base + STAGE_CHUNK && i < total; i += 1024) {
+        f32x4 v = *(const f32x4*)(d.w + i);
+        if (bn) { const float sc = scale_of((int)(i / cols));
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = __fmul_rn(v[t], sc); }
+        if (d.kind == 3) *(f32x4*)((float*)d.dst + i) = v;
+        else if (sizeof(T) == 4) *(f32x4*)((float*)d.dst + i) = v;
+        else {
+          unsigned int* o = (unsigned int*)((unsigned short*)d.dst + i);
+          o[0] = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+          o[1] = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        }
+      }
     } else {
-      co = (int)(i % rows); const long t = i / rows;
-      const int tapf = (int)(t % 9); const int ci = (int)(t / 9);
-      src = ((long)co * cols + ci) * 9 + (8 - tapf);
+      for (long i = base + threadIdx.x; i < base + STAGE_CHUNK && i < total; i += 256) {
+        float v = d.w[i];
+        if (bn) v = __fmul_rn(v, scale_of((int)(i / cols)));
+        if (d.kind == 3) ((float*)d.dst)[i] = v;
+        else Elem<T>::store((T*)d.dst + i, v);
+      }
     }
-    float v = d.w[src];
-    if (bn) v = __fmul_rn(v, __fmul_rn(d.bn_weight[co], __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(d.bn_var[co], eps)))));
-    if (d.kind == 3) ((float*)d.dst)[i] = v;
-    else Elem<T>::store((T*)d.dst + i, v);
+  } else if (d.kind == 1) {                                   // OIHW [co][ci][tap] -> [co][tap][ci]
+    const int cic = stage_ci_chunk(cols), nch = (cols + cic - 1) / cic;
+    const int co = blk / nch, ci0 = (blk - co * nch) * cic;
+    const int CI = min(cic, cols - ci0);
+    const float* src = d.w + ((long)co * cols + ci0) * 9;
+    for (int e = threadIdx.x; e < CI * 9; e += 256) s_t[e] = src[e];
+    __syncthreads();
+    const float sc = bn ? scale_of(co) : 1.f;
+    T* dst = (T*)d.dst + (long)co * 9 * cols + ci0;
+    for (int e = threadIdx.x; e < CI * 9; e += 256) {
+      const int tap = e / CI, ci = e - tap * CI;
+      const float v = s_t[ci * 9 + tap];
+      Elem<T>::store(dst + (long)tap * cols + ci, bn ? __fmul_rn(v, sc) : v);
+    }
+  } else {                                                    // OIHW -> [ci][8 - tap][co]
+    constexpr int PITCH = STAGE_CI2 * 9 + 2;                  // 65: the write phase walks co at a fixed (ci, tap)
+    const int nci = (cols + STAGE_CI2 - 1) / STAGE_CI2;
+    const int cob = blk / nci, ci0 = (blk - cob * nci) * STAGE_CI2, co0 = cob * STAGE_CO2;
+    const int CI = min(STAGE_CI2, cols - ci0), CO = min(STAGE_CO2, rows - co0);
+    const int run = CI * 9;
+    for (int e = threadIdx.x; e < CO * run; e += 256) {
+      const int col = e / run, k = e - col * run;
+      s_t[col * PITCH + k] = d.w[((long)(co0 + col) * cols + ci0) * 9 + k];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < run * CO; e += 256) {
+      const int col = e % CO, k = e / CO;                     // k = ci_l * 9 + tapf
+      const int cil = k / 9, tapf = k - cil * 9;
+      float v = s_t[col * PITCH + cil * 9 + (8 - tapf)];
+      if (bn) v = __fmul_rn(v, scale_of(co0 + col));
+      Elem<T>::store((T*)d.dst + ((long)(ci0 + cil) * 9 + tapf) * rows + co0 + col, v);
+    }
   }
 }
 
@@ -609,7 +657,9 @@ extern "C" int sw_rpn_loss(long n, long n_anchors, const float* logits, const fl
 }
 
 extern "C" int sw_stage_blocks(int kind, int rows, int cols) {
-  const long total = (long)rows * (kind == 0 || kind == 3 ? (long)cols : 9L * cols);
+  if (kind == 1) { const int cic = stage_ci_chunk(cols); return rows * ((cols + cic - 1) / cic); }
+  if (kind == 2) return ((rows + STAGE_CO2 - 1) / STAGE_CO2) * ((cols + STAGE_CI2 - 1) / STAGE_CI2);
+  const long total = (long)rows * cols;
   return (int)((total + STAGE_CHUNK - 1) / STAGE_CHUNK);
 }
 

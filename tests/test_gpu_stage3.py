@@ -626,3 +626,51 @@ def test_small_map_weight_gradient_kernel(ops):
         F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
         want = w.grad * scale.view(-1, 1, 1, 1)
         assert float((dw - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weight_staging_kernel_layouts_and_frozenbn_fold(ops, dtype):
+    """sw_stage_weights_multi (ops.StagePlan): kind 0 (rows as they lie), 1 (OIHW -> [co][tap][ci]), 2 (OIHW -> [ci][8 - tap][co]),
+    3 (f32 copy), with and without the FrozenBN fold w * scale[co]; channel counts that do and do not fill the kernel's blocks
+    (448 < 512 input channels: two ranges per output channel; 72 output channels: a partial 64-channel tile; cols % 4 != 0).
+    Layout and fold product: every staged element bit for bit against `w * scale` with the scale the kernel wrote; that scale /
+    shift against layers/batch_norm.py:52-60 evaluated on the CPU (scale = bn_w * (1 / sqrt(var + eps))) within 3e-7 relative
+    (the device's sqrt / divide differ from the host's in the last bit for a few channels)."""
+    torch.manual_seed(11)
+    dev = "cuda"
+    entries, want = [], []
+
+    def bn_of(c):
+        return (torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev), torch.randn(c, device=dev), torch.rand(c, device=dev) + 0.1)
+    for kind, co, ci, with_bn in [(0, 72, 130, True), (0, 256, 64, False), (0, 40, 12544, True), (1, 72, 128, True), (1, 64, 512, False),
+                                  (1, 24, 40, True), (2, 72, 128, True), (2, 512, 20, False), (2, 130, 7, True), (3, 1, 104, False)]:
+        w = torch.randn(co, ci, 3, 3, device=dev) if kind in (1, 2) else torch.randn(co, ci, device=dev)
+        dst = torch.full((w.numel(),), float("nan"), device=dev, dtype=torch.float32 if kind == 3 else dtype)
+        e = dict(kind=kind, w=w, dst=dst)
+        if with_bn:
+            e.update(bn=bn_of(co), scale=torch.empty(co, device=dev), shift=torch.empty(co, device=dev))
+        entries.append(e)
+    ops.StagePlan(entries, dtype).run()
+    torch.cuda.synchronize()
+    bad = []
+    for e in entries:
+        w, kind = e["w"], e["kind"]
+        weff = w
+        if "bn" in e:
+            bw, bb, bm, bv = (t.cpu() for t in e["bn"])
+            sc = bw * (1.0 / torch.sqrt(bv + 1e-5))
+            sh = bb - bm * sc
+            ok_f = bool(torch.allclose(e["scale"].cpu(), sc, rtol=3e-7, atol=0)) and bool(torch.allclose(e["shift"].cpu(), sh, rtol=3e-6, atol=1e-6))
+            weff = w * e["scale"].view(-1, *([1] * (w.dim() - 1)))
+        else:
+            ok_f = True
+        if kind == 1:
+            ref = weff.permute(0, 2, 3, 1).reshape(-1)                       # [co][tap][ci]
+        elif kind == 2:
+            ref = weff.flip(2, 3).permute(1, 2, 3, 0).reshape(-1)            # [ci][8 - tap][co]
+        else:
+            ref = weff.reshape(-1)
+        ref = ref.to(e["dst"].dtype)
+        if not (bool(torch.equal(e["dst"], ref)) and ok_f):
+            bad.append((kind, tuple(w.shape), "bn" in e, int((e["dst"].float() != ref.float()).sum()), ok_f))
+    assert not bad, bad
