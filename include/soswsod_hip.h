@@ -115,6 +115,11 @@ int sw_conv3x3_wgrad_small_acc(int dtype, int nimg, int H, int W, int Cin, int C
 int sw_conv3x3_wgrad_slabs(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* x,
                            const void* dy, float* workspace, int splitk, sw_stream_t stream);
 int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, sw_stream_t stream);
+/* sw_conv3x3_wgrad_fold with dW[co] multiplied by cout_scale[co] (DEVICE [Cout] or NULL) and, when accumulate != 0, added to
+ * dw_oihw: the ONE fold over the slabs of several (x, dy) pairs of the same weight written by sw_conv3x3_wgrad_grouped — the RPN
+ * head's convolution runs on 5 FPN levels in each of the student's two passes (rpn.py:118-133) */
+int sw_conv3x3_wgrad_fold_acc(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, const float* cout_scale,
+                              int accumulate, sw_stream_t stream);
 /* ALL weight gradients of a backward pass in ONE launch: problem i writes the slabs sw_conv3x3_wgrad_slabs(..., splitk =
  * nsplit) would write (sw_conv3x3_wgrad_workspace_floats(...) floats at `slabs`), computed on 256x256 tiles by one resident
  * workgroup per CU walking the (problem, K-split, tile) list — instead of one launch of 128x128 tiles per layer and view,

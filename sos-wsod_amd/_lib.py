@@ -136,6 +136,7 @@ SIGNATURES = {
     "sw_conv3x3_wgrad_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p]),
     "sw_conv3x3_wgrad_fold": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_conv3x3_wgrad_fold_acc": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sw_conv3x3_wgrad_fold_multi": (c_int, [c_int, ctypes.POINTER(WgradFold), c_void_p]),
     "sw_colsum_fold_multi": (c_int, [c_int, ctypes.POINTER(ColsumFold), c_void_p]),
     "sw_colsum_partial_multi": (c_int, [c_int, c_int, ctypes.POINTER(ColsumPart), c_void_p]),

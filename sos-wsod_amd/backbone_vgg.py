@@ -63,18 +63,18 @@ def _wgrad_splitk(cout, cin, npix):
 _WGRAD_PLAN_CACHE = {}
 
 
-def _wgrad_grouped_target(shapes, bk, n_cu=256):
+def _wgrad_grouped_target(shapes, bk, n_cu=256, candidates=(40, 48, 56, 64, 72, 80, 96, 112, 128, 160)):
     """K-tiles per work item of the grouped weight-gradient launch for this set of problems.  shapes: [(npix, cout, n_cols)].
     The launch deals the item list round-robin to n_cu resident workgroups, so its length is the busiest workgroup's sum of
     K-tiles: simulated here for a few targets (plus the extra slab traffic of more K-splits, priced at ~25 K-tile-times per
     extra slab of a 512 x 4608 gradient) and the cheapest kept.  Cached per shape set: the schedule of a training run's view
     sizes is computed once."""
-    key = (tuple(shapes), bk, n_cu)
+    key = (tuple(shapes), bk, n_cu, candidates)
     hit = _WGRAD_PLAN_CACHE.get(key)
     if hit is not None:
         return hit
     best = None
-    for T in (40, 48, 56, 64, 72, 80, 96, 112, 128, 160):
+    for T in candidates:
         load = [0.0] * n_cu
         t, slabs = 0, 0.0
         for npix, cout, ncols in shapes:

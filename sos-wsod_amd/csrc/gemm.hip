@@ -1373,6 +1373,11 @@ extern "C" int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* 
   SW_ENTER();
   return wgrad_fold_impl(Cin, Cout, nslab, workspace, dw_oihw, nullptr, stream);
 }
+extern "C" int sw_conv3x3_wgrad_fold_acc(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, const float* cout_scale,
+                                        int accumulate, hipStream_t stream) {
+  SW_ENTER();
+  return wgrad_fold_impl(Cin, Cout, nslab, workspace, dw_oihw, cout_scale, stream, accumulate);
+}
 static int wgrad_fold_impl(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, const float* cout_scale,
                            hipStream_t stream, int accumulate) {
   if (nslab < 1 || (Cin % 4)) return -5;

@@ -202,6 +202,8 @@ class _Conv3x3Fn(torch.autograd.Function):
         ops.conv3x3(x, staged, out, 1, ops.make_epilogue(bias=bias, relu=relu, out_dtype=cd))
         ctx.save_for_backward(x, staged_d, out if relu else None, scale)
         ctx.relu, ctx.cout, ctx.wkey, ctx.bkey = relu, cout, id(w), (None if b is None else id(b))
+        if ctx.needs_input_grad[6]:
+            ops.count_use(id(w))
         return out
 
     @staticmethod
@@ -286,15 +288,68 @@ def _bias_grad(gs2d, n, key=None):
     return db.view(n)
 
 
+_GROUP_TARGETS = (8, 12, 16, 24, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128, 160)      # K-tiles per work item tried for a grouped launch
+
+
+def _small_map(H, W):
+    """maps of a few pixels (p5 / p6 of small images: 4x4, 2x2) are below the gathering loader's tile geometry (sw_conv3x3_wgrad
+    returns -6): a direct kernel, one thread per (co, ci), takes them"""
+    return (64 // W) + 1 > 2 * H
+
+
+def _flush_wgrad_3x3(q):
+    """all queued (x, dy) pairs of one 3x3 weight: ONE grouped 256x256-tile launch (sw_conv3x3_wgrad_grouped: every pair's K-splits
+    as work items of one resident grid) + ONE fold over all slabs (x FrozenBN scale) into the buffer autograd already holds.
+    Measured (tools/stage3_grouped_wgrad_probe.py): the RPN head's 10 uses 641 -> 383 us, an FPN output convolution's two 330 -> 256
+    (p2) / 71 -> 46 (p4), res5 conv2 83 -> 48, res3 conv2 74 -> 52."""
+    from .backbone_vgg import _wgrad_grouped_splits, _wgrad_grouped_target
+    dw, scale, probs = q["buf"], q["scale"], q["probs"]
+    cout, cin = dw.shape[:2]
+    big = [(x, dz) for x, dz in probs if not _small_map(x.shape[1], x.shape[2])]
+    small = [(x, dz) for x, dz in probs if _small_map(x.shape[1], x.shape[2])]
+    wrote = False
+    if big:
+        bk = 64 if big[0][0].dtype == torch.bfloat16 else 32
+        shapes = [(x.shape[0] * x.shape[1] * x.shape[2], cout, 9 * cin) for x, _ in big]
+        target = _wgrad_grouped_target(shapes, bk, candidates=_GROUP_TARGETS)
+        splits = [_wgrad_grouped_splits(sh[0], bk, target) for sh in shapes]
+        nsl = [ops.conv3x3_wgrad_nslab(x, cout, sp) for (x, _), sp in zip(big, splits)]
+        ws = torch.empty(sum(nsl), cout * 9 * cin, device=dw.device, dtype=torch.float32)
+        off, items = 0, []
+        for (x, dz), sp, n in zip(big, splits, nsl):
+            items.append((x, dz, ws[off:], 1, sp))
+            off += n
+        ops.conv3x3_wgrad_grouped(items)
+        ops.conv3x3_wgrad_fold(ws, sum(nsl), dw, cout_scale=scale)
+        wrote = True
+    for x, dz in small:
+        ops.conv3x3_wgrad_small(x, dz, dw, cout_scale=scale, accumulate=wrote)
+        wrote = True
+    q["probs"] = []
+
+
 def _wgrad_3x3(x4, dz4, scale, key=None):
-    """dW (cout, cin, 3, 3) f32 of a 3x3 convolution (sw_conv3x3_wgrad: slabs + fold, x FrozenBN scale); grad_scope as _wgrad_1x1"""
+    """dW (cout, cin, 3, 3) f32 of a 3x3 convolution (sw_conv3x3_wgrad: slabs + fold, x FrozenBN scale).  Inside ops.grad_scope: a
+    weight whose uses were counted in the forward passes (ops.count_use) queues its (x, dy) pairs and the LAST use computes all of
+    them at once (_flush_wgrad_3x3) into the buffer the first use handed to autograd; an uncounted weight adds to the first use's
+    buffer in the fold, as _wgrad_1x1 does."""
     n, H, W, cin = x4.shape
     cout = dz4.shape[3]
+    sc = ops.GRAD_SCOPE
+    if sc is not None and key is not None and sc.uses.get(key, 0) > 1:
+        q = sc.queued.get(key)
+        first = q is None
+        if first:
+            q = sc.queued[key] = dict(buf=torch.empty(cout, cin, 3, 3, device=x4.device, dtype=torch.float32), scale=scale, probs=[],
+                                      left=sc.uses[key])
+        q["probs"].append((x4, dz4))
+        q["left"] -= 1
+        if q["left"] == 0:
+            _flush_wgrad_3x3(q)
+        return q["buf"].view(cout, cin, 3, 3) if first else None
     prev = ops.pending_grad(key, (cout, cin, 3, 3))
     dw = prev if prev is not None else torch.empty(cout, cin, 3, 3, device=x4.device, dtype=torch.float32)
-    if (64 // W) + 1 > 2 * H:
-        # maps of a few pixels (p5 / p6 of small images: 4x4, 2x2) are below the gathering loader's tile geometry
-        # (sw_conv3x3_wgrad returns -6): a direct kernel, one thread per (co, ci)
+    if _small_map(H, W):
         ops.conv3x3_wgrad_small(x4, dz4, dw, cout_scale=scale, accumulate=prev is not None)
     else:
         tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
@@ -353,6 +408,8 @@ class _BottleneckFn(torch.autograd.Function):
                               s1.scale, s2.scale, s3.scale, None if sc is None else _staged_of(sc).scale)
         ctx.geom = (n, H, W, cin, mid, cout, c1.stride, full_shape)
         ctx.keys = tuple(id(w) for w in weights) + (None,) * (4 - len(weights))
+        if ctx.needs_input_grad[3]:
+            ops.count_use(id(weights[1]))                                # conv2: its weight gradient may be grouped with the other pass's
         return out.view(n, H, W, cout)
 
     @staticmethod

@@ -89,33 +89,51 @@ def param_key(p):
     return (p.data_ptr(), p._version, INVALIDATE_EPOCH, p.__dict__.get("_sw_epoch", 0))
 
 
-GRAD_SCOPE = None      # inside `with grad_scope():` — id(parameter) -> the gradient buffer a backward node has produced in THIS backward pass
+GRAD_SCOPE = None      # the active grad_scope (or None)
 
 
 class grad_scope:
-    """Wrap ONE `backward()` call whose graph uses parameters more than once (the Stage-3 student: two forward passes per iteration,
-    unbias/ubteacher/engine/trainer.py:527-538).  Autograd would hand every use's weight gradient to the parameter's accumulator and
-    add them with a torch kernel; inside the scope the first weight-gradient node of a parameter registers the buffer it returns
-    (`note_grad`) and every later node of the same parameter ADDS to that buffer inside its own fold / GEMM epilogue
-    (`pending_grad`) and returns no gradient.  The accumulator node runs after all of them (it waits for every incoming edge), on
-    the same stream, so it sees the sum.  Outside a scope both helpers are inert: plain autograd behaviour."""
+    """Wrap the forward passes AND the one `backward()` call of an iteration whose graph uses parameters more than once (the Stage-3
+    student: two forward passes per iteration, unbias/ubteacher/engine/trainer.py:527-538; the RPN head's convolution on five FPN
+    levels in each).  Autograd would hand every use's weight gradient to the parameter's accumulator and add them with a torch
+    kernel.  Inside the scope
+      * the first weight-gradient node of a parameter registers the buffer it returns (`note_grad`) and every later node of the same
+        parameter ADDS to that buffer inside its own fold / GEMM epilogue (`pending_grad`) and returns no gradient;
+      * a forward pass counts the uses of a 3x3 weight (`count_use`); its weight-gradient nodes then only QUEUE their (x, dy)
+        pair and the last of them runs all pairs as one grouped launch + one fold (frcnn._wgrad_3x3).
+    The accumulator node of a parameter runs after all of its incoming edges (every use), on the same stream, so it sees the
+    finished sum; the data-parallel reducer's hooks hang on that node and are therefore not affected.  A counted use whose
+    backward node never runs would leave a queued gradient unfinished: __exit__ raises in that case (opt out: do not open a
+    scope).  Outside a scope every helper is inert: plain autograd behaviour."""
 
     def __enter__(self):
         global GRAD_SCOPE
-        self._prev, GRAD_SCOPE = GRAD_SCOPE, {}
+        self._prev, GRAD_SCOPE = GRAD_SCOPE, self
+        self.bufs, self.uses, self.queued = {}, {}, {}
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, *exc):
         global GRAD_SCOPE
         GRAD_SCOPE = self._prev
+        left = [k for k, q in self.queued.items() if q["probs"]]
+        self.bufs, self.uses, self.queued = {}, {}, {}
+        if left and exc_type is None:
+            raise RuntimeError(f"grad_scope: {len(left)} queued weight gradient(s) were never finished — a use counted in the forward pass "
+                               "did not take part in backward(); run this graph without ops.grad_scope")
         return False
+
+
+def count_use(key):
+    """forward side: this pass will contribute one weight-gradient node for `key`"""
+    if GRAD_SCOPE is not None and key is not None:
+        GRAD_SCOPE.uses[key] = GRAD_SCOPE.uses.get(key, 0) + 1
 
 
 def pending_grad(key, shape):
     """the f32 buffer an earlier node of this backward pass registered for `key` (viewed as `shape`), or None"""
     if GRAD_SCOPE is None or key is None:
         return None
-    buf = GRAD_SCOPE.get(key)
+    buf = GRAD_SCOPE.bufs.get(key)
     if buf is None or buf.numel() != int(torch.Size(shape).numel()) or not buf.is_contiguous():
         return None
     return buf.view(shape)
@@ -125,7 +143,7 @@ def note_grad(key, buf):
     if GRAD_SCOPE is not None and key is not None:
         # an ALIAS (its own tensor object on the same storage): autograd's accumulator adopts a gradient without copying it only
         # when nobody else holds the tensor object it was handed (18 device-to-device copies per Stage-3 iteration otherwise)
-        GRAD_SCOPE[key] = buf.view(buf.shape)
+        GRAD_SCOPE.bufs[key] = buf.view(buf.shape)
 
 
 def grad_target(param, shape, dev):
@@ -280,10 +298,11 @@ def conv3x3_wgrad_grouped(problems):
     check(lib.sw_conv3x3_wgrad_grouped(dt(problems[0][0]), n, arr, _stream()), "sw_conv3x3_wgrad_grouped")
 
 
-def conv3x3_wgrad_fold(workspace, nslab, dw_oihw):
-    """dw_oihw (Cout, Cin, 3, 3) f32 = ordered sum of `nslab` consecutive [co][tap][ci] slabs"""
+def conv3x3_wgrad_fold(workspace, nslab, dw_oihw, cout_scale=None, accumulate=False):
+    """dw_oihw (Cout, Cin, 3, 3) f32 = (+=, accumulate) cout_scale[co] * ordered sum of `nslab` consecutive [co][tap][ci] slabs"""
     Cout, Cin = dw_oihw.shape[:2]
-    check(lib.sw_conv3x3_wgrad_fold(Cin, Cout, nslab, _p(workspace), _p(dw_oihw), _stream()), "sw_conv3x3_wgrad_fold")
+    check(lib.sw_conv3x3_wgrad_fold_acc(Cin, Cout, nslab, _p(workspace), _p(dw_oihw), _p(cout_scale), int(accumulate), _stream()),
+          "sw_conv3x3_wgrad_fold")
     return dw_oihw
 
 

@@ -203,6 +203,14 @@ class SemiSupStep:
         self.iter = 0
 
     def run_step(self, data):
+        if self.fuse_grad_sums:
+            # the student's two passes share every weight: inside the scope their gradients are summed in the kernels, and the uses of
+            # a 3x3 weight counted during the forward passes run as one grouped launch (ops.grad_scope)
+            with ops.grad_scope():
+                return self._step(data)
+        return self._step(data)
+
+    def _step(self, data):
         label_q, label_k, unlabel_q, unlabel_k = data
         if self.iter < self.burn_up_step:
             batch = list(label_q) + list(label_k) if self.burn_up_with_strong_aug else label_k
@@ -230,11 +238,7 @@ class SemiSupStep:
             loss_dict = weight_losses(record, self.unsup_loss_weight)
         losses = sum(loss_dict.values())
         self.optimizer.zero_grad()
-        if self.fuse_grad_sums:
-            with ops.grad_scope():           # the student's two passes share every weight: their gradients are summed in the kernels
-                losses.backward()
-        else:
-            losses.backward()
+        losses.backward()
         self.optimizer.step()
         self.iter += 1
         return record, loss_dict
