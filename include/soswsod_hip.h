@@ -131,6 +131,22 @@ typedef struct {
   float* slabs;
 } sw_wgrad_problem;
 int sw_conv3x3_wgrad_grouped(int dtype, int n_problems, const sw_wgrad_problem* problems, sw_stream_t stream);
+/* The same resident-grid launch for a list of PLAIN weight-gradient GEMMs, slabs[z][M][N] = sum over the z-th K range of
+ * A[k][m] * B[k][n] (A [K][lda], B [K][ldb], both K-strided; M, N, lda, ldb multiples of 16 bytes): the 1x1 convolutions of a ResNet
+ * bottleneck (reference: autograd's conv2d backward, detectron2/modeling/backbone/resnet.py:155-213) — several weights, each used
+ * by every forward pass of an iteration.  `problems` is a HOST array.  sw_gemm_kk_grouped_slabs(dtype, K, nsplit) = slabs a problem
+ * writes.  Fold with sw_splitk_fold_multi. */
+typedef struct sw_gemm_kk_problem {
+  const void* A; const void* B; float* slabs;
+  int32_t M, N, K, nsplit;
+  long lda, ldb;
+} sw_gemm_kk_problem;
+int sw_gemm_kk_grouped(int dtype, int n_problems, const sw_gemm_kk_problem* problems, sw_stream_t stream);
+long sw_gemm_kk_grouped_slabs(int dtype, int K, int nsplit);
+/* n ordered slab folds in ONE launch: C[m][n] = (accumulate ? C[m][n] : 0) + row_scale[m] * sum_z workspace[z][m][n] (row_scale
+ * DEVICE [M] or NULL; N % 4 == 0, ldc % 4 == 0, 16-byte aligned).  `folds` is a HOST array. */
+typedef struct sw_splitk_fold { int32_t M, N, nslab, accumulate; const float* workspace; float* C; long ldc; const float* row_scale; } sw_splitk_fold;
+int sw_splitk_fold_multi(int n, const sw_splitk_fold* folds, sw_stream_t stream);
 /* n folds (sw_conv3x3_wgrad_fold) in ONE launch; `folds` is a HOST array */
 typedef struct { int Cin, Cout, nslab; const float* workspace; float* dw_oihw; } sw_wgrad_fold;
 int sw_conv3x3_wgrad_fold_multi(int n, const sw_wgrad_fold* folds, sw_stream_t stream);

@@ -45,6 +45,18 @@ class WgradFold(ctypes.Structure):
                 ("dw_oihw", ctypes.c_void_p)]
 
 
+class GemmKKProblem(ctypes.Structure):
+    """sw_gemm_kk_problem"""
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("slabs", ctypes.c_void_p), ("M", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("K", ctypes.c_int32), ("nsplit", ctypes.c_int32), ("lda", ctypes.c_long), ("ldb", ctypes.c_long)]
+
+
+class SplitkFold(ctypes.Structure):
+    """sw_splitk_fold"""
+    _fields_ = [("M", ctypes.c_int32), ("N", ctypes.c_int32), ("nslab", ctypes.c_int32), ("accumulate", ctypes.c_int32),
+                ("workspace", ctypes.c_void_p), ("C", ctypes.c_void_p), ("ldc", ctypes.c_long), ("row_scale", ctypes.c_void_p)]
+
+
 class CopyDesc(ctypes.Structure):
     """sw_copy_desc"""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_long)]
@@ -138,6 +150,9 @@ SIGNATURES = {
     "sw_conv3x3_wgrad_fold": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_conv3x3_wgrad_fold_acc": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sw_conv3x3_wgrad_fold_multi": (c_int, [c_int, ctypes.POINTER(WgradFold), c_void_p]),
+    "sw_gemm_kk_grouped": (c_int, [c_int, c_int, ctypes.POINTER(GemmKKProblem), c_void_p]),
+    "sw_gemm_kk_grouped_slabs": (c_long, [c_int, c_int, c_int]),
+    "sw_splitk_fold_multi": (c_int, [c_int, ctypes.POINTER(SplitkFold), c_void_p]),
     "sw_colsum_fold_multi": (c_int, [c_int, ctypes.POINTER(ColsumFold), c_void_p]),
     "sw_colsum_partial_multi": (c_int, [c_int, c_int, ctypes.POINTER(ColsumPart), c_void_p]),
     "sw_conv3x3_wgrad_grouped": (c_int, [c_int, c_int, ctypes.POINTER(WgradProblem), c_void_p]),

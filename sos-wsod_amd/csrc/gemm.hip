@@ -793,6 +793,7 @@ struct GroupedProblem {
   const void* A; const void* B; float* C;        // dy [pixels][Cout], x NHWC, slabs [nsplit][Cout][9*Cin]
   int M, N, K, cH, cW, cC, cDil, k_per_split, nsplit, tiles_m, tiles_n;
   unsigned a_bytes, b_bytes;
+  int lda, ldb;                                  // plain problems (both operands K-strided: sw_gemm_kk_grouped); conv: lda = M, ldb unused
 };
 constexpr int GROUPED_MAX = 40;
 struct GroupedArgs {
@@ -801,7 +802,7 @@ struct GroupedArgs {
   GroupedProblem p[GROUPED_MAX];
 };
 
-template <typename T>
+template <typename T, int BMODE = OP_CONV_B>
 __global__ __launch_bounds__(1024, 1) void gemm2_grouped_kernel(GroupedArgs ga) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // resident workgroup b serves the virtual ids b, b + G, b + 2G, ... (G = gridDim.x, a multiple of 8: all on one XCD).  Inside a
@@ -822,11 +823,11 @@ __global__ __launch_bounds__(1024, 1) void gemm2_grouped_kernel(GroupedArgs ga) 
     const int ntile = P.tiles_m * P.tiles_n;
     const int zsplit = local / ntile, tl = local - zsplit * ntile;
     GemmArgs g = {};
-    g.A = P.A; g.B = P.B; g.C = P.C; g.M = P.M; g.N = P.N; g.K = P.K; g.lda = P.M; g.ldb = 0; g.ldc = P.N;
+    g.A = P.A; g.B = P.B; g.C = P.C; g.M = P.M; g.N = P.N; g.K = P.K; g.lda = P.lda; g.ldb = P.ldb; g.ldc = P.N;
     g.cH = P.cH; g.cW = P.cW; g.cC = P.cC; g.cDil = P.cDil; g.k_per_split = P.k_per_split;
     g.tiles_m = P.tiles_m; g.tiles_n = P.tiles_n; g.a_bytes = P.a_bytes; g.b_bytes = P.b_bytes;
     g.slab_stride = (long)P.M * P.N; g.drop_scale = 1.f; g.ref_scale = 1.f;
-    gemm2_tile<T, OP_KSTRIDED, OP_CONV_B, 256, 256, 2, 64, 64>(g, tl % P.tiles_m, tl / P.tiles_m, zsplit, smem);
+    gemm2_tile<T, OP_KSTRIDED, BMODE, 256, 256, 2, 64, 64>(g, tl % P.tiles_m, tl / P.tiles_m, zsplit, smem);
     __syncthreads();                                              // the next item restarts the LDS ring
   }
 }
@@ -1414,7 +1415,7 @@ extern "C" int sw_conv3x3_wgrad_grouped(int dtype, int n_problems, const sw_wgra
       if (check_align(q.x) || check_align(q.dy) || check_align(q.slabs)) return -4;
       if ((64 / q.W) + 1 > 2 * q.H) return -6;          // pixel-advance carry logic of the gather (tiny maps only)
       GroupedProblem& P = ga.p[i];
-      P.A = q.dy; P.B = q.x; P.C = q.slabs;
+      P.A = q.dy; P.B = q.x; P.C = q.slabs; P.lda = q.Cout; P.ldb = 0;
       P.M = q.Cout; P.N = 9 * q.Cin; P.K = q.nimg * q.H * q.W; P.cH = q.H; P.cW = q.W; P.cC = q.Cin; P.cDil = q.dilation;
       int ns = q.nsplit < 1 ? 1 : q.nsplit;
       long kps = (P.K + ns - 1) / ns;
@@ -1442,6 +1443,133 @@ extern "C" int sw_conv3x3_wgrad_grouped(int dtype, int n_problems, const sw_wgra
       if (e != hipSuccess) return (int)e;
       hipLaunchKernelGGL(gemm2_grouped_kernel<float>, dim3(G), dim3(1024), LDS, stream, ga);
     }
+    SW_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// The same resident-grid launch for PLAIN weight-gradient GEMMs (both operands K-strided: C = A^T B over K = pixels): the 1x1
+// convolutions of a ResNet bottleneck — three weights per block, each used by every forward pass of the iteration.
+extern "C" int sw_gemm_kk_grouped(int dtype, int n_problems, const sw_gemm_kk_problem* problems, hipStream_t stream) {
+  SW_ENTER();
+  if (dtype != SW_BF16 && dtype != SW_F32) return -1;
+  if (n_problems <= 0) return 0;
+  const int epc = dtype == SW_BF16 ? 8 : 4, bk = dtype == SW_BF16 ? 64 : 32;
+  const long es = dtype == SW_BF16 ? 2 : 4;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
+    else ncu = 256;
+  }
+  constexpr int LDS = 4 * Geom2<unsigned short, OP_KSTRIDED, 256>::BYTES;
+  static_assert(LDS == 4 * Geom2<float, OP_KSTRIDED, 256>::BYTES, "one LDS size for both types");
+  for (int base = 0; base < n_problems; base += GROUPED_MAX) {
+    GroupedArgs ga = {};
+    ga.n_problems = n_problems - base < GROUPED_MAX ? n_problems - base : GROUPED_MAX;
+    int items = 0;
+    for (int i = 0; i < ga.n_problems; ++i) {
+      const sw_gemm_kk_problem& q = problems[base + i];
+      if (q.M <= 0 || q.N <= 0 || q.K <= 0) return -5;
+      if ((q.M % epc) || (q.N % epc) || (q.lda % epc) || (q.ldb % epc) || q.lda < q.M || q.ldb < q.N) return -5;
+      if (check_align(q.A) || check_align(q.B) || check_align(q.slabs)) return -4;
+      GroupedProblem& P = ga.p[i];
+      P.A = q.A; P.B = q.B; P.C = q.slabs; P.lda = (int)q.lda; P.ldb = (int)q.ldb;
+      P.M = q.M; P.N = q.N; P.K = q.K;
+      int ns = q.nsplit < 1 ? 1 : q.nsplit;
+      long kps = (P.K + ns - 1) / ns;
+      kps = ((kps + bk - 1) / bk) * bk;
+      P.k_per_split = (int)kps;
+      P.nsplit = (int)((P.K + kps - 1) / kps);
+      P.tiles_m = (P.M + 255) / 256; P.tiles_n = (P.N + 255) / 256;
+      const long ab = (long)P.K * q.lda * es, bb = (long)P.K * q.ldb * es;
+      if (ab >= 0xFFFFFF00L || bb >= 0xFFFFFF00L) return -6;
+      P.a_bytes = (unsigned)ab; P.b_bytes = (unsigned)bb;
+      ga.first_item[i] = items;
+      items += P.nsplit * P.tiles_m * P.tiles_n;
+    }
+    ga.first_item[ga.n_problems] = items;
+    ga.n_items = items;
+    int G = ncu - (ncu % 8);
+    if (G < 8) G = 8;
+    hipError_t e;
+    if (dtype == SW_BF16) {
+      e = hipFuncSetAttribute((const void*)gemm2_grouped_kernel<unsigned short, OP_KSTRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL((gemm2_grouped_kernel<unsigned short, OP_KSTRIDED>), dim3(G), dim3(1024), LDS, stream, ga);
+    } else {
+      e = hipFuncSetAttribute((const void*)gemm2_grouped_kernel<float, OP_KSTRIDED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL((gemm2_grouped_kernel<float, OP_KSTRIDED>), dim3(G), dim3(1024), LDS, stream, ga);
+    }
+    SW_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" long sw_gemm_kk_grouped_slabs(int dtype, int K, int nsplit) {        // slabs problem (K, nsplit) really writes
+  const int bk = dtype == SW_BF16 ? 64 : 32;
+  int ns = nsplit < 1 ? 1 : nsplit;
+  long kps = ((long)K + ns - 1) / ns;
+  kps = ((kps + bk - 1) / bk) * bk;
+  return K <= 0 ? 0 : ((long)K + kps - 1) / kps;
+}
+
+// n ordered folds (splitk_reduce_kernel: C = [C +] row_scale * sum of slabs) in ONE launch; 16-byte pieces only
+namespace {
+constexpr int SFOLD_MAX = 24;
+struct SplitkFoldMulti {
+  int n;
+  int first_wg[SFOLD_MAX + 1];
+  int M[SFOLD_MAX], N[SFOLD_MAX], nslab[SFOLD_MAX], acc[SFOLD_MAX];
+  const float* ws[SFOLD_MAX]; float* C[SFOLD_MAX]; const float* row_scale[SFOLD_MAX];
+  long ldc[SFOLD_MAX];
+};
+__global__ __launch_bounds__(256) void splitk_fold_multi_kernel(SplitkFoldMulti f) {
+  int i = 0;
+  while (i + 1 < f.n && (int)blockIdx.x >= f.first_wg[i + 1]) ++i;
+  const int blk = blockIdx.x - f.first_wg[i], nblk = f.first_wg[i + 1] - f.first_wg[i];
+  const int M = f.M[i], N = f.N[i], nslab = f.nslab[i];
+  const long nv = ((long)M * N) >> 2;
+  const int nq = N >> 2;
+  const float* rs = f.row_scale[i];
+  for (long q = blk * 256L + threadIdx.x; q < nv; q += (long)nblk * 256) {
+    const f32x4* src = (const f32x4*)f.ws[i] + q;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    int z = 0;
+    for (; z + 4 <= nslab; z += 4) {
+      const f32x4 v0 = src[(long)z * nv], v1 = src[(long)(z + 1) * nv], v2 = src[(long)(z + 2) * nv], v3 = src[(long)(z + 3) * nv];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; z < nslab; ++z) a0 += src[(long)z * nv];
+    const long m = q / nq; const int n4 = (int)(q - m * nq);
+    f32x4 r = (a0 + a1) + (a2 + a3);
+    if (rs) { const float sc = rs[m]; r[0] = __fmul_rn(r[0], sc); r[1] = __fmul_rn(r[1], sc); r[2] = __fmul_rn(r[2], sc); r[3] = __fmul_rn(r[3], sc); }
+    f32x4* dst = (f32x4*)(f.C[i] + m * f.ldc[i] + n4 * 4);
+    if (f.acc[i]) r += *dst;
+    *dst = r;
+  }
+}
+}  // namespace
+
+extern "C" int sw_splitk_fold_multi(int n, const sw_splitk_fold* folds, hipStream_t stream) {
+  SW_ENTER();
+  for (int base = 0; base < n; base += SFOLD_MAX) {
+    SplitkFoldMulti f = {};
+    f.n = n - base < SFOLD_MAX ? n - base : SFOLD_MAX;
+    int wgs = 0;
+    for (int i = 0; i < f.n; ++i) {
+      const sw_splitk_fold& q = folds[base + i];
+      if (q.M <= 0 || q.N <= 0 || q.nslab < 1 || (q.N % 4) || (q.ldc % 4) || (((uintptr_t)q.C) & 15) || (((uintptr_t)q.workspace) & 15)) return -5;
+      f.M[i] = q.M; f.N[i] = q.N; f.nslab[i] = q.nslab; f.acc[i] = q.accumulate; f.ws[i] = q.workspace; f.C[i] = q.C;
+      f.row_scale[i] = q.row_scale; f.ldc[i] = q.ldc;
+      long b = (((long)q.M * q.N >> 2) + 255) / 256;
+      b = b < 1 ? 1 : (b > 1024 ? 1024 : b);
+      f.first_wg[i] = wgs;
+      wgs += (int)b;
+    }
+    f.first_wg[f.n] = wgs;
+    hipLaunchKernelGGL(splitk_fold_multi_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, f);
     SW_CHECK_LAUNCH();
   }
   return 0;

@@ -288,6 +288,33 @@ def _bias_grad(gs2d, n, key=None):
     return db.view(n)
 
 
+_GROUP_TARGETS_1X1 = (4, 6, 8, 12, 16, 24, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128, 160)
+
+
+def _flush_wgrad_1x1(q):
+    """the queued 1x1 weight-gradient problems of one bottleneck block — per use (dh1, x), (gs, h2)[, (gs, x)] — as ONE
+    sw_gemm_kk_grouped launch and ONE sw_splitk_fold_multi (x FrozenBN scale) into the buffers autograd already holds"""
+    from .backbone_vgg import _wgrad_grouped_splits, _wgrad_grouped_target
+    uses, bufs, scales = q["probs"], q["bufs"], q["scales"]
+    dtype = uses[0][0][0].dtype
+    bk = 64 if dtype == torch.bfloat16 else 32
+    shapes = [(a.shape[0], a.shape[1], b.shape[1]) for use in uses for a, b in use]
+    target = _wgrad_grouped_target(shapes, bk, candidates=_GROUP_TARGETS_1X1)
+    probs, folds = [], []
+    for w, (buf, scale) in enumerate(zip(bufs, scales)):
+        ns = [_wgrad_grouped_splits(use[w][0].shape[0], bk, target) for use in uses]
+        nsl = [ops.gemm_kk_nslab(dtype, use[w][0].shape[0], s_) for use, s_ in zip(uses, ns)]
+        ws = torch.empty(sum(nsl), buf.numel(), device=buf.device, dtype=torch.float32)
+        off = 0
+        for use, s_, k in zip(uses, ns, nsl):
+            probs.append((use[w][0], use[w][1], ws[off:], s_))
+            off += k
+        folds.append((ws, sum(nsl), buf, scale, False))
+    ops.gemm_kk_grouped(probs)
+    ops.splitk_fold_multi(folds)
+    q["probs"] = []
+
+
 _GROUP_TARGETS = (8, 12, 16, 24, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128, 160)      # K-tiles per work item tried for a grouped launch
 
 
@@ -410,6 +437,8 @@ class _BottleneckFn(torch.autograd.Function):
         ctx.keys = tuple(id(w) for w in weights) + (None,) * (4 - len(weights))
         if ctx.needs_input_grad[3]:
             ops.count_use(id(weights[1]))                                # conv2: its weight gradient may be grouped with the other pass's
+        if all(ctx.needs_input_grad[2:]):
+            ops.count_use(("1x1", id(weights[0])))                      # the block's 1x1 weights: one grouped launch for all passes
         return out.view(n, H, W, cout)
 
     @staticmethod
@@ -427,22 +456,41 @@ class _BottleneckFn(torch.autograd.Function):
             ops.gemm(a, w, d, P, D, K, b_kstrided=True, ep=ops.make_epilogue(out_dtype=cd, **ep), splitk=_few_tile_splits(P, D, K))
             return d
         keys = ctx.keys
-        dw3 = _view4(_wgrad_1x1(gs, h2, sc3, keys[2]), cout, mid) if need[4] else None
         dh2 = dgrad(gs, w3, mid, relu_ref=h2)                         # masked by conv2's ReLU
         dw2 = _wgrad_3x3(h1.view(n, H, W, mid), dh2.view(n, H, W, mid), sc2, keys[1]) if need[3] else None
         dh1 = torch.empty(n, H, W, mid, device=g.device, dtype=cd)
         ops.conv3x3(dh2.view(n, H, W, mid), w2d, dh1, 1, ops.make_epilogue(out_dtype=cd, relu_ref=h1))        # masked by conv1's ReLU
         dh1 = dh1.view(P, mid)
-        dw1 = _view4(_wgrad_1x1(dh1, x2, sc1, keys[0]), mid, cin) if need[2] else None
-        dwsc = None
-        if wsc is not None and len(need) > 5 and need[5]:
-            dwsc = _view4(_wgrad_1x1(gs, x2, scs, keys[3]), cout, cin)
         dx = None
         if need[0]:
             side = gs if wsc is None else dgrad(gs, wsc, cin)         # the shortcut branch's gradient of the (subsampled) block input
             dx = dgrad(dh1, w1, cin, residual=side).view(n, H, W, cin)
             if stride == 2:
                 dx = ops.scatter2x(dx, torch.empty(full_shape, device=g.device, dtype=cd))
+        # ---- the 1x1 weight gradients: conv1 (dh1^T x), conv3 (gs^T h2), shortcut (gs^T x)
+        scope = ops.GRAD_SCOPE
+        bkey = ("1x1", keys[0])
+        dw1 = dw3 = dwsc = None
+        if scope is not None and all(need[2:]) and scope.uses.get(bkey, 0) > 1:
+            # every pass's three problems are queued; the last use runs all of them as ONE grouped launch + ONE multi-fold
+            q = scope.queued.get(bkey)
+            first = q is None
+            if first:
+                shp = [(mid, cin), (cout, mid)] + ([(cout, cin)] if wsc is not None else [])
+                q = scope.queued[bkey] = dict(bufs=[torch.empty(a, b, device=g.device, dtype=torch.float32) for a, b in shp],
+                                              scales=[sc1, sc3] + ([scs] if wsc is not None else []), probs=[], left=scope.uses[bkey])
+            q["probs"].append([(dh1, x2), (gs, h2)] + ([(gs, x2)] if wsc is not None else []))
+            q["left"] -= 1
+            if q["left"] == 0:
+                _flush_wgrad_1x1(q)
+            if first:
+                dw1, dw3 = q["bufs"][0].view(mid, cin, 1, 1), q["bufs"][1].view(cout, mid, 1, 1)
+                dwsc = q["bufs"][2].view(cout, cin, 1, 1) if wsc is not None else None
+        else:
+            dw3 = _view4(_wgrad_1x1(gs, h2, sc3, keys[2]), cout, mid) if need[4] else None
+            dw1 = _view4(_wgrad_1x1(dh1, x2, sc1, keys[0]), mid, cin) if need[2] else None
+            if wsc is not None and len(need) > 5 and need[5]:
+                dwsc = _view4(_wgrad_1x1(gs, x2, scs, keys[3]), cout, cin)
         return (dx, None, dw1, dw2, dw3) + ((dwsc,) if wsc is not None else ())
 
 

@@ -319,6 +319,44 @@ def conv3x3_wgrad_fold_multi(folds):
     check(lib.sw_conv3x3_wgrad_fold_multi(n, arr, _stream()), "sw_conv3x3_wgrad_fold_multi")
 
 
+def gemm_kk_nslab(dtype, K, nsplit):
+    """slabs a problem of gemm_kk_grouped with this K and split count writes"""
+    return int(lib.sw_gemm_kk_grouped_slabs(dt(dtype), int(K), int(nsplit)))
+
+
+def gemm_kk_grouped(problems):
+    """problems: list of (A (K, M) rows of pitch lda, B (K, N) rows of pitch ldb, slabs f32, nsplit): slabs[z] = A_z^T B_z for all of them
+    in ONE launch (sw_gemm_kk_grouped: resident 256x256-tile grid over every problem's K-splits)"""
+    from ._lib import GemmKKProblem
+    n = len(problems)
+    if n == 0:
+        return
+    arr = (GemmKKProblem * n)()
+    for i, (A, B, slabs, nsplit) in enumerate(problems):
+        _need_gpu(A, B, slabs)
+        q = arr[i]
+        q.A, q.B, q.slabs = A.data_ptr(), B.data_ptr(), slabs.data_ptr()
+        q.K, q.M, q.N, q.nsplit = A.shape[0], A.shape[1], B.shape[1], int(nsplit)
+        q.lda, q.ldb = A.stride(0), B.stride(0)
+    check(lib.sw_gemm_kk_grouped(dt(problems[0][0]), n, arr, _stream()), "sw_gemm_kk_grouped")
+
+
+def splitk_fold_multi(folds):
+    """folds: list of (workspace, nslab, C (M, N) f32, row_scale or None, accumulate): C = [C +] row_scale[:, None] * sum of the slabs,
+    all in ONE launch (sw_splitk_fold_multi)"""
+    from ._lib import SplitkFold
+    n = len(folds)
+    if n == 0:
+        return
+    arr = (SplitkFold * n)()
+    for i, (ws, nslab, C, rs, acc) in enumerate(folds):
+        _need_gpu(ws, C)
+        q = arr[i]
+        q.M, q.N, q.nslab, q.accumulate = C.shape[0], C.shape[1], int(nslab), int(bool(acc))
+        q.workspace, q.C, q.ldc, q.row_scale = ws.data_ptr(), C.data_ptr(), C.stride(0), (None if rs is None else rs.data_ptr())
+    check(lib.sw_splitk_fold_multi(n, arr, _stream()), "sw_splitk_fold_multi")
+
+
 def colsum_fold_multi(folds):
     """folds: list of (workspace, n_rows, out): every bias-gradient fold of a backward pass in one launch"""
     from ._lib import ColsumFold

@@ -910,3 +910,39 @@ def test_gemm_split_k_with_an_epilogue_folds_like_the_single_launch(ops, out_bf1
         torch.cuda.synchronize()
         err = float((C.double() - (prod + res.double())).abs().max() / prod.abs().max())
         assert err <= 2e-5, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_grouped_plain_weight_gradient_gemms_and_multi_fold(ops, dtype):
+    """sw_gemm_kk_grouped + sw_splitk_fold_multi: several C = A^T B problems (both operands K-strided, K = pixels) of different
+    sizes, pitches and split counts in one launch, folded — with a row scale, and added to an existing C — in one more launch.
+    Against torch in f64; two problems of the same weight share one fold over all of their slabs."""
+    torch.manual_seed(3)
+    dev = "cuda"
+    spec = [(128, 512, 3800, 3, None), (512, 128, 950, 2, None), (2048, 512, 1900, 4, "scale"), (64, 256, 7000, 5, "acc"),
+            (256, 1024, 333, 1, "scale")]
+    probs, folds, refs, outs = [], [], [], []
+    for M, N, K, ns, opt in spec:
+        A = torch.randn(K, M + 8, device=dev).to(dtype)[:, :M]            # pitch > M
+        B = torch.randn(K, N, device=dev).to(dtype)
+        A2 = torch.randn(K // 2 + 7, M, device=dev).to(dtype)             # a second use of the same weight (another pass)
+        B2 = torch.randn(K // 2 + 7, N, device=dev).to(dtype)
+        n1, n2 = ops.gemm_kk_nslab(dtype, K, ns), ops.gemm_kk_nslab(dtype, A2.shape[0], 2)
+        ws = torch.full((n1 + n2, M * N), float("nan"), device=dev)
+        probs += [(A, B, ws, ns), (A2, B2, ws[n1:], 2)]
+        ref = A.double().t() @ B.double() + A2.double().t() @ B2.double()
+        rs = (torch.rand(M, device=dev) + 0.5) if opt == "scale" else None
+        C = torch.randn(M, N, device=dev) if opt == "acc" else torch.full((M, N), float("nan"), device=dev)
+        if rs is not None:
+            ref = ref * rs.double()[:, None]
+        if opt == "acc":
+            ref = ref + C.double()
+        folds.append((ws, n1 + n2, C, rs, opt == "acc"))
+        refs.append(ref); outs.append(C)
+    ops.gemm_kk_grouped(probs)
+    ops.splitk_fold_multi(folds)
+    torch.cuda.synchronize()
+    for (M, N, K, ns, opt), C, ref in zip(spec, outs, refs):
+        err = float((C.double() - ref).abs().max() / ref.abs().max())
+        assert err <= 2e-5, (M, N, K, ns, opt, err)
