@@ -36,6 +36,7 @@ SCALE_CLAMP = math.log(1000.0 / 16)
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))        # proposal_utils.py:170
 
 
+GROUP_LINEAR_WGRADS = True   # _LinearFn layers used several times per backward queue their weight gradients for one grouped launch (ops.grad_scope)
 FUSED_BLOCKS = True      # BottleneckBlock as one autograd node (_BottleneckFn); False: layer by layer (the form the fused one is tested against)
 
 
@@ -135,6 +136,8 @@ class _LinearFn(torch.autograd.Function):
         ctx.relu, ctx.out_f, ctx.splits = relu, out_f, tuple(splits)
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.wkey = id(params[0]) if params else None
+        if GROUP_LINEAR_WGRADS and params and any(ctx.needs_input_grad[8:8 + len(splits)]):
+            ops.count_use(("lin", ctx.wkey))
         ctx.bkey = id(params[len(splits)]) if len(params) > len(splits) else None
         return y
 
@@ -170,8 +173,27 @@ class _LinearFn(torch.autograd.Function):
             # sw_gemm (deterministic; unsplit, 4 workgroups walked 60 000 pixels).  FrozenBN: dW = scale * dW_eff, applied to the rows
             # inside the fold; `scale` covers the out_f real rows, the pad rows of dwp are never handed out.  None: added to the
             # buffer an earlier node of this backward pass returned (ops.grad_scope)
-            dwp = (_wgrad_1x1(gs, x, None if scale is None else _pad_scale(scale, ld), ctx.wkey) if P > 0
-                   else torch.zeros(ld, D, device=g.device, dtype=torch.float32))
+            scope = ops.GRAD_SCOPE
+            lkey = ("lin", ctx.wkey)
+            if scope is not None and ctx.wkey is not None and scope.uses.get(lkey, 0) > 1:
+                # every use of this weight queues its (gs, x) pair; the last one runs them as one grouped launch + one fold
+                q = scope.queued.get(lkey)
+                first = q is None
+                if first:
+                    q = scope.queued[lkey] = dict(bufs=[torch.empty(ld, D, device=g.device, dtype=torch.float32)], probs=[],
+                                                  scales=[None if scale is None else _pad_scale(scale, ld)], left=scope.uses[lkey])
+                if P > 0:
+                    q["probs"].append([(gs, x)])
+                q["left"] -= 1
+                if q["left"] == 0:
+                    if q["probs"]:
+                        _flush_wgrad_1x1(q)
+                    else:
+                        q["bufs"][0].zero_()
+                dwp = q["bufs"][0] if first else None
+            else:
+                dwp = (_wgrad_1x1(gs, x, None if scale is None else _pad_scale(scale, ld), ctx.wkey) if P > 0
+                       else torch.zeros(ld, D, device=g.device, dtype=torch.float32))
             r0 = 0
             for i, n in enumerate(ctx.splits):
                 if need[8 + i] and dwp is not None:
