@@ -657,10 +657,14 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
   // 0.7 ms per Stage-3 iteration); the wave's own LDS accesses execute in order: no barrier
   const bool res_staged = staged && g.res && g.res_bf16 && (g.ldres % 8) == 0 && ((((uintptr_t)g.res) & 15) == 0);
   // the same for the ReLU-mask reference when there is no residual (a data gradient masked by its consumer's input)
-  const bool ref_staged = staged && !g.res && g.ref && g.ref_bf16 && (g.ldr % 8) == 0 && ((((uintptr_t)g.ref) & 15) == 0);
-  if (res_staged || ref_staged) {
-    const unsigned short* src = (const unsigned short*)(res_staged ? g.res : g.ref);
-    const long lds_ = res_staged ? g.ldres : g.ldr;
+  const bool ref_ok = staged && g.ref && g.ref_bf16 && (g.ldr % 8) == 0 && ((((uintptr_t)g.ref) & 15) == 0);
+  const bool ref_staged = ref_ok && !g.res;
+  // residual AND mask (a bottleneck's block-input gradient: shortcut gradient added, then masked by the block input's ReLU): the
+  // mask reference goes to a second staging tile when the ring has room for two (the 8-wave tiles: 2 x 32 KiB)
+  constexpr bool TWO_TILES = 2L * NW * WTM * WTN * 2 <= (long)STAGES * STAGE_BYTES;
+  const bool ref_staged2 = TWO_TILES && ref_ok && res_staged;
+  unsigned short* stile2 = stile + NW * (WTM * WTN);
+  auto fetch_tile = [&](const unsigned short* src, const long lds_, unsigned short* dst) {
     constexpr int CPRW = WTN / 8;
 #pragma unroll
     for (int q = 0; q < (WTM * CPRW) / 64; ++q) {
@@ -668,8 +672,13 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
       const int m = m0 + wm * WTM + lrow, n = n0t + wn * WTN + ch * 8;
       u32x4 rv = {0u, 0u, 0u, 0u};
       if (m < g.M && n < g.N) rv = *(const u32x4*)(src + (long)m * lds_ + n);
-      *(u32x4*)(stile + lrow * WTN + ch * 8) = rv;
+      *(u32x4*)(dst + lrow * WTN + ch * 8) = rv;
     }
+  };
+  if (res_staged || ref_staged) {
+    if (res_staged) fetch_tile((const unsigned short*)g.res, g.ldres, stile);
+    else fetch_tile((const unsigned short*)g.ref, g.ldr, stile);
+    if (ref_staged2) fetch_tile((const unsigned short*)g.ref, g.ldr, stile2);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (also keeps the compiler from moving the 2-byte reads above these stores)
     __builtin_amdgcn_wave_barrier();
   }
@@ -702,6 +711,8 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
         }
         if (ref_staged) {
           v = bf16_bits_to_f32(stile[lrow * WTN + j * TS + r]) > 0.f ? v * g.ref_scale : 0.f;
+        } else if (ref_staged2) {
+          v = bf16_bits_to_f32(stile2[lrow * WTN + j * TS + r]) > 0.f ? v * g.ref_scale : 0.f;
         } else if (g.ref && ok) {
           const float rv = g.ref_bf16 ? bf16_bits_to_f32(((const unsigned short*)g.ref)[(long)m * g.ldr + n])
                                       : ((const float*)g.ref)[(long)m * g.ldr + n];

@@ -20,6 +20,7 @@ Random sampling (detectron2/modeling/sampling.py:49-50 draws torch.randperm per 
 64-bit seed per list, the kernels give the candidate at position i of the list the key splitmix64(seed + i) >> 40 and the `num`
 smallest keys win; tests inject the seeds of the closed-form keys the fixtures were generated with."""
 import math
+import os
 from typing import Dict, List
 
 import torch
@@ -36,6 +37,14 @@ SCALE_CLAMP = math.log(1000.0 / 16)
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))        # proposal_utils.py:170
 
 
+# layer flags (the `relu` argument of _LinearFn / _Conv3x3Fn; True / False keep their meaning).  A ReLU mask in the backward pass is a
+# kernel of its own (relu_bwd: read the output and the gradient, write the masked gradient) unless the PRODUCER of that gradient — the
+# data-gradient kernel of the layer's only consumer — applies it in its epilogue:
+#   _MASK_INPUT_GRAD  on the consumer: its input is a ReLU output nobody else reads; d/d(input) leaves the layer masked by input > 0;
+#   _GRAD_PREMASKED   on the producer of that input: the gradient it receives is already masked, its own relu_bwd is skipped.
+# The two are set in pairs by the module that owns both layers (bottleneck chain of a stage, RPN head, box head -> predictor).
+_RELU, _MASK_INPUT_GRAD, _GRAD_PREMASKED = 1, 2, 4
+MASKS_IN_PRODUCERS = os.environ.get("SW_S3_MASKS_IN_PRODUCERS", "1") != "0"    # off: every layer masks its own incoming gradient (relu_bwd), the flag pairs are ignored
 GROUP_LINEAR_WGRADS = True   # _LinearFn layers used several times per backward queue their weight gradients for one grouped launch (ops.grad_scope)
 FUSED_BLOCKS = True      # BottleneckBlock as one autograd node (_BottleneckFn); False: layer by layer (the form the fused one is tested against)
 
@@ -117,6 +126,8 @@ class _LinearFn(torch.autograd.Function):
         out_f = sum(splits)
         cd = x.dtype
         ld = staged.shape[0]
+        flags = int(relu) if MASKS_IN_PRODUCERS else (int(relu) & _RELU)
+        relu = bool(flags & _RELU)
         ydt = torch.float32 if out_f32 else cd
         assert not (relu and out_f32) and ld == (out_f + 7) // 8 * 8 and staged.dtype == cd
         ybuf = torch.empty(P, ld, device=x.device, dtype=ydt)
@@ -134,6 +145,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, staged, ybuf if relu else None, scale)
         assert residual is None or (residual.shape == (P, out_f) and residual.dtype == ydt and residual.is_contiguous())
         ctx.relu, ctx.out_f, ctx.splits = relu, out_f, tuple(splits)
+        ctx.mask_in, ctx.premasked = bool(flags & _MASK_INPUT_GRAD), bool(flags & _GRAD_PREMASKED)
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.wkey = id(params[0]) if params else None
         if GROUP_LINEAR_WGRADS and params and any(ctx.needs_input_grad[8:8 + len(splits)]):
@@ -149,7 +161,7 @@ class _LinearFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         need_w = any(need[8:8 + nw]); need_b = any(need[8 + nw:])
         if ld == out_f:
-            if ctx.relu:
+            if ctx.relu and not ctx.premasked:
                 gs = ops.relu_bwd(ybuf, g.contiguous(), out=torch.empty(P, ld, device=g.device, dtype=cd)) if P > 0 else g.contiguous()
             else:
                 gs = g.contiguous() if g.dtype == cd else g.to(cd)
@@ -164,7 +176,8 @@ class _LinearFn(torch.autograd.Function):
         if need[0]:
             dx = torch.empty(P, D, device=g.device, dtype=cd)
             if P > 0:
-                ops.gemm(gs, ws, dx, P, D, ld, b_kstrided=True, ep=ops.make_epilogue(out_dtype=cd), splitk=_few_tile_splits(P, D, ld))
+                ops.gemm(gs, ws, dx, P, D, ld, b_kstrided=True, ep=ops.make_epilogue(out_dtype=cd, relu_ref=x if ctx.mask_in else None),
+                         splitk=_few_tile_splits(P, D, ld))
             else:
                 dx.zero_()
         dws, dbs = [None] * nw, [None] * (len(ctx.shapes) - nw)
@@ -220,6 +233,9 @@ class _Conv3x3Fn(torch.autograd.Function):
         n, H, W, cin = x.shape
         cout = w.shape[0]
         cd = x.dtype
+        flags = int(relu) if MASKS_IN_PRODUCERS else (int(relu) & _RELU)
+        relu = bool(flags & _RELU)
+        ctx.premasked = bool(flags & _GRAD_PREMASKED)
         out = torch.empty(n, H, W, cout, device=x.device, dtype=cd)
         ops.conv3x3(x, staged, out, 1, ops.make_epilogue(bias=bias, relu=relu, out_dtype=cd))
         ctx.save_for_backward(x, staged_d, out if relu else None, scale)
@@ -235,7 +251,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         cout = ctx.cout
         cd = x.dtype
         g = g.contiguous()
-        dz = ops.relu_bwd(out, g, out=torch.empty_like(g)) if ctx.relu else g
+        dz = ops.relu_bwd(out, g, out=torch.empty_like(g)) if (ctx.relu and not ctx.premasked) else g
         dx = dw = db = None
         if ctx.needs_input_grad[6]:
             dw = _wgrad_3x3(x, dz, scale, ctx.wkey)
@@ -456,6 +472,7 @@ class _BottleneckFn(torch.autograd.Function):
         ctx.save_for_backward(x2, h1, h2, out, s1.w, s2.wd, s3.w, None if sc is None else _staged_of(sc).w,
                               s1.scale, s2.scale, s3.scale, None if sc is None else _staged_of(sc).scale)
         ctx.geom = (n, H, W, cin, mid, cout, c1.stride, full_shape)
+        ctx.flags = (bool(blk.mask_input_grad) and c1.stride == 1, bool(blk.grad_premasked)) if MASKS_IN_PRODUCERS else (False, False)
         ctx.keys = tuple(id(w) for w in weights) + (None,) * (4 - len(weights))
         if ctx.needs_input_grad[3]:
             ops.count_use(id(weights[1]))                                # conv2: its weight gradient may be grouped with the other pass's
@@ -470,7 +487,10 @@ class _BottleneckFn(torch.autograd.Function):
         P = n * H * W
         cd = x2.dtype
         need = ctx.needs_input_grad                                   # (x, blk, w1, w2, w3[, wsc])
-        gs = ops.relu_bwd(out, g.contiguous().view(P, cout), out=torch.empty(P, cout, device=g.device, dtype=cd))
+        mask_in, premasked = ctx.flags
+        g2 = g.contiguous().view(P, cout)
+        # (premasked: this block's output is read by the next block only, whose conv1 data gradient left masked by it)
+        gs = g2 if premasked else ops.relu_bwd(out, g2, out=torch.empty(P, cout, device=g.device, dtype=cd))
 
         def dgrad(a, w, D, **ep):
             d = torch.empty(P, D, device=a.device, dtype=cd)
@@ -486,7 +506,7 @@ class _BottleneckFn(torch.autograd.Function):
         dx = None
         if need[0]:
             side = gs if wsc is None else dgrad(gs, wsc, cin)         # the shortcut branch's gradient of the (subsampled) block input
-            dx = dgrad(dh1, w1, cin, residual=side).view(n, H, W, cin)
+            dx = dgrad(dh1, w1, cin, residual=side, **({"relu_ref": x2} if mask_in else {})).view(n, H, W, cin)
             if stride == 2:
                 dx = ops.scatter2x(dx, torch.empty(full_shape, device=g.device, dtype=cd))
         # ---- the 1x1 weight gradients: conv1 (dh1^T x), conv3 (gs^T h2), shortcut (gs^T x)
@@ -735,6 +755,7 @@ class Conv(nn.Module):
         return ent
 
     def forward(self, x, relu=False):
+        """relu: False / True or layer flags (_RELU | _GRAD_PREMASKED ...)"""
         st = _staged_of(self)
         if self.k == 3:
             return _Conv3x3Fn.apply(x, st.w, st.wd, self.bias.detach(), None, relu, self.weight, self.bias)
@@ -765,6 +786,9 @@ class BottleneckBlock(nn.Module):
         super().__init__()
         self.shortcut = ConvBN(cin, cout, 1, stride) if cin != cout else None
         self.conv1 = ConvBN(cin, mid, 1, stride); self.conv2 = ConvBN(mid, mid, 3); self.conv3 = ConvBN(mid, cout, 1)
+        # set by the owner of a chain of blocks (ResNet): this block's input is the previous block's output and nobody else reads it /
+        # this block's output is read by the next block only (see _MASK_INPUT_GRAD / _GRAD_PREMASKED; fused form only)
+        self.mask_input_grad = self.grad_premasked = False
 
     def forward(self, x):
         if FUSED_BLOCKS:
@@ -797,6 +821,9 @@ class ResNet(nn.Module):
         self.stage_names = []
         for name, nblk, mid, cout, stride in R50_STAGES:
             blocks = [BottleneckBlock(cin if b == 0 else cout, cout, mid, stride if b == 0 else 1) for b in range(nblk)]
+            for b, blk in enumerate(blocks):         # inside a stage block b's output feeds block b + 1 and nothing else (the LAST
+                blk.mask_input_grad = b > 0          # block's is the stage output: the next stage and an FPN lateral read it)
+                blk.grad_premasked = b < nblk - 1
             self.add_module(name, nn.Sequential(*blocks))
             self.stage_names.append(name)
             cin = cout
@@ -865,13 +892,14 @@ class StandardRPNHead(nn.Module):
         it into the reference's anchor order for the losses and the proposal selection"""
         A = self.A
         st = _staged_of(self)
-        ts = [self.conv(f, relu=True) for f in feats]
+        # (each conv output is read by the packed 1x1 GEMM only: that GEMM's data gradient leaves masked by the conv's ReLU)
+        ts = [self.conv(f, relu=_RELU | _GRAD_PREMASKED) for f in feats]
         C = ts[0].shape[3]
         N = ts[0].shape[0]
         hw = [t.shape[1] * t.shape[2] for t in ts]
         rows = sum(N * v for v in hw)
         x = torch.empty(rows, C, device=ts[0].device, dtype=ts[0].dtype)
-        y = _LinearFn.apply(_CatRowsFn.apply(x, *[t.reshape(N * v, C) for t, v in zip(ts, hw)]), st.w, st.bias, None, False, True,
+        y = _LinearFn.apply(_CatRowsFn.apply(x, *[t.reshape(N * v, C) for t, v in zip(ts, hw)]), st.w, st.bias, None, _MASK_INPUT_GRAD, True,
                             (A, 4 * A), None, self.objectness_logits.weight, self.anchor_deltas.weight, self.objectness_logits.bias,
                             self.anchor_deltas.bias)
         return y, N, tuple(hw)
@@ -1033,10 +1061,13 @@ class FastRCNNConvFCHead(nn.Module):
         self.__dict__["_st"] = st
         return ent
 
-    def forward(self, x):
+    def forward(self, x, out_grad_premasked=False):
+        """out_grad_premasked: the caller's only consumer of the result masks its data gradient by result > 0 (_MASK_INPUT_GRAD)"""
         s1, s2 = _staged_of(self)
-        x = _LinearFn.apply(x, s1.w, self.fc1.bias.detach(), None, True, False, (self.fc1.out_features,), None, self.fc1.weight, self.fc1.bias)
-        return _LinearFn.apply(x, s2.w, self.fc2.bias.detach(), None, True, False, (self.fc2.out_features,), None, self.fc2.weight, self.fc2.bias)
+        x = _LinearFn.apply(x, s1.w, self.fc1.bias.detach(), None, _RELU | _GRAD_PREMASKED, False, (self.fc1.out_features,), None,
+                            self.fc1.weight, self.fc1.bias)
+        f2 = _RELU | _MASK_INPUT_GRAD | (_GRAD_PREMASKED if out_grad_premasked else 0)
+        return _LinearFn.apply(x, s2.w, self.fc2.bias.detach(), None, f2, False, (self.fc2.out_features,), None, self.fc2.weight, self.fc2.bias)
 
 
 class FastRCNNFocaltLossOutputLayers(nn.Module):
@@ -1056,11 +1087,12 @@ class FastRCNNFocaltLossOutputLayers(nn.Module):
         self.__dict__["_st"] = st
         return ent
 
-    def forward(self, x):
-        """-> packed f32 logits (R, 5K+1) = [cls_score | bbox_pred]: one GEMM"""
+    def forward(self, x, mask_input_grad=False):
+        """-> packed f32 logits (R, 5K+1) = [cls_score | bbox_pred]: one GEMM.  mask_input_grad: x is a ReLU output that only this layer
+        reads (the box head's): d/dx leaves masked by x > 0"""
         st = _staged_of(self)
         K = self.num_classes
-        return _LinearFn.apply(x, st.w, st.bias, None, False, True, (K + 1, 4 * K), None, self.cls_score.weight, self.bbox_pred.weight,
+        return _LinearFn.apply(x, st.w, st.bias, None, _MASK_INPUT_GRAD if mask_input_grad else 0, True, (K + 1, 4 * K), None, self.cls_score.weight, self.bbox_pred.weight,
                                self.cls_score.bias, self.bbox_pred.bias)
 
 
@@ -1127,7 +1159,7 @@ class StandardROIHeadsPseudoLab(nn.Module):
         elif compute_val_loss:
             proposals = self.label_and_sample_proposals(proposals, targets, False)
         pooled = self._pool(feats, [p.proposal_boxes.tensor for p in proposals])
-        logits = self.box_predictor(self.box_head(pooled))
+        logits = self.box_predictor(self.box_head(pooled, out_grad_premasked=True), mask_input_grad=True)
         K = self.num_classes
         if (self.training and compute_loss) or compute_val_loss:
             self.last_sampled, self.last_logits = proposals, logits
