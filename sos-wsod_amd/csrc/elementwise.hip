@@ -673,6 +673,26 @@ __global__ void relu_bwd_kernel(long n, const T* __restrict__ ref, const T* g, T
     out[i] = Elem<T>::load(ref + i) > 0.f ? g[i] : (T)0;
 }
 
+// 16-byte pieces (n a multiple of 8 bf16 / 4 f32 elements, aligned tensors)
+template <typename T>
+__global__ void relu_bwd_vec_kernel(long nv, const T* __restrict__ ref, const T* g, T* out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    const u32x4 r = ((const u32x4*)ref)[i];
+    u32x4 v = ((const u32x4*)g)[i];
+    if (sizeof(T) == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool lo = __uint_as_float(r[k] << 16) > 0.f, hi = __uint_as_float(r[k] & 0xFFFF0000u) > 0.f;
+        v[k] = (lo ? (v[k] & 0x0000FFFFu) : 0u) | (hi ? (v[k] & 0xFFFF0000u) : 0u);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = __uint_as_float(r[k]) > 0.f ? v[k] : 0u;
+    }
+    ((u32x4*)out)[i] = v;
+  }
+}
+
 // out[m][n] = in[m][n] * colscale[n]  (f32 -> dtype): applies the per-loss cotangents to the unit logit gradients
 template <typename T>
 __global__ void scale_cols_kernel(int M, int N, const float* __restrict__ in, long ld_in, const float* __restrict__ cs,
@@ -988,6 +1008,17 @@ extern "C" int sw_nchw_to_nhwc(int dtype, int N, int C, int H, int W, int cpad, 
 extern "C" int sw_relu_bwd_out(int dtype, long n, const void* ref, const void* grad, void* out, hipStream_t stream) {
   SW_ENTER();
   if (n <= 0) return 0;
+  {
+    const long V = dtype == SW_BF16 ? 8 : 4;
+    if ((n % V) == 0 && ((((uintptr_t)ref | (uintptr_t)grad | (uintptr_t)out) & 15) == 0)) {
+      const long nv = n / V;
+      DISPATCH_T(dtype,
+        hipLaunchKernelGGL(relu_bwd_vec_kernel<unsigned short>, dim3(grid_for(nv)), dim3(256), 0, stream, nv, (const unsigned short*)ref, (const unsigned short*)grad, (unsigned short*)out),
+        hipLaunchKernelGGL(relu_bwd_vec_kernel<float>, dim3(grid_for(nv)), dim3(256), 0, stream, nv, (const float*)ref, (const float*)grad, (float*)out));
+      SW_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(relu_bwd_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const unsigned short*)ref, (const unsigned short*)grad, (unsigned short*)out),
     hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, n, (const float*)ref, (const float*)grad, (float*)out));
