@@ -107,6 +107,50 @@ __global__ void maxpool3x3s2_kernel(int N, int H, int W, int C, int OH, int OW, 
   }
 }
 
+// 16-byte pieces (C a multiple of 8 bf16 / 4 f32 elements)
+template <typename T>
+__global__ void maxpool3x3s2_vec_kernel(int N, int H, int W, int C, int OH, int OW, const T* __restrict__ in, T* __restrict__ out) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int cp = C / V;
+  const long n = (long)N * OH * OW * cp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cp) * V; long r = i / cp;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH); const int b = (int)(r / OH);
+    float m[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) m[k] = -FLT_MAX;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int y = oy * 2 - 1 + ky;
+      if (y < 0 || y >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int x = ox * 2 - 1 + kx;
+        if (x < 0 || x >= W) continue;
+        const u32x4 q = *(const u32x4*)(in + (((long)b * H + y) * W + x) * C + c);
+        if (sizeof(T) == 2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            m[2 * k] = fmaxf(m[2 * k], __uint_as_float(q[k] << 16));
+            m[2 * k + 1] = fmaxf(m[2 * k + 1], __uint_as_float(q[k] & 0xFFFF0000u));
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], __uint_as_float(q[k]));
+        }
+      }
+    }
+    u32x4 o;
+    if (sizeof(T) == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (unsigned)f32_to_bf16_bits(m[2 * k]) | ((unsigned)f32_to_bf16_bits(m[2 * k + 1]) << 16);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(m[k]);
+    }
+    *(u32x4*)(out + ((((long)b * OH + oy) * OW + ox) * C + c)) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------- stride-2 subsample / scatter
 // out[n][y][x][:] = in[n][2y][2x][:]  (the pixels a 1x1 stride-2 convolution reads; also FPN's p6 = max_pool(k 1, s 2) of p5)
 template <typename T>
@@ -127,7 +171,7 @@ __global__ void scatter2_kernel(int N, int H, int W, int C, int OH, int OW, cons
     const int c = (int)(i % C); long r = i / C;
     const int x = (int)(r % W); r /= W;
     const int y = (int)(r % H); const int b = (int)(r / H);
-    T v = (T)0;
+    T v = {};
     if (!(y & 1) && !(x & 1)) v = g[(((long)b * OH + (y >> 1)) * OW + (x >> 1)) * C + c];
     out[i] = v;
   }
@@ -193,6 +237,36 @@ __global__ void downsample2_sum_kernel(int N, int h, int w, int C, const T* __re
     const T* p = g + (((long)b * 2 * h + 2 * y) * 2 * w + 2 * x) * C + c;
     const float v = (Elem<T>::load(p) + Elem<T>::load(p + C)) + (Elem<T>::load(p + (long)2 * w * C) + Elem<T>::load(p + (long)2 * w * C + C));
     Elem<T>::store(out + i, v);
+  }
+}
+
+// the same with 16-byte pieces: (a + b) + (c + d) per element in f32, as above
+template <typename T>
+__global__ void downsample2_sum_vec_kernel(int N, int h, int w, int C, const T* __restrict__ g, T* __restrict__ out) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int cp = C / V;
+  const long n = (long)N * h * w * cp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cp) * V; long r = i / cp;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h); const int b = (int)(r / h);
+    const T* p = g + (((long)b * 2 * h + 2 * y) * 2 * w + 2 * x) * C + c;
+    const u32x4 q0 = *(const u32x4*)p, q1 = *(const u32x4*)(p + C), q2 = *(const u32x4*)(p + (long)2 * w * C), q3 = *(const u32x4*)(p + (long)2 * w * C + C);
+    u32x4 o;
+    if (sizeof(T) == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = (__uint_as_float(q0[k] << 16) + __uint_as_float(q1[k] << 16)) + (__uint_as_float(q2[k] << 16) + __uint_as_float(q3[k] << 16));
+        const float hi = (__uint_as_float(q0[k] & 0xFFFF0000u) + __uint_as_float(q1[k] & 0xFFFF0000u)) +
+                         (__uint_as_float(q2[k] & 0xFFFF0000u) + __uint_as_float(q3[k] & 0xFFFF0000u));
+        o[k] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        o[k] = __float_as_uint((__uint_as_float(q0[k]) + __uint_as_float(q1[k])) + (__uint_as_float(q2[k]) + __uint_as_float(q3[k])));
+    }
+    *(u32x4*)(out + ((((long)b * h + y) * w + x) * C + c)) = o;
   }
 }
 
@@ -548,6 +622,18 @@ extern "C" int sw_maxpool3x3s2(int dtype, int N, int H, int W, int C, const void
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long n = (long)N * OH * OW * C;
   if (n <= 0) return 0;
+  {
+    const int V = dtype == SW_BF16 ? 8 : 4;
+    if ((C % V) == 0 && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0)) {
+      DISPATCH_T(dtype,
+        hipLaunchKernelGGL(maxpool3x3s2_vec_kernel<unsigned short>, dim3(grid_for_n(n / V)), dim3(256), 0, stream, N, H, W, C, OH, OW,
+                           (const unsigned short*)in, (unsigned short*)out),
+        hipLaunchKernelGGL(maxpool3x3s2_vec_kernel<float>, dim3(grid_for_n(n / V)), dim3(256), 0, stream, N, H, W, C, OH, OW,
+                           (const float*)in, (float*)out));
+      SW_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(maxpool3x3s2_kernel<unsigned short>, dim3(grid_for_n(n)), dim3(256), 0, stream, N, H, W, C, OH, OW,
                        (const unsigned short*)in, (unsigned short*)out),
@@ -562,6 +648,16 @@ extern "C" int sw_subsample2x(int dtype, int N, int H, int W, int C, const void*
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const long n = (long)N * OH * OW * C;
   if (n <= 0) return 0;
+  {                                                           // a copy: 16-byte pieces of a pixel's channel run when they exist
+    const long es = dtype == SW_BF16 ? 2 : 4;
+    if (((long)C * es) % 16 == 0 && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0) && (dtype == SW_BF16 || dtype == SW_F32)) {
+      const int Cp = (int)((long)C * es / 16);
+      hipLaunchKernelGGL(subsample2_kernel<u32x4>, dim3(grid_for_n((long)N * OH * OW * Cp)), dim3(256), 0, stream, N, H, W, Cp, OH, OW,
+                         (const u32x4*)in, (u32x4*)out);
+      SW_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(subsample2_kernel<unsigned short>, dim3(grid_for_n(n)), dim3(256), 0, stream, N, H, W, C, OH, OW,
                        (const unsigned short*)in, (unsigned short*)out),
@@ -576,6 +672,16 @@ extern "C" int sw_scatter2x(int dtype, int N, int H, int W, int C, const void* g
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const long n = (long)N * H * W * C;
   if (n <= 0) return 0;
+  {
+    const long es = dtype == SW_BF16 ? 2 : 4;
+    if (((long)C * es) % 16 == 0 && ((((uintptr_t)g | (uintptr_t)out) & 15) == 0) && (dtype == SW_BF16 || dtype == SW_F32)) {
+      const int Cp = (int)((long)C * es / 16);
+      hipLaunchKernelGGL(scatter2_kernel<u32x4>, dim3(grid_for_n((long)N * H * W * Cp)), dim3(256), 0, stream, N, H, W, Cp, OH, OW,
+                         (const u32x4*)g, (u32x4*)out);
+      SW_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(scatter2_kernel<unsigned short>, dim3(grid_for_n(n)), dim3(256), 0, stream, N, H, W, C, OH, OW,
                        (const unsigned short*)g, (unsigned short*)out),
@@ -626,6 +732,18 @@ extern "C" int sw_downsample2x_sum(int dtype, int N, int h, int w, int C, const 
   SW_ENTER();
   const long n = (long)N * h * w * C;
   if (n <= 0) return 0;
+  {
+    const int V = dtype == SW_BF16 ? 8 : 4;
+    if ((C % V) == 0 && ((((uintptr_t)g | (uintptr_t)out) & 15) == 0)) {
+      DISPATCH_T(dtype,
+        hipLaunchKernelGGL(downsample2_sum_vec_kernel<unsigned short>, dim3(grid_for_n(n / V)), dim3(256), 0, stream, N, h, w, C,
+                           (const unsigned short*)g, (unsigned short*)out),
+        hipLaunchKernelGGL(downsample2_sum_vec_kernel<float>, dim3(grid_for_n(n / V)), dim3(256), 0, stream, N, h, w, C, (const float*)g,
+                           (float*)out));
+      SW_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   DISPATCH_T(dtype,
     hipLaunchKernelGGL(downsample2_sum_kernel<unsigned short>, dim3(grid_for_n(n)), dim3(256), 0, stream, N, h, w, C,
                        (const unsigned short*)g, (unsigned short*)out),
