@@ -86,6 +86,16 @@ long sw_gemm_splitk_workspace_floats(int M, int N, int K, int splitk);
  * Used for forward (ep: bias+relu) and for the data gradient (wk = flipped/transposed weights, ep: relu_ref). */
 int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in,
                      const void* wk, void* out, const sw_epilogue* ep, sw_stream_t stream);
+/* n stride-1, dilation-1 3x3 convolutions of different maps (and possibly different weights) in ONE launch of the direct kernel:
+ * the FPN levels of a detector (reference: the per-level loops of detectron2/modeling/proposal_generator/rpn.py:118-133 and
+ * detectron2/modeling/backbone/fpn.py:131-160).  `probs` is a HOST array, n <= 8; every epilogue like sw_conv3x3_igemm's (bias,
+ * relu, relu_ref; bf16 only).  Returns 1 = launched, 0 = a problem is not covered (launch them one by one), < 0 = error. */
+typedef struct sw_conv_problem {
+  int32_t nimg, H, W, Cin, Cout;
+  const void* in; const void* wk; void* out;
+  const sw_epilogue* ep;
+} sw_conv_problem;
+int sw_conv3x3_multi(int dtype, int n, const sw_conv_problem* probs, sw_stream_t stream);
 /* dW (OIHW f32, overwritten) from x [nimg][H][W][Cin] and dy [nimg][H][W][Cout].  workspace: at least
  * sw_conv3x3_wgrad_workspace_floats(...) floats: every K-split stores its partial [co][tap][ci] tile into its own
  * slab (plain stores), a second kernel adds the slabs in fixed order and permutes to OIHW (deterministic). */

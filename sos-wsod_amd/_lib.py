@@ -57,6 +57,12 @@ class SplitkFold(ctypes.Structure):
                 ("workspace", ctypes.c_void_p), ("C", ctypes.c_void_p), ("ldc", ctypes.c_long), ("row_scale", ctypes.c_void_p)]
 
 
+class ConvProblem(ctypes.Structure):
+    """sw_conv_problem"""
+    _fields_ = [("nimg", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32),
+                ("in_", ctypes.c_void_p), ("wk", ctypes.c_void_p), ("out", ctypes.c_void_p), ("ep", ctypes.POINTER(Epilogue))]
+
+
 class CopyDesc(ctypes.Structure):
     """sw_copy_desc"""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_long)]
@@ -150,6 +156,7 @@ SIGNATURES = {
     "sw_conv3x3_wgrad_fold": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_conv3x3_wgrad_fold_acc": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sw_conv3x3_wgrad_fold_multi": (c_int, [c_int, ctypes.POINTER(WgradFold), c_void_p]),
+    "sw_conv3x3_multi": (c_int, [c_int, c_int, ctypes.POINTER(ConvProblem), c_void_p]),
     "sw_gemm_kk_grouped": (c_int, [c_int, c_int, ctypes.POINTER(GemmKKProblem), c_void_p]),
     "sw_gemm_kk_grouped_slabs": (c_long, [c_int, c_int, c_int]),
     "sw_splitk_fold_multi": (c_int, [c_int, ctypes.POINTER(SplitkFold), c_void_p]),

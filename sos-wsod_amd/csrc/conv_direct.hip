@@ -52,7 +52,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // ~7 us of prologue (first patch + weights from HBM) and epilogue (partial-sum exchange, store) of the 38 us launch overlap with
 // nothing; inside the training step the second backbone stream's launches fill them (two concurrent launches: 62 us for both).
 template <int DIL, int TN, int KG = 1>
-__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_direct_kernel(DirectArgs g) {
+__device__ __forceinline__ void conv3x3_direct_body(const DirectArgs& g, const unsigned bid) {
   static_assert(KG == 1 || (KG == 2 && TN == 64), "K groups: two groups of four waves, 64-channel tiles");
   constexpr int DEPTH = 2;                                  // weight tap-row buffers
   constexpr int NI = TN / 16;                              // MFMA tiles along the output channels
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_direct_kern
   // workgroup -> (pixel tile, channel block): XCD x (= blockIdx & 7) takes a contiguous run of the work list in which the
   // channel block runs fastest, so the 8 channel blocks of a pixel tile share its input patch in that XCD's L2
   const int per_xcd = (g.total + 7) >> 3;
-  const int f = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per_xcd || f >= g.total) return;
+  const int f = (bid & 7) * per_xcd + (bid >> 3);
+  if ((int)(bid >> 3) >= per_xcd || f >= g.total) return;
   const int px_tile = f / g.n_co_blocks, co_blk = f - px_tile * g.n_co_blocks;
   const int img = px_tile / (g.tiles_x * g.tiles_y);
   const int trem = px_tile - img * (g.tiles_x * g.tiles_y);
@@ -281,6 +281,26 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_direct_kern
   }
 }
 
+template <int DIL, int TN, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_direct_kernel(DirectArgs g) {
+  conv3x3_direct_body<DIL, TN, KG>(g, blockIdx.x);
+}
+
+// Several convolutions (different maps, possibly different weights) as ONE launch: the FPN levels of a detector — the RPN head's
+// shared 3x3 convolution on p2..p6, the four FPN output convolutions — are independent launches of which only the finest map fills
+// the chip; side by side the small ones run in its shadow.  Workgroup ranges per problem are multiples of 8 (XCD map of the body).
+constexpr int DIRECT_MULTI_MAX = 8;
+struct DirectMulti {
+  int n;
+  unsigned first[DIRECT_MULTI_MAX + 1];
+  DirectArgs p[DIRECT_MULTI_MAX];
+};
+__global__ __launch_bounds__(256, 2) void conv3x3_direct_multi_kernel(DirectMulti m) {
+  int i = 0;
+  while (i + 1 < m.n && blockIdx.x >= m.first[i + 1]) ++i;
+  conv3x3_direct_body<1, 64, 1>(m.p[i], blockIdx.x - m.first[i]);
+}
+
 // First layer (conv1_1: 3 real input channels padded to 8, 64 output channels, forward only).  As an implicit GEMM its K is
 // 72 and nearly all time went into per-chunk tap arithmetic of the generic loader (100 us for 2 x 512 x 512 pixels whose
 // output alone is 67 MB = 13 us of HBM).  Here K = 9 taps x 8 channels is laid out as 3 MFMA K-steps of 4 taps: the A
@@ -419,6 +439,51 @@ int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilatio
   else if (tn == 64) { if (d == 1) SW_LAUNCH_DIRECT(1, 64, 1); else SW_LAUNCH_DIRECT(2, 64, 1); }
   else return 0;
 #undef SW_LAUNCH_DIRECT
+  e = hipGetLastError();
+  if (e != hipSuccess) return -(int)e;
+  return 1;
+}
+
+
+// n stride-1, dilation-1 bf16 convolutions in one launch (see conv3x3_direct_multi_kernel).  Returns 1 if launched, 0 if some problem is
+// not covered by the direct kernel (the caller then launches them one by one), < 0 on error.
+extern "C" int sw_conv3x3_multi(int dtype, int n, const sw_conv_problem* probs, hipStream_t stream) {
+  SW_ENTER();
+  if (n <= 0) return 1;
+  if (dtype != SW_BF16 || n > DIRECT_MULTI_MAX) return 0;
+  static const char* sw = getenv("SW_CONV_DIRECT");
+  if (sw && sw[0] == '0') return 0;
+  DirectMulti m = {};
+  m.n = n;
+  unsigned wgs = 0;
+  for (int i = 0; i < n; ++i) {
+    const sw_conv_problem& q = probs[i];
+    const sw_epilogue* ep = q.ep;
+    if (!ep || q.nimg <= 0 || q.H <= 0 || q.W <= 0) return 0;
+    if ((q.Cin % CK) || q.Cin < 64 || (q.Cout % 8)) return 0;
+    if (ep->out_dtype != SW_BF16 || ep->drop_mask || ep->accumulate_atomic || ep->absmax_out || (ep->drop_hash_p > 0.f) || ep->residual) return 0;
+    if (ep->relu_ref && (ep->ref_dtype != SW_BF16 || ep->ld_ref != q.Cout || ep->ref_scale != 1.0f)) return 0;
+    if ((((uintptr_t)q.in | (uintptr_t)q.wk | (uintptr_t)q.out | (uintptr_t)ep->relu_ref) & 15)) return 0;
+    DirectArgs& g = m.p[i];
+    g.in = q.in; g.wk = q.wk; g.out = q.out; g.bias = ep->bias; g.ref = ep->relu_ref; g.relu = ep->relu;
+    g.nimg = q.nimg; g.H = q.H; g.W = q.W; g.Cin = q.Cin; g.Cout = q.Cout;
+    g.tiles_x = (q.W + TW - 1) / TW; g.tiles_y = (q.H + TH - 1) / TH;
+    g.n_px_tiles = g.tiles_x * g.tiles_y * q.nimg;
+    g.n_co_blocks = (q.Cout + 63) / 64;
+    g.total = g.n_px_tiles * g.n_co_blocks;
+    const long ib = (long)q.nimg * q.H * q.W * q.Cin * 2, wb = (long)q.Cout * 9 * q.Cin * 2;
+    if (ib >= 0xFFFFFF00L || wb >= 0xFFFFFF00L) return 0;
+    g.in_bytes = (unsigned)ib; g.wk_bytes = (unsigned)wb;
+    m.first[i] = wgs;
+    wgs += (unsigned)(((g.total + 7) / 8) * 8);
+  }
+  m.first[n] = wgs;
+  constexpr int P = (TH + 2) * (TW + 2);
+  constexpr int apw = ((P * 4 + 63) / 64 + 3) / 4;
+  constexpr size_t lds = (size_t)2 * apw * 4096 + (size_t)2 * (3 * 64 * 64);
+  hipError_t e = hipFuncSetAttribute((const void*)conv3x3_direct_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return -(int)e;
+  hipLaunchKernelGGL(conv3x3_direct_multi_kernel, dim3(wgs), dim3(256), lds, stream, m);
   e = hipGetLastError();
   if (e != hipSuccess) return -(int)e;
   return 1;

@@ -243,6 +243,30 @@ def conv3x3(x, wk, out, dilation, ep, tag=None):
     return out
 
 
+def conv3x3_multi(problems):
+    """problems: list of (x NHWC, wk [Cout][9][Cin], out NHWC, epilogue) — stride-1, dilation-1 convolutions of different maps (the FPN
+    levels of a detector) in ONE launch of the direct kernel (sw_conv3x3_multi); shapes it does not cover run one by one"""
+    from ._lib import ConvProblem
+    n = len(problems)
+    if n == 0:
+        return
+    if 1 < n <= 8 and problems[0][0].dtype == torch.bfloat16:
+        arr = (ConvProblem * n)()
+        for i, (x, wk, out, ep) in enumerate(problems):
+            _need_gpu(x, wk, out)
+            q = arr[i]
+            q.nimg, q.H, q.W, q.Cin = x.shape
+            q.Cout = out.shape[3]
+            q.in_, q.wk, q.out, q.ep = x.data_ptr(), wk.data_ptr(), out.data_ptr(), ctypes.pointer(ep)
+        rc = int(lib.sw_conv3x3_multi(SW_BF16, n, arr, _stream()))
+        if rc == 1:
+            return
+        if rc < 0:
+            check(rc, "sw_conv3x3_multi")
+    for x, wk, out, ep in problems:
+        conv3x3(x, wk, out, 1, ep)
+
+
 def conv3x3_wgrad(x, dy, dw_oihw, dilation, splitk=1, workspace=None, tag=None, cout_scale=None, accumulate=False):
     """dw_oihw (Cout, Cin, 3, 3) f32 is overwritten (accumulate: added to); workspace: Cout*9*Cin floats (allocated here if None);
     cout_scale (Cout,) f32: dw[co] *= cout_scale[co] inside the slab fold (FrozenBN fold of the gradient)"""
