@@ -536,6 +536,70 @@ class _BottleneckFn(torch.autograd.Function):
         return (dx, None, dw1, dw2, dw3) + ((dwsc,) if wsc is not None else ())
 
 
+class _Conv3x3LevelsFn(torch.autograd.Function):
+    """L independent 3x3 convolutions (stride 1, padding 1, + bias, optional ReLU) of L maps as ONE launch each way (ops.conv3x3_multi:
+    the FPN levels — the RPN head's shared convolution on p2..p6, the four FPN output convolutions).  args: L, flags (the `relu`
+    argument of _Conv3x3Fn), then L inputs, L staged forward weights, L staged data-gradient weights, L bias values, L weight parameters,
+    L bias parameters (a shared layer repeats its tensors).  Weight / bias gradients go through the same helpers as _Conv3x3Fn."""
+
+    @staticmethod
+    def forward(ctx, L, relu, *ts):
+        xs, sws, swds, bvs, ws, bs = (ts[i * L:(i + 1) * L] for i in range(6))
+        flags = int(relu) if MASKS_IN_PRODUCERS else (int(relu) & _RELU)
+        relu = bool(flags & _RELU)
+        cd = xs[0].dtype
+        outs, probs = [], []
+        for x, sw, bv, w in zip(xs, sws, bvs, ws):
+            n, H, W, _ = x.shape
+            out = torch.empty(n, H, W, w.shape[0], device=x.device, dtype=cd)
+            probs.append((x, sw, out, ops.make_epilogue(bias=bv, relu=relu, out_dtype=cd)))
+            outs.append(out)
+        ops.conv3x3_multi(probs)
+        ctx.save_for_backward(*xs, *swds, *(outs if relu else ()))
+        ctx.L, ctx.relu, ctx.premasked = L, relu, bool(flags & _GRAD_PREMASKED)
+        ctx.wkeys, ctx.bkeys = [id(w) for w in ws], [id(b) for b in bs]
+        need = ctx.needs_input_grad
+        for i, w in enumerate(ws):
+            if need[2 + 4 * L + i]:
+                ops.count_use(id(w))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        L = ctx.L
+        sv = ctx.saved_tensors
+        xs, swds, outs = sv[:L], sv[L:2 * L], sv[2 * L:]
+        need = ctx.needs_input_grad
+        cd = xs[0].dtype
+        dzs = []
+        for i, g in enumerate(gs):
+            g = g.contiguous()
+            dzs.append(ops.relu_bwd(outs[i], g, out=torch.empty_like(g)) if (ctx.relu and not ctx.premasked) else g)
+        dxs, dws, dbs = [None] * L, [None] * L, [None] * L
+        for i in range(L):
+            n, H, W, _ = xs[i].shape
+            cout = dzs[i].shape[3]
+            if need[2 + 4 * L + i]:
+                dws[i] = _wgrad_3x3(xs[i], dzs[i], None, ctx.wkeys[i])
+            if need[2 + 5 * L + i]:
+                dbs[i] = _bias_grad(dzs[i].view(n * H * W, cout), cout, ctx.bkeys[i])
+        probs = []
+        for i in range(L):
+            if need[2 + i]:
+                dxs[i] = torch.empty_like(xs[i])
+                probs.append((dzs[i], swds[i], dxs[i], ops.make_epilogue(out_dtype=cd)))
+        ops.conv3x3_multi(probs)
+        return (None, None) + tuple(dxs) + (None,) * (3 * L) + tuple(dws) + tuple(dbs)
+
+
+def _conv3x3_levels(convs, xs, relu=False):
+    """the 3x3 `Conv` modules `convs[i]` applied to `xs[i]` (convs may repeat one module: a layer shared by the levels)"""
+    L = len(xs)
+    sts = [_staged_of(c) for c in convs]
+    return _Conv3x3LevelsFn.apply(L, relu, *xs, *[st.w for st in sts], *[st.wd for st in sts], *[c.bias.detach() for c in convs],
+                                  *[c.weight for c in convs], *[c.bias for c in convs])
+
+
 class _Subsample2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -862,11 +926,13 @@ class FPN(nn.Module):
 
     def forward(self, x4):
         c = self.bottom_up(x4)
-        outs, prev = [], None
+        prevs, prev = [], None
         for s in reversed(FPN_STAGES):
             lat = getattr(self, f"fpn_lateral{s}")(c[f"res{s}"])
             prev = lat if prev is None else _UpsampleAddFn.apply(lat, prev)
-            outs.insert(0, getattr(self, f"fpn_output{s}")(prev))
+            prevs.insert(0, prev)
+        # the four output convolutions are independent once the top-down sums exist: one launch (each way)
+        outs = list(_conv3x3_levels([getattr(self, f"fpn_output{s}") for s in FPN_STAGES], [p.contiguous() for p in prevs]))
         outs.append(_Subsample2Fn.apply(outs[-1]))
         return outs                                                  # [p2, p3, p4, p5, p6] NHWC
 
@@ -893,7 +959,7 @@ class StandardRPNHead(nn.Module):
         A = self.A
         st = _staged_of(self)
         # (each conv output is read by the packed 1x1 GEMM only: that GEMM's data gradient leaves masked by the conv's ReLU)
-        ts = [self.conv(f, relu=_RELU | _GRAD_PREMASKED) for f in feats]
+        ts = _conv3x3_levels([self.conv] * len(feats), [f.contiguous() for f in feats], relu=_RELU | _GRAD_PREMASKED)
         C = ts[0].shape[3]
         N = ts[0].shape[0]
         hw = [t.shape[1] * t.shape[2] for t in ts]
