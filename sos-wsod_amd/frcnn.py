@@ -557,7 +557,7 @@ class _Conv3x3LevelsFn(torch.autograd.Function):
         ops.conv3x3_multi(probs)
         ctx.save_for_backward(*xs, *swds, *(outs if relu else ()))
         ctx.L, ctx.relu, ctx.premasked = L, relu, bool(flags & _GRAD_PREMASKED)
-        ctx.wkeys, ctx.bkeys = [id(w) for w in ws], [id(b) for b in bs]
+        ctx.wkeys, ctx.bkeys, ctx.couts = [id(w) for w in ws], [id(b) for b in bs], [int(w.shape[0]) for w in ws]
         need = ctx.needs_input_grad
         for i, w in enumerate(ws):
             if need[2 + 4 * L + i]:
@@ -573,6 +573,9 @@ class _Conv3x3LevelsFn(torch.autograd.Function):
         cd = xs[0].dtype
         dzs = []
         for i, g in enumerate(gs):
+            if g is None:                                             # an output nobody used in the loss
+                n, H, W, _ = xs[i].shape
+                g = ops.fill_zero(torch.empty(n, H, W, ctx.couts[i], device=xs[i].device, dtype=cd))
             g = g.contiguous()
             dzs.append(ops.relu_bwd(outs[i], g, out=torch.empty_like(g)) if (ctx.relu and not ctx.premasked) else g)
         dxs, dws, dbs = [None] * L, [None] * L, [None] * L

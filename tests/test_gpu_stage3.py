@@ -674,3 +674,58 @@ def test_weight_staging_kernel_layouts_and_frozenbn_fold(ops, dtype):
         if not (bool(torch.equal(e["dst"], ref)) and ok_f):
             bad.append((kind, tuple(w.shape), "bn" in e, int((e["dst"].float() != ref.float()).sum()), ok_f))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_levels_convolution_node_against_single_launches_and_with_unused_outputs(golden_dir, dtype):
+    """frcnn._Conv3x3LevelsFn (the FPN output convolutions / the RPN head's shared convolution as ONE launch each way,
+    sw_conv3x3_multi; fp32: the one-by-one path behind the same node): outputs and every gradient equal the per-level
+    `Conv.forward` calls (fp32 bit for bit, bf16 to the last bit of a result: see below); a loss that uses ONE of the outputs
+    leaves the other levels' input gradients exactly zero instead of failing on their missing cotangents."""
+    import sos_wsod_amd.frcnn as F
+    t = np.load(os.path.join(golden_dir, "stage3_a.npz"))
+    K = int(t["K"])
+    P = FO.make_params(K, tag="s3a", head_scale=float(t["head_scale"]))
+    model = _model(K, P, "s3a", dtype=dtype)
+    model.train()
+    model.refresh_staged_weights()
+    fpn = model.backbone
+    convs = [getattr(fpn, f"fpn_output{s}") for s in F.FPN_STAGES]
+    torch.manual_seed(2)
+    xs = [torch.randn(2, h, w, 256, device="cuda").to(dtype).requires_grad_(True) for h, w in ((40, 56), (20, 28), (10, 14), (5, 7))]
+    gs = [torch.randn(2, h, w, 256, device="cuda").to(dtype) for h, w in ((40, 56), (20, 28), (10, 14), (5, 7))]
+
+    def grads():
+        out = [x.grad.clone() for x in xs] + [c.weight.grad.clone() for c in convs] + [c.bias.grad.clone() for c in convs]
+        for x in xs:
+            x.grad = None
+        for c in convs:
+            c.weight.grad = None; c.bias.grad = None
+        return out
+    outs = F._conv3x3_levels(convs, xs)
+    torch.autograd.backward(list(outs), gs)
+    got = grads()
+    ref_o = [c(x) for c, x in zip(convs, xs)]
+    torch.autograd.backward(ref_o, gs)
+    want = grads()
+    torch.cuda.synchronize()
+    # fp32: the same launches behind the node: identical.  bf16: alone, a map of few tiles runs the kernel's two-K-group form
+    # (partial sums of alternate channel chunks exchanged at the end), in the shared launch the one-group form: the f32 sums are
+    # associated differently, so a result may differ in its last bf16 bit
+    def close(a, b):
+        if dtype == torch.float32:
+            return bool(torch.equal(a, b))
+        return float((a.float() - b.float()).abs().max()) <= 1.6e-2 * float(b.float().abs().max()) + 1e-6
+    assert all(close(a, b) for a, b in zip(outs, ref_o))
+    assert all(close(a, b) for a, b in zip(got, want)), [float((a.float() - b.float()).abs().max() / b.float().abs().max()) for a, b in zip(got, want)]
+    # a shared layer on every level (the RPN head's form) and a loss on one output only
+    outs = F._conv3x3_levels([convs[0]] * 4, xs, relu=True)
+    outs[1].float().sum().backward()
+    torch.cuda.synchronize()
+    assert xs[1].grad is not None and float(xs[1].grad.abs().max()) > 0
+    assert all(float(xs[i].grad.abs().max()) == 0 for i in (0, 2, 3))
+    ref = convs[0](xs[1].detach().requires_grad_(True), relu=True)
+    w_before = convs[0].weight.grad.clone()
+    convs[0].weight.grad = None
+    ref.float().sum().backward()
+    assert close(w_before, convs[0].weight.grad)
