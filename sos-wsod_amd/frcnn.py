@@ -441,17 +441,37 @@ class _BottleneckFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, blk, *weights):
+        """x (n, H, W, cin) -> (n, H', W', cout); or, blk = (block, maps): x (rows, cin) = the rows of SEVERAL maps [(n, H, W), ...] back
+        to back (the student's passes in lockstep: every 1x1 convolution is one GEMM over all rows, the 3x3 one multi-problem launch)
+        -> (rows', cout) in the same map order"""
+        single = not isinstance(blk, tuple)
+        if single:
+            maps = [tuple(x.shape[:3])]
+            cin = x.shape[3]
+            x = x.reshape(-1, cin)
+        else:
+            blk, maps = blk
+            maps = [tuple(m) for m in maps]
+            cin = x.shape[1]
         c1, c2, c3, sc = blk.conv1, blk.conv2, blk.conv3, blk.shortcut
         s1, s2, s3 = _staged_of(c1), _staged_of(c2), _staged_of(c3)
         cd = x.dtype
-        full_shape = tuple(x.shape)
+        in_maps = maps
         if c1.stride == 2:
-            n, H, W, C = x.shape
-            x = ops.subsample2x(x, torch.empty(n, (H + 1) // 2, (W + 1) // 2, C, device=x.device, dtype=cd))
-        n, H, W, cin = x.shape
-        P = n * H * W
+            maps = [(n, (H + 1) // 2, (W + 1) // 2) for n, H, W in in_maps]
+            xs = torch.empty(sum(n * H * W for n, H, W in maps), cin, device=x.device, dtype=cd)
+            r0 = q0 = 0
+            for (n, H, W), (_, h, w) in zip(in_maps, maps):
+                ops.subsample2x(x[r0:r0 + n * H * W].view(n, H, W, cin), xs[q0:q0 + n * h * w].view(n, h, w, cin))
+                r0 += n * H * W; q0 += n * h * w
+            x = xs
+        P = x.shape[0]
+        offs = [0]
+        for n, H, W in maps:
+            offs.append(offs[-1] + n * H * W)
+        assert offs[-1] == P
         mid, cout = c1.weight.shape[0], c3.weight.shape[0]
-        x2 = x.reshape(P, cin)
+        x2 = x
 
         def lin(a, st, relu, out_f, residual=None):
             y = torch.empty(P, out_f, device=a.device, dtype=cd)
@@ -464,27 +484,29 @@ class _BottleneckFn(torch.autograd.Function):
                 ops.TIMER.note("s3_gemm_fwd_bytes", float(es) * (P * D + out_f * D + P * out_f))
             return y
         h1 = lin(x2, s1, True, mid)
-        h2 = torch.empty(n, H, W, mid, device=x.device, dtype=cd)
-        ops.conv3x3(h1.view(n, H, W, mid), s2.w, h2, 1, ops.make_epilogue(bias=s2.shift, relu=True, out_dtype=cd))
-        h2 = h2.view(P, mid)
+        h2 = torch.empty(P, mid, device=x.device, dtype=cd)
+        ops.conv3x3_multi([(h1[offs[i]:offs[i + 1]].view(n, H, W, mid), s2.w, h2[offs[i]:offs[i + 1]].view(n, H, W, mid),
+                            ops.make_epilogue(bias=s2.shift, relu=True, out_dtype=cd)) for i, (n, H, W) in enumerate(maps)])
         short = x2 if sc is None else lin(x2, _staged_of(sc), False, cout)
         out = lin(h2, s3, True, cout, residual=short)
         ctx.save_for_backward(x2, h1, h2, out, s1.w, s2.wd, s3.w, None if sc is None else _staged_of(sc).w,
                               s1.scale, s2.scale, s3.scale, None if sc is None else _staged_of(sc).scale)
-        ctx.geom = (n, H, W, cin, mid, cout, c1.stride, full_shape)
+        ctx.geom = (maps, in_maps, offs, cin, mid, cout, c1.stride, single)
         ctx.flags = (bool(blk.mask_input_grad) and c1.stride == 1, bool(blk.grad_premasked)) if MASKS_IN_PRODUCERS else (False, False)
         ctx.keys = tuple(id(w) for w in weights) + (None,) * (4 - len(weights))
         if ctx.needs_input_grad[3]:
-            ops.count_use(id(weights[1]))                                # conv2: its weight gradient may be grouped with the other pass's
+            for _ in maps:
+                ops.count_use(id(weights[1]))                            # conv2: every map's weight gradient joins one grouped launch
         if all(ctx.needs_input_grad[2:]):
             ops.count_use(("1x1", id(weights[0])))                      # the block's 1x1 weights: one grouped launch for all passes
-        return out.view(n, H, W, cout)
+        n, H, W = maps[0]
+        return out.view(n, H, W, cout) if single else out
 
     @staticmethod
     def backward(ctx, g):
         x2, h1, h2, out, w1, w2d, w3, wsc, sc1, sc2, sc3, scs = ctx.saved_tensors
-        n, H, W, cin, mid, cout, stride, full_shape = ctx.geom
-        P = n * H * W
+        maps, in_maps, offs, cin, mid, cout, stride, single = ctx.geom
+        P = offs[-1]
         cd = x2.dtype
         need = ctx.needs_input_grad                                   # (x, blk, w1, w2, w3[, wsc])
         mask_in, premasked = ctx.flags
@@ -497,24 +519,43 @@ class _BottleneckFn(torch.autograd.Function):
             K = a.shape[1]
             ops.gemm(a, w, d, P, D, K, b_kstrided=True, ep=ops.make_epilogue(out_dtype=cd, **ep), splitk=_few_tile_splits(P, D, K))
             return d
+
+        def m4(t, i, c):                                              # map i of a row-concatenated (P, c) tensor as NHWC
+            n, H, W = maps[i]
+            return t[offs[i]:offs[i + 1]].view(n, H, W, c)
         keys = ctx.keys
         dh2 = dgrad(gs, w3, mid, relu_ref=h2)                         # masked by conv2's ReLU
-        dw2 = _wgrad_3x3(h1.view(n, H, W, mid), dh2.view(n, H, W, mid), sc2, keys[1]) if need[3] else None
-        dh1 = torch.empty(n, H, W, mid, device=g.device, dtype=cd)
-        ops.conv3x3(dh2.view(n, H, W, mid), w2d, dh1, 1, ops.make_epilogue(out_dtype=cd, relu_ref=h1))        # masked by conv1's ReLU
-        dh1 = dh1.view(P, mid)
+        dw2 = None
+        if need[3]:
+            for i in range(len(maps)):
+                r = _wgrad_3x3(m4(h1, i, mid), m4(dh2, i, mid), sc2, keys[1])
+                dw2 = r if dw2 is None else dw2                       # (inside ops.grad_scope only the first use hands out a buffer)
+                if r is not None and r is not dw2:
+                    dw2 = dw2 + r                                     # outside a scope: plain sums
+        dh1 = torch.empty(P, mid, device=g.device, dtype=cd)
+        ops.conv3x3_multi([(m4(dh2, i, mid), w2d, m4(dh1, i, mid), ops.make_epilogue(out_dtype=cd, relu_ref=h1[offs[i]:offs[i + 1]]))
+                           for i in range(len(maps))])                # masked by conv1's ReLU (reference as (pixels, mid) rows)
         dx = None
         if need[0]:
             side = gs if wsc is None else dgrad(gs, wsc, cin)         # the shortcut branch's gradient of the (subsampled) block input
-            dx = dgrad(dh1, w1, cin, residual=side, **({"relu_ref": x2} if mask_in else {})).view(n, H, W, cin)
+            dx = dgrad(dh1, w1, cin, residual=side, **({"relu_ref": x2} if mask_in else {}))
             if stride == 2:
-                dx = ops.scatter2x(dx, torch.empty(full_shape, device=g.device, dtype=cd))
+                full = torch.empty(sum(n * H * W for n, H, W in in_maps), cin, device=g.device, dtype=cd)
+                r0 = 0
+                for i, (n, H, W) in enumerate(in_maps):
+                    ops.scatter2x(m4(dx, i, cin), full[r0:r0 + n * H * W].view(n, H, W, cin))
+                    r0 += n * H * W
+                dx = full
+            if single:
+                n, H, W = in_maps[0]
+                dx = dx.view(n, H, W, cin)
         # ---- the 1x1 weight gradients: conv1 (dh1^T x), conv3 (gs^T h2), shortcut (gs^T x)
         scope = ops.GRAD_SCOPE
         bkey = ("1x1", keys[0])
         dw1 = dw3 = dwsc = None
-        if scope is not None and all(need[2:]) and scope.uses.get(bkey, 0) > 1:
+        if scope is not None and all(need[2:]) and (scope.uses.get(bkey, 0) > 1 or (len(maps) > 1 and scope.uses.get(bkey, 0) == 1)):
             # every pass's three problems are queued; the last use runs all of them as ONE grouped launch + ONE multi-fold
+            # (several maps in one call: the rows of all of them are one problem per weight — still one grouped launch)
             q = scope.queued.get(bkey)
             first = q is None
             if first:
@@ -916,6 +957,38 @@ class ResNet(nn.Module):
             feats[name] = x
         return feats
 
+    def forward_lockstep(self, x4s):
+        """several independent batches (different padded sizes allowed) through the trainable stages IN LOCKSTEP: after the frozen
+        stem + res2 of every batch, the batches' rows sit back to back in one matrix, every 1x1 convolution of res3..res5 is ONE GEMM
+        over all rows and every 3x3 convolution one multi-problem launch over the batches' maps (_BottleneckFn with several maps).
+        Rows are independent in every layer, so each image's features are what forward() gives for its own batch.
+        -> one feature dict per batch.  Needs the fused block form and freeze_at == 2; anything else runs the batches one by one."""
+        if not (FUSED_BLOCKS and self.freeze_at == 2 and len(x4s) > 1):
+            return [self.forward(x) for x in x4s]
+        feats = [{} for _ in x4s]
+        res2 = []
+        with torch.no_grad():
+            for f, x4 in zip(feats, x4s):
+                x = getattr(self, self.stage_names[0])(self.stem(x4))
+                f[self.stage_names[0]] = x
+                res2.append(x)
+        C = res2[0].shape[3]
+        maps = [tuple(x.shape[:3]) for x in res2]
+        joint = torch.empty(sum(n * H * W for n, H, W in maps), C, device=res2[0].device, dtype=res2[0].dtype)
+        r0, pairs = 0, []
+        for x, (n, H, W) in zip(res2, maps):
+            pairs.append((x.reshape(n * H * W, C), joint[r0:r0 + n * H * W])); r0 += n * H * W
+        ops.copy_multi(pairs)
+        for name in self.stage_names[1:]:
+            for blk in getattr(self, name):
+                ws = (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight) + (() if blk.shortcut is None else (blk.shortcut.weight,))
+                joint = _BottleneckFn.apply(joint, (blk, maps), *ws)
+                if blk.conv1.stride == 2:
+                    maps = [(n, (H + 1) // 2, (W + 1) // 2) for n, H, W in maps]
+            for f, v in zip(feats, _SplitRowsFn.apply(joint, maps)):
+                f[name] = v
+        return feats
+
 
 class FPN(nn.Module):
     """backbone/fpn.py:18-188: laterals 1x1, top-down nearest upsampling + add, outputs 3x3, p6 = p5 subsampled (LastLevelMaxPool)"""
@@ -928,7 +1001,10 @@ class FPN(nn.Module):
             self.add_module(f"fpn_lateral{s}", Conv(c, 256, 1)); self.add_module(f"fpn_output{s}", Conv(256, 256, 3))
 
     def forward(self, x4):
-        c = self.bottom_up(x4)
+        return self.forward_top(self.bottom_up(x4))
+
+    def forward_top(self, c):
+        """the pyramid from the bottom-up features {res2..res5}"""
         prevs, prev = [], None
         for s in reversed(FPN_STAGES):
             lat = getattr(self, f"fpn_lateral{s}")(c[f"res{s}"])
@@ -993,6 +1069,36 @@ class _CatRowsFn(torch.autograd.Function):
         for r in ctx.rows:
             out.append(g[r0:r0 + r]); r0 += r
         return (None,) + tuple(out)
+
+
+class _SplitRowsFn(torch.autograd.Function):
+    """(rows, C) holding several maps back to back -> one (n, H, W, C) view per map (no copy); backward: the maps' gradients copied
+    back to back into one (rows, C) gradient (one sw_copy_multi launch; a map nobody used: zeros)"""
+
+    @staticmethod
+    def forward(ctx, buf, maps):
+        ctx.maps, ctx.C = [tuple(m) for m in maps], buf.shape[1]
+        out, r0 = [], 0
+        for n, H, W in ctx.maps:
+            out.append(buf[r0:r0 + n * H * W].view(n, H, W, ctx.C))
+            r0 += n * H * W
+        ctx.rows = r0
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        full = torch.empty(ctx.rows, ctx.C, device=ref.device, dtype=ref.dtype)
+        pairs, r0 = [], 0
+        for (n, H, W), g in zip(ctx.maps, gs):
+            dst = full[r0:r0 + n * H * W]
+            if g is None:
+                ops.fill_zero(dst)
+            else:
+                pairs.append((g.contiguous().view(n * H * W, ctx.C), dst))
+            r0 += n * H * W
+        ops.copy_multi(pairs)
+        return full, None
 
 
 def _splitmix64(x):
@@ -1370,10 +1476,28 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
             ops.preprocess_pad(im.contiguous(), out[i], mean, std)
         return out, sizes
 
-    def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False):
+    def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False, second=None):
+        """second (branch "supervised" only): a SECOND, independent batch of the same branch — the semi-supervised step's pseudo-labelled
+        views next to its labelled ones (unbias/ubteacher/engine/trainer.py:527-538 calls the model twice).  Both batches' backbones run
+        in lockstep (ResNet.forward_lockstep), everything image- and loss-specific per batch, first batch first (the order of the two
+        calls: the label samplers draw their keys in it) -> (result of the first batch, result of the second batch)"""
         if (not self.training) and (not val_mode):
             return self.inference(batched_inputs)
         self.refresh_staged_weights()
+        if second is not None:
+            if branch != "supervised":
+                raise ValueError("second batch: branch 'supervised' only")
+            results = []
+            pre = [self.preprocess_image(b) for b in (batched_inputs, second)]
+            cs = self.backbone.bottom_up.forward_lockstep([x4 for x4, _ in pre])
+            for b, (_, sizes), c in zip((batched_inputs, second), pre, cs):
+                gt = [x["instances"] for x in b] if "instances" in b[0] else None
+                feats = self.backbone.forward_top(c)
+                proposals, rpn_losses = self.proposal_generator(sizes, feats, gt)
+                _, det_losses = self.roi_heads(feats, proposals, gt, branch=branch)
+                losses = dict(det_losses); losses.update(rpn_losses)
+                results.append((losses, [], [], None))
+            return tuple(results)
         x4, sizes = self.preprocess_image(batched_inputs)
         gt = [x["instances"] for x in batched_inputs] if "instances" in batched_inputs[0] else None
         feats = self.backbone(x4)

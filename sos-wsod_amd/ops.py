@@ -192,6 +192,8 @@ def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_re
     ep.drop_mask = None if drop_mask is None else drop_mask.data_ptr()
     ep.ld_drop = 0 if drop_mask is None else drop_mask.stride(0)
     ep.drop_scale = float(drop_scale)
+    if relu_ref is not None and relu_ref.dim() != 2:
+        raise ValueError("relu_ref: a (rows, columns) matrix (its row pitch is the reference's leading dimension)")
     ep.relu_ref = None if relu_ref is None else relu_ref.data_ptr()
     ep.ld_ref = 0 if relu_ref is None else relu_ref.stride(0)
     ep.ref_scale = float(ref_scale)
@@ -204,6 +206,8 @@ def make_epilogue(bias=None, relu=False, drop_mask=None, drop_scale=2.0, relu_re
         ep.drop_seed, ep.drop_offset, ep.drop_hash_p = int(drop_hash[0]) & (2 ** 64 - 1), int(drop_hash[1]), float(drop_hash[2])
         if len(drop_hash) > 3 and drop_hash[3] is not None:
             ep.drop_offset_dev = drop_hash[3].data_ptr()
+    if residual is not None and residual.dim() != 2:
+        raise ValueError("residual: a (rows, columns) matrix")
     ep.residual = None if residual is None else residual.data_ptr()
     ep.ld_res = 0 if residual is None else residual.stride(0)
     ep.res_dtype = SW_F32 if residual is None else dt(residual)

@@ -194,9 +194,12 @@ class SemiSupStep:
     """`run_step_full_semisup` (trainer.py:436-549) over any student / teacher pair with the reference's branch interface."""
 
     def __init__(self, model, model_teacher, optimizer, *, burn_up_step, teacher_update_iter=1, ema_keep_rate=0.9996,
-                 bbox_threshold=0.7, unsup_loss_weight=4.0, burn_up_with_strong_aug=True, has_multi_label=False, fuse_grad_sums=True):
+                 bbox_threshold=0.7, unsup_loss_weight=4.0, burn_up_with_strong_aug=True, has_multi_label=False, fuse_grad_sums=True,
+                 lockstep=True):
         self.model, self.model_teacher, self.optimizer = model, model_teacher, optimizer
         self.fuse_grad_sums = fuse_grad_sums          # ops.grad_scope around backward (False: autograd sums the two passes' weight gradients)
+        core = getattr(model, "module", model)                                 # (DistributedDataParallel wraps the student)
+        self.lockstep = bool(lockstep) and hasattr(getattr(getattr(core, "backbone", None), "bottom_up", None), "forward_lockstep")
         self.burn_up_step, self.teacher_update_iter, self.ema_keep_rate = burn_up_step, teacher_update_iter, ema_keep_rate
         self.bbox_threshold, self.unsup_loss_weight = bbox_threshold, unsup_loss_weight
         self.burn_up_with_strong_aug, self.has_multi_label = burn_up_with_strong_aug, has_multi_label
@@ -231,9 +234,14 @@ class SemiSupStep:
                 d.pop("instances", None)
             for dq, dk, lab in zip(unlabel_q, unlabel_k, pseudo_roih):                                # add_label
                 dq["instances"] = lab; dk["instances"] = lab
-            rec_label, _, _, _ = self.model(list(label_q) + list(label_k), branch="supervised")
+            if self.lockstep:
+                # both student passes through ONE call: their backbones run in lockstep (frcnn: forward(..., second=...))
+                (rec_label, _, _, _), (rec_unlabel, _, _, _) = self.model(list(label_q) + list(label_k), branch="supervised",
+                                                                          second=list(unlabel_q))
+            else:
+                rec_label, _, _, _ = self.model(list(label_q) + list(label_k), branch="supervised")
+                rec_unlabel, _, _, _ = self.model(unlabel_q, branch="supervised")
             record.update(rec_label)
-            rec_unlabel, _, _, _ = self.model(unlabel_q, branch="supervised")
             record.update({k + "_pseudo": v for k, v in rec_unlabel.items()})
             loss_dict = weight_losses(record, self.unsup_loss_weight)
         losses = sum(loss_dict.values())
