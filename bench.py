@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Throughput of the Stage-1 OICR+ training step on MI355X (BASELINE.json metric: images/s, VGG16+OICR, 2000 proposals).
 
 One "step" = one OICR+ iteration per GPU = 4 views (2 scales x {orig, h-flip}) of one image:

@@ -359,6 +359,7 @@ __global__ __launch_bounds__(1024) void rpn_sort_pack_kernel(int CAP, RpnLevels 
 }
 
 // ---------------------------------------------------------------------------------------------------- RPN anchor labels
+constexpr int LABEL_MAX_IMG = 8;
 struct LabelArgs {
   long A; int N;
   const float* anchors;          // [A][4]
@@ -476,10 +477,11 @@ __global__ __launch_bounds__(256) void label_keys_kernel(LabelArgs g, const int8
 // One workgroup per image over its P proposals (+ G ground-truth boxes appended, roi_heads.py:343-345): IoU >= thr -> foreground with
 // the matched gt's class, else background K (matcher thresholds [0.5], labels [0, 1]); up to max_pos foreground and batch - that many
 // background rows with the smallest random keys, each list in key order (sampling.py:49-54 + roi_heads.py:300-322).
+constexpr int ROI_MAX_IMG = 64;          // per-image tables by value: 1.5 KiB of kernel arguments
 struct RoiSampleArgs {
   int n_img, p_stride;
-  int g_off[8], g_cnt[8];
-  unsigned long long seeds[16];
+  int g_off[ROI_MAX_IMG], g_cnt[ROI_MAX_IMG];
+  unsigned long long seeds[2 * ROI_MAX_IMG];
 };
 template <int CAP>
 __global__ __launch_bounds__(1024) void roi_sample_kernel(RoiSampleArgs ra, const int* __restrict__ p_cnt, const float* __restrict__ props,
@@ -562,6 +564,14 @@ __global__ __launch_bounds__(1024) void roi_sample_kernel(RoiSampleArgs ra, cons
     ((float4*)out_box)[o] = box_of(i);
     ((float4*)out_gt)[o] = G > 0 ? gb[s_m[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // rows the sampler did not fill (more than max_pos foreground candidates AND fewer than batch - max_pos background ones: sampling.py
+  // returns num_pos + num_neg < batch rows) are defined, never stale memory: class -1 (= ignore), empty boxes.  The caller reads out_cnt.
+  for (int r = num_pos + num_neg + threadIdx.x; r < batch; r += blockDim.x) {
+    const long o = (long)img * out_stride + r;
+    out_idx[o] = -1; out_cls[o] = -1;
+    ((float4*)out_box)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ((float4*)out_gt)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 
@@ -611,8 +621,8 @@ __global__ void rpn_unpack_bwd_kernel(RpnMap m, long rows, const float* __restri
 // ---------------------------------------------------------------------------------------------------- FPN level of every ROI
 // poolers.py:17-50 assign_boxes_to_levels + convert_boxes_to_pooler_format: dense ROI rows [R][5] = (image, box) gathered from the
 // images' box blocks, level = clamp(floor(4 + log2(sqrt(area) / 224 + 1e-8)), 2, 5) - 2, and per level the rows of that level in
-// ascending order (as nonzero lists them) with their count — one workgroup, R <= 8192.
-struct LevelArgs { int n_img; int row_off[8], row_cnt[8]; long box_off[8]; };
+// ascending order (as nonzero lists them) with their count — one workgroup (R <= 2^20, <= 64 images).
+struct LevelArgs { int n_img; int row_off[ROI_MAX_IMG], row_cnt[ROI_MAX_IMG]; long box_off[ROI_MAX_IMG]; };
 __global__ __launch_bounds__(1024) void roi_levels_kernel(LevelArgs g, int R, const float* __restrict__ boxes, float* __restrict__ rois,
                                                           int* __restrict__ level_of, int* __restrict__ sel /*[4][R]*/, int* __restrict__ sel_cnt) {
   __shared__ unsigned sh[1024];
@@ -783,6 +793,7 @@ extern "C" long sw_rpn_select_workspace_bytes(int N, int L, const int* n_per_lev
   long tot = 0; int mx = 0;
   for (int l = 0; l < L; ++l) { tot += n_per_level[l]; mx = n_per_level[l] > mx ? n_per_level[l] : mx; }
   const int max_chunks = (mx + CHUNK - 1) / CHUNK;
+  if (L >= 1 && L <= 8 && N * L > MAX_SEG) N = MAX_SEG / L;           // sw_rpn_select_pack walks image ranges of this size
   return (long)((sel_workspace_bytes(N * L, max_chunks) + 15) & ~(size_t)15) + (long)N * tot * 4 + 64;
 }
 
@@ -791,7 +802,26 @@ extern "C" int sw_rpn_select_pack(int N, int L, const float* const* logits, cons
                                   const int* img_hw_dev, float* cand_scores, float* cand_boxes, int* finite_dev, int* sel_idx,
                                   void* workspace, long workspace_bytes, hipStream_t stream) {
   SW_ENTER();
-  if (N < 1 || L < 1 || L > 8 || N * L > MAX_SEG || pre_topk < 1 || pre_topk > 16384 || img_stride < 0) return -5;
+  if (N < 1 || L < 1 || L > 8 || pre_topk < 1 || pre_topk > 16384 || img_stride < 0) return -5;
+  if (N * L > MAX_SEG) {
+    // the segment table travels by value (MAX_SEG entries): more images run as consecutive calls over image ranges; every output
+    // is per image and the workspace is reused in stream order
+    const int per = MAX_SEG / L;
+    const long rows = (long)L * pre_topk;
+    for (int i0 = 0; i0 < N; i0 += per) {
+      const int nc = N - i0 < per ? N - i0 : per;
+      const float* lg[8]; const float* dl[8];
+      for (int l = 0; l < L; ++l) {
+        const long adv = (long)i0 * (img_stride ? img_stride : n_per_level[l]);
+        lg[l] = logits[l] + adv; dl[l] = deltas[l] + adv * 4;
+      }
+      const int rc = sw_rpn_select_pack(nc, L, lg, dl, anchors, n_per_level, img_stride, pre_topk, weights4, scale_clamp, img_hw_dev + 2 * i0,
+                                        cand_scores + (long)i0 * rows * (L + 1), cand_boxes + (long)i0 * rows * 4 * L, finite_dev + i0,
+                                        sel_idx + (long)i0 * L * pre_topk, workspace, workspace_bytes, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if (workspace_bytes < sw_rpn_select_workspace_bytes(N, L, n_per_level)) return -6;
   RpnLevels lv = {};
   lv.L = L; lv.N = N; lv.img_stride = img_stride;
@@ -834,6 +864,7 @@ extern "C" int sw_rpn_select_pack(int N, int L, const float* const* logits, cons
 
 extern "C" long sw_rpn_label_workspace_bytes(int N, long A, int total_gt) {
   const int max_chunks = (int)((A + CHUNK - 1) / CHUNK);
+  if (N > LABEL_MAX_IMG) N = LABEL_MAX_IMG;                             // sw_rpn_label_anchors walks image ranges of this size (total_gt: an upper bound)
   return (long)((sel_workspace_bytes(2 * N, max_chunks) + 15) & ~(size_t)15) + (long)2 * N * A * 4 + (long)2 * N * max_chunks * 4 +
          (long)(total_gt + 8) * 4 + (long)2 * N * 8 + (long)N * A + 512;
 }
@@ -842,7 +873,21 @@ extern "C" int sw_rpn_label_anchors(int N, long A, const float* anchors, const f
                                     float thr_lo, float thr_hi, int batch_size, int max_pos, const uint64_t* seeds,
                                     int8_t* labels, float* matched, void* workspace, long workspace_bytes, hipStream_t stream) {
   SW_ENTER();
-  if (N < 1 || N > 8 || 2 * N > MAX_SEG || A < 1 || A > 0x3FFFFFFFL) return -5;
+  if (N < 1 || A < 1 || A > 0x3FFFFFFFL) return -5;
+  if (N > LABEL_MAX_IMG) {
+    // per-image tables travel by value (LABEL_MAX_IMG entries): more images run as consecutive calls over image ranges (outputs are
+    // per image, seeds per image, the workspace is reused in stream order)
+    int g0 = 0;
+    for (int i0 = 0; i0 < N; i0 += LABEL_MAX_IMG) {
+      const int nc = N - i0 < LABEL_MAX_IMG ? N - i0 : LABEL_MAX_IMG;
+      const int rc = sw_rpn_label_anchors(nc, A, anchors, gt_boxes ? gt_boxes + (long)g0 * 4 : nullptr, gt_count_per_image + i0, thr_lo, thr_hi,
+                                          batch_size, max_pos, seeds + 2 * i0, labels + (long)i0 * A, matched + (long)i0 * A * 4, workspace,
+                                          workspace_bytes, stream);
+      if (rc) return rc;
+      for (int i = 0; i < nc; ++i) g0 += gt_count_per_image[i0 + i];
+    }
+    return 0;
+  }
   int total_gt = 0;
   for (int i = 0; i < N; ++i) total_gt += gt_count_per_image[i];
   if (workspace_bytes < sw_rpn_label_workspace_bytes(N, A, total_gt)) return -6;
@@ -886,7 +931,18 @@ extern "C" int sw_roi_label_sample(int n_img, const int* p_cnt_dev, int p_stride
                                    int32_t* out_count, int32_t* out_index, int32_t* out_classes, float* out_boxes, float* out_gt_boxes,
                                    hipStream_t stream) {
   SW_ENTER();
-  if (n_img < 1 || n_img > 8 || out_stride < batch_size || batch_size < 1 || max_pos < 0 || max_pos > batch_size) return -5;
+  if (n_img < 1 || out_stride < batch_size || batch_size < 1 || max_pos < 0 || max_pos > batch_size) return -5;
+  if (n_img > ROI_MAX_IMG) {                                            // image ranges (one workgroup per image: nothing is shared)
+    for (int i0 = 0; i0 < n_img; i0 += ROI_MAX_IMG) {
+      const int nc = n_img - i0 < ROI_MAX_IMG ? n_img - i0 : ROI_MAX_IMG;
+      const int rc = sw_roi_label_sample(nc, p_cnt_dev + i0, p_stride, proposals + (long)i0 * p_stride * 4, g_off + i0, g_cnt + i0, gt_boxes,
+                                         gt_classes, append_gt, iou_thresh, num_classes, batch_size, max_pos, seeds + 2 * i0, out_stride,
+                                         out_count + i0, out_index + (long)i0 * out_stride, out_classes + (long)i0 * out_stride,
+                                         out_boxes + (long)i0 * out_stride * 4, out_gt_boxes + (long)i0 * out_stride * 4, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   RoiSampleArgs ra = {};
   ra.n_img = n_img; ra.p_stride = p_stride;
   for (int i = 0; i < n_img; ++i) {
@@ -936,12 +992,12 @@ extern "C" int sw_rpn_unpack_bwd(int N, int L, int A, const int* hw_per_level, c
 extern "C" int sw_roi_assign_levels(int n_img, const int* row_cnt, const long* box_off_floats, const float* boxes, float* rois,
                                     int32_t* level_of, int32_t* sel, int32_t* sel_cnt, hipStream_t stream) {
   SW_ENTER();
-  if (n_img < 1 || n_img > 8) return -5;
+  if (n_img < 1 || n_img > ROI_MAX_IMG) return -5;                      // (the per-level lists run over all images: one call, one table)
   LevelArgs g = {};
   g.n_img = n_img;
   int R = 0;
   for (int i = 0; i < n_img; ++i) { g.row_off[i] = R; g.row_cnt[i] = row_cnt[i]; g.box_off[i] = box_off_floats[i]; R += row_cnt[i]; }
-  if (R > 8192) return -6;
+  if (R > (1 << 20)) return -6;
   if (R == 0) return (int)hipMemsetAsync(sel_cnt, 0, 16, stream);
   hipLaunchKernelGGL(roi_levels_kernel, dim3(1), dim3(1024), 0, stream, g, R, boxes, rois, level_of, sel, sel_cnt);
   SW_CHECK_LAUNCH();

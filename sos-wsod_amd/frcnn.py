@@ -1308,9 +1308,15 @@ class StandardROIHeadsPseudoLab(nn.Module):
             gt_b = gt_c = None
         seeds = [self.sampler.next_seed() for _ in range(2 * N)]                            # (foreground, background) per image
         cnt, idx, cls, both = ops.roi_label_sample(cnt_dev, buf, gt_b, gt_c, counts, seeds, append_gt, 0.5, K, B, int(B * self.positive_fraction))
+        # Rows per image = num_pos + num_neg of sampling.py:36-47 = min(n_pos, max_pos) + min(n_neg, B - num_pos): LESS than min(B, candidates)
+        # when an image has more than max_pos foreground candidates and fewer than B - max_pos background ones (200 fg + 100 bg -> 228,
+        # not 300).  Only the kernel knows n_pos, so its count is read (one host read per call; the rows beyond it are class -1 / empty
+        # boxes, never stale memory).  Without ground truth every candidate is background: the count is min(B, candidates), no read.
+        need = [i for i in range(N) if counts[i] > 0]
+        got = cnt.tolist() if need else None
         out = []
         for i, p in enumerate(proposals):
-            n = min(B, len(p) + (counts[i] if append_gt else 0))        # every candidate is foreground or background: the count is known
+            n = int(got[i]) if got is not None else min(B, len(p))
             s_ = Instances(p.image_size)
             s_.proposal_boxes = Boxes(both[0, i, :n]); s_.gt_classes = cls[i, :n]; s_.gt_boxes = Boxes(both[1, i, :n])
             s_._sw_dense = (both, cls, i, n)

@@ -112,6 +112,16 @@ class grad_scope:
         self.bufs, self.uses, self.queued = {}, {}, {}
         return self
 
+    def finish(self):
+        """Call between `backward()` and `optimizer.step()`: every queued weight gradient must have been run by its last use.  A
+        counted use whose backward node never ran leaves the buffer autograd was handed unfinished (uninitialised memory): raise
+        BEFORE the optimizer applies it."""
+        left = [k for k, q in self.queued.items() if q["probs"]]
+        if left:
+            self.bufs, self.uses, self.queued = {}, {}, {}
+            raise RuntimeError(f"grad_scope: {len(left)} queued weight gradient(s) were never finished — a use counted in the forward pass "
+                               "did not take part in backward(); run this graph without ops.grad_scope")
+
     def __exit__(self, exc_type, *exc):
         global GRAD_SCOPE
         GRAD_SCOPE = self._prev
@@ -124,8 +134,9 @@ class grad_scope:
 
 
 def count_use(key):
-    """forward side: this pass will contribute one weight-gradient node for `key`"""
-    if GRAD_SCOPE is not None and key is not None:
+    """forward side: this pass will contribute one weight-gradient node for `key`.  A pass under torch.no_grad() builds no node
+    (ctx.needs_input_grad stays True for a parameter that requires grad, so the caller's own test does not see it): not counted."""
+    if GRAD_SCOPE is not None and key is not None and torch.is_grad_enabled():
         GRAD_SCOPE.uses[key] = GRAD_SCOPE.uses.get(key, 0) + 1
 
 
@@ -1007,6 +1018,9 @@ def roi_assign_levels(boxes_base, row_cnt, box_off_floats):
     _need_gpu(boxes_base)
     n = len(row_cnt)
     R = int(sum(row_cnt))
+    if n > 64 or R > (1 << 20):
+        raise ValueError(f"sw_roi_assign_levels takes at most 64 images and 2^20 boxes per call (got {n} images, {R} boxes): its per-level "
+                         "row lists run over all images of the call; pool larger batches in several calls")
     dev = boxes_base.device
     rois = torch.empty(R, 5, device=dev); lv = torch.empty(R, device=dev, dtype=torch.int32)
     sel = torch.empty(4, max(R, 1), device=dev, dtype=torch.int32); cnt = torch.empty(4, device=dev, dtype=torch.int32)

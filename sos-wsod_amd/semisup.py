@@ -50,12 +50,18 @@ def update_teacher_model(student: torch.nn.Module, teacher: torch.nn.Module, kee
                 fused_t.append(v); fused_s.append(s)
             else:
                 rest.append((v, s))
-        hit = (weakref.ref(student), ptrs, ops.EmaPlan(fused_t, fused_s), rest)
+        hit = (weakref.ref(student), ptrs, ops.EmaPlan(fused_t, fused_s), rest, list(teacher.parameters()))
         _EMA_PLANS[teacher] = hit
     for v, s in hit[3]:
         v.copy_(s * (1 - keep_rate) + v * keep_rate)
     hit[2].run(keep_rate)
-    ops.invalidate_all_staged(); ops.BUFFER_EPOCH += 1     # the kernel wrote the teacher's state behind torch's version counters: cached copies are stale
+    # the kernel wrote the TEACHER's state behind torch's version counters: its cached compute-dtype copies are stale — the teacher's
+    # only (a wholesale ops.invalidate_all_staged() here re-staged every frozen weight of every model alive in the process once per
+    # iteration: the student's stem / res2, a VGG / OICR model next to it)
+    ops.PARAM_EPOCH += 1
+    for p_ in hit[4]:
+        ops.mark_updated(p_)
+    ops.BUFFER_EPOCH += 1
 
 
 def threshold_bbox(data_inst: Optional[dict], proposals: Instances, thres: float = 0.7, proposal_type: str = "roih",
@@ -247,6 +253,8 @@ class SemiSupStep:
         losses = sum(loss_dict.values())
         self.optimizer.zero_grad()
         losses.backward()
+        if ops.GRAD_SCOPE is not None:
+            ops.GRAD_SCOPE.finish()                   # a queued weight gradient that never ran must not reach the optimizer
         self.optimizer.step()
         self.iter += 1
         return record, loss_dict

@@ -451,6 +451,118 @@ def test_roi_label_sample_kernel_against_the_oracle(ops, P, n_gt, append):
         assert (cls[i, :n] != K).sum() <= 128
 
 
+def test_roi_label_sample_short_batch_more_foreground_than_the_cap_and_few_background(ops):
+    """sampling.py:36-47: num_pos = min(n_pos, B * frac), num_neg = min(n_neg, B - num_pos).  An image with MORE foreground candidates than
+    the cap and FEWER background ones than B - cap returns fewer rows than min(B, candidates) (200 fg + 100 bg + 2 gt -> 128 + 100 = 228,
+    not 302): the kernel's count says so, rows beyond it are class -1 / empty boxes (never stale memory), and the module level
+    (`label_and_sample_proposals`) hands on exactly the counted rows — ADVICE r4: the host used to assume min(B, candidates)."""
+    from sos_wsod_amd.frcnn import StandardROIHeadsPseudoLab
+    from sos_wsod_amd.structures import Boxes, Instances
+    K, B = 20, 512
+    rng = np.random.RandomState(77)
+    H, W = 400, 600
+    gb = np.array([[50, 60, 250, 260], [300, 100, 520, 330]], np.float32); gc = np.array([3, 11])
+    fg = gb[rng.randint(0, 2, 200)] + rng.randn(200, 4).astype(np.float32) * 3          # IoU with its gt box well above 0.5
+    x1 = rng.rand(100) * 40; y1 = 340 + rng.rand(100) * 20
+    bg = np.stack([x1, y1, x1 + 12, y1 + 12], 1).astype(np.float32)                      # far from both gt boxes
+    pb = np.concatenate([fg, bg], 0)[rng.permutation(300)].astype(np.float32)
+    tag = "roishort"
+    want = FO.roi_label_and_sample([{"boxes": pb}], [(gb, gc)], K, FO.Perm(tag), append_gt=True)
+    assert len(want[0]["sampled_idx"]) == 228
+    buf = torch.full((1, 320, 4), 7.0, device="cuda"); buf[0, :300] = torch.from_numpy(pb).cuda()
+    cnt, idx, cls, both = ops.roi_label_sample(torch.tensor([300], dtype=torch.int32).cuda(), buf, torch.from_numpy(gb).cuda(),
+                                               torch.from_numpy(gc.astype(np.int32)).cuda(), [2], [_seed(tag, 0), _seed(tag, 1)], True, 0.5, K, B, 128)
+    torch.cuda.synchronize()
+    n = int(cnt[0])
+    assert n == 228
+    assert np.array_equal(idx[0, :n].cpu().numpy(), want[0]["sampled_idx"])
+    assert np.array_equal(cls[0, :n].cpu().numpy(), want[0]["gt_classes"])
+    assert np.array_equal(both[0, 0, :n].cpu().numpy(), want[0]["boxes"])
+    assert (cls[0, n:] == -1).all() and (idx[0, n:] == -1).all() and float(both[:, 0, n:].abs().max()) == 0.0
+    # the module level: Instances of exactly the counted rows, the dense fast path (every image a full batch) not taken
+    heads = StandardROIHeadsPseudoLab(K, _Keys(tag))
+    prop = Instances((H, W)); prop.proposal_boxes = Boxes(torch.from_numpy(pb).cuda())
+    tgt = Instances((H, W)); tgt.gt_boxes = Boxes(torch.from_numpy(gb).cuda()); tgt.gt_classes = torch.from_numpy(gc).cuda()
+    out = heads.label_and_sample_proposals([prop], [tgt], True)
+    assert len(out[0]) == 228 and out[0]._sw_dense[3] == 228
+    assert np.array_equal(out[0].gt_classes.cpu().numpy(), want[0]["gt_classes"])
+    assert np.array_equal(out[0].proposal_boxes.tensor.cpu().numpy(), want[0]["boxes"])
+
+
+def test_index_side_kernels_take_more_than_eight_images(ops):
+    """the per-image tables of csrc/proposals.hip travel by value in the kernel arguments (8 images / 40 segments); a
+    supervised call of voc_ssod.yaml on one GPU is label_q + label_k = 16 images.  The entry points now walk image ranges: 11 images
+    through sw_rpn_label_anchors, sw_rpn_select_pack, sw_roi_label_sample and sw_roi_assign_levels must equal the same images run in
+    two calls of <= 8 (which the tests above pin against the oracle)."""
+    N = 11
+    rng = np.random.RandomState(3)
+    h, w = 96, 128
+    grids = [((h + s - 1) // s, (w + s - 1) // s) for s in (4, 8, 16, 32, 64)]
+    anchors = torch.from_numpy(np.concatenate(FO.grid_anchors(grids), 0).astype(np.float32)).cuda()
+    n_gt = [int(v) for v in rng.randint(0, 4, N)]
+    gts = []
+    for n in n_gt:
+        x1 = rng.rand(n) * (w - 40); y1 = rng.rand(n) * (h - 40)
+        gts.append(np.stack([x1, y1, x1 + 16 + rng.rand(n) * 20, y1 + 16 + rng.rand(n) * 20], 1).astype(np.float32))
+    cat = torch.from_numpy(np.concatenate(gts, 0)).cuda()
+    seeds = [_seed("many", k) for k in range(2 * N)]
+    split = 6
+    g0 = sum(n_gt[:split])
+
+    def two(fn_all, fn_a, fn_b):
+        a, b = fn_a(), fn_b()
+        return fn_all(), [torch.cat([x, y], 0) for x, y in zip(a, b)]
+    # anchors -> labels
+    got, want = two(lambda: ops.rpn_label_anchors(anchors, cat, n_gt, seeds, 256, 64),
+                    lambda: ops.rpn_label_anchors(anchors, cat[:g0], n_gt[:split], seeds[:2 * split], 256, 64),
+                    lambda: ops.rpn_label_anchors(anchors, cat[g0:].contiguous(), n_gt[split:], seeds[2 * split:], 256, 64))
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+    # top-k selection + decode
+    n_l = [3000, 800, 200, 60, 20]
+    lv_anchors, logits, deltas = [], [], []
+    for n in n_l:
+        x1 = rng.rand(n) * (w - 20); y1 = rng.rand(n) * (h - 20)
+        lv_anchors.append(torch.from_numpy(np.stack([x1, y1, x1 + 8 + rng.rand(n) * 60, y1 + 8 + rng.rand(n) * 40], 1).astype(np.float32)).cuda())
+        logits.append(torch.from_numpy((np.round(rng.randn(N, n) * 8) / 8).astype(np.float32)).cuda())
+        deltas.append(torch.from_numpy((rng.randn(N, n, 4) * 0.3).astype(np.float32)).cuda())
+    img_hw = torch.tensor([[h, w]] * N, dtype=torch.int32).cuda()
+    sel = lambda a, b: ops.rpn_select_pack([l[a:b].contiguous() for l in logits], [d[a:b].contiguous() for d in deltas], lv_anchors, 500,
+                                           (1.0, 1.0, 1.0, 1.0), float(np.log(1000.0 / 16)), img_hw[a:b].contiguous())
+    got, want = two(lambda: sel(0, N), lambda: sel(0, split), lambda: sel(split, N))
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+    # the single-tensor (anchor order) form of the same call
+    lg1 = torch.cat(logits, 1).contiguous(); dl1 = torch.cat(deltas, 1).contiguous()
+    one = ops.rpn_select_pack(lg1, dl1, lv_anchors, 500, (1.0, 1.0, 1.0, 1.0), float(np.log(1000.0 / 16)), img_hw)
+    for x, y in zip(one, got):
+        assert torch.equal(x, y)
+    # ROI matching + sampling
+    P = 600
+    buf = torch.from_numpy(np.concatenate([rng.rand(N, P, 2) * 60, 70 + rng.rand(N, P, 2) * 50], 2).astype(np.float32)).cuda()
+    pc = torch.from_numpy(rng.randint(500, P + 1, N).astype(np.int32)).cuda()
+    cc = torch.from_numpy(rng.randint(0, 20, sum(n_gt)).astype(np.int32)).cuda()
+    rs = lambda a, b: ops.roi_label_sample(pc[a:b].contiguous(), buf[a:b].contiguous(), cat[sum(n_gt[:a]):sum(n_gt[:b])].contiguous(),
+                                           cc[sum(n_gt[:a]):sum(n_gt[:b])].contiguous(), n_gt[a:b], seeds[2 * a:2 * b], True, 0.5, 20, 512, 128)
+    full, a_, b_ = rs(0, N), rs(0, split), rs(split, N)
+    assert torch.equal(full[0], torch.cat([a_[0], b_[0]])) and torch.equal(full[1], torch.cat([a_[1], b_[1]]))
+    assert torch.equal(full[2], torch.cat([a_[2], b_[2]])) and torch.equal(full[3], torch.cat([a_[3], b_[3]], 1))
+    # FPN levels over 11 images / 11 * 1000 boxes (> the old 8192-row cap)
+    boxes = torch.from_numpy(np.concatenate([rng.rand(N, 1000, 2) * 300, 310 + rng.rand(N, 1000, 2) * 400], 2).astype(np.float32)).cuda()
+    rois, lv, sl, cnt = ops.roi_assign_levels(boxes, [1000] * N, [i * 4000 for i in range(N)])
+    torch.cuda.synchronize()
+    assert np.array_equal(rois[:, 0].cpu().numpy(), np.repeat(np.arange(N), 1000).astype(np.float32))
+    assert torch.equal(rois[:, 1:], boxes.view(-1, 4))
+    b = boxes.view(-1, 4)
+    want_lv = torch.clamp(torch.floor(4 + torch.log2(torch.sqrt((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])) / 224 + 1e-8)), 2, 5).to(torch.int32) - 2
+    assert int((lv != want_lv).sum()) <= 2                                # (log2 ulps at a level edge)
+    for l in range(4):
+        n = int(cnt[l])
+        assert torch.equal(sl[l, :n], torch.nonzero(lv == l).flatten().to(torch.int32))
+    with pytest.raises(ValueError, match="at most 64 images"):
+        ops.roi_assign_levels(boxes, [1] * 65, [0] * 65)
+
+
 # ------------------------------------------------------------------------------------------ the step on the real modules
 def test_semisup_step_burn_in_and_semi_supervised_iteration_on_the_real_detector():
     """unbias/ubteacher/engine/trainer.py:436-549 with the real student / teacher: iteration 0 = burn-in (supervised branch on the

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Does the steady-state training step still call hipMalloc / hipFree (caching-allocator misses)?"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

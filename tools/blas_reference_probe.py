@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Orientation only (not a product path): what the vendor BLAS behind torch.mm reaches at the fc6 / fc7 GEMM shapes of the step on
 this GPU, next to sw_gemm's figures in the bench line.  bf16 in, bf16 / f32 out."""
 import torch, time

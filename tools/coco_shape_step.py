@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """One-GPU step at BASELINE config #4's shape: 800x1333 views (F = 99x165), R = 4000 proposals, K = 80 classes"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """cProfile of the host side of the training step (who spends the CPU time between kernel launches)."""
 import cProfile
 import os

@@ -1,7 +1,9 @@
-#!/usr/bin/env python
 """The data-parallel step on an RCCL process group of world size 1 (one GPU) at BASELINE config #2's shape: N eager DDP steps,
-for `rocprofv3 --kernel-trace --stats` (what does a rank launch per step beyond the single-process step?) and for timing.
-    python tools/ddp_world1_step.py [steps] [ddp: 1|0]"""
+for a kernel trace (what does a rank launch per step beyond the single-process step?) and for timing.
+    python tools/ddp_world1_step.py [steps] [ddp: 1|0]
+    rocprofv3 --kernel-trace --stats -d gpurun_out/ddp -- python tools/ddp_world1_step.py 20 1
+(no shebang on purpose: under rocprofv3 the interpreter itself must follow `--`; an env / shell hop would exec after the profiler's
+preloaded library has initialised the GPU, which this pool forbids)"""
 import os, sys, time, socket, datetime
 import torch, torch.distributed as dist
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")

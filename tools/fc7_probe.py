@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """fc7-sized GEMMs (8000 x 4096 x 4096: 2 rounds of 256x256 tiles with only 64 K-steps each) under the tile / loop variants the
 development switches select (run one process per variant: SW_GEMM_V, SW_GEMM_PP are read once)."""
 import os, sys, torch

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Randomised parity sweep of the integer / index kernels against the oracle (development aid, not a test: the pytest suite
 holds the fixed cases).  ROIPool forward over random map sizes (plane / band / narrow-slab / gather forms), dtypes, ROI sets with
 degenerate and out-of-image boxes: bins, argmax and values bit-exact vs oracle/roipool_oracle.c, the backward within the

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """1x1-convolution-shaped GEMMs (many pixels, few channels: memory bound) on the 256x256 ping-pong tile against the 128x128 one
 (SW_GEMM_V=8 forces the small tile).  y (P, N) = x (P, K) @ W^T (N, K), bf16, bias + ReLU epilogue."""
 import os, sys, torch

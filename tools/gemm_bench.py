@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Micro-benchmark of the MFMA GEMM / implicit-GEMM conv kernels on the hot path's shapes (GPU only).
 usage: python tools/gemm_bench.py [filter]"""
 import os

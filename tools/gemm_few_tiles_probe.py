@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Few-tile, long-K GEMMs of the Stage-3 detector (res4 / res5 1x1 convolutions, their data and weight gradients, the box head's fc6
 at 512-1024 ROIs): SW_GEMM_DEEP=0 (2-buffer ring) against the default (4-buffer ring when tiles x splits <= 256, K >= 512)."""
 import os, sys, torch

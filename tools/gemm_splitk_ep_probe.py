@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """bf16-output GEMMs with an epilogue (bias + residual + ReLU) as ONE launch against split-K slabs + the fold that applies the
 epilogue (sw_gemm with splitk > 1 and a non-plain epilogue), on the few-tile shapes of the Stage-3 detector."""
 import os, sys, torch

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Inference throughput (not a BASELINE metric): single 512x512 view, and the reference's TTA (6 scales x h-flip) of a 375x500 image,
 2000 proposals.  Shows where the test-time path spends its time."""
 import os, sys, time, torch

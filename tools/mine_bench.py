@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """sw_oicr_mine_label alone (4 refinement rounds, as the step launches it): R proposals, G image-level classes, top 10 % per class"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Training steps on mapper-built views of a VOC-sized image (375x500, 2000 proposals) at the recipe's scale pairs:
 which kernels fall off their fast paths when the two view pairs have different, non-square sizes?"""
 import os, sys, time, torch

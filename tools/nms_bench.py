@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """sw_detect_postprocess in its RPN use (frcnn.PseudoLabRPN.predict_proposals): 5 levels as classes, 2000 / 2000 / 2000 / 2000 / 741
 candidates, anchor-like boxes on an 800 x 1216 image, NMS 0.7, best 1000."""
 import os, sys, torch

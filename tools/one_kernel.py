@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Run ONE hot-path kernel shape a few times (for rocprofv3 --pmc passes).
 usage: one_kernel.py conv5_3|conv3_2|wgrad*|wgrad_grouped|roi_fwd|roi_bwd|fc6_fwd|fc6_dgrad|fc6_wgrad [repeats]"""
 import os, sys, torch

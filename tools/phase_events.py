@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """GPU time of the step's phases from events recorded on the main stream (no host syncs inside the step)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

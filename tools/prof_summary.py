@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Condense a rocprofv3 --kernel-trace --stats run (…_kernel_stats.csv) into a per-step table for profiles/."""
 import csv
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """ROIPool forward / backward alone at the benchmark shape (2 x 63 x 63 x 512 map, 4000 ROIs), bytes of output + argmax per second."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """ROIPool forward / backward at a given map size (env RH, RW, RR; default the VOC-sized 76 x 114 map, 4000 ROIs on 2 images): which
 slab width is faster when the plane exceeds 76 KiB?  SW_ROI_FWD_PXB=16|8|4|0 forces the forward's slab bytes per pixel (0 = gather)."""
 import os, sys, torch

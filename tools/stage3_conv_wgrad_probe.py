@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """3x3 weight gradients of the Stage-3 detector's shapes (sw_conv3x3_wgrad: K-split gather GEMM + fold) for several split counts.
 usage: stage3_conv_wgrad_probe.py   (GPU only)"""
 import os, sys, torch

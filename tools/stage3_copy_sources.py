@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Where do the memcpy / fill / at::native launches of one Stage-3 iteration come from?  torch.profiler over ONE iteration; every aten
 op that launches a copy / fill / elementwise kernel is reported with the chain of profiler events that enclose it (autograd nodes,
 module-level record_function ranges).  (development tool)"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Which GEMMs does one Stage-3 iteration launch, and how fast is each?  ops.gemm is wrapped to log (M, N, K, operand forms,
 epilogue) for ONE iteration; every distinct shape is then timed alone (20 launches between two events) with the same operand
 forms.  Output: per shape count x time, bytes, GB/s, TFLOP/s, sorted by time per iteration.  (development tool, GPU only)"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """1x1 weight gradients of one bottleneck block (conv1, conv3, shortcut) for the student's two passes: one sw_gemm per weight and
 pass (K-split + fold each) against ONE sw_gemm_kk_grouped launch over all of them + ONE sw_splitk_fold_multi."""
 import os, sys, torch

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Would the grouped 256x256 weight-gradient launch (sw_conv3x3_wgrad_grouped, one launch for a list of problems + ONE fold over
 all their slabs) pay for the Stage-3 detector's repeated uses of a 3x3 weight?  Sets: the RPN head's convolution (5 levels x
 batch 2 and batch 1), an FPN output convolution (2 uses), res4 / res5 conv2 (2 uses).  Against one sw_conv3x3_wgrad per use."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """One GPU's share of the Stage-3 (Unbiased-Teacher) semi-supervised step at BASELINE config #5's shape: per GPU one labelled and
 one unlabelled image, each in a strong and a weak view (voc_ssod.yaml: 8 + 8 images over 8 GPUs) -> teacher forward on 1 image,
 student forward + backward on 2 + 1 images, SGD, teacher EMA.  usage: stage3_step.py [bf16|fp32] [H W]   (also imported by bench.py)"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Weight-gradient GEMMs of the Stage-3 detector's 1x1 convolutions / fc layers (dW (out, in) = dY^T (out, P) @ X (P, in), K = P
 pixels): the K-strided form `frcnn._LinearFn.backward` launches, at several split-K factors, against explicit transposes + the
 K-contiguous form.  Shapes: ResNet-50 + FPN laterals + box head at 800 x 1216, 2 images."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Wall-clock split of one training step into phases. Synchronises between phases, so the sum exceeds the pipelined
 step bench.py reports; use it to see where the step goes, not as a throughput number."""
 import os

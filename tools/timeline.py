@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Per-step kernel timeline from a rocprofv3 --kernel-trace CSV: start, duration, queue, and the GPU-idle gap before
 each kernel (time since the latest end of any earlier kernel).  usage: timeline.py kernel_trace.csv [step_from_end]"""
 import csv

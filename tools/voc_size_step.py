@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Step time at a VOC-like non-square size (not the benchmark configuration): which kernels fall off their fast paths?"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """What would a conv weight gradient reach as an NN GEMM (A = dy^T K-contiguous, B K-strided, no gather)?  M = Cout, N = 9 Cin,
 K = pixels, split-K slabs as the grouped launch uses them.  Compare with TN (both K-strided), the form the grouped kernel runs."""
 import os, sys, torch
