@@ -91,10 +91,9 @@ def build(device, dtype, K=None, freeze_at=2):
     return model.to(device)
 
 
-def cpu_baseline():
-    """The oracle's restatement of the same step (fp32, torch-CPU contractions + C ROIPool), one full-size iteration."""
+def _cpu_params(K_):
+    """random-init parameters of the benchmarked architecture under the reference's state-dict names (numpy, fp32)"""
     from oracle import oicr_oracle as O
-    threads = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
     P = {}
     for stage, cin, cout, nconv, _, _ in O.VGG_CFG:
@@ -108,36 +107,53 @@ def cpu_baseline():
         P[f"roi_heads.box_head.fc{i + 1}.bias"] = np.full(d, 0.1, np.float32)
         d_in = d
     for n in ("cls", "det"):
-        P[f"roi_heads.box_predictor.{n}.weight"] = (torch.randn(K, d_in, generator=g) * 0.02).numpy()
-        P[f"roi_heads.box_predictor.{n}.bias"] = np.zeros(K, np.float32)
+        P[f"roi_heads.box_predictor.{n}.weight"] = (torch.randn(K_, d_in, generator=g) * 0.02).numpy()
+        P[f"roi_heads.box_predictor.{n}.bias"] = np.zeros(K_, np.float32)
     for k in range(4):
-        P[f"roi_heads.box_refinery_{k}.cls_score.weight"] = (torch.randn(K + 1, d_in, generator=g) * 0.01).numpy()
-        P[f"roi_heads.box_refinery_{k}.cls_score.bias"] = np.zeros(K + 1, np.float32)
-        P[f"roi_heads.box_refinery_{k}.bbox_pred.weight"] = (torch.randn(4 * K, d_in, generator=g) * 0.001).numpy()
-        P[f"roi_heads.box_refinery_{k}.bbox_pred.bias"] = np.zeros(4 * K, np.float32)
-    views, gt = O.make_views(H, W, R, n_gt=2, K=K, scale2=1.0, tag="cpubase")
-    masks = [[(torch.rand(R, d, generator=g) >= 0.5).numpy().astype(np.uint8) for d in DAN] for _ in range(4)]
-    # warm-up first (page faults of the 544 MB weight set, thread-pool start), then the median of the timed
-    # iterations with the forward / backward split; bounded by `budget_s` so that the default bench run stays within minutes
-    n_warm, n_timed, budget_s = 1, 3, 60.0
-    t_all = time.perf_counter()
+        P[f"roi_heads.box_refinery_{k}.cls_score.weight"] = (torch.randn(K_ + 1, d_in, generator=g) * 0.01).numpy()
+        P[f"roi_heads.box_refinery_{k}.cls_score.bias"] = np.zeros(K_ + 1, np.float32)
+        P[f"roi_heads.box_refinery_{k}.bbox_pred.weight"] = (torch.randn(4 * K_, d_in, generator=g) * 0.001).numpy()
+        P[f"roi_heads.box_refinery_{k}.bbox_pred.bias"] = np.zeros(4 * K_, np.float32)
+    return P, g
+
+
+def _cpu_time_config(P, g, R_, scale2, n_warm, n_timed, tag):
+    """SURVEY §8d / BASELINE.md §4 protocol: `n_warm` untimed iterations (page faults of the 544 MB weight set, thread-pool start),
+    then the MEDIAN of `n_timed` timed ones, each a full forward + backward of one 4-view OICR+ iteration through the oracle, with the
+    seconds of every stage (backbone / ROIPool / fc6+fc7 / heads) of the median run"""
+    from oracle import oicr_oracle as O
+    views, gt = O.make_views(H, W, R_, n_gt=2, K=K, scale2=scale2, tag=tag)
+    masks = [[(torch.rand(R_, d, generator=g) >= 0.5).numpy().astype(np.uint8) for d in DAN] for _ in range(4)]
     runs = []
     for i in range(n_warm + n_timed):
         t0 = time.perf_counter()
         _, aux, _ = O.oicr_plus_iteration(P, views, gt, masks, K=K, want_grads=True)
         dt = time.perf_counter() - t0
         if i >= n_warm:
-            runs.append((dt, aux["timing"]["fwd_s"], aux["timing"]["bwd_s"]))
-        if i >= n_warm and time.perf_counter() - t_all > budget_s:
-            break
-    runs.sort()
-    dt, fwd_s, bwd_s = runs[len(runs) // 2]
-    return {"value": round(4.0 / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
-            "fwd_s": round(fwd_s, 2), "bwd_s": round(bwd_s, 2), "iteration_s": round(dt, 2), "timed_iterations": len(runs),
-            "warmup_iterations": n_warm, "all_iteration_s": [round(r[0], 2) for r in runs],
-            "sample": f"median of {len(runs)} full OICR+ iterations after {n_warm} warm-up (4 views {H}x{W}, R={R}, K={K}, fp32) forward+backward "
-                      f"through the oracle (torch-CPU contractions with {threads} threads + single-thread C ROIPool), no optimizer step; "
-                      f"{dt:.1f} s per iteration = {fwd_s:.1f} s forward + {bwd_s:.1f} s backward"}
+            runs.append((dt, aux["timing"]))
+    runs.sort(key=lambda r: r[0])
+    dt, tm = runs[len(runs) // 2]
+    rd = lambda d: {k: round(v, 2) for k, v in d.items()}
+    return {"value": round(4.0 / dt, 4), "iteration_s": round(dt, 2), "fwd_s": round(tm["fwd_s"], 2), "bwd_s": round(tm["bwd_s"], 2),
+            "fwd_stage_s": rd(tm["fwd_stage_s"]), "bwd_stage_s": rd(tm["bwd_stage_s"]),
+            "timed_iterations": len(runs), "warmup_iterations": n_warm, "all_iteration_s": [round(r[0], 2) for r in runs]}
+
+
+def cpu_baseline():
+    """The oracle's restatement of the same step (fp32, torch-CPU contractions + the serial C ROIPool the reference's CPU file states),
+    at BASELINE config #2's shape (the one `value` is quoted on) and at config #1's (the reference's own CPU-runnable case)."""
+    threads = torch.get_num_threads()
+    P, g = _cpu_params(K)
+    c2 = _cpu_time_config(P, g, R, 1.0, 2, 5, "cpubase")
+    c1 = _cpu_time_config(P, g, 500, 1.25, 2, 5, "cpubase1")
+    out = {"value": c2["value"], "unit": "images/s", "cores": threads, "kind": "port"}
+    out.update({k: v for k, v in c2.items() if k != "value"})
+    out["config1"] = dict(c1, unit="images/s", shape=f"views {H}x{W} + {int(H * 1.25 + 0.5)}x{int(W * 1.25 + 0.5)}, R=500, K={K}, fp32")
+    out["sample"] = (f"median of {c2['timed_iterations']} full OICR+ iterations after {c2['warmup_iterations']} warm-ups (4 views {H}x{W}, R={R}, "
+                     f"K={K}, fp32) forward+backward through the oracle (torch-CPU contractions with {threads} threads; ROIPool = the serial C "
+                     f"loop of the reference's CPU file), no optimizer step; {c2['iteration_s']:.1f} s per iteration = {c2['fwd_s']:.1f} s forward "
+                     f"+ {c2['bwd_s']:.1f} s backward; per-stage seconds in fwd_stage_s / bwd_stage_s; config #1's shape under `config1`")
+    return out
 
 
 def main():

@@ -9,9 +9,12 @@ CPU restatement of the model-independent parts of the Stage-3 Unbiased-Teacher s
   /root/reference/unbias/ubteacher/modeling/roi_heads/fast_rcnn.py
     :73-105   comput_focal_loss / FocalLoss.forward   (CE = cross_entropy(x, t); p = exp(-CE); sum (1 - p)^gamma CE / N)
 
-PARITY PINNING: parity unpinned — the reference file imports the whole detectron2 engine / data stack (absent here: fvcore,
-yacs, …), so no fixture could be generated from it; these few lines are restated from the source text cited above and the
-reference's tests hold no vectors for them.
+PARITY PINNING: pinned (round 5).  tests/golden/make_stage3_step_golden.py loads the reference's trainer file from where it lies (its
+engine / data / evaluation / checkpoint imports registered as placeholders: imported, never called — the technique of ref_shim_d2.py)
+and RUNS UBTeacherTrainer.run_step_full_semisup, threshold_bbox, process_pseudo_label, add_label and _update_teacher_model as unbound
+methods on the reference's own student / teacher for three iterations (burn-in, copy step, EMA step); tests/golden/stage3_step.npz
+holds what they logged and produced.  tests/test_oracle_stage3_step_cpu.py checks every function below against it: thresholded
+detections bit for bit, the weighted sum the reference differentiated, the teacher tensors after copy and EMA bit for bit.
 """
 import numpy as np
 

@@ -448,3 +448,66 @@ def test_config2_bf16_backbone_backward_teacher_forced_against_the_oracle():
         print("   %-40s %.3e %.6f" % (n, r, c))
     assert len(rows) == 18 and not bad, bad
     torch.set_num_threads(nthreads)
+
+
+def test_config2_bf16_fc6_dgrad_and_wgrad_isolated_against_float64():
+    """The fc6 pair of the backward at BASELINE config #2's size (M = 4 x 2000 ROIs, 25088 -> 4096), each GEMM ALONE and in the exact
+    launch form the heads use (roi_heads_oicrplus._train_backward_fc6 / _train_backward_pool: data gradient = NT on the transposed weight
+    copy with the |max| epilogue, weight gradient = transpose of dZ + NN GEMM with the tail peel) against a float64 contraction of the SAME
+    bf16 operands on the host.  The conv family has such a check (…backbone_backward_teacher_forced…); the end-to-end bf16 tests only bound
+    these two through the 5-19 % chaos floor of two free-running bf16 evaluations.  What is left here is the kernels' own arithmetic:
+    f32 accumulation over K = 4096 / 8000 and the one rounding of a bf16 output.  Operands as in training: pooled >= 0 with zeros,
+    dZ masked by ReLU x dropout (75 % zeros) with a heavy-tailed scale per row."""
+    import sos_wsod_amd.ops as ops
+    from sos_wsod_amd.roi_heads_oicrplus import _padded
+    dev = torch.device("cuda", 0)
+    M, D0, D1 = 8000, 25088, 4096
+    g = torch.Generator(device="cpu").manual_seed(11)
+    bf = torch.bfloat16
+    pooled = _padded(M, D0, dev, bf, pad=64)
+    dz1 = _padded(M, D1, dev, bf)
+    W1T = _padded(D0, D1, dev, bf)
+    for r0 in range(0, M, 1000):                                         # filled in row blocks: the host side stays small
+        x = torch.randn(1000, D0, generator=g).clamp_(min=0) * (0.5 + torch.rand(1000, 1, generator=g) * 3)
+        pooled[r0:r0 + 1000] = x.to(bf).to(dev)
+        z = torch.randn(1000, D1, generator=g) * torch.exp(torch.randn(1000, 1, generator=g) * 2.0) * 1e-4
+        z = z * (torch.rand(1000, D1, generator=g) < 0.25)
+        dz1[r0:r0 + 1000] = z.to(bf).to(dev)
+    for r0 in range(0, D0, 3136):
+        W1T[r0:r0 + 3136] = (torch.randn(3136, D1, generator=g) * 0.005).to(bf).to(dev)
+    # ---- data gradient: dpooled = dZ1 . W1  (M x D0, K = D1), bf16 out, max|.| in the epilogue
+    dpooled = _padded(M, D0, dev, bf, pad=64)
+    amax = ops.fill_zero(torch.empty(1, device=dev, dtype=torch.float32))
+    ops.gemm(dz1, W1T, dpooled, M, D0, D1, ep=ops.make_epilogue(out_dtype=bf, absmax_out=amax))
+    # ---- weight gradient: dW1 = dZ1^T . pooled  (D1 x D0, K = M), f32 out
+    dW1 = torch.empty(D1, D0, device=dev, dtype=torch.float32)
+    dzt = ops.transpose_2d(dz1, torch.empty(D1, M + 64, device=dev, dtype=bf)[:, :M], M, D1)
+    ops.gemm(dzt, pooled, dW1, D1, D0, M, b_kstrided=True)
+    torch.cuda.synchronize()
+    rows_m = torch.tensor(sorted({0, 1, 255, 256, 4095, 4096, 7999} | {int(v) for v in torch.randint(0, M, (41,), generator=g)}))
+    rows_o = torch.tensor(sorted({0, 255, 256, 2047, 4095} | {int(v) for v in torch.randint(0, D1, (43,), generator=g)}))
+    W64 = W1T.cpu().double()                                             # (D0, D1)
+    ref_d = dz1[rows_m.to(dev)].cpu().double() @ W64.t()                 # (48, D0)
+    got_d = dpooled[rows_m.to(dev)].cpu().double()
+    err = (got_d - ref_d).abs()
+    # one bf16 rounding of the output (2^-9 relative) + f32 accumulation over K = 4096 (~1e-6 of the row's scale; bar 1e-5)
+    scale = ref_d.abs().amax(dim=1, keepdim=True)
+    assert bool((err <= ref_d.abs() * 2.0 ** -8 + scale * 1e-5).all()), float((err / (ref_d.abs() * 2.0 ** -8 + scale * 1e-5)).max())
+    rel_d = float((got_d - ref_d).norm() / ref_d.norm())
+    assert rel_d <= 3e-3, rel_d
+    want_max = float((dz1.cpu().double() @ W64[:64].t()).abs().max())   # the |max| epilogue sees every element; checked on a slab it must dominate
+    assert float(amax.item()) >= want_max * (1 - 2.0 ** -8)
+    del W64
+    dzs = dz1[:, rows_o.to(dev)].cpu().double().t().contiguous()         # (48, M)
+    rel_w, worst = 0.0, 0.0
+    num = den = 0.0
+    for c0 in range(0, D0, 3584):
+        ref = dzs @ pooled[:, c0:c0 + 3584].cpu().double()               # (48, 3584)
+        got = dW1[rows_o.to(dev), c0:c0 + 3584].cpu().double()
+        d = got - ref
+        num += float((d * d).sum()); den += float((ref * ref).sum())
+        worst = max(worst, float((d.abs() / ref.abs().amax(dim=1, keepdim=True)).max()))
+    rel_w = (num / den) ** 0.5
+    # f32 output, f32 accumulation over K = 8000 in a fixed tile / split order (incl. the last 512 columns: the split-K tail peel)
+    assert rel_w <= 1e-5 and worst <= 1e-5, (rel_w, worst)                      # (a bf16-sized error would be 4e-3)
+    print(f"fc6 alone, bf16 operands vs float64: dgrad rel-L2 {rel_d:.2e} (bf16 out), wgrad rel-L2 {rel_w:.2e}, worst element / row max {worst:.2e}")

@@ -644,6 +644,91 @@ def test_semisup_step_burn_in_and_semi_supervised_iteration_on_the_real_detector
     print("semi-supervised iteration:", {k: round(float(v), 5) for k, v in record.items() if k.startswith("loss")})
 
 
+def test_semisup_step_against_the_reference_run_of_its_own_trainer_methods(golden_dir):
+    """tests/golden/stage3_step.npz was written by RUNNING the reference's UBTeacherTrainer.run_step_full_semisup (with its
+    threshold_bbox / process_pseudo_label / add_label / _update_teacher_model, unbias/ubteacher/engine/trainer.py:362-604) on the
+    reference's own student and teacher for three iterations: burn-in, the copy step + a semi-supervised step, one EMA update + a
+    semi-supervised step.  `semisup.SemiSupStep` on the HIP detectors, same closed-form weights / data / sampling keys / SGD, must log
+    the same record dict, attach the same pseudo labels, differentiate the same weighted sum and leave the same teacher.
+    Tolerances: RPN losses 1e-4, ROI-head losses 2e-3 (position-based sampling over proposals whose logits tie to ~1e-7, see the test
+    above); the *_pseudo losses 5e-3 (the HIP teacher's boxes differ from the reference's by < 1e-2 px, which moves anchors whose IoU
+    sits within 1e-5 of the 0.3 / 0.7 thresholds)."""
+    from sos_wsod_amd.semisup import SemiSupStep
+    from sos_wsod_amd.structures import Boxes, Instances
+    G = np.load(os.path.join(golden_dir, "stage3_step.npz"))
+    K = int(G["K"])
+    sizes = [tuple(int(v) for v in s_) for s_ in G["sizes"]]
+    P = FO.make_params(K, tag="s3s", head_scale=float(G["head_scale"]))
+    student, teacher = _model(K, P, "s3s"), _model(K, P, "s3s")
+    student.train(); teacher.train()
+    student.proposal_generator.sampler = student.roi_heads.sampler = student.sampler
+    opt = torch.optim.SGD([p for p in student.parameters() if p.requires_grad], lr=float(G["lr"]), momentum=float(G["momentum"]))
+    step = SemiSupStep(student, teacher, opt, burn_up_step=int(G["cfg/BURN_UP_STEP"]), teacher_update_iter=int(G["cfg/TEACHER_UPDATE_ITER"]),
+                       ema_keep_rate=float(G["cfg/EMA_KEEP_RATE"]), bbox_threshold=float(G["cfg/BBOX_THRESHOLD"]),
+                       unsup_loss_weight=float(G["cfg/UNSUP_LOSS_WEIGHT"]), burn_up_with_strong_aug=bool(G["cfg/BURN_UP_WITH_STRONG_AUG"]))
+
+    def batch(tag, n_gt):
+        out = []
+        for i, (h, w) in enumerate(sizes):
+            d = {"image": torch.from_numpy(FO.make_image(h, w, f"{tag}{i}")).cuda(), "height": h, "width": w}
+            if n_gt:
+                b, c = FO.make_gt(h, w, n_gt, K, f"{tag}{i}")
+                inst = Instances((h, w)); inst.gt_boxes = Boxes(torch.from_numpy(b).cuda()); inst.gt_classes = torch.from_numpy(c).cuda()
+                d["instances"] = inst
+            out.append(d)
+        return out
+    named = dict(student.named_parameters())
+    stride = int(G["stride"])
+    sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for it in range(3):
+        data = (batch("s3s_lq", 2), batch("s3s_lk", 3), batch("s3s_uq", 0), batch("s3s_uk", 0))
+        s_before, t_before = sd(student), sd(teacher)
+        record, loss_dict = step.run_step(data)
+        torch.cuda.synchronize()
+        want = {k[len(f"it{it}/record/"):]: float(G[k]) for k in G.files if k.startswith(f"it{it}/record/") and "/loss" in k}
+        assert set(k for k in record if k.startswith("loss")) == set(want), (it, sorted(record), sorted(want))
+        for k, v in want.items():
+            tol = 5e-3 if k.endswith("_pseudo") else (1e-4 if "rpn" in k else 2e-3)
+            assert abs(float(record[k]) - v) <= tol * abs(v) + 1e-7, (it, k, float(record[k]), v)
+        total = float(sum(float(v) for v in loss_dict.values()))
+        assert abs(total - float(G[f"it{it}/total_loss"])) <= 4e-3 * abs(float(G[f"it{it}/total_loss"])), (it, total)
+        if it == 0:
+            assert all(torch.equal(t_before[k], v) for k, v in sd(teacher).items())                  # burn-in leaves the teacher alone
+            for n in list(G["watch"]) + list(G["watch_full"]):                                          # gradient of the (unit-weighted) sum
+                g_ = named[str(n)].grad.detach().cpu().numpy()
+                wg = G[f"it0/grad/{n}"]
+                got = g_.ravel()[::stride] if str(n) in set(G["watch"]) else g_
+                assert np.abs(got - wg).max() <= 2e-3 * np.abs(wg).max() + 1e-12, (n, float(np.abs(got - wg).max() / np.abs(wg).max()))
+            continue
+        assert float(loss_dict["loss_box_reg_pseudo"]) == 0.0 and float(loss_dict["loss_rpn_loc_pseudo"]) == 0.0
+        # the pseudo labels add_label attached to the strong views
+        for i, d in enumerate(data[2]):
+            inst = d["instances"]
+            assert np.array_equal(inst.gt_classes.cpu().numpy(), G[f"it{it}/pseudo_classes{i}"]), (it, i)
+            np.testing.assert_allclose(inst.gt_boxes.tensor.cpu().numpy(), G[f"it{it}/pseudo_boxes{i}"], rtol=1e-4, atol=2e-2)
+            np.testing.assert_allclose(inst.scores.cpu().numpy(), G[f"it{it}/pseudo_scores{i}"], rtol=2e-3)
+        # the teacher after its update: the rule on every tensor, and the reference's own values on the sampled ones
+        keep = 0.0 if it == 1 else float(G["cfg/EMA_KEEP_RATE"])
+        t_after = sd(teacher)
+        for k, v in t_after.items():
+            if keep == 0.0:
+                assert torch.equal(v, s_before[k]), k
+            elif v.dtype == torch.float32:
+                rule = s_before[k] * (1 - keep) + t_before[k] * keep
+                assert float((v - rule).abs().max()) <= 1e-6 * float(rule.abs().max()) + 1e-12, k
+        for n in G["watch"]:
+            ref_t = G[f"it{it}/teacher/{n}"]
+            got = t_after[str(n)].cpu().numpy().ravel()[::stride]
+            assert np.abs(got - ref_t).max() <= 1e-5 * np.abs(ref_t).max(), n
+        # the weighted gradient (x UNSUP_LOSS_WEIGHT on the pseudo classification / objectness terms, x 0 on the pseudo box terms): the
+        # sampled ROI / anchor sets may differ by a row (above), so a bound that a wrong weight (x1 or x4 instead of x2: > 25 %) cannot meet
+        for n in ("roi_heads.box_predictor.cls_score.bias", "proposal_generator.rpn_head.objectness_logits.bias",
+                  "roi_heads.box_predictor.bbox_pred.bias", "proposal_generator.rpn_head.anchor_deltas.bias"):
+            g_ = named[n].grad.detach().cpu().numpy(); wg = G[f"it{it}/grad/{n}"]
+            assert np.abs(g_ - wg).max() <= 5e-2 * np.abs(wg).max(), (it, n, float(np.abs(g_ - wg).max() / np.abs(wg).max()))
+        print(f"iteration {it}:", {k: (round(float(record[k]), 5), round(v, 5)) for k, v in want.items()})
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_weight_gradients_summed_in_the_kernels_equal_autograd_sums(mode):
     """ops.grad_scope: in a semi-supervised iteration every student weight is used by two forward passes (and the RPN head's 3x3
