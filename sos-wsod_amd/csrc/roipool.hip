@@ -658,6 +658,323 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Forward, ROW SPARSE TABLE form (round 5; bf16 maps of < 65535 pixels, the hot path).
+//
+// The feature-stationary scan above visits every pixel of every bin window: ~15 VALU per visited pixel and 8 channels, so a call
+// costs in proportion to the ROI AREA in map pixels (63x63 map / 4000 ROIs: 202 us = 0.25 of the output stream's HBM time;
+// 99x165 / 8000 ROIs: 1.18 ms = 0.085).  Here the LDS copy of the slab holds, per pixel and channel, the FINISHED 32-bit candidate
+//     key << 16 | (0xFFFE - pixel)
+// (order-preserving 16-bit key of the bf16 value; larger candidate = larger value, else EARLIER pixel in row-major order: exactly
+// the winner of the reference's strict '>' scan, ROILoopPool_cpu.cpp:60-72) and is then turned IN PLACE into the row sparse table of
+// level L:  T_L[y][x] = max of the candidates of pixels x .. min(x + 2^L, W) - 1 of row y  (T_L = max(T_{L-1}[x], T_{L-1}[x + 2^{L-1}])).
+// max is associative and the candidate carries its own pixel, so the maximum of ANY union of spans is still the reference's winner.
+// A window row [ws, we) of width bw >= 2^L is the union of the two spans at ws and we - 2^L: TWO reads per window row, whatever
+// its width.  Levels are per ROI: L = floor(log2(narrowest unclipped bin window)) — the unclipped widths of one ROI differ by at
+// most one pixel, so 2^L <= bw <= 2^(L+1) and the two spans cover.  Windows the map's right edge clips below 2^L read ONE span
+// (the table is clipped at W); anything else narrower (a ROI sticking out on the left) takes a pixel loop over global memory.
+// A workgroup sorts ITS share of the image's ROIs (every n_zsplit-th block of 128 rows) by (level, window-height class), then walks the
+// levels upwards, advancing its table between them, in chunks of 128 ROIs.  Per (ROI, bin, 8 channels): ~13 VALU per
+// window ROW instead of ~31 per pixel PAIR; what remains is the per-task work outside the scan (16 two-byte stores, key -> value ->
+// x prior -> bf16).
+// CB = 8: two 16-byte planes (channels 0-3 | 4-7) = 32 B per pixel, the whole map in LDS (<= ~4600 pixels: 63x63);
+// CB = 4 + BAND: one plane, row bands with a halo as in the scan form above (large maps: 99x165 -> 3 bands), rows below a band from
+// global memory.
+constexpr int SP_NT = 1024, SP_CH = 128, SP_NLEV = 6, SP_NHC = 7, SP_NCLS = SP_NLEV * SP_NHC;
+
+__device__ __forceinline__ unsigned int key16_of(unsigned int bts) {          // pix_to_keys for one bf16 value
+  unsigned int key = (bts & 0x8000u) ? (bts ^ 0xFFFFu) : (bts | 0x8000u);
+  if (bts > 0x7F80u && bts < 0x8000u) key = 0;                                // +NaN never wins
+  if (bts == 0x8000u) key = 0x8000u;                                          // -0.0 == +0.0 under '>'
+  return key;
+}
+
+template <typename IT, int CB, bool BAND, int PFIX = 0>
+__global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W, int C, long ld, int PH_, int PW_, float scale,
+                                                                    const unsigned short* __restrict__ feat,
+                                                                    const float* __restrict__ rois, int R,
+                                                                    const float* __restrict__ row_scale, float row_scale_add,
+                                                                    unsigned short* __restrict__ out, IT* __restrict__ argmax,
+                                                                    int band_S, int band_rows, int n_bands, int n_zsplit) {
+  // PFIX = 7: the pooled size as a compile-time constant (the hot path's 7 x 7): the 16 stores of a task then take immediate offsets
+  // (q * 98 bytes) instead of 64-bit address arithmetic per channel, and the task counters fold
+  const int PH = PFIX ? PFIX : PH_, PW = PFIX ? PFIX : PW_;
+  constexpr int NPL = CB / 4;                                       // 16-byte planes
+  constexpr int PXT = CB == 8 ? 5 : 10;                             // table pixels per thread (host: rows * W <= PXT * SP_NT)
+  constexpr int NT = SP_NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_start[SP_NCLS + 1], s_fill[SP_NCLS];
+  __shared__ int s_ntask;
+  const int band = BAND ? (int)(blockIdx.z % n_bands) : 0, zfirst = BAND ? (int)(blockIdx.z / n_bands) : (int)blockIdx.z;
+  const int y0 = BAND ? band * band_S : 0, y1 = BAND ? min(H, y0 + band_rows) : H;      // map rows [y0, y1) live in LDS
+  const int lds_rows = BAND ? band_rows : H;
+  const int npl_px = lds_rows * W;                                  // pixels per plane (allocated)
+  const int npx_t = (y1 - y0) * W;                                  // pixels held
+  u32x4* tab = (u32x4*)smem;                                        // [NPL][npl_px]
+  unsigned short* s_lvl = (unsigned short*)(smem + (size_t)NPL * npl_px * 16);          // [R] ROI rows of this image, by class
+  const int r_even = (R + 1) & ~1;
+  int* s_r = (int*)(s_lvl + r_even);                                // [CH] ROI row of the chunk's entries
+  float* s_mul = (float*)(s_r + SP_CH);                             // [CH] output scale
+  unsigned short* s_hb = (unsigned short*)(s_mul + SP_CH);          // [CH][PH] bin row range  start | end << 8
+  unsigned short* s_wb = s_hb + SP_CH * PH;                         // [CH][PW]
+  unsigned int* s_task = (unsigned int*)(s_wb + SP_CH * PW + ((SP_CH * (PH + PW)) & 1));   // BAND: [CH * PH] owned (entry << 8 | bin row)
+  const int c0 = xcd_grouped_slab() * CB, img = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int nb = PH * PW;
+  const unsigned short* fimg = feat + (long)img * H * W * C + c0;
+
+  // ---- 1. this image's ROIs sorted by (level, height class): counting sort, two passes over the ROI geometry
+  auto roi_class = [&](int r) {
+    const RoiGeom g = roi_geom(rois + (long)r * 5, scale, PH, PW);
+    int m = 1 << 30;                                                // narrowest UNCLIPPED window of the ROI
+    for (int pw = 0; pw < PW; ++pw) {
+      const int ws = (int)floorf(__fmul_rn((float)pw, g.bin_w)), we = (int)ceilf(__fmul_rn((float)(pw + 1), g.bin_w));
+      m = min(m, we - ws);
+    }
+    m = max(m, 1);
+    const int L = min(31 - __clz(m), SP_NLEV - 1);
+    const float b = g.bin_h;
+    const int hc = b < 1.f ? 0 : b < 2.f ? 1 : b < 3.f ? 2 : b < 4.f ? 3 : b < 6.f ? 4 : b < 8.f ? 5 : 6;
+    return L * SP_NHC + hc;
+  };
+  // The n_zsplit workgroups of one (slab, image, band) split the ROIs by ROW BLOCK (128 consecutive rows of `rois` each, dealt
+  // round-robin), not by position in the sorted list: the order inside a class is whatever the atomics give, so a list position means
+  // something to the workgroup that built the list only.  BAND: only ROIs with a bin row that STARTS in this band's own rows enter
+  // the list (first / last bin row start are monotone in the bin row) — every chunk's tables are then built for ROIs that have
+  // work here (with all ROIs listed, a band of nine spent most of a chunk on the geometry of ROIs whose bins belong to other bands).
+  auto for_my_rois = [&](auto&& fn) {
+    for (int b0 = zfirst; b0 * 128 < R; b0 += 8 * n_zsplit) {
+      const int r = (b0 + (tid >> 7) * n_zsplit) * 128 + (tid & 127);
+      if (r < R && (int)rois[(long)r * 5] == img) {
+        if (BAND) {
+          const RoiGeom g = roi_geom(rois + (long)r * 5, scale, PH, PW);
+          const int h_first = min(max(g.start_h, 0), H);
+          const int h_last = min(max((int)floorf(__fmul_rn((float)(PH - 1), g.bin_h)) + g.start_h, 0), H);
+          if (min(h_first / band_S, n_bands - 1) > band || min(h_last / band_S, n_bands - 1) < band) continue;
+        }
+        fn(r);
+      }
+    }
+  };
+  if (tid <= SP_NCLS) s_start[tid] = 0;
+  __syncthreads();
+  for_my_rois([&](int r) { atomicAdd(&s_start[roi_class(r) + 1], 1); });
+  __syncthreads();
+  if (tid == 0) { for (int c = 1; c <= SP_NCLS; ++c) s_start[c] += s_start[c - 1]; }
+  __syncthreads();
+  if (tid < SP_NCLS) s_fill[tid] = s_start[tid];
+  __syncthreads();
+  for_my_rois([&](int r) { s_lvl[atomicAdd(&s_fill[roi_class(r)], 1)] = (unsigned short)r; });
+  const int n_rois = s_start[SP_NCLS];
+  if (n_rois == 0) return;                                          // (uniform: s_start is final since the barrier above)
+
+  // ---- 2. level 0: candidates of the slab's pixels
+  int xk[PXT];                                                      // column of this thread's k-th table pixel (for the level advance)
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) {
+    const int px = tid + k * NT;
+    xk[k] = px < npx_t ? px - (px / W) * W : -1;
+    if (px < npx_t) {
+      const int gpx = y0 * W + px;
+      const unsigned int inv = 0xFFFEu - (unsigned)gpx;
+      unsigned int u[CB / 2];
+      if (CB == 8) { const u32x4 w = *(const u32x4*)(fimg + (long)gpx * C); u[0] = w[0]; u[1] = w[1]; u[2] = w[2]; u[3] = w[3]; }
+      else { const u32x2 w = *(const u32x2*)(fimg + (long)gpx * C); u[0] = w[0]; u[1] = w[1]; }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        u32x4 t;
+        t[0] = (key16_of(u[2 * pl] & 0xFFFFu) << 16) | inv;     t[1] = (key16_of(u[2 * pl] >> 16) << 16) | inv;
+        t[2] = (key16_of(u[2 * pl + 1] & 0xFFFFu) << 16) | inv; t[3] = (key16_of(u[2 * pl + 1] >> 16) << 16) | inv;
+        tab[pl * npl_px + px] = t;
+      }
+    }
+  }
+  constexpr unsigned KEY_INIT = 0x007FFFFFu;                        // key(-inf) << 16 | 0xFFFF
+  for (int L = 0; L < SP_NLEV; ++L) {
+    const int c_lo = s_start[L * SP_NHC], c_hi = s_start[(L + 1) * SP_NHC];
+    if (c_lo >= n_rois) break;                                      // no ROI at this or a higher level
+    __syncthreads();                                                // level L - 1 fully scanned (L = 0: table and list written)
+    if (L > 0) {
+      // ---- 3. T_L from T_{L-1}, in place: every thread reads its pixels' two spans, barrier, writes
+      const int d = 1 << (L - 1);
+      u32x4 nv[PXT][NPL];
+#pragma unroll
+      for (int k = 0; k < PXT; ++k) {
+        const int px = tid + k * NT;
+        if (px < npx_t) {
+          const bool two = xk[k] + d < W;                           // the second span starts inside the row
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {
+            const u32x4 a = tab[pl * npl_px + px];
+            const u32x4 b = two ? tab[pl * npl_px + px + d] : a;
+            nv[k][pl] = u32x4{max(a[0], b[0]), max(a[1], b[1]), max(a[2], b[2]), max(a[3], b[3])};
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < PXT; ++k) {
+        const int px = tid + k * NT;
+        if (px < npx_t) {
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) tab[pl * npl_px + px] = nv[k][pl];
+        }
+      }
+      __syncthreads();
+    }
+    const int span = 1 << L;
+    for (int cs = c_lo; cs < c_hi; cs += SP_CH) {
+      const int cnt = min(SP_CH, c_hi - cs);
+      __syncthreads();                                              // the previous chunk's tables are no longer read
+      if (tid == 0) s_ntask = 0;
+      for (int i = tid; i < cnt * (PH + PW); i += NT) {
+        const int li = i / (PH + PW), k = i - li * (PH + PW);
+        const int r = s_lvl[cs + li];
+        const RoiGeom g = roi_geom(rois + (long)r * 5, scale, PH, PW);
+        if (k == 0) { s_r[li] = r; s_mul[li] = row_scale ? (row_scale[r] + row_scale_add) : 1.0f; }
+        if (k < PH) {
+          int hs = (int)floorf(__fmul_rn((float)k, g.bin_h)), he = (int)ceilf(__fmul_rn((float)(k + 1), g.bin_h));
+          hs = min(max(hs + g.start_h, 0), H); he = min(max(he + g.start_h, 0), H);
+          s_hb[li * PH + k] = (unsigned short)(hs | (he << 8));
+        } else {
+          const int pw = k - PH;
+          int ws = (int)floorf(__fmul_rn((float)pw, g.bin_w)), we = (int)ceilf(__fmul_rn((float)(pw + 1), g.bin_w));
+          ws = min(max(ws + g.start_w, 0), W); we = min(max(we + g.start_w, 0), W);
+          s_wb[li * PW + pw] = (unsigned short)(ws | (we << 8));
+        }
+      }
+      __syncthreads();
+      int ntask = cnt * PH;                                         // (ROI, bin row) pairs this workgroup works on
+      if (BAND) {
+        const int lane = tid & 63;
+        for (int e0 = 0; e0 < cnt * PH; e0 += NT) {
+          const int e = e0 + tid;
+          bool mine = false;
+          if (e < cnt * PH) mine = min((int)(s_hb[e] & 0xFF) / band_S, n_bands - 1) == band;
+          const unsigned long long mk = __ballot(mine);
+          int base = 0;
+          if (lane == 0 && mk) base = atomicAdd(&s_ntask, __popcll(mk));
+          base = __shfl(base, 0);
+          if (mine) { const int li_ = e / PH; s_task[base + __popcll(mk & ((1ull << lane) - 1))] = (unsigned)(li_ << 8) | (unsigned)(e - li_ * PH); }
+        }
+        __syncthreads();
+        ntask = s_ntask;
+      }
+      const int total = ntask * PW;
+      const int dli = NT / nb, dph = (NT - dli * nb) / PW, dpw = NT - dli * nb - dph * PW;
+      int li = tid / nb, ph = (tid - li * nb) / PW, pw = tid - li * nb - ph * PW;
+      const int dte = NT / PW, dtw = NT - dte * PW;
+      int te = tid / PW;
+      if (BAND) pw = tid - te * PW;
+      for (int t = tid; t < total; t += NT) {
+        if (BAND) { const unsigned int pk = s_task[te]; li = (int)(pk >> 8); ph = (int)(pk & 0xFF); }
+        const int b = ph * PW + pw;
+        const int r = s_r[li];
+        const int hb = s_hb[li * PH + ph], wb = s_wb[li * PW + pw];
+        const int hs = hb & 0xFF, he = hb >> 8, ws = wb & 0xFF, we = wb >> 8;
+        const bool empty = (he <= hs) || (we <= ws);
+        unsigned int best[CB];
+#pragma unroll
+        for (int q = 0; q < CB; ++q) best[q] = KEY_INIT;
+        if (!empty) {
+          const int bw = we - ws;
+          const int he_lds = BAND ? min(he, y1) : he;
+          int cold_from = BAND ? max(hs, y1) : he;                  // first window row read from global memory
+          if (bw >= span) {
+            const int offB = bw - span;
+            // two window rows per step (the second clamped to the last row: re-reading a row cannot change a maximum): all 4 * NPL
+            // reads of a step are issued before the first use — one LDS round trip per row PAIR instead of per row (rocprof, one row
+            // per step: the waves of this kernel were parked at s_waitcnt / barriers 53 % of their time, VALU and LDS both < 50 % busy)
+            const int last = (he_lds - 1 - y0) * W + ws;
+            for (int hh = hs; hh < he_lds; hh += 2) {
+              const int i0 = (hh - y0) * W + ws, i1 = min(i0 + W, last);
+              u32x4 a0[NPL], b0[NPL], a1[NPL], b1[NPL];
+#pragma unroll
+              for (int pl = 0; pl < NPL; ++pl) {
+                a0[pl] = tab[pl * npl_px + i0]; b0[pl] = tab[pl * npl_px + i0 + offB];
+                a1[pl] = tab[pl * npl_px + i1]; b1[pl] = tab[pl * npl_px + i1 + offB];
+              }
+#pragma unroll
+              for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  best[4 * pl + e] = max(max(max(max(best[4 * pl + e], a0[pl][e]), b0[pl][e]), a1[pl][e]), b1[pl][e]);     // 2 x v_max3_u32
+              if (2 * span < bw) {                                  // only when the level was capped (SP_NLEV): spans in between
+                for (int rr = 0; rr < 2; ++rr) {
+                  const int ib = rr ? i1 : i0;
+                  for (int x = span; x < offB; x += span) {
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) {
+                      const u32x4 a = tab[pl * npl_px + ib + x];
+#pragma unroll
+                      for (int e = 0; e < 4; ++e) best[4 * pl + e] = max(best[4 * pl + e], a[e]);
+                    }
+                  }
+                }
+              }
+            }
+          } else if (we == W) {                                     // clipped by the map's right edge: the span at ws ends at W
+            for (int hh = hs; hh < he_lds; ++hh) {
+              const int i0 = (hh - y0) * W + ws;
+#pragma unroll
+              for (int pl = 0; pl < NPL; ++pl) {
+                const u32x4 a = tab[pl * npl_px + i0];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) best[4 * pl + e] = max(best[4 * pl + e], a[e]);
+              }
+            }
+          } else {
+            cold_from = hs;                                         // narrower than the ROI's span for another reason: pixel loop
+          }
+          for (int hh = cold_from; hh < he; ++hh)
+            for (int x = ws; x < we; ++x) {
+              const int gi = hh * W + x;
+              const unsigned int inv0 = 0xFFFEu - (unsigned)gi;
+              unsigned int u[CB / 2];
+              if (CB == 8) { const u32x4 w = *(const u32x4*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; u[2] = w[2]; u[3] = w[3]; }
+              else { const u32x2 w = *(const u32x2*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; }
+#pragma unroll
+              for (int i = 0; i < CB / 2; ++i) {
+                best[2 * i] = max(best[2 * i], (key16_of(u[i] & 0xFFFFu) << 16) | inv0);
+                best[2 * i + 1] = max(best[2 * i + 1], (key16_of(u[i] >> 16) << 16) | inv0);
+              }
+            }
+        }
+        // candidate -> (bf16 bits, pixel): as in the scan form above
+        float mv[CB]; int mi[CB];
+        unsigned int lowest = best[0];
+#pragma unroll
+        for (int q = 0; q < CB; ++q) {
+          const unsigned int m = (unsigned int)((int)best[q] >> 31);
+          mv[q] = __uint_as_float((best[q] & 0xFFFF0000u) ^ (0x80000000u | (~m & 0x7FFF0000u)));
+          mi[q] = (int)(0xFFFEu - (best[q] & 0xFFFFu));
+          lowest = min(lowest, best[q]);
+        }
+        if (lowest == KEY_INIT) {
+#pragma unroll
+          for (int q = 0; q < CB; ++q)
+            if (best[q] == KEY_INIT) mv[q] = empty ? 0.f : -FLT_MAX;
+        }
+        const float mul = s_mul[li];
+        const long o = (long)r * ld + (long)c0 * nb + b;
+#pragma unroll
+        for (int q = 0; q < CB; ++q) {
+          Elem<unsigned short>::store(out + o + (long)q * nb, __fmul_rn(mv[q], mul));
+          argmax[o + (long)q * nb] = ArgIdx<IT>::enc(mi[q]);
+        }
+        if (BAND) {
+          pw += dtw; te += dte;
+          if (pw >= PW) { pw -= PW; ++te; }
+        } else {
+          pw += dpw; ph += dph; li += dli;
+          if (pw >= PW) { pw -= PW; ++ph; }
+          if (ph >= PH) { ph -= PH; ++li; }
+        }
+      }
+    }   // chunks of the level
+  }     // levels
+}
+
 // max |x| over n elements -> out[0] (f32; caller zero-fills).  |x| as IEEE bits is monotone => integer atomicMax; a NaN in x
 // yields NaN, an Inf yields Inf.
 template <typename T>
@@ -735,6 +1052,74 @@ int launch_fwd_band(int nimg, int H, int W, int C, long ld, int PH, int PW, floa
   return 0;
 }
 
+// sparse-table form: LDS = table planes + the image's sorted ROI list + one chunk's tables
+inline size_t sparse_tables_bytes(int R, int PH, int PW, bool band) {
+  return (size_t)((R + 1) & ~1) * 2 + (size_t)SP_CH * (4 + 4 + 2 * (PH + PW)) + 4 + (band ? (size_t)SP_CH * PH * 4 : 0) + 16;
+}
+template <typename IT, int CB, bool BAND>
+int launch_sparse_kernel(dim3 grid, size_t lds, int H, int W, int C, long ld, int PH, int PW, float scale, const void* feat, const float* rois,
+                         int R, const float* row_scale, float row_scale_add, void* out, void* argmax, int S, int rows, int n_bands, int nz,
+                         hipStream_t stream) {
+  auto kern = (PH == 7 && PW == 7) ? roi_pool_fwd_sparse_kernel<IT, CB, BAND, 7> : roi_pool_fwd_sparse_kernel<IT, CB, BAND, 0>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, H, W, C, ld, PH, PW, scale, (const unsigned short*)feat, rois, R, row_scale,
+                     row_scale_add, (unsigned short*)out, (IT*)argmax, S, rows, n_bands, nz);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename IT>
+int launch_fwd_sparse(int nimg, int H, int W, int C, long ld, int PH, int PW, float scale, const void* feat, const float* rois, int R,
+                      const float* row_scale, float row_scale_add, void* out, void* argmax, hipStream_t stream) {
+  constexpr size_t LDS_MAX = 160 * 1024 - 1536;                     // the kernel's static LDS (class tables) + alignment
+  const int n_blocks = (R + 127) / 128;                             // row blocks of 128 ROIs are dealt to the workgroups of a (slab, image)
+  // workgroups: ONE per CU (every form here holds most of a CU's LDS, and a workgroup's fixed work — its share of the ROI sort, the
+  // slab fetch, the level advances — is paid per workgroup: 63x63 / 4000 ROIs 156 us at 256 workgroups, 188 at 768, 226 at 1536);
+  // SW_ROI_FWD_WGS overrides the target
+  static const int forced = getenv("SW_ROI_FWD_WGS") ? atoi(getenv("SW_ROI_FWD_WGS")) : 0;      // development switch
+  auto zsplit = [&](int wg_per_z) {
+    const int target = forced ? forced : 256;
+    int nz = (target + wg_per_z / 2) / wg_per_z;
+    nz = nz < 1 ? 1 : nz;
+    return nz > n_blocks ? n_blocks : nz;
+  };
+  static const bool force_cb4 = getenv("SW_ROI_SPARSE_CB4") != nullptr;                // development switch: 4 channels per lane everywhere
+  const size_t plane8 = (size_t)H * W * 32 + sparse_tables_bytes(R, PH, PW, false);
+  if (!force_cb4 && plane8 <= LDS_MAX && (long)H * W <= 5 * SP_NT) {
+    const int nz = zsplit((C / 8) * nimg);
+    return launch_sparse_kernel<IT, 8, false>(dim3(C / 8, nimg, nz), plane8, H, W, C, ld, PH, PW, scale, feat, rois, R, row_scale,
+                                              row_scale_add, out, argmax, H, H, 1, nz, stream);
+  }
+  // row bands: 4 channels per lane (16 B per pixel).  8 channels (32 B per pixel: a third of the rows per band) measured slower on
+  // every banded map (99x165 / 8000 ROIs: 956 vs 669 us with 9 vs 3 bands; 125x167: 525 vs 383; 76x114: 245 vs 219) — the bands'
+  // redundant ROI tables and slab fetches outweigh the halved task count; SW_ROI_SPARSE_CB8BAND=1 tries it first (A/B timing)
+  static const bool try_cb8_band = getenv("SW_ROI_SPARSE_CB8BAND") != nullptr;          // development switch
+  const size_t tb = sparse_tables_bytes(R, PH, PW, true);
+  if (PH > 255) return -100;
+  const int halo = (H + PH - 1) / PH + 1;
+  for (int cb = (try_cb8_band && !force_cb4) ? 8 : 4; cb >= 4; cb >>= 1) {
+    const int pxb = cb * 4, pxt = cb == 8 ? 5 : 10;
+    if (tb + (size_t)W * pxb * 8 > LDS_MAX) continue;
+    int fit = (int)((LDS_MAX - tb) / ((size_t)W * pxb));
+    if ((long)fit * W > (long)pxt * SP_NT) fit = pxt * SP_NT / W;
+    int S, rows;
+    if (fit >= H) { S = H; rows = H; }                              // the whole map fits: one band
+    else { if (fit - halo < 8) continue; S = fit - halo; rows = fit; }
+    const int n_bands = (H + S - 1) / S;
+    const size_t lds = (size_t)rows * W * pxb + tb;
+    const int nz = zsplit((C / cb) * nimg * n_bands);
+    if ((long)n_bands * nz > 65535) continue;
+    dim3 grid(C / cb, nimg, n_bands * nz);
+    if (cb == 8)
+      return launch_sparse_kernel<IT, 8, true>(grid, lds, H, W, C, ld, PH, PW, scale, feat, rois, R, row_scale, row_scale_add, out, argmax,
+                                               S, rows, n_bands, nz, stream);
+    return launch_sparse_kernel<IT, 4, true>(grid, lds, H, W, C, ld, PH, PW, scale, feat, rois, R, row_scale, row_scale_add, out, argmax,
+                                             S, rows, n_bands, nz, stream);
+  }
+  return -100;
+}
+
 template <typename IT>
 int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, long ld, int PH, int PW, float spatial_scale, const void* feat,
                      const float* rois, int R, const float* row_scale, float row_scale_add, void* out, void* argmax,
@@ -754,6 +1139,14 @@ int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, long ld, int PH, 
     if (force_pxb) {
       const int want = atoi(force_pxb);
       pxb = (want && (C % (want / (int)es)) == 0 && (size_t)H * W * want <= 150 * 1024) ? want : 0;
+    }
+    // row sparse table form (bf16, packed candidates): the whole map at 32 B per pixel (8 channels per lane), else row bands at 16 B
+    // per pixel (4 channels per lane); SW_ROI_FWD_SPARSE=0 keeps the scan forms below (A/B timing)
+    static const char* sparse_sw = getenv("SW_ROI_FWD_SPARSE");                       // development switch
+    if (!(sparse_sw && sparse_sw[0] == '0') && !force_pxb && dtype == SW_BF16 && (C % 8) == 0 && (long)H * W < 65535 && R <= 16384 &&
+        PH <= 8 && PW <= 8) {
+      const int rc = launch_fwd_sparse<IT>(nimg, H, W, C, ld, PH, PW, spatial_scale, feat, rois, R, row_scale, row_scale_add, out, argmax, stream);
+      if (rc != -100) return rc;                                                   // -100: shape not covered, use the forms below
     }
     static const bool no_band = getenv("SW_ROI_FWD_NO_BAND") != nullptr;            // development switch
     int bS = 0, brows = 0;

@@ -640,7 +640,17 @@ class OICRPlusHeads(nn.Module):
         epc = 8 if dt_ == torch.bfloat16 else 4
         db1 = ops.grad_target(self.box_head.fc1.bias, (D1,), dev); ops.colsum(dz1, M, D1, db1)
         dW1 = ops.grad_target(self.box_head.fc1.weight, (D1, D0), dev)
-        if M % epc == 0:                                 # dZ^T as in stage 1; the tagged region holds the transpose too: one "fc6_wgrad" measurement
+        panels = getattr(self, "_fc6_panels", None)       # (n, callback): the data-parallel reducer's SW_DDP_FC1_PANELS
+        if M % epc == 0 and panels is not None and panels[0] > 1 and D1 % (256 * panels[0]) == 0:
+            # the weight gradient in n row panels (whole 256-row tile rows each, so every output tile is computed exactly as in the
+            # one-launch form: same bits); after each the reducer starts that panel's all-reduce — the 411 MB leave in n pieces
+            # while the later panels still compute
+            dzt = ops.transpose_2d(dz1, torch.empty(D1, M + 8 * epc, device=dev, dtype=dt_)[:, :M], M, D1)
+            rows = D1 // panels[0]
+            for i in range(panels[0]):
+                ops.gemm(dzt[i * rows:(i + 1) * rows], pooled, dW1[i * rows:(i + 1) * rows], rows, D0, M, b_kstrided=True)
+                panels[1](i, dW1[i * rows:(i + 1) * rows])
+        elif M % epc == 0:                               # dZ^T as in stage 1; the tagged region holds the transpose too: one "fc6_wgrad" measurement
             def nn():
                 dzt = ops.transpose_2d(dz1, torch.empty(D1, M + 8 * epc, device=dev, dtype=dt_)[:, :M], M, D1)
                 ops.gemm(dzt, pooled, dW1, D1, D0, M, b_kstrided=True)
@@ -772,9 +782,21 @@ class OICRPlusHeads(nn.Module):
         self._gt_int32 = inp["gt_int32"]            # `gt_classes_img_int` (the reference's attribute) converts on access
         params = self._flat_params()              # fc6 W, b, fc7 W, b, then the predictors' (W, b) pairs
         box = [None]
-        h0 = _HeadsPoolFunction.apply(self, inp, params, box, *feats)
-        h1 = _HeadsFc6Function.apply(self, box, h0, params[0], params[1])
-        vec, total = _HeadsLossFunction.apply(self, box, h1, *params[2:])
+        # `_staged` (set by trainer._NativeDDP): the backward is run in stages with collectives between them, so the graph is CUT at
+        # the edges between the three nodes and at the feature tensors: each cut is a detached leaf that collects the gradient of
+        # the stage above; the caller resumes below it with `lower.backward(leaf.grad)` (an `inputs=` partial backward also runs the
+        # node BELOW a non-leaf input, i.e. the stage that was to wait).  _cuts = (feature pairs, (h0, leaf), (h1, leaf)).
+        staged = getattr(self, "_staged", False) and torch.is_grad_enabled()
+
+        def cut(t):
+            return t.detach().requires_grad_(True) if (staged and t.requires_grad) else t
+        feats_in = [cut(f) for f in feats]
+        h0 = _HeadsPoolFunction.apply(self, inp, params, box, *feats_in)
+        h0c = cut(h0)
+        h1 = _HeadsFc6Function.apply(self, box, h0c, params[0], params[1])
+        h1c = cut(h1)
+        vec, total = _HeadsLossFunction.apply(self, box, h1c, *params[2:])
+        self.__dict__["_cuts"] = ([(f, c) for f, c in zip(feats, feats_in) if c is not f], (h0, h0c), (h1, h1c)) if staged else None
         names = loss_names(self.refine_K)
         losses = LossDict(names, vec, total, self._last_finite)
         self.iter = self.iter + 1

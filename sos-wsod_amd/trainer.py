@@ -77,7 +77,21 @@ class Trainer:
             prepare()                       # flat predictor master, compute-dtype weight copies: BEFORE DDP looks at the parameters
         use_ddp = ddp if ddp is not None else self.world > 1
         self._bucket_views = []
-        if use_ddp:
+        self._native = None
+        self.overlap_update = False
+        # The data-parallel step WITHOUT torch's reducer (round 5; default for the OICR+ model on GPUs with HipSGD and ITER_SIZE 1,
+        # SW_DDP_NATIVE=0 keeps DistributedDataParallel): flat gradient buckets the kernels write into, the backward cut into four
+        # stages at the heads' node boundaries, one all-reduce per bucket issued between the stages, the update of a bucket queued
+        # behind its all-reduce — and, because nothing of the collective lives inside the stages, each stage is a hipGraph.
+        native_ok = (use_ddp and os.environ.get("SW_DDP_NATIVE", "1") == "1" and self.iter_size == 1 and not find_unused
+                     and hasattr(optimizer, "step_params") and hasattr(model, "roi_heads") and hasattr(model, "backbone")
+                     and next(model.parameters()).is_cuda and dist.is_available() and dist.is_initialized())
+        if native_ok:
+            self.model = model
+            self._native = _NativeDDP(self, model, optimizer, grad_compress or os.environ.get("SW_DDP_GRAD_COMPRESS"),
+                                      use_graph=self._want_graph)
+            self.overlap_update = True
+        elif use_ddp:
             if os.environ.get("SW_DDP_GRAD_IN_BUCKET", "1") == "1":
                 # ops.grad_target users: fc / conv weights and biases (the 20 predictor tensors are row slices of ONE packed gradient
                 # matrix; the reducer copies those into its bucket)
@@ -174,7 +188,9 @@ class Trainer:
                 data = next(self.data_iter)
         if self.iter == self.start_iter:
             self.optimizer.zero_grad()                                     # :143-144
-        if self._graphs is not None:
+        if self._native is not None:
+            loss_dict, losses = self._native.step(data)
+        elif self._graphs is not None:
             # every step of a graph-enabled trainer — eager, capture or replay — runs on ONE side stream: a capture cannot use
             # the default stream, and autograd pins each parameter's gradient accumulation to the stream its first forward ran
             # on; an eager warm-up on the default stream followed by a capture elsewhere makes autograd synchronise the two
@@ -248,9 +264,274 @@ class Trainer:
                 for k, r in enumerate(aux.get("rounds", [])):
                     self.storage.put_scalar(f"roi_head/num_pgt_r{k}", r["pgt_count"].detach().clone())
 
+    @staticmethod
+    def _graphs_stage(static, data, owner):
+        """copy a step's inputs into a captured graph's static input tensors (one launch) and stage the labels"""
+        pairs, slow = [], []
+        for s_, x in zip(static, data):
+            for k in _StepGraphs.VIEW_KEYS:
+                for src, dst in ((x["image" + k], s_["image" + k]),
+                                 (x["proposals" + k].proposal_boxes.tensor, s_["proposals" + k].proposal_boxes.tensor),
+                                 (x["proposals" + k].objectness_logits, s_["proposals" + k].objectness_logits)):
+                    (pairs if src.dtype == dst.dtype and src.is_contiguous() else slow).append((src, dst))
+        from . import ops
+        ops.copy_multi(pairs)
+        for src, dst in slow:
+            dst.copy_(src, non_blocking=True)
+        owner.heads.stage_labels([x["instances1"] for x in data], owner.labels)
+
     def finish(self):
         """call after the last step: surfaces a pending non-finite flag"""
         self._raise_if_nonfinite()
+
+
+class _Bucket:
+    """One flat float32 gradient buffer; parameter p's gradient is the view `views[i]`.  The weight-gradient kernels write straight
+    into the views (ops.grad_target through p._sw_grad_view); gradients produced elsewhere (the predictor tensors: row slices of one
+    packed matrix) are gathered with ONE copy launch."""
+
+    def __init__(self, params, device):
+        self.params = list(params)
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) & ~3                              # 16-byte aligned segments
+        self.flat = torch.zeros(max(n, 4), device=device, dtype=torch.float32)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, self.params)]
+        for p, v in zip(self.params, self.views):
+            p.__dict__["_sw_grad_view"] = v
+        self.work = []
+
+    def gather(self):
+        from . import ops
+        pairs = []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()                                           # (a parameter no kernel produced a gradient for: contributes 0)
+            elif g.data_ptr() != v.data_ptr():
+                pairs.append((g.contiguous(), v))
+        if pairs:
+            ops.copy_multi(pairs)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+
+class _NativeDDP:
+    """Data parallelism of the OICR+ step without torch's reducer (train_net_multi.py:76-78,143-164 is what it replaces).
+
+    Buckets, in the order the backward produces them:  0 = predictors + fc7 (68 MB), 1 = fc6 (411 MB), 2 = backbone (59 MB).
+    Stages of a step (main stream), with what is issued between them:
+        S1  forward + loss + backward of the heads' top (predictors, fc7, dZ1)        -> all-reduce 0, update 0 behind it
+        S2  fc6 weight gradient (optionally in row panels, each all-reduced as it finishes) -> all-reduce 1
+        S3  fc6 data gradient + ROIPool backward  (the last readers of fc6's weight copies) -> update 1 behind all-reduce 1 AND S3
+        S4  conv backward                                                               -> all-reduce 2, update 2
+    The stages are cut with `torch.autograd.backward(..., inputs=...)` at the heads' handle tensors (roi_heads_oicrplus._cuts); the
+    collectives are plain eager `dist.all_reduce(async_op=True)` calls BETWEEN stages, the updates run on a side stream — so with
+    use_graph every stage is one captured hipGraph (RCCL inside a capture segfaults on this stack; here it never is inside one).
+    Gradients are summed with the backward seeded by 1 / world (no averaging pass), as the torch-DDP path does."""
+
+    def __init__(self, trainer, model, optimizer, grad_compress=None, use_graph=False):
+        self.tr, self.model, self.opt = trainer, model, optimizer
+        self.heads = model.roi_heads
+        self.dev = next(model.parameters()).device
+        self.world = dist.get_world_size()
+        self.group = dist.group.WORLD
+        self.compress = grad_compress
+        assert grad_compress in (None, "", "bf16"), f"unknown gradient compression {grad_compress!r}"
+        trainer._seed_scale = 1.0 / self.world
+        fc1 = self.heads.box_head.fc1
+        top, fc6, bb = [], [], []
+        for n, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            (fc6 if (p is fc1.weight or p is fc1.bias) else bb if n.startswith("backbone.") else top).append(p)
+        self.buckets = [_Bucket(ps, self.dev) for ps in (top, fc6, bb)]
+        self.fc1_weight = fc1.weight
+        # DDP's constructor hands rank 0's parameters and buffers to every rank; so does this one
+        if self.world > 1:
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t.data, 0, group=self.group)
+            from . import ops
+            ops.invalidate_all_staged()
+        self.upd = torch.cuda.Stream(device=self.dev)
+        self.main = torch.cuda.Stream(device=self.dev) if use_graph else None
+        n_pan = int(os.environ.get("SW_DDP_FC1_PANELS", "0"))
+        self.panels = n_pan if n_pan > 1 else 0
+        self._panel_work = []
+        self.use_graph = bool(use_graph)
+        self.graphs = OrderedDict()
+        self.seen = {}
+        self.pool = None
+        self.replays = self.captures = 0
+        self.labels = torch.zeros(4096, dtype=torch.float32, device=self.dev) if use_graph else None
+        if use_graph and hasattr(optimizer, "sync_hyper"):
+            optimizer.device_hyper = True
+        self._live = None
+
+    # ------------------------------------------------------------------ the four stages (eager, or inside a capture)
+    def _s1(self, data):
+        tr = self.tr
+        self.heads._staged = True
+        try:
+            with tr.storage:
+                loss_dict = self.model(data)
+                total = loss_dict.total()
+                total.backward(gradient=tr._seed_grad(total))       # stops at the leaf above the fc6 node
+        finally:
+            self.heads._staged = False
+        self.buckets[0].gather()
+        self._live = (loss_dict, total, self.heads._cuts)
+        self.heads.__dict__["_cuts"] = None
+
+    def _s2(self):
+        h1, h1c = self._live[2][2]
+        h1.backward(h1c.grad)                                       # fc6 weight / bias gradient
+        self.buckets[1].gather()
+
+    def _s3(self):
+        h0, h0c = self._live[2][1]
+        h0.backward(h0c.grad)                                       # fc6 data gradient + ROIPool backward: the feature leaves' .grad
+
+    def _s4(self):
+        pairs = [(f, c) for f, c in self._live[2][0] if c.grad is not None]
+        if pairs:
+            torch.autograd.backward([f for f, _ in pairs], [c.grad for _, c in pairs])
+        self.buckets[2].gather()
+
+    # ------------------------------------------------------------------ between the stages
+    def _allreduce(self, t):
+        if self.compress == "bf16":                                # opt-in, NOT the reference's numerics: half the bytes on the ring
+            c = t.to(torch.bfloat16)
+            w = dist.all_reduce(c, group=self.group, async_op=True)
+            return (w, c, t)
+        return (dist.all_reduce(t, group=self.group, async_op=True), None, t)
+
+    @staticmethod
+    def _wait(job):
+        w, c, t = job
+        w.wait()                                                   # RCCL: the CURRENT stream waits; gloo: the host does
+        if c is not None:
+            t.copy_(c)
+
+    def _reduce(self, i):
+        b = self.buckets[i]
+        if i == 1 and self._panel_work:
+            b.work = self._panel_work + [self._allreduce(b.views[k]) for k, p in enumerate(b.params) if p is not self.fc1_weight]
+            self._panel_work = []
+        else:
+            b.work = [self._allreduce(b.flat)]
+
+    def _update(self, i, after=None):
+        b = self.buckets[i]
+        with torch.cuda.stream(self.upd):
+            for job in b.work:
+                self._wait(job)
+            if after is not None:
+                self.upd.wait_event(after)
+            self.opt.step_params(b.params, b.views)
+        b.work = []
+
+    def _panel_cb(self, i, rows):
+        self._panel_work.append(self._allreduce(rows))
+
+    # ------------------------------------------------------------------ one step
+    def step(self, data):
+        caller = torch.cuda.current_stream()
+        if self.main is not None:
+            # graph mode: every step runs on one side stream (a capture cannot use the default stream; see Trainer.run_step)
+            self.main.wait_stream(caller)
+            with torch.cuda.stream(self.main):
+                out = self._step_on(self.main, data)
+            caller.wait_stream(self.main)
+            return out
+        return self._step_on(caller, data)
+
+    def _step_on(self, main, data):
+        tr = self.tr
+        self.upd.wait_stream(main)                                  # the previous step's readers of the weights are queued
+        hit = self._graph_for(data) if (self.use_graph and tr.iter > tr.start_iter) else None
+        self.heads._fc6_panels = (self.panels, self._panel_cb) if (self.panels and hit is None) else None
+        if hit is not None:
+            g1, g2, g3, g4, static, loss_dict, total = hit
+            tr._graphs_stage(static, data, self)
+            if hasattr(self.opt, "sync_hyper"):
+                self.opt.sync_hyper()
+            stages = (g1.replay, g2.replay, g3.replay, g4.replay)
+            self.replays += 1
+        else:
+            stages = (lambda: self._s1(data), self._s2, self._s3, self._s4)
+        try:
+            stages[0]()
+            self._reduce(0); self._update(0)
+            stages[1]()
+            self._reduce(1)
+            stages[2]()
+            e3 = torch.cuda.Event(); e3.record(main)
+            self._update(1, after=e3)
+            stages[3]()
+            self._reduce(2); self._update(2)
+        finally:
+            self.heads._fc6_panels = None
+            self.heads._prestaged_labels = None
+        main.wait_stream(self.upd)
+        if hit is None:
+            loss_dict, total = self._live[0], self._live[1]
+            self._live = None
+        self.opt.step()                                             # (nothing is left for it: every parameter sits in a bucket)
+        self.opt.zero_grad()
+        self.last_step_replayed = hit is not None
+        return loss_dict, total
+
+    # ------------------------------------------------------------------ stage graphs
+    def _graph_for(self, data):
+        sig = _StepGraphs._signature(self, data)
+        if sig is None:
+            return None
+        hit = self.graphs.get(sig)
+        if hit is not None:
+            self.graphs.move_to_end(sig)
+            return hit
+        n = self.seen.get(sig, 0) + 1
+        self.seen[sig] = n
+        if n < 2:
+            return None
+        for p in self.model.parameters():                           # the update must not create state between the stages
+            if p.requires_grad and "momentum_buffer" not in self.opt.state.get(p, {}):
+                return None
+        while len(self.graphs) >= _StepGraphs.MAX_GRAPHS:
+            old, _ = self.graphs.popitem(last=False)
+            self.seen[old] = 0
+        static = _StepGraphs._clone_inputs(data)
+        self.heads.stage_labels([x["instances1"] for x in data], self.labels)
+        if hasattr(self.opt, "sync_hyper"):
+            self.opt.sync_hyper()
+        torch.cuda.synchronize()
+        gs = [torch.cuda.CUDAGraph() for _ in range(4)]
+        fns = (lambda: self._s1(static), self._s2, self._s3, self._s4)
+        stream = torch.cuda.current_stream()
+        try:
+            for g, fn in zip(gs, fns):
+                with torch.cuda.graph(g, pool=self.pool, stream=stream):
+                    fn()
+                if self.pool is None:
+                    self.pool = g.pool()
+        finally:
+            self.heads._prestaged_labels = None
+        loss_dict, total = self._live[0], self._live[1]
+        self._live = None
+        for b in self.buckets:                                      # the captures only recorded the kernels: no gradient was produced
+            for p in b.params:
+                p.grad = None
+        self.captures += 1
+        hit = (gs[0], gs[1], gs[2], gs[3], static, loss_dict, total)
+        self.graphs[sig] = hit
+        return hit
+
+    # attributes _StepGraphs._signature reads
+    VIEW_KEYS = ("1", "1_flip", "2", "2_flip")
+    lr_in_signature = False
 
 
 class _StepGraphs:

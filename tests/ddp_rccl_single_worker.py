@@ -45,12 +45,15 @@ def main():
         return [{"params": [p], "lr": 2e-2 if n.endswith(".bias") else 1e-2, "weight_decay": 0.0 if n.endswith(".bias") else 5e-4}
                 for n, p in m.named_parameters() if p.requires_grad]
 
+    graph = len(sys.argv) > 4 and sys.argv[4] == "graph"          # the data-parallel step as four stage graphs (trainer._NativeDDP)
+    n_steps = 5 if graph else 3
+
     def run(ddp):
         m = fresh()
         opt = HipSGD(groups(m), 1e-2, momentum=0.9)
-        tr = Trainer(m, opt, ddp=ddp, use_graph=False, check_finite_every=1, metrics_period=1)
+        tr = Trainer(m, opt, ddp=ddp, use_graph=(graph and ddp), check_finite_every=1, metrics_period=1)
         left = []
-        for step in range(3):
+        for step in range(n_steps):
             orig = opt.step
 
             def spy(*a, **k):
@@ -64,7 +67,9 @@ def main():
         return m, tr, left
 
     m_ddp, tr_ddp, left = run(True)
-    assert isinstance(tr_ddp.model, torch.nn.parallel.DistributedDataParallel)
+    native = os.environ.get("SW_DDP_NATIVE", "1") == "1"
+    assert (tr_ddp._native is not None) if native else isinstance(tr_ddp.model, torch.nn.parallel.DistributedDataParallel)
+    replays = tr_ddp._native.replays if (native and graph) else 0
     # the bucket-by-bucket update (several HipSGD calls per step) must leave EVERY staged compute-dtype weight copy current: a
     # forward after the steps re-stages nothing (a global update counter once invalidated all but the last bucket's stamps)
     import sos_wsod_amd.ops as ops
@@ -84,7 +89,7 @@ def main():
     same = all(torch.equal(a.detach(), b.detach()) for a, b in zip(m_ddp.parameters(), m_ref.parameters()))
     moved = float((m_ddp.roi_heads.box_head.fc1.weight.detach() - torch.from_numpy(P["roi_heads.box_head.fc1.weight"]).to(dev)).abs().max())
     torch.save({"same": same, "moved": moved, "overlap_update": tr_ddp.overlap_update, "left_for_step": left, "stale_staged": stale,
-                "backend": dist.get_backend(),
+                "backend": dist.get_backend(), "native": native, "replays": replays, "n_steps": n_steps,
                 "metrics": {k: float(v) for k, v in tr_ddp.storage.latest().items() if k.startswith("loss")},
                 "metrics_ref": {k: float(v) for k, v in tr_ref.storage.latest().items() if k.startswith("loss")}}, out_path)
     dist.barrier()

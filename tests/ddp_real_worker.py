@@ -94,10 +94,12 @@ def main():
     set_stream(model, rank, 0)
     opt = HipSGD(groups(model), 1e-2, momentum=0.9)
     tr = Trainer(model, opt, check_finite_every=1, metrics_period=1)
-    assert isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+    native = os.environ.get("SW_DDP_NATIVE", "1") == "1"
+    assert (tr._native is not None) if native else isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+    name_of = {id(p): n for n, p in model.named_parameters()}
     flat_w, _ = model.roi_heads._head_flat                           # flattened BEFORE the DDP wrap (prepare_for_training)
     assert model.roi_heads.box_predictor.cls.weight.data_ptr() == flat_w.data_ptr()
-    res = {"grad_err": [], "rank": rank, "overlap_update": tr.overlap_update, "left_for_step": []}
+    res = {"grad_err": [], "rank": rank, "overlap_update": tr.overlap_update, "left_for_step": [], "native": native}
     for step in range(N_STEPS):
         # look at the all-reduced gradients of this step before the optimizer consumes them
         seen = {}
@@ -112,12 +114,17 @@ def main():
         opt.step = spy_step
         tr.run_step(data_of(rank, step))
         opt.step = orig_step
+        if native:
+            # the reduced gradients live in the reducer's flat buckets (a replayed stage graph runs no autograd: .grad stays None)
+            torch.cuda.synchronize()
+            seen = {name_of[id(p)]: v.detach().clone() for b in tr._native.buckets for p, v in zip(b.params, b.views)}
         assert set(seen) == set(mean_grads[step])
         for n, g in seen.items():
             ref = mean_grads[step][n]
             res["grad_err"].append(float((g - ref).abs().max() / (ref.abs().max() + 1e-20)))
     tr.finish()
     torch.cuda.synchronize()
+    res["replays"] = tr._native.replays if native else 0
     # ---- parameters: bit-identical across ranks, equal to the replica's
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]

@@ -30,7 +30,7 @@ def test_real_model_two_ranks_update_after_the_backward(tmp_path):
     out = str(tmp_path / "ddpseq")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_real_worker.py"), out, "bf16"]
-    r = subprocess.run(cmd, env=dict(_env(), SW_DDP_OVERLAP_UPDATE="0"), capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, env=dict(_env(), SW_DDP_OVERLAP_UPDATE="0", SW_DDP_NATIVE="0"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     for rank in range(2):
         res = torch.load(f"{out}.rank{rank}")
@@ -38,15 +38,24 @@ def test_real_model_two_ranks_update_after_the_backward(tmp_path):
         assert max(res["grad_err"]) <= 1e-6 and res["same_across_ranks"] and res["replica_err"] <= 1e-6
 
 
+@pytest.mark.parametrize("mode", ["native", "native-graph", "torch-ddp"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_real_model_two_ranks_gradients_and_parameters(tmp_path, dtype):
+def test_real_model_two_ranks_gradients_and_parameters(tmp_path, dtype, mode):
+    """native: trainer._NativeDDP (own flat buckets, the backward in four stages, all-reduces between them, per-bucket updates on a
+    side stream); native-graph: the same with every stage replayed as a captured hipGraph; torch-ddp: DistributedDataParallel with
+    the per-bucket update in its communication hook (SW_DDP_NATIVE=0).  All three: reduced gradients == the mean of the ranks'
+    single-process gradients, parameters bit-identical across ranks and equal to the single-process replica."""
     out = str(tmp_path / "ddp")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_real_worker.py"), out, dtype]
-    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    extra = {"native": {}, "native-graph": {"SW_STEP_GRAPH": "1"}, "torch-ddp": {"SW_DDP_NATIVE": "0"}}[mode]
+    r = subprocess.run(cmd, env=dict(_env(), **extra), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     for rank in range(2):
         res = torch.load(f"{out}.rank{rank}")
+        assert res["native"] == (mode != "torch-ddp")
+        if mode == "native-graph":
+            assert res["replays"] >= 2, res["replays"]              # step 0 eager, step 1 captures and replays, step 2 replays
         # DDP divides by the world size before the all-reduce, the replica after the sum: equal up to the f32 rounding of /2,
         # i.e. exactly, except for denormals; bf16 activations do not enter (both sides run the same kernels)
         assert max(res["grad_err"]) <= 1e-6, max(res["grad_err"])
@@ -59,13 +68,15 @@ def test_real_model_two_ranks_gradients_and_parameters(tmp_path, dtype):
         assert res["overlap_update"] and res["left_for_step"] == [0, 0, 0], res["left_for_step"]
 
 
-def test_real_model_two_ranks_at_config3_per_gpu_size(tmp_path):
+@pytest.mark.parametrize("panels", [0, 4])
+def test_real_model_two_ranks_at_config3_per_gpu_size(tmp_path, panels):
     """the same check once at BASELINE config #3's per-rank shape (512x512 views, R = 2000, fc 4096/4096, bf16): 543 MB of
-    gradients through DDP's real bucket layout (fc1.weight a 411 MB bucket of its own)"""
+    gradients through the real bucket layout (fc6 a 411 MB bucket of its own).  panels = 4: SW_DDP_FC1_PANELS — fc1.weight's gradient
+    is computed and all-reduced in four row panels (each leaves while the next is still in its GEMM); same gradients, same parameters"""
     out = str(tmp_path / "ddpfull")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_real_worker.py"), out, "bf16", "full"]
-    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1500)
+    r = subprocess.run(cmd, env=dict(_env(), SW_DDP_FC1_PANELS=str(panels)), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     for rank in range(2):
         res = torch.load(f"{out}.rank{rank}")
@@ -100,17 +111,23 @@ def test_stage3_semisup_step_two_ranks(tmp_path):
         assert any(k.endswith("_pseudo") for k in res["losses"])
 
 
+@pytest.mark.parametrize("mode", ["native", "native-graph", "torch-ddp"])
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
-def test_ddp_trainer_over_rccl_world_size_one(tmp_path, dtype):
+def test_ddp_trainer_over_rccl_world_size_one(tmp_path, dtype, mode):
     """the multi-GPU code path on the real RCCL backend (ProcessGroupNCCL streams / futures, DDP reducer, the per-bucket update hook,
     the metrics all-reduce) with the one GPU a test box has: bit-identical parameters to the plain Trainer"""
     out = str(tmp_path / "rccl1.pt")
     cmd = [sys.executable, os.path.join(ROOT, "tests", "ddp_rccl_single_worker.py"), out, dtype, str(_free_port())]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    if mode == "native-graph":
+        cmd.append("graph")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, SW_DDP_NATIVE="0" if mode == "torch-ddp" else "1")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     res = torch.load(out)
     assert res["backend"] == "nccl" and res["same"] and res["moved"] > 0
-    assert res["overlap_update"] and res["left_for_step"] == [0, 0, 0], res["left_for_step"]
+    assert res["native"] == (mode != "torch-ddp")
+    if mode == "native-graph":
+        assert res["replays"] >= 3, res["replays"]                # RCCL all-reduces between the replayed stage graphs
+    assert res["overlap_update"] and res["left_for_step"] == [0] * res["n_steps"], res["left_for_step"]
     assert res["stale_staged"] == [], res["stale_staged"]        # every bucket's update stamped its weight copies; none re-staged
     assert res["metrics"] == res["metrics_ref"] and len(res["metrics"]) == 9

@@ -395,6 +395,69 @@ def test_roi_pool_forward_slab_widths_of_large_maps(ops, dtype, H, W):
     assert torch.equal(out.cpu().float().reshape(ref_out.shape), torch.from_numpy(ref_out).to(dtype).float())
 
 
+@pytest.mark.parametrize("H,W,R", [(63, 63, 1500), (21, 30, 300), (60, 75, 900), (76, 114, 1200), (99, 165, 1600), (150, 200, 700), (9, 200, 200)])
+def test_roi_pool_forward_row_sparse_table_form_bit_exact(ops, H, W, R):
+    """bf16 forward through the row sparse table kernel (csrc/roipool.hip roi_pool_fwd_sparse_kernel: whole-map form up to ~4600 pixels,
+    row-band form beyond) against the C oracle on EVERY bin of every ROI of one 8-channel slab group: values, argmax and the objectness
+    prior.  The ROI set holds what the level rule has to survive: ROIs sticking out of the map on every side (windows the right edge
+    clips below the ROI's span read one span; on the left they take the pixel loop), ROIs far outside, malformed (end < start), one
+    pixel wide, the whole map, half-integer edges, widths right at a power of two, and (band form) ROIs reaching far below their
+    band.  Maps with plateaus (quantised values): ties must go to the first pixel in row-major order through the span maxima."""
+    n, C = 2, 16
+    rng = np.random.RandomState(H * 1000 + W)
+    feat = (np.round(rng.randn(n, C, H, W) * 2) / 2).astype(np.float32)          # many exact ties, negatives, zeros
+    feat[0, 3] = -np.inf; feat[1, 5, ::2] = np.nan; feat[0, 7] = -0.0
+    IH, IW = H * 8 + 8, W * 8 + 8                                                    # the image the map came from (map = H/8 - 1)
+    x1 = rng.rand(R) * (IW - 32); y1 = rng.rand(R) * (IH - 32)
+    bw = 16 + rng.rand(R) * (IW - x1 - 16); bh = 16 + rng.rand(R) * (IH - y1 - 16)
+    small = rng.rand(R) < 0.35                                                       # VOC-like: many small boxes
+    bw[small] = 16 + rng.rand(small.sum()) * 120; bh[small] = 16 + rng.rand(small.sum()) * 120
+    boxes = np.stack([x1, y1, np.minimum(x1 + bw, IW), np.minimum(y1 + bh, IH)], 1).astype(np.float32)
+    k = R // 10
+    boxes[:k, 0] -= rng.rand(k) * 200; boxes[:k, 1] -= rng.rand(k) * 200            # out on the left / top
+    boxes[k:2 * k, 2] += rng.rand(k) * 300; boxes[k:2 * k, 3] += rng.rand(k) * 300  # out on the right / bottom
+    pow2 = np.array([[8.0 * a, 8.0 * b, 8.0 * a + 8 * 7 * w_ - 8, 8.0 * b + 8 * 7 * w_ - 8] for a, b, w_ in
+                     [(1, 1, 1), (2, 3, 2), (0, 0, 4), (5, 1, 8), (W - 9, 2, 1), (W - 17, H - 17, 2), (W - 30, 1, 4)] if a >= 0 and b >= 0], np.float32)
+    special = np.array([[0, 0, 1e4, 1e4], [-500, -500, -100, -100], [100, 100, 90, 90], [IW - 9, IH - 9, IW + 40, IH + 40], [3.9, 3.9, 4.1, 4.1],
+                        [-40, 10, 8 * W + 50, 30], [20, -30, 40, 8 * H + 90], [4, 4, 12, 8 * H], [-1e4, -1e4, 1e4, 1e4], [60, 60, 67.9, 68.1]], np.float32)
+    boxes[2 * k:2 * k + len(special)] = special
+    boxes[2 * k + len(special):2 * k + len(special) + len(pow2)] = pow2
+    rois = np.concatenate([(np.arange(R) % n)[:, None].astype(np.float32), boxes], 1).astype(np.float32)
+    obj = rng.rand(R).astype(np.float32)
+    ref_out, ref_arg = O.roi_pool_fwd(feat, rois, 1.0 / 8)
+    ref_scaled = torch.from_numpy(ref_out) * (torch.from_numpy(obj) + 1).view(-1, 1, 1, 1)
+    f = _nhwc(torch.from_numpy(feat)).to(torch.bfloat16).cuda()
+    assert torch.equal(f.float().cpu().nan_to_num(7.0), _nhwc(torch.from_numpy(feat)).nan_to_num(7.0))       # the fixture is bf16-exact
+    for adt in (torch.int16, torch.int32):
+        out = torch.full((R, C * 49 + 8), 7.0, device="cuda", dtype=torch.bfloat16)[:, :C * 49]
+        arg = torch.empty(R, C * 49 + 8, device="cuda", dtype=adt)[:, :C * 49]
+        ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7, row_scale=torch.from_numpy(obj).cuda(), row_scale_add=1.0)
+        got_arg = ops.argmax_to_int32(arg.contiguous()).cpu().numpy().reshape(ref_arg.shape)
+        bad = np.argwhere(got_arg != ref_arg)
+        assert len(bad) == 0, (adt, len(bad), bad[:4].tolist(), [rois[b[0]].tolist() for b in bad[:2]])
+        got = out.cpu().float().reshape(ref_scaled.shape)
+        want = ref_scaled.to(torch.bfloat16).float()
+        assert torch.equal(got.nan_to_num(123.0), want.nan_to_num(123.0))
+        assert torch.all(out.as_strided((R, 8), (C * 49 + 8, 1), C * 49) == 7.0)
+
+
+def test_roi_pool_forward_row_sparse_table_form_other_pooled_sizes(ops):
+    """the sparse-table kernel with a pooled size other than the hot path's compile-time 7 x 7 (runtime PH x PW form): 6 x 5 and 3 x 8"""
+    n, C, H, W, R = 2, 8, 40, 52, 500
+    rng = np.random.RandomState(12)
+    feat = (np.round(rng.randn(n, C, H, W) * 2) / 2).astype(np.float32)
+    x1 = rng.rand(R) * (W * 8 - 32); y1 = rng.rand(R) * (H * 8 - 32)
+    boxes = np.stack([x1 - 20, y1 - 20, x1 + 16 + rng.rand(R) * 300, y1 + 16 + rng.rand(R) * 300], 1).astype(np.float32)
+    rois = np.concatenate([(np.arange(R) % n)[:, None].astype(np.float32), boxes], 1).astype(np.float32)
+    f = _nhwc(torch.from_numpy(feat)).to(torch.bfloat16).cuda()
+    for ph, pw in ((6, 5), (3, 8)):
+        ref_out, ref_arg = O.roi_pool_fwd(feat, rois, 1.0 / 8, ph, pw)
+        out = torch.empty(R, C * ph * pw, device="cuda", dtype=torch.bfloat16); arg = torch.empty(R, C * ph * pw, device="cuda", dtype=torch.int32)
+        ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, ph, pw)
+        assert np.array_equal(arg.cpu().numpy().reshape(ref_arg.shape), ref_arg), (ph, pw)
+        assert torch.equal(out.cpu().float().reshape(ref_out.shape), torch.from_numpy(ref_out))
+
+
 def test_roi_pool_large_map_uses_gather_form(ops):
     """a map whose H*W plane does not fit LDS falls back to the gather kernel; > 65534 pixels needs int32 indices"""
     n, C, H, W, R = 1, 8, 260, 256, 64
