@@ -221,7 +221,11 @@ def main():
     use_graph = (world == 1) if args.graph is None else bool(args.graph)
     trainer = Trainer(model, opt, use_graph=use_graph)
     B = args.images_per_gpu
-    batches = [sum((make_inputs(device, 100 + rank * 17 + 2 * i + 1000 * b) for b in range(B)), []) for i in range(2)]
+    # which (synthetic) images a rank sees: its shard of the shared-seed permutation stream, as the reference's TrainingSampler deals a
+    # dataset out (distributed_sampler.py:38-55; sos-wsod_amd/samplers.py) — rank r takes indices[r::world] of one VOC07-sized stream
+    from sos_wsod_amd.samplers import TrainingSampler
+    mine = TrainingSampler(5011, shuffle=True, seed=1234, rank=rank, world_size=world).take(2 * B)
+    batches = [sum((make_inputs(device, 100 + mine[i * B + b]) for b in range(B)), []) for i in range(2)]
 
     def sync():
         if world > 1:
@@ -521,14 +525,26 @@ def main():
                     md = build(device, dtype); md.train()
                     gs = [{"params": [p], "lr": 2e-3 if nm.endswith(".bias") else 1e-3, "weight_decay": 0.0 if nm.endswith(".bias") else 5e-4}
                           for nm, p in md.named_parameters() if p.requires_grad]
-                    td = Trainer(md, HipSGD(gs, 1e-3, momentum=0.9), ddp=True, use_graph=False)
-                    for i in range(6):
+                    # trainer._NativeDDP: own flat buckets, the backward in four stages with the all-reduces between them; with
+                    # use_graph every stage is a captured hipGraph (the collectives stay eager launches between the replays)
+                    td = Trainer(md, HipSGD(gs, 1e-3, momentum=0.9), ddp=True, use_graph=True)
+                    for i in range(8):
                         td.run_step(batches[i % 2])
                     torch.cuda.synchronize(); t1 = time.perf_counter()
                     for i in range(20):
                         td.run_step(batches[i % 2])
                     torch.cuda.synchronize()
                     out["ddp_rccl_world1_ms_per_step"] = round((time.perf_counter() - t1) / 20 * 1e3, 3)
+                    out["ddp_rccl_world1_mode"] = ("native reducer, 4 stage graphs + eager RCCL all-reduces" if td._native is not None and td._native.replays
+                                                   else "native reducer, eager" if td._native is not None else "torch DDP, eager")
+                    if td._native is not None:
+                        td._native.use_graph = False               # the same trainer issuing the stages launch by launch
+                        td.run_step(batches[0])
+                        torch.cuda.synchronize(); t1 = time.perf_counter()
+                        for i in range(10):
+                            td.run_step(batches[i % 2])
+                        torch.cuda.synchronize()
+                        out["ddp_rccl_world1_eager_ms_per_step"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
                     td.finish()
                     del td, md
                 finally:

@@ -641,14 +641,18 @@ class OICRPlusHeads(nn.Module):
         db1 = ops.grad_target(self.box_head.fc1.bias, (D1,), dev); ops.colsum(dz1, M, D1, db1)
         dW1 = ops.grad_target(self.box_head.fc1.weight, (D1, D0), dev)
         panels = getattr(self, "_fc6_panels", None)       # (n, callback): the data-parallel reducer's SW_DDP_FC1_PANELS
-        if M % epc == 0 and panels is not None and panels[0] > 1 and D1 % (256 * panels[0]) == 0:
+        if panels is not None and panels[0] > 1 and D1 % (256 * panels[0]) == 0:
             # the weight gradient in n row panels (whole 256-row tile rows each, so every output tile is computed exactly as in the
             # one-launch form: same bits); after each the reducer starts that panel's all-reduce — the 411 MB leave in n pieces
-            # while the later panels still compute
-            dzt = ops.transpose_2d(dz1, torch.empty(D1, M + 8 * epc, device=dev, dtype=dt_)[:, :M], M, D1)
+            # while the later panels still compute.  The panel count depends on D1 only: every rank issues the same collectives
+            # whatever its own proposal count (which only picks the GEMM form).
             rows = D1 // panels[0]
+            dzt = ops.transpose_2d(dz1, torch.empty(D1, M + 8 * epc, device=dev, dtype=dt_)[:, :M], M, D1) if M % epc == 0 else None
             for i in range(panels[0]):
-                ops.gemm(dzt[i * rows:(i + 1) * rows], pooled, dW1[i * rows:(i + 1) * rows], rows, D0, M, b_kstrided=True)
+                if dzt is not None:
+                    ops.gemm(dzt[i * rows:(i + 1) * rows], pooled, dW1[i * rows:(i + 1) * rows], rows, D0, M, b_kstrided=True)
+                else:
+                    ops.gemm(dz1[:, i * rows:(i + 1) * rows], pooled, dW1[i * rows:(i + 1) * rows], rows, D0, M, a_kstrided=True, b_kstrided=True)
                 panels[1](i, dW1[i * rows:(i + 1) * rows])
         elif M % epc == 0:                               # dZ^T as in stage 1; the tagged region holds the transpose too: one "fc6_wgrad" measurement
             def nn():

@@ -357,6 +357,8 @@ class _NativeDDP:
             ops.invalidate_all_staged()
         self.upd = torch.cuda.Stream(device=self.dev)
         self.main = torch.cuda.Stream(device=self.dev) if use_graph else None
+        self._dbg_sync = os.environ.get("SW_DDP_DEBUG_SYNC", "0") == "1"          # development switches
+        self._dbg_upd_main = os.environ.get("SW_DDP_UPD_MAIN", "0") == "1"
         n_pan = int(os.environ.get("SW_DDP_FC1_PANELS", "0"))
         self.panels = n_pan if n_pan > 1 else 0
         self._panel_work = []
@@ -425,7 +427,9 @@ class _NativeDDP:
 
     def _update(self, i, after=None):
         b = self.buckets[i]
-        with torch.cuda.stream(self.upd):
+        if self._dbg_sync:
+            torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.current_stream() if self._dbg_upd_main else self.upd):
             for job in b.work:
                 self._wait(job)
             if after is not None:

@@ -38,10 +38,14 @@ def main():
     K, R, H, W, dan = (20, 2000, 512, 512, (4096, 4096)) if full else (20, 60, 96, 128, (256, 256))
     P = O.make_params(K, dan, tag="pddp", head_scale=20.0)
 
+    graph = os.environ.get("SW_STEP_GRAPH", "0") == "1"        # stage graphs: a signature is captured the second time it is seen
+
     def data_of(r, step):
         views, gt = O.make_views(H + 16 * r, W, R + 7 * r, n_gt=2, K=K, scale2=1.0 if full else 1.25,
                                  tag=f"vddp{r}_{step}")                                       # ranks see different sizes
-        return to_batched_inputs(views, gt)
+        if graph:                                                  # one signature per rank: the number of image-level classes is part of it
+            _, gt = O.make_views(H + 16 * r, W, R + 7 * r, n_gt=2, K=K, scale2=1.0 if full else 1.25, tag=f"vddp{r}_0")
+        return to_batched_inputs(views, gt, device=dev if graph else None)
 
     def fresh():
         m = build_model(K, dan, dtype, device=dev)
@@ -49,8 +53,10 @@ def main():
         m.train()
         return m
 
+    LR = 1e-4 if graph else 1e-2      # (five steps at 1e-2 diverge on this fixture: loss 7 -> 233 -> 2e4 -> 3e21 -> NaN, data parallel or not)
+
     def groups(m):
-        return [{"params": [p], "lr": 2e-2 if n.endswith(".bias") else 1e-2, "weight_decay": 0.0 if n.endswith(".bias") else 5e-4}
+        return [{"params": [p], "lr": 2 * LR if n.endswith(".bias") else LR, "weight_decay": 0.0 if n.endswith(".bias") else 5e-4}
                 for n, p in m.named_parameters() if p.requires_grad]
 
     def set_stream(m, r, counter):
@@ -64,9 +70,9 @@ def main():
 
     from sos_wsod_amd.events import EventStorage
     # ---- single-process replica: per step the mean of both ranks' gradients, own HipSGD
-    N_STEPS = 1 if full else 3
+    N_STEPS = 1 if full else (5 if graph else 3)
     rep = fresh()
-    rep_opt = HipSGD(groups(rep), 1e-2, momentum=0.9)
+    rep_opt = HipSGD(groups(rep), LR, momentum=0.9)
     counters = [0, 0]
     mean_grads = []
     for step in range(N_STEPS):
@@ -92,7 +98,7 @@ def main():
     # ---- the DDP run
     model = fresh()
     set_stream(model, rank, 0)
-    opt = HipSGD(groups(model), 1e-2, momentum=0.9)
+    opt = HipSGD(groups(model), LR, momentum=0.9)
     tr = Trainer(model, opt, check_finite_every=1, metrics_period=1)
     native = os.environ.get("SW_DDP_NATIVE", "1") == "1"
     assert (tr._native is not None) if native else isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)

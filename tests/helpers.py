@@ -38,7 +38,8 @@ def load_params(model, P):
             sd[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
 
 
-def to_batched_inputs(views, gt):
+def to_batched_inputs(views, gt, device=None):
+    """device: put the images and proposals there (a step graph replays only for device-resident inputs; labels stay on the host)"""
     from sos_wsod_amd.structures import Boxes, Instances
     d = {}
     for name, v in zip(["1", "1_flip", "2", "2_flip"], views):
@@ -50,6 +51,9 @@ def to_batched_inputs(views, gt):
         t.gt_boxes = Boxes(torch.zeros(len(gt), 4))
         t.gt_classes = torch.from_numpy(np.asarray(gt, np.int64))
         d["image" + name] = torch.from_numpy(np.ascontiguousarray(v["image"]))
+        if device is not None:
+            p.proposal_boxes = Boxes(p.proposal_boxes.tensor.to(device)); p.objectness_logits = p.objectness_logits.to(device)
+            d["image" + name] = d["image" + name].to(device)
         d["proposals" + name] = p
         d["instances" + name] = t
     return [d]

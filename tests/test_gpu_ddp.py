@@ -65,7 +65,7 @@ def test_real_model_two_ranks_gradients_and_parameters(tmp_path, dtype, mode):
         assert res["dropout_seeds_differ"]
         assert len(res["metrics"]) == 9 and all(v == v for v in res["metrics"].values())
         # the update ran bucket by bucket inside DDP's communication hook: nothing was left for the step() after the backward
-        assert res["overlap_update"] and res["left_for_step"] == [0, 0, 0], res["left_for_step"]
+        assert res["overlap_update"] and set(res["left_for_step"]) == {0}, res["left_for_step"]
 
 
 @pytest.mark.parametrize("panels", [0, 4])
