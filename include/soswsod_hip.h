@@ -96,6 +96,18 @@ typedef struct sw_conv_problem {
   const sw_epilogue* ep;
 } sw_conv_problem;
 int sw_conv3x3_multi(int dtype, int n, const sw_conv_problem* probs, sw_stream_t stream);
+/* The same convolution (reference: uwsod/projects/WSL/wsl/modeling/backbone/vgg.py:104-122 forward, autograd's data gradient) in
+ * Winograd F(2x2, 3x3) form — 16 multiplications per 2x2 outputs instead of 36 — for bf16 layers with Cin % 32 == 0, dilation 1
+ * or 2 (dilation 2 = the four parity classes of the pixel grid as dilation-1 problems).  U: the transformed filters
+ * [16][Cout][Cin] bf16 written by sw_winograd_weight_prep.  Epilogue as sw_conv3x3_igemm's (bias, relu | relu_ref).
+ * Returns 1 = launched, 0 = shape / epilogue not covered (call sw_conv3x3_igemm), < 0 = error. */
+int sw_conv3x3_winograd(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in, const void* U,
+                        void* out, const sw_epilogue* ep, sw_stream_t stream);
+/* Transformed filters U = G g G^T of n layers in ONE launch, from the f32 OIHW masters (w: Cout x Cin x 3 x 3), rounded to bf16 once.
+ * mode 0: forward filters, U [16][Cout][Cin]; mode 1: the data gradient's filters g'[ci][co][ky][kx] = g[co][ci][2-ky][2-kx],
+ * U [16][Cin][Cout].  `descs` is a HOST array. */
+typedef struct sw_winograd_prep { const float* w; void* U; int32_t Cout, Cin, mode; } sw_winograd_prep;
+int sw_winograd_weight_prep(int n, const sw_winograd_prep* descs, sw_stream_t stream);
 /* dW (OIHW f32, overwritten) from x [nimg][H][W][Cin] and dy [nimg][H][W][Cout].  workspace: at least
  * sw_conv3x3_wgrad_workspace_floats(...) floats: every K-split stores its partial [co][tap][ci] tile into its own
  * slab (plain stores), a second kernel adds the slabs in fixed order and permutes to OIHW (deterministic). */

@@ -63,6 +63,11 @@ class ConvProblem(ctypes.Structure):
                 ("in_", ctypes.c_void_p), ("wk", ctypes.c_void_p), ("out", ctypes.c_void_p), ("ep", ctypes.POINTER(Epilogue))]
 
 
+class WinogradPrep(ctypes.Structure):
+    """sw_winograd_prep"""
+    _fields_ = [("w", ctypes.c_void_p), ("U", ctypes.c_void_p), ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32), ("mode", ctypes.c_int32)]
+
+
 class CopyDesc(ctypes.Structure):
     """sw_copy_desc"""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_long)]
@@ -157,6 +162,8 @@ SIGNATURES = {
     "sw_conv3x3_wgrad_fold_acc": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sw_conv3x3_wgrad_fold_multi": (c_int, [c_int, ctypes.POINTER(WgradFold), c_void_p]),
     "sw_conv3x3_multi": (c_int, [c_int, c_int, ctypes.POINTER(ConvProblem), c_void_p]),
+    "sw_conv3x3_winograd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, _EP, c_void_p]),
+    "sw_winograd_weight_prep": (c_int, [c_int, ctypes.POINTER(WinogradPrep), c_void_p]),
     "sw_gemm_kk_grouped": (c_int, [c_int, c_int, ctypes.POINTER(GemmKKProblem), c_void_p]),
     "sw_gemm_kk_grouped_slabs": (c_long, [c_int, c_int, c_int]),
     "sw_splitk_fold_multi": (c_int, [c_int, ctypes.POINTER(SplitkFold), c_void_p]),

@@ -146,10 +146,12 @@ class _VGGFunction(torch.autograd.Function):
                 w, b = params[pi], params[pi + 1]
                 pi += 2
                 cin = cur.shape[3]
-                wk = module.staged_weight(w, 0, cin, dtype)
                 out = torch.empty(cur.shape[0], cur.shape[1], cur.shape[2], blk.out_channels, device=x.device, dtype=dtype)
-                ops.conv3x3(cur, wk, out, blk.dilation, ops.make_epilogue(bias=b, relu=True, out_dtype=dtype),
-                            tag=f"{blk.tag}.conv{ci + 1}_fwd")
+                ep = ops.make_epilogue(bias=b, relu=True, out_dtype=dtype)
+                if not (module.winograd_ok(cin, blk.out_channels) and
+                        ops.conv3x3_winograd(cur, module.winograd_weight(w, 0), out, blk.dilation, ep, tag=f"{blk.tag}.conv{ci + 1}_fwd")):
+                    wk = module.staged_weight(w, 0, cin, dtype)
+                    ops.conv3x3(cur, wk, out, blk.dilation, ep, tag=f"{blk.tag}.conv{ci + 1}_fwd")
                 conv_io.append((cur, out))
                 cur = out
             pre_pool = None
@@ -290,10 +292,13 @@ class _VGGFunction(torch.autograd.Function):
                     return
                 # data gradient: conv with flipped/transposed weights; ReLU mask of the producer fused when the
                 # input is a direct conv output (ci > 0); stage inputs go through the pool backward instead
-                wkd = module.staged_weight(w, 1, cin, dtype)
                 dx = torch.empty(n, H, W, cin, device=g.device, dtype=dtype)
                 ref = x_in.view(n * H * W, cin) if ci > 0 else None
-                ops.conv3x3(dz, wkd, dx, blk.dilation, ops.make_epilogue(relu_ref=ref, out_dtype=dtype))
+                epd = ops.make_epilogue(relu_ref=ref, out_dtype=dtype)
+                if not (module.winograd_ok(blk.out_channels, cin) and
+                        ops.conv3x3_winograd(dz, module.winograd_weight(w, 1), dx, blk.dilation, epd)):
+                    wkd = module.staged_weight(w, 1, cin, dtype)
+                    ops.conv3x3(dz, wkd, dx, blk.dilation, epd)
                 dz = dx
             # dz is now the gradient wrt this stage's input = previous stage's pooled output
             prev_pre_pool = stage_info[si - 1][1]
@@ -315,6 +320,14 @@ class VGG16(nn.Module):
         self.wgrad_target_ktiles = int(os.environ.get("SW_WGRAD_KTILES", "0"))   # 0: chosen per shape set (_wgrad_grouped_target)
         self._side = None
         self._wk_cache = {}
+        # Winograd F(2x2, 3x3) for the forward / data gradient of the wide bf16 layers (csrc/conv_winograd.hip): 2.25x fewer MFMA cycles
+        # than the direct kernel — built, bit-validated (relative L2 3.8e-3 against float64, the direct form 2.4e-3) and MEASURED SLOWER
+        # on this part: conv5_3 42.4 vs 38.2 us, conv3_2 49.4 vs 39.3 us (profiles/r05_winograd_experiment.txt: the f32 input transform
+        # and three barriers per 32-channel chunk cost more than the MFMAs saved).  So it is OFF by default; SW_CONV_WINOGRAD=1 routes
+        # the layers with Cin >= SW_WINOGRAD_MIN_CIN (default 256: conv3_2 .. conv5_3) through it.  fp32 mode never uses it.
+        self.winograd = os.environ.get("SW_CONV_WINOGRAD", "0") == "1" and compute_dtype == torch.bfloat16
+        self.winograd_min_cin = int(os.environ.get("SW_WINOGRAD_MIN_CIN", "256"))
+        self._wino_cache = {}
         self._out_feature_strides, self._out_feature_channels = {}, {}
         self.stages_and_names = []
         strides = {"plain1": 2, "plain2": 4, "plain3": 8, "plain4": 8 if conv5_dilation == 2 else 16,
@@ -367,6 +380,35 @@ class VGG16(nn.Module):
             self._register_staging(w, dtype)
         return wk
 
+    def winograd_ok(self, cin, cout):
+        return self.winograd and cin >= self.winograd_min_cin and cin % 32 == 0 and cout % 2 == 0
+
+    def winograd_weight(self, w, mode):
+        """the transformed filters U = G g G^T (bf16, (16, n_out, n_in)) of an OIHW master for the Winograd kernel — mode 0 forward,
+        1 data gradient — current for the parameter's present value (stage_all_weights builds every stale one in ONE launch; a
+        miss here builds its own)"""
+        hit = self._wino_cache.get((id(w), mode))
+        if hit is None or hit[0] != ops.param_key(w):
+            self._winograd_refresh([(w, mode)])
+            hit = self._wino_cache[(id(w), mode)]
+        return hit[1]
+
+    def _winograd_refresh(self, wanted):
+        items = []
+        for w, mode in wanted:
+            key = ops.param_key(w)
+            hit = self._wino_cache.get((id(w), mode))
+            if hit is not None and hit[0] == key:
+                continue
+            cout, cin = w.shape[:2]
+            shape = (16, cout, cin) if mode == 0 else (16, cin, cout)
+            U = hit[1] if (hit is not None and tuple(hit[1].shape) == shape and hit[1].device == w.device) else \
+                torch.empty(shape, device=w.device, dtype=torch.bfloat16)
+            items.append((w.detach(), U, mode))
+            self._wino_cache[(id(w), mode)] = (key, U)
+        if items:
+            ops.winograd_weight_prep(items)
+
     def _register_staging(self, w, dtype):
         cout, cin = w.shape[:2]
         s0, s1 = self._wk_cache.get((id(w), 0)), self._wk_cache.get((id(w), 1))
@@ -387,12 +429,24 @@ class VGG16(nn.Module):
         dtype = self.compute_dtype
         epc = _epc(dtype)
         ft = self.first_trainable_conv()
+        wino = []
         for si, blk in enumerate(self.blocks):
             for ci, c in enumerate(blk.convs()):
-                cin = c.weight.shape[1]
+                cout, cin = c.weight.shape[:2]
+                if self.winograd_ok(cin, cout):                      # the Winograd layers take transformed filters instead
+                    wino.append((c.weight, 0))
+                    if with_dgrad and ft is not None and (si, ci) > ft and self.winograd_ok(cout, cin):
+                        wino.append((c.weight, 1))
+                    elif with_dgrad and ft is not None and (si, ci) > ft:
+                        self.staged_weight(c.weight, 1, cin, dtype)
+                    continue
                 self.staged_weight(c.weight, 0, (cin + epc - 1) // epc * epc, dtype)
                 if with_dgrad and ft is not None and (si, ci) > ft:
-                    self.staged_weight(c.weight, 1, cin, dtype)
+                    if self.winograd_ok(cout, cin):
+                        wino.append((c.weight, 1))
+                    else:
+                        self.staged_weight(c.weight, 1, cin, dtype)
+        self._winograd_refresh(wino)
 
     def first_trainable_conv(self):
         for si, blk in enumerate(self.blocks):

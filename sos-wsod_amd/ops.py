@@ -248,6 +248,31 @@ def gemm(A, B, C, M, N, K, a_kstrided=False, b_kstrided=False, lda=None, ldb=Non
     return C
 
 
+def conv3x3_winograd(x, U, out, dilation, ep, tag=None):
+    """x [n][H][W][Cin], U [16][Cout][Cin] (winograd_weight_prep), out [n][H][W][Cout], bf16.  -> True if the Winograd kernel ran"""
+    _need_gpu(x, U, out)
+    n, H, W, Cin = x.shape
+    Cout = out.shape[3]
+    rc = _launch(tag, lambda: lib.sw_conv3x3_winograd(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(U), _p(out), ctypes.byref(ep), _stream()))
+    if rc < 0:
+        check(-rc, "sw_conv3x3_winograd")
+    return rc == 1
+
+
+def winograd_weight_prep(items):
+    """items: [(w f32 OIHW master, U bf16 (16, n_out, n_in), mode)]: every layer's transformed filters in one launch"""
+    from ._lib import WinogradPrep
+    n = len(items)
+    if n == 0:
+        return
+    arr = (WinogradPrep * n)()
+    for i, (w, U, mode) in enumerate(items):
+        _need_gpu(w, U)
+        assert w.dtype == torch.float32 and w.is_contiguous() and U.dtype == torch.bfloat16 and U.is_contiguous() and U.numel() == 16 * w.shape[0] * w.shape[1]
+        arr[i].w, arr[i].U, arr[i].Cout, arr[i].Cin, arr[i].mode = w.data_ptr(), U.data_ptr(), w.shape[0], w.shape[1], int(mode)
+    check(lib.sw_winograd_weight_prep(n, arr, _stream()), "sw_winograd_weight_prep")
+
+
 def conv3x3(x, wk, out, dilation, ep, tag=None):
     """x [n][H][W][Cin], wk [Cout][9][Cin], out [n][H][W][Cout]"""
     _need_gpu(x, wk, out)

@@ -236,6 +236,44 @@ def test_maxpool_fwd_bwd(ops, dtype, stride, C, H, W):
     assert (din.cpu().float() - ref).abs().max() <= tol * ref.abs().max()
 
 
+@pytest.mark.parametrize("n,H,W,Cin,Cout,dil,mode", [(1, 37, 50, 64, 96, 1, 0), (2, 21, 30, 64, 64, 2, 0), (1, 37, 50, 96, 64, 2, 1),
+                                                    (2, 63, 63, 256, 128, 2, 0), (1, 64, 64, 128, 256, 1, 1)])
+def test_conv3x3_winograd_form_against_float64_and_the_direct_kernel(ops, n, H, W, Cin, Cout, dil, mode):
+    """csrc/conv_winograd.hip (F(2x2, 3x3), bf16; an opt-in form: SW_CONV_WINOGRAD=1): forward (bias + ReLU) and data gradient (flipped
+    filters, ReLU mask of the producer) on ragged maps, a channel count that is not a multiple of the 64-channel block, dilation 2
+    (four parity classes).  Against a float64 convolution of the same bf16 inputs and f32 master filters: relative L2 <= 6e-3 (measured
+    3.7e-3 - 4.3e-3; the direct kernel 2.3e-3; one bf16 rounding of the output alone is 1.7e-3), and within 1e-2 of the direct kernel."""
+    import math
+    g = torch.Generator().manual_seed(H * 7 + Cin + mode)
+    x = (torch.randn(n, H, W, Cin, generator=g).relu() * 1.5).to(torch.bfloat16).cuda()
+    wm = (torch.randn(Cout, Cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * Cin))).cuda()
+    bias = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    if mode == 0:
+        n_out, n_in, xin = Cout, Cin, x
+        ep = ops.make_epilogue(bias=bias, relu=True, out_dtype=torch.bfloat16)
+        wk = torch.zeros(Cout, 9, Cin, device="cuda", dtype=torch.bfloat16); ops.conv_weight_prep(wm, wk, 0, Cin)
+        ref = F.conv2d(xin.double().cpu().permute(0, 3, 1, 2), wm.double().cpu(), bias.double().cpu(), padding=dil, dilation=dil).relu()
+    else:
+        n_out, n_in = Cin, Cout
+        xin = (torch.randn(n, H, W, Cout, generator=g) * 0.1).to(torch.bfloat16).cuda()
+        ep = ops.make_epilogue(relu_ref=x.view(n * H * W, Cin), out_dtype=torch.bfloat16)
+        wk = torch.zeros(Cin, 9, Cout, device="cuda", dtype=torch.bfloat16); ops.conv_weight_prep(wm, wk, 1, None)
+        wt = wm.double().cpu().flip(2, 3).permute(1, 0, 2, 3)
+        ref = F.conv2d(xin.double().cpu().permute(0, 3, 1, 2), wt, None, padding=dil, dilation=dil) * (x.double().cpu().permute(0, 3, 1, 2) > 0)
+    ref = ref.permute(0, 2, 3, 1)
+    U = torch.empty(16, n_out, n_in, device="cuda", dtype=torch.bfloat16)
+    ops.winograd_weight_prep([(wm, U, mode)])
+    out_w = torch.full((n, H, W, n_out), 7.0, device="cuda", dtype=torch.bfloat16); out_d = torch.empty_like(out_w)
+    assert ops.conv3x3_winograd(xin, U, out_w, dil, ep)
+    ops.conv3x3(xin, wk, out_d, dil, ep)
+    torch.cuda.synchronize()
+    ew = float((out_w.double().cpu() - ref).norm() / ref.norm())
+    assert ew <= 6e-3, ew
+    assert float((out_w.double() - out_d.double()).norm() / out_d.double().norm()) <= 1e-2
+    if mode == 1:                                                 # masked positions are exact zeros in both forms
+        assert torch.equal(out_w == 0, out_d == 0) or float(((out_w == 0) != (out_d == 0)).float().mean()) < 1e-3
+
+
 # ------------------------------------------------------------------------------------------ ROIPool
 @pytest.mark.parametrize("adt", [torch.int32, torch.int16])
 @pytest.mark.parametrize("dtype", DT)
