@@ -314,7 +314,7 @@ def main():
         e1.record(); torch.cuda.synchronize()
         conv_alone_ms = e0.elapsed_time(e1) / 20
         # HBM bytes per call from the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh): (2*FETCH_SIZE + WRITE_SIZE)*1024
-        pmc = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"))
+        pmc = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"))
                     if os.path.exists(p)), None)
         traffic = json.load(open(pmc)) if pmc else {}
         roofline = roof(dom)
@@ -334,7 +334,7 @@ def main():
         # counter-based MFMA utilisation of the same kernels run alone (tools/pmc_mfma.sh, committed under profiles/):
         # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32).  The FLOP-based `frac` prices against the 2.4 GHz peak;
         # under MFMA load the chip runs 1.6-2.0 GHz (DVFS), so the pipe is busier than `frac` says.
-        busy_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_mfma_busy.json", "r03_mfma_busy.json", "r02_mfma_busy.json", "r01_mfma_busy.json"))
+        busy_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r05_mfma_busy.json", "r04_mfma_busy.json", "r03_mfma_busy.json", "r02_mfma_busy.json", "r01_mfma_busy.json"))
                           if os.path.exists(p)), None)
         busy = json.load(open(busy_path)) if busy_path else {}
 
@@ -467,6 +467,26 @@ def main():
             torch.cuda.synchronize()
             phase("mixed run")
             out["mixed_ms_per_step"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+            # (2b) where training actually runs: the VOC recipe draws two DISTINCT short sides from 480 .. 1216 (step 32) per image
+            # (voc07_oicr_plus.yaml:30, dataset_mapper.py:303-317); a 500 x 375 image at 6 seeded scale pairs, eager launches
+            # (every pair is a new input signature), 2 timed steps each after 1 warm-up: the mean is `recipe_ms_per_step`
+            import random
+            rnd = random.Random(1234)
+            shorts = list(range(480, 1217, 32))
+            pairs_ = [tuple(rnd.sample(shorts, 2)) for _ in range(6)]
+            per_pair = []
+            for s1, s2 in pairs_:
+                dat = make_inputs(device, 900 + s1, H=s1, W=int(500.0 / 375.0 * s1 + 0.5), scale2=s2 / s1)
+                tmx.run_step(dat)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(2):
+                    tmx.run_step(dat)
+                torch.cuda.synchronize()
+                per_pair.append(round((time.perf_counter() - t1) / 2 * 1e3, 2))
+                del dat
+            out["recipe_ms_per_step"] = round(sum(per_pair) / len(per_pair), 3)
+            out["recipe_pairs"] = {"short_sides": pairs_, "ms_per_step": per_pair, "image": "500x375 (W x H), R=2000, K=20"}
+            phase("recipe-scale run")
             del tmx, mm
             torch.cuda.empty_cache()
             mb = build(device, dtype)
@@ -482,6 +502,7 @@ def main():
             out["coco_ms_per_step"] = round(ms, 3)
             out["extra_shapes"] = {"peaky": "the headline shape with the class predictors scaled x30 (mining / NMS see > 1000 candidates), lr 0",
                                    "mixed": "views 512x512 + 640x640 (two different scales, as the reference's mapper always draws), eager launches",
+                                   "recipe": "a 500x375 image at 6 seeded pairs of the VOC recipe's short sides (480..1216 step 32), eager launches",
                                    "b2": "BASELINE configs[2] per GPU: 2 images = 8 views 512x512, R=2000, K=20",
                                    "coco": "BASELINE configs[3] per GPU: 4 views 800x1333 (99x165 maps), R=4000, K=80, FREEZE_AT 3"}
             del mc

@@ -54,7 +54,7 @@ class PlainBlock(nn.Module):
 
 def _wgrad_splitk(cout, cin, npix):
     """K-splits of a conv weight gradient: tiles x splits just under one resident wave of workgroups (256 CUs x 2 at 64 KiB
-    LDS each = 512 slots) was the optimum for every conv3..conv5 shape (tools/wgrad_sweep.py: 3 / 7 / 14 / 28 splits); one
+    LDS each = 512 slots) was the optimum for every conv3..conv5 shape (tools/probes/wgrad_sweep.py: 3 / 7 / 14 / 28 splits); one
     more split starts a second, mostly empty wave (+30 %)"""
     tiles = ((cout + 127) // 128) * ((9 * cin + 127) // 128)
     return max(1, min(32, 512 // tiles, max(1, npix // 1024)))

@@ -47,7 +47,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // wave pair).  Those layers have only ~256 tiles of 256 pixels x 64 channels: one four-wave workgroup per CU leaves one wave
 // per SIMD (nothing to overlap LDS latency with), 32-channel tiles give two waves per SIMD but read 0.75 KiB of LDS per MFMA
 // (6 fragments per 8 MFMAs).  Splitting K inside the workgroup gives two waves per SIMD at 0.5 KiB per MFMA and 30 % fewer bytes
-// staged per output.  160 KiB LDS at dilation 2.  Counters of the conv5_3 launch (tools/pmc_kernel.sh conv5_3): MFMA pipe 51 % busy,
+// staged per output.  160 KiB LDS at dilation 2.  Counters of the conv5_3 launch (tools/probes/pmc_kernel.sh conv5_3): MFMA pipe 51 % busy,
 // LDS 27 % busy with 0 bank-conflict cycles, 2.4 M non-MFMA VALU instructions against 2.36 M MFMAs — with ONE workgroup per CU the
 // ~7 us of prologue (first patch + weights from HBM) and epilogue (partial-sum exchange, store) of the 38 us launch overlap with
 // nothing; inside the training step the second backbone stream's launches fill them (two concurrent launches: 62 us for both).

@@ -549,7 +549,7 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
         constexpr int PPR = WTN / CP;
         // 64 % PPR == 0: a lane keeps the SAME CP columns for every row piece it handles — its bias values are loaded once per
         // quarter, not once per element, and the ReLU-mask reference of a full 16-byte-aligned piece is ONE load (fc6's data
-        // gradient 1.258 -> 1.23 ms inside the step; tools/fc7_probe.py: a bias / ReLU / mask epilogue costs 10 us per round of
+        // gradient 1.258 -> 1.23 ms inside the step; tools/probes/fc7_probe.py: a bias / ReLU / mask epilogue costs 10 us per round of
         // 256x256 tiles over the plain one)
         const int c0 = (lane % PPR) * CP;
         const int nb = n0t + wn * WTN + c0;
@@ -911,7 +911,7 @@ int launch_auto(GemmArgs& g, int splitk, hipStream_t s) {
   auto tiles = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * sk; };
   // the 256x256 tile pays off once the K loop is long enough to hide its prologue / epilogue: the 1x1 convolutions of a ResNet
   // (121 600 pixels x 256 channels, K = 64 .. 256: memory bound) ran 4x slower on it than on the 128x128 tile, two workgroups per
-  // CU (244 vs 57 us; tools/gemm_1x1_probe.py).  Every fc / conv shape of the OICR+ step has K >= 1152.
+  // CU (244 vs 57 us; tools/probes/gemm_1x1_probe.py).  Every fc / conv shape of the OICR+ step has K >= 1152.
   const bool big = (v && v[0] == '4') ? true : (v && v[0] == '8') ? false : (g.N > 128 && tiles(256, 256) >= 200 && g.K >= 1024);
   if (big) {
 #ifdef SW_GEMM_TRY_4WAVE
@@ -1065,7 +1065,7 @@ bool peel_geometry(int M, int N, int* r_out, long* sk_out) {
   if (!r) return false;
   const int N2 = N - (int)((tn - r) * 256);
   // the tail runs on 128x128 tiles, two workgroups per CU: K-splits to ~512 workgroups (fc6: 4 splits of 128 tiles =
-  // 60 us; 8 splits put it on 256x256 tiles: 81 us; tools/wgrad_tail.py)
+  // 60 us; 8 splits put it on 256x256 tiles: 81 us; tools/probes/wgrad_tail.py)
   const long t128 = ((M + 127) / 128) * ((N2 + 127) / 128);
   long sk = 512 / t128;
   sk = sk < 1 ? 1 : (sk > 8 ? 8 : sk);

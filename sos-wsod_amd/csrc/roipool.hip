@@ -201,7 +201,7 @@ __global__ __launch_bounds__(1024) void roi_pool_bwd_kernel(int H, int W, int C,
   }
 }
 
-// Backward, fixed-point path.  Measured on MI355X (tools/roi_bench.py): LDS float atomics (ds_add_f32) run ~3.4x
+// Backward, fixed-point path.  Measured on MI355X (tools/probes/roi_bench.py): LDS float atomics (ds_add_f32) run ~3.4x
 // slower than LDS integer atomics (ds_add_u32 / ds_add_u64 ~ plain ds_write rate) and set the kernel's time.  So the slab
 // accumulates in 64-bit fixed point: every product grad*scale (rounded to f32 exactly as the float path does) is
 // converted with 2^FRAC, FRAC chosen from max|grad|*max|scale| so that 2^40 bounds one term and PH*PW*R_image terms (a pixel

@@ -265,7 +265,7 @@ class _Conv3x3Fn(torch.autograd.Function):
 
 def _few_tile_splits(P, N, K):
     """K-splits of a bf16 / f32 GEMM with an epilogue whose tile grid fills a fraction of the chip (res5's 1x1 convolutions, the box
-    head's fc6 on 512-1024 ROIs): slabs + the epilogue in the fold (sw_gemm).  Measured (tools/gemm_splitk_ep_probe.py): pays from
+    head's fc6 on 512-1024 ROIs): slabs + the epilogue in the fold (sw_gemm).  Measured (tools/probes/gemm_splitk_ep_probe.py): pays from
     K = 2048 on — K = 12544, 64 tiles: 103 -> 46 us; K = 2048, 32-64 tiles: 28 -> 22 us; K = 1024: 19 -> 22 us (not split)."""
     if K < 2048:
         return 1
@@ -365,7 +365,7 @@ def _small_map(H, W):
 def _flush_wgrad_3x3(q):
     """all queued (x, dy) pairs of one 3x3 weight: ONE grouped 256x256-tile launch (sw_conv3x3_wgrad_grouped: every pair's K-splits
     as work items of one resident grid) + ONE fold over all slabs (x FrozenBN scale) into the buffer autograd already holds.
-    Measured (tools/stage3_grouped_wgrad_probe.py): the RPN head's 10 uses 641 -> 383 us, an FPN output convolution's two 330 -> 256
+    Measured (tools/probes/stage3_grouped_wgrad_probe.py): the RPN head's 10 uses 641 -> 383 us, an FPN output convolution's two 330 -> 256
     (p2) / 71 -> 46 (p4), res5 conv2 83 -> 48, res3 conv2 74 -> 52."""
     from .backbone_vgg import _wgrad_grouped_splits, _wgrad_grouped_target
     dw, scale, probs = q["buf"], q["scale"], q["probs"]

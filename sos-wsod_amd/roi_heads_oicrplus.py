@@ -53,7 +53,7 @@ def get_image_level_gt(targets, num_classes):
 def _padded(rows, cols, device, dtype, pad=128):
     """rows x cols matrix whose row pitch is NOT a multiple of 1 KiB.  The 4096- and 25088-wide bf16 matrices of the box
     head have 8 KiB / 49 KiB pitches: the rows of a GEMM tile then start on the same HBM channel / L2 set and the
-    K-tile loads queue behind each other (measured: fc7 fwd 267 -> 221 us, fc6 dgrad 1840 -> 1684 us; tools/gemm_ld_sweep*.py)."""
+    K-tile loads queue behind each other (measured: fc7 fwd 267 -> 221 us, fc6 dgrad 1840 -> 1684 us; tools/probes/gemm_ld_sweep*.py)."""
     return torch.empty(rows, cols + pad, device=device, dtype=dtype)[:, :cols]
 
 

@@ -1,6 +1,6 @@
 """Does the steady-state training step still call hipMalloc / hipFree (caching-allocator misses)?"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench
 from sos_wsod_amd.solver import HipSGD
 from sos_wsod_amd.trainer import Trainer

@@ -1,6 +1,6 @@
 """conv5_3 / conv4_2 forward alone (20 back-to-back launches), for kernel experiments"""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 rnd = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(dt)

@@ -1,7 +1,7 @@
 """direct conv forward at batch 2 vs batch 4 (= both scales of an image in ONE launch when their sizes agree) under the kernel's
 development switches: which tile form wins when a layer's two view batches share a launch?  TAG / SW_CONV_DIRECT_KG / _TN from env."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 rnd = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(dt)

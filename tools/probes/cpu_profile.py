@@ -7,7 +7,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench  # noqa: E402
 from sos_wsod_amd.solver import HipSGD  # noqa: E402
 from sos_wsod_amd.trainer import Trainer  # noqa: E402

@@ -1,6 +1,6 @@
 """How much of the fc6 weight-gradient GEMM is its f32 epilogue: the same output tiles with K = 64 (one K-tile)"""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def timeit(fn, n=10):

@@ -1,7 +1,7 @@
 """fc7-sized GEMMs (8000 x 4096 x 4096: 2 rounds of 256x256 tiles with only 64 K-steps each) under the tile / loop variants the
 development switches select (run one process per variant: SW_GEMM_V, SW_GEMM_PP are read once)."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def t(fn, n=20):

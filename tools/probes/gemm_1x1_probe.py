@@ -1,7 +1,7 @@
 """1x1-convolution-shaped GEMMs (many pixels, few channels: memory bound) on the 256x256 ping-pong tile against the 128x128 one
 (SW_GEMM_V=8 forces the small tile).  y (P, N) = x (P, K) @ W^T (N, K), bf16, bias + ReLU epilogue."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def t(fn, n=20):

@@ -1,6 +1,6 @@
 """fc6 dgrad / wgrad as they are (NN / TN) vs as NT GEMMs on pre-transposed operands (what explicit transposes could buy)."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def timeit(fn, n=10):

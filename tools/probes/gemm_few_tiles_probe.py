@@ -1,7 +1,7 @@
 """Few-tile, long-K GEMMs of the Stage-3 detector (res4 / res5 1x1 convolutions, their data and weight gradients, the box head's fc6
 at 512-1024 ROIs): SW_GEMM_DEEP=0 (2-buffer ring) against the default (4-buffer ring when tiles x splits <= 256, K >= 512)."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def t(fn, n=20):

@@ -1,6 +1,6 @@
 """bf16 GEMM rate against K at the fc shapes (how much of a launch is prologue / epilogue)."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def timeit(fn, n=10):

@@ -1,6 +1,6 @@
 """bf16 GEMM rate by operand layout at one neutral shape (M=N=K=8192): which operand's K-strided staging costs what."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def timeit(fn, n=10):

@@ -1,6 +1,6 @@
 """Row-pitch sensitivity of the fc7 GEMMs (power-of-two 8 KiB pitch) and of fc6 fwd with a padded W1 pitch."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def timeit(fn, n=20):

@@ -1,6 +1,6 @@
 """Plain NT GEMM at the conv4/conv5 implicit-GEMM shape (M=8192 px, N=512, K=4608) vs the conv kernel itself."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def timeit(fn, n=50):

@@ -1,7 +1,7 @@
 """bf16-output GEMMs with an epilogue (bias + residual + ReLU) as ONE launch against split-K slabs + the fold that applies the
 epilogue (sw_gemm with splitk > 1 and a non-plain epilogue), on the few-tile shapes of the Stage-3 detector."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def t(fn, n=20):

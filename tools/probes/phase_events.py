@@ -1,6 +1,6 @@
 """GPU time of the step's phases from events recorded on the main stream (no host syncs inside the step)."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench
 from sos_wsod_amd.solver import HipSGD
 from sos_wsod_amd.events import EventStorage

@@ -1,6 +1,6 @@
 """ROIPool forward / backward alone at the benchmark shape (2 x 63 x 63 x 512 map, 4000 ROIs), bytes of output + argmax per second."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 R, C, H, W = 4000, 512, 63, 63

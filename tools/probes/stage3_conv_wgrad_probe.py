@@ -1,7 +1,7 @@
 """3x3 weight gradients of the Stage-3 detector's shapes (sw_conv3x3_wgrad: K-split gather GEMM + fold) for several split counts.
 usage: stage3_conv_wgrad_probe.py   (GPU only)"""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def t(fn, n=20):

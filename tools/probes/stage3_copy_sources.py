@@ -3,7 +3,7 @@ op that launches a copy / fill / elementwise kernel is reported with the chain o
 module-level record_function ranges).  (development tool)"""
 import collections, os, sys
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import stage3_step as S
 from torch.profiler import profile, ProfilerActivity

@@ -3,7 +3,7 @@ epilogue) for ONE iteration; every distinct shape is then timed alone (20 launch
 forms.  Output: per shape count x time, bytes, GB/s, TFLOP/s, sorted by time per iteration.  (development tool, GPU only)"""
 import collections, os, sys
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sos_wsod_amd.ops as ops
 import stage3_step as S

@@ -1,7 +1,7 @@
 """1x1 weight gradients of one bottleneck block (conv1, conv3, shortcut) for the student's two passes: one sw_gemm per weight and
 pass (K-split + fold each) against ONE sw_gemm_kk_grouped launch over all of them + ONE sw_splitk_fold_multi."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 from sos_wsod_amd.backbone_vgg import _wgrad_grouped_target, _wgrad_grouped_splits
 dt, dev = torch.bfloat16, "cuda"

@@ -2,7 +2,7 @@
 all their slabs) pay for the Stage-3 detector's repeated uses of a 3x3 weight?  Sets: the RPN head's convolution (5 levels x
 batch 2 and batch 1), an FPN output convolution (2 uses), res4 / res5 conv2 (2 uses).  Against one sw_conv3x3_wgrad per use."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 from sos_wsod_amd.backbone_vgg import _wgrad_grouped_target, _wgrad_grouped_splits
 dt, dev = torch.bfloat16, "cuda"

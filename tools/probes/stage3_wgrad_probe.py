@@ -2,7 +2,7 @@
 pixels): the K-strided form `frcnn._LinearFn.backward` launches, at several split-K factors, against explicit transposes + the
 K-contiguous form.  Shapes: ResNet-50 + FPN laterals + box head at 800 x 1216, 2 images."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 
 dt, dev = torch.bfloat16, "cuda"

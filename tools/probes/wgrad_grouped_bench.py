@@ -1,7 +1,7 @@
 """All conv weight gradients of one backward pass (8 trainable layers x 2 view batches at the bench shapes): the grouped launch
 (sw_conv3x3_wgrad_grouped + one fold per layer) for several K-tile targets against the per-layer launches it replaces."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 from sos_wsod_amd.backbone_vgg import _wgrad_grouped_splits, _wgrad_splitk
 dt, dev = torch.bfloat16, "cuda"

@@ -1,7 +1,7 @@
 """What would a conv weight gradient reach as an NN GEMM (A = dy^T K-contiguous, B K-strided, no gather)?  M = Cout, N = 9 Cin,
 K = pixels, split-K slabs as the grouped launch uses them.  Compare with TN (both K-strided), the form the grouped kernel runs."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dev = "cuda"
 def t(fn, n=10):

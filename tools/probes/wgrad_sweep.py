@@ -1,6 +1,6 @@
 """conv3..conv5 weight gradient (implicit GEMM + slab reduce) against the split-K factor; SKS=3,7,14 selects the factors."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def timeit(fn, n=20):

@@ -1,6 +1,6 @@
 """fc6 weight-gradient tail (the 2 peeled tile columns: M=4096, N=512, K=8000, f32 atomics): split-K factor sweep"""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sos_wsod_amd.ops as ops
 dt, dev = torch.bfloat16, "cuda"
 def timeit(fn, n=20):
