@@ -402,6 +402,17 @@ def main():
                 t32.run_step(batches[i % 2])
             torch.cuda.synchronize()
             out["fp32_ms_per_step"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+            # the same precision class with the fc6 / fc7 GEMMs as six-product bf16x3 GEMMs (three bf16 pieces per f32 operand, f32
+            # accumulation: ~2^-24 per product; tests: config #2 fp32 e2e parity under it) — an extra, never `value`
+            m32.roi_heads.fp32x3 = True
+            for i in range(2):
+                t32.run_step(batches[i % 2])
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for i in range(5):
+                t32.run_step(batches[i % 2])
+            torch.cuda.synchronize()
+            out["fp32x3_ms_per_step"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+            out["fp32x3_images_per_s"] = round(4.0 / out["fp32x3_ms_per_step"] * 1e3, 1)
             del t32, m32
         if world == 1 and dtype == torch.bfloat16 and not args.no_extra_shapes:
             # the other BASELINE shapes on one GPU, for the record (not the metric): config #3's per-GPU shape = 2 images per step,

@@ -389,6 +389,13 @@ int sw_colsum_fold_multi(int n, const sw_colsum_fold_desc* folds, sw_stream_t st
 /* rows x cols copy/convert f32 -> dtype with independent leading dimensions (weight staging). */
 int sw_convert_2d(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,
                   sw_stream_t stream);
+/* Reference-precision GEMMs on the bf16 MFMA (the fp32 mode's fc layers, W/roi_heads/box_head.py:82-91 and their autograd backward):
+ * an f32 matrix as three bf16 pieces a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)), laid out as one
+ * operand of a six-product GEMM  a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)  = ONE bf16 sw_gemm over K' = 6 K with f32
+ * accumulation (the dropped products are below 2^-24 |a||b|).  side 0: blocks [a1|a1|a2|a1|a2|a3]; side 1: [b1|b2|b1|b3|b2|b1].
+ * along_rows 0: the K blocks follow each other along the columns (dst: rows x 6 cols); 1: along the rows (dst: 6 rows x cols). */
+int sw_split_bf16x3(int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst, int side, int along_rows,
+                    sw_stream_t stream);
 /* dst[c][r] = src[r][c] converted to dtype (rows x cols f32 source; dst has cols rows of pitch ld_dst): the eager form of
  * sw_sgd_multi's stage_kind 3 transposed copy (first step / after a checkpoint load). */
 int sw_convert_2d_t(int dtype, int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst,

@@ -171,6 +171,7 @@ SIGNATURES = {
     "sw_colsum_partial_multi": (c_int, [c_int, c_int, ctypes.POINTER(ColsumPart), c_void_p]),
     "sw_conv3x3_wgrad_grouped": (c_int, [c_int, c_int, ctypes.POINTER(WgradProblem), c_void_p]),
     "sw_convert_2d": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p]),
+    "sw_split_bf16x3": (c_int, [c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),
     "sw_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sw_relu_bwd": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "sw_relu_bwd_out": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -983,6 +983,53 @@ extern "C" int sw_convert_2d(int dtype, int rows, int cols, const float* src, lo
   return 0;
 }
 
+// f32 -> three bf16 pieces a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2) (both differences exact in f32), written as
+// the operand of the six-product GEMM of sw_split_bf16x3: `side` 0 lays the pieces out as [a1 | a1 | a2 | a1 | a2 | a3], side 1 as
+// [b1 | b2 | b1 | b3 | b2 | b1], block p of the K-concatenated operand.  along_rows = 0: K runs along the columns (block p = columns
+// [p * cols, (p + 1) * cols) of every row); 1: K runs along the rows (block p = rows [p * rows, (p + 1) * rows)).
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(int rows, int cols4, const float* __restrict__ src, long ld_src,
+                                                           unsigned short* __restrict__ dst, long ld_dst, int side, int along_rows) {
+  const long n = (long)rows * cols4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols4), c = (int)(i - (long)r * cols4) * 4;
+    const f32x4 a = *(const f32x4*)(src + (long)r * ld_src + c);
+    u32x2 pc[3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned short q[3][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float v = a[2 * h + e];
+        const unsigned short b1 = f32_to_bf16_bits(v);
+        const float r1 = __fsub_rn(v, bf16_bits_to_f32(b1));
+        const unsigned short b2 = f32_to_bf16_bits(r1);
+        const float r2 = __fsub_rn(r1, bf16_bits_to_f32(b2));
+        q[0][e] = b1; q[1][e] = b2; q[2][e] = f32_to_bf16_bits(r2);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pc[k][h] = (unsigned)q[k][0] | ((unsigned)q[k][1] << 16);
+    }
+    const int patA[6] = {0, 0, 1, 0, 1, 2}, patB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int k = side == 0 ? patA[p] : patB[p];
+      const long o = along_rows ? ((long)p * rows + r) * ld_dst + c : (long)r * ld_dst + (long)p * cols4 * 4 + c;
+      *(u32x2*)(dst + o) = pc[k];
+    }
+  }
+}
+
+extern "C" int sw_split_bf16x3(int rows, int cols, const float* src, long ld_src, void* dst, long ld_dst, int side, int along_rows,
+                               hipStream_t stream) {
+  SW_ENTER();
+  if (rows <= 0 || cols <= 0) return 0;
+  if ((cols % 4) || (ld_src % 4) || (ld_dst % 4) || (((uintptr_t)src) & 15) || (((uintptr_t)dst) & 7) || (side != 0 && side != 1)) return -5;
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(grid_for((long)rows * (cols / 4))), dim3(256), 0, stream, rows, cols / 4, src, ld_src,
+                     (unsigned short*)dst, ld_dst, side, along_rows ? 1 : 0);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sw_to_f32(int dtype, long n, const void* src, float* dst, hipStream_t stream) {
   SW_ENTER();
   if (n <= 0) return 0;

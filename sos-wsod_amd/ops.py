@@ -663,6 +663,31 @@ def convert_2d(src_f32, dst, rows, cols, ld_src=None, ld_dst=None):
     return dst
 
 
+def split_bf16x3(src_f32, side, along_rows=False, out=None):
+    """the K-concatenated three-piece bf16 operand of an f32 matrix (sw_split_bf16x3): (rows, cols) f32 -> (rows, 6 cols) bf16, or
+    (6 rows, cols) with along_rows.  side 0 = the A operand's block pattern, 1 = the B operand's.  Row pitch padded by 128 elements."""
+    _need_gpu(src_f32)
+    rows, cols = src_f32.shape
+    assert src_f32.dtype == torch.float32 and src_f32.stride(1) == 1
+    shape = (6 * rows, cols) if along_rows else (rows, 6 * cols)
+    if out is None or tuple(out.shape) != shape:
+        out = torch.empty(shape[0], shape[1] + 128, device=src_f32.device, dtype=torch.bfloat16)[:, :shape[1]]
+    check(lib.sw_split_bf16x3(rows, cols, _p(src_f32), src_f32.stride(0), _p(out), out.stride(0), int(side), int(bool(along_rows)), _stream()),
+          "sw_split_bf16x3")
+    return out
+
+
+def gemm_f32x3(A, B, C, M, N, K, a_kstrided=False, b_kstrided=False, ep=None, tag=None, A3=None, B3=None):
+    """C = A . B for f32 operands at (about) f32 accuracy on the bf16 MFMA: both operands split into three bf16 pieces, six products
+    accumulated in f32 as ONE bf16 GEMM over 6 K (sw_split_bf16x3).  A3 / B3: an operand already split (weights, cached per update).
+    Operand forms as ops.gemm: A (M, K) or, a_kstrided, (K, M); B (N, K) or, b_kstrided, (K, N)."""
+    if A3 is None:
+        A3 = split_bf16x3(A, 0, along_rows=a_kstrided)
+    if B3 is None:
+        B3 = split_bf16x3(B, 1, along_rows=b_kstrided)
+    return gemm(A3, B3, C, M, N, 6 * K, a_kstrided=a_kstrided, b_kstrided=b_kstrided, ep=ep, tag=tag)
+
+
 def convert_2d_t(src_f32, dst, rows, cols):
     """dst[c][r] = src[r][c] in dst's dtype (rows, cols multiples of 64)"""
     check(lib.sw_convert_2d_t(dt(dst), rows, cols, _p(src_f32), src_f32.stride(0), _p(dst), dst.stride(0), _stream()),

@@ -20,6 +20,7 @@ Reference quirks kept on purpose: losses_k2_flip pairs predictions_
 always kept (#4), CE mean over all R / box loss / R, L1 (#5), targets are proposals[gt_index] (#6)."""
 from typing import Dict, List
 
+import os
 import numpy as np
 import torch
 import torch.nn as nn
@@ -238,6 +239,11 @@ class OICRPlusHeads(nn.Module):
         self._drop_ctr_dev = None         # a captured hipGraph of the step draws a fresh mask on every replay
         self._prestaged_labels = None     # graph capture / replay: (static device buffer, per-image class counts), see stage_labels
         self._stage_cache = {}            # name -> (key list, persistent compute-dtype weight copy)
+        # fp32 mode only: the fc6 / fc7 GEMMs (forward, data and weight gradient: 97 % of the fp32 step's MFMA time) as six-product
+        # bf16x3 GEMMs — about f32 accuracy at 16/6 of the exact-f32 MFMA rate (ops.gemm_f32x3).  Off by default: the parity mode
+        # stays the exact-f32 MFMA; MODEL.AMD.FP32_GEMM "bf16x3" / SW_FP32X3=1 turn it on.
+        self.fp32x3 = compute_dtype == torch.float32 and os.environ.get("SW_FP32X3", "0") == "1"
+        self._x3_cache = {}
         self.debug_drop_masks = None      # tests: [[m1, m2] per view] uint8 keep masks (A.2 #9)
         self.last_aux = None              # tests / metrics: device tensors of the last iteration
         K = num_classes
@@ -444,6 +450,23 @@ class OICRPlusHeads(nn.Module):
                                  stamp=lambda pk, key=key: key.__setitem__(0, pk))
         return (buf, buf_t) if transposed else buf
 
+    def _x3_weight(self, name, w_master, staged_f32):
+        """the three-piece bf16 operand (B side, K along the columns) of a staged f32 weight matrix, rebuilt when the master changed"""
+        key = ops.param_key(w_master)
+        hit = self._x3_cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.split_bf16x3(staged_f32, 1, out=None if hit is None else hit[1]))
+            self._x3_cache[name] = hit
+        return hit[1]
+
+    def _fc_gemm(self, A, B, C, M, N, K, ep=None, tag=None, a_kstrided=False, b_kstrided=False, wname=None, wmaster=None):
+        """an fc-family GEMM: the compute dtype's own sw_gemm, or (fp32 mode with fp32x3) the six-product bf16x3 form; wname / wmaster:
+        B is a staged weight whose split is cached per update"""
+        if self.fp32x3 and A.dtype == torch.float32 and K % 8 == 0 and M % 4 == 0 and N % 4 == 0:
+            B3 = self._x3_weight(wname, wmaster, B) if wname is not None else None
+            return ops.gemm_f32x3(A, B, C, M, N, K, a_kstrided=a_kstrided, b_kstrided=b_kstrided, ep=ep, tag=tag, B3=B3)
+        return ops.gemm(A, B, C, M, N, K, a_kstrided=a_kstrided, b_kstrided=b_kstrided, ep=ep, tag=tag)
+
     # ------------------------------------------------------------------ training forward (explicit)
     def _train_forward(self, inp, feats, params):
         """feats: 2 NHWC maps per image (scale 1, scale 2), each a batch of 2 (view, flipped view).  Rows of every stacked
@@ -489,11 +512,11 @@ class OICRPlusHeads(nn.Module):
         W2 = self._staged_matrix("fc2", fc2w, dev, transposed=inp["need_grad"])
         W2, W2T = W2 if isinstance(W2, tuple) else (W2, None)
         h1 = _padded(M, D1, dev, dt_)
-        ops.gemm(pooled, W1, h1, M, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], drop_hash=hashes[0], out_dtype=dt_),
-                 tag="fc6_fwd")
+        self._fc_gemm(pooled, W1, h1, M, D1, D0, ep=ops.make_epilogue(bias=fc1b, relu=True, drop_mask=masks[0], drop_hash=hashes[0], out_dtype=dt_),
+                      tag="fc6_fwd", wname="fc1", wmaster=fc1w)
         h2 = _padded(M, D2, dev, dt_)
-        ops.gemm(h1, W2, h2, M, D2, D1, ep=ops.make_epilogue(bias=fc2b, relu=True, drop_mask=masks[1], drop_hash=hashes[1],
-                                                         out_dtype=dt_))
+        self._fc_gemm(h1, W2, h2, M, D2, D1, ep=ops.make_epilogue(bias=fc2b, relu=True, drop_mask=masks[1], drop_hash=hashes[1],
+                                                              out_dtype=dt_), wname="fc2", wmaster=fc2w)
         if hashes[0] is not None:
             ops.counter_add(hashes[0][3], M * (D1 + D2))                       # in stream order, after both readers
         # --- all 10 predictor matrices as one GEMM, f32 logits
@@ -613,12 +636,13 @@ class OICRPlusHeads(nn.Module):
             return ops.transpose_2d(dz, torch.empty(D, M + 8 * epc, device=dev, dtype=dt_)[:, :M], M, D)
         dW2 = ops.grad_target(self.box_head.fc2.weight, (D2, D1), dev)
         if wgrad_nn:
-            ops.gemm(dz_t(dz2, D2), h1, dW2, D2, D1, M, b_kstrided=True)
+            self._fc_gemm(dz_t(dz2, D2), h1, dW2, D2, D1, M, b_kstrided=True)
         else:
             ops.gemm(dz2, h1, dW2, D2, D1, M, a_kstrided=True, b_kstrided=True)
         dz1 = _padded(M, D1, dev, dt_)
         if st.get("W2T") is not None:
-            ops.gemm(dz2, st["W2T"], dz1, M, D1, D2, ep=ops.make_epilogue(relu_ref=h1, ref_scale=rs, out_dtype=dt_))
+            self._fc_gemm(dz2, st["W2T"], dz1, M, D1, D2, ep=ops.make_epilogue(relu_ref=h1, ref_scale=rs, out_dtype=dt_),
+                          wname="fc2T", wmaster=self.box_head.fc2.weight)
         else:
             ops.gemm(dz2, W2, dz1, M, D1, D2, b_kstrided=True, ep=ops.make_epilogue(relu_ref=h1, ref_scale=rs, out_dtype=dt_))
         st["dz1"] = dz1
@@ -657,7 +681,7 @@ class OICRPlusHeads(nn.Module):
         elif M % epc == 0:                               # dZ^T as in stage 1; the tagged region holds the transpose too: one "fc6_wgrad" measurement
             def nn():
                 dzt = ops.transpose_2d(dz1, torch.empty(D1, M + 8 * epc, device=dev, dtype=dt_)[:, :M], M, D1)
-                ops.gemm(dzt, pooled, dW1, D1, D0, M, b_kstrided=True)
+                self._fc_gemm(dzt, pooled, dW1, D1, D0, M, b_kstrided=True)
             ops._launch("fc6_wgrad", nn)
         else:
             ops.gemm(dz1, pooled, dW1, D1, D0, M, a_kstrided=True, b_kstrided=True, tag="fc6_wgrad")
@@ -676,8 +700,8 @@ class OICRPlusHeads(nn.Module):
             dpooled = _padded(M, D0, dev, dt_, pad=64)          # same pitch as argmax (one pitch per ROIPool call)
             amax = ops.fill_zero(torch.empty(1, device=dev, dtype=torch.float32))   # max|dpooled| -> fixed-point scale of the ROI scatter
             if st["W1T"] is not None:       # NT: B = W1^T (D0 x D1), K-contiguous
-                ops.gemm(dz1, st["W1T"], dpooled, M, D0, D1, ep=ops.make_epilogue(out_dtype=dt_, absmax_out=amax),
-                         tag="fc6_dgrad")
+                self._fc_gemm(dz1, st["W1T"], dpooled, M, D0, D1, ep=ops.make_epilogue(out_dtype=dt_, absmax_out=amax),
+                              tag="fc6_dgrad", wname="fc1T", wmaster=self.box_head.fc1.weight)
             else:
                 ops.gemm(dz1, W1, dpooled, M, D0, D1, b_kstrided=True, ep=ops.make_epilogue(out_dtype=dt_, absmax_out=amax),
                          tag="fc6_dgrad")

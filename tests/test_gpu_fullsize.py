@@ -157,8 +157,11 @@ def test_config3_per_gpu_shape_two_images_512_r2000_against_the_oracle():
     _check_roipool_against_c_oracle(model, data, R, image=1)
 
 
-def test_config2_fp32_end_to_end_against_the_oracle():
-    """BASELINE configs[1] in the reference's own precision, WHOLE path, nothing shrunk: 4 u8 views 512x512 in, R = 2000, K = 20,
+@pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
+def test_config2_fp32_end_to_end_against_the_oracle(gemm):
+    """gemm = "bf16x3": the same test with the fc6 / fc7 GEMMs (forward, data and weight gradients) as six-product bf16x3 GEMMs
+    (ops.gemm_f32x3: three bf16 pieces per operand, ~2^-24 |a||b| per product, f32 accumulation) — same bars.
+    BASELINE configs[1] in the reference's own precision, WHOLE path, nothing shrunk: 4 u8 views 512x512 in, R = 2000, K = 20,
     fc 4096/4096 (136 M closed-form parameters), injected dropout masks -> the oracle's full iteration with autograd on the host
     (the same call bench.py's cpu_baseline times: ~20 s on the GPU box) against the HIP path: the 9 losses within 1e-4 relative,
     mined pseudo boxes / proposal labels bit exact, EVERY gradient tensor within 2e-3 of its largest element (see the note at the
@@ -176,6 +179,7 @@ def test_config2_fp32_end_to_end_against_the_oracle():
     load_params(model, P)
     model.train()
     model.roi_heads.debug_drop_masks = [[torch.from_numpy(m) for m in v] for v in masks]
+    model.roi_heads.fp32x3 = gemm == "bf16x3"
     with EventStorage(0):
         losses = model(to_batched_inputs(views, gt))
         sum(losses.values()).backward()

@@ -274,6 +274,32 @@ def test_conv3x3_winograd_form_against_float64_and_the_direct_kernel(ops, n, H, 
         assert torch.equal(out_w == 0, out_d == 0) or float(((out_w == 0) != (out_d == 0)).float().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("a_ks,b_ks", [(False, False), (False, True), (True, True)])
+def test_gemm_f32x3_six_product_bf16_form_against_float64(ops, a_ks, b_ks):
+    """ops.gemm_f32x3: an f32 GEMM as three bf16 pieces per operand and six products on the bf16 MFMA (sw_split_bf16x3 + one sw_gemm
+    over 6 K).  Against a float64 contraction: no worse than 2x the exact-f32 MFMA GEMM's error (both are summation-order noise of an
+    f32 accumulator over K = 1536: ~1e-6 of the row scale); operands with a wide dynamic range so that the second and third
+    pieces matter (dropping them — a plain bf16 GEMM — is 2e-3 here).  The three operand forms the fc layers use."""
+    M, N, K = 320, 448, 1536
+    g = torch.Generator().manual_seed(9)
+    A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).cuda()
+    B = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    ref = A.double() @ B.double().t()
+    Ain = A.t().contiguous() if a_ks else A
+    Bin = B.t().contiguous() if b_ks else B
+    C3 = torch.empty(M, N, device="cuda"); C1 = torch.empty(M, N, device="cuda")
+    ops.gemm_f32x3(Ain, Bin, C3, M, N, K, a_kstrided=a_ks, b_kstrided=b_ks)
+    ops.gemm(Ain, Bin, C1, M, N, K, a_kstrided=a_ks, b_kstrided=b_ks)
+    Cb = torch.empty(M, N, device="cuda")
+    ops.gemm(Ain.to(torch.bfloat16), Bin.to(torch.bfloat16), Cb, M, N, K, a_kstrided=a_ks, b_kstrided=b_ks)
+    torch.cuda.synchronize()
+    scale = ref.abs().amax(dim=1, keepdim=True)
+    e3 = float(((C3.double() - ref).abs() / scale).max()); e1 = float(((C1.double() - ref).abs() / scale).max())
+    eb = float(((Cb.double() - ref).abs() / scale).max())
+    print(f"gemm_f32x3 vs float64: max error / row scale {e3:.2e} (exact-f32 MFMA {e1:.2e}, plain bf16 {eb:.2e})")
+    assert e3 <= max(2 * e1, 2e-6) and eb > 100 * e3
+
+
 # ------------------------------------------------------------------------------------------ ROIPool
 @pytest.mark.parametrize("adt", [torch.int32, torch.int16])
 @pytest.mark.parametrize("dtype", DT)
