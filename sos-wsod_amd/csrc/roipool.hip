@@ -860,140 +860,114 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
         __syncthreads();
         ntask = s_ntask;
       }
-      // A lane takes TWO neighbouring bins of one bin row (columns 2k, 2k + 1; the last lane of an odd row takes one): the task's
-      // set-up (list entry, ROI row, bin-row range, output scale, addresses) is paid once per pair, and the pair's values leave as ONE
-      // 4-byte store per channel (two bf16 / two u16 indices, adjacent in the (C, PH, PW) row) instead of two 2-byte stores — the
-      // one-bin-per-lane form spent most of its ~300 VALU instructions per (ROI, bin, 8 channels) outside the scan and its waves
-      // waited 53 % of their time behind 16 two-byte stores per task.  (The address is 2-byte aligned: gfx950 takes unaligned dwords.)
-      typedef unsigned int __attribute__((aligned(2))) u32_a2;
-      const int npair = (PW + 1) >> 1, nbp = PH * npair;
-      const int total = ntask * npair;
-      const int dli = NT / nbp, dph = (NT - dli * nbp) / npair, dk = NT - dli * nbp - dph * npair;
-      int li = tid / nbp, ph = (tid - li * nbp) / npair, kp = tid - li * nbp - ph * npair;
-      const int dte = NT / npair, dtk = NT - dte * npair;
-      int te = tid / npair;
-      if (BAND) kp = tid - te * npair;
+      const int total = ntask * PW;
+      const int dli = NT / nb, dph = (NT - dli * nb) / PW, dpw = NT - dli * nb - dph * PW;
+      int li = tid / nb, ph = (tid - li * nb) / PW, pw = tid - li * nb - ph * PW;
+      const int dte = NT / PW, dtw = NT - dte * PW;
+      int te = tid / PW;
+      if (BAND) pw = tid - te * PW;
       for (int t = tid; t < total; t += NT) {
         if (BAND) { const unsigned int pk = s_task[te]; li = (int)(pk >> 8); ph = (int)(pk & 0xFF); }
+        const int b = ph * PW + pw;
         const int r = s_r[li];
-        const int hb = s_hb[li * PH + ph];
-        const int hs = hb & 0xFF, he = hb >> 8;
-        const float mul = s_mul[li];
-        const int he_lds = BAND ? min(he, y1) : he;
-        // one bin: best candidate per channel -> (value x prior as bf16 bits, argmax code)
-        auto one_bin = [&](int pw, unsigned short (&vb)[CB], int (&mi)[CB]) {
-          const int wb = s_wb[li * PW + pw];
-          const int ws = wb & 0xFF, we = wb >> 8;
-          const bool empty = (he <= hs) || (we <= ws);
-          unsigned int best[CB];
+        const int hb = s_hb[li * PH + ph], wb = s_wb[li * PW + pw];
+        const int hs = hb & 0xFF, he = hb >> 8, ws = wb & 0xFF, we = wb >> 8;
+        const bool empty = (he <= hs) || (we <= ws);
+        unsigned int best[CB];
 #pragma unroll
-          for (int q = 0; q < CB; ++q) best[q] = KEY_INIT;
-          if (!empty) {
-            const int bw = we - ws;
-            int cold_from = BAND ? max(hs, y1) : he;                  // first window row read from global memory
-            if (bw >= span) {
-              const int offB = bw - span;
-              // two window rows per step (the second clamped to the last row: re-reading a row cannot change a maximum)
-              const int last = (he_lds - 1 - y0) * W + ws;
-              for (int hh = hs; hh < he_lds; hh += 2) {
-                const int i0 = (hh - y0) * W + ws, i1 = min(i0 + W, last);
-                u32x4 a0[NPL], b0[NPL], a1[NPL], b1[NPL];
+        for (int q = 0; q < CB; ++q) best[q] = KEY_INIT;
+        if (!empty) {
+          const int bw = we - ws;
+          const int he_lds = BAND ? min(he, y1) : he;
+          int cold_from = BAND ? max(hs, y1) : he;                  // first window row read from global memory
+          if (bw >= span) {
+            const int offB = bw - span;
+            // two window rows per step (the second clamped to the last row: re-reading a row cannot change a maximum): all 4 * NPL
+            // reads of a step are issued before the first use — one LDS round trip per row PAIR instead of per row (rocprof, one row
+            // per step: the waves of this kernel were parked at s_waitcnt / barriers 53 % of their time, VALU and LDS both < 50 % busy)
+            const int last = (he_lds - 1 - y0) * W + ws;
+            for (int hh = hs; hh < he_lds; hh += 2) {
+              const int i0 = (hh - y0) * W + ws, i1 = min(i0 + W, last);
+              u32x4 a0[NPL], b0[NPL], a1[NPL], b1[NPL];
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
-                  a0[pl] = tab[pl * npl_px + i0]; b0[pl] = tab[pl * npl_px + i0 + offB];
-                  a1[pl] = tab[pl * npl_px + i1]; b1[pl] = tab[pl * npl_px + i1 + offB];
-                }
+              for (int pl = 0; pl < NPL; ++pl) {
+                a0[pl] = tab[pl * npl_px + i0]; b0[pl] = tab[pl * npl_px + i0 + offB];
+                a1[pl] = tab[pl * npl_px + i1]; b1[pl] = tab[pl * npl_px + i1 + offB];
+              }
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
+              for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-                  for (int e = 0; e < 4; ++e)
-                    best[4 * pl + e] = max(max(max(max(best[4 * pl + e], a0[pl][e]), b0[pl][e]), a1[pl][e]), b1[pl][e]);     // 2 x v_max3_u32
-                if (2 * span < bw) {                                  // only when the level was capped (SP_NLEV): spans in between
-                  for (int rr = 0; rr < 2; ++rr) {
-                    const int ib = rr ? i1 : i0;
-                    for (int x = span; x < offB; x += span) {
+                for (int e = 0; e < 4; ++e)
+                  best[4 * pl + e] = max(max(max(max(best[4 * pl + e], a0[pl][e]), b0[pl][e]), a1[pl][e]), b1[pl][e]);     // 2 x v_max3_u32
+              if (2 * span < bw) {                                  // only when the level was capped (SP_NLEV): spans in between
+                for (int rr = 0; rr < 2; ++rr) {
+                  const int ib = rr ? i1 : i0;
+                  for (int x = span; x < offB; x += span) {
 #pragma unroll
-                      for (int pl = 0; pl < NPL; ++pl) {
-                        const u32x4 a = tab[pl * npl_px + ib + x];
+                    for (int pl = 0; pl < NPL; ++pl) {
+                      const u32x4 a = tab[pl * npl_px + ib + x];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) best[4 * pl + e] = max(best[4 * pl + e], a[e]);
-                      }
+                      for (int e = 0; e < 4; ++e) best[4 * pl + e] = max(best[4 * pl + e], a[e]);
                     }
                   }
                 }
               }
-            } else if (we == W) {                                     // clipped by the map's right edge: the span at ws ends at W
-              for (int hh = hs; hh < he_lds; ++hh) {
-                const int i0 = (hh - y0) * W + ws;
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
-                  const u32x4 a = tab[pl * npl_px + i0];
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) best[4 * pl + e] = max(best[4 * pl + e], a[e]);
-                }
-              }
-            } else {
-              cold_from = hs;                                         // narrower than the ROI's span for another reason: pixel loop
             }
-            for (int hh = cold_from; hh < he; ++hh)
-              for (int x = ws; x < we; ++x) {
-                const int gi = hh * W + x;
-                const unsigned int inv0 = 0xFFFEu - (unsigned)gi;
-                unsigned int u[CB / 2];
-                if (CB == 8) { const u32x4 w = *(const u32x4*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; u[2] = w[2]; u[3] = w[3]; }
-                else { const u32x2 w = *(const u32x2*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; }
+          } else if (we == W) {                                     // clipped by the map's right edge: the span at ws ends at W
+            for (int hh = hs; hh < he_lds; ++hh) {
+              const int i0 = (hh - y0) * W + ws;
 #pragma unroll
-                for (int i = 0; i < CB / 2; ++i) {
-                  best[2 * i] = max(best[2 * i], (key16_of(u[i] & 0xFFFFu) << 16) | inv0);
-                  best[2 * i + 1] = max(best[2 * i + 1], (key16_of(u[i] >> 16) << 16) | inv0);
-                }
+              for (int pl = 0; pl < NPL; ++pl) {
+                const u32x4 a = tab[pl * npl_px + i0];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) best[4 * pl + e] = max(best[4 * pl + e], a[e]);
               }
+            }
+          } else {
+            cold_from = hs;                                         // narrower than the ROI's span for another reason: pixel loop
           }
-          // candidate -> (bf16 bits, pixel): as in the scan form above
-          float mv[CB];
-          unsigned int lowest = best[0];
+          for (int hh = cold_from; hh < he; ++hh)
+            for (int x = ws; x < we; ++x) {
+              const int gi = hh * W + x;
+              const unsigned int inv0 = 0xFFFEu - (unsigned)gi;
+              unsigned int u[CB / 2];
+              if (CB == 8) { const u32x4 w = *(const u32x4*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; u[2] = w[2]; u[3] = w[3]; }
+              else { const u32x2 w = *(const u32x2*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; }
 #pragma unroll
-          for (int q = 0; q < CB; ++q) {
-            const unsigned int m = (unsigned int)((int)best[q] >> 31);
-            mv[q] = __uint_as_float((best[q] & 0xFFFF0000u) ^ (0x80000000u | (~m & 0x7FFF0000u)));
-            mi[q] = (int)(0xFFFEu - (best[q] & 0xFFFFu));
-            lowest = min(lowest, best[q]);
-          }
-          if (lowest == KEY_INIT) {
+              for (int i = 0; i < CB / 2; ++i) {
+                best[2 * i] = max(best[2 * i], (key16_of(u[i] & 0xFFFFu) << 16) | inv0);
+                best[2 * i + 1] = max(best[2 * i + 1], (key16_of(u[i] >> 16) << 16) | inv0);
+              }
+            }
+        }
+        // candidate -> (bf16 bits, pixel): as in the scan form above
+        float mv[CB]; int mi[CB];
+        unsigned int lowest = best[0];
 #pragma unroll
-            for (int q = 0; q < CB; ++q)
-              if (best[q] == KEY_INIT) mv[q] = empty ? 0.f : -FLT_MAX;
-          }
+        for (int q = 0; q < CB; ++q) {
+          const unsigned int m = (unsigned int)((int)best[q] >> 31);
+          mv[q] = __uint_as_float((best[q] & 0xFFFF0000u) ^ (0x80000000u | (~m & 0x7FFF0000u)));
+          mi[q] = (int)(0xFFFEu - (best[q] & 0xFFFFu));
+          lowest = min(lowest, best[q]);
+        }
+        if (lowest == KEY_INIT) {
 #pragma unroll
-          for (int q = 0; q < CB; ++q) vb[q] = f32_to_bf16_bits(__fmul_rn(mv[q], mul));
-        };
-        const int pw0 = 2 * kp;
-        const long o = (long)r * ld + (long)c0 * nb + ph * PW + pw0;
-        unsigned short va[CB]; int ia[CB];
-        one_bin(pw0, va, ia);
-        if (pw0 + 1 < PW) {
-          unsigned short vc[CB]; int ic[CB];
-          one_bin(pw0 + 1, vc, ic);
+          for (int q = 0; q < CB; ++q)
+            if (best[q] == KEY_INIT) mv[q] = empty ? 0.f : -FLT_MAX;
+        }
+        const float mul = s_mul[li];
+        const long o = (long)r * ld + (long)c0 * nb + b;
 #pragma unroll
-          for (int q = 0; q < CB; ++q) {
-            *(u32_a2*)(out + o + (long)q * nb) = (unsigned)va[q] | ((unsigned)vc[q] << 16);
-            if (sizeof(IT) == 2)
-              *(u32_a2*)(argmax + o + (long)q * nb) = (unsigned)(unsigned short)ArgIdx<IT>::enc(ia[q]) | ((unsigned)(unsigned short)ArgIdx<IT>::enc(ic[q]) << 16);
-            else { argmax[o + (long)q * nb] = ArgIdx<IT>::enc(ia[q]); argmax[o + (long)q * nb + 1] = ArgIdx<IT>::enc(ic[q]); }
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < CB; ++q) {
-            out[o + (long)q * nb] = va[q];
-            argmax[o + (long)q * nb] = ArgIdx<IT>::enc(ia[q]);
-          }
+        for (int q = 0; q < CB; ++q) {
+          Elem<unsigned short>::store(out + o + (long)q * nb, __fmul_rn(mv[q], mul));
+          argmax[o + (long)q * nb] = ArgIdx<IT>::enc(mi[q]);
         }
         if (BAND) {
-          kp += dtk; te += dte;
-          if (kp >= npair) { kp -= npair; ++te; }
+          pw += dtw; te += dte;
+          if (pw >= PW) { pw -= PW; ++te; }
         } else {
-          kp += dk; ph += dph; li += dli;
-          if (kp >= npair) { kp -= npair; ++ph; }
+          pw += dpw; ph += dph; li += dli;
+          if (pw >= PW) { pw -= PW; ++ph; }
           if (ph >= PH) { ph -= PH; ++li; }
         }
       }
