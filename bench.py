@@ -480,7 +480,7 @@ def main():
             out["mixed_ms_per_step"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
             # (2b) where training actually runs: the VOC recipe draws two DISTINCT short sides from 480 .. 1216 (step 32) per image
             # (voc07_oicr_plus.yaml:30, dataset_mapper.py:303-317); a 500 x 375 image at 6 seeded scale pairs, eager launches
-            # (every pair is a new input signature), 2 timed steps each after 1 warm-up: the mean is `recipe_ms_per_step`
+            # (every pair is a new input signature), median of 3 timed steps each after 2 warm-ups: the mean over the pairs is `recipe_ms_per_step`
             import random
             rnd = random.Random(1234)
             shorts = list(range(480, 1217, 32))
@@ -488,12 +488,15 @@ def main():
             per_pair = []
             for s1, s2 in pairs_:
                 dat = make_inputs(device, 900 + s1, H=s1, W=int(500.0 / 375.0 * s1 + 0.5), scale2=s2 / s1)
-                tmx.run_step(dat)
-                torch.cuda.synchronize(); t1 = time.perf_counter()
-                for _ in range(2):
+                for _ in range(2):                     # (new shapes: the allocator grows during the first steps)
                     tmx.run_step(dat)
-                torch.cuda.synchronize()
-                per_pair.append(round((time.perf_counter() - t1) / 2 * 1e3, 2))
+                ts_ = []
+                for _ in range(3):
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    tmx.run_step(dat)
+                    torch.cuda.synchronize()
+                    ts_.append((time.perf_counter() - t1) * 1e3)
+                per_pair.append(round(sorted(ts_)[1], 2))            # median of 3
                 del dat
             out["recipe_ms_per_step"] = round(sum(per_pair) / len(per_pair), 3)
             out["recipe_pairs"] = {"short_sides": pairs_, "ms_per_step": per_pair, "image": "500x375 (W x H), R=2000, K=20"}
