@@ -26,11 +26,10 @@
 namespace {
 
 constexpr int WT = 8, WPS = 2 * WT + 2, WNPX = WPS * WPS;      // tiles per side, patch side (18), patch pixels (324)
-constexpr int WCK = 16, WTN = 64, WNT = 1024;                  // channels per phase, output channels per workgroup, threads
-constexpr int W_RAW_INSTR = (WNPX + 31) / 32;                  // 1 KiB LDS-DMA instructions per patch sub-chunk: 32 rows of 32 B (11)
-constexpr int W_RAW_BYTES = W_RAW_INSTR * 1024;                // per buffer
-constexpr int W_V_BYTES = 16 * 64 * 32, W_U_BYTES = 16 * WTN * 32;      // per buffer: [xi][64 rows][32 B]
-constexpr int W_LDS = 2 * (W_RAW_BYTES + W_V_BYTES + W_U_BYTES);
+constexpr int WCK = 32, WTN = 64, WNT = 1024;                  // channels per chunk, output channels per workgroup, threads
+constexpr int W_RAW_INSTR = (WNPX + 15) / 16;                  // 1 KiB LDS-DMA instructions per patch chunk (21)
+constexpr int W_RAW_BYTES = 32 * 1024;                         // 2 instructions per wave x 16 waves (21 carry pixels, the rest zero fill)
+constexpr int W_V_BYTES = 16 * 64 * 64, W_U_BYTES = 16 * WTN * 64;
 constexpr unsigned W_INVALID = 0xFFFFFF00u;
 
 struct WinoArgs {
@@ -41,9 +40,7 @@ struct WinoArgs {
   unsigned in_bytes, u_bytes;
 };
 
-// 32-byte LDS rows (16 channels): row r keeps its two 16-byte halves swapped when bit 3 of r is set — the 16 lanes of every
-// ds_read_b128 service group then hit 16 distinct 16-byte slots of the 256-byte bank window (rows r and r + 8 / r + 24 share a slot pair)
-__device__ __forceinline__ int w_swz(int row) { return (row >> 3) & 1; }
+__device__ __forceinline__ int w_swz(int row) { return ((row >> 2) & 1) << 1; }     // 16-byte slot XOR (conv_direct.hip)
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -52,19 +49,12 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {       
   return __builtin_bit_cast(unsigned int, v);
 }
 
-// Phase p (one 16-channel sub-chunk, Cin / 16 of them), ONE barrier per phase, everything double buffered:
-//   at the barrier: V[p & 1] (transform of sub-chunk p), U[p & 1], patch[(p + 1) & 1] are complete
-//   issue LDS-DMA: U(p + 1) -> U[(p + 1) & 1], patch(p + 2) -> patch[p & 1]            (both buffers were last read one phase ago)
-//   M(p): wave xi multiplies V[p & 1][xi] (64 tiles x 16) by U[p & 1][xi] (16 x 64): 4 x v_mfma_f32_32x32x16_bf16
-//   T(p + 1): waves 0-7, one (tile, channel pair) per thread: patch[(p + 1) & 1] -> f32 B^T d B -> bf16 -> V[(p + 1) & 1]
-// The transform's vector work issues in the shadow of the wave's own MFMAs and of the other waves' — the two-phase form
-// (transform, barrier, multiply, barrier on single buffers of 32 channels) ran them one after the other: 42 vs 38 us for the direct kernel.
 __global__ __launch_bounds__(WNT) void conv3x3_winograd_kernel(WinoArgs g) {
   typedef __attribute__((address_space(3))) void* lvoid;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const sRAW = smem;                                       // [2][11 KiB]
-  char* const sV = smem + 2 * W_RAW_BYTES;                       // [2][32 KiB]
-  char* const sU = sV + 2 * W_V_BYTES;                           // [2][32 KiB]
+  char* const sRAW = smem;
+  char* const sV = smem + W_RAW_BYTES;
+  char* const sU = sV + W_V_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // workgroup -> (channel block, pixel block): XCD x takes a contiguous run of the work list in which the pixel block runs
@@ -86,137 +76,147 @@ __global__ __launch_bounds__(WNT) void conv3x3_winograd_kernel(WinoArgs g) {
   const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)g.U, 0, (int)g.u_bytes, 0x00020000);
 
   // ---- fixed per-lane DMA offsets.  Patch image: row r' = u * 18 + perm(v), perm = even columns first: the patch pixels of
-  // horizontally adjacent tiles (v and v + 2) are adjacent rows, so a wave's 8 tiles x 8 channel pairs read 256 contiguous bytes.
-  // Instruction q (waves 0 .. 10 issue one each) carries rows 32 q .. 32 q + 31, two 16-byte halves per row.
-  unsigned a_v;
-  {
-    const int r = wave * 32 + (lane >> 1), half = lane & 1;
-    const int u = r / WPS, pv = r - u * WPS;
-    const int v = pv < 9 ? 2 * pv : 2 * (pv - 9) + 1;
-    const int y = py + d * (2 * WT * by - 1 + u), x = px + d * (2 * WT * bx - 1 + v);
-    const bool ok = wave < W_RAW_INSTR && r < WNPX && y >= 0 && y < g.H && x >= 0 && x < g.W;
-    a_v = ok ? (unsigned)(((((long)img * g.H + y) * g.W + x) * g.Cin + half * 8) * 2) : W_INVALID;
-  }
-  unsigned u_v[2];                                               // 32 instructions per sub-chunk, two per wave: rows xi * 64 + co
+  // horizontally adjacent tiles (v and v + 2) are adjacent rows, so a wave's 4 tiles x 16 channel pairs read 256 contiguous bytes
+  unsigned a_v[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int q = wave + 16 * s;
-    const int row = q * 32 + (lane >> 1), slot = lane & 1;
-    const int xi = row >> 6, co = row & 63;
-    const int src = slot ^ w_swz(co);
-    u_v[s] = (co0 + co < g.Cout) ? (unsigned)((((long)xi * g.Cout + co0 + co) * g.Cin + src * 8) * 2) : W_INVALID;
+    const int r = q * 16 + (lane >> 2), slot = lane & 3;
+    const int u = r / WPS, pv = r - u * WPS;
+    const int v = pv < 9 ? 2 * pv : 2 * (pv - 9) + 1;
+    const int y = py + d * (2 * WT * by - 1 + u), x = px + d * (2 * WT * bx - 1 + v);
+    const bool ok = r < WNPX && y >= 0 && y < g.H && x >= 0 && x < g.W;      // (instructions 21 .. 31 carry no pixel: zero fill)
+    a_v[s] = ok ? (unsigned)(((((long)img * g.H + y) * g.W + x) * g.Cin + slot * 8) * 2) : W_INVALID;
   }
-  auto issue_raw = [&](int sub) {
-    if (wave < W_RAW_INSTR)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lvoid)(sRAW + (sub & 1) * W_RAW_BYTES + wave * 1024), 16, (int)a_v,
-                                               (int)((unsigned)sub * (WCK * 2)), 0, 0);
-  };
-  auto issue_u = [&](int sub) {
+  // U is staged in two halves of 32 output channels (32 instructions of 1 KiB each, two per wave): while the MFMAs of one half
+  // run, the other half's buffer is being refilled — a whole-chunk buffer could only be refilled between two chunks, with the
+  // MFMAs waiting for it (44 vs 38 us for the direct kernel at conv5_3)
+  unsigned u_v[2][2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int q = wave + 16 * s;                            // 32 instructions per half: xi = q >> 1, 16 channel rows each
+      const int xi = q >> 1, co = hf * 32 + (q & 1) * 16 + (lane >> 2), slot = lane & 3;
+      const int src = slot ^ w_swz(co);
+      u_v[hf][s] = (co0 + co < g.Cout) ? (unsigned)((((long)xi * g.Cout + co0 + co) * g.Cin + src * 8) * 2) : W_INVALID;
+    }
+  auto issue_raw = [&](int chunk) {                           // every wave issues 2 (uniform vmcnt accounting); surplus ones: zero fill
+    const unsigned soff = (unsigned)chunk * (WCK * 2);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (lvoid)(sU + (sub & 1) * W_U_BYTES + (wave + 16 * s) * 1024), 16, (int)u_v[s],
-                                               (int)((unsigned)sub * (WCK * 2)), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lvoid)(sRAW + (wave + 16 * s) * 1024), 16, (int)a_v[s], (int)soff, 0, 0);
+  };
+  auto issue_u = [&](int chunk, int hf) {                     // LDS image of a half: [xi][32 channels][64 B]
+    const unsigned soff = (unsigned)chunk * (WCK * 2);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (lvoid)(sU + hf * (W_U_BYTES / 2) + (wave + 16 * s) * 1024), 16, (int)u_v[hf][s],
+                                               (int)soff, 0, 0);
   };
 
-  // ---- transform side (threads 0 .. 511): thread = (tile t, channel pair cp of the sub-chunk's 8)
-  const int t_tile = (tid >> 3) & 63, cp = tid & 7;
+  // ---- transform side: thread = (tile t, channel pair cp)
+  const int t_tile = tid >> 4, cp = tid & 15;
   const int tty = t_tile >> 3, ttx = t_tile & 7;
   // patch pixel (2 tty + a, 2 ttx + b) sits in row (2 tty + a) * 18 + (b & 1) * 9 + ttx + (b >> 1): a constant distance from the
   // tile's first pixel for every (a, b)
-  const int raw_base = ((2 * tty) * WPS + ttx) * 32 + cp * 4;
-  const int v_off = t_tile * 32 + (((cp >> 2) ^ w_swz(t_tile)) << 4) + (cp & 3) * 4;       // + xi * 2048
-  auto transform = [&](int sub) {
-    const char* const R = sRAW + (sub & 1) * W_RAW_BYTES + raw_base;
-    char* const Vw = sV + (sub & 1) * W_V_BYTES + v_off;
-    float lo[4][4], hi[4][4];
+  const char* const raw_base = sRAW + ((2 * tty) * WPS + ttx) * 64 + cp * 4;
+  const int v_off = t_tile * 64 + (((cp >> 2) ^ w_swz(t_tile)) << 4) + (cp & 3) * 4;      // + xi * 4096
+
+  // ---- MFMA side: wave = transform position xi
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int frag_off = l15 * 64 + ((kq ^ w_swz(l15)) << 4);                                // + block * 1024 (16 rows of 64 B)
+  const char* const Vx = sV + wave * 4096;
+  const char* const Ux = sU + wave * 2048;                       // + half * 32 KiB, + block * 1024
+  f32x4 acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = g.Cin / WCK;
+  auto mma_half = [&](int hf) {
+    u32x4 fa[4], fb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *(const u32x4*)(Vx + i * 1024 + frag_off);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *(const u32x4*)(Ux + hf * (W_U_BYTES / 2) + j * 1024 + frag_off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][2 * hf + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                     acc[i][2 * hf + j], 0, 0, 0);
+  };
+  // DMA in flight, oldest first, at each wait (2 instructions per wave each):
+  //   B1  patch(c) | U_lo(c)                 -> vmcnt(2): patch(c) landed;       then issue U_hi(c)
+  //   B2  U_lo(c) | U_hi(c)                  -> vmcnt(2): U_lo(c) landed;        then issue patch(c + 1)
+  //   B3  U_hi(c) | patch(c + 1)             -> vmcnt(2): U_hi(c) landed;        then issue U_lo(c + 1)
+  issue_raw(0);
+  issue_u(0, 0);
+  for (int c = 0; c < nchunk; ++c) {
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // B1: patch(c) complete; every wave is done with M_hi(c - 1): V and U_hi are free
+    issue_u(c, 1);
+    {
+      // T: B^T d B in f32 for two channels; rows first (index a), then columns (index b)
+      float lo[4][4], hi[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const unsigned int w = *(const unsigned int*)(raw_base + (a * WPS + (b & 1) * 9 + (b >> 1)) * 64);
+          lo[a][b] = __uint_as_float(w << 16); hi[a][b] = __uint_as_float(w & 0xFFFF0000u);
+        }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const unsigned int w = *(const unsigned int*)(R + (a * WPS + (b & 1) * 9 + (b >> 1)) * 32);
-        lo[a][b] = __uint_as_float(w << 16); hi[a][b] = __uint_as_float(w & 0xFFFF0000u);
+        const float l0 = lo[0][b] - lo[2][b], l1 = lo[1][b] + lo[2][b], l2 = lo[2][b] - lo[1][b], l3 = lo[1][b] - lo[3][b];
+        lo[0][b] = l0; lo[1][b] = l1; lo[2][b] = l2; lo[3][b] = l3;
+        const float h0 = hi[0][b] - hi[2][b], h1 = hi[1][b] + hi[2][b], h2 = hi[2][b] - hi[1][b], h3 = hi[1][b] - hi[3][b];
+        hi[0][b] = h0; hi[1][b] = h1; hi[2][b] = h2; hi[3][b] = h3;
       }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const float l0 = lo[0][b] - lo[2][b], l1 = lo[1][b] + lo[2][b], l2 = lo[2][b] - lo[1][b], l3 = lo[1][b] - lo[3][b];
-      lo[0][b] = l0; lo[1][b] = l1; lo[2][b] = l2; lo[3][b] = l3;
-      const float h0 = hi[0][b] - hi[2][b], h1 = hi[1][b] + hi[2][b], h2 = hi[2][b] - hi[1][b], h3 = hi[1][b] - hi[3][b];
-      hi[0][b] = h0; hi[1][b] = h1; hi[2][b] = h2; hi[3][b] = h3;
+      for (int a = 0; a < 4; ++a) {
+        const float l0 = lo[a][0] - lo[a][2], l1 = lo[a][1] + lo[a][2], l2 = lo[a][2] - lo[a][1], l3 = lo[a][1] - lo[a][3];
+        const float h0 = hi[a][0] - hi[a][2], h1 = hi[a][1] + hi[a][2], h2 = hi[a][2] - hi[a][1], h3 = hi[a][1] - hi[a][3];
+        char* dst = sV + (a * 4) * 4096 + v_off;
+        *(unsigned int*)(dst) = pack_bf16x2(l0, h0);
+        *(unsigned int*)(dst + 4096) = pack_bf16x2(l1, h1);
+        *(unsigned int*)(dst + 8192) = pack_bf16x2(l2, h2);
+        *(unsigned int*)(dst + 12288) = pack_bf16x2(l3, h3);
+      }
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const float l0 = lo[a][0] - lo[a][2], l1 = lo[a][1] + lo[a][2], l2 = lo[a][2] - lo[a][1], l3 = lo[a][1] - lo[a][3];
-      const float h0 = hi[a][0] - hi[a][2], h1 = hi[a][1] + hi[a][2], h2 = hi[a][2] - hi[a][1], h3 = hi[a][1] - hi[a][3];
-      char* dst = Vw + (a * 4) * 2048;
-      *(unsigned int*)(dst) = pack_bf16x2(l0, h0);
-      *(unsigned int*)(dst + 2048) = pack_bf16x2(l1, h1);
-      *(unsigned int*)(dst + 4096) = pack_bf16x2(l2, h2);
-      *(unsigned int*)(dst + 6144) = pack_bf16x2(l3, h3);
-    }
-  };
-
-  // ---- MFMA side: wave = transform position xi; 32x32x16: lane (row = lane & 31, K half = lane >> 5)
-  const int l31 = lane & 31, kh = lane >> 5;
-  const int frag_off = wave * 2048 + l31 * 32 + ((kh ^ w_swz(l31)) << 4);                   // + block * 1024 (32 rows of 32 B)
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nsub = g.Cin / WCK;
-  issue_raw(0);
-  issue_u(0);
-  if (nsub > 1) issue_raw(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid < 512) transform(0);
-  for (int p = 0; p < nsub; ++p) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // own pieces of U(p) and patch(p + 1), issued a phase ago
-    __syncthreads();                                            // V[p & 1] written (LDS drained), U(p), patch(p + 1) complete; phase p - 1's readers are done
-    if (p + 1 < nsub) issue_u(p + 1);
-    if (p + 2 < nsub) issue_raw(p + 2);
-    {
-      const char* const Vb = sV + (p & 1) * W_V_BYTES + frag_off;
-      const char* const Ub = sU + (p & 1) * W_U_BYTES + frag_off;
-      u32x4 fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(Vb + i * 1024);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *(const u32x4*)(Ub + j * 1024);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
-                                                              acc[i][j], 0, 0, 0);
-    }
-    if (p + 1 < nsub && tid < 512) transform(p + 1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __syncthreads();                                            // B2: V complete (LDS writes drained), U_lo(c) complete, the patch buffer is free
+    if (c + 1 < nchunk) issue_raw(c + 1);
+    mma_half(0);
+    if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // B3: every wave is done with U_lo(c); U_hi(c) complete
+    if (c + 1 < nchunk) issue_u(c + 1, 0);
+    mma_half(1);
   }
   // ---- output transform: the 16 positions of a (tile, channel) meet through LDS, 32 channels at a time
   float* const X = (float*)smem;                                 // [xi][tile 64][32 channels] f32 = 128 KiB
   unsigned short* const out = (unsigned short*)g.out;
   const unsigned short* const ref = (const unsigned short*)g.ref;
-  const int o_tile = tid >> 4, ocp = tid & 15;                   // output side: thread = (tile, channel pair of the half's 16)
-  const int oty = o_tile >> 3, otx = o_tile & 7;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     __syncthreads();                                             // h = 0: every wave is done with V / U; h = 1: X has been read
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e)                               // C/D map of 32x32: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-        X[(wave * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + l31] = acc[i][h][e];
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          X[(wave * 64 + i * 16 + kq * 4 + e) * 32 + jj * 16 + l15] = acc[i][2 * h + jj][e];
     __syncthreads();
     float m[16][2];
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) {
-      const float2 v2 = *(const float2*)(X + (xi * 64 + o_tile) * 32 + 2 * ocp);
+      const float2 v2 = *(const float2*)(X + (xi * 64 + t_tile) * 32 + 2 * cp);
       m[xi][0] = v2.x; m[xi][1] = v2.y;
     }
-    const int co = co0 + 32 * h + 2 * ocp;
+    const int co = co0 + 32 * h + 2 * cp;
     float bv[2] = {0.f, 0.f};
     if (g.bias && co < g.Cout) { bv[0] = g.bias[co]; bv[1] = g.bias[co + 1]; }
     float y[2][2][2];                                            // [a][b][channel]
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WNT) void conv3x3_winograd_kernel(WinoArgs g) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int yy = py + d * (2 * WT * by + 2 * oty + a), xx = px + d * (2 * WT * bx + 2 * otx + b);
+        const int yy = py + d * (2 * WT * by + 2 * tty + a), xx = px + d * (2 * WT * bx + 2 * ttx + b);
         if (yy < g.H && xx < g.W && co < g.Cout) {
           float v0 = y[a][b][0] + bv[0], v1 = y[a][b][1] + bv[1];
           if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void winograd_weight_prep_kernel(WinoPrepMulti
 extern "C" int sw_conv3x3_winograd(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in, const void* U,
                                    void* out, const sw_epilogue* ep, hipStream_t stream) {
   SW_ENTER();
-  if (dtype != SW_BF16 || !ep || (Cin % 32) || (Cout % 2) || (dilation != 1 && dilation != 2) || nimg < 1 || H < 1 || W < 1) return 0;
+  if (dtype != SW_BF16 || !ep || (Cin % WCK) || (Cout % 2) || (dilation != 1 && dilation != 2) || nimg < 1 || H < 1 || W < 1) return 0;
   if (ep->out_dtype != SW_BF16 || ep->drop_mask || ep->accumulate_atomic || ep->absmax_out || ep->drop_hash_p > 0.f || ep->residual) return 0;
   if (ep->relu_ref && (ep->ref_dtype != SW_BF16 || ep->ld_ref != Cout || ep->ref_scale != 1.0f)) return 0;
   if ((((uintptr_t)in | (uintptr_t)U | (uintptr_t)out | (uintptr_t)ep->relu_ref) & 15)) return 0;
@@ -317,7 +317,7 @@ extern "C" int sw_conv3x3_winograd(int dtype, int nimg, int H, int W, int Cin, i
   const long ib = (long)nimg * H * W * Cin * 2, ub = (long)16 * Cout * Cin * 2;
   if (ib >= 0xFFFFFF00L || ub >= 0xFFFFFF00L) return 0;
   g.in_bytes = (unsigned)ib; g.u_bytes = (unsigned)ub;
-  const size_t lds = (size_t)W_LDS;
+  const size_t lds = (size_t)W_RAW_BYTES + W_V_BYTES + W_U_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_winograd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
