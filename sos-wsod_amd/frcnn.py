@@ -111,7 +111,7 @@ def _pad_scale(scale, ld):
     return torch.cat([scale, torch.ones(ld - scale.shape[0], device=scale.device, dtype=scale.dtype)])
 
 
-class _LinearFn(torch.autograd.Function):
+class _LinearFn(ops.CountedFunction):
     """y (P, out) = x (P, in) @ W_eff^T (+ bias) (ReLU): sw_gemm with the epilogue fused; explicit backward (dgrad, wgrad GEMMs, column
     sums).  `staged` (ld, in) is the compute-dtype copy of the effective weight (rows beyond `out` zero), written by the model's
     stage plan; `bias` f32 or None; `scale` (out,) f32 or None = the FrozenBN fold (W_eff = W * scale: dW = scale * dW_eff).
@@ -223,7 +223,7 @@ class _LinearFn(torch.autograd.Function):
         return (dx, None, None, None, None, None, None, dres) + tuple(dws) + tuple(dbs)
 
 
-class _Conv3x3Fn(torch.autograd.Function):
+class _Conv3x3Fn(ops.CountedFunction):
     """3x3, stride 1, padding 1 on NHWC: sw_conv3x3_igemm (+ bias, ReLU fused) on the staged [co][tap][ci] copy of the effective
     weight; backward = weight gradient (split-K slabs, ordered fold; x FrozenBN scale), column sums, data gradient through the
     staged flipped-tap layout `staged_d` [ci][tap][co].  `w` / `b`: the parameters the gradients go to (b may be None)."""
@@ -428,7 +428,7 @@ def _wgrad_3x3(x4, dz4, scale, key=None):
     return dw.view(cout, cin, 3, 3)
 
 
-class _BottleneckFn(torch.autograd.Function):
+class _BottleneckFn(ops.CountedFunction):
     """One bottleneck block (conv1 1x1 [stride s] -> ReLU -> conv2 3x3 -> ReLU -> conv3 1x1, + shortcut, ReLU) as ONE autograd node
     with an explicit backward.  Layer by layer (`_LinearFn` / `_Conv3x3Fn` nodes) every ReLU mask was a kernel of its own in front of
     the layer's gradients and autograd added the two gradients of the block input with a torch kernel; here the masks of conv1's and
@@ -577,7 +577,7 @@ class _BottleneckFn(torch.autograd.Function):
         return (dx, None, dw1, dw2, dw3) + ((dwsc,) if wsc is not None else ())
 
 
-class _Conv3x3LevelsFn(torch.autograd.Function):
+class _Conv3x3LevelsFn(ops.CountedFunction):
     """L independent 3x3 convolutions (stride 1, padding 1, + bias, optional ReLU) of L maps as ONE launch each way (ops.conv3x3_multi:
     the FPN levels — the RPN head's shared convolution on p2..p6, the four FPN output convolutions).  args: L, flags (the `relu`
     argument of _Conv3x3Fn), then L inputs, L staged forward weights, L staged data-gradient weights, L bias values, L weight parameters,

@@ -133,10 +133,30 @@ class grad_scope:
         return False
 
 
+CALLER_GRAD_ENABLED = True      # grad mode of the code that called the running CountedFunction.apply (see there)
+
+
+class CountedFunction(torch.autograd.Function):
+    """torch.autograd.Function whose forward may call `count_use`.  Inside `forward` autograd has ALREADY switched grad mode off —
+    whether the caller ran under torch.no_grad() or not — and ctx.needs_input_grad stays True for a parameter that requires grad:
+    the only place that still sees the caller's mode is `apply` itself, so it is recorded there.  (Round 5 first tested
+    torch.is_grad_enabled() inside count_use: always False in a forward, so nothing was counted and every Stage-3 weight gradient
+    silently took the one-by-one path — 16.2 -> 17.3 ms; found in the kernel statistics, where the grouped launches had disappeared.)"""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        global CALLER_GRAD_ENABLED
+        prev, CALLER_GRAD_ENABLED = CALLER_GRAD_ENABLED, torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            CALLER_GRAD_ENABLED = prev
+
+
 def count_use(key):
-    """forward side: this pass will contribute one weight-gradient node for `key`.  A pass under torch.no_grad() builds no node
-    (ctx.needs_input_grad stays True for a parameter that requires grad, so the caller's own test does not see it): not counted."""
-    if GRAD_SCOPE is not None and key is not None and torch.is_grad_enabled():
+    """forward side (inside a CountedFunction.forward): this pass will contribute one weight-gradient node for `key`.  A pass under
+    torch.no_grad() builds no node: not counted (a counted use that never reaches backward would leave a queued gradient unfinished)."""
+    if GRAD_SCOPE is not None and key is not None and CALLER_GRAD_ENABLED:
         GRAD_SCOPE.uses[key] = GRAD_SCOPE.uses.get(key, 0) + 1
 
 

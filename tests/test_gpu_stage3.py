@@ -764,7 +764,18 @@ def test_weight_gradients_summed_in_the_kernels_equal_autograd_sums(mode):
             out.append(d)
         return out
     grads = {}
+    import sos_wsod_amd.ops as ops
+    calls = {True: [0, 0], False: [0, 0]}           # grouped launches (3x3, 1x1) per setting: the fused step must actually take them
+    real3, real1 = ops.conv3x3_wgrad_grouped, ops.gemm_kk_grouped
     for fuse in (True, False):
+        def spy3(*a, _f=fuse, **k):
+            calls[_f][0] += 1
+            return real3(*a, **k)
+
+        def spy1(*a, _f=fuse, **k):
+            calls[_f][1] += 1
+            return real1(*a, **k)
+        ops.conv3x3_wgrad_grouped, ops.gemm_kk_grouped = spy3, spy1
         student, teacher = _model(K, P, "s3g", dtype=dtype), _model(K, P, "s3g", dtype=dtype)
         student.train(); teacher.train()
         student.proposal_generator.sampler = student.roi_heads.sampler = student.sampler
@@ -774,6 +785,10 @@ def test_weight_gradients_summed_in_the_kernels_equal_autograd_sums(mode):
         torch.cuda.synchronize()
         assert "loss_cls_pseudo" in record
         grads[fuse] = {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}
+    ops.conv3x3_wgrad_grouped, ops.gemm_kk_grouped = real3, real1
+    # the uses were counted (ops.CountedFunction) and the last use of a weight ran all pairs as ONE grouped launch: >= one launch per
+    # 3x3 weight with several uses (13 bottleneck conv2 + the RPN head + 4 FPN outputs) and per bottleneck block's 1x1 weights
+    assert calls[True][0] >= 10 and calls[True][1] >= 10, calls
     assert set(grads[True]) == set(grads[False]) and len(grads[True]) > 60
     # the sums themselves are the same f32 additions in the same order; the comparison is not bit-exact because the ROIAlign backward
     # scatters with f32 atomics (run-to-run noise of ~1e-7 in everything below the pooler); 1e-5 of the tensor's largest element

@@ -24,14 +24,14 @@ def main():
     m = bench.build(dev, torch.bfloat16); m.train()
     gs = [{"params": [p], "lr": 2e-3 if nm.endswith(".bias") else 1e-3, "weight_decay": 0.0 if nm.endswith(".bias") else 5e-4}
           for nm, p in m.named_parameters() if p.requires_grad]
-    tr = Trainer(m, HipSGD(gs, 1e-3, momentum=0.9), ddp=ddp, use_graph=False)
-    for i in range(6):
+    tr = Trainer(m, HipSGD(gs, 1e-3, momentum=0.9), ddp=ddp, use_graph=os.environ.get("USE_GRAPH", "0") == "1")
+    for i in range(8):
         tr.run_step(batches[i % 2])
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(n):
         tr.run_step(batches[i % 2])
     torch.cuda.synchronize()
-    print(f"{'DDP over RCCL world 1' if ddp else 'single process'}, eager: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step", file=sys.stderr)
+    print(f"{'DDP over RCCL world 1' if ddp else 'single process'}, {'graphs' if os.environ.get('USE_GRAPH', '0') == '1' else 'eager'}, upd_main={os.environ.get('SW_DDP_UPD_MAIN', '0')}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step", file=sys.stderr)
     tr.finish()
     if ddp:
         dist.destroy_process_group()
