@@ -682,6 +682,18 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_plane_kernel(int H, int W, in
 // global memory.
 constexpr int SP_NT = 1024, SP_CH = 128, SP_NLEV = 6, SP_NHC = 7, SP_NCLS = SP_NLEV * SP_NHC;
 
+// development instrumentation (tools/build_variant.sh phases SRC=roipool -DSW_ROI_PHASES; tools/probes/roi_phases.py): shader-clock cycles
+// of workgroup thread 0 per phase, summed over the workgroups.  0 sort, 1 level-0 table, 2 level advances, 3 chunk tables + task list,
+// 4 task scan, 5 wait at the barriers behind a scan (imbalance inside a chunk), 6 whole kernel, 7 workgroups
+#ifdef SW_ROI_PHASES
+__device__ unsigned long long g_roi_phase[8];
+#define SP_T(var) const long long var = (long long)clock64()
+#define SP_ADD(i, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_roi_phase[i], (unsigned long long)((b) - (a))); } while (0)
+#else
+#define SP_T(var) do {} while (0)
+#define SP_ADD(i, a, b) do {} while (0)
+#endif
+
 __device__ __forceinline__ unsigned int key16_of(unsigned int bts) {          // pix_to_keys for one bf16 value
   unsigned int key = (bts & 0x8000u) ? (bts ^ 0xFFFFu) : (bts | 0x8000u);
   if (bts > 0x7F80u && bts < 0x8000u) key = 0;                                // +NaN never wins
@@ -756,6 +768,7 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
       }
     }
   };
+  SP_T(t_begin);
   if (tid <= SP_NCLS) s_start[tid] = 0;
   __syncthreads();
   for_my_rois([&](int r) { atomicAdd(&s_start[roi_class(r) + 1], 1); });
@@ -766,6 +779,7 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
   __syncthreads();
   for_my_rois([&](int r) { s_lvl[atomicAdd(&s_fill[roi_class(r)], 1)] = (unsigned short)r; });
   const int n_rois = s_start[SP_NCLS];
+  SP_T(t_sorted); SP_ADD(0, t_begin, t_sorted); SP_ADD(7, 0, 1);
   if (n_rois == 0) return;                                          // (uniform: s_start is final since the barrier above)
 
   // ---- 2. level 0: candidates of the slab's pixels
@@ -790,10 +804,13 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
     }
   }
   constexpr unsigned KEY_INIT = 0x007FFFFFu;                        // key(-inf) << 16 | 0xFFFF
+  SP_T(t_tab0); SP_ADD(1, t_sorted, t_tab0);
   for (int L = 0; L < SP_NLEV; ++L) {
     const int c_lo = s_start[L * SP_NHC], c_hi = s_start[(L + 1) * SP_NHC];
     if (c_lo >= n_rois) break;                                      // no ROI at this or a higher level
+    SP_T(t_lv0);
     __syncthreads();                                                // level L - 1 fully scanned (L = 0: table and list written)
+    SP_T(t_lv1); SP_ADD(5, t_lv0, t_lv1);
     if (L > 0) {
       // ---- 3. T_L from T_{L-1}, in place: every thread reads its pixels' two spans, barrier, writes
       const int d = 1 << (L - 1);
@@ -823,9 +840,12 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
       __syncthreads();
     }
     const int span = 1 << L;
+    SP_T(t_lv2); SP_ADD(2, t_lv1, t_lv2);
     for (int cs = c_lo; cs < c_hi; cs += SP_CH) {
       const int cnt = min(SP_CH, c_hi - cs);
+      SP_T(t_c0);
       __syncthreads();                                              // the previous chunk's tables are no longer read
+      SP_T(t_c1); SP_ADD(5, t_c0, t_c1);
       if (tid == 0) s_ntask = 0;
       for (int i = tid; i < cnt * (PH + PW); i += NT) {
         const int li = i / (PH + PW), k = i - li * (PH + PW);
@@ -860,6 +880,7 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
         __syncthreads();
         ntask = s_ntask;
       }
+      SP_T(t_c2); SP_ADD(3, t_c1, t_c2);
       const int total = ntask * PW;
       const int dli = NT / nb, dph = (NT - dli * nb) / PW, dpw = NT - dli * nb - dph * PW;
       int li = tid / nb, ph = (tid - li * nb) / PW, pw = tid - li * nb - ph * PW;
@@ -971,8 +992,10 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
           if (ph >= PH) { ph -= PH; ++li; }
         }
       }
+      SP_T(t_c3); SP_ADD(4, t_c2, t_c3);
     }   // chunks of the level
   }     // levels
+  SP_T(t_end); SP_ADD(6, t_begin, t_end);
 }
 
 // max |x| over n elements -> out[0] (f32; caller zero-fills).  |x| as IEEE bits is monotone => integer atomicMax; a NaN in x
@@ -1291,3 +1314,12 @@ extern "C" int sw_absmax(int dtype, long n, const void* x, float* out, hipStream
   SW_CHECK_LAUNCH();
   return 0;
 }
+
+#ifdef SW_ROI_PHASES
+extern "C" int sw_debug_roi_phases(unsigned long long* out8, int reset) {
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess && out8) e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_roi_phase), 64);
+  if (e == hipSuccess && reset) { unsigned long long z[8] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_roi_phase), z, 64); }
+  return e == hipSuccess ? 0 : -(int)e;
+}
+#endif

@@ -6,6 +6,7 @@ f=$(ls gpurun_out/prof_s3/*/*kernel_stats.csv | head -1)
 t=$(ls gpurun_out/prof_s3/*/*kernel_trace.csv | head -1)
 head -40 $f | cut -c1-200 > gpurun_out/s3_kernel_stats_head.csv
 cp $f gpurun_out/s3_kernel_stats.csv
+cp $t gpurun_out/s3_kernel_trace.csv
 python - <<PY
 import csv
 rows = list(csv.DictReader(open("$t")))
