@@ -1167,11 +1167,16 @@ class PseudoLabRPN(nn.Module):
                                      int(self.batch_size_per_image * self.positive_fraction))
 
     def _image_hw(self, image_sizes, device):
+        # (a dict: one iteration of the semi-supervised step calls this with three different batches — a one-entry cache rebuilt the
+        # tensor and copied it to the device every call)
         key = (tuple((int(h), int(w)) for h, w in image_sizes), str(device))
-        hit = self.__dict__.get("_hw_cache")
-        if hit is None or hit[0] != key:
-            hit = self.__dict__["_hw_cache"] = (key, torch.tensor([list(k) for k in key[0]], dtype=torch.int32).to(device))
-        return hit[1]
+        cache = self.__dict__.setdefault("_hw_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 64:
+                cache.clear()
+            hit = cache[key] = torch.tensor([list(k) for k in key[0]], dtype=torch.int32).to(device)
+        return hit
 
     @torch.no_grad()
     def predict_proposals(self, anchors, logits, deltas, image_sizes):
@@ -1482,11 +1487,14 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
             ops.preprocess_pad(im.contiguous(), out[i], mean, std)
         return out, sizes
 
-    def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False, second=None):
+    def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False, second=None, second_targets=None):
         """second (branch "supervised" only): a SECOND, independent batch of the same branch — the semi-supervised step's pseudo-labelled
         views next to its labelled ones (unbias/ubteacher/engine/trainer.py:527-538 calls the model twice).  Both batches' backbones run
         in lockstep (ResNet.forward_lockstep), everything image- and loss-specific per batch, first batch first (the order of the two
-        calls: the label samplers draw their keys in it) -> (result of the first batch, result of the second batch)"""
+        calls: the label samplers draw their keys in it) -> (result of the first batch, result of the second batch).
+        second_targets: a callable returning the second batch's list of Instances, called only when its heads need them — after both
+        backbones and the first batch's heads are queued: the teacher that produces the pseudo labels can run beside all of that on
+        another stream (semisup.SemiSupStep)."""
         if (not self.training) and (not val_mode):
             return self.inference(batched_inputs)
         self.refresh_staged_weights()
@@ -1496,8 +1504,11 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
             results = []
             pre = [self.preprocess_image(b) for b in (batched_inputs, second)]
             cs = self.backbone.bottom_up.forward_lockstep([x4 for x4, _ in pre])
-            for b, (_, sizes), c in zip((batched_inputs, second), pre, cs):
-                gt = [x["instances"] for x in b] if "instances" in b[0] else None
+            for bi, (b, (_, sizes), c) in enumerate(zip((batched_inputs, second), pre, cs)):
+                if bi == 1 and second_targets is not None:
+                    gt = second_targets()
+                else:
+                    gt = [x["instances"] for x in b] if "instances" in b[0] else None
                 feats = self.backbone.forward_top(c)
                 proposals, rpn_losses = self.proposal_generator(sizes, feats, gt)
                 _, det_losses = self.roi_heads(feats, proposals, gt, branch=branch)

@@ -14,6 +14,7 @@ from typing import Dict, Optional
 
 import weakref
 
+import os
 import torch
 
 from . import ops
@@ -23,8 +24,26 @@ from .structures import Boxes, Instances
 _EMA_PLANS = weakref.WeakKeyDictionary()       # teacher module -> (weakref to the student, storage pointers, EmaPlan, rest)
 
 
+_MODULE_LISTS = weakref.WeakKeyDictionary()     # model -> list of its modules (the tree walk of .parameters() / .buffers() is the cost)
+
+
 def _storage_ptrs(m):
-    return tuple(t.data_ptr() for t in m.parameters()) + tuple(t.data_ptr() for t in m.buffers())
+    """where every parameter and buffer of `m` lives now.  Read from the modules' own dicts (a replaced Parameter / buffer object, a
+    .to() or a load that re-allocates all change it); the list of modules itself is cached — m.parameters() + m.buffers() walk the
+    module tree with a memo set each, 1.8 ms of host time per iteration for the two ResNet-50-FPN detectors (cProfile,
+    tools/diag/stage3_host_profile.py), and a module ADDED to a model between two EMA updates is not something training does."""
+    mods = _MODULE_LISTS.get(m)
+    if mods is None:
+        mods = _MODULE_LISTS[m] = list(m.modules())
+    out = []
+    for mod in mods:
+        for t in mod._parameters.values():
+            if t is not None:
+                out.append(t.data_ptr())
+        for t in mod._buffers.values():
+            if t is not None:
+                out.append(t.data_ptr())
+    return out
 
 
 @torch.no_grad()
@@ -201,7 +220,7 @@ class SemiSupStep:
 
     def __init__(self, model, model_teacher, optimizer, *, burn_up_step, teacher_update_iter=1, ema_keep_rate=0.9996,
                  bbox_threshold=0.7, unsup_loss_weight=4.0, burn_up_with_strong_aug=True, has_multi_label=False, fuse_grad_sums=True,
-                 lockstep=True):
+                 lockstep=True, overlap_teacher=False):
         self.model, self.model_teacher, self.optimizer = model, model_teacher, optimizer
         self.fuse_grad_sums = fuse_grad_sums          # ops.grad_scope around backward (False: autograd sums the two passes' weight gradients)
         core = getattr(model, "module", model)                                 # (DistributedDataParallel wraps the student)
@@ -209,6 +228,12 @@ class SemiSupStep:
         self.burn_up_step, self.teacher_update_iter, self.ema_keep_rate = burn_up_step, teacher_update_iter, ema_keep_rate
         self.bbox_threshold, self.unsup_loss_weight = bbox_threshold, unsup_loss_weight
         self.burn_up_with_strong_aug, self.has_multi_label = burn_up_with_strong_aug, has_multi_label
+        # the teacher's pass on a second stream, beside the student's backbones and labelled-batch heads (lockstep form only: that is
+        # the call that can take the pseudo labels late).  OFF by default: measured 16.0-16.9 ms against 15.7-16.3 ms without it (three
+        # runs each, one box) — the iteration is bound by the issuing threads (11 ms of CPU time in the forward thread alone, seven
+        # count read-backs), not by GPU occupancy, so running kernels side by side gains nothing yet.  SW_S3_TEACHER_STREAM=1 turns it on.
+        self.overlap_teacher = (bool(overlap_teacher) or os.environ.get("SW_S3_TEACHER_STREAM", "0") == "1") and self.lockstep
+        self._side = None
         self.iter = 0
 
     def run_step(self, data):
@@ -231,20 +256,53 @@ class SemiSupStep:
             elif (self.iter - self.burn_up_step) % self.teacher_update_iter == 0:
                 update_teacher_model(self.model, self.model_teacher, keep_rate=self.ema_keep_rate)
             record = {}
-            with torch.no_grad():
-                _, props_rpn, props_roih, _ = self.model_teacher(unlabel_k, branch="unsup_data_weak")
-            process_pseudo_label(unlabel_k, props_rpn, self.bbox_threshold, "rpn")                 # :490-494 (joint dict, unused after)
-            pseudo_roih, _ = process_pseudo_label(unlabel_k, props_roih, self.bbox_threshold, "roih",
-                                                  has_multi_label=self.has_multi_label)
-            for d in list(unlabel_q) + list(unlabel_k):                                               # remove_label
-                d.pop("instances", None)
-            for dq, dk, lab in zip(unlabel_q, unlabel_k, pseudo_roih):                                # add_label
-                dq["instances"] = lab; dk["instances"] = lab
-            if self.lockstep:
+
+            def teacher_pass():
+                with torch.no_grad():
+                    _, props_rpn, props_roih, _ = self.model_teacher(unlabel_k, branch="unsup_data_weak")
+                return props_rpn, props_roih
+
+            def pseudo_labels(props_rpn, props_roih):
+                process_pseudo_label(unlabel_k, props_rpn, self.bbox_threshold, "rpn")             # :490-494 (joint dict, unused after)
+                pseudo_roih, _ = process_pseudo_label(unlabel_k, props_roih, self.bbox_threshold, "roih",
+                                                      has_multi_label=self.has_multi_label)
+                for d in list(unlabel_q) + list(unlabel_k):                                           # remove_label
+                    d.pop("instances", None)
+                for dq, dk, lab in zip(unlabel_q, unlabel_k, pseudo_roih):                            # add_label
+                    dq["instances"] = lab; dk["instances"] = lab
+                return pseudo_roih
+            dev = next(self.model_teacher.parameters()).device
+            if self.overlap_teacher and dev.type == "cuda":
+                # Teacher on the side stream, student on the caller's: the GPU runs the teacher's ~150 small launches (one 800x1216 image:
+                # res4 / res5 / FPN kernels of a few hundred workgroups) between the student's.  Its labels are asked for by the student's
+                # call only when the pseudo-labelled batch's heads are next (second_targets): by then both student backbones and the
+                # labelled batch's RPN / ROI heads are queued.  The thresholding's count read-backs wait for the SIDE stream only.
+                main = torch.cuda.current_stream(dev)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                side = self._side
+                side.wait_stream(main)                               # the EMA update above wrote the teacher's weights on `main`
+                with torch.cuda.stream(side):
+                    props = teacher_pass()
+
+                def late_targets():
+                    with torch.cuda.stream(side):
+                        labs = pseudo_labels(*props)
+                    main.wait_stream(side)
+                    for lab in labs:                                 # allocated on `side`, read by kernels queued on `main`
+                        for t in (lab.gt_boxes.tensor, lab.gt_classes, lab.scores):
+                            t.record_stream(main)
+                    return labs
+                (rec_label, _, _, _), (rec_unlabel, _, _, _) = self.model(list(label_q) + list(label_k), branch="supervised",
+                                                                          second=list(unlabel_q), second_targets=late_targets)
+                side.wait_stream(main)                               # (the next teacher pass starts behind this step's readers anyway)
+            elif self.lockstep:
+                pseudo_labels(*teacher_pass())
                 # both student passes through ONE call: their backbones run in lockstep (frcnn: forward(..., second=...))
                 (rec_label, _, _, _), (rec_unlabel, _, _, _) = self.model(list(label_q) + list(label_k), branch="supervised",
                                                                           second=list(unlabel_q))
             else:
+                pseudo_labels(*teacher_pass())
                 rec_label, _, _, _ = self.model(list(label_q) + list(label_k), branch="supervised")
                 rec_unlabel, _, _, _ = self.model(unlabel_q, branch="supervised")
             record.update(rec_label)

@@ -852,6 +852,53 @@ def test_student_passes_in_lockstep_equal_two_calls(mode):
     print(f"lockstep vs two calls ({mode}): losses {res[True][0]}; worst gradient difference {worst[1]:.1e} ({worst[0]})")
 
 
+def test_teacher_on_a_side_stream_gives_the_same_step():
+    """SemiSupStep(overlap_teacher=True): the teacher's weak pass runs on a second stream and the student's call asks for the pseudo
+    labels only when the pseudo-labelled batch's heads are next (frcnn forward(second_targets=...)).  Same kernels, same order per
+    stream, the labels handed over behind a stream wait.  Three iterations at learning rate 0 with a teacher that starts AWAY from the
+    student (every iteration's EMA update, keep rate 0.5, moves it: the update has to wait for the previous iteration's teacher
+    readers, the teacher's pass for the update) — nothing in the losses depends on the gradients (whose ROIAlign backward scatters
+    with float atomics), so the 8 losses of every iteration and the teacher's parameters must be EQUAL to the sequential form's."""
+    from sos_wsod_amd.semisup import SemiSupStep
+    from sos_wsod_amd.solver import HipSGD
+    from sos_wsod_amd.structures import Boxes, Instances
+    K = 20
+    P, PT = FO.make_params(K, tag="s3l", head_scale=14.0), FO.make_params(K, tag="s3o_teacher", head_scale=14.0)
+
+    def batch(tag, sizes, n_gt):
+        out = []
+        for i, (h, w) in enumerate(sizes):
+            d = {"image": torch.from_numpy(FO.make_image(h, w, f"{tag}{i}")).cuda(), "height": h, "width": w}
+            if n_gt:
+                b, c = FO.make_gt(h, w, n_gt, K, f"{tag}{i}")
+                inst = Instances((h, w)); inst.gt_boxes = Boxes(torch.from_numpy(b).cuda()); inst.gt_classes = torch.from_numpy(c).cuda()
+                d["instances"] = inst
+            out.append(d)
+        return out
+    res = {}
+    for overlap in (True, False):
+        student, teacher = _model(K, P, "s3l"), _model(K, PT, "s3l")
+        student.train(); teacher.train()
+        student.proposal_generator.sampler = student.roi_heads.sampler = student.sampler
+        opt = HipSGD([p for p in student.parameters() if p.requires_grad], 0.0, momentum=0.9)
+        step = SemiSupStep(student, teacher, opt, burn_up_step=0, bbox_threshold=0.0, unsup_loss_weight=2.0, ema_keep_rate=0.5,
+                           overlap_teacher=overlap)
+        assert step.overlap_teacher == overlap
+        recs = []
+        for it in range(3):
+            record, _ = step.run_step((batch(f"s3o{it}_lq", [(96, 128)], 2), batch(f"s3o{it}_lk", [(128, 112)], 3),
+                                       batch(f"s3o{it}_uq", [(160, 96)], 0), batch(f"s3o{it}_uk", [(160, 96)], 0)))
+            recs.append({k: float(v) for k, v in record.items() if k.startswith("loss")})
+        torch.cuda.synchronize()
+        res[overlap] = (recs, {n: p.detach().clone() for n, p in teacher.named_parameters()})
+    for it in range(3):
+        assert len(res[True][0][it]) == 8
+        for k, v in res[False][0][it].items():
+            assert res[True][0][it][k] == v, (it, k, res[True][0][it][k], v)
+    assert res[True][0][0] != res[True][0][1] != res[True][0][2]                      # the teacher did move between the iterations
+    assert all(torch.equal(a, res[False][1][n]) for n, a in res[True][1].items())
+
+
 def test_detector_trains_the_same_under_hipsgd_and_torch_sgd(golden_dir):
     """Stage 3's solver is the same SGD (momentum 0.9, weight decay) as Stage 1's: the fused HipSGD and torch.optim.SGD drive the
     detector to the same parameters and losses over 3 supervised steps.  HipSGD writes the parameters behind torch's version

@@ -49,11 +49,17 @@ def time_step(dtype, H=800, W=1216, dev=None, warm=3, n=8):
     batches = make_batches(warm + n, H, W, dev)
     for i in range(warm):
         rec, _ = step.run_step(batches[i])
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    torch.cuda.synchronize(); t0 = time.perf_counter(); c0 = time.thread_time()
     for i in range(n):
         rec, _ = step.run_step(batches[warm + i])
+    c1 = time.thread_time()
     torch.cuda.synchronize()
+    global HOST_MS
+    HOST_MS = (c1 - c0) / n * 1e3            # CPU time of the issuing thread per iteration (close to the wall time = host bound)
     return (time.perf_counter() - t0) / n * 1e3, rec
+
+
+HOST_MS = None
 
 
 if __name__ == "__main__":
@@ -62,4 +68,4 @@ if __name__ == "__main__":
     ms, rec = time_step(dtype, H, W, n=int(os.environ.get("ITERS", 8)))
     print(f"stage-3 semi-sup step {dtype} {H}x{W}: {ms:.1f} ms per iteration per GPU (4 views: teacher fwd 1, student fwd+bwd 3), "
           f"losses finite: {all(bool(torch.isfinite(v)) for k, v in rec.items() if k.startswith('loss'))}, "
-          f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+          f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; issuing thread's CPU time {HOST_MS:.1f} ms per iteration")
