@@ -852,7 +852,7 @@ def test_student_passes_in_lockstep_equal_two_calls(mode):
     print(f"lockstep vs two calls ({mode}): losses {res[True][0]}; worst gradient difference {worst[1]:.1e} ({worst[0]})")
 
 
-def test_teacher_on_a_side_stream_gives_the_same_step():
+def test_teacher_on_a_side_stream_and_its_backbone_as_a_graph_give_the_same_step():
     """SemiSupStep(overlap_teacher=True): the teacher's weak pass runs on a second stream and the student's call asks for the pseudo
     labels only when the pseudo-labelled batch's heads are next (frcnn forward(second_targets=...)).  Same kernels, same order per
     stream, the labels handed over behind a stream wait.  Three iterations at learning rate 0 with a teacher that starts AWAY from the
@@ -876,7 +876,11 @@ def test_teacher_on_a_side_stream_gives_the_same_step():
             out.append(d)
         return out
     res = {}
-    for overlap in (True, False):
+    # (overlap, backbone graph): the teacher's no-grad backbone pass is a hipGraph replay from its third call with one input shape on
+    # (frcnn._features) — iteration 0 launches, iteration 1 captures and replays, iteration 2 replays, with the EMA moving the weights
+    # under the graph every time; the baseline launches everything
+    for overlap, graph in ((True, True), (False, True), (False, False)):
+        os.environ["SW_S3_BACKBONE_GRAPH"] = "1" if graph else "0"
         student, teacher = _model(K, P, "s3l"), _model(K, PT, "s3l")
         student.train(); teacher.train()
         student.proposal_generator.sampler = student.roi_heads.sampler = student.sampler
@@ -890,13 +894,17 @@ def test_teacher_on_a_side_stream_gives_the_same_step():
                                        batch(f"s3o{it}_uq", [(160, 96)], 0), batch(f"s3o{it}_uk", [(160, 96)], 0)))
             recs.append({k: float(v) for k, v in record.items() if k.startswith("loss")})
         torch.cuda.synchronize()
-        res[overlap] = (recs, {n: p.detach().clone() for n, p in teacher.named_parameters()})
-    for it in range(3):
-        assert len(res[True][0][it]) == 8
-        for k, v in res[False][0][it].items():
-            assert res[True][0][it][k] == v, (it, k, res[True][0][it][k], v)
-    assert res[True][0][0] != res[True][0][1] != res[True][0][2]                      # the teacher did move between the iterations
-    assert all(torch.equal(a, res[False][1][n]) for n, a in res[True][1].items())
+        assert (len([v for v in teacher.__dict__.get("_bb_graphs", {}).values() if v != 1]) == 1) == graph
+        res[(overlap, graph)] = (recs, {n: p.detach().clone() for n, p in teacher.named_parameters()})
+    os.environ.pop("SW_S3_BACKBONE_GRAPH", None)
+    base = res[(False, False)]
+    for variant in ((True, True), (False, True)):
+        for it in range(3):
+            assert len(res[variant][0][it]) == 8
+            for k, v in base[0][it].items():
+                assert res[variant][0][it][k] == v, (variant, it, k, res[variant][0][it][k], v)
+        assert all(torch.equal(a, base[1][n]) for n, a in res[variant][1].items())
+    assert base[0][0] != base[0][1] != base[0][2]                                     # the teacher did move between the iterations
 
 
 def test_detector_trains_the_same_under_hipsgd_and_torch_sgd(golden_dir):
