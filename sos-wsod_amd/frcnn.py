@@ -789,7 +789,14 @@ class FrozenBatchNorm2d(nn.Module):
         hit = self.__dict__.get("_fold")
         if hit is None or hit[0] != key:
             scale = self.weight * torch.rsqrt(self.running_var + 1e-5)
-            hit = (key, (scale.contiguous(), (self.bias - self.running_mean * scale).contiguous()))
+            shift = self.bias - self.running_mean * scale
+            if hit is not None and hit[1][0].device == scale.device and hit[1][0].shape == scale.shape:
+                # the SAME two tensors for the module's lifetime, rewritten in place: a captured launch that read them (the no-grad
+                # backbone graph of TwoStagePseudoLabGeneralizedRCNN._features) sees the new values
+                hit[1][0].copy_(scale); hit[1][1].copy_(shift)
+                hit = (key, hit[1])
+            else:
+                hit = (key, (scale.contiguous(), shift.contiguous()))
             self.__dict__["_fold"] = hit
         return hit[1]
 
@@ -1122,6 +1129,59 @@ class Sampler:
         return _splitmix64(((self.seed & 0xFFFFFFFF) << 32) ^ self.k)
 
 
+class Speculation:
+    """Counts the training path would otherwise read back from the device, ASSUMED and checked once per iteration.
+
+    A semi-supervised iteration read eight counts back (per model call the proposals left by the RPN's NMS and its finite flags, per
+    student batch the sampled rows, the teacher's detections, two pseudo-label counts): every read drains the queue and the GPU then
+    idles until new launches arrive — 16.0 -> 14.2 ms with the reads stubbed out (and 13.1 with the teacher's pass beside the
+    student's, which only pays once the reads are gone).  In training the first three kinds are constants in all but degenerate cases:
+    the NMS leaves its cap (post_nms_topk) whenever the image has that many distinct candidates, the sampler fills its batch whenever
+    there are that many proposals.  While a ledger is open (`with Speculation() as sp:` sets frcnn.SPECULATE) those sites assume the
+    constant, keep the device tensor and go on — their padded rows are defined (zero boxes, class -1, score 0) so that a wrong
+    assumption computes garbage, never touches memory it should not.  `sp.holds()` compares everything in ONE read (all ranks agree
+    through a MAX all-reduce when a process group is up); the caller (semisup.SemiSupStep) then either steps the optimizer or throws
+    the attempt away and repeats the iteration with the exact, reading code."""
+
+    def __init__(self):
+        self.items, self._prev = [], None
+
+    def __enter__(self):
+        global SPECULATE
+        self._prev, SPECULATE = SPECULATE, self
+        return self
+
+    def __exit__(self, *exc):
+        global SPECULATE
+        SPECULATE = self._prev
+        return False
+
+    def expect(self, dev_ints, values):
+        """dev_ints (int32, any shape) is assumed to equal `values` (flat list of ints)"""
+        self.items.append((dev_ints.reshape(-1), [int(v) for v in values]))
+
+    def holds(self):
+        if not self.items:
+            ok = True
+        else:
+            got = torch.cat([t for t, _ in self.items]) if len(self.items) > 1 else self.items[0][0]
+            want = [v for _, vs in self.items for v in vs]
+            have = got.tolist()
+            ok = have == want
+            if not ok and os.environ.get("SW_S3_SPEC_DEBUG"):
+                print("speculation miss: have", have, "want", want, flush=True)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dev = self.items[0][0].device if (self.items and dist.get_backend() == "nccl") else "cpu"
+            flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            ok = int(flag.item()) == 0
+        return ok
+
+
+SPECULATE = None
+
+
 class PseudoLabRPN(nn.Module):
     """unbias/ubteacher/modeling/proposal_generator/rpn.py:11-57 over detectron2's RPN"""
 
@@ -1191,12 +1251,20 @@ class PseudoLabRPN(nn.Module):
         ints = torch.empty(2 * N, device=dev, dtype=torch.int32)                          # proposal counts | finite flags
         sc, bx, _ = ops.rpn_select_pack(logits, deltas, anchors, pre, self.bbox_weights, SCALE_CLAMP, self._image_hw(image_sizes, dev),
                                         ints_out=ints[N:])
-        dboxes = torch.empty(N, post, 4, device=dev); dscores = torch.empty(N, post, device=dev)
+        spec = SPECULATE if self.training else None
+        if spec is not None:                                             # rows beyond an image's count stay zero boxes (see Speculation)
+            dboxes = torch.zeros(N, post, 4, device=dev); dscores = torch.zeros(N, post, device=dev)
+        else:
+            dboxes = torch.empty(N, post, 4, device=dev); dscores = torch.empty(N, post, device=dev)
         scratch = torch.empty(2, post, device=dev, dtype=torch.int32)
         for n, (h, w) in enumerate(image_sizes):
             ops.detect_postprocess(sc[n], bx[n], int(h), int(w), -3.0e38, self.nms_thresh, post,
                                    out=(ints[n:n + 1], dboxes[n], dscores[n], scratch[0], scratch[1]))
-        host = ints.tolist()
+        if spec is not None:
+            host = [post] * N + [-1] * N                                 # every image at the cap, everything finite (sw_rpn_select_pack
+            spec.expect(ints, host)                                      # leaves the flag at 0xFFFFFFFF): checked by spec.holds()
+        else:
+            host = ints.tolist()
         out = []
         for n, (h, w) in enumerate(image_sizes):
             k, fin = host[n], host[N + n]
@@ -1319,7 +1387,11 @@ class StandardROIHeadsPseudoLab(nn.Module):
         # not 300).  Only the kernel knows n_pos, so its count is read (one host read per call; the rows beyond it are class -1 / empty
         # boxes, never stale memory).  Without ground truth every candidate is background: the count is min(B, candidates), no read.
         need = [i for i in range(N) if counts[i] > 0]
-        got = cnt.tolist() if need else None
+        if SPECULATE is not None and self.training and all(len(p) >= B for p in proposals):
+            got = [B] * N                                                # full batches (padded rows: class -1, zero boxes): checked later
+            SPECULATE.expect(cnt, got)
+        else:
+            got = cnt.tolist() if need else None
         out = []
         for i, p in enumerate(proposals):
             n = int(got[i]) if got is not None else min(B, len(p))
@@ -1377,8 +1449,15 @@ class StandardROIHeadsPseudoLab(nn.Module):
                 ops.oicr_predict(lg[off:off + n], n, K, 1, 0, 5 * K + 1, p.proposal_boxes.tensor.float().contiguous(), bp.bbox_weights,
                                  SCALE_CLAMP, sc, bx)
                 cnt, b, s, c, _ = ops.detect_postprocess(sc, bx, int(h), int(w), bp.test_score_thresh, bp.test_nms_thresh, bp.test_topk_per_image)
-                k = int(cnt.item())
-                r.pred_boxes = Boxes(b[:k].clone()); r.scores = s[:k].clone(); r.pred_classes = c[:k].to(torch.int64)
+                if SPECULATE is not None and self.training:
+                    # the teacher's weak pass inside a speculative iteration: all topk rows, the ones beyond the count with score 0 /
+                    # zero box / class 0 (ops.detect_postprocess zero-fills) — the only consumer is the pseudo-label threshold
+                    # (score > thres >= 0: semisup.threshold_bbox), which compacts on the device; no count is read here
+                    r.pred_boxes = Boxes(b); r.scores = s; r.pred_classes = c.to(torch.int64)
+                    r._sw_count = cnt
+                else:
+                    k = int(cnt.item())
+                    r.pred_boxes = Boxes(b[:k].clone()); r.scores = s[:k].clone(); r.pred_classes = c[:k].to(torch.int64)
             else:
                 r.pred_boxes = Boxes(torch.zeros(0, 4, device=lg.device)); r.scores = torch.zeros(0, device=lg.device)
                 r.pred_classes = torch.zeros(0, dtype=torch.int64, device=lg.device)
@@ -1422,6 +1501,7 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
         self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
         self.compute_dtype = compute_dtype
         self.sampler = sampler
+        self.graph_nograd_backbone = False                       # _features
 
     @staticmethod
     def _cfg_kwargs(M, T):
@@ -1495,14 +1575,20 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
         ResNet-50 + FPN are shape-static and leave no autograd state: the second time an input shape is seen they are captured, from
         then on ONE hipGraph replay into the graph's own buffers (valid until the next call with this shape; every consumer runs on
         the same stream before that).  The staged weights live in persistent buffers the stage plan rewrites in place (WeightStage), so
-        a replay reads the current teacher.  OPT-IN (SW_S3_BACKBONE_GRAPH=1): bit-equal to plain launches
-        (test_teacher_on_a_side_stream_and_its_backbone_as_a_graph_give_the_same_step), but the semi-supervised iteration measured
-        15.7-16.1 ms with it and 15.8-16.0 without — the teacher's backbone is a GPU-bound stretch (2.8 ms of kernels for ~1 ms of
-        issue time); what the iteration loses is the run-ahead at its seven count read-backs (semisup.SemiSupStep), which this does
-        not touch.  It holds one activation set per input shape, so it stays off unless asked for."""
-        if (torch.is_grad_enabled() or not x4.is_cuda or ops.TIMER is not None or os.environ.get("SW_S3_BACKBONE_GRAPH", "0") != "1"
-                or torch.cuda.is_current_stream_capturing()):
+        a replay reads the current teacher.  Off unless `graph_nograd_backbone` is set (semisup.SemiSupStep sets it on its teacher when
+        it speculates; SW_S3_BACKBONE_GRAPH=0/1 overrides): bit-equal to plain launches
+        (test_teacher_on_a_side_stream_and_its_backbone_as_a_graph_give_the_same_step); it holds one activation set per input shape.
+        Alone it gained nothing (15.7-16.1 vs 15.8-16.0 ms: the iteration waited at its count read-backs, not for launches) — see
+        semisup.SemiSupStep for what it does once those are gone."""
+        env = os.environ.get("SW_S3_BACKBONE_GRAPH")
+        on = self.graph_nograd_backbone if env is None else env == "1"
+        if torch.is_grad_enabled() or not on or not x4.is_cuda or ops.TIMER is not None or torch.cuda.is_current_stream_capturing():
             return self.backbone(x4)
+        # What the backbone reads besides the input and the staged weights (refresh_staged_weights, done by the caller) must be brought
+        # up to date HERE, outside the graph, into buffers that never move: the stem's FrozenBN fold is cached per buffer epoch — a
+        # capture made while the cache was warm holds no launch that recomputes it (found by a replay that followed two calls inside
+        # one EMA epoch: stale fold, 2 % off in the pseudo losses; tools/diag/s3_graph_debug.py)
+        self.backbone.bottom_up.stem.conv1.norm.fold()
         cache = self.__dict__.setdefault("_bb_graphs", OrderedDict())
         key = (tuple(x4.shape), x4.dtype, x4.device.index)
         hit = cache.get(key)

@@ -14,6 +14,7 @@ from typing import Dict, Optional
 
 import weakref
 
+import copy
 import os
 import torch
 
@@ -34,9 +35,9 @@ def _storage_ptrs(m):
     tools/diag/stage3_host_profile.py), and a module ADDED to a model between two EMA updates is not something training does."""
     mods = _MODULE_LISTS.get(m)
     if mods is None:
-        mods = _MODULE_LISTS[m] = list(m.modules())
+        mods = _MODULE_LISTS[m] = [x for x in m.modules() if x is not m]          # (not the key itself: the entry must die with the model)
     out = []
-    for mod in mods:
+    for mod in [m] + mods:
         for t in mod._parameters.values():
             if t is not None:
                 out.append(t.data_ptr())
@@ -94,6 +95,10 @@ def threshold_bbox(data_inst: Optional[dict], proposals: Instances, thres: float
         n = int(cnt.item())
         out.gt_boxes = Boxes(b[:n]); out.objectness_logits = sc[:n]
     elif proposal_type == "roih":
+        pad_cnt = getattr(proposals, "_sw_count", None)
+        if pad_cnt is not None and thres < 0:
+            # padded detections of a speculative iteration (frcnn: rows beyond the count have score 0): a negative threshold would keep them
+            proposals = proposals[:int(pad_cnt.item())]
         allowed = None
         if has_multi_label:
             allowed = torch.as_tensor(data_inst["multi_label"], dtype=torch.int32).to(proposals.scores.device)
@@ -220,7 +225,7 @@ class SemiSupStep:
 
     def __init__(self, model, model_teacher, optimizer, *, burn_up_step, teacher_update_iter=1, ema_keep_rate=0.9996,
                  bbox_threshold=0.7, unsup_loss_weight=4.0, burn_up_with_strong_aug=True, has_multi_label=False, fuse_grad_sums=True,
-                 lockstep=True, overlap_teacher=False):
+                 lockstep=True, overlap_teacher=None, speculate=True):
         self.model, self.model_teacher, self.optimizer = model, model_teacher, optimizer
         self.fuse_grad_sums = fuse_grad_sums          # ops.grad_scope around backward (False: autograd sums the two passes' weight gradients)
         core = getattr(model, "module", model)                                 # (DistributedDataParallel wraps the student)
@@ -228,33 +233,84 @@ class SemiSupStep:
         self.burn_up_step, self.teacher_update_iter, self.ema_keep_rate = burn_up_step, teacher_update_iter, ema_keep_rate
         self.bbox_threshold, self.unsup_loss_weight = bbox_threshold, unsup_loss_weight
         self.burn_up_with_strong_aug, self.has_multi_label = burn_up_with_strong_aug, has_multi_label
-        # the teacher's pass on a second stream, beside the student's backbones and labelled-batch heads (lockstep form only: that is
-        # the call that can take the pseudo labels late).  OFF by default: measured 16.0-16.9 ms against 15.7-16.3 ms without it (three
-        # runs each, one box) — the iteration is bound by the issuing threads (11 ms of CPU time in the forward thread alone, seven
-        # count read-backs), not by GPU occupancy, so running kernels side by side gains nothing yet.  SW_S3_TEACHER_STREAM=1 turns it on.
-        self.overlap_teacher = (bool(overlap_teacher) or os.environ.get("SW_S3_TEACHER_STREAM", "0") == "1") and self.lockstep
+        # speculate: the iteration's count read-backs are assumed and confirmed once (run_step; frcnn.Speculation).  SW_S3_SPECULATE=0
+        # turns it off.  With the reads gone the GPU side decides the iteration, so the teacher's pass goes on a second stream beside the
+        # student's backbones and labelled-batch heads (lockstep form only: that is the call that can take the pseudo labels late) and
+        # its backbone replays as a hipGraph — each measured WITHOUT gain while the reads were in (16.0-16.9 vs 15.7-16.3 ms: the
+        # issuing thread kept waiting at them), together 16.0 -> 13.1 ms once they were stubbed out.  overlap_teacher=None follows
+        # `speculate`; SW_S3_TEACHER_STREAM=0/1 and SW_S3_BACKBONE_GRAPH=0/1 override.
+        self.speculate = bool(speculate) and os.environ.get("SW_S3_SPECULATE", "1") != "0"
+        self.spec_misses, self._spec_pause = 0, 0
+        ov = self.speculate if overlap_teacher is None else bool(overlap_teacher)
+        env = os.environ.get("SW_S3_TEACHER_STREAM")
+        self.overlap_teacher = (ov if env is None else env == "1") and self.lockstep
+        tcore = getattr(model_teacher, "module", model_teacher)
+        if self.speculate and hasattr(tcore, "graph_nograd_backbone"):
+            tcore.graph_nograd_backbone = True
         self._side = None
         self.iter = 0
 
+    # ------------------------------------------------------------------ one iteration
+    def _samplers(self):
+        core = getattr(self.model, "module", self.model)
+        seen, out = set(), []
+        for holder in (core, getattr(core, "proposal_generator", None), getattr(core, "roi_heads", None)):
+            sp = getattr(holder, "sampler", None)
+            if sp is not None and id(sp) not in seen:
+                seen.add(id(sp)); out.append(sp)
+        return out
+
     def run_step(self, data):
+        """One iteration.  With `speculate` (default on a GPU) the forward / backward runs inside a frcnn.Speculation ledger — the
+        count read-backs of the training path are assumed, not read — and ONE read before the optimizer step confirms them; a wrong
+        assumption (an image whose NMS left fewer proposals than the cap, a sampler that could not fill its batch, a non-finite RPN
+        output) discards the attempt, rewinds the label samplers and repeats the iteration with the reading code, which also raises
+        what the reference raises.  After a miss the next 20 iterations do not speculate."""
+        self._ema_update()
+        dev = next(self.model_teacher.parameters()).device
+        if self.speculate and dev.type == "cuda" and self._spec_pause == 0:
+            from .frcnn import Speculation
+            snaps = [(sp, copy.deepcopy(sp.__dict__)) for sp in self._samplers()]
+            with Speculation() as ledger:
+                out = self._attempt(data)
+            if ledger.holds():
+                self.optimizer.step()
+                self.iter += 1
+                return out
+            self.spec_misses += 1
+            self._spec_pause = 20
+            for sp, snap in snaps:
+                sp.__dict__.clear(); sp.__dict__.update(snap)
+        elif self._spec_pause > 0:
+            self._spec_pause -= 1
+        out = self._attempt(data)
+        self.optimizer.step()
+        self.iter += 1
+        return out
+
+    def _attempt(self, data):
         if self.fuse_grad_sums:
             # the student's two passes share every weight: inside the scope their gradients are summed in the kernels, and the uses of
             # a 3x3 weight counted during the forward passes run as one grouped launch (ops.grad_scope)
             with ops.grad_scope():
-                return self._step(data)
-        return self._step(data)
+                return self._forward_backward(data)
+        return self._forward_backward(data)
 
-    def _step(self, data):
+    def _ema_update(self):
+        if self.iter < self.burn_up_step:
+            return
+        if self.iter == self.burn_up_step and self.burn_up_step > 0:
+            update_teacher_model(self.model, self.model_teacher, keep_rate=0.00)
+        elif (self.iter - self.burn_up_step) % self.teacher_update_iter == 0:
+            update_teacher_model(self.model, self.model_teacher, keep_rate=self.ema_keep_rate)
+
+    def _forward_backward(self, data):
         label_q, label_k, unlabel_q, unlabel_k = data
         if self.iter < self.burn_up_step:
             batch = list(label_q) + list(label_k) if self.burn_up_with_strong_aug else label_k
             record, _, _, _ = self.model(batch, branch="supervised")
             loss_dict = {k: v * 1 for k, v in record.items() if k[:4] == "loss"}
         else:
-            if self.iter == self.burn_up_step and self.burn_up_step > 0:
-                update_teacher_model(self.model, self.model_teacher, keep_rate=0.00)
-            elif (self.iter - self.burn_up_step) % self.teacher_update_iter == 0:
-                update_teacher_model(self.model, self.model_teacher, keep_rate=self.ema_keep_rate)
             record = {}
 
             def teacher_pass():
@@ -263,7 +319,8 @@ class SemiSupStep:
                 return props_rpn, props_roih
 
             def pseudo_labels(props_rpn, props_roih):
-                process_pseudo_label(unlabel_k, props_rpn, self.bbox_threshold, "rpn")             # :490-494 (joint dict, unused after)
+                # (trainer.py:490-494 also thresholds the RPN's proposals into `joint_proposal_dict["proposals_pseudo_rpn"]`, which
+                # nothing reads afterwards: not computed — it cost two launches and a count read-back per iteration)
                 pseudo_roih, _ = process_pseudo_label(unlabel_k, props_roih, self.bbox_threshold, "roih",
                                                       has_multi_label=self.has_multi_label)
                 for d in list(unlabel_q) + list(unlabel_k):                                           # remove_label
@@ -313,6 +370,4 @@ class SemiSupStep:
         losses.backward()
         if ops.GRAD_SCOPE is not None:
             ops.GRAD_SCOPE.finish()                   # a queued weight gradient that never ran must not reach the optimizer
-        self.optimizer.step()
-        self.iter += 1
         return record, loss_dict

@@ -886,8 +886,8 @@ def test_teacher_on_a_side_stream_and_its_backbone_as_a_graph_give_the_same_step
         student.proposal_generator.sampler = student.roi_heads.sampler = student.sampler
         opt = HipSGD([p for p in student.parameters() if p.requires_grad], 0.0, momentum=0.9)
         step = SemiSupStep(student, teacher, opt, burn_up_step=0, bbox_threshold=0.0, unsup_loss_weight=2.0, ema_keep_rate=0.5,
-                           overlap_teacher=overlap)
-        assert step.overlap_teacher == overlap
+                           overlap_teacher=overlap, speculate=False)
+        assert step.overlap_teacher == overlap and not step.speculate
         recs = []
         for it in range(3):
             record, _ = step.run_step((batch(f"s3o{it}_lq", [(96, 128)], 2), batch(f"s3o{it}_lk", [(128, 112)], 3),
@@ -905,6 +905,73 @@ def test_teacher_on_a_side_stream_and_its_backbone_as_a_graph_give_the_same_step
                 assert res[variant][0][it][k] == v, (variant, it, k, res[variant][0][it][k], v)
         assert all(torch.equal(a, base[1][n]) for n, a in res[variant][1].items())
     assert base[0][0] != base[0][1] != base[0][2]                                     # the teacher did move between the iterations
+
+
+@pytest.mark.parametrize("caps_reached", [True, False])
+def test_speculative_iteration_equals_the_reading_one(caps_reached):
+    """SemiSupStep(speculate=True): the count read-backs of the training path (proposals left by the RPN's NMS + finite flags, rows the
+    ROI sampler filled, the teacher's detection count) are assumed to sit at their caps and confirmed by ONE read before the optimizer
+    step (frcnn.Speculation).  caps_reached: caps set so that these small images reach them (NMS cap 100, ROI batch 16) — no miss, the
+    padded rows (zero boxes / class -1 / score 0) never show; not reached (the default caps 1000 / 512 on a 160x96 image): every
+    speculative attempt is discarded, the samplers are rewound and the iteration repeated by the reading code, then 20 iterations
+    without speculation.  Either way, against a run that never speculates (fp32, teacher on the main stream in both): three
+    iterations at learning rate 0 with a teacher that starts away from the student and moves every iteration (EMA 0.5) give EQUAL
+    losses in every iteration and an equal teacher; one iteration at learning rate 1e-4 leaves the student's parameters within 1e-5
+    (the ROIAlign backward's float atomics are the run-to-run noise of the gradients; a free-running second iteration would amplify
+    it through the pseudo labels)."""
+    from sos_wsod_amd.semisup import SemiSupStep
+    from sos_wsod_amd.solver import HipSGD
+    from sos_wsod_amd.structures import Boxes, Instances
+    K = 20
+    P, PT = FO.make_params(K, tag="s3l", head_scale=14.0), FO.make_params(K, tag="s3o_teacher", head_scale=14.0)
+
+    def batch(tag, sizes, n_gt):
+        out = []
+        for i, (h, w) in enumerate(sizes):
+            d = {"image": torch.from_numpy(FO.make_image(h, w, f"{tag}{i}")).cuda(), "height": h, "width": w}
+            if n_gt:
+                b, c = FO.make_gt(h, w, n_gt, K, f"{tag}{i}")
+                inst = Instances((h, w)); inst.gt_boxes = Boxes(torch.from_numpy(b).cuda()); inst.gt_classes = torch.from_numpy(c).cuda()
+                d["instances"] = inst
+            out.append(d)
+        return out
+    res = {}
+    for spec in (True, False):
+        for lr, n_it in ((0.0, 3), (1e-4, 1)):
+            student, teacher = _model(K, P, "s3l"), _model(K, PT, "s3l")
+            student.train(); teacher.train()
+            student.proposal_generator.sampler = student.roi_heads.sampler = student.sampler
+            if caps_reached:
+                for m in (student, teacher):
+                    m.proposal_generator.post_nms_topk = (100, 100)
+                    m.roi_heads.batch_size_per_image = 16
+            opt = HipSGD([p for p in student.parameters() if p.requires_grad], lr, momentum=0.9)
+            step = SemiSupStep(student, teacher, opt, burn_up_step=0, bbox_threshold=0.0, unsup_loss_weight=2.0, ema_keep_rate=0.5,
+                               overlap_teacher=False, speculate=spec)
+            assert step.speculate == spec
+            recs = []
+            for it in range(n_it):
+                record, _ = step.run_step((batch(f"s3o{it}_lq", [(96, 128)], 2), batch(f"s3o{it}_lk", [(128, 112)], 3),
+                                           batch(f"s3o{it}_uq", [(160, 96)], 0), batch(f"s3o{it}_uk", [(160, 96)], 0)))
+                recs.append({k: float(v) for k, v in record.items() if k.startswith("loss")})
+            torch.cuda.synchronize()
+            if spec:
+                assert step.spec_misses == (0 if caps_reached else 1), step.spec_misses  # (after a miss: 20 iterations of the reading code)
+            res[(spec, lr)] = (recs, {n: p.detach().clone() for n, p in student.named_parameters()},
+                               {n: p.detach().clone() for n, p in teacher.named_parameters()})
+    a, b = res[(True, 0.0)], res[(False, 0.0)]
+    for it in range(3):
+        assert len(a[0][it]) == 8
+        for k, v in b[0][it].items():
+            assert a[0][it][k] == v, (it, k, a[0][it][k], v)
+    assert a[0][0] != a[0][1] != a[0][2] and all(torch.equal(t, b[2][n]) for n, t in a[2].items())
+    a, b = res[(True, 1e-4)], res[(False, 1e-4)]
+    for k, v in b[0][0].items():
+        assert a[0][0][k] == v, (k, a[0][0][k], v)
+    worst = max(float((t - b[1][n]).abs().max() / (b[1][n].abs().max() + 1e-30)) for n, t in a[1].items())
+    assert worst <= 1e-5, worst
+    assert any(not torch.equal(t, torch.from_numpy(P[n]).cuda()) for n, t in a[1].items() if n in P)             # the step did move the student
+    print(f"speculative vs reading iteration (caps reached: {caps_reached}): worst parameter difference after a step {worst:.1e}")
 
 
 def test_detector_trains_the_same_under_hipsgd_and_torch_sgd(golden_dir):

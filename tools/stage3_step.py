@@ -54,12 +54,13 @@ def time_step(dtype, H=800, W=1216, dev=None, warm=3, n=8):
         rec, _ = step.run_step(batches[warm + i])
     c1 = time.thread_time()
     torch.cuda.synchronize()
-    global HOST_MS
+    global HOST_MS, MISSES
     HOST_MS = (c1 - c0) / n * 1e3            # CPU time of the issuing thread per iteration (close to the wall time = host bound)
+    MISSES = getattr(step, "spec_misses", None)
     return (time.perf_counter() - t0) / n * 1e3, rec
 
 
-HOST_MS = None
+HOST_MS = MISSES = None
 
 
 if __name__ == "__main__":
@@ -68,4 +69,4 @@ if __name__ == "__main__":
     ms, rec = time_step(dtype, H, W, n=int(os.environ.get("ITERS", 8)))
     print(f"stage-3 semi-sup step {dtype} {H}x{W}: {ms:.1f} ms per iteration per GPU (4 views: teacher fwd 1, student fwd+bwd 3), "
           f"losses finite: {all(bool(torch.isfinite(v)) for k, v in rec.items() if k.startswith('loss'))}, "
-          f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; issuing thread's CPU time {HOST_MS:.1f} ms per iteration")
+          f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; issuing thread's CPU time {HOST_MS:.1f} ms per iteration; speculation misses {MISSES}")
