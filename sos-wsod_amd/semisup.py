@@ -336,7 +336,7 @@ class SemiSupStep:
                 # labelled batch's RPN / ROI heads are queued.  The thresholding's count read-backs wait for the SIDE stream only.
                 main = torch.cuda.current_stream(dev)
                 if self._side is None:
-                    self._side = torch.cuda.Stream(device=dev)
+                    self._side = torch.cuda.Stream(device=dev, priority=-1)      # the pseudo labels are waited for: teacher kernels first
                 side = self._side
                 side.wait_stream(main)                               # the EMA update above wrote the teacher's weights on `main`
                 with torch.cuda.stream(side):
@@ -367,6 +367,9 @@ class SemiSupStep:
             loss_dict = weight_losses(record, self.unsup_loss_weight)
         losses = sum(loss_dict.values())
         self.optimizer.zero_grad()
+        from . import frcnn as _fr
+        if _fr.SPECULATE is not None:
+            _fr.SPECULATE.seal()                      # the forward is queued: compare its counts beside the backward (frcnn.Speculation.seal)
         losses.backward()
         if ops.GRAD_SCOPE is not None:
             ops.GRAD_SCOPE.finish()                   # a queued weight gradient that never ran must not reach the optimizer
