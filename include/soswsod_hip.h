@@ -337,6 +337,14 @@ int sw_transpose_2d(int dtype, int rows, int cols, const void* src, long ld_src,
  * teacher / student / numel are HOST arrays (of device pointers / element counts). */
 int sw_ema_multi(int n_tensors, float* const* teacher, const float* const* student, const long* numel, double keep_rate,
                  sw_stream_t stream);
+/* Weighted sum of n <= 32 scalar losses living anywhere on the device (unbias/ubteacher/engine/trainer.py:520-540: every loss of the
+ * record times its weight — 0 for the two pseudo box-regression losses, UNSUP_LOSS_WEIGHT for the other pseudo losses, 1 otherwise —
+ * then `sum(loss_dict.values())`): out[i] = values[i][0] * weights[i], out[n] = ((out[0] + out[1]) + out[2]) + ... in that order
+ * (the f32 additions of Python's sum over the dict).  values / weights: host arrays.  sw_scale_scalars is its backward:
+ * out[i] = g[0] * weights[i].  One launch each instead of 2 n (+ n backward) framework launches per iteration. */
+int sw_weighted_sum(int n, const float* const* values, const float* weights, float* out, sw_stream_t stream);
+int sw_scale_scalars(int n, const float* g, const float* weights, float* out, sw_stream_t stream);
+
 /* sw_threshold_select: pseudo-label thresholding (threshold_bbox :361-400): keeps detection i iff scores[i] > thres (and, when
  * allowed_classes != NULL, classes[i] is one of the n_allowed image-level labels: the "multi_label" filter), compacted in input
  * order.  out_count[1]; out_boxes [n][4], out_classes [n] (optional: the "rpn" branch has none), out_scores [n], out_index [n]

@@ -195,6 +195,8 @@ SIGNATURES = {
     "sw_ema_multi": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_long), ctypes.c_double, c_void_p]),
     "sw_threshold_select": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
+    "sw_weighted_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sw_scale_scalars": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_counter_add": (c_int, [c_void_p, c_u64, c_void_p]),
     "sw_focal_loss": (c_int, [c_int, c_int, c_void_p, c_long, c_void_p, c_float, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_copy_multi": (c_int, [c_int, ctypes.POINTER(CopyDesc), c_void_p]),

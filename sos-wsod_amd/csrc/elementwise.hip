@@ -1494,6 +1494,48 @@ extern "C" int sw_ema_multi(int n_tensors, float* const* teacher, const float* c
   return 0;
 }
 
+// ---- weighted sum of scalar losses (and its backward): one launch each instead of n multiplications + n additions
+namespace {
+constexpr int WS_MAX = 32;
+struct ScalarList { const float* p[WS_MAX]; float w[WS_MAX]; int n; };
+__global__ void weighted_sum_kernel(ScalarList a, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < a.n; ++i) {                                   // ((0 + w0 v0) + w1 v1) + ...: Python's sum() over the weighted dict
+    const float v = __fmul_rn(*a.p[i], a.w[i]);
+    out[i] = v;
+    s = i == 0 ? v : __fadd_rn(s, v);
+  }
+  out[a.n] = s;
+}
+__global__ void scale_scalars_kernel(ScalarList a, const float* __restrict__ g, float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (blockIdx.x == 0 && i < a.n) out[i] = __fmul_rn(g[0], a.w[i]);
+}
+}  // namespace
+
+extern "C" int sw_weighted_sum(int n, const float* const* values, const float* weights, float* out, hipStream_t stream) {
+  SW_ENTER();
+  if (n < 1 || n > WS_MAX) return -5;
+  ScalarList a = {};
+  a.n = n;
+  for (int i = 0; i < n; ++i) { a.p[i] = values[i]; a.w[i] = weights[i]; }
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, stream, a, out);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_scale_scalars(int n, const float* g, const float* weights, float* out, hipStream_t stream) {
+  SW_ENTER();
+  if (n < 1 || n > WS_MAX) return -5;
+  ScalarList a = {};
+  a.n = n;
+  for (int i = 0; i < n; ++i) a.w[i] = weights[i];
+  hipLaunchKernelGGL(scale_scalars_kernel, dim3(1), dim3(64), 0, stream, a, g, out);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sw_threshold_select(int n, const float* scores, const int32_t* classes, const float* boxes, float thres,
                                    const int32_t* allowed_classes, int n_allowed, int32_t* out_count, float* out_boxes,
                                    int32_t* out_classes, float* out_scores, int32_t* out_index, hipStream_t stream) {

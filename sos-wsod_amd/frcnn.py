@@ -591,9 +591,15 @@ class _Conv3x3LevelsFn(ops.CountedFunction):
         relu = bool(flags & _RELU)
         cd = xs[0].dtype
         outs, probs = [], []
+        global _LEVELS_CAT
+        cat, _LEVELS_CAT = _LEVELS_CAT, None          # (rows, cout) buffer the caller wants the L outputs in, maps back to back (RPN head)
+        r0 = 0
         for x, sw, bv, w in zip(xs, sws, bvs, ws):
             n, H, W, _ = x.shape
-            out = torch.empty(n, H, W, w.shape[0], device=x.device, dtype=cd)
+            if cat is not None:
+                out = cat[r0:r0 + n * H * W].view(n, H, W, w.shape[0]); r0 += n * H * W
+            else:
+                out = torch.empty(n, H, W, w.shape[0], device=x.device, dtype=cd)
             probs.append((x, sw, out, ops.make_epilogue(bias=bv, relu=relu, out_dtype=cd)))
             outs.append(out)
         ops.conv3x3_multi(probs)
@@ -637,10 +643,16 @@ class _Conv3x3LevelsFn(ops.CountedFunction):
         return (None, None) + tuple(dxs) + (None,) * (3 * L) + tuple(dws) + tuple(dbs)
 
 
-def _conv3x3_levels(convs, xs, relu=False):
-    """the 3x3 `Conv` modules `convs[i]` applied to `xs[i]` (convs may repeat one module: a layer shared by the levels)"""
+_LEVELS_CAT = None
+
+
+def _conv3x3_levels(convs, xs, relu=False, cat=None):
+    """the 3x3 `Conv` modules `convs[i]` applied to `xs[i]` (convs may repeat one module: a layer shared by the levels).  cat: a
+    (sum of the maps' pixels, cout) buffer — the outputs are then row blocks of it, written there by the convolution itself"""
+    global _LEVELS_CAT
     L = len(xs)
     sts = [_staged_of(c) for c in convs]
+    _LEVELS_CAT = cat
     return _Conv3x3LevelsFn.apply(L, relu, *xs, *[st.w for st in sts], *[st.wd for st in sts], *[c.bias.detach() for c in convs],
                                   *[c.weight for c in convs], *[c.bias for c in convs])
 
@@ -921,12 +933,19 @@ class BasicStem(nn.Module):
         super().__init__()
         self.conv1 = ConvBN(3, 64, 7, 2)
 
-    def forward(self, x4):                                          # (N, H, W, 4) normalised + padded -> (N, H/4, W/4, 64)
+    @staticmethod
+    def out_hw(H, W):
+        h2, w2 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        return (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+
+    def forward(self, x4, out=None):                                # (N, H, W, 4) normalised + padded -> (N, H/4, W/4, 64) [written to `out`]
         n, H, W, _ = x4.shape
         scale, shift = self.conv1.norm.fold()
         y = ops.stem_conv7x7(x4, self.conv1.weight.detach().contiguous(), scale.contiguous(), shift.contiguous(),
                              torch.empty(n, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, device=x4.device, dtype=x4.dtype))
-        return ops.maxpool3x3s2(y, torch.empty(n, (y.shape[1] - 1) // 2 + 1, (y.shape[2] - 1) // 2 + 1, 64, device=y.device, dtype=y.dtype))
+        if out is None:
+            out = torch.empty(n, (y.shape[1] - 1) // 2 + 1, (y.shape[2] - 1) // 2 + 1, 64, device=y.device, dtype=y.dtype)
+        return ops.maxpool3x3s2(y, out)
 
 
 class ResNet(nn.Module):
@@ -966,28 +985,23 @@ class ResNet(nn.Module):
         return feats
 
     def forward_lockstep(self, x4s):
-        """several independent batches (different padded sizes allowed) through the trainable stages IN LOCKSTEP: after the frozen
-        stem + res2 of every batch, the batches' rows sit back to back in one matrix, every 1x1 convolution of res3..res5 is ONE GEMM
-        over all rows and every 3x3 convolution one multi-problem launch over the batches' maps (_BottleneckFn with several maps).
+        """several independent batches (different padded sizes allowed) through the residual stages IN LOCKSTEP: after the stem of
+        every batch, the batches' rows sit back to back in one matrix, every 1x1 convolution of res2..res5 is ONE GEMM over all rows
+        and every 3x3 convolution one multi-problem launch over the batches' maps (_BottleneckFn with several maps).
         Rows are independent in every layer, so each image's features are what forward() gives for its own batch.
         -> one feature dict per batch.  Needs the fused block form and freeze_at == 2; anything else runs the batches one by one."""
         if not (FUSED_BLOCKS and self.freeze_at == 2 and len(x4s) > 1):
             return [self.forward(x) for x in x4s]
         feats = [{} for _ in x4s]
-        res2 = []
+        # the stems' max-pools write their outputs back to back into ONE matrix: from there on — res2 included (round 5; it ran per batch
+        # and its outputs were then copied together: 93 MB, 123 us) — every block is one pass over all batches' rows
+        maps = [(int(x4.shape[0]),) + self.stem.out_hw(int(x4.shape[1]), int(x4.shape[2])) for x4 in x4s]
+        joint = torch.empty(sum(n * H * W for n, H, W in maps), 64, device=x4s[0].device, dtype=x4s[0].dtype)
+        r0 = 0
         with torch.no_grad():
-            for f, x4 in zip(feats, x4s):
-                x = getattr(self, self.stage_names[0])(self.stem(x4))
-                f[self.stage_names[0]] = x
-                res2.append(x)
-        C = res2[0].shape[3]
-        maps = [tuple(x.shape[:3]) for x in res2]
-        joint = torch.empty(sum(n * H * W for n, H, W in maps), C, device=res2[0].device, dtype=res2[0].dtype)
-        r0, pairs = 0, []
-        for x, (n, H, W) in zip(res2, maps):
-            pairs.append((x.reshape(n * H * W, C), joint[r0:r0 + n * H * W])); r0 += n * H * W
-        ops.copy_multi(pairs)
-        for name in self.stage_names[1:]:
+            for x4, (n, H, W) in zip(x4s, maps):
+                self.stem(x4, out=joint[r0:r0 + n * H * W].view(n, H, W, 64)); r0 += n * H * W
+        for name in self.stage_names:
             for blk in getattr(self, name):
                 ws = (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight) + (() if blk.shortcut is None else (blk.shortcut.weight,))
                 joint = _BottleneckFn.apply(joint, (blk, maps), *ws)
@@ -1046,12 +1060,13 @@ class StandardRPNHead(nn.Module):
         A = self.A
         st = _staged_of(self)
         # (each conv output is read by the packed 1x1 GEMM only: that GEMM's data gradient leaves masked by the conv's ReLU)
-        ts = _conv3x3_levels([self.conv] * len(feats), [f.contiguous() for f in feats], relu=_RELU | _GRAD_PREMASKED)
-        C = ts[0].shape[3]
-        N = ts[0].shape[0]
-        hw = [t.shape[1] * t.shape[2] for t in ts]
+        # the five conv outputs ARE the row blocks of the GEMM's operand: the convolution writes them there (the copy that packed them
+        # was 34 + 84 + 34 us per iteration)
+        N, C = feats[0].shape[0], self.conv.weight.shape[0]
+        hw = [f.shape[1] * f.shape[2] for f in feats]
         rows = sum(N * v for v in hw)
-        x = torch.empty(rows, C, device=ts[0].device, dtype=ts[0].dtype)
+        x = torch.empty(rows, C, device=feats[0].device, dtype=feats[0].dtype)
+        ts = _conv3x3_levels([self.conv] * len(feats), [f.contiguous() for f in feats], relu=_RELU | _GRAD_PREMASKED, cat=x)
         y = _LinearFn.apply(_CatRowsFn.apply(x, *[t.reshape(N * v, C) for t, v in zip(ts, hw)]), st.w, st.bias, None, _MASK_INPUT_GRAD, True,
                             (A, 4 * A), None, self.objectness_logits.weight, self.anchor_deltas.weight, self.objectness_logits.bias,
                             self.anchor_deltas.bias)
@@ -1065,9 +1080,12 @@ class _CatRowsFn(torch.autograd.Function):
     def forward(ctx, buf, *parts):
         r0, pairs = 0, []
         for p in parts:
-            pairs.append((p.contiguous(), buf[r0:r0 + p.shape[0]]))
+            dst = buf[r0:r0 + p.shape[0]]
+            if not (p.is_contiguous() and p.data_ptr() == dst.data_ptr() and p.shape == dst.shape):      # (already written in place)
+                pairs.append((p.contiguous(), dst))
             r0 += p.shape[0]
-        ops.copy_multi(pairs)
+        if pairs:
+            ops.copy_multi(pairs)
         ctx.rows = [p.shape[0] for p in parts]
         return buf
 
@@ -1174,14 +1192,18 @@ class Speculation:
         if chk is None:
             chk = _CHECK_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
         chk.wait_stream(main)
-        want = torch.tensor([v for _, vs in self.items for v in vs], dtype=torch.int32).pin_memory()
+        want_l = tuple(v for _, vs in self.items for v in vs)
+        const = _CHECK_CONST.get(dev.index)
+        if const is None or const[0] != want_l:                          # the expectation is the same list every iteration: uploaded once
+            const = _CHECK_CONST[dev.index] = (want_l, torch.tensor(want_l, dtype=torch.int32).to(dev), torch.empty(1, dtype=torch.int32).pin_memory())
+            torch.cuda.current_stream(dev).synchronize()
+        want, host = const[1], const[2]
         with torch.cuda.stream(chk):
             got = torch.cat([t for t, _ in self.items]) if len(self.items) > 1 else self.items[0][0]
-            flag = (got != want.to(dev, non_blocking=True)).any().to(torch.int32).reshape(1)
+            flag = (got != want).any().to(torch.int32).reshape(1)
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl":
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)               # (RCCL waits for `chk`, the current stream, only)
                 self._agreed = True
-            host = torch.empty(1, dtype=torch.int32).pin_memory()
             host.copy_(flag, non_blocking=True)
             ev = torch.cuda.Event(); ev.record(chk)
         main.wait_stream(chk)                                             # (the ledger's tensors are not freed under the comparison)
@@ -1214,6 +1236,7 @@ class Speculation:
 
 SPECULATE = None
 _CHECK_STREAMS = {}
+_CHECK_CONST = {}
 
 
 class PseudoLabRPN(nn.Module):

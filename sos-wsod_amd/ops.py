@@ -859,6 +859,26 @@ def ema_multi(teacher, student, keep_rate):
     EmaPlan(teacher, student).run(keep_rate)
 
 
+def weighted_sum(values, weights, out):
+    """out[i] = values[i] * weights[i] (f32 scalars anywhere on the device), out[n] = their sum in index order (sw_weighted_sum)"""
+    n = len(values)
+    _need_gpu(out, *values)
+    assert all(v.dtype == torch.float32 and v.numel() == 1 for v in values) and out.dtype == torch.float32 and out.numel() >= n + 1
+    ptrs = (ctypes.c_void_p * n)(*[v.data_ptr() for v in values])
+    ws = (ctypes.c_float * n)(*[float(w) for w in weights])
+    check(lib.sw_weighted_sum(n, ptrs, ws, _p(out), _stream()), "sw_weighted_sum")
+    return out
+
+
+def scale_scalars(g, weights, out):
+    """out[i] = g * weights[i] (sw_scale_scalars)"""
+    n = len(weights)
+    _need_gpu(g, out)
+    ws = (ctypes.c_float * n)(*[float(w) for w in weights])
+    check(lib.sw_scale_scalars(n, _p(g), ws, _p(out), _stream()), "sw_scale_scalars")
+    return out
+
+
 def threshold_select(scores, classes, boxes, thres, allowed=None):
     """-> (count[1] i32, boxes [n,4], classes [n] i32 or None, scores [n], index [n] i32): entries with score > thres (and class in
     `allowed`, an int32 device tensor, when given), compacted in input order; the first count rows are valid"""

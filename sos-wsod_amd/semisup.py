@@ -123,6 +123,47 @@ def process_pseudo_label(unlabel_data, proposals, cur_threshold, proposal_type, 
     return insts, total / max(len(proposals), 1)
 
 
+def loss_weights(record, unsup_loss_weight: float) -> Dict[str, float]:
+    """the factor weight_losses (below) multiplies each loss of the record by"""
+    out = {}
+    for key in record:
+        if key[:4] == "loss":
+            out[key] = 0.0 if key in ("loss_rpn_loc_pseudo", "loss_box_reg_pseudo") else (float(unsup_loss_weight) if key[-6:] == "pseudo" else 1.0)
+    return out
+
+
+class _WeightedSumFn(torch.autograd.Function):
+    """(total, weighted) of scalar losses in ONE launch (sw_weighted_sum; backward sw_scale_scalars): the reference's loop of
+    multiplications followed by sum(loss_dict.values()) (trainer.py:520-540) was 2 n framework launches and n more in the backward per
+    iteration, all in the stretch between the forward's last kernel and the backward's first, where nothing else keeps the GPU busy.
+    Same f32 products and the same order of additions: total and every weighted loss bit-identical."""
+
+    @staticmethod
+    def forward(ctx, weights, *vals):
+        out = torch.empty(len(vals) + 1, device=vals[0].device, dtype=torch.float32)
+        ops.weighted_sum([v.detach() for v in vals], weights, out)
+        ctx.weights = weights
+        ctx.mark_non_differentiable(out)
+        return out[len(vals)], out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_out):
+        g = torch.empty(len(ctx.weights), device=g_total.device, dtype=torch.float32)
+        ops.scale_scalars(g_total.contiguous(), ctx.weights, g)
+        return (None,) + tuple(g[i] for i in range(len(ctx.weights)))
+
+
+def weighted_total(record, weights: Dict[str, float]):
+    """-> (sum of weights[k] * record[k] in the record's key order, {k: weights[k] * record[k]} detached)"""
+    keys = [k for k in record if k in weights]
+    vals = [record[k] for k in keys]
+    if vals and all(torch.is_tensor(v) and v.is_cuda and v.dtype == torch.float32 and v.numel() == 1 for v in vals) and len(vals) <= 32:
+        total, out = _WeightedSumFn.apply(tuple(weights[k] for k in keys), *vals)
+        return total, {k: out[i] for i, k in enumerate(keys)}
+    loss_dict = {k: record[k] * weights[k] for k in keys}
+    return sum(loss_dict.values()), loss_dict
+
+
 def weight_losses(record: Dict[str, torch.Tensor], unsup_loss_weight: float) -> Dict[str, torch.Tensor]:
     """trainer.py:520-534: pseudo box-regression losses x 0, other *_pseudo losses x UNSUP_LOSS_WEIGHT, supervised x 1"""
     out = {}
@@ -309,7 +350,7 @@ class SemiSupStep:
         if self.iter < self.burn_up_step:
             batch = list(label_q) + list(label_k) if self.burn_up_with_strong_aug else label_k
             record, _, _, _ = self.model(batch, branch="supervised")
-            loss_dict = {k: v * 1 for k, v in record.items() if k[:4] == "loss"}
+            weights = {k: 1.0 for k in record if k[:4] == "loss"}
         else:
             record = {}
 
@@ -364,8 +405,8 @@ class SemiSupStep:
                 rec_unlabel, _, _, _ = self.model(unlabel_q, branch="supervised")
             record.update(rec_label)
             record.update({k + "_pseudo": v for k, v in rec_unlabel.items()})
-            loss_dict = weight_losses(record, self.unsup_loss_weight)
-        losses = sum(loss_dict.values())
+            weights = loss_weights(record, self.unsup_loss_weight)
+        losses, loss_dict = weighted_total(record, weights)
         self.optimizer.zero_grad()
         from . import frcnn as _fr
         if _fr.SPECULATE is not None:
