@@ -377,7 +377,9 @@ class SemiSupStep:
                 # labelled batch's RPN / ROI heads are queued.  The thresholding's count read-backs wait for the SIDE stream only.
                 main = torch.cuda.current_stream(dev)
                 if self._side is None:
-                    self._side = torch.cuda.Stream(device=dev, priority=-1)      # the pseudo labels are waited for: teacher kernels first
+                    # (normal priority: a high-priority stream starved — 24.8 instead of 13.0 ms per iteration — in a process whose earlier
+                    # streams had used up the four hardware queues; tools/diag/s3_in_bench.py)
+                    self._side = torch.cuda.Stream(device=dev)
                 side = self._side
                 side.wait_stream(main)                               # the EMA update above wrote the teacher's weights on `main`
                 with torch.cuda.stream(side):
