@@ -30,6 +30,14 @@ K = 20
 DAN = (4096, 4096)
 
 
+def _drop():
+    """after deleting a trainer / model of an extra run: collect NOW (a step graph in a reference cycle must not be finalized by a
+    collection that happens to run inside a later capture: ops.capture_guard), then hand the memory back"""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def make_inputs(device, seed, H=None, W=None, R=None, K=None, n_gt=2, scale2=1.0):
     """Synthetic VOC-shaped 4-view input: u8 images, proposals sorted by objectness, flipped views mirror x.
     Sizes default to the module constants (BASELINE config #2); config #4 = make_inputs(dev, s, 800, 1333, 4000, 80).
@@ -390,7 +398,7 @@ def main():
         if world == 1 and dtype == torch.bfloat16 and not args.no_fp32_line:
             # the reference's own precision (fp32 storage, exact-f32 MFMA: 1/16 of the bf16 rate), a short run for the record
             trainer = opt = model = graphs = None
-            torch.cuda.empty_cache()
+            _drop()
             m32 = build(device, torch.float32); m32.train()
             g32 = [{"params": [p], "lr": 2e-3 if n.endswith(".bias") else 1e-3, "weight_decay": 0.0 if n.endswith(".bias") else 5e-4}
                    for n, p in m32.named_parameters() if p.requires_grad]
@@ -418,7 +426,7 @@ def main():
             # the other BASELINE shapes on one GPU, for the record (not the metric): config #3's per-GPU shape = 2 images per step,
             # config #4's = 800x1333 views / 4000 proposals / 80 classes / FREEZE_AT 3.  Same trainer mode as the headline.
             trainer = opt = model = graphs = None
-            torch.cuda.empty_cache()
+            _drop()
 
             def short_run(m, data2, n=8):
                 m.train()
@@ -462,7 +470,7 @@ def main():
             aux = mp.roi_heads.last_aux
             out["peaky_pseudo_boxes_per_round"] = [int(r_["pgt_count"].reshape(-1)[0].item()) for r_ in aux["rounds"]] if aux and "rounds" in aux else None
             del tp, mp
-            torch.cuda.empty_cache()
+            _drop()
             # (2) what real data gives: two DIFFERENT scales per image (512x512 + 640x640) and no graph replay (a dataset's view sizes
             # and proposal counts rarely repeat) — eager launches
             mm = build(device, dtype); mm.train()
@@ -502,14 +510,14 @@ def main():
             out["recipe_pairs"] = {"short_sides": pairs_, "ms_per_step": per_pair, "image": "500x375 (W x H), R=2000, K=20"}
             phase("recipe-scale run")
             del tmx, mm
-            torch.cuda.empty_cache()
+            _drop()
             mb = build(device, dtype)
             ms = short_run(mb, [make_inputs(device, 300 + 2 * i) + make_inputs(device, 1300 + 2 * i) for i in range(2)])
             phase("b2 run")
             out["b2_ms_per_step"] = round(ms, 3)
             out["b2_images_per_s"] = round(8.0 / ms * 1e3, 1)
             del mb
-            torch.cuda.empty_cache()
+            _drop()
             mc = build(device, dtype, K=80, freeze_at=3)
             ms = short_run(mc, [make_inputs(device, 500 + i, H=800, W=1333, R=4000, K=80, n_gt=5) for i in range(2)], n=5)
             phase("coco run")
@@ -520,7 +528,7 @@ def main():
                                    "b2": "BASELINE configs[2] per GPU: 2 images = 8 views 512x512, R=2000, K=20",
                                    "coco": "BASELINE configs[3] per GPU: 4 views 800x1333 (99x165 maps), R=4000, K=80, FREEZE_AT 3"}
             del mc
-            torch.cuda.empty_cache()
+            _drop()
             # BASELINE configs[4] (Stage 3, Unbiased Teacher): one GPU's share of an iteration — teacher forward on 1 view, student
             # forward + backward on 3, SGD, teacher EMA — on the ResNet-50-FPN detector of sos-wsod_amd/frcnn.py
             sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
@@ -544,7 +552,7 @@ def main():
                                           "flop_per_byte": round(fl / by, 1), "mfma_tflops": round(fl / sec / 1e12, 2),
                                           "launches_per_iter": round(len(tms) / 3.0, 1), "ms_per_iter": round(sum(tms) / 3.0, 3),
                                           "gflop_per_iter": round(fl / 3.0 / 1e9, 1), "mbytes_per_iter": round(by / 3.0 / 1e6, 1)}
-            torch.cuda.empty_cache()
+            _drop()
             # The multi-GPU step on this one GPU: the same model inside Trainer's DistributedDataParallel over a real RCCL process
             # group of world size 1 (reducer, bucket views, per-bucket HipSGD update from the communication hook, launches issued
             # from Python — no step graph): what a rank pays per step at N > 1 before any bytes cross xGMI.  Best effort: the key is
@@ -586,7 +594,7 @@ def main():
                     dist.destroy_process_group()
             except Exception as ex:                                  # noqa: BLE001 — an extra, never the reason a bench run fails
                 out["ddp_rccl_world1_error"] = repr(ex)[:200]
-            torch.cuda.empty_cache()
+            _drop()
         phase("extras done; cpu baseline")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -1662,7 +1662,7 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
             static_in = torch.empty_like(x4)
             static_in.copy_(x4)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with ops.capture_guard(), torch.cuda.graph(g):
                 outs = self.backbone(static_in)
             hit = cache[key] = (g, static_in, outs)
         g, static_in, outs = hit

@@ -92,6 +92,27 @@ def param_key(p):
 GRAD_SCOPE = None      # the active grad_scope (or None)
 
 
+class capture_guard:
+    """Around a hipGraph capture: Python's cycle collector stays off.  A collection that happens to run inside the capture — it can,
+    on the autograd thread too, whenever the allocation counter says so — may finalize an older torch.cuda.CUDAGraph that was
+    waiting in a reference cycle (a deleted Trainer and its graphs), and destroying a graph while ANY stream of the process
+    captures is an error of the runtime ("operation not permitted when stream is capturing" from ~CUDAGraph: the whole process
+    dies; seen in bench.py between two of its short runs).  Collect first, then disable until the capture is over."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 class grad_scope:
     """Wrap the forward passes AND the one `backward()` call of an iteration whose graph uses parameters more than once (the Stage-3
     student: two forward passes per iteration, unbias/ubteacher/engine/trainer.py:527-538; the RPN head's convolution on five FPN

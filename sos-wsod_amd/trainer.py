@@ -512,15 +512,17 @@ class _NativeDDP:
         if hasattr(self.opt, "sync_hyper"):
             self.opt.sync_hyper()
         torch.cuda.synchronize()
+        from . import ops
         gs = [torch.cuda.CUDAGraph() for _ in range(4)]
         fns = (lambda: self._s1(static), self._s2, self._s3, self._s4)
         stream = torch.cuda.current_stream()
         try:
-            for g, fn in zip(gs, fns):
-                with torch.cuda.graph(g, pool=self.pool, stream=stream):
-                    fn()
-                if self.pool is None:
-                    self.pool = g.pool()
+            with ops.capture_guard():
+                for g, fn in zip(gs, fns):
+                    with torch.cuda.graph(g, pool=self.pool, stream=stream):
+                        fn()
+                    if self.pool is None:
+                        self.pool = g.pool()
         finally:
             self.heads._prestaged_labels = None
         loss_dict, total = self._live[0], self._live[1]
@@ -672,9 +674,10 @@ class _StepGraphs:
         static = self._clone_inputs(data)
         self.heads.stage_labels([x["instances1"] for x in data], self.labels)
         torch.cuda.synchronize()
+        from . import ops
         graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
+            with ops.capture_guard(), torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
                 loss_dict, losses = tr._forward_backward_update(static)
         finally:
             self.heads._prestaged_labels = None
