@@ -415,11 +415,11 @@ class VGG16(nn.Module):
         s0 = s0 if s0 is not None and s0[0][3] == dtype else None
         s1 = s1 if s1 is not None and s1[0][3] == dtype else None
 
-        def stamp(pk, wid=id(w)):
+        def stamp(pk, wid=id(w), cache=self._wk_cache):               # (captures the cache dict, not the module: ops.register_staging)
             for mode in (0, 1):
-                h = self._wk_cache.get((wid, mode))
+                h = cache.get((wid, mode))
                 if h is not None and h[0][3] == dtype:
-                    self._wk_cache[(wid, mode)] = ((pk, mode, h[0][2], dtype), h[1])
+                    cache[(wid, mode)] = ((pk, mode, h[0][2], dtype), h[1])
 
         ops.register_staging(w, 2, dtype, stage0=None if s0 is None else s0[1], stage1=None if s1 is None else s1[1],
                              d0=cout, d1=cin, d2=(s0[0][2] if s0 is not None else cin), stamp=stamp)

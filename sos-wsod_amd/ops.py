@@ -217,8 +217,22 @@ STAGING = {}
 
 
 def register_staging(p, kind, dtype, stage0=None, stage1=None, d0=0, d1=0, d2=0, ld0=0, ld1=0, stamp=None):
-    STAGING[id(p)] = dict(param=p, kind=kind, dtype=dtype, stage0=stage0, stage1=stage1, d0=d0, d1=d1, d2=d2, ld0=ld0,
-                          ld1=ld1, stamp=stamp)
+    """The registry must not keep a model alive: the parameter is held weakly and its entry (with the staged copies) leaves when the
+    parameter dies — a strong reference here leaked every deleted model's fc6 weight and its two bf16 copies (0.8 GB per VGG16
+    detector; bench.py builds and drops six).  `stamp` closures must not capture their module either."""
+    import weakref
+    key = id(p)
+    fresh = key not in STAGING or STAGING[key]["param"]() is not p
+    STAGING[key] = dict(param=weakref.ref(p), kind=kind, dtype=dtype, stage0=stage0, stage1=stage1, d0=d0, d1=d1, d2=d2, ld0=ld0,
+                        ld1=ld1, stamp=stamp)
+    if fresh:
+        weakref.finalize(p, _drop_staging, key)
+
+
+def _drop_staging(key):
+    ent = STAGING.get(key)
+    if ent is not None and ent["param"]() is None:             # (an id reused by a live parameter keeps its entry)
+        STAGING.pop(key, None)
 
 
 def _launch(tag, fn):

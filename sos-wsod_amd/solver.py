@@ -84,7 +84,7 @@ class HipSGD(torch.optim.Optimizer):
             if first:
                 st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
             staging = ops.STAGING.get(id(p))
-            if staging is not None and (staging["param"] is not p or not self._staging_usable(staging, p)):
+            if staging is not None and (staging["param"]() is not p or not self._staging_usable(staging, p)):
                 staging = None
             by_mom.setdefault(float(group["momentum"]), []).append(
                 dict(param=p, grad=g, buf=st["momentum_buffer"], lr=group["lr"], weight_decay=group["weight_decay"],
