@@ -242,7 +242,7 @@ def test_fused_staging_keeps_weight_copies_current(golden_dir, dtype):
     assert len(ops.STAGING) >= 9 + 2 + 10, len(ops.STAGING)        # conv3_1..conv5_3, fc6/fc7, 10 predictor matrices
     n_checked = 0
     for st in ops.STAGING.values():
-        p = st["param"]
+        p = st["param"]()
         if st["kind"] == 2:
             for mode, buf in ((0, st["stage0"]), (1, st["stage1"])):
                 if buf is None:
