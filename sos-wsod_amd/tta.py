@@ -32,8 +32,8 @@ class ViewTransform:
         sx, sy = self.new_hw[1] / self.orig_hw[1], self.new_hw[0] / self.orig_hw[0]
         if self.crop_xy is not None:
             x0, y0 = self.crop_xy
-            boxes = boxes - boxes.new_tensor([x0, y0, x0, y0])
-        b = boxes * boxes.new_tensor([sx, sy, sx, sy])
+            boxes = _offset_xyxy(boxes, -float(x0), -float(y0))
+        b = _scale_xyxy(boxes, sx, sy)
         if self.flip:                                        # HFlipTransform.apply_box: x -> W - x, corners re-sorted
             w = float(self.new_hw[1])
             b = torch.stack([w - b[:, 2], b[:, 1], w - b[:, 0], b[:, 3]], 1)
@@ -46,7 +46,24 @@ class ViewTransform:
             w = float(self.new_hw[1])
             b = torch.stack([w - b[:, 2], b[:, 1], w - b[:, 0], b[:, 3]], 1)
         sx, sy = self.orig_hw[1] / self.new_hw[1], self.orig_hw[0] / self.new_hw[0]
-        return b * b.new_tensor([sx, sy, sx, sy])
+        return _scale_xyxy(b, sx, sy)
+
+
+def _scale_xyxy(b: torch.Tensor, sx: float, sy: float) -> torch.Tensor:
+    """b * [sx, sy, sx, sy] without building that 4-vector on the device: `b.new_tensor([...])` is a pageable host-to-device copy that
+    waits for the stream — 24 of them were 13.8 of the 20 ms of a 12-view TTA call (tools/diag/infer_host_profile.py).  The scalar
+    form multiplies by the same float32 values: identical bits."""
+    out = b.clone()
+    out[:, 0::2].mul_(sx)
+    out[:, 1::2].mul_(sy)
+    return out
+
+
+def _offset_xyxy(b: torch.Tensor, dx: float, dy: float) -> torch.Tensor:
+    out = b.clone()
+    out[:, 0::2].add_(dx)
+    out[:, 1::2].add_(dy)
+    return out
 
 
 class DeviceTTAMapper:
@@ -141,7 +158,7 @@ class GeneralizedRCNNWithTTAAVG(torch.nn.Module):
                 back = tfm.inverse_box(boxes.reshape(R * K, 4)).reshape(R, 4 * K)
                 if (tfm.orig_hw != orig):                        # the mapper resized from the tensor's size, not the dataset's
                     sx, sy = orig[1] / tfm.orig_hw[1], orig[0] / tfm.orig_hw[0]
-                    back = (back.reshape(R * K, 4) * back.new_tensor([sx, sy, sx, sy])).reshape(R, 4 * K)
+                    back = _scale_xyxy(back.reshape(R * K, 4), sx, sy).reshape(R, 4 * K)
                 sum_scores = scores.clone() if sum_scores is None else sum_scores + scores
                 sum_boxes = back if sum_boxes is None else sum_boxes + back
         finally:
