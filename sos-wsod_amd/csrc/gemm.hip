@@ -427,8 +427,9 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
   // LDS-DMA schedule (2 buffers): the pieces of tile t+2 go out in phase 3 of tile t (its buffer was last read in phase 2: the
   // second group drains those reads before the barrier) and phases 0-2 of tile t+1; each wave waits for them with a counted
   // vmcnt at the end of tile t+1, one barrier before the first read.
-  constexpr bool PP = (BM == 256 && BN == 256 && WTM == 128 && WTN == 64 && STAGES == 2 && sizeof(T) == 2 && TS == 16 &&
+  constexpr bool PP = (BM == 256 && BN == 256 && WTM == 128 && WTN == 64 && STAGES == 2 && sizeof(T) == 2 && (TS == 16 || TS == 32) &&
                        AMODE <= OP_KSTRIDED && BMODE <= OP_KSTRIDED);
+  constexpr int QI = 64 / TS, QJ = 32 / TS;             // sub-tiles of a 64x32 quadrant (16x16x32: 4 x 2 x 2 K sub-steps; 32x32x16: 2 x 1 x 4)
   if constexpr (PP) {
     const int grp = wm;                                   // 0: waves 0-3, 1: waves 4-7
     auto dma_pair = [&](int tile, int j) {
@@ -444,7 +445,7 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
 #ifndef SW_PP_NOSTAGGER
     if (grp == 1) __builtin_amdgcn_s_barrier();           // the stagger: group 1 runs one segment behind
 #endif
-    u32x4 fa[4][2], fb[2][2][2];
+    u32x4 fa[QI][NSTEP], fb[2][QJ][NSTEP];
     for (int kt = 0; kt < nt; ++kt) {
       const char* sa = smem + (kt & 1) * STAGE_BYTES;
       const char* sb = sa + GA::BYTES;
@@ -455,15 +456,15 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
         __builtin_amdgcn_sched_barrier(0);
         if (p == 0 || p == 2) {
 #pragma unroll
-          for (int ii = 0; ii < 4; ++ii)
+          for (int ii = 0; ii < QI; ++ii)
 #pragma unroll
-            for (int st = 0; st < 2; ++st) fa[ii][st] = load_frag2<T, GA::KS, GA::ROW_BYTES>(sa, wm * WTM + (mq * 4 + ii) * TS, st, lane);
+            for (int st = 0; st < NSTEP; ++st) fa[ii][st] = load_frag2<T, GA::KS, GA::ROW_BYTES>(sa, wm * WTM + (mq * QI + ii) * TS, st, lane);
         }
         if (p == 0 || p == 1) {
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
+          for (int jj = 0; jj < QJ; ++jj)
 #pragma unroll
-            for (int st = 0; st < 2; ++st) fb[nq][jj][st] = load_frag2<T, GB::KS, GB::ROW_BYTES>(sb, wn * WTN + (nq * 2 + jj) * TS, st, lane);
+            for (int st = 0; st < NSTEP; ++st) fb[nq][jj][st] = load_frag2<T, GB::KS, GB::ROW_BYTES>(sb, wn * WTN + (nq * QJ + jj) * TS, st, lane);
         }
         if (p == 3) dma_pair(kt + 2, 0); else dma_pair(kt + 1, p + 1);
         if (grp == 1 && p == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // tile kt's last reads done before its buffer is refilled
@@ -477,11 +478,11 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
         __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < NSTEP; ++st)
 #pragma unroll
-          for (int ii = 0; ii < 4; ++ii)
+          for (int ii = 0; ii < QI; ++ii)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) MM::mma(acc[mq * 4 + ii][nq * 2 + jj], fa[ii][st], fb[nq][jj][st]);
+            for (int jj = 0; jj < QJ; ++jj) MM::mma(acc[mq * QI + ii][nq * QJ + jj], fa[ii][st], fb[nq][jj][st]);
 #ifndef SW_PP_NOPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -534,11 +535,11 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
     auto quarter = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
+      for (int ii = 0; ii < 32 / TS; ++ii)                          // the sub-tiles of this 32-row quarter (two of 16 rows / one of 32)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-          for (int e = 0; e < NACC; ++e) wt[(ii * TS + MM::row(lane, e)) * LDW + j * TS + r] = acc[2 * q + ii][j][e];
+          for (int e = 0; e < NACC; ++e) wt[(ii * TS + MM::row(lane, e)) * LDW + j * TS + r] = acc[(32 / TS) * q + ii][j][e];
       __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): own LDS writes before own reads (same wave)
       // a lane owns CP consecutive columns of one row: 8 for bf16 rows (16-byte stores), 4 for f32 rows.  CP and "no
       // per-element work" are compile-time cases: left as run-time tests inside the element loop, hipcc keeps that loop rolled
