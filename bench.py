@@ -533,7 +533,7 @@ def main():
             # forward + backward on 3, SGD, teacher EMA — on the ResNet-50-FPN detector of sos-wsod_amd/frcnn.py
             sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
             import stage3_step
-            ms, _ = stage3_step.time_step(torch.bfloat16, 800, 1216, dev=device, warm=3, n=6)
+            ms, _ = stage3_step.time_step(torch.bfloat16, 800, 1216, dev=device, warm=4, n=16)
             phase("stage3 run")
             out["stage3_ms_per_iter"] = round(ms, 2)
             # the dominant kernel family of that iteration: the forward GEMMs of the 1x1 convolutions / fc layers (gemm2 128x128 tiles),

@@ -466,7 +466,7 @@ class VGG16(nn.Module):
         if not self.dual_stream:
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = ops.worker_stream("side")
         return self._side
 
     def forward_nhwc(self, x_nhwc):

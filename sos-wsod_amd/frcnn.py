@@ -1190,7 +1190,7 @@ class Speculation:
         main = torch.cuda.current_stream(dev)
         chk = _CHECK_STREAMS.get(dev.index)
         if chk is None:
-            chk = _CHECK_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+            chk = _CHECK_STREAMS[dev.index] = ops.worker_stream("chk", dev)
         chk.wait_stream(main)
         want_l = tuple(v for _, vs in self.items for v in vs)
         const = _CHECK_CONST.get(dev.index)

@@ -4,6 +4,7 @@ torch is used here only for device memory and the current HIP stream; every comp
 hand-written gfx950 kernel.  All tensors must live on the GPU and be contiguous where stated.
 """
 import ctypes
+import os
 
 import torch
 
@@ -90,6 +91,28 @@ def param_key(p):
 
 
 GRAD_SCOPE = None      # the active grad_scope (or None)
+
+
+_WORKER_STREAMS = {}
+_WORKER_ROLES = ("main", "side", "upd", "chk")
+
+
+def worker_stream(role, device=None):
+    """The process's ONE stream per role and device — "main" (a step graph's capture / replay stream), "side" (the second backbone
+    scale, the Stage-3 teacher), "upd" (the data-parallel bucket updates), "chk" (the speculation ledger's comparison).  All four are
+    created together, in this order, the first time any is asked for.  Why not a fresh torch.cuda.Stream() per model / trainer: the
+    runtime spreads streams over a handful of hardware queues in creation order, and two streams that are meant to run side by side
+    but landed on one queue serialise — or stall each other at their event waits.  With every trainer of a process creating its own
+    streams, the SAME code measured 12.8 or 18.9 ms per Stage-3 iteration and 8.5 or 11.3 ms per data-parallel step depending on how
+    many models had lived in the process before (bench.py's extras).  Sharing a role's stream between models only adds ordering."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if os.environ.get("SW_FRESH_STREAMS") == "1":                   # development switch: a new pool stream per call (the old behaviour)
+        return torch.cuda.Stream(device=torch.device("cuda", idx))
+    got = _WORKER_STREAMS.get(idx)
+    if got is None:
+        got = _WORKER_STREAMS[idx] = {r: torch.cuda.Stream(device=torch.device("cuda", idx)) for r in _WORKER_ROLES}
+    return got[role]
 
 
 class capture_guard:

@@ -379,7 +379,7 @@ class SemiSupStep:
                 if self._side is None:
                     # (normal priority: a high-priority stream starved — 24.8 instead of 13.0 ms per iteration — in a process whose earlier
                     # streams had used up the four hardware queues; tools/diag/s3_in_bench.py)
-                    self._side = torch.cuda.Stream(device=dev)
+                    self._side = ops.worker_stream("side", dev)
                 side = self._side
                 side.wait_stream(main)                               # the EMA update above wrote the teacher's weights on `main`
                 with torch.cuda.stream(side):

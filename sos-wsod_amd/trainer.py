@@ -355,8 +355,9 @@ class _NativeDDP:
                     dist.broadcast(t.data, 0, group=self.group)
             from . import ops
             ops.invalidate_all_staged()
-        self.upd = torch.cuda.Stream(device=self.dev)
-        self.main = torch.cuda.Stream(device=self.dev) if use_graph else None
+        from . import ops as _ops
+        self.upd = _ops.worker_stream("upd", self.dev)
+        self.main = _ops.worker_stream("main", self.dev) if use_graph else None
         self._dbg_sync = os.environ.get("SW_DDP_DEBUG_SYNC", "0") == "1"          # development switches
         self._dbg_upd_main = os.environ.get("SW_DDP_UPD_MAIN", "0") == "1"
         n_pan = int(os.environ.get("SW_DDP_FC1_PANELS", "0"))
@@ -573,7 +574,8 @@ class _StepGraphs:
         if not self.lr_in_signature:
             trainer.optimizer.device_hyper = True
         self.labels = torch.zeros(4096, dtype=torch.float32, device=self.dev)
-        self.stream = torch.cuda.Stream(device=self.dev)
+        from . import ops as _ops
+        self.stream = _ops.worker_stream("main", self.dev)
         self.replays = self.captures = 0
         self.enabled = True                  # False: every step runs eagerly (on the same stream) — measurements, debugging
 

@@ -15,5 +15,5 @@ if os.environ.get("PRE", "1") == "1":
     torch.cuda.synchronize()
     del tr, m, b
     torch.cuda.empty_cache()
-ms, _ = stage3_step.time_step(torch.bfloat16, 800, 1216, dev=dev, warm=3, n=6)
+ms, _ = stage3_step.time_step(torch.bfloat16, 800, 1216, dev=dev, warm=int(os.environ.get("WARM", "3")), n=int(os.environ.get("N", "6")))
 print(f"stage3 {ms:.2f} ms, misses {stage3_step.MISSES}, host {stage3_step.HOST_MS:.1f} ms")
