@@ -86,6 +86,12 @@ long sw_gemm_splitk_workspace_floats(int M, int N, int K, int splitk);
  * Used for forward (ep: bias+relu) and for the data gradient (wk = flipped/transposed weights, ep: relu_ref). */
 int sw_conv3x3_igemm(int dtype, int nimg, int H, int W, int Cin, int Cout, int dilation, const void* in,
                      const void* wk, void* out, const sw_epilogue* ep, sw_stream_t stream);
+/* 3x3 convolution (stride 1, dilation 1, bf16, Cin % 32 == 0 and >= 64, Cout % 64 == 0) + bias + ReLU + 2x2 / stride-2 max pool as ONE
+ * launch; out_pooled [nimg][(H-2)/2+1][(W-2)/2+1][Cout].  For layers nothing differentiates through (vgg.py:104-122 below FREEZE_AT):
+ * the unpooled map is never written.  Returns 1 = launched, 0 = not covered (run sw_conv3x3_igemm + sw_maxpool2x2_fwd), < 0 error;
+ * bit-identical to that pair. */
+int sw_conv3x3_relu_pool2(int dtype, int nimg, int H, int W, int Cin, int Cout, const void* in, const void* wk, const float* bias,
+                          void* out_pooled, sw_stream_t stream);
 /* n stride-1, dilation-1 3x3 convolutions of different maps (and possibly different weights) in ONE launch of the direct kernel:
  * the FPN levels of a detector (reference: the per-level loops of detectron2/modeling/proposal_generator/rpn.py:118-133 and
  * detectron2/modeling/backbone/fpn.py:131-160).  `probs` is a HOST array, n <= 8; every epilogue like sw_conv3x3_igemm's (bias,

@@ -195,6 +195,7 @@ SIGNATURES = {
     "sw_ema_multi": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_long), ctypes.c_double, c_void_p]),
     "sw_threshold_select": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
+    "sw_conv3x3_relu_pool2": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_weighted_sum": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_scale_scalars": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_counter_add": (c_int, [c_void_p, c_u64, c_void_p]),

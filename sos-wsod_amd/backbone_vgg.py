@@ -140,12 +140,23 @@ class _VGGFunction(torch.autograd.Function):
         cur = x
         pi = 0
         stage_info = []     # per stage: ([(input act, output act) per conv], pre-pool act or None)
-        for blk in module.blocks:
+        ft = module.first_trainable_conv()
+        for bi, blk in enumerate(module.blocks):
             conv_io = []
             for ci in range(blk.num_conv):
                 w, b = params[pi], params[pi + 1]
                 pi += 2
                 cin = cur.shape[3]
+                # a stage nothing differentiates through (below FREEZE_AT): its last convolution pools inside its epilogue — the
+                # unpooled map (67 MB per 512x512 view pair at conv1_2) is never written, read back or kept (sw_conv3x3_relu_pool2)
+                if (ci == blk.num_conv - 1 and blk.has_pool and blk.pool_stride == 2 and blk.dilation == 1 and dtype == torch.bfloat16
+                        and (ft is None or bi < ft[0]) and cur.shape[1] >= 2 and cur.shape[2] >= 2):
+                    oh, ow = (cur.shape[1] - 2) // 2 + 1, (cur.shape[2] - 2) // 2 + 1
+                    pooled = torch.empty(cur.shape[0], oh, ow, blk.out_channels, device=x.device, dtype=dtype)
+                    if ops.conv3x3_relu_pool2(cur, module.staged_weight(w, 0, cin, dtype), b, pooled, tag=f"{blk.tag}.conv{ci + 1}_fwd"):
+                        conv_io.append((cur, None))
+                        cur = pooled
+                        continue
                 out = torch.empty(cur.shape[0], cur.shape[1], cur.shape[2], blk.out_channels, device=x.device, dtype=dtype)
                 ep = ops.make_epilogue(bias=b, relu=True, out_dtype=dtype)
                 if not (module.winograd_ok(cin, blk.out_channels) and
@@ -155,7 +166,7 @@ class _VGGFunction(torch.autograd.Function):
                 conv_io.append((cur, out))
                 cur = out
             pre_pool = None
-            if blk.has_pool:
+            if blk.has_pool and conv_io[-1][1] is not None:
                 pre_pool = cur
                 s = blk.pool_stride
                 oh, ow = (cur.shape[1] - 2) // s + 1, (cur.shape[2] - 2) // s + 1

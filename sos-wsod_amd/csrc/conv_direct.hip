@@ -32,6 +32,7 @@ struct DirectArgs {
   const void* in; const void* wk; void* out;
   const float* bias; const void* ref;
   int nimg, H, W, Cin, Cout, relu;
+  int pool;                            // 1: `out` is the 2x2 / stride-2 max-pooled map [nimg][(H-2)/2+1][(W-2)/2+1][Cout] (KG = 1 form only)
   int tiles_x, tiles_y, n_px_tiles, n_co_blocks, total;
   unsigned in_bytes, wk_bytes;
 };
@@ -259,6 +260,39 @@ __device__ __forceinline__ void conv3x3_direct_body(const DirectArgs& g, const u
       }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): own LDS writes visible to own reads (same wave)
+  if (g.pool) {
+    // 2x2 / stride-2 max pool inside the epilogue (frozen layers: nobody reads the unpooled map).  The wave's 64 pixels are the image
+    // rows 2w, 2w+1 of the tile x 32 columns = 16 whole windows (tile origins are multiples of 8 x 32): a lane takes the windows'
+    // 16-byte channel groups, maximum in the order of sw_maxpool2x2_fwd ((y,x), (y,x+1), (y+1,x), (y+1,x+1)) on the bf16 values the
+    // unfused pair would have stored and re-read: identical bits.  A window that does not fit the image (odd H / W) has no output.
+    const int OH = (g.H - 2) / 2 + 1, OW = (g.W - 2) / 2 + 1;
+#pragma unroll
+    for (int it = 0; it < (16 * (TN / 8) + 63) / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int pp = idx / (TN / 8), ch = idx % (TN / 8);
+      const int oy = (ty0 + 2 * wave) >> 1, ox = (tx0 >> 1) + pp;
+      const int co = co0 + ch * 8;
+      if (pp < 16 && oy < OH && ox < OW && co < g.Cout) {
+        float a[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int pl = (t >> 1) * 32 + 2 * pp + (t & 1);
+          const u32x4 v = *(const u32x4*)(S + pl * TN + ((ch ^ (pl & (TN / 8 - 1))) << 3));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = __uint_as_float(v[q] << 16), hi = __uint_as_float(v[q] & 0xFFFF0000u);
+            a[2 * q] = t == 0 ? lo : fmaxf(a[2 * q], lo);
+            a[2 * q + 1] = t == 0 ? hi : fmaxf(a[2 * q + 1], hi);
+          }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (unsigned)f32_to_bf16_bits(a[2 * q]) | ((unsigned)f32_to_bf16_bits(a[2 * q + 1]) << 16);
+        *(u32x4*)(out + (((long)img * OH + oy) * OW + ox) * g.Cout + co) = o;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < TN / 8; ++it) {
     const int idx = it * 64 + lane;
@@ -442,6 +476,44 @@ int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilatio
   e = hipGetLastError();
   if (e != hipSuccess) return -(int)e;
   return 1;
+}
+
+
+// 3x3 convolution (stride 1, dilation 1, bf16) + bias + ReLU + 2x2 / stride-2 max pool in ONE launch: `out` is the pooled map only.  For
+// layers nobody differentiates through (the frozen conv1_2 / conv2_2 of the VGG16 backbone, vgg.py:104-122 with FREEZE_AT 2): the
+// unpooled map (67 MB per 512x512 view pair at conv1_2) is never written or read back.  Returns 1 = launched, 0 = shape not covered
+// (the caller runs sw_conv3x3_igemm + sw_maxpool2x2_fwd), < 0 on error.  Results identical to that pair, bit for bit.
+extern "C" int sw_conv3x3_relu_pool2(int dtype, int nimg, int H, int W, int Cin, int Cout, const void* in, const void* wk, const float* bias,
+                                     void* out_pooled, hipStream_t stream) {
+  SW_ENTER();
+  static const char* sw = getenv("SW_CONV_DIRECT");
+  static const char* fsw = getenv("SW_CONV_POOL_FUSED");      // development switch: "0" = never
+  if ((sw && sw[0] == '0') || (fsw && fsw[0] == '0')) return 0;
+  if (dtype != SW_BF16 || (Cin % CK) || Cin < 64 || (Cout % 64) || H < 2 || W < 2) return 0;
+  if ((((uintptr_t)in | (uintptr_t)wk | (uintptr_t)out_pooled) & 15)) return 0;
+  DirectArgs g = {};
+  g.in = in; g.wk = wk; g.out = out_pooled; g.bias = bias; g.ref = nullptr; g.relu = 1; g.pool = 1;
+  g.nimg = nimg; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+  g.tiles_x = (W + TW - 1) / TW; g.tiles_y = (H + TH - 1) / TH;
+  g.n_px_tiles = g.tiles_x * g.tiles_y * nimg;
+  g.n_co_blocks = Cout / 64;
+  g.total = g.n_px_tiles * g.n_co_blocks;
+  // few tiles: sw_conv3x3_igemm would split K inside the workgroup or take 32-channel tiles (another order of additions): not covered,
+  // so that the fused launch always equals the unfused pair bit for bit
+  if (g.total <= 384) return 0;
+  const long ib = (long)nimg * H * W * Cin * 2, wb = (long)Cout * 9 * Cin * 2;
+  if (ib >= 0xFFFFFF00L || wb >= 0xFFFFFF00L) return 0;
+  g.in_bytes = (unsigned)ib; g.wk_bytes = (unsigned)wb;
+  const int per_xcd = (g.total + 7) / 8;
+  constexpr int P = (TH + 2) * (TW + 2);
+  constexpr int apw = ((P * 4 + 63) / 64 + 3) / 4;
+  const size_t lds = (size_t)2 * apw * 4096 + (size_t)2 * (3 * 64 * 64);
+  auto kern = conv3x3_direct_kernel<1, 64, 1>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return -(int)e;
+  hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256), lds, stream, g);
+  e = hipGetLastError();
+  return e == hipSuccess ? 1 : -(int)e;
 }
 
 

@@ -361,6 +361,18 @@ def conv3x3(x, wk, out, dilation, ep, tag=None):
     return out
 
 
+def conv3x3_relu_pool2(x, wk, bias, out_pooled, tag=None):
+    """x [n][H][W][Cin] -> out_pooled [n][(H-2)//2+1][(W-2)//2+1][Cout] = maxpool2x2/2(relu(conv3x3(x) + bias)) in one launch
+    (sw_conv3x3_relu_pool2); False when the shape is not covered (the caller then runs conv3x3 + maxpool_fwd)"""
+    _need_gpu(x, wk, out_pooled)
+    n, H, W, Cin = x.shape
+    Cout = out_pooled.shape[3]
+    rc = _launch(tag, lambda: lib.sw_conv3x3_relu_pool2(dt(x), n, H, W, Cin, Cout, _p(x), _p(wk), _p(bias), _p(out_pooled), _stream()))
+    if rc < 0:
+        check(rc, "sw_conv3x3_relu_pool2")
+    return rc == 1
+
+
 def conv3x3_multi(problems):
     """problems: list of (x NHWC, wk [Cout][9][Cin], out NHWC, epilogue) — stride-1, dilation-1 convolutions of different maps (the FPN
     levels of a detector) in ONE launch of the direct kernel (sw_conv3x3_multi); shapes it does not cover run one by one"""

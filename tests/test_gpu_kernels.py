@@ -1073,3 +1073,31 @@ def test_grouped_plain_weight_gradient_gemms_and_multi_fold(ops, dtype):
     for (M, N, K, ns, opt), C, ref in zip(spec, outs, refs):
         err = float((C.double() - ref).abs().max() / ref.abs().max())
         assert err <= 2e-5, (M, N, K, ns, opt, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 256, 256, 64, 64), (1, 375, 501, 64, 128), (2, 187, 250, 128, 128), (1, 9, 66, 64, 64)])
+def test_conv3x3_relu_pool2_fused_equals_conv_then_pool(shape):
+    """sw_conv3x3_relu_pool2 (the frozen conv1_2 / conv2_2 of the backbone: 2x2 / stride-2 max pool inside the convolution's epilogue,
+    vgg.py:104-122) against sw_conv3x3_igemm + sw_maxpool2x2_fwd on the same operands: identical bits, odd heights / widths (the last
+    row / column belongs to no window) and partial tiles included."""
+    import sos_wsod_amd.ops as ops
+    n, H, W, cin, cout = shape
+    g = torch.Generator(device="cuda"); g.manual_seed(H * 1000 + W)
+    x = (torch.randn(n, H, W, cin, device="cuda", generator=g) * 0.7).to(torch.bfloat16)
+    wk = (torch.randn(cout, 9, cin, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(cout, device="cuda", generator=g) * 0.1
+    full = torch.empty(n, H, W, cout, device="cuda", dtype=torch.bfloat16)
+    ops.conv3x3(x, wk, full, 1, ops.make_epilogue(bias=b, relu=True, out_dtype=torch.bfloat16))
+    oh, ow = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    want = torch.empty(n, oh, ow, cout, device="cuda", dtype=torch.bfloat16)
+    ops.maxpool_fwd(full, want, 2)
+    got = torch.full((n, oh, ow, cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    took = ops.conv3x3_relu_pool2(x, wk, b, got)
+    if H * W < 4096:                 # few tiles: the unfused convolution runs another kernel form (K groups) — the fused entry declines
+        assert not took
+        return
+    assert took
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert float(want.float().abs().max()) > 0
