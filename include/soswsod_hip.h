@@ -149,9 +149,12 @@ int sw_conv3x3_wgrad_fold(int Cin, int Cout, int nslab, const float* workspace, 
 int sw_conv3x3_wgrad_fold_acc(int Cin, int Cout, int nslab, const float* workspace, float* dw_oihw, const float* cout_scale,
                               int accumulate, sw_stream_t stream);
 /* ALL weight gradients of a backward pass in ONE launch: problem i writes the slabs sw_conv3x3_wgrad_slabs(..., splitk =
- * nsplit) would write (sw_conv3x3_wgrad_workspace_floats(...) floats at `slabs`), computed on 256x256 tiles by one resident
- * workgroup per CU walking the (problem, K-split, tile) list — instead of one launch of 128x128 tiles per layer and view,
- * each cut into many K-splits to fill the chip.  `problems` is a HOST array.  Fold with sw_conv3x3_wgrad_fold. */
+ * nsplit) would write (sw_conv3x3_wgrad_workspace_floats(...) floats at `slabs`), computed by resident workgroups walking the
+ * (problem, split, tile) list — instead of one launch of 128x128 tiles per layer and view, each cut into many K-splits to fill the
+ * chip.  bf16 lists whose every problem has Cin % 64 == 0, Cout % 64 == 0, dilation 1 or 2, H >= 8 and >= 8 strip rows per split run
+ * the direct weight-gradient kernel (conv_wgrad_direct.hip: an input row staged once for all nine taps; the splits are ranges of
+ * (image, 32-pixel strip, row) steps — same slab count and layout, another order of additions inside a slab); every other list the
+ * implicit GEMM on 256x256 tiles.  `problems` is a HOST array.  Fold with sw_conv3x3_wgrad_fold. */
 typedef struct {
   int nimg, H, W, Cin, Cout, dilation, nsplit;
   const void* x;      /* [nimg][H][W][Cin] */

@@ -95,6 +95,61 @@ def _wgrad_grouped_target(shapes, bk, n_cu=256, candidates=(40, 48, 56, 64, 72, 
     return best[1]
 
 
+def _wgrad_direct_covers(probs, dtype):
+    """the shape conditions of the direct weight-gradient kernel (csrc/conv_wgrad_direct.hip, sw_conv3x3_wgrad_direct_try): every
+    problem (n, H, W, cin, cout, dil) of a grouped launch must meet them, else the whole list runs as implicit GEMMs"""
+    if dtype != torch.bfloat16 or os.environ.get("SW_WGRAD_DIRECT", "1") == "0":
+        return False
+    return all(cout % 64 == 0 and cin % 64 == 0 and dil in (1, 2) and H >= 8 and n * ((W + 31) // 32) * H >= 8
+               for n, H, W, cin, cout, dil in probs)
+
+
+def _wgrad_nslab(npix, nsplit, bk=64):
+    """slabs sw_conv3x3_wgrad_workspace_floats(..., splitk = nsplit) stands for (the K range of a split is a multiple of bk pixels)"""
+    kps = -(-(-(-npix // max(1, nsplit))) // bk) * bk
+    return -(-npix // kps)
+
+
+def _wgrad_direct_splits(probs, n_slots=512, candidates=(160, 192, 224, 256, 320, 384, 448, 512)):
+    """pixel splits per problem for the direct weight-gradient kernel.  Its work items are (problem, split, 64 x 64 channel block), all of
+    one problem equally long (steps = image rows of 32-pixel strips); the resident workgroups (two per CU) take the item list round-robin.
+    For a few target item lengths: simulate that deal (plus ~6 steps of prologue / epilogue per item; a CU's two workgroups share its
+    matrix pipes — ~1 us per step each side by side, ~0.6 us for one alone) and price the slabs (written by the kernel, read by the
+    fold: ~0.25 us per MB) — keep the cheapest.  Measured (tools/wgrad_shapes.py, headline / recipe / COCO shape sets): 300-400 steps per
+    item is the flat optimum, shorter items pay in slab traffic, one item per block loses the L2 sharing of a pixel range.  Cached per
+    shape set."""
+    key = ("direct", tuple(probs), n_slots, candidates)
+    hit = _WGRAD_PLAN_CACHE.get(key)
+    if hit is not None:
+        return hit
+    best = None
+    for S in candidates:
+        load = [0.0] * n_slots
+        t, mb, ns_list = 0, 0.0, []
+        for n, H, W, cin, cout, dil in probs:
+            steps = n * ((W + 31) // 32) * H
+            ns = max(1, min(int(steps / S + 0.5), steps // 8))
+            eff = _wgrad_nslab(n * H * W, ns)
+            while eff > 1 and -(-steps // eff) < 8:
+                ns -= 1
+                eff = _wgrad_nslab(n * H * W, ns)
+            per = -(-steps // eff)
+            ns_list.append(ns)
+            for _ in range(eff * (cout // 64) * (cin // 64)):
+                load[t % n_slots] += per + 6
+                t += 1
+            mb += eff * cout * 9 * cin * 4e-6
+        half = n_slots // 2
+        busiest = max(min(load[c], load[c + half]) + 0.6 * abs(load[c] - load[c + half]) for c in range(half))
+        cost = busiest + 0.25 * mb
+        if best is None or cost < best[0]:
+            best = (cost, ns_list)
+    if len(_WGRAD_PLAN_CACHE) > 512:
+        _WGRAD_PLAN_CACHE.clear()
+    _WGRAD_PLAN_CACHE[key] = best[1]
+    return best[1]
+
+
 def _wgrad_grouped_splits(npix, bk, target_ktiles):
     """K-splits of one (layer, view batch) problem of the grouped weight-gradient launch: work items of ~target_ktiles K-tiles
     each, so that the 256x256 items of all layers are of similar length (conv3 maps hold 4x the pixels of conv4 / conv5)"""
@@ -200,8 +255,9 @@ class _VGGFunction(torch.autograd.Function):
         deferred = []
         module._colsum_deferred = []
         target = module.wgrad_target_ktiles
+        direct_ns = None                        # (pidx, view batch) -> splits, when the direct weight-gradient kernel takes the list
         if grouped and target <= 0:             # pick the K-tiles per item for THIS set of (layer, view batch) problems
-            shapes = []
+            shapes, probs6, keys = [], [], []
             pj = len(params)
             for sj in range(len(module.blocks) - 1, -1, -1):
                 bj = module.blocks[sj]
@@ -211,6 +267,10 @@ class _VGGFunction(torch.autograd.Function):
                         for i in live:
                             xin = infos[i][sj][0][cj][0]
                             shapes.append((xin.shape[0] * xin.shape[1] * xin.shape[2], bj.out_channels, 9 * xin.shape[3]))
+                            probs6.append((xin.shape[0], xin.shape[1], xin.shape[2], xin.shape[3], bj.out_channels, bj.dilation))
+                            keys.append((pj, i))
+            if _wgrad_direct_covers(probs6, dtype):
+                direct_ns = dict(zip(keys, _wgrad_direct_splits(probs6)))
             target = _wgrad_grouped_target(shapes, bk)
         plan = {}            # pidx -> dict(ws, rows, per-batch offsets, totals, dw, db)
         pidx = len(params)
@@ -225,7 +285,8 @@ class _VGGFunction(torch.autograd.Function):
                     for i in live:
                         x_in = infos[i][si][0][ci][0]
                         n, H, W, cin = x_in.shape
-                        splits[i] = (_wgrad_grouped_splits(n * H * W, bk, target) if grouped
+                        splits[i] = (direct_ns[(pidx, i)] if direct_ns is not None
+                                     else _wgrad_grouped_splits(n * H * W, bk, target) if grouped
                                      else _wgrad_splitk(cout, cin, n * H * W))
                         slab_off[i], row_off[i] = nslab, nrow
                         nslab += ops.conv3x3_wgrad_nslab(x_in, cout, splits[i])

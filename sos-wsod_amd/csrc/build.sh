@@ -12,7 +12,7 @@ mkdir -p "$HERE/_obj"
 CCV="$($HIPCC --version 2>/dev/null | head -n 2 | tr '\n' ' ')"
 pids=()
 rebuilt=0
-for f in gemm conv_direct conv_winograd roipool elementwise heads detector proposals; do
+for f in gemm conv_direct conv_wgrad_direct conv_winograd roipool elementwise heads detector proposals; do
   key="$( (echo "$FLAGS $CCV"; cat "$HERE/$f.hip" "$HERE/common.h" "$ROOT/include/soswsod_hip.h") | sha256sum | cut -d' ' -f1)"
   if [ ! -f "$HERE/_obj/$f.o" ] || [ "$(cat "$HERE/_obj/$f.key" 2>/dev/null)" != "$key" ]; then
     ( $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/_obj/$f.o" && echo "$key" > "$HERE/_obj/$f.key" ) &
@@ -22,6 +22,6 @@ for f in gemm conv_direct conv_winograd roipool elementwise heads detector propo
 done
 for p in "${pids[@]}"; do wait $p; done
 if [ "$rebuilt" = 1 ] || [ ! -f "$OUT" ]; then
-  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/_obj/gemm.o" "$HERE/_obj/conv_direct.o" "$HERE/_obj/conv_winograd.o" "$HERE/_obj/roipool.o" "$HERE/_obj/elementwise.o" "$HERE/_obj/heads.o" "$HERE/_obj/detector.o" "$HERE/_obj/proposals.o"
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/_obj/gemm.o" "$HERE/_obj/conv_direct.o" "$HERE/_obj/conv_wgrad_direct.o" "$HERE/_obj/conv_winograd.o" "$HERE/_obj/roipool.o" "$HERE/_obj/elementwise.o" "$HERE/_obj/heads.o" "$HERE/_obj/detector.o" "$HERE/_obj/proposals.o"
 fi
 echo "built $OUT"

@@ -20,6 +20,7 @@
 // XOR the 16 lanes of every group hit 64 distinct banks for ANY start row, i.e. for every tap shift (found by exhaustive
 // search; the obvious (row >> 2) & 3 measured 45 % of the LDS cycles as bank conflicts).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "soswsod_hip.h"
 
@@ -146,37 +147,56 @@ __device__ __forceinline__ void conv3x3_direct_body(const DirectArgs& g, const u
   // pipeline with the barrier moved into the last tap was measured 4-12 % slower: 256 VGPRs, longer dependency stalls.)
   issue_a(0);
   issue_b(0);
-  auto compute_step = [&](int step, int chunk, int ty) {
-    const char* A = sA + (chunk & 1) * A_BYTES;
-    const char* B = sB + (step & 1) * B_BYTES;
+  // Ragged right / bottom edge (round 6): a tile whose columns tx0 + 16 .. tx0 + 31 all lie outside the image runs the LEFT form of the
+  // loop — the 16-pixel sub-tiles i = 1, 3 are neither read nor multiplied (half the MFMAs of the tile: a 166-pixel-wide map issues 5.5
+  // tile columns instead of 6) — and a wave whose two rows lie below the image runs the EMPTY form (staging and barriers only; its
+  // SIMD's matrix pipe goes to the other workgroup of the CU).  Uniform per wave; the full tile's code is unchanged.
+  constexpr int FORM_FULL = 0, FORM_LEFT = 1, FORM_EMPTY = 2;
+  auto main_loop = [&](auto form_c) {
+    constexpr int FORM = decltype(form_c)::value;
+    auto compute_step = [&](int step, int chunk, int ty) {
+      const char* A = sA + (chunk & 1) * A_BYTES;
+      const char* B = sB + (step & 1) * B_BYTES;
 #pragma unroll
-    for (int tx = 0; tx < 3; ++tx) {
-      u32x4 fa[4], fb[NI];
+      for (int tx = 0; tx < 3; ++tx) {
+        u32x4 fa[4], fb[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int prow = (2 * wave + (i >> 1) + ty * DIL) * PW + (i & 1) * 16 + tx * DIL + l15;
-        fa[i] = *(const u32x4*)(A + prow * 64 + ((kq ^ (((prow >> 2) & 1) << 1)) << 4));
+        for (int i = 0; i < 4; ++i) {
+          if (FORM == FORM_LEFT && (i & 1)) continue;
+          const int prow = (2 * wave + (i >> 1) + ty * DIL) * PW + (i & 1) * 16 + tx * DIL + l15;
+          fa[i] = *(const u32x4*)(A + prow * 64 + ((kq ^ (((prow >> 2) & 1) << 1)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[j] = *(const u32x4*)(B + tx * (TN * 64) + b_off[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (FORM == FORM_LEFT && (i & 1)) continue;
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                acc[i][j], 0, 0, 0);
+        }
       }
+    };
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) fb[j] = *(const u32x4*)(B + tx * (TN * 64) + b_off[j]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
-                                                              acc[i][j], 0, 0, 0);
+      for (int ty = 0; ty < 3; ++ty) {
+        const int step = chunk * 3 + ty;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (step + 1 < nstep) issue_b(step + 1);
+        if (ty == 0 && chunk + 1 < nchunk) issue_a(chunk + 1);
+        if (FORM != FORM_EMPTY) compute_step(step, chunk, ty);
+      }
     }
   };
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-#pragma unroll
-    for (int ty = 0; ty < 3; ++ty) {
-      const int step = chunk * 3 + ty;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (step + 1 < nstep) issue_b(step + 1);
-      if (ty == 0 && chunk + 1 < nchunk) issue_a(chunk + 1);
-      compute_step(step, chunk, ty);
-    }
+  {
+    static_assert(TW == 32 && TH == 8, "edge forms: 16-pixel sub-tiles, two rows per wave");
+    const bool left_only = tx0 + 16 >= g.W;                  // workgroup-uniform
+    const bool no_rows = ty0 + 2 * wave >= g.H;              // wave-uniform
+    if (no_rows) main_loop(std::integral_constant<int, FORM_EMPTY>{});
+    else if (left_only) main_loop(std::integral_constant<int, FORM_LEFT>{});
+    else main_loop(std::integral_constant<int, FORM_FULL>{});
   }
   __syncthreads();                                          // every wave is done with the staging buffers
 

@@ -1403,10 +1403,24 @@ static int wgrad_fold_impl(int Cin, int Cout, int nslab, const float* workspace,
   return 0;
 }
 
+int sw_conv3x3_wgrad_direct_try(int n_problems, const sw_wgrad_problem* problems, const int* eff, hipStream_t stream);   // conv_wgrad_direct.hip
+
 extern "C" int sw_conv3x3_wgrad_grouped(int dtype, int n_problems, const sw_wgrad_problem* problems, hipStream_t stream) {
   SW_ENTER();
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
   if (n_problems <= 0) return 0;
+  if (dtype == SW_BF16 && n_problems <= 256) {
+    // round 6: the direct weight-gradient kernel (input rows staged once for all nine taps) when it covers every problem of the list;
+    // it writes the same slabs (count and layout) as the implicit GEMM below
+    int eff[256];
+    for (int i = 0; i < n_problems; ++i) {
+      const sw_wgrad_problem& q = problems[i];
+      eff[i] = (int)(sw_conv3x3_wgrad_workspace_floats(dtype, q.nimg, q.H, q.W, q.Cin, q.Cout, q.nsplit) / ((long)q.Cout * 9 * q.Cin));
+    }
+    const int rc = sw_conv3x3_wgrad_direct_try(n_problems, problems, eff, stream);
+    if (rc < 0) return -rc;
+    if (rc == 1) return 0;
+  }
   const int epc = dtype == SW_BF16 ? 8 : 4, bk = dtype == SW_BF16 ? 64 : 32;
   const long es = dtype == SW_BF16 ? 2 : 4;
   static int ncu = 0;

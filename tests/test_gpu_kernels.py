@@ -156,6 +156,33 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cin, cout, dil):
     assert ((dx.cpu().double() - gx_ref).abs().max() / gx_ref.abs().max()) < 3e-5
 
 
+@pytest.mark.parametrize("n,H,W,cin,cout,dil", [(2, 19, 40, 64, 64, 1), (1, 26, 77, 64, 128, 2), (2, 100, 166, 128, 64, 2), (2, 106, 141, 64, 128, 1),
+                                                  (1, 9, 16, 128, 64, 1), (1, 70, 200, 64, 72, 1)])
+def test_conv3x3_direct_ragged_edge_forms(ops, n, H, W, cin, cout, dil):
+    """the direct kernel's edge forms (conv_direct.hip, round 6): tiles whose right 16 columns lie outside the map skip those sub-tiles,
+    waves whose rows lie below it only stage — forward (bias + ReLU) and the data-gradient form (ReLU mask from a reference map) against a
+    float64 convolution of the same bf16 operands; few-tile shapes take the two-K-group form, the others the four-wave form"""
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda"); g.manual_seed(H * 1000 + W + dil)
+    x = (torch.randn(n, H, W, cin, device="cuda", generator=g) * 0.7).to(dt)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * 0.05).to(dt)
+    b = torch.randn(cout, device="cuda", generator=g) * 0.1
+    wk = torch.empty(cout, 9, cin, device="cuda", dtype=dt)
+    ops.conv_weight_prep(w.float(), wk, 0, cin)
+    out = torch.full((n, H, W, cout), float("nan"), device="cuda", dtype=dt)
+    ops.conv3x3(x, wk, out, dil, ops.make_epilogue(bias=b, relu=True, out_dtype=dt))
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=dil, dilation=dil)
+    ref = F.relu(y).permute(0, 2, 3, 1)
+    assert torch.isfinite(out.float()).all()
+    assert ((out.double() - ref).abs().max() / ref.abs().max()) < 1e-2                     # bf16 output rounding
+    mask = (torch.randn(n, H, W, cout, device="cuda", generator=g) * 0.5).to(dt)
+    out2 = torch.full((n, H, W, cout), float("nan"), device="cuda", dtype=dt)
+    ops.conv3x3(x, wk, out2, dil, ops.make_epilogue(relu_ref=mask.view(n * H * W, cout), out_dtype=dt))
+    ref2 = (y - b.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1) * (mask.double() > 0)
+    assert torch.isfinite(out2.float()).all()
+    assert ((out2.double() - ref2).abs().max() / ref2.abs().max()) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows,cols", [(8000, 4096), (130, 72), (64, 64), (37, 200)])
 def test_transpose_2d(ops, dtype, rows, cols):
@@ -212,6 +239,33 @@ def test_conv3x3_wgrad_grouped_launch(ops, dtype):
     ops.conv3x3_wgrad_fold(last[2], last[3], dw)
     want = ref_grad(last[0], last[1], last[4], last[5], last[6])
     assert ((dw.cpu().double() - want).abs().max() / want.abs().max()) < 3e-5
+
+
+@pytest.mark.parametrize("spec", [(2, 19, 40, 64, 128, 1, 2), (1, 26, 77, 128, 256, 2, 3), (2, 33, 33, 64, 128, 2, 1), (2, 64, 64, 128, 128, 1, 4),
+                                  (2, 10, 330, 64, 128, 1, 7), (2, 12, 70, 64, 128, 2, 4), (1, 8, 32, 64, 128, 1, 1), (2, 63, 63, 128, 256, 2, 5)])
+def test_conv3x3_wgrad_direct_kernel(ops, spec):
+    """conv_wgrad_direct.hip (round 6: input rows staged once for the nine taps, transposed LDS reads, 128 x 64 x 9 register blocks) behind
+    sw_conv3x3_wgrad_grouped: ragged strips (W % 32 != 0), both dilations, split boundaries that get moved off a strip's first / last rows,
+    one- and many-split problems — against a float64 convolution gradient of the same bf16 operands, and against the implicit-GEMM path
+    (SW_WGRAD_DIRECT is read once per process, so that path is reached through a shape the direct kernel declines: the per-launch entry)"""
+    n, H, W, cin, cout, dil, ns = spec
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda"); g.manual_seed(H * 977 + W)
+    x = (torch.randn(n, H, W, cin, device="cuda", generator=g) * 0.7).to(dt)
+    dz = (torch.randn(n, H, W, cout, device="cuda", generator=g) * 0.5).to(dt)
+    nslab = ops.conv3x3_wgrad_nslab(x, cout, ns)
+    slabs = torch.full((nslab, cout * 9 * cin), float("nan"), device="cuda")
+    ops.conv3x3_wgrad_grouped([(x, dz, slabs, dil, ns)])
+    dw = torch.empty(cout, cin, 3, 3, device="cuda")
+    ops.conv3x3_wgrad_fold(slabs, nslab, dw)
+    assert torch.isfinite(slabs).all()
+    wd = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), wd, None, padding=dil, dilation=dil)
+    want = torch.autograd.grad(y, wd, dz.double().permute(0, 3, 1, 2))[0]
+    assert ((dw.double() - want).abs().max() / want.abs().max()) < 3e-5
+    one = torch.empty(cout, cin, 3, 3, device="cuda")                        # the implicit-GEMM path on the same problem
+    ops.conv3x3_wgrad(x, dz, one, dil, splitk=1)
+    assert ((dw - one).abs().max() / one.abs().max()) < 2e-5
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -1076,7 +1130,8 @@ def test_grouped_plain_weight_gradient_gemms_and_multi_fold(ops, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 256, 256, 64, 64), (1, 375, 501, 64, 128), (2, 187, 250, 128, 128), (1, 9, 66, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 256, 256, 64, 64), (1, 375, 501, 64, 128), (2, 187, 250, 128, 128), (1, 9, 66, 64, 64),
+                                   (2, 131, 270, 64, 128)])
 def test_conv3x3_relu_pool2_fused_equals_conv_then_pool(shape):
     """sw_conv3x3_relu_pool2 (the frozen conv1_2 / conv2_2 of the backbone: 2x2 / stride-2 max pool inside the convolution's epilogue,
     vgg.py:104-122) against sw_conv3x3_igemm + sw_maxpool2x2_fwd on the same operands: identical bits, odd heights / widths (the last

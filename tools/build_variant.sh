@@ -9,7 +9,7 @@ SRC=gemm
 case "$1" in SRC=*) SRC="${1#SRC=}"; shift;; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -I"$ROOT/include" -I"$C" -Wno-unused-result "$@" -c "$C/$SRC.hip" -o "$C/_obj/${SRC}_$NAME.o"
 OBJS=""
-for f in gemm conv_direct conv_winograd roipool elementwise heads detector proposals; do
+for f in gemm conv_direct conv_wgrad_direct conv_winograd roipool elementwise heads detector proposals; do
   if [ "$f" = "$SRC" ]; then OBJS="$OBJS $C/_obj/${SRC}_$NAME.o"; else OBJS="$OBJS $C/_obj/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/sos-wsod_amd/libsoswsod_hip_$NAME.so" $OBJS
