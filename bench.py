@@ -226,7 +226,9 @@ def main():
             groups.append({"params": [p], "lr": 2e-3 if name.endswith(".bias") else 1e-3,
                            "weight_decay": 0.0 if name.endswith(".bias") else 5e-4})
     opt = HipSGD(groups, 1e-3, momentum=0.9)
-    use_graph = (world == 1) if args.graph is None else bool(args.graph)
+    # single GPU: the whole step is one hipGraph; data parallel (trainer._NativeDDP): four stage graphs with the eager RCCL all-reduces
+    # between them (round 6: that mode is `value` for N > 1 too; the launch-by-launch time is the extra `eager_ms_per_step`)
+    use_graph = True if args.graph is None else bool(args.graph)
     trainer = Trainer(model, opt, use_graph=use_graph)
     B = args.images_per_gpu
     # which (synthetic) images a rank sees: its shard of the shared-seed permutation stream, as the reference's TrainingSampler deals a
@@ -241,7 +243,8 @@ def main():
         torch.cuda.synchronize()
 
     graphs = trainer._graphs
-    if graphs is not None:                       # "compile" phase: every distinct input signature is captured before any timing
+    native = trainer._native
+    if graphs is not None or (native is not None and native.use_graph):    # "compile" phase: every input signature is captured before any timing
         for i in range(6):
             trainer.run_step(batches[i % 2])
     for i in range(args.warmup):
@@ -261,9 +264,13 @@ def main():
     replays = captures = None
     n_timer_steps = 8
     eager_ms = dt / args.steps * 1e3
-    if graphs is not None:                       # the same step issued launch by launch, for the record
-        replays, captures = graphs.replays, graphs.captures
-        graphs.enabled = False                   # same trainer, same stream, no replay
+    if graphs is not None or (native is not None and native.use_graph):     # the same step issued launch by launch, for the record
+        if graphs is not None:
+            replays, captures = graphs.replays, graphs.captures
+            graphs.enabled = False               # same trainer, same stream, no replay
+        else:
+            replays, captures = native.replays, native.captures
+            native.use_graph = False             # every rank alike: the collectives stay in step
         trainer.run_step(batches[0])
         sync(); t1 = time.perf_counter()
         for i in range(n_timer_steps):
@@ -280,7 +287,17 @@ def main():
     ops.TIMER = None
     rank_ms = [dt / args.steps * 1e3]
     rccl_ranks = 1
+    ranks_in_sync = None
     if world > 1:
+        # self-check of the data-parallel step (train_net_multi.py:76-78: DDP keeps the replicas identical; the hand-rolled reducer has to
+        # prove it): an exact integer checksum of every parameter's bits after all the steps above, MIN == MAX over the ranks
+        with torch.no_grad():
+            cs = torch.zeros(1, dtype=torch.int64, device=device)
+            for p_ in model.parameters():
+                cs += p_.detach().contiguous().view(torch.int32).to(torch.int64).sum()
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_in_sync = bool((lo == hi).item())
         # self-check of the record: the number of ranks that really took part (an all-reduce of ones over the data-path
         # communicator) and every rank's own time for the K steps; `value` uses the MAX over ranks as the contract says
         ones = torch.ones(1, device=device)
@@ -363,7 +380,7 @@ def main():
                                    f"R={R} proposals/view, K={K}, VGG16 dilated-C5 + ROIPool 7x7 + fc6/fc7 4096 + WSDDN + 4 OICR heads, "
                                    "fwd+bwd+SGD(momentum, wd)", "views_per_step_per_gpu": 4 * B, "image": "one view",
                        "oicr_iterations_per_s": round(B * world * args.steps / dt, 3), "parallelism": f"dp{world}"},
-            "rccl_ranks": rccl_ranks, "backend": (dist.get_backend() if world > 1 else None),
+            "rccl_ranks": rccl_ranks, "backend": (dist.get_backend() if world > 1 else None), "ranks_in_sync": ranks_in_sync,
             "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
             "roofline": roofline,
             # the other two launches of the same GEMM family (`roofline` above is the costliest of the three)
@@ -392,8 +409,45 @@ def main():
             "step_launch": ({"mode": "hipGraph replay", "graph_replays": replays, "graph_captures": captures,
                              "eager_ms_per_step": round(eager_ms, 3), "instrumented_ms_per_step": round(instrumented_ms, 3)}
                             if graphs is not None else
+                            {"mode": "data parallel: 4 stage graphs + eager all-reduces between them", "graph_replays": replays,
+                             "graph_captures": captures, "eager_ms_per_step": round(eager_ms, 3),
+                             "instrumented_ms_per_step": round(instrumented_ms, 3)}
+                            if replays is not None else
                             {"mode": "eager launches", "instrumented_ms_per_step": round(instrumented_ms, 3)}),
         }
+        if world == 1 and dtype == torch.bfloat16:
+            # the same two kernels ALONE on the maps the recipe / COCO run on (round 6): conv5 at 99x165, ROIPool forward at 99x165 / 8000
+            # ROIs and 150x200 / 4000 ROIs (one call = view + flip of one scale), 10-20 launches each, HIP events on the launch stream
+            def alone_ms(fn, n):
+                for _ in range(3):
+                    fn()
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record()
+                for _ in range(n):
+                    fn()
+                b_.record(); torch.cuda.synchronize()
+                return a_.elapsed_time(b_) / n
+            xc = (torch.randn(2, 99, 165, 512, device=device) * 0.5).to(dtype); oc = torch.empty_like(xc)
+            tcv = alone_ms(lambda: ops.conv3x3(xc, wk5, oc, 2, ep5), 20)
+            flc = 2.0 * (2 * 99 * 165) * 512 * 4608
+            out["roofline_conv5_99x165_alone"] = {"kernel": "conv5 fwd, batch 2, 99x165, 512->512, dilation 2 (the COCO shape's map)", "bound": "mfma",
+                                                  "achieved": round(flc / (tcv * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                                                  "frac": round(flc / (tcv * 1e-3) / 1e12 / peak, 4), "avg_ms": round(tcv, 4)}
+            del xc, oc
+            gr = torch.Generator().manual_seed(0)
+            for (hm, wm, rr) in ((99, 165, 8000), (150, 200, 4000)):
+                x1_ = torch.rand(rr, generator=gr) * (wm * 8 - 32); y1_ = torch.rand(rr, generator=gr) * (hm * 8 - 32)
+                bw_ = 24 + torch.rand(rr, generator=gr) * (wm * 8 - x1_ - 24); bh_ = 24 + torch.rand(rr, generator=gr) * (hm * 8 - y1_ - 24)
+                rois_ = torch.stack([(torch.arange(rr) >= rr // 2).float(), x1_, y1_, (x1_ + bw_).clamp(max=wm * 8), (y1_ + bh_).clamp(max=hm * 8)], 1).to(device)
+                feat_ = torch.randn(2, hm, wm, 512, device=device).relu().to(dtype); obj_ = torch.rand(rr, device=device)
+                o_ = torch.empty(rr, 25088, device=device, dtype=dtype); a16 = torch.empty(rr, 25088, device=device, dtype=torch.int16)
+                tr_ = alone_ms(lambda: ops.roi_pool_fwd(feat_, rois_, o_, a16, 0.125, 7, 7, row_scale=obj_, row_scale_add=1.0), 10)
+                by_ = rr * 25088 * (es + 2) + 2 * hm * wm * 512 * es
+                out["roofline_roipool"][f"fwd_{hm}x{wm}"] = {"kernel": f"roi_pool_fwd alone: {rr} ROIs on a 2 x {hm}x{wm} x 512 map", "bound": "hbm",
+                                                            "achieved": round(by_ / (tr_ * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                                            "frac": round(by_ / (tr_ * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes": by_,
+                                                            "avg_ms": round(tr_, 4)}
+                del rois_, feat_, o_, a16
         phase("kernel timers + conv5_3 alone done")
         if world == 1 and dtype == torch.bfloat16 and not args.no_fp32_line:
             # the reference's own precision (fp32 storage, exact-f32 MFMA: 1/16 of the bf16 rate), a short run for the record
@@ -508,6 +562,58 @@ def main():
                 del dat
             out["recipe_ms_per_step"] = round(sum(per_pair) / len(per_pair), 3)
             out["recipe_pairs"] = {"short_sides": pairs_, "ms_per_step": per_pair, "image": "500x375 (W x H), R=2000, K=20"}
+            # (2c) the kernel families that dominate THERE (round 6): the recipe's mean scale (848: short sides 832 + 864, maps 104x139 and
+            # 108x144), every launch of a family timed live with HIP events on its stream over 3 eager steps.  The backbone's two scales
+            # run on two streams that share the CUs: a launch's duration holds the other stream's work too, so the conv rows also give
+            # the family's FLOP over HALF the summed durations ("two streams side by side").
+            s1, s2 = 832, 864
+            dat = make_inputs(device, 900 + s1, H=s1, W=int(500.0 / 375.0 * s1 + 0.5), scale2=s2 / s1)
+            for _ in range(2):
+                tmx.run_step(dat)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(3):
+                tmx.run_step(dat)
+            torch.cuda.synchronize()
+            mean_scale_ms = (time.perf_counter() - t1) / 3 * 1e3
+
+            def fam(t):
+                return "conv_fwd" if (t.endswith("_fwd") and ".conv" in t) else "conv_dgrad" if t.endswith("_dgrad") else None
+            ops.TIMER = ops.KernelTimer(["conv_fwd", "conv_dgrad", "wgrad_grouped", "roi_fwd", "roi_bwd"], family=fam)
+            for _ in range(3):
+                tmx.run_step(dat)
+            tms_, work_ = ops.TIMER.summary_ms(), dict(ops.TIMER.work)
+            ops.TIMER = None
+            pool3_ = lambda v: (((v - 2) // 2 + 1 - 2) // 2 + 1 - 2) // 2 + 1                    # three 2x2 / stride-2 pools (vgg.py:104-122)
+            W1_ = int(500.0 / 375.0 * s1 + 0.5)
+            H2_, W2_ = int(s1 * (s2 / s1) + 0.5), int(W1_ * (s2 / s1) + 0.5)                        # make_inputs' second scale
+            maps_ = [(pool3_(s1), pool3_(W1_)), (pool3_(H2_), pool3_(W2_))]
+
+            def mfma_row(tag_list, what, side_by_side):
+                sec = sum(sum(tms_[t]) for t in tag_list) * 1e-3
+                fl = sum(work_[t] for t in tag_list)
+                n_l = sum(len(tms_[t]) for t in tag_list)
+                if not sec:
+                    return None
+                row = {"kernel": what, "bound": "mfma", "peak": peak, "unit": "TFLOP/s", "launches_per_step": round(n_l / 3.0, 1),
+                       "ms_per_step_summed": round(sec / 3 * 1e3, 3), "gflop_per_step": round(fl / 3 / 1e9, 1),
+                       "achieved": round(fl / sec / 1e12, 1), "frac": round(fl / sec / 1e12 / peak, 4)}
+                if side_by_side:
+                    row["frac_two_streams_side_by_side"] = round(2.0 * fl / sec / 1e12 / peak, 4)
+                return row
+            roi_b = [2 * R * 25088 * (es + 2) + 2 * h_ * w_ * 512 * es for h_, w_ in maps_]
+            roi_s = sum(tms_["roi_fwd"]) * 1e-3
+            out["roofline_recipe"] = {
+                "shape": f"500x375 image at short sides {s1} + {s2} (the recipe's mean scale 848): views {s1}x{W1_} + {H2_}x{W2_}, "
+                         f"conv5 maps {maps_[0][0]}x{maps_[0][1]} and {maps_[1][0]}x{maps_[1][1]}, R={R}, K={K}, eager launches",
+                "ms_per_step": round(mean_scale_ms, 3),
+                "conv_fwd_dgrad": mfma_row(["conv_fwd", "conv_dgrad"], "conv3x3_direct_kernel: every forward + data-gradient convolution launch of the step", True),
+                "wgrad_grouped": mfma_row(["wgrad_grouped"], "conv_wgrad_direct_kernel: all weight gradients, one launch (folds not included)", False),
+                "roi_pool_fwd": ({"kernel": "roi_pool_fwd_sparse_kernel: 2 calls x 4000 ROIs x 512 x 7 x 7", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+                                  "algorithmic_bytes_per_step": sum(roi_b), "ms_per_step": round(roi_s / 3 * 1e3, 3),
+                                  "achieved": round(sum(roi_b) * 3 / roi_s / 1e9, 1), "frac": round(sum(roi_b) * 3 / roi_s / 1e9 / 8000.0, 4)}
+                                 if roi_s else None),
+                "source": "live HIP events (ops.KernelTimer, family tags); rocprofv3 summary of the same shape: profiles/r06_recipe_kernel_stats.csv"}
+            del dat
             phase("recipe-scale run")
             del tmx, mm
             _drop()
@@ -604,6 +710,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if ranks_in_sync is False:               # the line above says so; a run whose replicas diverged is not a measurement
+            print(f"[bench] rank {rank}: parameter checksums differ across ranks", file=sys.stderr, flush=True)
+            sys.exit(3)
 
 
 if __name__ == "__main__":

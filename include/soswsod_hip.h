@@ -534,6 +534,15 @@ int sw_roi_align_fwd(int dtype, int H, int W, int C, int PH, int PW, float spati
 int sw_roi_align_bwd(int dtype, int H, int W, int C, int PH, int PW, float spatial_scale, int sampling_ratio, const void* gout,
                      long ld, const float* rois, const int32_t* sel, int n_sel, const int32_t* n_sel_dev, float* dfeat_f32,
                      sw_stream_t stream);
+/* The deterministic backward of ROIAlign (the reference's CPU path, ROIAlign_cpu.cpp:286-400, is a sequential loop: reproducible; f32
+ * atomics are not): the same contributions as sw_roi_align_bwd accumulated as 64-bit fixed-point integers, llrint(v * 2^40 / max|gout|)
+ * — integer addition commutes, two runs give the same bits.  gout_absmax: DEVICE float holding max|gout| over the whole gradient
+ * (sw_absmax); acc_i64 [N][H][W][C] int64, zero-filled by the caller.  sw_fx_to_float: out[i] = acc[i] * absmax / 2^40 (f32 / bf16;
+ * every element NaN when absmax is NaN / Inf). */
+int sw_roi_align_bwd_fx(int dtype, int H, int W, int C, int PH, int PW, float spatial_scale, int sampling_ratio, const void* gout,
+                        long ld, const float* rois, const int32_t* sel, int n_sel, const int32_t* n_sel_dev, const float* gout_absmax,
+                        long long* acc_i64, sw_stream_t stream);
+int sw_fx_to_float(int out_dtype, long n, const long long* acc_i64, const float* absmax, void* out, sw_stream_t stream);
 /* Box2BoxTransform.apply_deltas (box_regression.py:76-116): out[i] = decode(deltas[i], boxes[i % n_boxes]); deltas row pitch
  * ld_deltas floats; weights4: HOST float[4]; dw, dh clamped to scale_clamp. */
 int sw_decode_boxes(long n, long n_boxes, const float* deltas, long ld_deltas, const float* boxes, const float* weights4,

@@ -216,6 +216,9 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_long, c_void_p]),
     "sw_roi_align_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p, c_void_p,
                                  c_int, c_void_p, c_void_p, c_void_p]),
+    "sw_roi_align_bwd_fx": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p, c_void_p,
+                                    c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sw_fx_to_float": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sw_wsddn_scores_bwd_workspace_floats": (c_long, [c_int, c_int]),
     "sw_wsddn_scores_bwd": (c_int, [c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p]),
     "sw_scale_col_blocks": (c_int, [c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),

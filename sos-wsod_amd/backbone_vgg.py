@@ -315,7 +315,7 @@ class _VGGFunction(torch.autograd.Function):
         if side is not None:
             main.wait_stream(side)
         if deferred:
-            ops.conv3x3_wgrad_grouped(deferred)
+            ops.conv3x3_wgrad_grouped(deferred, tag="wgrad_grouped")
             ops.colsum_partial_multi(module._colsum_deferred)
             deferred.clear()
         module._colsum_deferred = []
@@ -370,7 +370,7 @@ class _VGGFunction(torch.autograd.Function):
                 if not (module.winograd_ok(blk.out_channels, cin) and
                         ops.conv3x3_winograd(dz, module.winograd_weight(w, 1), dx, blk.dilation, epd)):
                     wkd = module.staged_weight(w, 1, cin, dtype)
-                    ops.conv3x3(dz, wkd, dx, blk.dilation, epd)
+                    ops.conv3x3(dz, wkd, dx, blk.dilation, epd, tag=f"{blk.tag}.conv{ci + 1}_dgrad")
                 dz = dx
             # dz is now the gradient wrt this stage's input = previous stage's pooled output
             prev_pre_pool = stage_info[si - 1][1]

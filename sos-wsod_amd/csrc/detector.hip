@@ -415,6 +415,71 @@ __global__ void roi_align_bwd_kernel(int H, int W, int C, int PH, int PW, float 
   }
 }
 
+// Deterministic backward (round 6).  The f32 atomics above add in arrival order: two runs of one iteration differ in the last bits of
+// the feature gradients, the student drifts, pseudo boxes jitter, position-keyed anchor sampling flips (tests had to allow 6e-2 on the
+// pseudo RPN losses).  Here the SAME contributions are accumulated as 64-bit fixed-point integers — integer addition commutes, so the sum
+// does not depend on the order: contribution v (|v| <= max|gout|: a bin hands out exactly its gradient, weights sum to count) is added as
+// llrint(v * 2^40 / max|gout|); a pixel collects at most R * PH * PW * 2^40 < 2^63 for R < 170 000 ROIs; resolution 2^-40 of the largest
+// gradient against f32's 2^-24.  acc [N][H][W][C] int64, zero-filled by the caller; fx_to_float_kernel turns it into the map (NaN / Inf in
+// gout: absmax reports it, the whole map comes out NaN — the f32 form poisoned the pixels the ROI touched).
+constexpr float FX_ONE = 1099511627776.0f;          // 2^40
+template <typename T>
+__global__ void roi_align_bwd_fx_kernel(int H, int W, int C, int PH, int PW, float scale, int sampling_ratio,
+                                        const T* __restrict__ gout, long ld, const float* __restrict__ rois,
+                                        const int* __restrict__ sel, int n_sel, const int* __restrict__ n_sel_dev,
+                                        const float* __restrict__ absmax, unsigned long long* __restrict__ acc) {
+  const float am = absmax[0];
+  if (!(am > 0.f) || !(am <= 3.0e38f)) return;                      // zero gradient: nothing to add; NaN / Inf: the conversion reports it
+  const float S = __fdiv_rn(FX_ONE, am);
+  const long n = (long)(n_sel_dev ? min(n_sel_dev[0], n_sel) : n_sel) * PH * PW * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long r = i / C;
+    const int pw = (int)(r % PW); r /= PW;
+    const int ph = (int)(r % PH); const int s = (int)(r / PH);
+    const int row = sel[s];
+    const AlignGeom g = align_geom(rois + (long)row * 5, scale, PH, PW, sampling_ratio);
+    const float go = Elem<T>::load(gout + (long)row * ld + ((long)c * PH + ph) * PW + pw);
+    unsigned long long* d = acc + (long)g.batch * H * W * C + c;
+    auto add = [&](unsigned long long* p, float v) { atomicAdd(p, (unsigned long long)__float2ll_rn(__fmul_rn(v, S))); };
+    if (g.grid_h < AXIS_MAX && g.grid_w < AXIS_MAX && g.bin_h <= (float)g.grid_h && g.bin_w <= (float)g.grid_w) {
+      const AxisW ay = align_axis_weights(g.start_h, ph, g.bin_h, g.grid_h, H);
+      const AxisW ax = align_axis_weights(g.start_w, pw, g.bin_w, g.grid_w, W);
+      if (ay.base < 0 || ax.base < 0) continue;
+      const float gs = __fdiv_rn(go, g.count);
+#pragma unroll
+      for (int ry = 0; ry < AXIS_MAX; ++ry) {
+        if (ay.w[ry] == 0.f) continue;
+        const float gy = __fmul_rn(gs, ay.w[ry]);
+        unsigned long long* drow = d + (long)(ay.base + ry) * W * C;
+#pragma unroll
+        for (int rx = 0; rx < AXIS_MAX; ++rx)
+          if (ax.w[rx] != 0.f) add(drow + (long)(ax.base + rx) * C, __fmul_rn(gy, ax.w[rx]));
+      }
+      continue;
+    }
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+      const float y = align_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        const float x = align_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
+        int yl, xl, yh, xh; float wg[4];
+        if (!align_corners(H, W, y, x, &yl, &xl, &yh, &xh, wg)) continue;
+        add(d + ((long)yl * W + xl) * C, __fdiv_rn(__fmul_rn(go, wg[0]), g.count));
+        add(d + ((long)yl * W + xh) * C, __fdiv_rn(__fmul_rn(go, wg[1]), g.count));
+        add(d + ((long)yh * W + xl) * C, __fdiv_rn(__fmul_rn(go, wg[2]), g.count));
+        add(d + ((long)yh * W + xh) * C, __fdiv_rn(__fmul_rn(go, wg[3]), g.count));
+      }
+    }
+  }
+}
+template <typename T>
+__global__ void fx_to_float_kernel(long n, const long long* __restrict__ acc, const float* __restrict__ absmax, T* __restrict__ out) {
+  const float am = absmax[0];
+  const bool bad = !(am <= 3.0e38f);                                  // NaN or Inf somewhere in the gradient
+  const double inv = (double)am / (double)FX_ONE;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    Elem<T>::store(out + i, bad ? __uint_as_float(0x7FC00000u) : (float)((double)acc[i] * inv));
+}
+
 // ------------------------------------------------------------------------------------------- box decoding, RPN losses
 // Box2BoxTransform.apply_deltas (detectron2/modeling/box_regression.py:76-116): deltas [n][4], boxes [n][4] (row r of boxes is
 // r % n_boxes: the anchors repeat over the images) -> out [n][4]
@@ -781,6 +846,34 @@ extern "C" int sw_roi_align_bwd(int dtype, int H, int W, int C, int PH, int PW, 
                        spatial_scale, sampling_ratio, (const unsigned short*)gout, ld, rois, sel, n_sel, n_sel_dev, dfeat_f32),
     hipLaunchKernelGGL(roi_align_bwd_kernel<float>, dim3(grid_for_n(n)), dim3(256), 0, stream, H, W, C, PH, PW, spatial_scale,
                        sampling_ratio, (const float*)gout, ld, rois, sel, n_sel, n_sel_dev, dfeat_f32));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_roi_align_bwd_fx(int dtype, int H, int W, int C, int PH, int PW, float spatial_scale, int sampling_ratio,
+                                   const void* gout, long ld, const float* rois, const int32_t* sel, int n_sel, const int32_t* n_sel_dev,
+                                   const float* gout_absmax, long long* acc_i64, hipStream_t stream) {
+  SW_ENTER();
+  if (n_sel <= 0) return 0;
+  if (ld < (long)C * PH * PW || !gout_absmax || !acc_i64) return -5;
+  const long n = (long)n_sel * PH * PW * C;
+  DISPATCH_T(dtype,
+    hipLaunchKernelGGL(roi_align_bwd_fx_kernel<unsigned short>, dim3(grid_for_n(n)), dim3(256), 0, stream, H, W, C, PH, PW,
+                       spatial_scale, sampling_ratio, (const unsigned short*)gout, ld, rois, sel, n_sel, n_sel_dev, gout_absmax,
+                       (unsigned long long*)acc_i64),
+    hipLaunchKernelGGL(roi_align_bwd_fx_kernel<float>, dim3(grid_for_n(n)), dim3(256), 0, stream, H, W, C, PH, PW, spatial_scale,
+                       sampling_ratio, (const float*)gout, ld, rois, sel, n_sel, n_sel_dev, gout_absmax, (unsigned long long*)acc_i64));
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sw_fx_to_float(int out_dtype, long n, const long long* acc_i64, const float* absmax, void* out, hipStream_t stream) {
+  SW_ENTER();
+  if (n <= 0) return 0;
+  if (!acc_i64 || !absmax || !out) return -5;
+  DISPATCH_T(out_dtype,
+    hipLaunchKernelGGL(fx_to_float_kernel<unsigned short>, dim3(grid_for_n(n)), dim3(256), 0, stream, n, acc_i64, absmax, (unsigned short*)out),
+    hipLaunchKernelGGL(fx_to_float_kernel<float>, dim3(grid_for_n(n)), dim3(256), 0, stream, n, acc_i64, absmax, (float*)out));
   SW_CHECK_LAUNCH();
   return 0;
 }

@@ -58,6 +58,8 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
+_ALIGN_BWD_FX = os.environ.get("SW_ROI_ALIGN_BWD_FX", "1") == "1"     # development switch: "0" = the f32-atomic ROIAlign backward
+
 class _Staged:
     """what one layer reads from the model's stage plan: w (+ wd: 3x3 data-gradient layout), scale / shift (FrozenBN) or packed bias"""
     __slots__ = ("w", "wd", "scale", "shift", "bias")
@@ -702,10 +704,20 @@ class _RoIAlignFn(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         grads = []
+        amax = None
         R = ctx.rois.shape[0]
         for l, (shp, sc, need) in enumerate(zip(ctx.shapes, ctx.scales, ctx.needs_input_grad[4:])):
             if not need:
                 grads.append(None)
+                continue
+            if _ALIGN_BWD_FX and R:
+                # deterministic (round 6): 64-bit fixed-point accumulation, one conversion into the map's dtype (csrc/detector.hip
+                # roi_align_bwd_fx_kernel) — the float-atomic form below left the iteration irreproducible in the last bits
+                if amax is None:
+                    amax = ops.absmax(g)
+                acc = ops.fill_zero(torch.empty(shp, device=g.device, dtype=torch.int64))
+                ops.roi_align_bwd_fx(g, ctx.rois, ctx.sel[l], acc, sc, amax, n_sel_dev=ctx.sel_cnt[l:l + 1])
+                grads.append(ops.fx_to_float(acc, amax, torch.empty(shp, device=g.device, dtype=ctx.dtype)))
                 continue
             d = ops.fill_zero(torch.empty(shp, device=g.device, dtype=torch.float32))
             if R:
@@ -1603,6 +1615,10 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
         ws = self.__dict__.get("_weight_stage")
         if ws is None or not ws.valid_for(self.compute_dtype):
             ws = self.__dict__["_weight_stage"] = WeightStage(self, self.compute_dtype)
+            # the captured no-grad backbone graphs (_features) replay against the OLD stage's buffers: a re-homed parameter (.to(),
+            # load_state_dict(assign=True), a flat-master re-pack, another compute dtype) would leave the teacher emitting features of
+            # stale weights with no error — they go with the stage they were captured on
+            self.__dict__.pop("_bb_graphs", None)
         ws.refresh()
 
     @property
@@ -1627,7 +1643,7 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
 
     BACKBONE_GRAPHS = 6          # input shapes whose no-grad backbone pass is kept as a hipGraph (least recently used goes)
 
-    def _features(self, x4):
+    def _features(self, x4, allow_graph=False):
         """FPN features of a preprocessed batch.  Under torch.no_grad() (the teacher's weak pass, inference) the ~105 launches of the
         ResNet-50 + FPN are shape-static and leave no autograd state: the second time an input shape is seen they are captured, from
         then on ONE hipGraph replay into the graph's own buffers (valid until the next call with this shape; every consumer runs on
@@ -1639,7 +1655,10 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
         semisup.SemiSupStep for what it does once those are gone."""
         env = os.environ.get("SW_S3_BACKBONE_GRAPH")
         on = self.graph_nograd_backbone if env is None else env == "1"
-        if torch.is_grad_enabled() or not on or not x4.is_cuda or ops.TIMER is not None or torch.cuda.is_current_stream_capturing():
+        # allow_graph: only the training iteration's weak pass (forward(branch="unsup_data_weak")) — evaluation (inference()) sees many
+        # padded shapes once each; with 6 graphs kept it would capture, evict and re-capture (a synchronize + an activation pool each)
+        if (not allow_graph or torch.is_grad_enabled() or not on or not x4.is_cuda or ops.TIMER is not None
+                or torch.cuda.is_current_stream_capturing()):
             return self.backbone(x4)
         # What the backbone reads besides the input and the staged weights (refresh_staged_weights, done by the caller) must be brought
         # up to date HERE, outside the graph, into buffers that never move: the stem's FrozenBN fold is cached per buffer epoch — a
@@ -1647,7 +1666,9 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
         # one EMA epoch: stale fold, 2 % off in the pseudo losses; tools/diag/s3_graph_debug.py)
         self.backbone.bottom_up.stem.conv1.norm.fold()
         cache = self.__dict__.setdefault("_bb_graphs", OrderedDict())
-        key = (tuple(x4.shape), x4.dtype, x4.device.index)
+        # what a capture bakes in besides the shape: the stage's staged buffers and the stem's weight / fold buffers
+        stem = self.backbone.bottom_up.stem.conv1
+        key = (tuple(x4.shape), x4.dtype, x4.device.index, id(self.__dict__.get("_weight_stage")), stem.weight.data_ptr())
         hit = cache.get(key)
         if hit is None:
             cache[key] = 1                                               # seen once: eager (caches and workspaces warm up)
@@ -1700,7 +1721,7 @@ class TwoStagePseudoLabGeneralizedRCNN(nn.Module):
             return tuple(results)
         x4, sizes = self.preprocess_image(batched_inputs)
         gt = [x["instances"] for x in batched_inputs] if "instances" in batched_inputs[0] else None
-        feats = self._features(x4)
+        feats = self._features(x4, allow_graph=(branch == "unsup_data_weak"))
         if branch == "supervised":
             proposals, rpn_losses = self.proposal_generator(sizes, feats, gt)
             _, det_losses = self.roi_heads(feats, proposals, gt, branch=branch)

@@ -39,17 +39,27 @@ class KernelTimer:
     """Optional in-process timing of tagged launches with HIP events recorded on the launch stream (used by
     bench.py to price the dominant kernels live; off by default => zero overhead)."""
 
-    def __init__(self, tags):
+    def __init__(self, tags, family=None):
+        """family: optional callable tag -> one of `tags` (or None): several call sites timed under one key, e.g. every backbone
+        convolution's forward launch (tags "plain3.conv2_fwd", ...) as "conv_fwd" """
         self.tags = set(tags)
+        self.family = family
         self.pairs = {t: [] for t in tags}
         self.work = {t: 0.0 for t in tags}        # algorithmic work (FLOP or bytes) noted by the call sites of a tag
 
-    def note(self, tag, amount):
+    def _key(self, tag):
         if tag in self.tags:
+            return tag
+        return self.family(tag) if self.family is not None else None
+
+    def note(self, tag, amount):
+        tag = self._key(tag)
+        if tag is not None:
             self.work[tag] += float(amount)
 
     def wrap(self, tag, fn):
-        if tag not in self.tags:
+        tag = self._key(tag)
+        if tag is None:
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -356,6 +366,8 @@ def conv3x3(x, wk, out, dilation, ep, tag=None):
     _need_gpu(x, wk, out)
     n, H, W, Cin = x.shape
     Cout = out.shape[3]
+    if TIMER is not None and tag is not None:
+        TIMER.note(tag, 2.0 * n * H * W * Cout * 9 * Cin)
     check(_launch(tag, lambda: lib.sw_conv3x3_igemm(dt(x), n, H, W, Cin, Cout, dilation, _p(x), _p(wk), _p(out),
                                                     ctypes.byref(ep), _stream())), "sw_conv3x3_igemm")
     return out
@@ -367,6 +379,8 @@ def conv3x3_relu_pool2(x, wk, bias, out_pooled, tag=None):
     _need_gpu(x, wk, out_pooled)
     n, H, W, Cin = x.shape
     Cout = out_pooled.shape[3]
+    if TIMER is not None and tag is not None:
+        TIMER.note(tag, 2.0 * n * H * W * Cout * 9 * Cin)
     rc = _launch(tag, lambda: lib.sw_conv3x3_relu_pool2(dt(x), n, H, W, Cin, Cout, _p(x), _p(wk), _p(bias), _p(out_pooled), _stream()))
     if rc < 0:
         check(rc, "sw_conv3x3_relu_pool2")
@@ -435,7 +449,7 @@ def conv3x3_wgrad_slabs(x, dy, workspace, dilation, splitk=1):
                                      _stream()), "sw_conv3x3_wgrad_slabs")
 
 
-def conv3x3_wgrad_grouped(problems):
+def conv3x3_wgrad_grouped(problems, tag=None):
     """problems: list of (x NHWC, dy NHWC, slabs f32 tensor, dilation, nsplit) — every weight gradient of a backward pass in one
     launch (sw_conv3x3_wgrad_grouped); each writes conv3x3_wgrad_nslab(x, cout, nsplit) slabs at `slabs`"""
     from ._lib import WgradProblem
@@ -449,7 +463,9 @@ def conv3x3_wgrad_grouped(problems):
         q.nimg, q.H, q.W, q.Cin = x.shape
         q.Cout, q.dilation, q.nsplit = dy.shape[3], int(dil), int(nsplit)
         q.x, q.dy, q.slabs = x.data_ptr(), dy.data_ptr(), slabs.data_ptr()
-    check(lib.sw_conv3x3_wgrad_grouped(dt(problems[0][0]), n, arr, _stream()), "sw_conv3x3_wgrad_grouped")
+    if TIMER is not None and tag is not None:
+        TIMER.note(tag, sum(2.0 * x.numel() * 9 * dy.shape[3] for x, dy, _, _, _ in problems))
+    check(_launch(tag, lambda: lib.sw_conv3x3_wgrad_grouped(dt(problems[0][0]), n, arr, _stream())), "sw_conv3x3_wgrad_grouped")
 
 
 def conv3x3_wgrad_fold(workspace, nslab, dw_oihw, cout_scale=None, accumulate=False):
@@ -1118,6 +1134,25 @@ def roi_align_bwd(gout, rois, sel_i32, dfeat_f32, scale, PH=7, PW=7, sampling_ra
     check(lib.sw_roi_align_bwd(dt(gout), H, W, C, PH, PW, float(scale), sampling_ratio, _p(gout), gout.stride(0), _p(rois),
                                _p(sel_i32), sel_i32.numel(), _p(n_sel_dev), _p(dfeat_f32), _stream()), "sw_roi_align_bwd")
     return dfeat_f32
+
+
+def roi_align_bwd_fx(gout, rois, sel_i32, acc_i64, scale, gout_absmax, PH=7, PW=7, sampling_ratio=0, n_sel_dev=None):
+    """the deterministic ROIAlign backward (sw_roi_align_bwd_fx): acc_i64 (N, H, W, C) int64, zero-filled, collects the level's
+    contributions as 64-bit fixed-point integers scaled by 2^40 / gout_absmax (device scalar from ops.absmax(gout)); fx_to_float
+    turns it into the gradient map"""
+    _need_gpu(gout, rois, sel_i32, acc_i64, gout_absmax)
+    assert acc_i64.dtype == torch.int64 and acc_i64.is_contiguous()
+    n, H, W, C = acc_i64.shape
+    check(lib.sw_roi_align_bwd_fx(dt(gout), H, W, C, PH, PW, float(scale), sampling_ratio, _p(gout), gout.stride(0), _p(rois),
+                                  _p(sel_i32), sel_i32.numel(), _p(n_sel_dev), _p(gout_absmax), _p(acc_i64), _stream()), "sw_roi_align_bwd_fx")
+
+
+def fx_to_float(acc_i64, absmax, out):
+    """out[i] = acc_i64[i] * absmax / 2^40 (sw_fx_to_float); out f32 or bf16, same element count"""
+    _need_gpu(acc_i64, absmax, out)
+    assert acc_i64.dtype == torch.int64 and out.numel() == acc_i64.numel() and out.is_contiguous()
+    check(lib.sw_fx_to_float(dt(out), acc_i64.numel(), _p(acc_i64), _p(absmax), _p(out), _stream()), "sw_fx_to_float")
+    return out
 
 
 def wsddn_scores_bwd(logits, K, g_scores, dlogits):

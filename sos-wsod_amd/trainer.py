@@ -79,11 +79,13 @@ class Trainer:
         self._bucket_views = []
         self._native = None
         self.overlap_update = False
-        # The data-parallel step WITHOUT torch's reducer (round 5; default for the OICR+ model on GPUs with HipSGD and ITER_SIZE 1,
-        # SW_DDP_NATIVE=0 keeps DistributedDataParallel): flat gradient buckets the kernels write into, the backward cut into four
-        # stages at the heads' node boundaries, one all-reduce per bucket issued between the stages, the update of a bucket queued
-        # behind its all-reduce — and, because nothing of the collective lives inside the stages, each stage is a hipGraph.
-        native_ok = (use_ddp and os.environ.get("SW_DDP_NATIVE", "1") == "1" and self.iter_size == 1 and not find_unused
+        # The data-parallel step WITHOUT torch's reducer (round 5; default for the OICR+ model on GPUs with HipSGD, SW_DDP_NATIVE=0
+        # keeps DistributedDataParallel): flat gradient buckets the kernels write into, the backward cut into four stages at the
+        # heads' node boundaries, one all-reduce per bucket issued between the stages, the update of a bucket queued behind its
+        # all-reduce — and, because nothing of the collective lives inside the stages, each stage is a hipGraph.  Round 6: also under
+        # gradient accumulation (ITER_SIZE > 1, what auto_scale_workers sets on 1-4 GPUs): micro-steps add into a second flat
+        # buffer per bucket and only the stepping iteration all-reduces and updates (_NativeDDP docstring).
+        native_ok = (use_ddp and os.environ.get("SW_DDP_NATIVE", "1") == "1" and not find_unused
                      and hasattr(optimizer, "step_params") and hasattr(model, "roi_heads") and hasattr(model, "backbone")
                      and next(model.parameters()).is_cuda and dist.is_available() and dist.is_initialized())
         if native_ok:
@@ -258,7 +260,8 @@ class Trainer:
             for i, k in enumerate(loss_dict.keys()):
                 self.storage.put_scalar(k, vec[i])
             self.storage.put_scalar("total_loss", vec.sum() if tot is None else tot)
-            if self._graphs is not None and self._graphs.last_step_replayed:
+            if ((self._graphs is not None and self._graphs.last_step_replayed)
+                    or (self._native is not None and self._native.last_step_replayed)):
                 # a replay does not run the heads' Python (which records these in eager steps): the counts are static graph outputs
                 aux = getattr(self.raw_model.roi_heads, "last_aux", None) or {}
                 for k, r in enumerate(aux.get("rounds", [])):
@@ -301,6 +304,8 @@ class _Bucket:
         for p, v in zip(self.params, self.views):
             p.__dict__["_sw_grad_view"] = v
         self.work = []
+        self.acc = None                  # gradient accumulation (ITER_SIZE > 1): the micro-steps' sum so far, allocated on first use
+        self.n_acc = 0
 
     def gather(self):
         from . import ops
@@ -329,7 +334,13 @@ class _NativeDDP:
     The stages are cut with `torch.autograd.backward(..., inputs=...)` at the heads' handle tensors (roi_heads_oicrplus._cuts); the
     collectives are plain eager `dist.all_reduce(async_op=True)` calls BETWEEN stages, the updates run on a side stream — so with
     use_graph every stage is one captured hipGraph (RCCL inside a capture segfaults on this stack; here it never is inside one).
-    Gradients are summed with the backward seeded by 1 / world (no averaging pass), as the torch-DDP path does."""
+    Gradients are summed with the backward seeded by 1 / world (no averaging pass), as the torch-DDP path does.
+
+    Gradient accumulation (ITER_SIZE > 1; train_net_multi.py:143-164 steps when iter % ITER_SIZE == 0 and never uses no_sync, so the
+    reference all-reduces 543 MB on EVERY micro-step): a non-stepping iteration runs the same four stages and adds each
+    bucket into its accumulation buffer — no collective, no update; the stepping iteration adds the accumulated sum to its own gradient,
+    then all-reduces and updates as above.  Same value as the reference's (mean over ranks of every micro-step, summed) up to the
+    order of the f32 additions; same collectives on every rank (the iteration counter decides, not the data)."""
 
     def __init__(self, trainer, model, optimizer, grad_compress=None, use_graph=False):
         self.tr, self.model, self.opt = trainer, model, optimizer
@@ -361,7 +372,11 @@ class _NativeDDP:
         self._dbg_sync = os.environ.get("SW_DDP_DEBUG_SYNC", "0") == "1"          # development switches
         self._dbg_upd_main = os.environ.get("SW_DDP_UPD_MAIN", "0") == "1"
         n_pan = int(os.environ.get("SW_DDP_FC1_PANELS", "0"))
-        self.panels = n_pan if n_pan > 1 else 0
+        # row panels of fc1.weight's gradient are all-reduced from inside the eager S2; a rank that REPLAYS its stage graph would issue
+        # one all-reduce of the whole bucket instead — ranks pick eager / replay by their own input signature, so with stage graphs
+        # (or accumulation: a panel would leave before the accumulated sum is added) the collective layout stays the rank-invariant
+        # one: whole buckets
+        self.panels = n_pan if (n_pan > 1 and not use_graph and trainer.iter_size == 1) else 0
         self._panel_work = []
         self.use_graph = bool(use_graph)
         self.graphs = OrderedDict()
@@ -372,6 +387,7 @@ class _NativeDDP:
         if use_graph and hasattr(optimizer, "sync_hyper"):
             optimizer.device_hyper = True
         self._live = None
+        self.last_step_replayed = False
 
     # ------------------------------------------------------------------ the four stages (eager, or inside a capture)
     def _s1(self, data):
@@ -407,6 +423,7 @@ class _NativeDDP:
     def _allreduce(self, t):
         if self.compress == "bf16":                                # opt-in, NOT the reference's numerics: half the bytes on the ring
             c = t.to(torch.bfloat16)
+            c.record_stream(self.upd)                              # consumed by t.copy_(c) on the update stream (_wait)
             w = dist.all_reduce(c, group=self.group, async_op=True)
             return (w, c, t)
         return (dist.all_reduce(t, group=self.group, async_op=True), None, t)
@@ -441,6 +458,24 @@ class _NativeDDP:
     def _panel_cb(self, i, rows):
         self._panel_work.append(self._allreduce(rows))
 
+    def _finish_bucket(self, i, stepping, after=None):
+        """bucket i's stage has run: stepping iteration -> (accumulated sum +) all-reduce, update behind it; else add into the accumulator"""
+        b = self.buckets[i]
+        if stepping:
+            if b.n_acc:
+                b.flat.add_(b.acc)
+                b.n_acc = 0
+            self._reduce(i)
+            return True
+        if b.acc is None:
+            b.acc = torch.empty_like(b.flat)
+        if b.n_acc:
+            b.acc.add_(b.flat)
+        else:
+            b.acc.copy_(b.flat)
+        b.n_acc += 1
+        return False
+
     # ------------------------------------------------------------------ one step
     def step(self, data):
         caller = torch.cuda.current_stream()
@@ -467,16 +502,20 @@ class _NativeDDP:
             self.replays += 1
         else:
             stages = (lambda: self._s1(data), self._s2, self._s3, self._s4)
+        stepping = tr.iter % tr.iter_size == 0                      # train_net_multi.py:149 (first step at iteration 0)
         try:
             stages[0]()
-            self._reduce(0); self._update(0)
+            if self._finish_bucket(0, stepping):
+                self._update(0)
             stages[1]()
-            self._reduce(1)
+            red1 = self._finish_bucket(1, stepping)
             stages[2]()
-            e3 = torch.cuda.Event(); e3.record(main)
-            self._update(1, after=e3)
+            if red1:
+                e3 = torch.cuda.Event(); e3.record(main)
+                self._update(1, after=e3)
             stages[3]()
-            self._reduce(2); self._update(2)
+            if self._finish_bucket(2, stepping):
+                self._update(2)
         finally:
             self.heads._fc6_panels = None
             self.heads._prestaged_labels = None
@@ -484,8 +523,9 @@ class _NativeDDP:
         if hit is None:
             loss_dict, total = self._live[0], self._live[1]
             self._live = None
-        self.opt.step()                                             # (nothing is left for it: every parameter sits in a bucket)
-        self.opt.zero_grad()
+        if stepping:
+            self.opt.step()                                         # (nothing is left for it: every parameter sits in a bucket)
+        self.opt.zero_grad()                                        # (.grad are views of the buckets: the next backward writes them anew)
         self.last_step_replayed = hit is not None
         return loss_dict, total
 

@@ -70,11 +70,13 @@ def main():
 
     from sos_wsod_amd.events import EventStorage
     # ---- single-process replica: per step the mean of both ranks' gradients, own HipSGD
-    N_STEPS = 1 if full else (5 if graph else 3)
+    ITER_SIZE = int(os.environ.get("SW_TEST_ITER_SIZE", "1"))      # > 1: gradient accumulation, step when iter % ITER_SIZE == 0 (train_net_multi.py:149)
+    N_STEPS = 1 if full else (5 if (graph or ITER_SIZE > 1) else 3)
     rep = fresh()
     rep_opt = HipSGD(groups(rep), LR, momentum=0.9)
     counters = [0, 0]
     mean_grads = []
+    rep_acc = None
     for step in range(N_STEPS):
         acc = None
         for r in range(2):
@@ -87,19 +89,24 @@ def main():
             counters[r] = rep.roi_heads._drop_counter
             g = {n: p.grad.detach().clone() for n, p in rep.named_parameters() if p.grad is not None}
             acc = g if acc is None else {n: (acc[n] + g[n]) for n in acc}
-        mean = {n: v / 2 for n, v in acc.items()}
-        mean_grads.append(mean)
-        for n, p in rep.named_parameters():
-            p.grad = mean.get(n)
-        rep_opt.step()
-        rep_opt.zero_grad()
+        mean = {n: v / 2 / ITER_SIZE for n, v in acc.items()}       # (losses / ITER_SIZE).backward(), mean over the ranks
+        rep_acc = mean if rep_acc is None else {n: rep_acc[n] + mean[n] for n in mean}
+        if step % ITER_SIZE == 0:
+            mean_grads.append(rep_acc)                                # what the optimizer consumes at this stepping iteration
+            for n, p in rep.named_parameters():
+                p.grad = rep_acc.get(n)
+            rep_opt.step()
+            rep_opt.zero_grad()
+            rep_acc = None
+        else:
+            mean_grads.append(None)                                   # accumulating iteration: nothing reduced, nothing applied
     torch.cuda.synchronize()
 
     # ---- the DDP run
     model = fresh()
     set_stream(model, rank, 0)
     opt = HipSGD(groups(model), LR, momentum=0.9)
-    tr = Trainer(model, opt, check_finite_every=1, metrics_period=1)
+    tr = Trainer(model, opt, check_finite_every=1, metrics_period=1, iter_size=ITER_SIZE)
     native = os.environ.get("SW_DDP_NATIVE", "1") == "1"
     assert (tr._native is not None) if native else isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
     name_of = {id(p): n for n, p in model.named_parameters()}
@@ -124,6 +131,9 @@ def main():
             # the reduced gradients live in the reducer's flat buckets (a replayed stage graph runs no autograd: .grad stays None)
             torch.cuda.synchronize()
             seen = {name_of[id(p)]: v.detach().clone() for b in tr._native.buckets for p, v in zip(b.params, b.views)}
+        if mean_grads[step] is None:                                  # accumulating iteration: no optimizer step, no collective
+            assert ITER_SIZE > 1 and step % ITER_SIZE != 0
+            continue
         assert set(seen) == set(mean_grads[step])
         for n, g in seen.items():
             ref = mean_grads[step][n]

@@ -68,6 +68,30 @@ def test_real_model_two_ranks_gradients_and_parameters(tmp_path, dtype, mode):
         assert res["overlap_update"] and set(res["left_for_step"]) == {0}, res["left_for_step"]
 
 
+@pytest.mark.parametrize("mode", ["native", "native-graph", "torch-ddp"])
+def test_real_model_two_ranks_gradient_accumulation(tmp_path, mode):
+    """ITER_SIZE = 2 (what auto_scale_workers sets when fewer GPUs than the recipe's run it, train_net_multi.py:306-324): the optimizer
+    steps at iterations 0, 2, 4 on the sum of the micro-steps' rank-mean gradients.  trainer._NativeDDP accumulates in a second flat
+    buffer per bucket and all-reduces only at the stepping iterations (round 6; the reference and torch DDP all-reduce every micro-step):
+    reduced gradients at every stepping iteration == the single-process replica's accumulated mean, parameters identical across the
+    ranks and equal to the replica's after 5 iterations — eager stages, stage graphs, and the torch-DDP path."""
+    out = str(tmp_path / "ddpacc")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_real_worker.py"), out, "bf16"]
+    extra = {"native": {}, "native-graph": {"SW_STEP_GRAPH": "1"}, "torch-ddp": {"SW_DDP_NATIVE": "0"}}[mode]
+    r = subprocess.run(cmd, env=dict(_env(), SW_TEST_ITER_SIZE="2", **extra), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    for rank in range(2):
+        res = torch.load(f"{out}.rank{rank}")
+        assert res["native"] == (mode != "torch-ddp")
+        if mode == "native-graph":
+            assert res["replays"] >= 2, res["replays"]
+        assert len(res["grad_err"]) > 0 and max(res["grad_err"]) <= 2e-6, max(res["grad_err"])     # (sum of means vs mean of sums: f32 rounding)
+        assert res["same_across_ranks"]
+        assert res["replica_err"] <= 2e-6, res["replica_err"]
+        assert res["moved"] > 0
+
+
 @pytest.mark.parametrize("panels", [0, 4])
 def test_real_model_two_ranks_at_config3_per_gpu_size(tmp_path, panels):
     """the same check once at BASELINE config #3's per-rank shape (512x512 views, R = 2000, fc 4096/4096, bf16): 543 MB of

@@ -97,6 +97,46 @@ def test_roi_align_forward_backward_against_the_c_oracle(ops):
     np.testing.assert_allclose(d.permute(0, 3, 1, 2).cpu().numpy(), gref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_roi_align_backward_fixed_point_form_is_reproducible(ops, dtype):
+    """sw_roi_align_bwd_fx (round 6): the ROIAlign backward as 64-bit fixed-point integer accumulation — against the C oracle (the
+    reference's sequential CPU loop, ROIAlign_cpu.cpp:286-400), BIT-equal over repeated runs with 2000 heavily overlapping ROIs (the f32
+    atomic form is checked to be the close-but-not-reproducible one it replaces), zero gradients, and a NaN in the gradient poisons the map"""
+    torch.manual_seed(3)
+    N, C, H, W, R = 2, 32, 25, 38, 2000
+    x1 = torch.rand(R) * 240; y1 = torch.rand(R) * 150
+    rois = torch.stack([(torch.arange(R) % N).float(), x1, y1, x1 + 2 + torch.rand(R) * 200, y1 + 2 + torch.rand(R) * 120], 1)
+    rois[:4, 1:] = torch.tensor([[-30.0, -20.0, 10.0, 12.0], [280.0, 180.0, 330.0, 230.0], [5.0, 5.0, 5.5, 5.5], [0.0, 0.0, 304.0, 200.0]])
+    scale = 1.0 / 8
+    g = (torch.randn(R, C, 7, 7) * torch.exp(torch.randn(R, 1, 1, 1) * 2)).to(dtype)       # heavy-tailed magnitudes
+    gref = FO.roi_align_bwd(g.float().numpy(), rois.numpy(), scale, (N, C, H, W))
+    gc, rc = g.view(R, -1).cuda().contiguous(), rois.cuda()
+    sel = torch.arange(R, dtype=torch.int32).cuda()
+    amax = ops.absmax(gc)
+    assert float(amax) == float(g.float().abs().max())
+
+    def run():
+        acc = torch.zeros(N, H, W, C, device="cuda", dtype=torch.int64)
+        ops.roi_align_bwd_fx(gc, rc, sel, acc, scale, amax)
+        return ops.fx_to_float(acc, amax, torch.empty(N, H, W, C, device="cuda", dtype=torch.float32))
+    a, b, c = run(), run(), run()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    ref = torch.from_numpy(gref).permute(0, 2, 3, 1)
+    assert float((a.cpu().double() - ref.double()).abs().max() / ref.abs().max()) < 3e-5     # (the oracle sums 2000 ROIs in f32, sequentially)
+    d1 = torch.zeros(N, H, W, C, device="cuda"); ops.roi_align_bwd(gc, rc, sel, d1, scale)   # the float-atomic form: the same up to rounding order
+    assert float((a - d1).abs().max() / d1.abs().max()) < 3e-5
+    out16 = ops.fx_to_float(torch.zeros(N, H, W, C, device="cuda", dtype=torch.int64), amax, torch.empty(N, H, W, C, device="cuda", dtype=torch.bfloat16))
+    assert float(out16.float().abs().max()) == 0.0
+    z = torch.zeros_like(gc); az = ops.absmax(z)
+    acc = torch.zeros(N, H, W, C, device="cuda", dtype=torch.int64)
+    ops.roi_align_bwd_fx(z, rc, sel, acc, scale, az)
+    assert float(ops.fx_to_float(acc, az, torch.empty(N, H, W, C, device="cuda")).abs().max()) == 0.0
+    gn = gc.clone(); gn[7, 11] = float("nan"); an = ops.absmax(gn)
+    acc = torch.zeros(N, H, W, C, device="cuda", dtype=torch.int64)
+    ops.roi_align_bwd_fx(gn, rc, sel, acc, scale, an)
+    assert torch.isnan(ops.fx_to_float(acc, an, torch.empty(N, H, W, C, device="cuda"))).all()
+
+
 def test_stem_pool_and_join_kernels_against_torch(ops):
     torch.manual_seed(1)
     # stem: 7x7 s2 p3 + affine + ReLU, then 3x3 s2 p1 max pool (resnet.py:334-359)
@@ -905,6 +945,43 @@ def test_teacher_on_a_side_stream_and_its_backbone_as_a_graph_give_the_same_step
                 assert res[variant][0][it][k] == v, (variant, it, k, res[variant][0][it][k], v)
         assert all(torch.equal(a, base[1][n]) for n, a in res[variant][1].items())
     assert base[0][0] != base[0][1] != base[0][2]                                     # the teacher did move between the iterations
+
+
+def test_backbone_graph_goes_with_the_weight_stage_it_was_captured_on():
+    """a captured no-grad backbone graph (frcnn._features) holds the addresses of the WeightStage's staged buffers.  Re-homing a
+    parameter (here: new storage with new values, as .to() / load_state_dict(assign=True) / a flat-master re-pack do) rebuilds the stage;
+    the graphs captured on the old one must go, or the teacher would replay stale weights with no error.  After the rebuild the replayed
+    features equal the plain launches' bit for bit — and differ from the old weights' features."""
+    K = 20
+    P = FO.make_params(K, tag="s3l", head_scale=14.0)
+    os.environ["SW_S3_BACKBONE_GRAPH"] = "1"
+    try:
+        m = _model(K, P, "s3l"); m.train()
+        h, w = 160, 96
+        b = [{"image": torch.from_numpy(FO.make_image(h, w, "bbg0")).cuda(), "height": h, "width": w}]
+
+        def leaves(f):
+            return list(f.values()) if isinstance(f, dict) else list(f)
+        with torch.no_grad():
+            m.refresh_staged_weights()
+            x4, _ = m.preprocess_image(b)
+            assert all(torch.equal(a, c) for a, c in zip(leaves(m._features(x4)), leaves(m.backbone(x4))))   # allow_graph off: plain launches
+            for _ in range(3):
+                old = [t.clone() for t in leaves(m._features(x4, allow_graph=True))]
+            assert len([v for v in m.__dict__["_bb_graphs"].values() if v != 1]) == 1
+            name, prm = next((n, q) for n, q in m.named_parameters() if "res3" in n and n.endswith("conv2.weight"))
+            prm.data = (prm.data * 1.5).clone()                                     # re-homed AND changed
+            m.refresh_staged_weights()
+            assert not [v for v in m.__dict__.get("_bb_graphs", {}).values() if v != 1], "graphs of the old stage kept"
+            for _ in range(3):                                                        # launches, capture + replay, replay
+                new = [t.clone() for t in leaves(m._features(x4, allow_graph=True))]
+            assert len([v for v in m.__dict__["_bb_graphs"].values() if v != 1]) == 1
+            ref = leaves(m.backbone(x4))
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, c) for a, c in zip(new, ref)), name
+            assert any(not torch.equal(a, c) for a, c in zip(new, old))
+    finally:
+        os.environ.pop("SW_S3_BACKBONE_GRAPH", None)
 
 
 @pytest.mark.parametrize("caps_reached", [True, False])
