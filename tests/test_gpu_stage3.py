@@ -690,9 +690,14 @@ def test_semisup_step_against_the_reference_run_of_its_own_trainer_methods(golde
     reference's own student and teacher for three iterations: burn-in, the copy step + a semi-supervised step, one EMA update + a
     semi-supervised step.  `semisup.SemiSupStep` on the HIP detectors, same closed-form weights / data / sampling keys / SGD, must log
     the same record dict, attach the same pseudo labels, differentiate the same weighted sum and leave the same teacher.
-    Tolerances: RPN losses 1e-4, ROI-head losses 2e-3 (position-based sampling over proposals whose logits tie to ~1e-7, see the test
-    above); the *_pseudo losses 5e-3 (the HIP teacher's boxes differ from the reference's by < 1e-2 px, which moves anchors whose IoU
-    sits within 1e-5 of the 0.3 / 0.7 thresholds)."""
+    Round 6: the ROIAlign backward accumulates in 64-bit fixed point (csrc/detector.hip roi_align_bwd_fx_kernel), so the iteration is
+    bitwise reproducible — the float-atomic form left the student different in the last bits from run to run, the pseudo boxes jittered
+    by ~1e-4 px and position-keyed anchor sampling flipped (loss_rpn_loc_pseudo 0.678 .. 0.7065 over runs: a 6e-2 bar).  Measured now
+    (tools/diag/s3_ref_dev.py, profiles/r06_stage3_reproducibility.txt; identical over 3 runs), relative to the reference's values:
+    iterations 0-1 every loss <= 2.1e-4 (loss_cls; the pseudo losses <= 2.5e-6); iteration 2 — the third step of a free-running
+    trajectory — <= 2.4e-3 except loss_rpn_loc_pseudo 1.3e-2 (0.6995 vs 0.6904: one anchor whose IoU with a pseudo box sits within
+    1e-5 of a threshold, and with it the positions of the later candidates in the sampler's list).  Bars: iterations 0-1 RPN 1e-4,
+    ROI heads 5e-4, pseudo 1e-4, total 5e-4; iteration 2 5e-3, loss_rpn_loc_pseudo 2e-2, total 2e-3."""
     from sos_wsod_amd.semisup import SemiSupStep
     from sos_wsod_amd.structures import Boxes, Instances
     G = np.load(os.path.join(golden_dir, "stage3_step.npz"))
@@ -720,6 +725,7 @@ def test_semisup_step_against_the_reference_run_of_its_own_trainer_methods(golde
     named = dict(student.named_parameters())
     stride = int(G["stride"])
     sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
+    trajectory = []
     for it in range(3):
         data = (batch("s3s_lq", 2), batch("s3s_lk", 3), batch("s3s_uq", 0), batch("s3s_uk", 0))
         s_before, t_before = sd(student), sd(teacher)
@@ -732,16 +738,16 @@ def test_semisup_step_against_the_reference_run_of_its_own_trainer_methods(golde
         # logic under test at iteration 2 is the EMA, checked on the teacher's tensors below
         loose = it == 2
         for k, v in want.items():
-            tol = 2e-2 if loose else (5e-3 if k.endswith("_pseudo") else (1e-4 if "rpn" in k else 2e-3))
-            if k in ("loss_rpn_cls_pseudo", "loss_rpn_loc_pseudo"):
+            if loose:
                 # the anchor sampler picks candidates by POSITION in the candidate list (sampling.py:49-53): one anchor whose IoU with a
-                # pseudo box crosses 0.3 / 0.7 moves every later candidate's key and with it the sampled set.  The pseudo boxes jitter by
-                # ~1e-4 px from run to run (iteration 0's ROIAlign backward sums with float atomics, so the student the teacher copies is
-                # not bitwise reproducible); measured over 8 runs: loss_rpn_loc_pseudo 0.678 / 0.691 / 0.693 / 0.7065 (the reference's)
-                tol = 6e-2
+                # pseudo box crosses 0.3 / 0.7 moves every later candidate's key and with it the sampled set
+                tol = 2e-2 if k == "loss_rpn_loc_pseudo" else 5e-3
+            else:
+                tol = 1e-4 if (k.endswith("_pseudo") or "rpn" in k) else 5e-4
             assert abs(float(record[k]) - v) <= tol * abs(v) + 1e-7, (it, k, float(record[k]), v)
         total = float(sum(float(v) for v in loss_dict.values()))
-        assert abs(total - float(G[f"it{it}/total_loss"])) <= (2e-2 if loose else 4e-3) * abs(float(G[f"it{it}/total_loss"])), (it, total)
+        assert abs(total - float(G[f"it{it}/total_loss"])) <= (2e-3 if loose else 5e-4) * abs(float(G[f"it{it}/total_loss"])), (it, total)
+        trajectory.append({k: float(v) for k, v in record.items() if k.startswith("loss")})
         if it == 0:
             assert all(torch.equal(t_before[k], v) for k, v in sd(teacher).items())                  # burn-in leaves the teacher alone
             for n in list(G["watch"]) + list(G["watch_full"]):                                          # gradient of the (unit-weighted) sum
@@ -778,6 +784,21 @@ def test_semisup_step_against_the_reference_run_of_its_own_trainer_methods(golde
             bar = 2e-1 if "rpn" in n else (1e-1 if loose else 5e-2)          # (RPN: the sampled anchor set may differ, above)
             assert np.abs(g_ - wg).max() <= bar * np.abs(wg).max(), (it, n, float(np.abs(g_ - wg).max() / np.abs(wg).max()))
         print(f"iteration {it}:", {k: (round(float(record[k]), 5), round(v, 5)) for k, v in want.items()})
+    # ---- the same three iterations on a fresh student / teacher pair: every logged loss and every student weight bit for bit (round 6)
+    final = sd(student)
+    student2, teacher2 = _model(K, P, "s3s"), _model(K, P, "s3s")
+    student2.train(); teacher2.train()
+    student2.proposal_generator.sampler = student2.roi_heads.sampler = student2.sampler
+    opt2 = torch.optim.SGD([p for p in student2.parameters() if p.requires_grad], lr=float(G["lr"]), momentum=float(G["momentum"]))
+    step2 = SemiSupStep(student2, teacher2, opt2, burn_up_step=int(G["cfg/BURN_UP_STEP"]), teacher_update_iter=int(G["cfg/TEACHER_UPDATE_ITER"]),
+                        ema_keep_rate=float(G["cfg/EMA_KEEP_RATE"]), bbox_threshold=float(G["cfg/BBOX_THRESHOLD"]),
+                        unsup_loss_weight=float(G["cfg/UNSUP_LOSS_WEIGHT"]), burn_up_with_strong_aug=bool(G["cfg/BURN_UP_WITH_STRONG_AUG"]))
+    for it in range(3):
+        record, _ = step2.run_step((batch("s3s_lq", 2), batch("s3s_lk", 3), batch("s3s_uq", 0), batch("s3s_uk", 0)))
+        again = {k: float(v) for k, v in record.items() if k.startswith("loss")}
+        assert again == trajectory[it], (it, {k: (again[k], trajectory[it][k]) for k in again if again[k] != trajectory[it][k]})
+    torch.cuda.synchronize()
+    assert all(torch.equal(v, final[k]) for k, v in sd(student2).items())
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
