@@ -80,6 +80,23 @@ __device__ __forceinline__ float block_reduce_max(float v, float* red) {
   return r;
 }
 
+// LDS-DMA (buffer_load_dwordx4 ... lds: 16 bytes per lane from a buffer resource straight into LDS at m0 + 16 * lane) issued through
+// inline assembly.  Through the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc's waitcnt pass knows an LDS write is in flight, and
+// in front of the next ds_read_b64_tr_b16 — the transposed-read intrinsic carries no alias information — it puts s_waitcnt vmcnt(0): a
+// kernel that prefetches K-tiles and reads fragments transposed then waits for the DMA it has just issued (found in round 6: the direct
+// conv weight gradient spent 52 % of its wave cycles parked there; the fc6 weight-gradient GEMM, K-strided B operand, had the same wait in
+// phases 0 and 1 of every K-tile).  The kernels order DMA -> read themselves (counted vmcnt + barrier), so nothing is lost.
+// (m0: written here, no other user in these kernels — no builtin LDS-DMA left beside it, no GWS, no movrel.)
+typedef __attribute__((ext_vector_type(4))) int sw_i32x4;
+__device__ __forceinline__ sw_i32x4 sw_make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  return sw_i32x4{(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void sw_dma16(const sw_i32x4 rsrc, const char* lds_dst, unsigned voff, unsigned soff) {
+  const unsigned m = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds_dst;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 // hipGetLastError() is a per-thread sticky value: a recoverable error of an unrelated earlier HIP call (e.g. torch probing a
 // device) would otherwise be reported by the first SW_CHECK_LAUNCH of this library.  Every entry point starts clean.
 #define SW_ENTER() (void)hipGetLastError()

@@ -152,22 +152,37 @@ __device__ __forceinline__ void conv3x3_direct_body(const DirectArgs& g, const u
   // tile columns instead of 6) — and a wave whose two rows lie below the image runs the EMPTY form (staging and barriers only; its
   // SIMD's matrix pipe goes to the other workgroup of the CU).  Uniform per wave; the full tile's code is unchanged.
   constexpr int FORM_FULL = 0, FORM_LEFT = 1, FORM_EMPTY = 2;
+  // Fragment addresses without vector arithmetic in the loop (round 6; the counters of the conv5 launch showed 0.8 non-MFMA vector
+  // instructions per MFMA — two address adds per input fragment — on an issue port the MFMAs of two waves already fill to 13 of 16
+  // cycles).  A patch row of the fragment (tap, sub-tile) is u + K with u = 2 * wave * PW + l15 per lane and K a compile-time constant;
+  // the XOR bit of its 16-byte position is bit 2 of (u + K), which depends on K only through K mod 8: EIGHT per-lane base pointers
+  // (four at dilation 2, where K is even), and every read is `base[K mod 8] + immediate`, the buffer parity of the chunk / step included
+  // (the chunk loop runs two chunks per turn).
+  const char* pa[8];
+  {
+    const int u = 2 * wave * PW + l15;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pa[k] = sA + u * 64 + ((kq ^ ((((u + k) >> 2) & 1) << 1)) << 4);
+  }
+  const char* pb[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) pb[j] = sB + b_off[j];
   auto main_loop = [&](auto form_c) {
     constexpr int FORM = decltype(form_c)::value;
-    auto compute_step = [&](int step, int chunk, int ty) {
-      const char* A = sA + (chunk & 1) * A_BYTES;
-      const char* B = sB + (step & 1) * B_BYTES;
+    auto compute_step = [&](auto par_c, auto ty_c) {           // par = chunk & 1 (compile time), ty = tap row
+      constexpr int PAR = decltype(par_c)::value, ty = decltype(ty_c)::value;
+      constexpr int BPAR = (PAR * 3 + ty) & 1;                  // step & 1 for step = chunk * 3 + ty
 #pragma unroll
       for (int tx = 0; tx < 3; ++tx) {
         u32x4 fa[4], fb[NI];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (FORM == FORM_LEFT && (i & 1)) continue;
-          const int prow = (2 * wave + (i >> 1) + ty * DIL) * PW + (i & 1) * 16 + tx * DIL + l15;
-          fa[i] = *(const u32x4*)(A + prow * 64 + ((kq ^ (((prow >> 2) & 1) << 1)) << 4));
+          const int K = ((i >> 1) + ty * DIL) * PW + (i & 1) * 16 + tx * DIL;
+          fa[i] = *(const u32x4*)(pa[K & 7] + (PAR * A_BYTES + K * 64));
         }
 #pragma unroll
-        for (int j = 0; j < NI; ++j) fb[j] = *(const u32x4*)(B + tx * (TN * 64) + b_off[j]);
+        for (int j = 0; j < NI; ++j) fb[j] = *(const u32x4*)(pb[j] + (BPAR * B_BYTES + tx * (TN * 64)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (FORM == FORM_LEFT && (i & 1)) continue;
@@ -178,16 +193,21 @@ __device__ __forceinline__ void conv3x3_direct_body(const DirectArgs& g, const u
         }
       }
     };
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-#pragma unroll
-      for (int ty = 0; ty < 3; ++ty) {
+    auto chunk_steps = [&](auto par_c, int chunk) {
+      auto one = [&](auto ty_c) {
+        constexpr int ty = decltype(ty_c)::value;
         const int step = chunk * 3 + ty;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (step + 1 < nstep) issue_b(step + 1);
         if (ty == 0 && chunk + 1 < nchunk) issue_a(chunk + 1);
-        if (FORM != FORM_EMPTY) compute_step(step, chunk, ty);
-      }
+        if (FORM != FORM_EMPTY) compute_step(par_c, ty_c);
+      };
+      one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+    };
+    for (int chunk = 0; chunk < nchunk; chunk += 2) {
+      chunk_steps(std::integral_constant<int, 0>{}, chunk);
+      if (chunk + 1 < nchunk) chunk_steps(std::integral_constant<int, 1>{}, chunk + 1);
     }
   };
   {

@@ -60,20 +60,6 @@ __device__ __forceinline__ u32x2 tr_read(const char* p) {
 }
 __device__ __forceinline__ int fsw(int pix) { return ((pix >> 1) & 1) | (((pix >> 3) & 1) << 1); }      // 128-byte rows: XOR of the 32-byte pair
 
-// LDS-DMA issued through inline assembly.  Through the builtin, hipcc's waitcnt pass sees an LDS write in flight and — the transposed-read
-// intrinsic carries no alias information — puts s_waitcnt vmcnt(0) in front of the next ds_read_b64_tr_b16: every step waited for the DMA
-// it had just issued for three steps later (measured: 52 % of the wave cycles parked).  The ordering DMA -> read is this kernel's own
-// business anyway (counted vmcnt + barrier below).
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long b = (unsigned long long)base;
-  return i32x4{(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
-}
-__device__ __forceinline__ void dma16(const i32x4 rsrc, const char* lds_dst, unsigned voff, unsigned soff) {
-  const unsigned m = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds_dst;
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m), "v"(voff), "s"(rsrc), "s"(soff) : "memory");      // (m0: no other user in this kernel — no builtin LDS-DMA, GWS or movrel)
-}
-
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int DIL>
@@ -128,7 +114,7 @@ __device__ __forceinline__ void wd_item(const WdProblem& P, const int co_blk, co
   // ---- DMA lane geometry: instruction q of a row image, LDS chunk q*64 + lane = (pixel pr, physical chunk pc) <- logical chunk lc
   auto lane_pix = [&](int q) { return (q * 64 + lane) >> 3; };
   auto lane_lc = [&](int q) { const int pr = (q * 64 + lane) >> 3, pc = lane & 7; return (((pc >> 1) ^ fsw(pr)) << 1) | (pc & 1); };
-  const i32x4 rsX = make_rsrc(P.x, P.x_bytes), rsD = make_rsrc(P.dy, P.dy_bytes);
+  const sw_i32x4 rsX = sw_make_rsrc(P.x, P.x_bytes), rsD = sw_make_rsrc(P.dy, P.dy_bytes);      // (sw_dma16: common.h)
   const unsigned x_row_bytes = (unsigned)(W * Cin * 2), d_row_bytes = (unsigned)(W * Cout * 2);
 
   int k = k0;
@@ -149,12 +135,12 @@ __device__ __forceinline__ void wd_item(const WdProblem& P, const int co_blk, co
     { const int pr = lane_pix(wave); d_off = (c0 + pr < W) ? (unsigned)(((c0 + pr) * Cout + co0 + lane_lc(wave) * 8) * 2) : INVALID; }
     auto load_x_row = [&](int y, int q, unsigned vo) {           // input row y, instruction q -> its ring slot
       const bool yok = y >= 0 && y < H;
-      dma16(rsX, sX + ((y + DIL) & (NSLOT - 1)) * XSLOT + q * 1024, yok ? vo : INVALID, yok ? x_img + (unsigned)y * x_row_bytes : 0u);
+      sw_dma16(rsX, sX + ((y + DIL) & (NSLOT - 1)) * XSLOT + q * 1024, yok ? vo : INVALID, yok ? x_img + (unsigned)y * x_row_bytes : 0u);
     };
     auto load_step = [&](int r) {                                // the one new input row (r + d) and the dY row of step r
       load_x_row(r + DIL, wave, xo_own);
       if (wave == 0) load_x_row(r + DIL, 4, xo_4);
-      dma16(rsD, sD + (r & (NDY - 1)) * DYB + wave * 1024, d_off, d_img + (unsigned)r * d_row_bytes);
+      sw_dma16(rsD, sD + (r & (NDY - 1)) * DYB + wave * 1024, d_off, d_img + (unsigned)r * d_row_bytes);
     };
     __builtin_amdgcn_s_barrier();                                // the previous run's (item's) readers are done with the rings
     // prime: rows r0-d .. r0+d-1 (the step's own load brings r0+d), then steps r0, r0+1, r0+2 in flight

@@ -196,8 +196,9 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
   constexpr unsigned ES = (unsigned)sizeof(T);
   constexpr bool a_fast = (AMODE == OP_CONV_A);            // Cin % BK == 0: the tap is uniform per K-tile
   const int tiles_per_tap = a_fast ? g.cC / BK : 1;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)g.b_bytes, 0x00020000);
+  // (sw_dma16, common.h: the DMA goes out through inline assembly — with the builtin the compiler put s_waitcnt vmcnt(0) in front of the
+  // first transposed fragment read after every DMA issue, i.e. the K-strided operand forms waited for the K-tile they had just requested)
+  const sw_i32x4 rsA = sw_make_rsrc(g.A, g.a_bytes), rsB = sw_make_rsrc(g.B, g.b_bytes);
 
   unsigned a_v[A_SLOTS];           // byte offset of this slot (valid rows) or INVALID
   bool a_ok[A_SLOTS];
@@ -322,7 +323,7 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
       soff = (unsigned)is_kt * a_sstep;
       if (is_tail && !(is_kb + a_k[i] < kend)) voff = INVALID;
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lvoid)(is_base + (i * NW + wave) * 1024), 16, (int)voff, (int)soff, 0, 0);
+    sw_dma16(rsA, is_base + (i * NW + wave) * 1024, voff, soff);
   };
   auto issue_b = [&](int i) {
     unsigned voff = b_v[i], soff = 0;
@@ -343,7 +344,7 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
       soff = (a_fast && BMODE == OP_KCONTIG) ? (unsigned)(a_tap * tiles_per_tap + a_chunk()) * b_sstep : (unsigned)is_kt * b_sstep;
       if (is_tail && !(is_kb + b_k[i] < kend)) voff = INVALID;
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lvoid)(is_base + GA::BYTES + (i * NW + wave) * 1024), 16, (int)voff, (int)soff, 0, 0);
+    sw_dma16(rsB, is_base + GA::BYTES + (i * NW + wave) * 1024, voff, soff);
   };
   auto issue_end = [&]() {
     if (a_fast) {

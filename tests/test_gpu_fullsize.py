@@ -454,8 +454,9 @@ def test_config2_bf16_backbone_backward_teacher_forced_against_the_oracle():
     torch.set_num_threads(nthreads)
 
 
-def test_config2_bf16_fc6_dgrad_and_wgrad_isolated_against_float64():
-    """The fc6 pair of the backward at BASELINE config #2's size (M = 4 x 2000 ROIs, 25088 -> 4096), each GEMM ALONE and in the exact
+@pytest.mark.parametrize("M", [8000, 16000])
+def test_config2_bf16_fc6_dgrad_and_wgrad_isolated_against_float64(M):
+    """(M = 16000: BASELINE config #4's row count, 4 views x 4000 ROIs — round 6.)  The fc6 pair of the backward at BASELINE config #2's size (M = 4 x 2000 ROIs, 25088 -> 4096), each GEMM ALONE and in the exact
     launch form the heads use (roi_heads_oicrplus._train_backward_fc6 / _train_backward_pool: data gradient = NT on the transposed weight
     copy with the |max| epilogue, weight gradient = transpose of dZ + NN GEMM with the tail peel) against a float64 contraction of the SAME
     bf16 operands on the host.  The conv family has such a check (…backbone_backward_teacher_forced…); the end-to-end bf16 tests only bound
@@ -465,7 +466,7 @@ def test_config2_bf16_fc6_dgrad_and_wgrad_isolated_against_float64():
     import sos_wsod_amd.ops as ops
     from sos_wsod_amd.roi_heads_oicrplus import _padded
     dev = torch.device("cuda", 0)
-    M, D0, D1 = 8000, 25088, 4096
+    D0, D1 = 25088, 4096
     g = torch.Generator(device="cpu").manual_seed(11)
     bf = torch.bfloat16
     pooled = _padded(M, D0, dev, bf, pad=64)
@@ -488,7 +489,7 @@ def test_config2_bf16_fc6_dgrad_and_wgrad_isolated_against_float64():
     dzt = ops.transpose_2d(dz1, torch.empty(D1, M + 64, device=dev, dtype=bf)[:, :M], M, D1)
     ops.gemm(dzt, pooled, dW1, D1, D0, M, b_kstrided=True)
     torch.cuda.synchronize()
-    rows_m = torch.tensor(sorted({0, 1, 255, 256, 4095, 4096, 7999} | {int(v) for v in torch.randint(0, M, (41,), generator=g)}))
+    rows_m = torch.tensor(sorted({0, 1, 255, 256, 4095, 4096, M - 1} | {int(v) for v in torch.randint(0, M, (41,), generator=g)}))
     rows_o = torch.tensor(sorted({0, 255, 256, 2047, 4095} | {int(v) for v in torch.randint(0, D1, (43,), generator=g)}))
     W64 = W1T.cpu().double()                                             # (D0, D1)
     ref_d = dz1[rows_m.to(dev)].cpu().double() @ W64.t()                 # (48, D0)
@@ -512,6 +513,67 @@ def test_config2_bf16_fc6_dgrad_and_wgrad_isolated_against_float64():
         num += float((d * d).sum()); den += float((ref * ref).sum())
         worst = max(worst, float((d.abs() / ref.abs().amax(dim=1, keepdim=True)).max()))
     rel_w = (num / den) ** 0.5
-    # f32 output, f32 accumulation over K = 8000 in a fixed tile / split order (incl. the last 512 columns: the split-K tail peel)
+    # f32 output, f32 accumulation over K = M in a fixed tile / split order (incl. the last 512 columns: the split-K tail peel)
     assert rel_w <= 1e-5 and worst <= 1e-5, (rel_w, worst)                      # (a bf16-sized error would be 4e-3)
     print(f"fc6 alone, bf16 operands vs float64: dgrad rel-L2 {rel_d:.2e} (bf16 out), wgrad rel-L2 {rel_w:.2e}, worst element / row max {worst:.2e}")
+
+
+def test_config4_bf16_conv5_forward_dgrad_wgrad_at_99x165_against_float64():
+    """BASELINE config #4's conv5 layers ALONE (round 6): 512 -> 512 channels, dilation 2, on the 99 x 165 map of an 800 x 1333 view pair —
+    the direct kernel's four-wave form with ragged right-edge tiles (165 = 5 x 32 + 5: the LEFT edge form) forward and as the data
+    gradient (flipped weights, ReLU mask from a reference map), and the direct weight-gradient kernel through the grouped entry with the
+    backbone's own split plan — each against a float64 convolution of the SAME bf16 operands, on a subset of output channels (forward,
+    weight gradient) / input channels (data gradient) the host can afford.  Operands as in training: inputs >= 0 with zeros, gradients
+    masked (half zeros) with a heavy-tailed scale per pixel.  What is left is the kernels' own arithmetic: f32 accumulation over K = 4608
+    (32 670 pixels for the weights) and one bf16 rounding of a bf16 output."""
+    import torch.nn.functional as F
+    import sos_wsod_amd.ops as ops
+    from sos_wsod_amd.backbone_vgg import _wgrad_direct_splits
+    dev = torch.device("cuda", 0)
+    bf = torch.bfloat16
+    n, H, W, C, dil = 2, 99, 165, 512, 2
+    g = torch.Generator(device="cpu").manual_seed(23)
+    x = (torch.randn(n, H, W, C, generator=g).clamp_(min=0) * (0.5 + 2 * torch.rand(n, H, W, 1, generator=g))).to(bf)
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.02).to(bf)                                       # OIHW
+    dy = (torch.randn(n, H, W, C, generator=g) * torch.exp(torch.randn(n, H, W, 1, generator=g) * 1.5) * 1e-3
+          * (torch.rand(n, H, W, C, generator=g) < 0.5)).to(bf)
+    bias = torch.randn(C, generator=g) * 0.1
+    sub = torch.tensor(sorted({0, 63, 64, 511} | {int(v) for v in torch.randint(0, C, (12,), generator=g)}))
+    xd, dyd, wd = x.double().permute(0, 3, 1, 2), dy.double().permute(0, 3, 1, 2), w.double()
+    xg, dyg = x.to(dev), dy.to(dev)
+    # ---- forward (+ bias + ReLU), bf16 out
+    wk = torch.empty(C, 9, C, device=dev, dtype=bf); ops.conv_weight_prep(w.float().to(dev), wk, 0, C)
+    out = torch.empty(n, H, W, C, device=dev, dtype=bf)
+    ops.conv3x3(xg, wk, out, dil, ops.make_epilogue(bias=bias.to(dev), relu=True, out_dtype=bf))
+    ref = F.relu(F.conv2d(xd, wd[sub], bias.double()[sub], padding=dil, dilation=dil)).permute(0, 2, 3, 1)      # (n, H, W, 16)
+    got = out[..., sub.to(dev)].cpu().double()
+    scale = ref.abs().amax()
+    assert bool(((got - ref).abs() <= ref.abs() * 2.0 ** -8 + scale * 1e-5).all())
+    rel_f = float((got - ref).norm() / ref.norm())
+    assert rel_f <= 3e-3, rel_f
+    # ---- data gradient: the same kernel on the flipped / transposed weight copy, masked by (x > 0)
+    wkd = torch.empty(C, 9, C, device=dev, dtype=bf); ops.conv_weight_prep(w.float().to(dev), wkd, 1)
+    dx = torch.empty(n, H, W, C, device=dev, dtype=bf)
+    ops.conv3x3(dyg, wkd, dx, dil, ops.make_epilogue(relu_ref=xg.view(n * H * W, C), out_dtype=bf))
+    wflip = wd.transpose(0, 1).flip(2, 3)                                                           # [ci][co][2-ky][2-kx]
+    refd = F.conv2d(dyd, wflip[sub], None, padding=dil, dilation=dil).permute(0, 2, 3, 1) * (x[..., sub].double() > 0)
+    gotd = dx[..., sub.to(dev)].cpu().double()
+    scale = refd.abs().amax()
+    assert bool(((gotd - refd).abs() <= refd.abs() * 2.0 ** -8 + scale * 1e-5).all())
+    rel_d = float((gotd - refd).norm() / refd.norm())
+    assert rel_d <= 3e-3, rel_d
+    # ---- weight gradient: the grouped entry (direct kernel) with the backbone's split plan + the ordered fold, f32 out
+    ns = _wgrad_direct_splits([(n, H, W, C, C, dil)])[0]
+    nslab = ops.conv3x3_wgrad_nslab(xg, C, ns)
+    slabs = torch.empty(nslab, C * 9 * C, device=dev)
+    ops.conv3x3_wgrad_grouped([(xg, dyg, slabs, dil, ns)])
+    dw = torch.empty(C, C, 3, 3, device=dev)
+    ops.conv3x3_wgrad_fold(slabs, nslab, dw)
+    wsub = torch.zeros(len(sub), C, 3, 3, dtype=torch.float64, requires_grad=True)
+    refw = torch.autograd.grad(F.conv2d(xd, wsub, None, padding=dil, dilation=dil), wsub, dyd[:, sub])[0]
+    gotw = dw[sub.to(dev)].cpu().double()
+    rel_w = float((gotw - refw).norm() / refw.norm())
+    worst = float(((gotw - refw).abs().flatten(1).amax(1) / refw.abs().flatten(1).amax(1)).max())
+    assert rel_w <= 2e-5 and worst <= 2e-5, (rel_w, worst)                      # (a bf16-sized error would be 4e-3)
+    print(f"conv5 at 99x165 alone, bf16 operands vs float64: fwd rel-L2 {rel_f:.2e}, dgrad {rel_d:.2e} (bf16 out), wgrad {rel_w:.2e} "
+          f"(worst row {worst:.2e}), {nslab} slab(s)")

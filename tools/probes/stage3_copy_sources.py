@@ -4,7 +4,7 @@ module-level record_function ranges).  (development tool)"""
 import collections, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import stage3_step as S
 from torch.profiler import profile, ProfilerActivity
 
@@ -14,7 +14,7 @@ batches = S.make_batches(4, 800, 1216, dev)
 for i in range(3):
     step.run_step(batches[i])
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step.run_step(batches[3])
     torch.cuda.synchronize()
 cnt = collections.Counter()
@@ -29,6 +29,7 @@ for ev in prof.events():
     shapes = ",".join(sorted(set(k.name[:40] for k in ev.kernels)))
     if ev.name == "aten::copy_" and "AccumulateGrad" in " ".join(chain):
         shapes += " " + str(ev.input_shapes[:1])
-    cnt[(ev.name, " < ".join(chain) or "(top level)", shapes)] += 1
+    site = next((f.strip()[-80:] for f in (ev.stack or []) if "sos-wsod_amd" in f or "sos_wsod_amd" in f), "")
+    cnt[(ev.name, (" < ".join(chain) or "(top level)") + "  @ " + site, shapes)] += 1
 for (name, chain, kern), n in cnt.most_common(70):
     print(f"{n:4d}  {name:16s} in {chain}   [{kern}]")
