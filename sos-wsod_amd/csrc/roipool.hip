@@ -707,8 +707,8 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
                                                                     const float* __restrict__ rois, int R,
                                                                     const float* __restrict__ row_scale, float row_scale_add,
                                                                     unsigned short* __restrict__ out, IT* __restrict__ argmax,
-                                                                    int band_S, int band_rows, int n_bands, int n_zsplit) {
-  // PFIX = 7: the pooled size as a compile-time constant (the hot path's 7 x 7): the 16 stores of a task then take immediate offsets
+                                                                    int band_S, int band_rows, int n_bands, int n_zsplit, int SP_CHK) {
+  // SP_CHK: ROIs per chunk (round 6: a run-time value; see launch_fwd_sparse).  PFIX = 7: the pooled size as a compile-time constant (the hot path's 7 x 7): the 16 stores of a task then take immediate offsets
   // (q * 98 bytes) instead of 64-bit address arithmetic per channel, and the task counters fold
   const int PH = PFIX ? PFIX : PH_, PW = PFIX ? PFIX : PW_;
   constexpr int NPL = CB / 4;                                       // 16-byte planes
@@ -726,10 +726,10 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
   unsigned short* s_lvl = (unsigned short*)(smem + (size_t)NPL * npl_px * 16);          // [R] ROI rows of this image, by class
   const int r_even = (R + 1) & ~1;
   int* s_r = (int*)(s_lvl + r_even);                                // [CH] ROI row of the chunk's entries
-  float* s_mul = (float*)(s_r + SP_CH);                             // [CH] output scale
-  unsigned short* s_hb = (unsigned short*)(s_mul + SP_CH);          // [CH][PH] bin row range  start | end << 8
-  unsigned short* s_wb = s_hb + SP_CH * PH;                         // [CH][PW]
-  unsigned int* s_task = (unsigned int*)(s_wb + SP_CH * PW + ((SP_CH * (PH + PW)) & 1));   // BAND: [CH * PH] owned (entry << 8 | bin row)
+  float* s_mul = (float*)(s_r + SP_CHK);                            // [CH] output scale
+  unsigned short* s_hb = (unsigned short*)(s_mul + SP_CHK);         // [CH][PH] bin row range  start | end << 8
+  unsigned short* s_wb = s_hb + SP_CHK * PH;                        // [CH][PW]
+  unsigned int* s_task = (unsigned int*)(s_wb + SP_CHK * PW + ((SP_CHK * (PH + PW)) & 1));   // BAND: [CH * PH] owned (entry << 8 | bin row)
   const int c0 = xcd_grouped_slab() * CB, img = blockIdx.y;
   const int tid = threadIdx.x;
   const int nb = PH * PW;
@@ -841,8 +841,8 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
     }
     const int span = 1 << L;
     SP_T(t_lv2); SP_ADD(2, t_lv1, t_lv2);
-    for (int cs = c_lo; cs < c_hi; cs += SP_CH) {
-      const int cnt = min(SP_CH, c_hi - cs);
+    for (int cs = c_lo; cs < c_hi; cs += SP_CHK) {
+      const int cnt = min(SP_CHK, c_hi - cs);
       SP_T(t_c0);
       __syncthreads();                                              // the previous chunk's tables are no longer read
       SP_T(t_c1); SP_ADD(5, t_c0, t_c1);
@@ -1076,18 +1076,18 @@ int launch_fwd_band(int nimg, int H, int W, int C, long ld, int PH, int PW, floa
 }
 
 // sparse-table form: LDS = table planes + the image's sorted ROI list + one chunk's tables
-inline size_t sparse_tables_bytes(int R, int PH, int PW, bool band) {
-  return (size_t)((R + 1) & ~1) * 2 + (size_t)SP_CH * (4 + 4 + 2 * (PH + PW)) + 4 + (band ? (size_t)SP_CH * PH * 4 : 0) + 16;
+inline size_t sparse_tables_bytes(int R, int PH, int PW, bool band, int chunk) {
+  return (size_t)((R + 1) & ~1) * 2 + (size_t)chunk * (4 + 4 + 2 * (PH + PW)) + 4 + (band ? (size_t)chunk * PH * 4 : 0) + 16;
 }
 template <typename IT, int CB, bool BAND>
 int launch_sparse_kernel(dim3 grid, size_t lds, int H, int W, int C, long ld, int PH, int PW, float scale, const void* feat, const float* rois,
                          int R, const float* row_scale, float row_scale_add, void* out, void* argmax, int S, int rows, int n_bands, int nz,
-                         hipStream_t stream) {
+                         int chunk, hipStream_t stream) {
   auto kern = (PH == 7 && PW == 7) ? roi_pool_fwd_sparse_kernel<IT, CB, BAND, 7> : roi_pool_fwd_sparse_kernel<IT, CB, BAND, 0>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, grid, dim3(SP_NT), lds, stream, H, W, C, ld, PH, PW, scale, (const unsigned short*)feat, rois, R, row_scale,
-                     row_scale_add, (unsigned short*)out, (IT*)argmax, S, rows, n_bands, nz);
+                     row_scale_add, (unsigned short*)out, (IT*)argmax, S, rows, n_bands, nz, chunk);
   SW_CHECK_LAUNCH();
   return 0;
 }
@@ -1108,17 +1108,23 @@ int launch_fwd_sparse(int nimg, int H, int W, int C, long ld, int PH, int PW, fl
     return nz > n_blocks ? n_blocks : nz;
   };
   static const bool force_cb4 = getenv("SW_ROI_SPARSE_CB4") != nullptr;                // development switch: 4 channels per lane everywhere
-  const size_t plane8 = (size_t)H * W * 32 + sparse_tables_bytes(R, PH, PW, false);
+  // ROIs per chunk: a run-time kernel argument since round 6 (SW_ROI_SPARSE_CHUNK, development switch).  The phase clocks of the band form
+  // (99x165 map: 29 % of a workgroup's cycles in chunk set-up, 21 % at the barrier behind a scan; profiles/r06_roi_phases.txt) suggested
+  // larger chunks; measured, they are slower on every map (99x165 / 8000 ROIs: 672 us at 128, 684 at 256, 792 at 512, 1041 at 1024 —
+  // their tables take LDS from the band's rows; profiles/r06_roi_chunk_sweep.txt): 128 stays
+  static const int chunk_env = getenv("SW_ROI_SPARSE_CHUNK") ? atoi(getenv("SW_ROI_SPARSE_CHUNK")) : 0;
+  const int chunk_plane = chunk_env > 0 ? chunk_env : SP_CH, chunk_band = chunk_env > 0 ? chunk_env : SP_CH;
+  const size_t plane8 = (size_t)H * W * 32 + sparse_tables_bytes(R, PH, PW, false, chunk_plane);
   if (!force_cb4 && plane8 <= LDS_MAX && (long)H * W <= 5 * SP_NT) {
     const int nz = zsplit((C / 8) * nimg);
     return launch_sparse_kernel<IT, 8, false>(dim3(C / 8, nimg, nz), plane8, H, W, C, ld, PH, PW, scale, feat, rois, R, row_scale,
-                                              row_scale_add, out, argmax, H, H, 1, nz, stream);
+                                              row_scale_add, out, argmax, H, H, 1, nz, chunk_plane, stream);
   }
   // row bands: 4 channels per lane (16 B per pixel).  8 channels (32 B per pixel: a third of the rows per band) measured slower on
   // every banded map (99x165 / 8000 ROIs: 956 vs 669 us with 9 vs 3 bands; 125x167: 525 vs 383; 76x114: 245 vs 219) — the bands'
   // redundant ROI tables and slab fetches outweigh the halved task count; SW_ROI_SPARSE_CB8BAND=1 tries it first (A/B timing)
   static const bool try_cb8_band = getenv("SW_ROI_SPARSE_CB8BAND") != nullptr;          // development switch
-  const size_t tb = sparse_tables_bytes(R, PH, PW, true);
+  const size_t tb = sparse_tables_bytes(R, PH, PW, true, chunk_band);
   if (PH > 255) return -100;
   const int halo = (H + PH - 1) / PH + 1;
   for (int cb = (try_cb8_band && !force_cb4) ? 8 : 4; cb >= 4; cb >>= 1) {
@@ -1136,9 +1142,9 @@ int launch_fwd_sparse(int nimg, int H, int W, int C, long ld, int PH, int PW, fl
     dim3 grid(C / cb, nimg, n_bands * nz);
     if (cb == 8)
       return launch_sparse_kernel<IT, 8, true>(grid, lds, H, W, C, ld, PH, PW, scale, feat, rois, R, row_scale, row_scale_add, out, argmax,
-                                               S, rows, n_bands, nz, stream);
+                                               S, rows, n_bands, nz, chunk_band, stream);
     return launch_sparse_kernel<IT, 4, true>(grid, lds, H, W, C, ld, PH, PW, scale, feat, rois, R, row_scale, row_scale_add, out, argmax,
-                                             S, rows, n_bands, nz, stream);
+                                             S, rows, n_bands, nz, chunk_band, stream);
   }
   return -100;
 }

@@ -19,15 +19,17 @@ elif which.startswith("wgrad") and which != "wgrad_grouped":
     x = rnd(n_, H_, W_, cin); dy = rnd(n_, H_, W_, cout); dw = torch.empty(cout, cin, 3, 3, device=dev); ws = torch.empty(cout * 9 * cin, device=dev)
     f = lambda: ops.conv3x3_wgrad(x, dy, dw, dil, splitk=sk, workspace=ws)
 elif which == "wgrad_grouped":          # every conv weight gradient of one backward pass (9 layers x 2 view batches), one launch
-    from sos_wsod_amd.backbone_vgg import _wgrad_grouped_splits, _wgrad_grouped_target
+    from sos_wsod_amd.backbone_vgg import _wgrad_grouped_splits, _wgrad_grouped_target, _wgrad_direct_splits
     L = [(128, 128, 128, 256, 1), (128, 128, 256, 256, 1), (128, 128, 256, 256, 1), (64, 64, 256, 512, 1), (64, 64, 512, 512, 1),
          (64, 64, 512, 512, 1), (63, 63, 512, 512, 2), (63, 63, 512, 512, 2), (63, 63, 512, 512, 2)]
     T = _wgrad_grouped_target([(2 * H * W, co, 9 * ci) for H, W, ci, co, _ in L for _v in range(2)], 64)
+    direct = os.environ.get("SW_WGRAD_DIRECT", "1") != "0"         # the direct kernel's own split plan (what the backbone passes)
+    plan = iter(_wgrad_direct_splits([(2, H, W, ci, co, dil) for H, W, ci, co, dil in L for _v in range(2)]))
     probs = []
     for H, W, ci, co, dil in L:
         for _v in range(2):
             x, dy = rnd(2, H, W, ci), rnd(2, H, W, co)
-            ns = _wgrad_grouped_splits(2 * H * W, 64, T)
+            ns = next(plan) if direct else _wgrad_grouped_splits(2 * H * W, 64, T)
             probs.append((x, dy, torch.empty(ops.conv3x3_wgrad_nslab(x, co, ns), co * 9 * ci, device=dev), dil, ns))
     f = lambda: ops.conv3x3_wgrad_grouped(probs)
 elif which in ("roi_fwd", "roi_bwd"):   # one ROIPool call of the step: 2 x 2000 ROIs (view + flipped view) on a 2 x 63 x 63 x 512 map

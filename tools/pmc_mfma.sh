@@ -18,7 +18,7 @@ for shape in sys.argv[1:]:
     for f in glob.glob(f"gpurun_out/pmc_mfma_{shape}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"] + " grid " + r.get("Grid_Size", "?")
-            if "gemm2" in k or "conv3x3" in k:
+            if "gemm2" in k or "conv3x3" in k or "conv_wgrad_direct" in k:
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     dur = collections.defaultdict(list)
     for f in glob.glob(f"gpurun_out/pmc_mfma_{shape}/*/*kernel_trace.csv"):
