@@ -249,7 +249,7 @@ def main():
             trainer.run_step(batches[i % 2])
     for i in range(args.warmup):
         trainer.run_step(batches[i % 2])
-    tags = ["fc6_fwd", "fc6_dgrad", "fc6_wgrad", "plain5.conv3_fwd", "roi_fwd", "roi_bwd"]
+    tags = ["fc6_fwd", "fc6_dgrad", "fc6_wgrad", "plain5.conv3_fwd", "roi_fwd", "roi_bwd", "wgrad_grouped"]
     sync()
     phase("model built, graphs captured, warm-up done")
     t0 = time.perf_counter()
@@ -284,6 +284,7 @@ def main():
     sync()
     instrumented_ms = (time.perf_counter() - t1) / n_timer_steps * 1e3
     times = ops.TIMER.summary_ms()
+    timer_work = dict(ops.TIMER.work)
     ops.TIMER = None
     rank_ms = [dt / args.steps * 1e3]
     rccl_ranks = 1
@@ -339,7 +340,7 @@ def main():
         e1.record(); torch.cuda.synchronize()
         conv_alone_ms = e0.elapsed_time(e1) / 20
         # HBM bytes per call from the committed rocprofv3 --pmc passes (tools/pmc_traffic.sh): (2*FETCH_SIZE + WRITE_SIZE)*1024
-        pmc = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"))
+        pmc = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"))
                     if os.path.exists(p)), None)
         traffic = json.load(open(pmc)) if pmc else {}
         roofline = roof(dom)
@@ -359,7 +360,7 @@ def main():
         # counter-based MFMA utilisation of the same kernels run alone (tools/pmc_mfma.sh, committed under profiles/):
         # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32).  The FLOP-based `frac` prices against the 2.4 GHz peak;
         # under MFMA load the chip runs 1.6-2.0 GHz (DVFS), so the pipe is busier than `frac` says.
-        busy_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r05_mfma_busy.json", "r04_mfma_busy.json", "r03_mfma_busy.json", "r02_mfma_busy.json", "r01_mfma_busy.json"))
+        busy_path = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r06_mfma_busy.json", "r05_mfma_busy.json", "r04_mfma_busy.json", "r03_mfma_busy.json", "r02_mfma_busy.json", "r01_mfma_busy.json"))
                           if os.path.exists(p)), None)
         busy = json.load(open(busy_path)) if busy_path else {}
 
@@ -392,6 +393,17 @@ def main():
                                                                if t in traffic else None))
                              for t in ("fc6_fwd", "fc6_dgrad", "fc6_wgrad")},
             "roofline_conv5_3": dict(roof("plain5.conv3_fwd"), note="inside the step: two streams share the CUs"),
+            # every conv weight gradient of the backward pass: ONE launch of the direct weight-gradient kernel (round 6)
+            "roofline_wgrad_grouped": ({"kernel": "conv_wgrad_direct_kernel: all conv weight gradients of the step, one launch (folds not included)",
+                                        "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+                                        "flop_per_launch": timer_work["wgrad_grouped"] / max(1, len(times["wgrad_grouped"])),
+                                        "avg_ms": round(avg_ms["wgrad_grouped"], 4),
+                                        "achieved": round(timer_work["wgrad_grouped"] / (sum(times["wgrad_grouped"]) * 1e-3) / 1e12, 2),
+                                        "frac": round(timer_work["wgrad_grouped"] / (sum(times["wgrad_grouped"]) * 1e-3) / 1e12 / peak, 4),
+                                        "traffic": (traffic.get("wgrad_grouped") or {}).get("hbm_bytes_per_launch"),
+                                        "algorithmic_bytes": (traffic.get("wgrad_grouped") or {}).get("algorithmic_bytes"),
+                                        "mfma_busy_counter": busy_of("wgrad_grouped")}
+                                       if times.get("wgrad_grouped") else None),
             "roofline_conv5_3_alone": {"kernel": "conv5_3 fwd, batch 2, 63x63, 512->512, dilation 2", "bound": "mfma",
                                        "traffic": (traffic.get("conv5_3") or {}).get("hbm_bytes_per_launch"),
                                        "algorithmic_bytes": (traffic.get("conv5_3") or {}).get("algorithmic_bytes"),

@@ -32,7 +32,7 @@ for shape in sys.argv[1:]:
         cyc = m("SQ_BUSY_CYCLES") / 32.0
         d = dur[k][skip:]
         us = sum(d) / max(1, len(d))
-        kk = k.replace("void (anonymous namespace)::", "").split("(")[0] + " grid " + k.rsplit(" grid ", 1)[1]
+        kk = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] + " grid " + k.rsplit(" grid ", 1)[1]
         res.setdefault(shape, {})[kk] = {
             "launches": n - skip, "avg_us_profiled": round(us, 2), "kernel_cycles": round(cyc),
             "grbm_gui_active_div8": round(m("GRBM_GUI_ACTIVE") / 8.0),
