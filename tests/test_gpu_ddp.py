@@ -125,6 +125,10 @@ def test_bench_launches_its_own_ranks():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp2"
+    # round 6: N > 1 times the stage-graph mode, gives the launch-by-launch time beside it, and proves the replicas stayed identical
+    assert rec["ranks_in_sync"] is True and rec["rccl_ranks"] == 2
+    assert rec["step_launch"]["mode"].startswith("data parallel: 4 stage graphs") and rec["step_launch"]["graph_replays"] > 0
+    assert rec["step_launch"]["eager_ms_per_step"] > 0
 
 
 def test_stage3_semisup_step_two_ranks(tmp_path):
