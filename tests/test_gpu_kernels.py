@@ -268,6 +268,33 @@ def test_conv3x3_wgrad_direct_kernel(ops, spec):
     assert ((dw - one).abs().max() / one.abs().max()) < 2e-5
 
 
+def test_conv3x3_wgrad_direct_kernel_many_problems_in_one_call(ops):
+    """more problems than one kernel-argument block of the direct weight-gradient kernel holds (32): the entry point launches in chunks;
+    mixed dilations, map sizes and split counts in one list, every gradient against float64"""
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    probs, refs = [], []
+    for i in range(37):
+        n, H, W = 1 + (i % 2), 16 + (i % 5) * 3, 20 + (i % 7) * 9
+        cin, cout, dil, ns = 64 * (1 + i % 2), 64 * (1 + (i // 2) % 2), 1 + (i % 3 == 0), 1 + (i % 2)
+        steps, npx = n * ((W + 31) // 32) * H, n * H * W
+        eff = -(-npx // (-(-(-(-npx // ns)) // 64) * 64))
+        assert -(-steps // eff) >= 8                                   # (every problem qualifies: the list runs on the direct kernel)
+        x = (torch.randn(n, H, W, cin, device="cuda", generator=g) * 0.7).to(dt)
+        dz = (torch.randn(n, H, W, cout, device="cuda", generator=g) * 0.5).to(dt)
+        nslab = ops.conv3x3_wgrad_nslab(x, cout, ns)
+        slabs = torch.full((nslab, cout * 9 * cin), float("nan"), device="cuda")
+        probs.append((x, dz, slabs, dil, ns)); refs.append((x, dz, slabs, nslab, cin, cout, dil))
+    ops.conv3x3_wgrad_grouped(probs)
+    for k, (x, dz, slabs, nslab, cin, cout, dil) in enumerate(refs):
+        dw = torch.empty(cout, cin, 3, 3, device="cuda")
+        ops.conv3x3_wgrad_fold(slabs, nslab, dw)
+        wd = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+        y = F.conv2d(x.double().permute(0, 3, 1, 2), wd, None, padding=dil, dilation=dil)
+        want = torch.autograd.grad(y, wd, dz.double().permute(0, 3, 1, 2))[0]
+        assert ((dw.double() - want).abs().max() / want.abs().max()) < 3e-5, k
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("C", [24, 6])
 @pytest.mark.parametrize("stride", [1, 2])
