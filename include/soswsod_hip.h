@@ -70,6 +70,16 @@ typedef struct sw_epilogue {
    * (detectron2/layers/batch_norm.py:52-58), without a pass of its own.  Without a fold (one split, plain f32 C) it runs as a
    * row-scaling pass after the GEMM; sw_gemm returns -5 for any other combination that does not end in a fold. */
   const float* fold_row_scale;
+  /* Fused SGD update (round 6; sw_gemm only, bf16 operands, f32 "output", no other epilogue option, the 256x256 ping-pong tile: K-contiguous
+   * A, M % 32 == 0, N % 64 == 0 — sw_gemm_sgd_fused_supported answers for a shape): C = A B is the GRADIENT of the [M][N] float32 parameter
+   * sgd_fused->param (row pitch = ldc; stage_kind 3: row-major copy stage0 [M][ld0] and transposed copy stage1 [N][ld1], bf16).  The
+   * epilogue applies torch.optim.SGD's momentum update (sw_sgd_multi's arithmetic, bit for bit) to the parameter, its momentum buffer and
+   * both copies; the gradient is NOT written, except the peeled tail columns (see sw_gemm), which go through C and the tiled update kernel.
+   * What it removes: the 411 MB write + read of fc1.weight's gradient and a serialized HBM-bound optimizer launch (the reference:
+   * optimizer.step() after the backward, train_net_multi.py:157-164; single GPU, ITER_SIZE 1 only — a data-parallel step needs the
+   * all-reduced gradient).  sgd_fused->grad, ->n, ->d1, ->d2 are ignored; ->d0 must equal N. */
+  const struct sw_sgd_tensor_s* sgd_fused;
+  float sgd_momentum, sgd_grad_scale;
 } sw_epilogue;
 
 /* ---- dense contractions (reference: cuBLAS via torch Linear — box_head.py:88-90,
@@ -447,7 +457,7 @@ int sw_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, l
  * matrix (d0 rows of pitch ld1) — fc6's weight is read K-contiguous by the forward AND by the data-gradient GEMM this
  * way (a K-strided operand of 49 KiB pitch costs that GEMM 25 %); n/d0 and d0 must be multiples of 64. */
 #define SW_SGD_MAX_TENSORS 24
-typedef struct {
+typedef struct sw_sgd_tensor_s {
   float* param;
   const float* grad;
   float* momentum_buf;
@@ -463,6 +473,8 @@ typedef struct {
                              * that a captured hipGraph of the step survives learning-rate schedule changes */
 } sw_sgd_tensor;
 int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float momentum, float grad_scale, sw_stream_t stream);
+/* 1 if sw_gemm(dtype, a_kstrided, b_kstrided, M, N, K, ...) accepts sw_epilogue.sgd_fused for this shape, else 0 */
+int sw_gemm_sgd_fused_supported(int dtype, int a_kstrided, int b_kstrided, int M, int N, int K);
 /* out[i] = mean over the n_images images of (sum_v loss_view[b][i][v] / V)   (loss assembly, roi_heads_oicrplus.py:283-288,
  * 384-388; the reference runs one image per GPU, n_images > 1 is the mean DDP would form over as many ranks);
  * total (optional, 2 floats): [0] = sum_i out[i] in index order (train_net_multi.py:129 sum(loss_dict.values())),

@@ -29,6 +29,7 @@ class Epilogue(ctypes.Structure):
         ("splitk_workspace", c_void_p),
         ("residual", c_void_p), ("ld_res", c_long), ("res_dtype", c_int),
         ("fold_row_scale", c_void_p),
+        ("sgd_fused", c_void_p), ("sgd_momentum", c_float), ("sgd_grad_scale", c_float),       # const sw_sgd_tensor* (round 6)
     ]
 
 
@@ -109,6 +110,7 @@ SIGNATURES = {
     "sw_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long,
                         _EP, c_int, c_void_p]),
     "sw_gemm_splitk_workspace_floats": (c_long, [c_int, c_int, c_int, c_int]),
+    "sw_gemm_sgd_fused_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "sw_conv3x3_igemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, _EP,
                                  c_void_p]),
     "sw_conv3x3_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1259,6 +1259,18 @@ extern "C" int sw_convert_2d_t(int dtype, int rows, int cols, const float* src, 
   return 0;
 }
 
+// the tiled update kernel on a column block of a 2D parameter (gemm.hip: the peeled tail columns of a GEMM with a fused SGD epilogue)
+int sw_sgd_tile_t_block(int rows, int cols, float* param, const float* grad, float* buf, long ld_src, float lr, float wd, int first,
+                        float mom, float gscale, unsigned short* st0, long ld0, unsigned short* st1, long ld1, const float* hyper,
+                        hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if ((rows % 64) || (cols % 64) || !st1) return -5;
+  hipLaunchKernelGGL(sgd_tile_t_kernel<unsigned short>, dim3(cols / 64, rows / 64), dim3(256), 0, stream, rows, cols, param, grad, buf,
+                     ld_src, lr, wd, first, mom, gscale, st0, ld0, st1, ld1, hyper);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sw_sgd_multi(int n_tensors, const sw_sgd_tensor* tensors, float momentum, float grad_scale,
                             hipStream_t stream) {
   SW_ENTER();

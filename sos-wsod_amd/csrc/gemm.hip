@@ -44,6 +44,12 @@ struct GemmArgs {
   int vgrid;                       // persistent form: virtual workgroup count walked by gridDim.x resident workgroups (0 = off)
   int krot;                        // conv: rotate the channel-chunk order by the M-tile index (L2 channel spread)
   float* absmax;                   // optional: atomicMax of |stored value| (IEEE bits of a non-negative float are monotone)
+  // fused SGD update (round 6, ping-pong form, plain f32 "output"): C[m][n] is the gradient of the [M][N] parameter sgd_param; the
+  // epilogue applies torch.optim.SGD's momentum update to it and rewrites the parameter's compute-dtype copies — the gradient is never
+  // written (sw_epilogue.sgd_fused)
+  float* sgd_param; float* sgd_mom; long sgd_ld;
+  unsigned short* sgd_st0; long sgd_ld0; unsigned short* sgd_st1; long sgd_ld1;
+  const float* sgd_hyper; float sgd_lr, sgd_wd, sgd_momentum, sgd_gscale; int sgd_first;
 };
 
 template <typename T> struct GT;
@@ -531,10 +537,31 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
     // (bf16 output) consecutive columns of one row, applies bias / ReLU / dropout / mask to them and stores 16 bytes.
     constexpr int LDW = WTN + 4;                                   // padded pitch: the 4 row groups of a store hit different banks
     float* wt = (float*)smem + wave * (32 * LDW);
+    // fused SGD: the updated weights of a quarter (32 rows x WTN columns) as bf16, column-major, for the TRANSPOSED compute copy
+    constexpr int TP = 40;                                         // halfwords per column (32 rows + pad; 80 B: 16-byte column starts)
+    unsigned short* tT = (unsigned short*)((float*)smem + NW * (32 * LDW)) + wave * (WTN * TP);
+    static_assert((long)NW * (32 * LDW) * 4 + (long)NW * WTN * TP * 2 <= (long)STAGES * STAGE_BYTES, "epilogue staging fits the ring");
+    float sgd_lr = g.sgd_lr, sgd_wd = g.sgd_wd;
+    if (g.sgd_param && g.sgd_hyper) { sgd_lr = g.sgd_hyper[0]; sgd_wd = g.sgd_hyper[1]; }
     __syncthreads();                                               // every wave is done reading the last K-tile
     const bool vec_ok = g.staged_out;                              // host: 16-byte row pieces are aligned and inside the row pitch
     auto quarter = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
+      // fused SGD: the quarter's parameter / momentum pieces are requested BEFORE the accumulators go through LDS — sixteen 16-byte
+      // loads in flight per lane instead of two per piece (alone: the epilogue is a one-workgroup-per-CU streaming phase, latency bound)
+      constexpr int NPC = (32 * (WTN / 4)) / 64;                    // row pieces of 4 columns per lane and quarter
+      f32x4 pw[NPC], pm[NPC];
+      if (g.sgd_param) {
+        const int nbq = n0t + wn * WTN + (lane % (WTN / 4)) * 4;
+#pragma unroll
+        for (int it = 0; it < NPC; ++it) {
+          const int mq = m0 + wm * WTM + q * 32 + (it * 64 + lane) / (WTN / 4);
+          const bool okq = mq < g.M && nbq < g.N;
+          const long po = (long)mq * g.sgd_ld + nbq;
+          pw[it] = okq ? *(const f32x4*)(g.sgd_param + po) : f32x4{0.f, 0.f, 0.f, 0.f};
+          pm[it] = (okq && !g.sgd_first) ? *(const f32x4*)(g.sgd_mom + po) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
 #pragma unroll
       for (int ii = 0; ii < 32 / TS; ++ii)                          // the sub-tiles of this 32-row quarter (two of 16 rows / one of 32)
 #pragma unroll
@@ -604,6 +631,29 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
             v[t] = x;
           }
           const long o = (long)m * g.ldc + nb;
+          if (CP == 4 && PLAIN && g.sgd_param) {
+            // ---- fused SGD (sgd_tile_t_kernel's arithmetic, elementwise.hip: identical bits): host guarantees full 16-byte pieces
+            const long po = (long)m * g.sgd_ld + nb;
+            const f32x4 w4 = pw[it * CP / 4 < NPC ? it * CP / 4 : 0];     // (CP == 4 here: piece `it` of the quarter)
+            f32x4 m4 = pm[it * CP / 4 < NPC ? it * CP / 4 : 0];
+            f32x4 wn;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float dd = v[t] * g.sgd_gscale + sgd_wd * w4[t];
+              m4[t] = g.sgd_first ? dd : g.sgd_momentum * m4[t] + dd;
+              wn[t] = w4[t] - sgd_lr * m4[t];
+            }
+            *(f32x4*)(g.sgd_mom + po) = m4;
+            *(f32x4*)(g.sgd_param + po) = wn;
+            const unsigned b01 = (unsigned)f32_to_bf16_bits(wn[0]) | ((unsigned)f32_to_bf16_bits(wn[1]) << 16);
+            const unsigned b23 = (unsigned)f32_to_bf16_bits(wn[2]) | ((unsigned)f32_to_bf16_bits(wn[3]) << 16);
+            if (g.sgd_st0) *(u32x2*)(g.sgd_st0 + (long)m * g.sgd_ld0 + nb) = u32x2{b01, b23};
+            if (g.sgd_st1) {
+              tT[(c0 + 0) * TP + row] = (unsigned short)(b01 & 0xFFFFu); tT[(c0 + 1) * TP + row] = (unsigned short)(b01 >> 16);
+              tT[(c0 + 2) * TP + row] = (unsigned short)(b23 & 0xFFFFu); tT[(c0 + 3) * TP + row] = (unsigned short)(b23 >> 16);
+            }
+            continue;
+          }
           if (CP == 4) {
             if (g.atomic && g.slab_stride <= 0) {
 #pragma unroll
@@ -646,6 +696,20 @@ __device__ __forceinline__ void gemm2_tile(const GemmArgs& g, const int bm, cons
       const bool bf16_rows = g.out_bf16 && g.slab_stride <= 0 && !g.atomic;
       if (bf16_rows) { if (plain_ep) pieces(IntC<8>{}, IntC<1>{}); else pieces(IntC<8>{}, IntC<0>{}); }
       else { if (plain_ep) pieces(IntC<4>{}, IntC<1>{}); else pieces(IntC<4>{}, IntC<0>{}); }
+      if (g.sgd_param && g.sgd_st1) {
+        // the quarter's updated weights, transposed: column c of the tile = row (n0 + c) of the transposed copy, its 32 rows one 64-byte
+        // run; lane -> (column lane >> 2 of 16 per pass, 8 rows = 16 bytes)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // own LDS writes before own reads
+        const int part = lane & 3;
+        const int mrow = m0 + wm * WTM + q * 32 + part * 8;
+#pragma unroll
+        for (int ps = 0; ps < WTN / 16; ++ps) {
+          const int c = ps * 16 + (lane >> 2);
+          const int n = n0t + wn * WTN + c;
+          if (n < g.N && mrow < g.M)
+            *(u32x4*)(g.sgd_st1 + (long)n * g.sgd_ld1 + mrow) = *(const u32x4*)(tT + c * TP + part * 8);
+        }
+      }
     };
     quarter(IntC<0>{}); quarter(IntC<1>{}); quarter(IntC<2>{}); quarter(IntC<3>{});
   } else {
@@ -1088,6 +1152,23 @@ int check_align(const void* p) { return (((uintptr_t)p) & 15) ? -4 : 0; }
 
 }  // namespace
 
+int sw_sgd_tile_t_block(int rows, int cols, float* param, const float* grad, float* buf, long ld_src, float lr, float wd, int first,
+                        float mom, float gscale, unsigned short* st0, long ld0, unsigned short* st1, long ld1, const float* hyper,
+                        hipStream_t stream);                                 // elementwise.hip
+
+// shapes the fused-SGD epilogue covers: launch_auto's ping-pong form (the only epilogue that implements it), whole 16-byte pieces
+static bool sgd_fused_shape_ok(int dtype, int a_kstrided, int b_kstrided, int M, int N, int K) {
+  static const char* pp = getenv("SW_GEMM_PP");
+  static const char* v = getenv("SW_GEMM_V");
+  if (dtype != SW_BF16 || a_kstrided || (pp && pp[0] == '0') || v) return false;
+  (void)b_kstrided;
+  if ((M % 32) || (N % 64) || (K % 64) || K < 1024 || N <= 128) return false;
+  return ((long)((M + 255) / 256) * ((N + 255) / 256)) >= 200;
+}
+extern "C" int sw_gemm_sgd_fused_supported(int dtype, int a_kstrided, int b_kstrided, int M, int N, int K) {
+  return sgd_fused_shape_ok(dtype, a_kstrided, b_kstrided, M, N, K) ? 1 : 0;
+}
+
 extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, int K, const void* A, long lda,
                        const void* B, long ldb, void* C, long ldc, const sw_epilogue* ep, int splitk,
                        hipStream_t stream) {
@@ -1123,9 +1204,15 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
       const char* B2 = (const char*)B + (b_kstrided ? (long)N1 * es : (long)N1 * ldb * es);
       sw_epilogue ep1 = {};
       ep1.out_dtype = SW_F32; ep1.drop_scale = 1.f; ep1.ref_scale = 1.f;
+      const sw_sgd_tensor* fz = ep ? ep->sgd_fused : nullptr;
+      if (fz) {                                     // the whole rounds update the parameter in their epilogue; the tail below goes through C
+        if (!sgd_fused_shape_ok(dtype, a_kstrided, b_kstrided, M, N1, K)) return -5;
+        ep1.sgd_fused = fz; ep1.sgd_momentum = ep->sgd_momentum; ep1.sgd_grad_scale = ep->sgd_grad_scale;
+      }
       int rc = sw_gemm(dtype, a_kstrided, b_kstrided, M, N1, K, A, lda, B, ldb, C, ldc, &ep1, 1, stream);
       if (rc) return rc;
       float* C2 = (float*)C + N1;
+      ep1.sgd_fused = nullptr;
       sw_epilogue ep2 = ep1;
       if (det_ws) ep2.splitk_workspace = det_ws;
       else if (sk > 1) {
@@ -1133,8 +1220,20 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
         if (e != hipSuccess) return (int)e;
         ep2.accumulate_atomic = 1;
       }
-      return sw_gemm(dtype, a_kstrided, b_kstrided, M, N2, K, A, lda, B2, ldb, C2, ldc, &ep2, (int)sk, stream);
+      rc = sw_gemm(dtype, a_kstrided, b_kstrided, M, N2, K, A, lda, B2, ldb, C2, ldc, &ep2, (int)sk, stream);
+      if (rc || !fz) return rc;
+      // the tail columns' gradient sits in C2: the tiled update kernel on that column block (same arithmetic, same copies)
+      return sw_sgd_tile_t_block(M, N2, fz->param + N1, C2, fz->momentum_buf + N1, ldc, fz->lr, fz->weight_decay, fz->first_step,
+                                 ep->sgd_momentum, ep->sgd_grad_scale, fz->stage0 ? (unsigned short*)fz->stage0 + N1 : nullptr, fz->ld0,
+                                 (unsigned short*)fz->stage1 + (long)N1 * fz->ld1, fz->ld1, fz->hyper_dev, stream);
     }
+  }
+  if (ep && ep->sgd_fused) {
+    const sw_sgd_tensor* fz = ep->sgd_fused;
+    if (!plain || splitk > 1 || !sgd_fused_shape_ok(dtype, a_kstrided, b_kstrided, M, N, K)) return -5;
+    if (fz->stage_kind != 3 || fz->stage_dtype != SW_BF16 || !fz->stage1 || fz->d0 < N || !fz->param || !fz->momentum_buf) return -5;
+    if ((ldc % 4) || (fz->ld0 % 4) || (fz->ld1 % 8) || ((((uintptr_t)fz->param) | ((uintptr_t)fz->momentum_buf)) & 15) ||
+        (((uintptr_t)fz->stage0) & 7) || (((uintptr_t)fz->stage1) & 15)) return -4;
   }
   const int eff = effective_splits(dtype, K, splitk);
   // split-K with an epilogue (a few-tile, long-K GEMM whose result is not a plain f32 matrix: the 1x1 convolutions of res4 / res5, a
@@ -1178,6 +1277,13 @@ extern "C" int sw_gemm(int dtype, int a_kstrided, int b_kstrided, int M, int N, 
     g.ref = ep->relu_ref; g.ldr = ep->ld_ref; g.ref_scale = ep->ref_scale; g.ref_bf16 = ep->ref_dtype == SW_BF16;
     g.res = ep->residual; g.ldres = ep->ld_res; g.res_bf16 = ep->res_dtype == SW_BF16;
     g.relu = ep->relu; g.out_bf16 = ep->out_dtype == SW_BF16; g.atomic = ep->accumulate_atomic; g.absmax = ep->absmax_out;
+    if (ep->sgd_fused) {
+      const sw_sgd_tensor* fz = ep->sgd_fused;
+      g.sgd_param = fz->param; g.sgd_mom = fz->momentum_buf; g.sgd_ld = ldc;
+      g.sgd_st0 = (unsigned short*)fz->stage0; g.sgd_ld0 = fz->ld0; g.sgd_st1 = (unsigned short*)fz->stage1; g.sgd_ld1 = fz->ld1;
+      g.sgd_hyper = fz->hyper_dev; g.sgd_lr = fz->lr; g.sgd_wd = fz->weight_decay; g.sgd_first = fz->first_step;
+      g.sgd_momentum = ep->sgd_momentum; g.sgd_gscale = ep->sgd_grad_scale;
+    }
     if (!ep->drop_mask && ep->drop_hash_p > 0.f) {
       unsigned long long x = ep->drop_seed;                  // splitmix64(seed), as the mask kernel mixes it
       x += 0x9E3779B97F4A7C15ull;

@@ -693,20 +693,42 @@ def sgd_multi(entries, momentum, grad_scale=1.0):
         return
     arr = (SgdTensor * n)()
     for i, e in enumerate(entries):
-        p, d = e["param"], arr[i]
-        d.param, d.grad, d.momentum_buf, d.n = p.data_ptr(), e["grad"].data_ptr(), e["buf"].data_ptr(), p.numel()
-        d.lr, d.weight_decay, d.first_step = float(e["lr"]), float(e["weight_decay"]), int(e["first"])
-        hy = e.get("hyper")
-        d.hyper_dev = None if hy is None else hy.data_ptr()
-        st = e.get("staging")
-        if st is None:
-            d.stage_kind = 0
-        else:
-            d.stage_kind, d.stage_dtype = st["kind"], dt(st["dtype"])
-            d.stage0 = None if st["stage0"] is None else st["stage0"].data_ptr()
-            d.stage1 = None if st["stage1"] is None else st["stage1"].data_ptr()
-            d.d0, d.d1, d.d2, d.ld0, d.ld1 = st["d0"], st["d1"], st["d2"], st["ld0"], st.get("ld1", 0)
+        _fill_sgd_tensor(arr[i], e)
     check(lib.sw_sgd_multi(n, arr, float(momentum), float(grad_scale), _stream()), "sw_sgd_multi")
+
+
+def _fill_sgd_tensor(d, e):
+    p = e["param"]
+    g = e.get("grad")
+    d.param, d.grad, d.momentum_buf, d.n = p.data_ptr(), (None if g is None else g.data_ptr()), e["buf"].data_ptr(), p.numel()
+    d.lr, d.weight_decay, d.first_step = float(e["lr"]), float(e["weight_decay"]), int(e["first"])
+    hy = e.get("hyper")
+    d.hyper_dev = None if hy is None else hy.data_ptr()
+    st = e.get("staging")
+    if st is None:
+        d.stage_kind = 0
+    else:
+        d.stage_kind, d.stage_dtype = st["kind"], dt(st["dtype"])
+        d.stage0 = None if st["stage0"] is None else st["stage0"].data_ptr()
+        d.stage1 = None if st["stage1"] is None else st["stage1"].data_ptr()
+        d.d0, d.d1, d.d2, d.ld0, d.ld1 = st["d0"], st["d1"], st["d2"], st["ld0"], st.get("ld1", 0)
+
+
+def gemm_sgd_fused_supported(dtype, M, N, K, a_kstrided=False, b_kstrided=False):
+    """can sw_gemm take an epilogue with `sgd_fused` for this shape (the ping-pong 256x256 form; see sw_epilogue.sgd_fused)?"""
+    return bool(lib.sw_gemm_sgd_fused_supported(dt(dtype), int(a_kstrided), int(b_kstrided), int(M), int(N), int(K)))
+
+
+def attach_sgd_fused(ep, entry, momentum, grad_scale=1.0):
+    """ep: an Epilogue for the weight-gradient GEMM of a 2D parameter; entry: the optimizer's record for that parameter (as for sgd_multi,
+    without a gradient).  The GEMM then applies the SGD update in its epilogue instead of writing the gradient (sw_epilogue.sgd_fused)."""
+    from ._lib import SgdTensor
+    d = SgdTensor()
+    _fill_sgd_tensor(d, entry)
+    ep.sgd_fused = ctypes.addressof(d)
+    ep.sgd_momentum, ep.sgd_grad_scale = float(momentum), float(grad_scale)
+    ep._keepalive = ep._keepalive + (d, entry["param"], entry["buf"], entry.get("hyper"))
+    return ep
 
 
 def mean_views(x, out):

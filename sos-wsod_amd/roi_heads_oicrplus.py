@@ -168,10 +168,13 @@ class _HeadsFc6Function(torch.autograd.Function):
         st = ctx.box[0]
         if g_handle is None or st is None or "dz1" not in st:
             return (None,) * 5
-        dW1, db1 = ctx.heads._train_backward_fc6(st)
+        # fused update (Trainer sets heads._fused_opt on the single-GPU, ITER_SIZE 1 path): fc1.weight's SGD step runs in the epilogue of its
+        # weight-gradient GEMM and rewrites the bf16 copies the fc6 DATA gradient reads — so that GEMM is deferred until the data gradient
+        # has been computed (stage 3), and fc1.weight receives no .grad (the optimizer's step() skips it)
+        dW1, db1 = ctx.heads._train_backward_fc6(st, defer_fused=bool(ctx.req[0]))
         if not ctx.req[0]:
             ctx.box[0] = None                      # no feature gradient wanted: this is the last stage
-        return (None, None, ctx.heads._handle(dW1.device) if ctx.req[0] else None,
+        return (None, None, ctx.heads._handle(db1.device) if ctx.req[0] else None,
                 dW1 if ctx.req[1] else None, db1 if ctx.req[2] else None)
 
 
@@ -655,7 +658,35 @@ class OICRPlusHeads(nn.Module):
             row += n
         return [g if p.requires_grad else None for g, p in zip(dparams, params_top)]
 
-    def _train_backward_fc6(self, st):
+    def _fused_fc1_plan(self, M, D0, D1):
+        """-> (entry, momentum, finish) when fc1.weight's update can run in its weight-gradient GEMM's epilogue, else None"""
+        opt = getattr(self, "_fused_opt", None)
+        if (opt is None or self.compute_dtype != torch.bfloat16 or (M % 8) or getattr(self, "fp32x3", False)
+                or getattr(self, "_fc6_panels", None) is not None or getattr(self, "_staged", False)
+                or not ops.gemm_sgd_fused_supported(torch.bfloat16, D1, D0, M, False, True)):
+            return None
+        w = self.box_head.fc1.weight
+        if not w.requires_grad or w.grad is not None:
+            return None
+        return opt.fused_update_entry(w)
+
+    def _fused_fc1_wgrad(self, st):
+        """the deferred weight-gradient GEMM of fc6 with fc1.weight's SGD update in its epilogue (sw_epilogue.sgd_fused)"""
+        plan = st.pop("fused_fc1")
+        entry, momentum, finish = plan
+        pooled, dz1 = st["pooled"], st["dz1"]
+        dev, M = pooled.device, st["inp"]["M"]
+        D0, D1 = pooled.shape[1], dz1.shape[1]
+
+        def nn():
+            dzt = ops.transpose_2d(dz1, torch.empty(D1, M + 64, device=dev, dtype=torch.bfloat16)[:, :M], M, D1)
+            scratch = torch.empty(D1, D0, device=dev, dtype=torch.float32)      # only the peeled tail columns are ever written
+            ep = ops.attach_sgd_fused(ops.make_epilogue(out_dtype=torch.float32), entry, momentum, 1.0)
+            ops.gemm(dzt, pooled, scratch, D1, D0, M, b_kstrided=True, ep=ep)
+        ops._launch("fc6_wgrad_sgd", nn)
+        finish()
+
+    def _train_backward_fc6(self, st, defer_fused=False):
         """stage 2: the fc6 weight and bias gradients (411 MB of the step's 544 MB of gradients)"""
         dt_ = self.compute_dtype
         pooled, dz1 = st["pooled"], st["dz1"]
@@ -663,6 +694,12 @@ class OICRPlusHeads(nn.Module):
         D0, D1 = pooled.shape[1], dz1.shape[1]
         epc = 8 if dt_ == torch.bfloat16 else 4
         db1 = ops.grad_target(self.box_head.fc1.bias, (D1,), dev); ops.colsum(dz1, M, D1, db1)
+        plan = self._fused_fc1_plan(M, D0, D1)
+        if plan is not None:
+            st["fused_fc1"] = plan
+            if not defer_fused:                           # nobody asks for the feature gradient: no data-gradient GEMM will read the copies
+                self._fused_fc1_wgrad(st)
+            return None, db1
         dW1 = ops.grad_target(self.box_head.fc1.weight, (D1, D0), dev)
         panels = getattr(self, "_fc6_panels", None)       # (n, callback): the data-parallel reducer's SW_DDP_FC1_PANELS
         if panels is not None and panels[0] > 1 and D1 % (256 * panels[0]) == 0:
@@ -718,6 +755,8 @@ class OICRPlusHeads(nn.Module):
                                      row_scale=inp["obj"][b][2 * s:2 * s + 2].reshape(-1), row_scale_add=1.0, relu_ref=f,
                                      dout_absmax=amax, tag="roi_bwd", spatial_scale=self.box_pooler.scale)
                     dfeats[2 * b + s] = df
+        if "fused_fc1" in st:                              # the data gradient above was the last reader of fc1.weight's copies
+            self._fused_fc1_wgrad(st)
         return dfeats
 
     # ------------------------------------------------------------------ public forward

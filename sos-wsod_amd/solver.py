@@ -68,6 +68,36 @@ class HipSGD(torch.optim.Optimizer):
             self._done.add(id(p))
         self._update(items, grad_scale)
 
+    @torch.no_grad()
+    def fused_update_entry(self, p):
+        """For a weight-gradient GEMM that applies this parameter's update in its epilogue (ops.attach_sgd_fused; round 6, fc1.weight on
+        the single-GPU path): -> (entry, momentum, finish) or None when the parameter cannot take it (no tiled staging registered).
+        `entry` is what sgd_multi would get minus the gradient; call finish() after the launch (epoch / staging stamps, as _update does).
+        The parameter must not receive a .grad this iteration (step() then has nothing to do for it)."""
+        if self._group_of is None:
+            self._group_of = {id(q): (group, gi) for gi, group in enumerate(self.param_groups) for q in group["params"]}
+        ent = self._group_of.get(id(p))
+        staging = ops.STAGING.get(id(p))
+        if (ent is None or staging is None or staging["param"]() is not p or staging["kind"] != 3 or not self._staging_usable(staging, p)
+                or p.dtype != torch.float32 or not p.is_contiguous()):
+            return None
+        group, gi = ent
+        if self.device_hyper and (self._hyper_dev is None or not torch.cuda.is_current_stream_capturing()):
+            self.sync_hyper()
+        st = self.state[p]
+        first = "momentum_buffer" not in st
+        if first:
+            st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
+        entry = dict(param=p, buf=st["momentum_buffer"], lr=group["lr"], weight_decay=group["weight_decay"], first=first,
+                     staging=staging, hyper=self._hyper_dev[gi] if self.device_hyper else None)
+
+        def finish():
+            ops.PARAM_EPOCH += 1
+            ops.mark_updated(p)
+            if staging["stamp"] is not None:
+                staging["stamp"](ops.param_key(p))
+        return entry, float(group["momentum"]), finish
+
     def _update(self, items, grad_scale):
         if not items:
             return

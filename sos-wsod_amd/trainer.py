@@ -163,6 +163,13 @@ class Trainer:
                 self.model.register_comm_hook(None, reduce_hook)
         else:
             self.model = model
+        # fc1.weight's SGD update inside its weight-gradient GEMM's epilogue (round 6; sw_epilogue.sgd_fused): single process, ITER_SIZE 1
+        # — a data-parallel step needs the all-reduced gradient, an accumulating one the sum of its micro-steps.  SW_FUSE_FC1_UPDATE=0: off
+        heads = getattr(model, "roi_heads", None)
+        if heads is not None and hasattr(heads, "_fused_fc1_plan"):
+            fuse = (not use_ddp and self.iter_size == 1 and hasattr(optimizer, "fused_update_entry")
+                    and os.environ.get("SW_FUSE_FC1_UPDATE", "1") == "1")
+            heads.__dict__["_fused_opt"] = optimizer if fuse else None
         if self._want_graph and not use_ddp and self.iter_size == 1 and hasattr(model, "roi_heads") and \
                 next(model.parameters()).is_cuda:
             self._graphs = _StepGraphs(self)

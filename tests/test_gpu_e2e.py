@@ -583,6 +583,58 @@ def test_full_size_iteration_is_reproducible():
     assert not diff, diff
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_fc1_update_equals_the_optimizer_step_bit_for_bit(monkeypatch, graph):
+    """Round 6: on the single-GPU path fc1.weight's SGD update runs in the epilogue of fc6's weight-gradient GEMM (sw_epilogue.sgd_fused;
+    the GEMM is deferred behind the fc6 data gradient, the last reader of the weight copies it rewrites; the 411 MB gradient is never
+    written).  Full-size model, five steps with a learning-rate milestone, against the same trainer with SW_FUSE_FC1_UPDATE=0: every loss
+    vector and every parameter identical bit for bit; eager and as one captured hipGraph; the fused launch really ran."""
+    import bench
+    import sos_wsod_amd.ops as ops
+    from sos_wsod_amd.solver import HipSGD, WarmupMultiStepLR
+    from sos_wsod_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    data = [bench.make_inputs(dev, 100 + i) for i in range(2)]
+    calls = {"n": 0}
+    real = ops.attach_sgd_fused
+
+    def spy(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(ops, "attach_sgd_fused", spy)
+
+    def run(fuse):
+        monkeypatch.setenv("SW_FUSE_FC1_UPDATE", "1" if fuse else "0")
+        model = bench.build(dev, torch.bfloat16); model.train()
+        gs = [{"params": [p], "lr": 2e-3 if n.endswith(".bias") else 1e-3, "weight_decay": 0.0 if n.endswith(".bias") else 5e-4}
+              for n, p in model.named_parameters() if p.requires_grad]
+        opt = HipSGD(gs, 1e-3, momentum=0.9)
+        tr = Trainer(model, opt, scheduler=WarmupMultiStepLR(opt, [3], gamma=0.5, warmup_iters=0), use_graph=graph)
+        assert (model.roi_heads.__dict__.get("_fused_opt") is opt) == fuse
+        losses = []
+        for i in range(5):
+            losses.append(tr.run_step(data[i % 2]).vector.detach().clone())
+        tr.finish()
+        torch.cuda.synchronize()
+        w1 = model.roi_heads.box_head.fc1.weight
+        assert ("momentum_buffer" in opt.state[w1])
+        out = (losses, {n: p.detach().clone() for n, p in model.named_parameters()}, opt.state[w1]["momentum_buffer"].clone())
+        del tr, opt, model
+        return out
+    n0 = calls["n"]
+    lf, wf, mf = run(True)
+    assert calls["n"] - n0 >= (2 if graph else 5), calls                      # (a replayed step launches from the graph: no Python call)
+    n1 = calls["n"]
+    lu, wu, mu = run(False)
+    assert calls["n"] == n1
+    for i, (a, b) in enumerate(zip(lf, lu)):
+        assert torch.equal(a, b), (i, a, b)
+    diff = [n for n in wf if not torch.equal(wf[n], wu[n])]
+    assert not diff, diff
+    assert torch.equal(mf, mu)
+    assert not torch.equal(wf["roi_heads.box_head.fc1.weight"], bench.build(dev, torch.bfloat16).roi_heads.box_head.fc1.weight)
+
+
 def test_train_loop_from_proposal_file_to_checkpoint(tmp_path):
     """the pieces of §8f in one loop, as train_net_multi.py wires them: proposal pickle -> device mapper -> Trainer.run_step
     (HipSGD + WarmupMultiStepLR) -> DetectionCheckpointer.save -> resume into a fresh model -> identical next iteration"""

@@ -801,6 +801,47 @@ def test_refine_loss_and_grad(ops, R, K):
     assert torch.all(dl.cpu()[:, :cls_col] == 7.0)             # other columns untouched
 
 
+@pytest.mark.parametrize("first", [True, False])
+@pytest.mark.parametrize("M,N,K", [(4096, 25088, 2048), (512, 25600, 1024)])
+def test_gemm_fused_sgd_epilogue_equals_gemm_then_optimizer(ops, M, N, K, first):
+    """sw_epilogue.sgd_fused (round 6): the weight-gradient GEMM applies the SGD update in its epilogue — parameter, momentum buffer, the
+    row-major and the transposed bf16 copies come out BIT-identical to the GEMM writing the gradient followed by the optimizer's tiled
+    kernel (sw_sgd_multi, stage_kind 3), whole rounds through the epilogue and the peeled tail columns through the tiled kernel
+    ((4096, 25088): fc6's shape = 6 rounds + 2 peeled tile columns; (512, 25600): 200 tiles, no peel), first step (no momentum yet) or not,
+    learning rate / weight decay from a device buffer."""
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda"); g.manual_seed(M + N + K + int(first))
+    A = (torch.randn(M, K + 64, device="cuda", generator=g) * 0.05).to(dt)[:, :K]          # dZ^T (K-contiguous)
+    B = (torch.randn(K, N + 64, device="cuda", generator=g).clamp_(min=0)).to(dt)[:, :N]  # pooled (K-strided)
+    w0 = torch.randn(M, N, device="cuda", generator=g) * 0.01
+    m0 = torch.randn(M, N, device="cuda", generator=g) * 0.001
+    hyper = torch.tensor([1e-3, 5e-4], device="cuda")
+    assert ops.gemm_sgd_fused_supported(dt, M, N, K, False, True)
+
+    def state():
+        w, mo = w0.clone(), m0.clone()
+        st0 = torch.zeros(M, N + 128, device="cuda", dtype=dt)[:, :N]; st1 = torch.zeros(N, M + 128, device="cuda", dtype=dt)[:, :M]
+        staging = dict(kind=3, dtype=dt, stage0=st0, stage1=st1, d0=N, d1=0, d2=0, ld0=st0.stride(0), ld1=st1.stride(0))
+        return w, mo, st0, st1, staging
+    # reference: gradient to memory, then the optimizer's kernel
+    w, mo, st0, st1, staging = state()
+    dW = torch.empty(M, N, device="cuda")
+    ops.gemm(A, B, dW, M, N, K, b_kstrided=True)
+    ops.sgd_multi([dict(param=w, grad=dW, buf=mo, lr=123.0, weight_decay=456.0, first=first, staging=staging, hyper=hyper)], 0.9, 1.0)
+    # fused
+    w2, mo2, st02, st12, staging2 = state()
+    dW2 = torch.full((M, N), float("nan"), device="cuda")
+    ep = ops.make_epilogue(out_dtype=torch.float32)
+    ops.attach_sgd_fused(ep, dict(param=w2, buf=mo2, lr=123.0, weight_decay=456.0, first=first, staging=staging2, hyper=hyper), 0.9, 1.0)
+    ops.gemm(A, B, dW2, M, N, K, b_kstrided=True, ep=ep)
+    torch.cuda.synchronize()
+    assert torch.equal(w2, w) and torch.equal(mo2, mo)
+    assert torch.equal(st02.view(torch.int16), st0.view(torch.int16)) and torch.equal(st12.view(torch.int16), st1.view(torch.int16))
+    assert not torch.equal(w, w0)
+    n_written = int(torch.isfinite(dW2).any(dim=0).sum())                     # only the peeled tail columns carry a gradient
+    assert n_written in (0, 512), n_written
+
+
 def test_gemm_hash_dropout_equals_mask_dropout(ops):
     """dropout decided inside the epilogue (seed, offset, p) == the same GEMM with the keep mask sw_dropout_mask writes"""
     dt = torch.bfloat16

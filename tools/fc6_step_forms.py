@@ -23,3 +23,17 @@ for name, f in (("fwd", lambda: ops.gemm(X, W1, Y, M, D1, D0)),
                 ("wgrad", lambda: ops.gemm(dZT, X, dW, D1, D0, M, b_kstrided=True))):
     t = timeit(f)
     print(f"{os.environ.get('TAG', '-'):8s} M={M} {name:6s} {t*1e3:7.0f} us  {fl/t/1e9:7.0f} TF/s  {fl/t/1e9/2500:.3f}", flush=True)
+# ---- the weight gradient + fc1.weight's SGD update: gradient to memory then the optimizer's tiled kernel, vs the fused epilogue (round 6)
+w = torch.randn(D1, D0, device=dev) * 0.01; mo = torch.zeros_like(w)
+st0 = torch.zeros(D1, D0 + 128, device=dev, dtype=dt)[:, :D0]; st1 = torch.zeros(D0, D1 + 128, device=dev, dtype=dt)[:, :D1]
+staging = dict(kind=3, dtype=dt, stage0=st0, stage1=st1, d0=D0, d1=0, d2=0, ld0=st0.stride(0), ld1=st1.stride(0))
+ent = dict(param=w, buf=mo, lr=1e-3, weight_decay=5e-4, first=False, staging=staging, hyper=None)
+def separate():
+    ops.gemm(dZT, X, dW, D1, D0, M, b_kstrided=True)
+    ops.sgd_multi([dict(ent, grad=dW)], 0.9, 1.0)
+epf = ops.attach_sgd_fused(ops.make_epilogue(out_dtype=torch.float32), ent, 0.9, 1.0)
+def fused():
+    ops.gemm(dZT, X, dW, D1, D0, M, b_kstrided=True, ep=epf)
+for name, f in (("wgrad then sgd_tile_t", separate), ("wgrad with the fused SGD epilogue", fused)):
+    t = timeit(f)
+    print(f"{os.environ.get('TAG', '-'):8s} M={M} {name:36s} {t*1e3:7.0f} us", flush=True)
