@@ -225,6 +225,16 @@ int sw_preprocess_multi(int dtype, int n, int H, int W, int cpad, const uint8_t*
 int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale, const void* feat,
                     const float* rois, int R, const float* row_scale, float row_scale_add, void* out,
                     void* argmax, int argmax_bits, long ld_out, sw_stream_t stream);
+/* The same with a device workspace of >= sw_roi_pool_fwd_workspace_bytes(nimg, R, PH, PW) bytes (16-byte aligned; contents need not
+ * survive the call).  With it, on bf16 maps of < 65535 pixels (H, W <= 255; PH, PW <= 8; C % 8 == 0) the ROI geometry — bin ranges,
+ * size classes, the (image, row band, class) task lists — is computed ONCE per call by a small kernel instead of once per channel
+ * slab inside the pooling kernel (large maps: half of that kernel's cycles).  Results are identical to sw_roi_pool_fwd's;
+ * workspace == NULL is sw_roi_pool_fwd. */
+long sw_roi_pool_fwd_workspace_bytes(int nimg, int R, int PH, int PW);
+int sw_roi_pool_fwd_ws(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale, const void* feat,
+                       const float* rois, int R, const float* row_scale, float row_scale_add, void* out,
+                       void* argmax, int argmax_bits, long ld_out, void* workspace, long workspace_bytes,
+                       sw_stream_t stream);
 /* dfeat [nimg][H][W][C] (dtype, fully overwritten) = scatter-add of dout by argmax, times the same row scale,
  * times (relu_ref > 0) when relu_ref != NULL (relu_ref has feat's layout/dtype).
  * dout_absmax (device scalar >= max|dout|, e.g. from sw_absmax or a GEMM epilogue; may be NULL): selects the fixed-point LDS

@@ -124,6 +124,9 @@ SIGNATURES = {
     "sw_preprocess_multi": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p), _F4, _F4, c_void_p, c_void_p]),
     "sw_roi_pool_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
                                 c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_void_p]),
+    "sw_roi_pool_fwd_workspace_bytes": (c_long, [c_int, c_int, c_int, c_int]),
+    "sw_roi_pool_fwd_ws": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
+                                   c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p]),
     "sw_roi_pool_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_long, c_void_p, c_int,
                                 c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "sw_absmax": (c_int, [c_int, c_long, c_void_p, c_void_p, c_void_p]),

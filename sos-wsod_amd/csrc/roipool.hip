@@ -998,6 +998,387 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
   SP_T(t_end); SP_ADD(6, t_begin, t_end);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Forward, ROW SPARSE TABLE form over a PREPARED TASK LIST (round 6; sw_roi_pool_fwd_ws with a workspace).
+//
+// The sparse-table kernel above spends half of a workgroup's cycles outside the scan on large maps (99x165 / 8000 ROIs, phase
+// clocks in profiles/r06_roi_phases.txt: ROI sort 5 %, per-chunk bin tables + owned-pair lists 29 %, barriers behind the chunk
+// scans 21 %) — and all of that is the SAME work in each of the 128 channel slabs.  Here a small kernel does it once per call:
+// every (ROI, bin row) pair becomes a 32-byte task record
+//     { r | ph << 16,  hs | he << 8,  output scale,  - ,   wb[0] | wb[1] << 16, ... wb[6] | wb[7] << 16 }      (wb = ws | we << 8, clipped)
+// filed under (image, row band of its first window row, class = level x window-height class) — a counting sort in ONE workgroup
+// per image.  The pooling kernel then only builds its table and walks the levels; at each level its lanes stream the (task, bin
+// column) items of that level straight from the list (records of the next item requested before the current one is scanned):
+// no chunks, no per-chunk barriers, one barrier per level.  Arithmetic, table and scan are the sparse kernel's, results
+// identical bit for bit.
+constexpr int TK_MAXB = 16;                                         // row bands per map at most (4 bits in RoiGeo::bands)
+constexpr int TK_SEG = SP_NCLS + 1;                                 // offsets per (image, band)
+
+__device__ __forceinline__ int tk_roi_class(const RoiGeom& g, int PW) {
+  int m = 1 << 30;                                                  // narrowest UNCLIPPED window of the ROI
+  for (int pw = 0; pw < PW; ++pw) {
+    const int ws = (int)floorf(__fmul_rn((float)pw, g.bin_w)), we = (int)ceilf(__fmul_rn((float)(pw + 1), g.bin_w));
+    m = min(m, we - ws);
+  }
+  m = max(m, 1);
+  const int L = min(31 - __clz(m), SP_NLEV - 1);
+  const float b = g.bin_h;
+  const int hc = b < 1.f ? 0 : b < 2.f ? 1 : b < 3.f ? 2 : b < 4.f ? 3 : b < 6.f ? 4 : b < 8.f ? 5 : 6;
+  return L * SP_NHC + hc;
+}
+
+// The list is built by two small launches, 256 ROIs per workgroup, thread = ROI (one workgroup per image took 25 us per 4000 ROIs,
+// all of it the ROI geometry on four SIMDs):
+//   roi_pool_geo_kernel    geometry of the ROI -> geo[r] (bin row / column ranges, class, bands, output scale) and the workgroup's
+//                          histogram over the cells (image, band, class) -> hist[workgroup][cell]
+//   roi_pool_tasks_kernel  every workgroup sums the histograms (cell totals -> the segment offsets, written by workgroup 0; the
+//                          workgroups before it -> where ITS tasks of a cell start) and files its ROIs' records; positions inside
+//                          a workgroup's share of a cell come from LDS atomics — any order gives the same pooled output.
+// tasks: [nimg][cap] records of 2 x u32x4; seg: [nimg][n_bands][TK_SEG] offsets into the image's records.
+constexpr int TK_CELLS = 64 * SP_NCLS;                              // nimg * n_bands <= 64
+constexpr int TK_PREP_NT = 256;
+struct RoiGeo { unsigned int hb[4], wb[4]; float mul; unsigned int bands; int cell0; unsigned int pad; };      // 48 bytes; cell0 = -1: no image
+
+__global__ __launch_bounds__(TK_PREP_NT) void roi_pool_geo_kernel(int nimg, int H, int W, int PH, int PW, float scale,
+                                                                  const float* __restrict__ rois, int R,
+                                                                  const float* __restrict__ row_scale, float row_scale_add, int band_S,
+                                                                  int band_rows, int n_bands, RoiGeo* __restrict__ geo, int* __restrict__ hist) {
+  __shared__ int s_cnt[TK_CELLS];
+  const int tid = threadIdx.x, ncell = nimg * n_bands * SP_NCLS;
+  for (int i = tid; i < ncell; i += TK_PREP_NT) s_cnt[i] = 0;
+  __syncthreads();
+  const int r = blockIdx.x * TK_PREP_NT + tid;
+  if (r < R) {
+    RoiGeo o;
+    const RoiGeom g = roi_geom(rois + (long)r * 5, scale, PH, PW);
+    const int img = g.batch;
+    o.cell0 = -1; o.bands = 0u; o.pad = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o.hb[k] = 0u; o.wb[k] = 0u; }
+    o.mul = row_scale ? (row_scale[r] + row_scale_add) : 1.0f;
+    if (img >= 0 && img < nimg) {
+      o.cell0 = img * n_bands * SP_NCLS + tk_roi_class(g, PW);
+      for (int pw = 0; pw < PW; ++pw) {
+        int ws = (int)floorf(__fmul_rn((float)pw, g.bin_w)), we = (int)ceilf(__fmul_rn((float)(pw + 1), g.bin_w));
+        ws = min(max(ws + g.start_w, 0), W); we = min(max(we + g.start_w, 0), W);
+        o.wb[pw >> 1] |= (unsigned)(ws | (we << 8)) << (16 * (pw & 1));
+      }
+      int row_lo = H, row_hi = 0;                                   // map rows any non-empty bin of the ROI reads
+      for (int ph = 0; ph < PH; ++ph) {
+        int hs = (int)floorf(__fmul_rn((float)ph, g.bin_h)), he = (int)ceilf(__fmul_rn((float)(ph + 1), g.bin_h));
+        hs = min(max(hs + g.start_h, 0), H); he = min(max(he + g.start_h, 0), H);
+        o.hb[ph >> 1] |= (unsigned)(hs | (he << 8)) << (16 * (ph & 1));
+        if (he > hs) { row_lo = min(row_lo, hs); row_hi = max(row_hi, he); }
+      }
+      // A ROI whose rows all lie inside ONE band's rows goes there whole: its 7 x 7 outputs per channel are then written by one
+      // workgroup as one 98-byte run, as on a map that fits LDS.  Bin rows of the other ROIs go to the band that owns the bin's first
+      // row (the 14-byte pieces of a channel's run then come from up to n_bands workgroups at different times: the partly written
+      // lines leave the L2 in between — 99x165 map / 8000 ROIs: 235 us of the call, tools/roi_tasks_forms.py with ROI_MAXH).
+      int whole = -1;
+      for (int b = 0; b < n_bands && whole < 0; ++b) {
+        const int y0 = min(b * band_S, max(0, H - band_rows));
+        if (row_lo >= row_hi || (row_lo >= y0 && row_hi <= y0 + band_rows)) whole = b;
+      }
+      int prev = -1, run = 0;
+      for (int ph = 0; ph < PH; ++ph) {
+        const int hs = (int)((o.hb[ph >> 1] >> (16 * (ph & 1))) & 0xFFu);
+        const int b = whole >= 0 ? whole : min(hs / band_S, n_bands - 1);                // (non-decreasing in ph)
+        o.bands |= (unsigned)b << (4 * ph);
+        if (b != prev) { if (run) atomicAdd(&s_cnt[o.cell0 + prev * SP_NCLS], run); prev = b; run = 0; }
+        ++run;
+      }
+      if (run) atomicAdd(&s_cnt[o.cell0 + prev * SP_NCLS], run);
+    }
+    geo[r] = o;
+  }
+  __syncthreads();
+  for (int i = tid; i < ncell; i += TK_PREP_NT) hist[(long)blockIdx.x * ncell + i] = s_cnt[i];
+}
+
+__global__ __launch_bounds__(TK_PREP_NT) void roi_pool_tasks_kernel(int nimg, int PH, int R, int n_bands, const RoiGeo* __restrict__ geo,
+                                                                    const int* __restrict__ hist, u32x4* __restrict__ tasks,
+                                                                    int* __restrict__ seg, long cap) {
+  __shared__ int s_tot[TK_CELLS], s_fill[TK_CELLS], s_band[65];
+  const int tid = threadIdx.x, ncell = nimg * n_bands * SP_NCLS, nwg = gridDim.x, me = blockIdx.x;
+  for (int c = tid; c < ncell; c += TK_PREP_NT) {
+    int tot = 0, before = 0;
+    for (int w = 0; w < nwg; ++w) { const int v = hist[(long)w * ncell + c]; tot += v; before += w < me ? v : 0; }
+    s_tot[c] = tot; s_fill[c] = before;
+  }
+  __syncthreads();
+  const int nib = nimg * n_bands;                                   // (image, band) pairs: tasks of a pair = one run of classes
+  if (tid < nib) { int t = 0; for (int c = 0; c < SP_NCLS; ++c) t += s_tot[tid * SP_NCLS + c]; s_band[tid + 1] = t; }
+  __syncthreads();
+  if (tid < nimg) {                                                 // exclusive offsets of the bands inside their image
+    int t = 0;
+    for (int b = 0; b < n_bands; ++b) { const int n = s_band[tid * n_bands + b + 1]; s_band[tid * n_bands + b + 1] = t; t += n; }
+  }
+  __syncthreads();
+  if (tid < nib) {
+    int t = s_band[tid + 1];
+    int* sg = seg + (long)tid * TK_SEG;
+    for (int c = 0; c < SP_NCLS; ++c) {
+      const int n = s_tot[tid * SP_NCLS + c];
+      s_fill[tid * SP_NCLS + c] += t;                               // cell start + the tasks earlier workgroups put there
+      if (me == 0) sg[c] = t;
+      t += n;
+    }
+    if (me == 0) sg[SP_NCLS] = t;
+  }
+  __syncthreads();
+  const int r = me * TK_PREP_NT + tid;
+  if (r >= R) return;
+  const RoiGeo o = geo[r];
+  if (o.cell0 < 0) return;
+  const int img = o.cell0 / (n_bands * SP_NCLS);
+  u32x4* my = tasks + (long)img * cap * 2;
+  int prev = -1, pos = 0;
+  for (int ph = 0; ph < PH; ++ph) {
+    const int b = (int)((o.bands >> (4 * ph)) & 15u);
+    if (b != prev) {                                                // reserve the whole run of bin rows this ROI has in band b
+      int run = 1;
+      for (int q = ph + 1; q < PH && (int)((o.bands >> (4 * q)) & 15u) == b; ++q) ++run;
+      pos = atomicAdd(&s_fill[o.cell0 + b * SP_NCLS], run);
+      prev = b;
+    }
+    const unsigned int hb = (o.hb[ph >> 1] >> (16 * (ph & 1))) & 0xFFFFu;
+    my[2 * (long)pos] = u32x4{(unsigned)r | ((unsigned)ph << 16), hb, __float_as_uint(o.mul), 0u};
+    my[2 * (long)pos + 1] = u32x4{o.wb[0], o.wb[1], o.wb[2], o.wb[3]};
+    ++pos;
+  }
+}
+
+template <typename IT, int CB, int NT, int PFIX = 0>
+__global__ __launch_bounds__(NT) void roi_pool_fwd_tasks_kernel(int H, int W, int C, long ld, int PH_, int PW_,
+                                                                const unsigned short* __restrict__ feat,
+                                                                const u32x4* __restrict__ tasks, const int* __restrict__ seg, long cap,
+                                                                unsigned short* __restrict__ out, IT* __restrict__ argmax,
+                                                                int band_S, int band_rows, int n_bands, int n_zsplit) {
+  const int PH = PFIX ? PFIX : PH_, PW = PFIX ? PFIX : PW_;
+  constexpr int EW = CB == 2 ? 2 : 4;                               // channels per table entry: 8-byte entries for 2-channel slabs, else 16
+  constexpr int NPL = CB / EW;                                      // planes of entries
+  typedef typename std::conditional<CB == 2, u32x2, u32x4>::type TE;
+  constexpr int PXT = (CB == 8 ? 5 : CB == 4 ? 10 : 20) * (1024 / NT);   // table pixels per thread (host: rows * W <= PXT * NT)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_seg[TK_SEG];
+  const int band = (int)(blockIdx.z % n_bands), zfirst = (int)(blockIdx.z / n_bands);
+  const int y0 = min(band * band_S, max(0, H - band_rows)), y1 = min(H, y0 + band_rows);        // map rows [y0, y1) live in LDS
+  const int npl_px = band_rows * W;                                 // pixels per plane (allocated)
+  const int npx_t = (y1 - y0) * W;                                  // pixels held
+  TE* tab = (TE*)smem;                                              // [NPL][npl_px]
+  const int c0 = xcd_grouped_slab() * CB, img = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int nb = PH * PW;
+  const unsigned short* fimg = feat + (long)img * H * W * C + c0;
+  if (tid < TK_SEG) s_seg[tid] = seg[((long)img * n_bands + band) * TK_SEG + tid];
+  __syncthreads();
+  const int n_tasks_end = s_seg[SP_NCLS];
+  if (n_tasks_end == s_seg[0]) return;                              // no bin row of this image starts in this band
+  const u32x4* my = tasks + (long)img * cap * 2;
+
+  // ---- level 0: candidates of the slab's pixels.  All of a thread's pixels are requested before the first is converted (one
+  // s_waitcnt per pixel left the 10 loads of a 4-channel slab in series: every one a 64-byte sector of its own at the NHWC pixel pitch)
+  int xk[PXT];
+  unsigned int raw[PXT][CB / 2];
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) {
+    const int px = tid + k * NT;
+    xk[k] = px < npx_t ? px - (px / W) * W : -1;
+#pragma unroll
+    for (int j = 0; j < CB / 2; ++j) raw[k][j] = 0u;
+    if (px < npx_t) {
+      const unsigned short* src = fimg + (long)(y0 * W + px) * C;
+      if (CB == 8) { const u32x4 w = *(const u32x4*)src; raw[k][0] = w[0]; raw[k][1] = w[1]; raw[k][2] = w[2]; raw[k][3] = w[3]; }
+      else if (CB == 4) { const u32x2 w = *(const u32x2*)src; raw[k][0] = w[0]; raw[k][1] = w[1]; }
+      else raw[k][0] = *(const unsigned int*)src;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PXT; ++k) {
+    const int px = tid + k * NT;
+    if (px < npx_t) {
+      const unsigned int inv = 0xFFFEu - (unsigned)(y0 * W + px);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        TE t;
+#pragma unroll
+        for (int e = 0; e < EW; ++e) {
+          const unsigned int w2 = raw[k][(EW * pl + e) >> 1];
+          t[e] = (key16_of((e & 1) ? (w2 >> 16) : (w2 & 0xFFFFu)) << 16) | inv;
+        }
+        tab[pl * npl_px + px] = t;
+      }
+    }
+  }
+  constexpr unsigned KEY_INIT = 0x007FFFFFu;                        // key(-inf) << 16 | 0xFFFF
+  const int stride = n_zsplit * NT;
+  for (int L = 0; L < SP_NLEV; ++L) {
+    const int t_lo = s_seg[L * SP_NHC], t_hi = s_seg[(L + 1) * SP_NHC];
+    if (t_lo >= n_tasks_end) break;                                 // no task at this or a higher level
+    __syncthreads();                                                // level L - 1 fully scanned (L = 0: table written)
+    if (L > 0) {
+      const int d = 1 << (L - 1);
+      TE nv[PXT][NPL];
+#pragma unroll
+      for (int k = 0; k < PXT; ++k) {
+        const int px = tid + k * NT;
+        if (px < npx_t) {
+          const bool two = xk[k] + d < W;
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {
+            const TE a = tab[pl * npl_px + px];
+            const TE b = two ? tab[pl * npl_px + px + d] : a;
+#pragma unroll
+            for (int e = 0; e < EW; ++e) nv[k][pl][e] = max(a[e], b[e]);
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < PXT; ++k) {
+        const int px = tid + k * NT;
+        if (px < npx_t) {
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) tab[pl * npl_px + px] = nv[k][pl];
+        }
+      }
+      __syncthreads();
+    }
+    const int span = 1 << L;
+    const int n_lvl = t_hi - t_lo, total = n_lvl * PW;
+    // Items (task, bin column) of the level: wave w of workgroup z takes items i_first + lane, i_first = z * NT + w * 64 + k * stride.
+    // The <= 10 records (7 bin columns) a wave's 64 items touch are consecutive in the list; 20 lanes fetch them (16 bytes each) THREE
+    // iterations ahead and the wave parks them in its own 2 x 320 bytes of LDS one iteration ahead: vector loads return in issue order with the
+    // output stores, so a record fetched one iteration ahead would make every iteration wait for the previous one's 16 stores to be
+    // acknowledged (measured: 63x63 map 152 -> 344 us); three iterations ahead the wave keeps ~48 stores in flight as the
+    // chunked kernel's fire-and-forget stores did.  No workgroup barrier inside a level.
+    const int i_w0 = zfirst * NT + (tid & ~63);
+    if (i_w0 < total) {                                             // (wave-uniform)
+    const int n_iter = (total - i_w0 + stride - 1) / stride;
+    const u32x4* lvl = my + 2 * (long)t_lo;
+    const int lane = tid & 63;
+    const int n_rec = (62 + PW) / PW + 1, slot = n_rec * 32;        // records a wave's 64 consecutive items can touch (7 columns: 10)
+    char* wbuf = smem + ((((size_t)NPL * npl_px * sizeof(TE)) + 15) & ~(size_t)15) + (size_t)(tid >> 6) * (2 * slot);
+    auto fetch = [&](int k) {                                       // lanes 0-19: their piece of iteration k's records
+      const int te = min((i_w0 + min(k, n_iter - 1) * stride) / PW + (lane >> 1), n_lvl - 1);
+      return lvl[2 * te + (lane & 1)];
+    };
+    u32x4 r1 = u32x4{0u, 0u, 0u, 0u}, r2 = r1;
+    if (lane < 2 * n_rec) { const u32x4 r0 = fetch(0); r1 = fetch(1); r2 = fetch(2); *(u32x4*)(wbuf + lane * 16) = r0; }
+    for (int k = 0; k < n_iter; ++k) {
+      u32x4 r3 = r2;
+      if (lane < 2 * n_rec) r3 = fetch(k + 3);
+      const int i_first = i_w0 + k * stride;
+      const int i = min(i_first + lane, total - 1);                 // lanes past the end redo the last item (same stores, same values)
+      const int te = i / PW, pw = i - te * PW;
+      const char* rec = wbuf + (k & 1) * slot + (te - i_first / PW) * 32;
+      const u32x4 q0 = *(const u32x4*)rec;
+      const unsigned int wb = *(const unsigned short*)(rec + 16 + 2 * pw);
+      const int r = (int)(q0[0] & 0xFFFFu), ph = (int)(q0[0] >> 16);
+      const int hs = (int)(q0[1] & 0xFFu), he = (int)(q0[1] >> 8);
+      const int ws = (int)(wb & 0xFFu), we = (int)(wb >> 8);
+      const int b = ph * PW + pw;
+      const bool empty = (he <= hs) || (we <= ws);
+      unsigned int best[CB];
+#pragma unroll
+      for (int q = 0; q < CB; ++q) best[q] = KEY_INIT;
+#ifdef SW_TK_NOSCAN                     // development ablation (tools/build_variant.sh): no window scan
+      if (!empty && hs == 250) {
+#else
+      if (!empty) {
+#endif
+        const int bw = we - ws;
+        const int he_lds = min(he, y1);
+        int cold_from = max(hs, y1);                                // first window row read from global memory
+        if (bw >= span) {
+          const int offB = bw - span;
+          const int last = (he_lds - 1 - y0) * W + ws;
+          for (int hh = hs; hh < he_lds; hh += 2) {
+            const int i0 = (hh - y0) * W + ws, i1 = min(i0 + W, last);
+            TE a0[NPL], b0[NPL], a1[NPL], b1[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+              a0[pl] = tab[pl * npl_px + i0]; b0[pl] = tab[pl * npl_px + i0 + offB];
+              a1[pl] = tab[pl * npl_px + i1]; b1[pl] = tab[pl * npl_px + i1 + offB];
+            }
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+              for (int e = 0; e < EW; ++e)
+                best[EW * pl + e] = max(max(max(max(best[EW * pl + e], a0[pl][e]), b0[pl][e]), a1[pl][e]), b1[pl][e]);
+            if (2 * span < bw) {                                    // only when the level was capped (SP_NLEV): spans in between
+              for (int rr = 0; rr < 2; ++rr) {
+                const int ib = rr ? i1 : i0;
+                for (int x = span; x < offB; x += span) {
+#pragma unroll
+                  for (int pl = 0; pl < NPL; ++pl) {
+                    const TE a = tab[pl * npl_px + ib + x];
+#pragma unroll
+                    for (int e = 0; e < EW; ++e) best[EW * pl + e] = max(best[EW * pl + e], a[e]);
+                  }
+                }
+              }
+            }
+          }
+        } else if (we == W) {                                       // clipped by the map's right edge: the span at ws ends at W
+          for (int hh = hs; hh < he_lds; ++hh) {
+            const int i0 = (hh - y0) * W + ws;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+              const TE a = tab[pl * npl_px + i0];
+#pragma unroll
+              for (int e = 0; e < EW; ++e) best[EW * pl + e] = max(best[EW * pl + e], a[e]);
+            }
+          }
+        } else {
+          cold_from = hs;                                           // narrower than the ROI's span for another reason: pixel loop
+        }
+        for (int hh = cold_from; hh < he; ++hh)
+          for (int x = ws; x < we; ++x) {
+            const int gi = hh * W + x;
+            const unsigned int inv0 = 0xFFFEu - (unsigned)gi;
+            unsigned int u[CB / 2];
+            if (CB == 8) { const u32x4 w = *(const u32x4*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; u[2] = w[2]; u[3] = w[3]; }
+            else if (CB == 4) { const u32x2 w = *(const u32x2*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; }
+            else u[0] = *(const unsigned int*)(fimg + (long)gi * C);
+#pragma unroll
+            for (int k = 0; k < CB / 2; ++k) {
+              best[2 * k] = max(best[2 * k], (key16_of(u[k] & 0xFFFFu) << 16) | inv0);
+              best[2 * k + 1] = max(best[2 * k + 1], (key16_of(u[k] >> 16) << 16) | inv0);
+            }
+          }
+      }
+      float mv[CB]; int mi[CB];
+      unsigned int lowest = best[0];
+#pragma unroll
+      for (int q = 0; q < CB; ++q) {
+        const unsigned int m = (unsigned int)((int)best[q] >> 31);
+        mv[q] = __uint_as_float((best[q] & 0xFFFF0000u) ^ (0x80000000u | (~m & 0x7FFF0000u)));
+        mi[q] = (int)(0xFFFEu - (best[q] & 0xFFFFu));
+        lowest = min(lowest, best[q]);
+      }
+      if (lowest == KEY_INIT) {
+#pragma unroll
+        for (int q = 0; q < CB; ++q)
+          if (best[q] == KEY_INIT) mv[q] = empty ? 0.f : -FLT_MAX;
+      }
+      const float mul = __uint_as_float(q0[2]);
+      const long o = (long)r * ld + (long)c0 * nb + b;
+#ifdef SW_TK_NOSTORE                    // development ablation: the 2 x CB stores only for a value that does not occur
+      if (lowest == 0x12345u)
+#endif
+#pragma unroll
+      for (int q = 0; q < CB; ++q) {
+        Elem<unsigned short>::store(out + o + (long)q * nb, __fmul_rn(mv[q], mul));
+        argmax[o + (long)q * nb] = ArgIdx<IT>::enc(mi[q]);
+      }
+      if (lane < 2 * n_rec) *(u32x4*)(wbuf + ((k + 1) & 1) * slot + lane * 16) = r1;     // iteration k + 1's records (fetched at k - 2)
+      r1 = r2; r2 = r3;
+    }
+    }
+  }     // levels
+}
+
 // max |x| over n elements -> out[0] (f32; caller zero-fills).  |x| as IEEE bits is monotone => integer atomicMax; a NaN in x
 // yields NaN, an Inf yields Inf.
 template <typename T>
@@ -1168,6 +1549,102 @@ int launch_fwd_sparse(int nimg, int H, int W, int C, long ld, int PH, int PW, fl
   return -100;
 }
 
+// prepared-task form (sw_roi_pool_fwd_ws): workspace = [nimg][TK_MAXB][TK_SEG] ints, then [nimg][R * PH] task records of 32 bytes
+inline size_t tasks_seg_bytes(int nimg) { return (((size_t)nimg * TK_MAXB * TK_SEG * 4) + 255) & ~(size_t)255; }
+inline size_t tasks_geo_bytes(int R) { return (((size_t)R * sizeof(RoiGeo)) + 255) & ~(size_t)255; }
+inline size_t tasks_hist_bytes(int nimg, int R) {
+  return ((((size_t)(R + TK_PREP_NT - 1) / TK_PREP_NT) * (size_t)nimg * TK_MAXB * SP_NCLS * 4) + 255) & ~(size_t)255;
+}
+inline bool tasks_shape_ok(int dtype, int nimg, int H, int W, int C, int PH, int PW, int R, const void* feat) {
+  return dtype == SW_BF16 && nimg > 0 && (C % 8) == 0 && (long)H * W < 65535 && H <= 255 && W <= 255 && R <= 65535 && PH <= 8 && PW <= 8 &&
+         (((uintptr_t)feat) & 15) == 0;
+}
+
+template <typename IT, int CB, int NT>
+int launch_tasks_kernel(dim3 grid, size_t lds, int H, int W, int C, long ld, int PH, int PW, const void* feat, const u32x4* tasks,
+                        const int* seg, long cap, void* out, void* argmax, int S, int rows, int n_bands, int nz, hipStream_t stream) {
+  auto kern = (PH == 7 && PW == 7) ? roi_pool_fwd_tasks_kernel<IT, CB, NT, 7> : roi_pool_fwd_tasks_kernel<IT, CB, NT, 0>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, H, W, C, ld, PH, PW, (const unsigned short*)feat, tasks, seg, cap,
+                     (unsigned short*)out, (IT*)argmax, S, rows, n_bands, nz);
+  SW_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename IT>
+int launch_fwd_tasks(int nimg, int H, int W, int C, long ld, int PH, int PW, float scale, const void* feat, const float* rois, int R,
+                     const float* row_scale, float row_scale_add, void* out, void* argmax, void* workspace, hipStream_t stream) {
+  // development switches: SW_ROI_TASKS_CB (4 / 8 channels per lane on banded maps), SW_ROI_TASKS_NT (1024 / 512 threads: one / two
+  // workgroups per CU), SW_ROI_TASKS_HALO (rows of overlap between bands; anything below ceil(H / PH) + 1 sends the tallest windows
+  // to the global-memory loop), SW_ROI_FWD_WGS (workgroup target)
+  static const int env_cb = getenv("SW_ROI_TASKS_CB") ? atoi(getenv("SW_ROI_TASKS_CB")) : 0;
+  static const int env_nt = getenv("SW_ROI_TASKS_NT") ? atoi(getenv("SW_ROI_TASKS_NT")) : 0;
+  static const int env_halo = getenv("SW_ROI_TASKS_HALO") ? atoi(getenv("SW_ROI_TASKS_HALO")) : 0;
+  static const int env_wgs = getenv("SW_ROI_FWD_WGS") ? atoi(getenv("SW_ROI_FWD_WGS")) : 0;
+  constexpr size_t LDS_ALL = 160 * 1024 - 1024;                     // the kernel's static LDS + alignment
+  int* seg = (int*)workspace;
+  RoiGeo* geo = (RoiGeo*)((char*)workspace + tasks_seg_bytes(nimg));
+  int* hist = (int*)((char*)geo + tasks_geo_bytes(R));
+  u32x4* tasks = (u32x4*)((char*)hist + tasks_hist_bytes(nimg, R));
+  const long cap = (long)R * PH;
+  // whole map at 32 B per pixel (8 channels per lane) where it fits, else row bands
+  int cb, nt, S, rows, n_bands;
+  if (PW < 3) return -100;                                          // a wave's 64 items then span more records than it has lanes to fetch
+  auto ring_bytes = [&](int nthreads) { return (size_t)(nthreads / 64) * 2 * (size_t)(((62 + PW) / PW + 1) * 32); };   // per-wave record ring
+  const bool plane8 = (size_t)H * W * 32 + ring_bytes(1024) <= LDS_ALL && (long)H * W <= 5 * 1024;
+  // maps that fit LDS whole at 8 channels per lane: the sparse kernel's per-chunk work is small there (63x63 / 4000 ROIs: 151 us against
+  // 155 + 18 us of list building), so they stay with it; SW_ROI_TASKS_PLANE=1 sends them here (A/B timing)
+  static const bool env_plane = getenv("SW_ROI_TASKS_PLANE") != nullptr;
+  if (plane8 && (env_cb == 0 || env_cb == 8)) {
+    if (!env_plane) return -100;
+    cb = 8; nt = 1024; S = H; rows = H; n_bands = 1;
+  }
+  else {
+    cb = env_cb == 8 ? 8 : env_cb == 2 ? 2 : 4;
+    nt = env_nt == 512 ? 512 : 1024;
+    const size_t budget = (nt == 512 ? LDS_ALL / 2 : LDS_ALL) - ring_bytes(nt);
+    const int pxb = cb * 4, pxt = (cb == 8 ? 5 : cb == 4 ? 10 : 20) * (1024 / nt);
+    int fit = (int)(budget / ((size_t)W * pxb));
+    if ((long)fit * W > (long)pxt * nt) fit = pxt * nt / W;
+    if (fit >= H) { S = H; rows = H; n_bands = 1; }
+    else {
+      const int halo = env_halo > 0 ? env_halo : (H + PH - 1) / PH + 1;
+      if (fit - halo < 4) return -100;
+      n_bands = (H + (fit - halo) - 1) / (fit - halo);
+      static const int env_bands = getenv("SW_ROI_TASKS_BANDS") ? atoi(getenv("SW_ROI_TASKS_BANDS")) : 0;   // development switch: more, overlapping bands
+      if (env_bands > n_bands) n_bands = env_bands;
+      S = (H + n_bands - 1) / n_bands;                              // equal bands
+      n_bands = (H + S - 1) / S;
+      static const bool tight = getenv("SW_ROI_TASKS_TIGHT") != nullptr;           // development switch: rows = S + halo as the sparse kernel
+      rows = tight ? S + halo : fit;                                // all the rows LDS holds: more ROIs lie inside one band
+      if (rows > H) rows = H;
+      if (n_bands > TK_MAXB) return -100;
+    }
+  }
+  if (nimg * n_bands > 64) return -100;
+  const int prep_wgs = (R + TK_PREP_NT - 1) / TK_PREP_NT;
+  hipLaunchKernelGGL(roi_pool_geo_kernel, dim3(prep_wgs), dim3(TK_PREP_NT), 0, stream, nimg, H, W, PH, PW, scale, rois, R, row_scale,
+                     row_scale_add, S, rows, n_bands, geo, hist);
+  hipLaunchKernelGGL(roi_pool_tasks_kernel, dim3(prep_wgs), dim3(TK_PREP_NT), 0, stream, nimg, PH, R, n_bands, (const RoiGeo*)geo,
+                     (const int*)hist, tasks, seg, cap);
+  SW_CHECK_LAUNCH();
+  const size_t lds = ((((size_t)rows * W * cb * 4) + 15) & ~(size_t)15) + ring_bytes(nt);
+  const int slabs = (C / cb) * nimg * n_bands;
+  const int target = env_wgs ? env_wgs : (nt == 512 ? 512 : 256);
+  int nz = (target + slabs / 2) / slabs;
+  nz = nz < 1 ? 1 : nz;
+  if ((long)n_bands * nz > 65535) return -6;
+  dim3 grid(C / cb, nimg, n_bands * nz);
+#define SW_TK(CBV, NTV) return launch_tasks_kernel<IT, CBV, NTV>(grid, lds, H, W, C, ld, PH, PW, feat, tasks, seg, cap, out, argmax, S, rows, \
+                                                                 n_bands, nz, stream)
+  if (cb == 8) { if (nt == 512) SW_TK(8, 512); SW_TK(8, 1024); }
+  if (cb == 2) { if (nt == 512) SW_TK(2, 512); SW_TK(2, 1024); }
+  if (nt == 512) SW_TK(4, 512);
+  SW_TK(4, 1024);
+#undef SW_TK
+}
+
 template <typename IT>
 int roi_fwd_dispatch(int dtype, int nimg, int H, int W, int C, long ld, int PH, int PW, float spatial_scale, const void* feat,
                      const float* rois, int R, const float* row_scale, float row_scale_add, void* out, void* argmax,
@@ -1288,15 +1765,37 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, con
 }
 }  // namespace
 
+extern "C" long sw_roi_pool_fwd_workspace_bytes(int nimg, int R, int PH, int PW) {
+  if (nimg <= 0 || R <= 0 || PH <= 0 || PW <= 0) return 0;
+  return (long)(tasks_seg_bytes(nimg) + tasks_geo_bytes(R) + tasks_hist_bytes(nimg, R)) + (long)nimg * R * PH * 32;
+}
+
 extern "C" int sw_roi_pool_fwd(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale,
                                const void* feat, const float* rois, int R, const float* row_scale,
                                float row_scale_add, void* out, void* argmax, int argmax_bits, long ld_out,
                                hipStream_t stream) {
+  return sw_roi_pool_fwd_ws(dtype, nimg, H, W, C, PH, PW, spatial_scale, feat, rois, R, row_scale, row_scale_add, out, argmax,
+                            argmax_bits, ld_out, nullptr, 0, stream);
+}
+
+extern "C" int sw_roi_pool_fwd_ws(int dtype, int nimg, int H, int W, int C, int PH, int PW, float spatial_scale,
+                                  const void* feat, const float* rois, int R, const float* row_scale,
+                                  float row_scale_add, void* out, void* argmax, int argmax_bits, long ld_out,
+                                  void* workspace, long workspace_bytes, hipStream_t stream) {
   SW_ENTER();
   if (R <= 0) return 0;
   const long ld = ld_out > 0 ? ld_out : (long)C * PH * PW;
   if (ld < (long)C * PH * PW) return -5;
   if (dtype != SW_BF16 && dtype != SW_F32) return -1;
+  static const bool no_tasks = getenv("SW_ROI_FWD_TASKS") && getenv("SW_ROI_FWD_TASKS")[0] == '0';      // development switch (A/B timing)
+  if (workspace && !no_tasks && (argmax_bits == 32 || argmax_bits == 16) && tasks_shape_ok(dtype, nimg, H, W, C, PH, PW, R, feat)) {
+    if ((((uintptr_t)workspace) & 15) || workspace_bytes < sw_roi_pool_fwd_workspace_bytes(nimg, R, PH, PW)) return -5;
+    const int rc = argmax_bits == 32
+        ? launch_fwd_tasks<int>(nimg, H, W, C, ld, PH, PW, spatial_scale, feat, rois, R, row_scale, row_scale_add, out, argmax, workspace, stream)
+        : launch_fwd_tasks<unsigned short>(nimg, H, W, C, ld, PH, PW, spatial_scale, feat, rois, R, row_scale, row_scale_add, out, argmax,
+                                           workspace, stream);
+    if (rc != -100) return rc;                                      // -100: shape not covered, the forms below take it
+  }
   if (argmax_bits == 32)
     return roi_fwd_dispatch<int>(dtype, nimg, H, W, C, ld, PH, PW, spatial_scale, feat, rois, R, row_scale, row_scale_add, out,
                                  argmax, stream);

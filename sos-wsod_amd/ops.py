@@ -610,15 +610,29 @@ def preprocess_multi(imgs_u8_chw, out_nhwc, mean, std):
     return out_nhwc
 
 
-def roi_pool_fwd(feat, rois, out, argmax, spatial_scale, PH, PW, row_scale=None, row_scale_add=0.0, tag=None):
+def roi_pool_fwd_workspace(n, R, PH, PW, device):
+    """scratch for roi_pool_fwd's prepared-task form (sw_roi_pool_fwd_ws); uint8, 256-byte aligned by the allocator"""
+    return torch.empty(max(16, lib.sw_roi_pool_fwd_workspace_bytes(n, R, PH, PW)), device=device, dtype=torch.uint8)
+
+
+def roi_pool_fwd(feat, rois, out, argmax, spatial_scale, PH, PW, row_scale=None, row_scale_add=0.0, tag=None, workspace="auto"):
     """feat [n][H][W][C], rois [R][5] f32, out [R][C*PH*PW]; argmax same shape, int32 (h*W+w or -1) or int16/uint16
-    storage holding uint16 (h*W+w or 0xFFFF; see argmax_to_int32)"""
+    storage holding uint16 (h*W+w or 0xFFFF; see argmax_to_int32).  workspace: roi_pool_fwd_workspace(...) tensor, "auto" = allocate
+    one here (caching allocator: graph-safe), None = the entry without workspace (sw_roi_pool_fwd)"""
     _need_gpu(feat, rois, out, argmax)
     n, H, W, C = feat.shape
     R = rois.shape[0]
-    check(_launch(tag, lambda: lib.sw_roi_pool_fwd(dt(feat), n, H, W, C, PH, PW, float(spatial_scale), _p(feat), _p(rois), R,
-                                                   _p(row_scale), float(row_scale_add), _p(out), _p(argmax), _argmax_bits(argmax),
-                                                   _roi_pitch(out, argmax), _stream())), "sw_roi_pool_fwd")
+    if isinstance(workspace, str):
+        workspace = roi_pool_fwd_workspace(n, R, PH, PW, feat.device) if R > 0 else None
+    if workspace is None:
+        check(_launch(tag, lambda: lib.sw_roi_pool_fwd(dt(feat), n, H, W, C, PH, PW, float(spatial_scale), _p(feat), _p(rois), R,
+                                                       _p(row_scale), float(row_scale_add), _p(out), _p(argmax), _argmax_bits(argmax),
+                                                       _roi_pitch(out, argmax), _stream())), "sw_roi_pool_fwd")
+    else:
+        check(_launch(tag, lambda: lib.sw_roi_pool_fwd_ws(dt(feat), n, H, W, C, PH, PW, float(spatial_scale), _p(feat), _p(rois), R,
+                                                          _p(row_scale), float(row_scale_add), _p(out), _p(argmax), _argmax_bits(argmax),
+                                                          _roi_pitch(out, argmax), _p(workspace), workspace.numel(), _stream())),
+              "sw_roi_pool_fwd_ws")
     return out, argmax
 
 

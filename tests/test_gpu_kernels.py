@@ -540,10 +540,12 @@ def test_roi_pool_forward_slab_widths_of_large_maps(ops, dtype, H, W):
     assert torch.equal(out.cpu().float().reshape(ref_out.shape), torch.from_numpy(ref_out).to(dtype).float())
 
 
+@pytest.mark.parametrize("ws", ["auto", None], ids=["prepared_tasks", "no_workspace"])
 @pytest.mark.parametrize("H,W,R", [(63, 63, 1500), (21, 30, 300), (60, 75, 900), (76, 114, 1200), (99, 165, 1600), (150, 200, 700), (9, 200, 200)])
-def test_roi_pool_forward_row_sparse_table_form_bit_exact(ops, H, W, R):
-    """bf16 forward through the row sparse table kernel (csrc/roipool.hip roi_pool_fwd_sparse_kernel: whole-map form up to ~4600 pixels,
-    row-band form beyond) against the C oracle on EVERY bin of every ROI of one 8-channel slab group: values, argmax and the objectness
+def test_roi_pool_forward_row_sparse_table_form_bit_exact(ops, H, W, R, ws):
+    """bf16 forward through the row sparse table kernels (csrc/roipool.hip: roi_pool_fwd_tasks_kernel over the task list
+    roi_pool_tasks_kernel prepares — sw_roi_pool_fwd_ws, the hot path — and roi_pool_fwd_sparse_kernel, the entry without workspace;
+    whole-map form up to ~4600 pixels, row-band form beyond) against the C oracle on EVERY bin of every ROI of one 8-channel slab group: values, argmax and the objectness
     prior.  The ROI set holds what the level rule has to survive: ROIs sticking out of the map on every side (windows the right edge
     clips below the ROI's span read one span; on the left they take the pixel loop), ROIs far outside, malformed (end < start), one
     pixel wide, the whole map, half-integer edges, widths right at a power of two, and (band form) ROIs reaching far below their
@@ -576,7 +578,8 @@ def test_roi_pool_forward_row_sparse_table_form_bit_exact(ops, H, W, R):
     for adt in (torch.int16, torch.int32):
         out = torch.full((R, C * 49 + 8), 7.0, device="cuda", dtype=torch.bfloat16)[:, :C * 49]
         arg = torch.empty(R, C * 49 + 8, device="cuda", dtype=adt)[:, :C * 49]
-        ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7, row_scale=torch.from_numpy(obj).cuda(), row_scale_add=1.0)
+        ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, 7, 7, row_scale=torch.from_numpy(obj).cuda(), row_scale_add=1.0,
+                         workspace=ws)
         got_arg = ops.argmax_to_int32(arg.contiguous()).cpu().numpy().reshape(ref_arg.shape)
         bad = np.argwhere(got_arg != ref_arg)
         assert len(bad) == 0, (adt, len(bad), bad[:4].tolist(), [rois[b[0]].tolist() for b in bad[:2]])
@@ -586,8 +589,9 @@ def test_roi_pool_forward_row_sparse_table_form_bit_exact(ops, H, W, R):
         assert torch.all(out.as_strided((R, 8), (C * 49 + 8, 1), C * 49) == 7.0)
 
 
-def test_roi_pool_forward_row_sparse_table_form_other_pooled_sizes(ops):
-    """the sparse-table kernel with a pooled size other than the hot path's compile-time 7 x 7 (runtime PH x PW form): 6 x 5 and 3 x 8"""
+@pytest.mark.parametrize("ws", ["auto", None], ids=["prepared_tasks", "no_workspace"])
+def test_roi_pool_forward_row_sparse_table_form_other_pooled_sizes(ops, ws):
+    """the sparse-table kernels with a pooled size other than the hot path's compile-time 7 x 7 (runtime PH x PW form): 6 x 5 and 3 x 8"""
     n, C, H, W, R = 2, 8, 40, 52, 500
     rng = np.random.RandomState(12)
     feat = (np.round(rng.randn(n, C, H, W) * 2) / 2).astype(np.float32)
@@ -598,7 +602,7 @@ def test_roi_pool_forward_row_sparse_table_form_other_pooled_sizes(ops):
     for ph, pw in ((6, 5), (3, 8)):
         ref_out, ref_arg = O.roi_pool_fwd(feat, rois, 1.0 / 8, ph, pw)
         out = torch.empty(R, C * ph * pw, device="cuda", dtype=torch.bfloat16); arg = torch.empty(R, C * ph * pw, device="cuda", dtype=torch.int32)
-        ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, ph, pw)
+        ops.roi_pool_fwd(f, torch.from_numpy(rois).cuda(), out, arg, 1.0 / 8, ph, pw, workspace=ws)
         assert np.array_equal(arg.cpu().numpy().reshape(ref_arg.shape), ref_arg), (ph, pw)
         assert torch.equal(out.cpu().float().reshape(ref_out.shape), torch.from_numpy(ref_out))
 
