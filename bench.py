@@ -495,9 +495,11 @@ def main():
                 t32.run_step(batches[i % 2])
             torch.cuda.synchronize()
             out["fp32_ms_per_step"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
-            # the same precision class with the fc6 / fc7 GEMMs as six-product bf16x3 GEMMs (three bf16 pieces per f32 operand, f32
-            # accumulation: ~2^-24 per product; tests: config #2 fp32 e2e parity under it) — an extra, never `value`
+            # the same precision class with the fc6 / fc7 GEMMs and the convolutions (all but conv1_1) as six-product bf16x3 GEMMs (three
+            # bf16 pieces per f32 operand, f32 accumulation: ~2^-24 per product; tests: config #2 fp32 e2e parity under it) — an
+            # extra, never `value`
             m32.roi_heads.fp32x3 = True
+            m32.backbone.fp32x3 = os.environ.get("SW_FP32X3_CONV", "1") != "0"     # the convolutions with >= 64 channels too (r6)
             for i in range(2):
                 t32.run_step(batches[i % 2])
             torch.cuda.synchronize(); t1 = time.perf_counter()

@@ -214,7 +214,16 @@ class _VGGFunction(torch.autograd.Function):
                         continue
                 out = torch.empty(cur.shape[0], cur.shape[1], cur.shape[2], blk.out_channels, device=x.device, dtype=dtype)
                 ep = ops.make_epilogue(bias=b, relu=True, out_dtype=dtype)
-                if not (module.winograd_ok(cin, blk.out_channels) and
+                if module.x3_layer(dtype, cin, blk.out_channels):
+                    # reference precision on the bf16 MFMA: the f32 input as three bf16 pieces, K-concatenated along the channels
+                    # ([a1|a1|a2|a1|a2|a3] against the weights' [b1|b2|b1|b3|b2|b1]): ONE bf16 convolution over 6 Cin, f32 accumulation
+                    # and output (sw_split_bf16x3; the fc layers' form, ops.gemm_f32x3)
+                    n_, h_, w_ = cur.shape[:3]
+                    x3 = ops.split_bf16x3(cur.view(n_ * h_ * w_, cin), 0,
+                                          out=torch.empty(n_ * h_ * w_, 6 * cin, device=x.device, dtype=torch.bfloat16))
+                    ops.conv3x3(x3.view(n_, h_, w_, 6 * cin), module.staged_weight_x3(w, 0, cin), out, blk.dilation, ep,
+                                tag=f"{blk.tag}.conv{ci + 1}_fwd")
+                elif not (module.winograd_ok(cin, blk.out_channels) and
                         ops.conv3x3_winograd(cur, module.winograd_weight(w, 0), out, blk.dilation, ep, tag=f"{blk.tag}.conv{ci + 1}_fwd")):
                     wk = module.staged_weight(w, 0, cin, dtype)
                     ops.conv3x3(cur, wk, out, blk.dilation, ep, tag=f"{blk.tag}.conv{ci + 1}_fwd")
@@ -251,7 +260,19 @@ class _VGGFunction(torch.autograd.Function):
         # grouped: the weight gradients of ALL layers and view batches run as ONE launch after the data-gradient chains
         # (sw_conv3x3_wgrad_grouped: 256x256 tiles, every CU busy); else one 128x128-tile launch per layer and view inside the chains
         grouped = module.grouped_wgrad
-        bk = 64 if dtype == torch.bfloat16 else 32
+        # fp32 mode with bf16x3: the weight gradients as bf16 problems over SIX stacked copies of the batch (the three-piece splits of dY
+        # and X along the image dimension, sw_split_bf16x3 along_rows: [a1;a1;a2;a1;a2;a3] against [b1;b2;b1;b3;b2;b1] — the sum over
+        # images is the sum of the six products) when every trainable convolution qualifies
+        x3w = False
+        if module.fp32x3 and dtype == torch.float32 and grouped:
+            x3w, pj = True, len(params)
+            for sj in range(len(module.blocks) - 1, -1, -1):
+                for cj in range(module.blocks[sj].num_conv - 1, -1, -1):
+                    pj -= 2
+                    if params[pj].requires_grad and not module.x3_layer(dtype, infos[live[0]][sj][0][cj][0].shape[3], module.blocks[sj].out_channels):
+                        x3w = False
+        wdt, nmul = (torch.bfloat16, 6) if x3w else (dtype, 1)
+        bk = 64 if wdt == torch.bfloat16 else 32
         deferred = []
         module._colsum_deferred = []
         target = module.wgrad_target_ktiles
@@ -266,10 +287,10 @@ class _VGGFunction(torch.autograd.Function):
                     if params[pj].requires_grad:
                         for i in live:
                             xin = infos[i][sj][0][cj][0]
-                            shapes.append((xin.shape[0] * xin.shape[1] * xin.shape[2], bj.out_channels, 9 * xin.shape[3]))
-                            probs6.append((xin.shape[0], xin.shape[1], xin.shape[2], xin.shape[3], bj.out_channels, bj.dilation))
+                            shapes.append((nmul * xin.shape[0] * xin.shape[1] * xin.shape[2], bj.out_channels, 9 * xin.shape[3]))
+                            probs6.append((nmul * xin.shape[0], xin.shape[1], xin.shape[2], xin.shape[3], bj.out_channels, bj.dilation))
                             keys.append((pj, i))
-            if _wgrad_direct_covers(probs6, dtype):
+            if _wgrad_direct_covers(probs6, wdt):
                 direct_ns = dict(zip(keys, _wgrad_direct_splits(probs6)))
             target = _wgrad_grouped_target(shapes, bk)
         plan = {}            # pidx -> dict(ws, rows, per-batch offsets, totals, dw, db)
@@ -286,10 +307,10 @@ class _VGGFunction(torch.autograd.Function):
                         x_in = infos[i][si][0][ci][0]
                         n, H, W, cin = x_in.shape
                         splits[i] = (direct_ns[(pidx, i)] if direct_ns is not None
-                                     else _wgrad_grouped_splits(n * H * W, bk, target) if grouped
+                                     else _wgrad_grouped_splits(nmul * n * H * W, bk, target) if grouped
                                      else _wgrad_splitk(cout, cin, n * H * W))
                         slab_off[i], row_off[i] = nslab, nrow
-                        nslab += ops.conv3x3_wgrad_nslab(x_in, cout, splits[i])
+                        nslab += ops.conv3x3_wgrad_nslab_shape(wdt, nmul * n, H, W, cin, cout, splits[i])
                         nrow += ops.colsum_nrows(dtype, n * H * W, cout)
                     cin = infos[live[0]][si][0][ci][0].shape[3]
                     plan[pidx] = dict(ws=torch.empty(nslab, cout * 9 * cin, device=dev, dtype=torch.float32),
@@ -310,7 +331,7 @@ class _VGGFunction(torch.autograd.Function):
                 if st is not main:
                     g.record_stream(st)
                 _VGGFunction._backward_one(module, infos[i], params, g, dtype, plan, i, first_trainable,
-                                           deferred if grouped else None, None if st is main else main)
+                                           deferred if grouped else None, None if st is main else main, x3w)
             infos[i] = None
         if side is not None:
             main.wait_stream(side)
@@ -329,7 +350,7 @@ class _VGGFunction(torch.autograd.Function):
         return (None, None) + (None,) * n_in + tuple(grads)
 
     @staticmethod
-    def _backward_one(module, stage_info, params, g, dtype, plan, i, first_trainable, deferred, consumer_stream):
+    def _backward_one(module, stage_info, params, g, dtype, plan, i, first_trainable, deferred, consumer_stream, x3w=False):
         g = g.contiguous()
         if g.dtype != dtype:
             g = g.to(dtype)
@@ -352,9 +373,17 @@ class _VGGFunction(torch.autograd.Function):
                     if deferred is None:
                         ops.conv3x3_wgrad_slabs(x_in, dz, pl["ws"][pl["slab_off"][i]:], blk.dilation, splitk=pl["splits"][i])
                     else:                       # the grouped launch reads (x_in, dz) later, on the main stream
+                        xw, dw_ = x_in, dz
+                        if x3w:                 # six stacked bf16 copies of the batch (see backward)
+                            cout = blk.out_channels
+                            xw = ops.split_bf16x3(x_in.view(npix, cin), 1, along_rows=True,
+                                                  out=torch.empty(6 * npix, cin, device=g.device, dtype=torch.bfloat16)).view(6 * n, H, W, cin)
+                            dw_ = ops.split_bf16x3(dz.view(npix, cout), 0, along_rows=True,
+                                                   out=torch.empty(6 * npix, cout, device=g.device, dtype=torch.bfloat16)).view(6 * n, H, W, cout)
                         if consumer_stream is not None:
-                            x_in.record_stream(consumer_stream); dz.record_stream(consumer_stream)
-                        deferred.append((x_in, dz, pl["ws"][pl["slab_off"][i]:], blk.dilation, pl["splits"][i]))
+                            xw.record_stream(consumer_stream); dw_.record_stream(consumer_stream)
+                            dz.record_stream(consumer_stream)
+                        deferred.append((xw, dw_, pl["ws"][pl["slab_off"][i]:], blk.dilation, pl["splits"][i]))
                     if deferred is None:
                         ops.colsum_partial(dz.view(npix, blk.out_channels), npix, blk.out_channels, pl["rows"][pl["row_off"][i]:])
                     else:       # bias partial rows of every layer x view batch: ONE launch behind the chains (18 launches before, each
@@ -367,7 +396,13 @@ class _VGGFunction(torch.autograd.Function):
                 dx = torch.empty(n, H, W, cin, device=g.device, dtype=dtype)
                 ref = x_in.view(n * H * W, cin) if ci > 0 else None
                 epd = ops.make_epilogue(relu_ref=ref, out_dtype=dtype)
-                if not (module.winograd_ok(blk.out_channels, cin) and
+                if module.x3_layer(dtype, blk.out_channels, cin):
+                    cout = blk.out_channels
+                    dz3 = ops.split_bf16x3(dz.view(n * H * W, cout), 0,
+                                           out=torch.empty(n * H * W, 6 * cout, device=g.device, dtype=torch.bfloat16))
+                    ops.conv3x3(dz3.view(n, H, W, 6 * cout), module.staged_weight_x3(w, 1, cin), dx, blk.dilation, epd,
+                                tag=f"{blk.tag}.conv{ci + 1}_dgrad")
+                elif not (module.winograd_ok(blk.out_channels, cin) and
                         ops.conv3x3_winograd(dz, module.winograd_weight(w, 1), dx, blk.dilation, epd)):
                     wkd = module.staged_weight(w, 1, cin, dtype)
                     ops.conv3x3(dz, wkd, dx, blk.dilation, epd, tag=f"{blk.tag}.conv{ci + 1}_dgrad")
@@ -392,6 +427,11 @@ class VGG16(nn.Module):
         self.wgrad_target_ktiles = int(os.environ.get("SW_WGRAD_KTILES", "0"))   # 0: chosen per shape set (_wgrad_grouped_target)
         self._side = None
         self._wk_cache = {}
+        self._wk3_cache = {}
+        # fp32 mode: the convolutions with >= 64 channels on both sides as six-product bf16x3 convolutions (the heads' fc GEMMs: roi_heads_oicrplus
+        # fp32x3).  SW_FP32X3_CONV=0 keeps them on the exact-f32 MFMA (A/B timing)
+        self.fp32x3 = (compute_dtype == torch.float32 and os.environ.get("SW_FP32X3", "0") == "1"
+                       and os.environ.get("SW_FP32X3_CONV", "1") != "0")
         # Winograd F(2x2, 3x3) for the forward / data gradient of the wide bf16 layers (csrc/conv_winograd.hip): 2.25x fewer MFMA cycles
         # than the direct kernel — built, bit-validated (relative L2 3.8e-3 against float64, the direct form 2.4e-3) and MEASURED SLOWER
         # on this part: conv5_3 42.4 vs 38.2 us, conv3_2 49.4 vs 39.3 us (profiles/r05_winograd_experiment.txt: the f32 input transform
@@ -451,6 +491,26 @@ class VGG16(nn.Module):
         if w.requires_grad:
             self._register_staging(w, dtype)
         return wk
+
+    def x3_layer(self, dtype, cin, cout):
+        """fp32 mode with MODEL.AMD.FP32_GEMM "bf16x3" (SW_FP32X3=1): this convolution runs as a six-product bf16 convolution"""
+        return self.fp32x3 and dtype == torch.float32 and cin % 64 == 0 and cout % 64 == 0
+
+    def staged_weight_x3(self, w, mode, cin_pad):
+        """the three-piece bf16 copy ([b1|b2|b1|b3|b2|b1] along the reduction channels) of the f32 kernel-layout weight staged_weight
+        holds: mode 0 [co][tap][6 ci], mode 1 [ci][tap][6 co]; rebuilt when the parameter changed"""
+        key = (ops.param_key(w), mode, cin_pad)
+        slot = (id(w), mode)
+        hit = self._wk3_cache.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        wk = self.staged_weight(w, mode, cin_pad, torch.float32)
+        rows, cols = wk.shape[0] * 9, wk.shape[2]
+        buf = hit[1] if hit is not None and tuple(hit[1].shape) == (wk.shape[0], 9, 6 * cols) else \
+            torch.empty(wk.shape[0], 9, 6 * cols, device=wk.device, dtype=torch.bfloat16)
+        ops.split_bf16x3(wk.view(rows, cols), 1, out=buf.view(rows, 6 * cols))
+        self._wk3_cache[slot] = (key, buf)
+        return buf
 
     def winograd_ok(self, cin, cout):
         return self.winograd and cin >= self.winograd_min_cin and cin % 32 == 0 and cout % 2 == 0
@@ -512,12 +572,17 @@ class VGG16(nn.Module):
                     elif with_dgrad and ft is not None and (si, ci) > ft:
                         self.staged_weight(c.weight, 1, cin, dtype)
                     continue
-                self.staged_weight(c.weight, 0, (cin + epc - 1) // epc * epc, dtype)
+                cin_pad = (cin + epc - 1) // epc * epc
+                self.staged_weight(c.weight, 0, cin_pad, dtype)
+                if self.x3_layer(dtype, cin_pad, cout):              # the three-piece copies too: both streams read them
+                    self.staged_weight_x3(c.weight, 0, cin_pad)
                 if with_dgrad and ft is not None and (si, ci) > ft:
                     if self.winograd_ok(cout, cin):
                         wino.append((c.weight, 1))
                     else:
                         self.staged_weight(c.weight, 1, cin, dtype)
+                        if self.x3_layer(dtype, cout, cin):
+                            self.staged_weight_x3(c.weight, 1, cin)
         self._winograd_refresh(wino)
 
     def first_trainable_conv(self):

@@ -34,6 +34,8 @@ struct DirectArgs {
   const float* bias; const void* ref;
   int nimg, H, W, Cin, Cout, relu;
   int pool;                            // 1: `out` is the 2x2 / stride-2 max-pooled map [nimg][(H-2)/2+1][(W-2)/2+1][Cout] (KG = 1 form only)
+  int out_f32;                         // 1: `out` (and `ref`, if any) hold f32: the bf16x3 convolutions of the fp32 mode (six-product form,
+                                       //    Cin = 6 x the layer's channels): the accumulators are stored as they are
   int tiles_x, tiles_y, n_px_tiles, n_co_blocks, total;
   unsigned in_bytes, wk_bytes;
 };
@@ -245,6 +247,32 @@ __device__ __forceinline__ void conv3x3_direct_body(const DirectArgs& g, const u
         fin[i2][j] = grp == 0 ? f32x4{mine[0] + got[0], mine[1] + got[1], mine[2] + got[2], mine[3] + got[3]}
                               : f32x4{got[0] + mine[0], got[1] + mine[1], got[2] + mine[2], got[3] + mine[3]};
       }
+    if (g.out_f32) {
+      // f32 output: straight from the accumulator layout (row = kq * 4 + e of the 16-pixel sub-tile, column = l15): 16 lanes write
+      // 64 contiguous bytes of a pixel; the launch runs 6x the K of a bf16 layer, the 4-byte stores do not show
+      float* outf = (float*)g.out;
+      const float* reff = (const float*)g.ref;
+      const int y = ty0 + 2 * wave + grp;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int co = co0 + j * 16 + l15;
+        const float bv = (g.bias && co < g.Cout) ? g.bias[co] : 0.f;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int x = tx0 + i2 * 16 + kq * 4 + e;
+            if (y < g.H && x < g.W && co < g.Cout) {
+              float v = fin[i2][j][e] + bv;
+              if (g.relu) v = fmaxf(v, 0.f);
+              const long o = (((long)img * g.H + y) * g.W + x) * g.Cout + co;
+              if (reff && !(reff[o] > 0.f)) v = 0.f;
+              outf[o] = v;
+            }
+          }
+      }
+      return;
+    }
     unsigned short* S = (unsigned short*)(smem + 8 * 2 * NI * 64 * 16 + wave_all * (32 * TN * 2));      // [32 pixels][TN]
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -280,6 +308,30 @@ __device__ __forceinline__ void conv3x3_direct_body(const DirectArgs& g, const u
         }
         *(u32x4*)(out + o) = v;
       }
+    }
+    return;
+  }
+  if (g.out_f32) {                                            // (see the K-group form above)
+    float* outf = (float*)g.out;
+    const float* reff = (const float*)g.ref;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int co = co0 + j * 16 + l15;
+      const float bv = (g.bias && co < g.Cout) ? g.bias[co] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pl = i * 16 + kq * 4 + e;
+          const int y = ty0 + 2 * wave + (pl >> 5), x = tx0 + (pl & 31);
+          if (y < g.H && x < g.W && co < g.Cout) {
+            float v = acc[i][j][e] + bv;
+            if (g.relu) v = fmaxf(v, 0.f);
+            const long o = (((long)img * g.H + y) * g.W + x) * g.Cout + co;
+            if (reff && !(reff[o] > 0.f)) v = 0.f;
+            outf[o] = v;
+          }
+        }
     }
     return;
   }
@@ -472,13 +524,16 @@ int sw_conv3x3_direct_try(int nimg, int H, int W, int Cin, int Cout, int dilatio
     return e1 == hipSuccess ? 1 : -(int)e1;
   }
   if ((Cin % CK) || (Cout % 8) || (dilation != 1 && dilation != 2)) return 0;
-  if (ep && (ep->out_dtype != SW_BF16 || ep->drop_mask || ep->accumulate_atomic || ep->absmax_out)) return 0;
+  if (ep && ((ep->out_dtype != SW_BF16 && ep->out_dtype != SW_F32) || ep->drop_mask || ep->accumulate_atomic || ep->absmax_out)) return 0;
   if (!ep) return 0;
-  if (ep->relu_ref && (ep->ref_dtype != SW_BF16 || ep->ld_ref != Cout || ep->ref_scale != 1.0f)) return 0;
+  // the ReLU-backward reference in the output's type (bf16 maps: bf16; the fp32 mode's bf16x3 convolutions: f32)
+  if (ep->relu_ref && (ep->ref_dtype != ep->out_dtype || ep->ld_ref != Cout || ep->ref_scale != 1.0f)) return 0;
+  if (ep->residual || ep->drop_hash_p > 0.f) return 0;
   if ((((uintptr_t)in | (uintptr_t)wk | (uintptr_t)out | (uintptr_t)ep->relu_ref) & 15)) return 0;
   if (!(sw && sw[0] == '1') && Cin < 64) return 0;           // (Cin % 32 == 0 leaves only conv1_1 to the implicit GEMM)
   DirectArgs g = {};
   g.in = in; g.wk = wk; g.out = out; g.bias = ep->bias; g.ref = ep->relu_ref; g.relu = ep->relu;
+  g.out_f32 = ep->out_dtype == SW_F32;
   g.nimg = nimg; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
   g.tiles_x = (W + TW - 1) / TW; g.tiles_y = (H + TH - 1) / TH;
   g.n_px_tiles = g.tiles_x * g.tiles_y * nimg;

@@ -441,6 +441,12 @@ def conv3x3_wgrad_nslab(x, cout, splitk):
     return int(lib.sw_conv3x3_wgrad_workspace_floats(dt(x), n, H, W, Cin, cout, splitk)) // (cout * 9 * Cin)
 
 
+def conv3x3_wgrad_nslab_shape(dtype, n, H, W, Cin, cout, splitk):
+    """conv3x3_wgrad_nslab for a batch given by its shape and torch dtype"""
+    code = SW_BF16 if dtype == torch.bfloat16 else SW_F32
+    return int(lib.sw_conv3x3_wgrad_workspace_floats(code, n, H, W, Cin, cout, splitk)) // (cout * 9 * Cin)
+
+
 def conv3x3_wgrad_slabs(x, dy, workspace, dilation, splitk=1):
     """split-K partial weight gradients of one (x, dy) pair into `workspace` (no fold): see sw_conv3x3_wgrad_slabs"""
     _need_gpu(x, dy, workspace)

@@ -159,8 +159,9 @@ def test_config3_per_gpu_shape_two_images_512_r2000_against_the_oracle():
 
 @pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
 def test_config2_fp32_end_to_end_against_the_oracle(gemm):
-    """gemm = "bf16x3": the same test with the fc6 / fc7 GEMMs (forward, data and weight gradients) as six-product bf16x3 GEMMs
-    (ops.gemm_f32x3: three bf16 pieces per operand, ~2^-24 |a||b| per product, f32 accumulation) — same bars.
+    """gemm = "bf16x3": the same test with the fc6 / fc7 GEMMs AND the convolutions from conv1_2 on (forward, data and weight
+    gradients) as six-product bf16x3 GEMMs (ops.gemm_f32x3 / backbone_vgg x3_layer: three bf16 pieces per operand, ~2^-24 |a||b| per
+    product, f32 accumulation) — same bars.
     BASELINE configs[1] in the reference's own precision, WHOLE path, nothing shrunk: 4 u8 views 512x512 in, R = 2000, K = 20,
     fc 4096/4096 (136 M closed-form parameters), injected dropout masks -> the oracle's full iteration with autograd on the host
     (the same call bench.py's cpu_baseline times: ~20 s on the GPU box) against the HIP path: the 9 losses within 1e-4 relative,
@@ -180,6 +181,7 @@ def test_config2_fp32_end_to_end_against_the_oracle(gemm):
     model.train()
     model.roi_heads.debug_drop_masks = [[torch.from_numpy(m) for m in v] for v in masks]
     model.roi_heads.fp32x3 = gemm == "bf16x3"
+    model.backbone.fp32x3 = gemm == "bf16x3"                 # the convolutions (>= 64 channels each side) as bf16x3 too (round 6)
     with EventStorage(0):
         losses = model(to_batched_inputs(views, gt))
         sum(losses.values()).backward()
@@ -208,6 +210,7 @@ def test_config2_fp32_end_to_end_against_the_oracle(gemm):
             assert p.grad is None and og.get(name) is not None      # the oracle differentiates everything; FREEZE_AT is the product's
             continue
         got, ref = p.grad.cpu().numpy(), og[name]
+        assert np.isfinite(got).all(), name
         err = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
         worst[name] = err
         if float(np.abs(ref).max()) <= 1e-6:                         # d/d(det.bias): analytically 0, noise on both sides

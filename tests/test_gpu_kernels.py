@@ -183,6 +183,38 @@ def test_conv3x3_direct_ragged_edge_forms(ops, n, H, W, cin, cout, dil):
     assert ((out2.double() - ref2).abs().max() / ref2.abs().max()) < 1e-2
 
 
+@pytest.mark.parametrize("n,H,W,cin,cout,dil", [(2, 19, 40, 64, 64, 1), (2, 63, 63, 128, 128, 2), (1, 70, 100, 64, 192, 1), (1, 9, 16, 128, 64, 1)])
+def test_conv3x3_bf16x3_convolution_is_f32_accurate(ops, n, H, W, cin, cout, dil):
+    """the fp32 mode's bf16x3 convolution (backbone_vgg.x3_layer): the f32 input and weights as three bf16 pieces each, K-concatenated
+    along the channels (sw_split_bf16x3 sides 0 / 1), ONE bf16 convolution over 6 Cin with f32 output — the direct kernel's f32 epilogue
+    (conv_direct.hip out_f32; few-tile shapes: the two-K-group form) — forward (bias + ReLU) and data-gradient form (f32 ReLU reference)
+    against a float64 convolution of the f32 operands: f32-class error (a plain bf16 convolution of these operands is ~3e-3)"""
+    g = torch.Generator(device="cuda"); g.manual_seed(H * 1000 + W + dil)
+    x = torch.randn(n, H, W, cin, device="cuda", generator=g) * torch.exp(torch.randn(n, H, W, cin, device="cuda", generator=g))
+    w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * 0.05
+    b = torch.randn(cout, device="cuda", generator=g) * 0.1
+    wk = torch.empty(cout, 9, cin, device="cuda", dtype=torch.float32)
+    ops.conv_weight_prep(w, wk, 0, cin)
+    wk3 = ops.split_bf16x3(wk.view(cout * 9, cin), 1, out=torch.empty(cout * 9, 6 * cin, device="cuda", dtype=torch.bfloat16)).view(cout, 9, 6 * cin)
+    x3 = ops.split_bf16x3(x.view(n * H * W, cin), 0, out=torch.empty(n * H * W, 6 * cin, device="cuda", dtype=torch.bfloat16)).view(n, H, W, 6 * cin)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=dil, dilation=dil)
+    ref = F.relu(y).permute(0, 2, 3, 1)
+    out = torch.full((n, H, W, cout), float("nan"), device="cuda")
+    ops.conv3x3(x3, wk3, out, dil, ops.make_epilogue(bias=b, relu=True, out_dtype=torch.float32))
+    assert torch.isfinite(out).all()
+    assert ((out.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    plain = torch.empty(n, H, W, cout, device="cuda")
+    wkb = wk.to(torch.bfloat16)
+    ops.conv3x3(x.to(torch.bfloat16), wkb, plain, dil, ops.make_epilogue(bias=b, relu=True, out_dtype=torch.float32))
+    assert ((plain.double() - ref).abs().max() / ref.abs().max()) > 2e-4              # the pieces matter on these operands
+    mask = torch.randn(n, H, W, cout, device="cuda", generator=g)
+    out2 = torch.full((n, H, W, cout), float("nan"), device="cuda")
+    ops.conv3x3(x3, wk3, out2, dil, ops.make_epilogue(relu_ref=mask.view(n * H * W, cout), out_dtype=torch.float32))
+    ref2 = (y - b.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1) * (mask.double() > 0)
+    assert torch.isfinite(out2).all()
+    assert ((out2.double() - ref2).abs().max() / ref2.abs().max()) < 2e-6
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("rows,cols", [(8000, 4096), (130, 72), (64, 64), (37, 200)])
 def test_transpose_2d(ops, dtype, rows, cols):

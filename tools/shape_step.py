@@ -1,5 +1,5 @@
 """One-GPU training step at a named shape, for rocprofv3 (tools/profile_shapes.sh) and quick timing:
-   python tools/shape_step.py recipe|coco|headline [steps]
+   python tools/shape_step.py recipe|coco|headline|fp32|fp32x3 [steps]
 recipe   = a 500x375 VOC image at the recipe's MEAN scale: short sides 832 and 864 (voc07_oicr_plus.yaml:30 draws two distinct sides from
            480..1216 step 32: mean 848) -> views 832x1109 + 864x1152, maps 104x139 and 108x144, R = 2000, K = 20, eager launches
 coco     = BASELINE configs[3] per GPU: 4 views 800x1333 (99x165 maps), R = 4000, K = 80, FREEZE_AT 3
@@ -22,6 +22,12 @@ def make(which, dev):
         model = bench.build(dev, torch.bfloat16)
         s1, s2 = RECIPE_MEAN
         data = [bench.make_inputs(dev, 900 + s1 + i, H=s1, W=int(500.0 / 375.0 * s1 + 0.5), scale2=s2 / s1) for i in range(2)]
+        graph = False
+    elif which in ("fp32", "fp32x3"):            # BASELINE configs[1] in the reference's precision; fp32x3: fc + conv GEMMs as bf16x3
+        model = bench.build(dev, torch.float32)
+        model.roi_heads.fp32x3 = which == "fp32x3"
+        model.backbone.fp32x3 = which == "fp32x3" and os.environ.get("SW_FP32X3_CONV", "1") != "0"
+        data = [bench.make_inputs(dev, 100 + i) for i in range(2)]
         graph = False
     else:
         model = bench.build(dev, torch.bfloat16)
