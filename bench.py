@@ -641,7 +641,7 @@ def main():
                 "ms_per_step": round(mean_scale_ms, 3),
                 "conv_fwd_dgrad": mfma_row(["conv_fwd", "conv_dgrad"], "conv3x3_direct_kernel: every forward + data-gradient convolution launch of the step", True),
                 "wgrad_grouped": mfma_row(["wgrad_grouped"], "conv_wgrad_direct_kernel: all weight gradients, one launch (folds not included)", False),
-                "roi_pool_fwd": ({"kernel": "roi_pool_fwd_sparse_kernel: 2 calls x 4000 ROIs x 512 x 7 x 7", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+                "roi_pool_fwd": ({"kernel": "roi_pool_fwd_tasks_kernel (+ the two list-building launches): 2 calls x 4000 ROIs x 512 x 7 x 7", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
                                   "algorithmic_bytes_per_step": sum(roi_b), "ms_per_step": round(roi_s / 3 * 1e3, 3),
                                   "achieved": round(sum(roi_b) * 3 / roi_s / 1e9, 1), "frac": round(sum(roi_b) * 3 / roi_s / 1e9 / 8000.0, 4)}
                                  if roi_s else None),
