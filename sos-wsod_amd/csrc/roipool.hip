@@ -1191,8 +1191,8 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_tasks_kernel(int H, int W, in
     for (int j = 0; j < CB / 2; ++j) raw[k][j] = 0u;
     if (px < npx_t) {
       const unsigned short* src = fimg + (long)(y0 * W + px) * C;
-      if (CB == 8) { const u32x4 w = *(const u32x4*)src; raw[k][0] = w[0]; raw[k][1] = w[1]; raw[k][2] = w[2]; raw[k][3] = w[3]; }
-      else if (CB == 4) { const u32x2 w = *(const u32x2*)src; raw[k][0] = w[0]; raw[k][1] = w[1]; }
+      if constexpr (CB == 8) { const u32x4 w = *(const u32x4*)src; raw[k][0] = w[0]; raw[k][1] = w[1]; raw[k][2] = w[2]; raw[k][3] = w[3]; }
+      else if constexpr (CB == 4) { const u32x2 w = *(const u32x2*)src; raw[k][0] = w[0]; raw[k][1] = w[1]; }
       else raw[k][0] = *(const unsigned int*)src;
     }
   }
@@ -1341,8 +1341,8 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_tasks_kernel(int H, int W, in
             const int gi = hh * W + x;
             const unsigned int inv0 = 0xFFFEu - (unsigned)gi;
             unsigned int u[CB / 2];
-            if (CB == 8) { const u32x4 w = *(const u32x4*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; u[2] = w[2]; u[3] = w[3]; }
-            else if (CB == 4) { const u32x2 w = *(const u32x2*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; }
+            if constexpr (CB == 8) { const u32x4 w = *(const u32x4*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; u[2] = w[2]; u[3] = w[3]; }
+            else if constexpr (CB == 4) { const u32x2 w = *(const u32x2*)(fimg + (long)gi * C); u[0] = w[0]; u[1] = w[1]; }
             else u[0] = *(const unsigned int*)(fimg + (long)gi * C);
 #pragma unroll
             for (int k = 0; k < CB / 2; ++k) {
@@ -1731,6 +1731,8 @@ int roi_bwd_dispatch(int nimg, int H, int W, int C, long ld, int PH, int PW, con
   constexpr size_t ACC_BUDGET = 150 * 1024;        // of the CU's 160 KiB: + 8 KiB ROI list + the static reduction scratch
   while (cbx > 4 && ((size_t)H * W * cbx * ab > ACC_BUDGET || (C % cbx) || (C / cbx) * nimg < 256)) cbx >>= 1;
   if (C % cbx) cbx = 0;
+  // (2-channel slabs on maps that need >= 3 pixel ranges at 4 channels — half the ranges, fewer ROIs straddling a range boundary and
+  // streamed twice — measured slower, round 6: 99x165 / 8000 ROIs 459 -> 486 us, 150x200 398 -> 458: twice the workgroups' fixed work)
   const int nsplit = cbx ? (int)(((size_t)H * W * cbx * ab + ACC_BUDGET - 1) / ACC_BUDGET) : 1;   // pixel ranges per plane
   if (cbx >= 4 && nsplit <= 16 && dout_absmax != nullptr && (((uintptr_t)dout & 7) == 0) && (((uintptr_t)argmax & 15) == 0) && (ld % 4) == 0 &&
       !float_atomics) {
