@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_tasks_kernel(int H, int W, in
   typedef typename std::conditional<CB == 2, u32x2, u32x4>::type TE;
   constexpr int PXT = (CB == 8 ? 5 : CB == 4 ? 10 : 20) * (1024 / NT);   // table pixels per thread (host: rows * W <= PXT * NT)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_seg[TK_SEG];
+  __shared__ int s_seg[TK_SEG], s_next[SP_NLEV];                  // s_next[L]: units of level L claimed so far
   // (band = blockIdx.z % n_bands keeps the 8 slabs of a 64-channel group, which write neighbouring runs of every ROI row, in the same
   // band at the same time on one XCD; dealing the bands so that the workgroups of a round differ in length — to take the chip out of
   // step: tables, then stores, everywhere at once — was slower: 99x165 / 8000 ROIs 486 -> 520 us per 8-slab group, 613 per slab)
@@ -1173,7 +1173,9 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_tasks_kernel(int H, int W, in
   const int tid = threadIdx.x;
   const int nb = PH * PW;
   const unsigned short* fimg = feat + (long)img * H * W * C + c0;
+  SP_T(t_begin);
   if (tid < TK_SEG) s_seg[tid] = seg[((long)img * n_bands + band) * TK_SEG + tid];
+  if (tid < SP_NLEV) s_next[tid] = 0;
   __syncthreads();
   const int n_tasks_end = s_seg[SP_NCLS];
   if (n_tasks_end == s_seg[0]) return;                              // no bin row of this image starts in this band
@@ -1213,12 +1215,21 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_tasks_kernel(int H, int W, in
       }
     }
   }
+  // Barriers of the level walk order LDS traffic only (table reads of level L - 1 before the advance writes, writes before the reads of
+  // level L): __syncthreads() also waits for vmcnt(0), i.e. for every output store the wave still has in flight — the phase clocks showed
+  // a wave parked at the level barriers for 26 % of a workgroup's cycles on the 99x165 map (most of it turned out to be the spread of
+  // the units' lengths, see the claims below; the stores' share is what this form removes)
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   constexpr unsigned KEY_INIT = 0x007FFFFFu;                        // key(-inf) << 16 | 0xFFFF
-  const int stride = n_zsplit * NT;
+  // (development instrumentation as in the sparse kernel, -DSW_ROI_PHASES: 0 -, 1 level-0 table, 2 level advances, 3 first records of
+  // a level, 4 item loop, 5 barrier at a level's start, 6 whole kernel, 7 workgroups)
+  SP_T(t_tab0); SP_ADD(1, t_begin, t_tab0); SP_ADD(7, 0, 1);
   for (int L = 0; L < SP_NLEV; ++L) {
     const int t_lo = s_seg[L * SP_NHC], t_hi = s_seg[(L + 1) * SP_NHC];
     if (t_lo >= n_tasks_end) break;                                 // no task at this or a higher level
-    __syncthreads();                                                // level L - 1 fully scanned (L = 0: table written)
+    SP_T(t_lv0);
+    lds_barrier();                                                // level L - 1 fully scanned (L = 0: table written)
+    SP_T(t_lv1); SP_ADD(L == 0 ? 0 : 5, t_lv0, t_lv1);
     if (L > 0) {
       const int d = 1 << (L - 1);
       TE nv[PXT][NPL];
@@ -1236,7 +1247,7 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_tasks_kernel(int H, int W, in
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int k = 0; k < PXT; ++k) {
         const int px = tid + k * NT;
@@ -1245,33 +1256,49 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_tasks_kernel(int H, int W, in
           for (int pl = 0; pl < NPL; ++pl) tab[pl * npl_px + px] = nv[k][pl];
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
     const int span = 1 << L;
+    SP_T(t_lv2); SP_ADD(2, t_lv1, t_lv2);
     const int n_lvl = t_hi - t_lo, total = n_lvl * PW;
-    // Items (task, bin column) of the level: wave w of workgroup z takes items i_first + lane, i_first = z * NT + w * 64 + k * stride.
+    // Items (task, bin column) of the level, in units of 64 consecutive ones per wave and iteration.
     // The <= 10 records (7 bin columns) a wave's 64 items touch are consecutive in the list; 20 lanes fetch them (16 bytes each) THREE
     // iterations ahead and the wave parks them in its own 2 x 320 bytes of LDS one iteration ahead: vector loads return in issue order with the
     // output stores, so a record fetched one iteration ahead would make every iteration wait for the previous one's 16 stores to be
     // acknowledged (measured: 63x63 map 152 -> 344 us); three iterations ahead the wave keeps ~48 stores in flight as the
     // chunked kernel's fire-and-forget stores did.  No workgroup barrier inside a level.
-    const int i_w0 = zfirst * NT + (tid & ~63);
-    if (i_w0 < total) {                                             // (wave-uniform)
-    const int n_iter = (total - i_w0 + stride - 1) / stride;
+    // The 64-item units are taken from the END of the level's list (the classes are filed by ascending window height: the long units go
+    // first, the level ends on short ones) and CLAIMED, not dealt: a wave takes the next unit of its workgroup's share (units z, z + n_zsplit,
+    // ...) from an LDS counter whenever it is free — four ahead, the records follow three ahead.  Dealt round-robin, the spread of the
+    // units' lengths (a class spans a factor of two in window rows and more beyond 8 rows) added up per wave: the phase clocks showed a
+    // wave parked at the next level's barrier for 19 % of a workgroup's cycles on the 99x165 map, 4-5 units' worth per level (claimed: 7 %;
+    // the call itself 1-3 % shorter: the parked wave's SIMD was serving its other three waves meanwhile).
+    const int n_units_all = (total + 63) >> 6;
+    const int n_units = n_units_all > zfirst ? (n_units_all - zfirst + n_zsplit - 1) / n_zsplit : 0;      // this workgroup's share
+    if (n_units > 0) {
     const u32x4* lvl = my + 2 * (long)t_lo;
     const int lane = tid & 63;
     const int n_rec = (62 + PW) / PW + 1, slot = n_rec * 32;        // records a wave's 64 consecutive items can touch (7 columns: 10)
     char* wbuf = smem + ((((size_t)NPL * npl_px * sizeof(TE)) + 15) & ~(size_t)15) + (size_t)(tid >> 6) * (2 * slot);
-    auto fetch = [&](int k) {                                       // lanes 0-19: their piece of iteration k's records
-      const int te = min((i_w0 + min(k, n_iter - 1) * stride) / PW + (lane >> 1), n_lvl - 1);
+    auto claim = [&]() {                                            // j-th claim of the workgroup -> first item of that unit, or -1
+      int j = 0;
+      if (lane == 0) j = atomicAdd(&s_next[L], 1);
+      j = __builtin_amdgcn_readfirstlane(j);
+      return j < n_units ? (zfirst + (n_units - 1 - j) * n_zsplit) * 64 : -1;
+    };
+    auto fetch = [&](int i_first) {                                 // lanes 0-19: their piece of the records of the unit at i_first
+      const int te = min(max(i_first, 0) / PW + (lane >> 1), n_lvl - 1);
       return lvl[2 * te + (lane & 1)];
     };
+    int un0 = claim(), un1 = claim(), un2 = claim(), un3 = claim();      // first items of the claimed units
     u32x4 r1 = u32x4{0u, 0u, 0u, 0u}, r2 = r1;
-    if (lane < 2 * n_rec) { const u32x4 r0 = fetch(0); r1 = fetch(1); r2 = fetch(2); *(u32x4*)(wbuf + lane * 16) = r0; }
-    for (int k = 0; k < n_iter; ++k) {
+    if (lane < 2 * n_rec) { const u32x4 r0 = fetch(un0); r1 = fetch(un1); r2 = fetch(un2); *(u32x4*)(wbuf + lane * 16) = r0; }
+    SP_T(t_lv3); SP_ADD(3, t_lv2, t_lv3);
+    for (int k = 0; un0 >= 0; ++k) {
       u32x4 r3 = r2;
-      if (lane < 2 * n_rec) r3 = fetch(k + 3);
-      const int i_first = i_w0 + k * stride;
+      if (lane < 2 * n_rec) r3 = fetch(un3);
+      const int un4 = claim();
+      const int i_first = un0;
       const int i = min(i_first + lane, total - 1);                 // lanes past the end redo the last item (same stores, same values)
       const int te = i / PW, pw = i - te * PW;
       const char* rec = wbuf + (k & 1) * slot + (te - i_first / PW) * 32;
@@ -1377,9 +1404,12 @@ __global__ __launch_bounds__(NT) void roi_pool_fwd_tasks_kernel(int H, int W, in
       }
       if (lane < 2 * n_rec) *(u32x4*)(wbuf + ((k + 1) & 1) * slot + lane * 16) = r1;     // iteration k + 1's records (fetched at k - 2)
       r1 = r2; r2 = r3;
+      un0 = un1; un1 = un2; un2 = un3; un3 = un4;
     }
+    SP_T(t_lv4); SP_ADD(4, t_lv3, t_lv4);
     }
   }     // levels
+  SP_T(t_end); SP_ADD(6, t_begin, t_end);
 }
 
 // max |x| over n elements -> out[0] (f32; caller zero-fills).  |x| as IEEE bits is monotone => integer atomicMax; a NaN in x

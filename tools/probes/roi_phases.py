@@ -7,8 +7,8 @@ import sos_wsod_amd.ops as ops
 from sos_wsod_amd import _lib
 lib = ctypes.CDLL(_lib.LIB_PATH)
 lib.sw_debug_roi_phases.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
-NAMES = ["sort", "level-0 table", "level advances", "chunk tables + task list", "task scan", "barrier wait behind a scan", "whole kernel", "workgroups"]
-for H, W, R in [(63, 63, 4000), (99, 165, 8000), (125, 167, 4000)]:
+NAMES = ["sort (sparse kernel)", "level-0 table", "level advances", "chunk tables + task list | first records of a level", "task scan | item loop", "barrier wait behind a scan / at a level's start", "whole kernel", "workgroups"]
+for H, W, R in [(63, 63, 4000), (99, 165, 8000), (150, 200, 4000)]:
     dt, dev, C = torch.bfloat16, "cuda", 512
     g = torch.Generator().manual_seed(0)
     x1 = torch.rand(R, generator=g) * (W * 8 - 32); y1 = torch.rand(R, generator=g) * (H * 8 - 32)
