@@ -716,7 +716,7 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
   constexpr int NT = SP_NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_start[SP_NCLS + 1], s_fill[SP_NCLS];
-  __shared__ int s_ntask;
+  __shared__ int s_ntask, s_claim;
   const int band = BAND ? (int)(blockIdx.z % n_bands) : 0, zfirst = BAND ? (int)(blockIdx.z / n_bands) : (int)blockIdx.z;
   const int y0 = BAND ? band * band_S : 0, y1 = BAND ? min(H, y0 + band_rows) : H;      // map rows [y0, y1) live in LDS
   const int lds_rows = BAND ? band_rows : H;
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
       SP_T(t_c0);
       __syncthreads();                                              // the previous chunk's tables are no longer read
       SP_T(t_c1); SP_ADD(5, t_c0, t_c1);
-      if (tid == 0) s_ntask = 0;
+      if (tid == 0) { s_ntask = 0; s_claim = 0; }
       for (int i = tid; i < cnt * (PH + PW); i += NT) {
         const int li = i / (PH + PW), k = i - li * (PH + PW);
         const int r = s_lvl[cs + li];
@@ -882,13 +882,17 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
       }
       SP_T(t_c2); SP_ADD(3, t_c1, t_c2);
       const int total = ntask * PW;
-      const int dli = NT / nb, dph = (NT - dli * nb) / PW, dpw = NT - dli * nb - dph * PW;
-      int li = tid / nb, ph = (tid - li * nb) / PW, pw = tid - li * nb - ph * PW;
-      const int dte = NT / PW, dtw = NT - dte * PW;
-      int te = tid / PW;
-      if (BAND) pw = tid - te * PW;
-      for (int t = tid; t < total; t += NT) {
-        if (BAND) { const unsigned int pk = s_task[te]; li = (int)(pk >> 8); ph = (int)(pk & 0xFF); }
+      // 64-item units CLAIMED by the waves from an LDS counter (round 6; dealt by position, a wave waited at the chunk's closing barrier
+      // for 23 % of the workgroup's cycles on the 63x63 map: 98 units per 128-ROI chunk over 16 waves, and the units differ in length)
+      for (;;) {
+        int u = 0;
+        if ((tid & 63) == 0) u = atomicAdd(&s_claim, 1);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u * 64 >= total) break;
+        const int t = min(u * 64 + (int)(tid & 63), total - 1);     // lanes past the end redo the last item (same stores, same values)
+        int li, ph, pw;
+        if (BAND) { const int te = t / PW; pw = t - te * PW; const unsigned int pk = s_task[te]; li = (int)(pk >> 8); ph = (int)(pk & 0xFF); }
+        else { li = t / nb; const int rem = t - li * nb; ph = rem / PW; pw = rem - ph * PW; }
         const int b = ph * PW + pw;
         const int r = s_r[li];
         const int hb = s_hb[li * PH + ph], wb = s_wb[li * PW + pw];
@@ -982,14 +986,6 @@ __global__ __launch_bounds__(SP_NT) void roi_pool_fwd_sparse_kernel(int H, int W
         for (int q = 0; q < CB; ++q) {
           Elem<unsigned short>::store(out + o + (long)q * nb, __fmul_rn(mv[q], mul));
           argmax[o + (long)q * nb] = ArgIdx<IT>::enc(mi[q]);
-        }
-        if (BAND) {
-          pw += dtw; te += dte;
-          if (pw >= PW) { pw -= PW; ++te; }
-        } else {
-          pw += dpw; ph += dph; li += dli;
-          if (pw >= PW) { pw -= PW; ++ph; }
-          if (ph >= PH) { ph -= PH; ++li; }
         }
       }
       SP_T(t_c3); SP_ADD(4, t_c2, t_c3);
