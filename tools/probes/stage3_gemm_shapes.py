@@ -4,7 +4,7 @@ forms.  Output: per shape count x time, bytes, GB/s, TFLOP/s, sorted by time per
 import collections, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import sos_wsod_amd.ops as ops
 import stage3_step as S
 
