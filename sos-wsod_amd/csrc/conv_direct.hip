@@ -149,7 +149,8 @@ __device__ __forceinline__ void conv3x3_direct_body(const DirectArgs& g, const u
   // pipeline with the barrier moved into the last tap was measured 4-12 % slower: 256 VGPRs, longer dependency stalls; round 6: the
   // fragments of tap tx + 1 requested before the MFMAs of tap tx inside a step, sched_barrier-fenced, 170 VGPRs: every layer of the
   // 512x512 and 800x1333 views within +-2 %.  On the 100x166 maps the loop runs at 0.54 of peak per ISSUED MFMA; what the true-FLOP
-  // figure loses there is the 8x32 tiling of the map (1.20x) and 2.44 -> 3 rounds of workgroups, not the loop.)
+  // figure loses there is the 8x32 tiling of the map (1.20x), not the loop — and not the round count either: whole rounds of 64-channel tiles + a launch of
+  // 32-channel tiles for the remaining pixel tiles ran slower, 133 -> 143 us at 106x141, 140 -> 150 at 100x166.)
   issue_a(0);
   issue_b(0);
   // Ragged right / bottom edge (round 6): a tile whose columns tx0 + 16 .. tx0 + 31 all lie outside the image runs the LEFT form of the
